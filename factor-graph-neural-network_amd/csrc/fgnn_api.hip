@@ -1,0 +1,28 @@
+// fgnn_api.hip — error plumbing and shape-only helpers of the C ABI (include/fgnn_hip.h).
+#include "fgnn_common.h"
+
+static thread_local char g_err[512] = "";
+
+void fgnn_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* fgnn_last_error(void) { return g_err; }
+extern "C" int fgnn_abi_version(void) { return 1; }
+
+// x read once, etype read once, indices read once (int64 as passed; a batch-shared
+// graph is read once), y written once, filters + bias/BN vectors once.
+extern "C" int64_t fgnn_mpconv_algorithmic_bytes(const fgnn_mpconv_desc* d) {
+    if (!d) return -1;
+    const int64_t s = d->dtype == FGNN_BF16 ? 2 : 4;
+    const int64_t B = d->B, mk = (int64_t)d->M * d->k;
+    const int64_t R = d->ext == FGNN_EXT_NONE ? d->nin : 2 * d->nin;
+    int64_t bytes = s * B * ((int64_t)d->nin * d->N + (int64_t)d->nou * d->M);
+    bytes += s * (d->et_sb == 0 ? 1 : B) * d->net * mk;
+    bytes += 8 * (d->idx_sb == 0 ? 1 : B) * mk;
+    bytes += 4 * (R * d->nou * d->net + 5 * (int64_t)d->nou);
+    return bytes;
+}

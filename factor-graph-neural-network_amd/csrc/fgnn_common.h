@@ -1,0 +1,36 @@
+// Shared device/host helpers for the FGNN gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "fgnn_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+
+#define FGNN_THREADS 256
+#define FGNN_WAVES 4
+
+// ---- storage-type helpers: kernels compute in f32, store f32 or bf16 ------------------
+struct bf16_t { uint16_t v; };
+
+__device__ __forceinline__ float fgnn_ld(const float* p) { return *p; }
+__device__ __forceinline__ float fgnn_ld(const bf16_t* p) {
+    return __uint_as_float(((uint32_t)p->v) << 16);
+}
+__device__ __forceinline__ void fgnn_st(float* p, float v) { *p = v; }
+__device__ __forceinline__ void fgnn_st(bf16_t* p, float v) {
+    // round-to-nearest-even, NaN preserved
+    uint32_t u = __float_as_uint(v);
+    if ((u & 0x7fffffffu) > 0x7f800000u) { p->v = (uint16_t)((u >> 16) | 0x40); return; }
+    u += 0x7fffu + ((u >> 16) & 1u);
+    p->v = (uint16_t)(u >> 16);
+}
+
+// ---- host-side error plumbing ---------------------------------------------------------
+void fgnn_set_error(const char* fmt, ...);
+#define FGNN_FAIL(code, ...) do { fgnn_set_error(__VA_ARGS__); return (code); } while (0)
+
+static inline int fgnn_round_up(int v, int m) { return (v + m - 1) / m * m; }

@@ -1,0 +1,105 @@
+"""ctypes binding of libfgnn_hip.so (C ABI declared in include/fgnn_hip.h).
+
+PyTorch is only the owner of device memory and streams here: every call passes raw
+device pointers, element strides and the current HIP stream.  There is no CPU or
+eager-PyTorch fallback: if the shared library is missing the import of the operator
+fails loudly (build it with ``python __graft_entry__.py`` or ``make -C csrc``).
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libfgnn_hip.so')
+
+EXT_NONE, EXT_NEIGHBOR, EXT_DIFF = 0, 1, 2
+AGG_MAX, AGG_LSE, AGG_MEAN = 0, 1, 2
+F32, BF16 = 0, 1
+
+AGG_CODES = {'max': AGG_MAX, 'softmax': AGG_LSE, 'mean': AGG_MEAN}
+
+EXPORTS = ('fgnn_mpconv_forward', 'fgnn_mpconv_backward', 'fgnn_mpconv_forward_lds_bytes',
+           'fgnn_mpconv_algorithmic_bytes', 'fgnn_last_error', 'fgnn_abi_version')
+
+
+class MPConvDesc(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in
+                ('B', 'nin', 'nou', 'net', 'N', 'M', 'k', 'ext', 'agg', 'dtype', 'relu', 'reserved')] + \
+               [(n, ctypes.c_int64) for n in
+                ('x_sb', 'x_sc', 'x_sn', 'idx_sb', 'idx_sm', 'idx_sk',
+                 'et_sb', 'et_se', 'et_sm', 'et_sk', 'y_sb', 'y_sc', 'y_sm')]
+
+
+class FgnnHipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    """Load libfgnn_hip.so once; raise (never fall back) when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FgnnHipError(
+            'libfgnn_hip.so not found at %s — the FGNN message operator has no CPU/eager '
+            'fallback; build it with `python __graft_entry__.py` (hipcc --offload-arch=gfx950).'
+            % LIB_PATH)
+    L = ctypes.CDLL(LIB_PATH)
+    vp, dp = ctypes.c_void_p, ctypes.POINTER(MPConvDesc)
+    L.fgnn_mpconv_forward.restype = ctypes.c_int
+    L.fgnn_mpconv_forward.argtypes = [dp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.fgnn_mpconv_backward.restype = ctypes.c_int
+    L.fgnn_mpconv_backward.argtypes = [dp] + [vp] * 12
+    L.fgnn_mpconv_forward_lds_bytes.restype = ctypes.c_int64
+    L.fgnn_mpconv_forward_lds_bytes.argtypes = [dp]
+    L.fgnn_mpconv_algorithmic_bytes.restype = ctypes.c_int64
+    L.fgnn_mpconv_algorithmic_bytes.argtypes = [dp]
+    L.fgnn_last_error.restype = ctypes.c_char_p
+    L.fgnn_abi_version.restype = ctypes.c_int
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != 0:
+        raise FgnnHipError('libfgnn_hip: %s (code %d)' % (lib().fgnn_last_error().decode(), rc))
+
+
+def _ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def dtype_code(t):
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise FgnnHipError('fgnn_amd supports float32 and bfloat16 tensors, got %s' % t.dtype)
+
+
+def make_desc(x, nn_idx, etype, nou, net, ext, agg, relu, y=None):
+    """Describe one operator call from tensor views (no copies).
+
+    x [B,nin,N,1] (any strides), nn_idx [B,M,k] int64, etype [B,net,M,k].  A batch
+    stride of 0 (``expand``-ed tensors) marks a graph / edge weights shared by the batch.
+    """
+    B, nin, N = x.shape[0], x.shape[1], x.shape[2]
+    M, k = nn_idx.shape[1], nn_idx.shape[2]
+    d = MPConvDesc()
+    d.B, d.nin, d.nou, d.net, d.N, d.M, d.k = B, nin, nou, net, N, M, k
+    d.ext, d.agg, d.dtype, d.relu = ext, agg, dtype_code(x), int(bool(relu))
+    d.x_sb, d.x_sc, d.x_sn = x.stride(0), x.stride(1), x.stride(2)
+    d.idx_sb, d.idx_sm, d.idx_sk = nn_idx.stride(0), nn_idx.stride(1), nn_idx.stride(2)
+    d.et_sb, d.et_se, d.et_sm, d.et_sk = (etype.stride(0), etype.stride(1),
+                                          etype.stride(2), etype.stride(3))
+    if y is not None:
+        d.y_sb, d.y_sc, d.y_sm = y.stride(0), y.stride(1), y.stride(2)
+    return d

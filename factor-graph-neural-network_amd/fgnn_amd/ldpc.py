@@ -1,0 +1,90 @@
+"""``LDPCModel`` — the 8-layer FGNN decoder for the 96.3.963 code, and its synthetic inputs.
+
+Same constructor / forward signature / state_dict keys (651 entries) as the class in the
+reference's training script (/root/reference/train_ldpc.py:19-99): ``FactorNN`` with
+dims [64,64,64,128,256,256,128,64,64], 4 edge types on the 288 parity edges plus a degree-96
+"hyper-factor" touching every variable, two edge-type MLPs and an SNR regressor head.
+32 message-operator calls per forward = 6144 VF+FV messages per codeword.
+"""
+import numpy as np
+import torch
+
+from .mpnn.assemblies import FactorNN
+from .tables import LdpcGraph
+
+MESSAGES_PER_CODEWORD = 8 * (288 + 288 + 96 + 96)
+
+
+def _edge_mlp(cin, hidden, cout):
+    return torch.nn.Sequential(torch.nn.Conv2d(cin, hidden, 1), torch.nn.ReLU(inplace=True),
+                               torch.nn.Conv2d(hidden, cout, 1))
+
+
+class LDPCModel(torch.nn.Module):
+    def __init__(self, nfeature_dim, hop_order, nedge_type, with_residual=True, aggregator='max'):
+        super().__init__()
+        self.main = FactorNN(nfeature_dim, [hop_order, 96],
+                             [64, 64, 64, 128, 256, 256, 128, 64, 64], [nedge_type, 1], 2,
+                             skip_link={4: 3, 5: 2, 7: 0}, ret_high=True, aggregator=aggregator)
+        self.emodel_f2v = _edge_mlp(7, 64, nedge_type)
+        self.emodel_v2f = _edge_mlp(7, 64, nedge_type)
+        frozen = lambda t: torch.nn.Parameter(t, requires_grad=False)
+        # hyper-factor: one factor listening to all 96 variables, every variable listening to it
+        self.hnn_idx_v2f = frozen(torch.arange(96, dtype=torch.int64).reshape(1, 1, 96))
+        self.hnn_idx_f2v = frozen(torch.zeros(1, 96, 1, dtype=torch.int64))
+        self.hetype_v2f = frozen(torch.ones(1, 1, 1, 96))
+        self.hetype_f2v = frozen(torch.ones(1, 1, 96, 1))
+        self.with_residual = with_residual
+        self.nhop_regressor = torch.nn.Sequential(
+            torch.nn.Linear(64, 128), torch.nn.BatchNorm1d(128), torch.nn.ReLU(),
+            torch.nn.Linear(128, 128), torch.nn.ReLU(), torch.nn.Linear(128, 1), torch.nn.ReLU())
+
+    def forward(self, node_feature, hop_feature, nn_idx_f2v, nn_idx_v2f, efeature_f2v,
+                efeature_v2f):
+        B = node_feature.shape[0]
+        etype_f2v = self.emodel_f2v(efeature_f2v)
+        etype_v2f = self.emodel_v2f(efeature_v2f)
+        hyper_in = node_feature[:, 0, :, :].detach().reshape(B, 96, 1, 1)
+        dt = node_feature.dtype
+        # expand (batch stride 0) instead of the reference's repeat: same values, and the kernel
+        # sees "one graph shared by the batch"
+        res, hops = self.main(
+            node_feature, [hop_feature, hyper_in],
+            [nn_idx_f2v, self.hnn_idx_f2v.expand(B, -1, -1)],
+            [nn_idx_v2f, self.hnn_idx_v2f.expand(B, -1, -1)],
+            [etype_f2v, self.hetype_f2v.to(dt).expand(B, -1, -1, -1)],
+            [etype_v2f, self.hetype_v2f.to(dt).expand(B, -1, -1, -1)])
+        if self.with_residual:
+            res = res + node_feature[:, :1, :, :]
+        res = res.reshape(B, 96)
+        snr_pred = self.nhop_regressor(hops[1].reshape(B, -1).float())
+        return res[:, :48].contiguous(), snr_pred
+
+
+def synthetic_batch(B, device, seed=0, dtype=torch.float32, shared_graph=True):
+    """Synthetic LDPC inputs of the exact reference shapes: received words
+    y ~ N(+-1, 1) and an SNR channel in {0..4} dB; features built as ldpc_dataset.py:92-106 does.
+    Returns (node_feature[B,2,96,1], hop_feature[B,6,48,1], nn_idx_f2v[B,96,3], nn_idx_v2f[B,48,6],
+    efeature_f2v[B,7,96,3], efeature_v2f[B,7,48,6], label[B,48], sigma_b[B])."""
+    g = LdpcGraph()
+    gen = torch.Generator(device='cpu').manual_seed(seed)
+    bits = torch.randint(0, 2, (B, 96), generator=gen).float()
+    y = (1 - 2 * bits) + torch.randn(B, 96, generator=gen)
+    snr = torch.randint(0, 5, (B,), generator=gen).float()
+    sigma_b = torch.randint(0, 6, (B,), generator=gen).float()
+    y, snr, bits, sigma_b = y.to(device), snr.to(device), bits.to(device), sigma_b.to(device)
+    f2v = torch.from_numpy(g.var_to_factors).to(device)
+    v2f = torch.from_numpy(g.factor_to_vars).to(device)
+    hop = y[:, v2f]                                                # [B,48,6]
+    node = torch.stack([y, snr[:, None].expand(B, 96)], 1).unsqueeze(-1)
+    ef_f2v = torch.cat([hop[:, f2v], y[:, :, None, None].expand(B, 96, 3, 1)], 3)   # [B,96,3,7]
+    ef_v2f = torch.cat([hop[:, :, None, :].expand(B, 48, 6, 6), hop[:, :, :, None]], 3)
+    if shared_graph:
+        idx_f2v, idx_v2f = f2v.unsqueeze(0).expand(B, -1, -1), v2f.unsqueeze(0).expand(B, -1, -1)
+    else:
+        idx_f2v, idx_v2f = f2v.unsqueeze(0).repeat(B, 1, 1), v2f.unsqueeze(0).repeat(B, 1, 1)
+    return (node.to(dtype).contiguous(), hop.permute(0, 2, 1).unsqueeze(-1).to(dtype).contiguous(),
+            idx_f2v, idx_v2f,
+            ef_f2v.permute(0, 3, 1, 2).to(dtype).contiguous(),
+            ef_v2f.permute(0, 3, 1, 2).to(dtype).contiguous(),
+            bits[:, :48].contiguous(), sigma_b)

@@ -1,0 +1,195 @@
+"""Model bodies that call the message operator: ``mp_sequential``, ``factor_mpnn``, ``FactorNN``.
+
+Same constructor signatures, ``forward`` signatures and state_dict keys as
+  mp_sequential   /root/reference/lib/model/mpnn/sequential.py:8-39
+  factor_mpnn     /root/reference/lib/model/mpnn/factor_mpnn.py:8-133
+  FactorNN        /root/reference/lib/model/mpnn/factor_mpnn_sp.py:25-178
+so the reference's train_*.py scripts construct and call them unchanged; every VF/FV
+message inside runs through the fused HIP operator.
+"""
+import torch
+
+from .blocks import (NodeInstanceNorm, iid_mapping, iid_mapping_bn, iid_mapping_in,
+                     mp_conv_residual)
+from .message_op import base_mp_nn, mp_conv_type, mp_conv_v2
+
+
+def _call(module, x, nn_idx, etype):
+    """The reference's dispatch contract: graph-aware modules get (x, nn_idx, etype)."""
+    if isinstance(module, base_mp_nn):
+        return module(x, nn_idx, etype)
+    return module(x)
+
+
+class mp_sequential(base_mp_nn):
+    def __init__(self, *module_list):
+        super().__init__()
+        self.module_list = list(module_list)
+        for i, m in enumerate(self.module_list):
+            self.add_module(str(i), m)
+
+    def forward(self, node_feature, *argv):
+        extras = []
+        for m in self.module_list:
+            out = m(node_feature, *argv) if isinstance(m, base_mp_nn) else m(node_feature)
+            if isinstance(out, tuple):
+                extras.extend(out[1:])
+                out = out[0]
+            node_feature = out
+        return (node_feature, extras) if extras else node_feature
+
+
+class factor_mpnn(torch.nn.Module):
+    """Synthetic-PGM body.  Per layer and factor type the variables and that type's factors are
+    concatenated along the node axis and pushed through one mp block (rows < nnode gather from
+    factors = F->V, rows >= nnode gather from variables = V->F), then split again."""
+
+    def __init__(self, node_feature_dim, factor_feature_dim_list, dim_mapping_list, netype_list,
+                 gnn_immediate_dim=64, max_mpnn_dim=64, final_filter=None, skip_link={}):
+        super().__init__()
+        self.node_feature_dim = node_feature_dim
+        self.map_dim = dim_mapping_list[0]
+        self.nfactor_types = len(factor_feature_dim_list)
+        self.final_filter = final_filter
+        self.skip_link = skip_link
+        self.mapping_modules = []
+        for i, din in enumerate([node_feature_dim] + list(factor_feature_dim_list)):
+            m = iid_mapping(din, self.map_dim)
+            self.add_module('mapping_modules_%d' % i, m)
+            self.mapping_modules.append(m)
+        self.mp_nn_modules, self.mp_merge_modules = [], []
+        nlayers = len(dim_mapping_list) - 1
+        for L in range(nlayers):
+            nin, nout = dim_mapping_list[L], dim_mapping_list[L + 1]
+            row = []
+            for j in range(self.nfactor_types):
+                if nin == nout:
+                    m = mp_conv_residual(nin, gnn_immediate_dim, netype_list[j])
+                elif nin <= max_mpnn_dim and nout <= max_mpnn_dim:
+                    m = mp_conv_v2(nin, nout, netype_list[j])
+                else:
+                    m = torch.nn.Sequential(torch.nn.Conv2d(nin, nout, 1), NodeInstanceNorm(),
+                                            torch.nn.ReLU(inplace=True))
+                self.add_module('mp_nn_%d_%d' % (L, j), m)
+                row.append(m)
+            self.mp_nn_modules.append(row)
+            width = nout * self.nfactor_types
+            if L < nlayers - 1:
+                merge = iid_mapping_bn(width, nout)
+            else:
+                merge = torch.nn.Sequential(
+                    torch.nn.Conv2d(width, 256, 1, bias=True), torch.nn.BatchNorm2d(256),
+                    torch.nn.LeakyReLU(), torch.nn.Conv2d(256, 256, 1, bias=True),
+                    torch.nn.LeakyReLU(), torch.nn.Conv2d(256, nout, 1, bias=True))
+            self.add_module('merge_module_%d' % L, merge)
+            self.mp_merge_modules.append(merge)
+
+    def forward(self, node_features, factor_features, graph_structures):
+        nnode = node_features.shape[2]
+        nfeat = self.mapping_modules[0](node_features)
+        ffeat = [m(f) for f, m in zip(factor_features, self.mapping_modules[1:])]
+        history = []
+        for L, row in enumerate(self.mp_nn_modules):
+            to_nodes, to_factors = [], []
+            for j, m in enumerate(row):
+                both = torch.cat([nfeat, ffeat[j]], dim=2).contiguous()
+                nn_idx, etype = graph_structures[j]
+                both = _call(m, both, nn_idx, etype)
+                to_nodes.append(both[:, :, :nnode, :])
+                to_factors.append(both[:, :, nnode:, :])
+            nfeat = self.mp_merge_modules[L](torch.cat(to_nodes, dim=1))
+            ffeat = to_factors
+            if L in self.skip_link:
+                pn, pf = history[self.skip_link[L]]
+                nfeat = nfeat + pn
+                ffeat = [a + b for a, b in zip(ffeat, pf)]
+            history.append([nfeat, ffeat])
+        if self.final_filter is not None:
+            nfeat = self.final_filter(nfeat, node_features)
+        return nfeat, ffeat
+
+
+class FactorNN(torch.nn.Module):
+    """LDPC body ("sp" variant): per layer and factor type an F->V block (factors are the
+    sources, variables the destinations) and a V->F block, plus node-wise v2v / f2f maps."""
+
+    def __init__(self, node_feature_dim, factor_feature_dim_list, dim_mapping_list, netype_list,
+                 nclass=2, gnn_immediate_dim=64, max_mpnn_dim=128, final_filter=None,
+                 skip_link={}, aggregator='max', ret_high=False):
+        super().__init__()
+        self.node_feature_dim = node_feature_dim
+        self.map_dim = dim_mapping_list[0]
+        self.final_filter = final_filter
+        self.dim_mapping_list = dim_mapping_list
+        self.nfactor_types = len(factor_feature_dim_list)
+        self.skip_link = skip_link
+        self.ret_high = ret_high
+        self.node_mapping_module = iid_mapping(node_feature_dim, self.map_dim)
+        self.factor_mapping_modules = []
+        for j, din in enumerate(factor_feature_dim_list):
+            m = iid_mapping_bn(din, self.map_dim)
+            self.add_module('factor_mapping_modules_%d' % j, m)
+            self.factor_mapping_modules.append(m)
+
+        def mp_block(nin, nout, netype):
+            kw = dict(extension=mp_conv_type.NO_EXTENSION)
+            if nin == nout:
+                return mp_conv_residual(nin, gnn_immediate_dim, netype, with_residual=False,
+                                        aggregator=aggregator, **kw)
+            if nin <= max_mpnn_dim and nout <= max_mpnn_dim:
+                return mp_conv_v2(nin, nout, netype, aggregtor=aggregator, **kw)
+            return mp_conv_residual(nin, gnn_immediate_dim, netype, with_residual=False,
+                                    nout=nout, aggregator=aggregator, **kw)
+
+        self.f2v_modules, self.v2f_modules, self.f2f_modules, self.v2v_modules = [], [], [], []
+        for L in range(len(dim_mapping_list) - 1):
+            nin, nout = dim_mapping_list[L], dim_mapping_list[L + 1]
+            v2v = iid_mapping_in(nin, nout)
+            self.add_module('v2v_%d' % L, v2v)
+            self.v2v_modules.append(v2v)
+            f2v_row, v2f_row, f2f_row = [], [], []
+            for j in range(self.nfactor_types):
+                f2f_row.append(iid_mapping_in(nin, nout))
+                f2v_row.append(mp_block(nin, nout, netype_list[j]))
+                v2f_row.append(mp_block(nin, nout, netype_list[j]))
+                self.add_module('f2v_%d_%d' % (L, j), f2v_row[-1])
+                self.add_module('v2f_%d_%d' % (L, j), v2f_row[-1])
+                self.add_module('f2f_%d_%d' % (L, j), f2f_row[-1])
+            self.f2f_modules.append(f2f_row)
+            self.f2v_modules.append(f2v_row)
+            self.v2f_modules.append(v2f_row)
+        final_dim = nclass if nclass > 2 else 1
+        self.final_classifier = torch.nn.Sequential(
+            torch.nn.Conv2d(dim_mapping_list[-1], 128, 1), NodeInstanceNorm(),
+            torch.nn.ReLU(inplace=True), torch.nn.Conv2d(128, final_dim, 1, bias=True))
+
+    def mpnn_forward(self, mpnn, node_feature, nn_idx, efeature):
+        return _call(mpnn, node_feature, nn_idx, efeature)
+
+    def forward(self, node_feature, hop_features, nn_idx_f2v, nn_idx_v2f, etype_f2v, etype_v2f):
+        var = self.node_mapping_module(node_feature)
+        fac = [m(f) for f, m in zip(hop_features, self.factor_mapping_modules)]
+        history = []
+        for L in range(len(self.v2f_modules)):
+            same_width = self.dim_mapping_list[L] == self.dim_mapping_list[L + 1]
+            new_var = self.v2v_modules[L](var)
+            new_fac = [m(f) for f, m in zip(fac, self.f2f_modules[L])]
+            for j in range(self.nfactor_types):
+                new_var = new_var + _call(self.f2v_modules[L][j], fac[j],
+                                          nn_idx_f2v[j].long(), etype_f2v[j])
+                new_fac[j] = new_fac[j] + self.v2f_modules[L][j](
+                    var, nn_idx_v2f[j].long(), etype_v2f[j])
+            if same_width:
+                var = var + new_var
+                fac = [a + b for a, b in zip(new_fac, fac)]
+            else:
+                var, fac = new_var, new_fac
+            if L in self.skip_link:
+                pv, pf = history[self.skip_link[L]]
+                var = var + pv
+                fac = [a + b for a, b in zip(pf, fac)]
+            history.append([var, fac])
+        out = self.final_classifier(var)
+        if self.final_filter is not None:
+            out = self.final_filter(out, node_feature)
+        return (out, fac) if self.ret_high else out

@@ -1,0 +1,96 @@
+"""Blocks around the message operator: ``mp_conv_residual`` and the node-wise 1x1 maps.
+
+Mirrors (names, constructor signatures, state_dict keys) of
+  mp_conv_residual                   /root/reference/lib/model/mpnn/mp_nn_residual.py:7-56
+  iid_mapping / _bn / _in            /root/reference/lib/model/mpnn/base_model.py:43-90
+  max_pool_layer, flatten            /root/reference/lib/model/mpnn/base_model.py:19-40
+"""
+import torch
+
+from .message_op import base_mp_nn, mp_conv_type, mp_conv_v2
+
+
+class NodeInstanceNorm(torch.nn.Module):
+    """InstanceNorm2d(affine=False, no running stats) over the node axis of [B,C,N,1].
+
+    A single node (the LDPC hyper-factor, factor_mpnn_sp.py:77,140) normalises to exactly 0
+    — (x-mean)/sqrt(0+eps) — which is what the reference's torch-1.0 era computed and what
+    newer torch refuses to compute.  No parameters, so state_dicts match
+    torch.nn.InstanceNorm2d's (empty) contribution.
+    """
+    eps = 1e-5
+
+    def forward(self, x):
+        if x.shape[2] * x.shape[3] == 1:
+            return torch.zeros_like(x)
+        return torch.nn.functional.instance_norm(x, eps=self.eps)
+
+
+def _conv_norm_act(cin, cout, norm, act, bias=True):
+    layers = [torch.nn.Conv2d(cin, cout, 1, bias=bias)]
+    if norm is not None:
+        layers.append(norm)
+    layers.append(act)
+    return torch.nn.Sequential(*layers)
+
+
+class iid_mapping(torch.nn.Module):
+    def __init__(self, nin, nout, bias=True):
+        super().__init__()
+        self.main = _conv_norm_act(nin, nout, None, torch.nn.LeakyReLU(inplace=True), bias)
+
+    def forward(self, x):
+        return self.main(x)
+
+
+class iid_mapping_bn(torch.nn.Module):
+    def __init__(self, nin, nout, bias=True, bn=True):
+        super().__init__()
+        self.main = _conv_norm_act(nin, nout, torch.nn.BatchNorm2d(nout),
+                                   torch.nn.ReLU(inplace=True), bias)
+
+    def forward(self, x):
+        return self.main(x)
+
+
+class iid_mapping_in(torch.nn.Module):
+    def __init__(self, nin, nout, bias=True):
+        super().__init__()
+        self.main = _conv_norm_act(nin, nout, NodeInstanceNorm(), torch.nn.ReLU(), bias)
+
+    def forward(self, x):
+        return self.main(x)
+
+
+class max_pool_layer(torch.nn.Module):
+    def __init__(self, dim=2):
+        super().__init__()
+        self.dim = dim
+
+    def forward(self, input):
+        return input.max(dim=self.dim, keepdim=True)[0]
+
+
+class flatten(torch.nn.Module):
+    def forward(self, input):
+        return input.view(input.size(0), -1)
+
+
+class mp_conv_residual(base_mp_nn):
+    """Bottleneck: 1x1 conv+BN+LeakyReLU on the sources -> message operator ->
+    1x1 conv+BN+LeakyReLU on the destinations (+ input when ``with_residual``)."""
+
+    def __init__(self, nin, nmed, netype, extension=mp_conv_type.ORIG_WITH_DIFF,
+                 with_residual=True, with_hop=False, aggregator='max', nout=None):
+        super().__init__()
+        nout = nin if nout is None else nout
+        leaky = lambda: torch.nn.LeakyReLU(inplace=True)
+        self.conv1 = _conv_norm_act(nin, nmed, torch.nn.BatchNorm2d(nmed), leaky())
+        self.mp_conv = mp_conv_v2(nmed, nmed, netype, extension=extension, aggregtor=aggregator)
+        self.conv2 = _conv_norm_act(nmed, nout, torch.nn.BatchNorm2d(nout), leaky())
+        self.with_residual = with_residual
+        self.with_hop = with_hop
+
+    def forward(self, node_feature, nn_idx, etype):
+        h = self.conv2(self.mp_conv(self.conv1(node_feature), nn_idx, etype))
+        return h + node_feature if self.with_residual else h

@@ -1,0 +1,130 @@
+"""Host-side entry points of the fused VF/FV message operator (HIP only).
+
+``mpconv(...)`` is what ``mp_conv_v2.forward`` calls.  It computes
+
+    z[b,o,m] = agg_j  sum_e etype[b,e,m,j] * msg[b,m,j,o,e]  + bias[o]
+
+(optionally followed, when no gradient is needed, by a folded per-channel affine and
+ReLU) in one kernel launch through the C ABI, and differentiates through a hand-written
+backward kernel.  Reference semantics: /root/reference/lib/model/mpnn/mp_nn.py:115-175.
+"""
+import ctypes
+
+import torch
+
+from . import _hip
+
+
+def _require_device(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise _hip.FgnnHipError(
+                'fgnn_amd operators run on a ROCm device only (got a %s tensor); '
+                'there is no CPU fallback — move the module and its inputs to cuda.' % t.device)
+
+
+def _channels_last_like(x):
+    """True when x [B,C,N,1] is laid out channel-fastest."""
+    return x.shape[1] > 1 and x.stride(1) == 1 and x.shape[2] > 1 and x.stride(2) != 1
+
+
+def _alloc_out(x, nou, M, dtype=None):
+    B = x.shape[0]
+    dtype = x.dtype if dtype is None else dtype
+    if _channels_last_like(x):
+        return torch.empty((B, M, 1, nou), device=x.device, dtype=dtype).permute(0, 3, 1, 2)
+    return torch.empty((B, nou, M, 1), device=x.device, dtype=dtype)
+
+
+def _check_shapes(x, nn_idx, etype, filters, nou, net, ext):
+    if x.dim() != 4 or x.shape[3] != 1:
+        raise ValueError('x must be [B, nin, N, 1], got %s' % (tuple(x.shape),))
+    if nn_idx.dim() != 3 or nn_idx.dtype != torch.int64:
+        raise ValueError('nn_idx must be int64 [B, M, k], got %s %s' % (nn_idx.dtype, tuple(nn_idx.shape)))
+    B = nn_idx.shape[0]
+    assert B == x.shape[0]          # same assertion as mp_nn.py:100
+    if etype.shape != (B, net, nn_idx.shape[1], nn_idx.shape[2]):
+        raise ValueError('etype must be [B, net, M, k] = %s, got %s' %
+                         ((B, net, nn_idx.shape[1], nn_idx.shape[2]), tuple(etype.shape)))
+    R = x.shape[1] if ext == _hip.EXT_NONE else 2 * x.shape[1]
+    if filters.shape != (R, nou * net):
+        raise ValueError('filters must be [%d, %d], got %s' % (R, nou * net, tuple(filters.shape)))
+    if etype.dtype != x.dtype:
+        raise ValueError('x and etype must share a dtype (%s vs %s)' % (x.dtype, etype.dtype))
+
+
+def mpconv_forward_raw(x, nn_idx, etype, filters, bias, nou, net, ext, agg, *,
+                       post_scale=None, post_shift=None, relu=False, want_argmax=False):
+    """One launch of fgnn_mpconv_forward.  Returns (y, argmax-or-None)."""
+    _require_device(x, nn_idx, etype, filters, bias)
+    _check_shapes(x, nn_idx, etype, filters, nou, net, ext)
+    L = _hip.lib()
+    M = nn_idx.shape[1]
+    y = _alloc_out(x, nou, M)
+    amax = None
+    if want_argmax and agg == _hip.AGG_MAX:
+        amax = torch.empty((x.shape[0], nou, M), device=x.device, dtype=torch.uint8)
+    filters = filters.detach()
+    if filters.dtype != torch.float32 or not filters.is_contiguous():
+        filters = filters.float().contiguous()
+    f32 = lambda t: None if t is None else t.detach().float().contiguous()
+    bias, post_scale, post_shift = f32(bias), f32(post_scale), f32(post_shift)
+    d = _hip.make_desc(x, nn_idx, etype, nou, net, ext, agg, relu, y)
+    _hip.check(L.fgnn_mpconv_forward(
+        ctypes.byref(d), _hip._ptr(x), _hip._ptr(nn_idx), _hip._ptr(etype), _hip._ptr(filters),
+        _hip._ptr(bias), _hip._ptr(post_scale), _hip._ptr(post_shift), _hip._ptr(y),
+        _hip._ptr(amax), _hip.stream_ptr()))
+    return y, amax
+
+
+class _MPConv(torch.autograd.Function):
+    """z = agg(messages) + bias with the hand-written HIP forward and backward."""
+
+    @staticmethod
+    def forward(ctx, x, nn_idx, etype, filters, bias, nou, net, ext, agg):
+        z, amax = mpconv_forward_raw(x, nn_idx, etype, filters, bias, nou, net, ext, agg,
+                                     want_argmax=True)
+        ctx.cfg = (nou, net, ext, agg)
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(x, nn_idx, etype, filters, amax,
+                              z if agg == _hip.AGG_LSE else None)
+        return z
+
+    @staticmethod
+    def backward(ctx, gz):
+        x, nn_idx, etype, filters, amax, z = ctx.saved_tensors
+        nou, net, ext, agg = ctx.cfg
+        L = _hip.lib()
+        B, M, k = nn_idx.shape
+        # gz must share z's layout/dtype (the descriptor carries one set of y strides)
+        zl = _alloc_out(x, nou, M)
+        if gz.dtype != zl.dtype or gz.stride() != zl.stride():
+            zl.copy_(gz)
+            gz = zl
+        dense = x.is_contiguous() or x.permute(0, 2, 3, 1).is_contiguous()
+        xx = x if dense else x.contiguous()
+        gx = torch.zeros_like(xx)          # preserve_format keeps xx's (dense) strides
+        get = torch.empty((B, net, M, k), device=x.device, dtype=torch.float32)
+        gw = torch.zeros(filters.shape, device=x.device, dtype=torch.float32)
+        gb = torch.zeros((nou,), device=x.device, dtype=torch.float32) if ctx.has_bias else None
+        w = filters.detach().float().contiguous()
+        d = _hip.make_desc(xx, nn_idx, etype, nou, net, ext, agg, False, gz)
+        _hip.check(L.fgnn_mpconv_backward(
+            ctypes.byref(d), _hip._ptr(xx), _hip._ptr(nn_idx), _hip._ptr(etype), _hip._ptr(w),
+            _hip._ptr(gz), _hip._ptr(z), _hip._ptr(amax), _hip._ptr(gx), _hip._ptr(get),
+            _hip._ptr(gw), _hip._ptr(gb), _hip.stream_ptr()))
+        if get.dtype != etype.dtype:
+            get = get.to(etype.dtype)
+        return (gx, None, get, gw.to(filters.dtype), gb, None, None, None, None)
+
+
+def mpconv(x, nn_idx, etype, filters, bias, nou, net, ext, agg):
+    """Differentiable pre-BatchNorm operator output z [B, nou, M, 1]."""
+    return _MPConv.apply(x, nn_idx, etype, filters, bias, nou, net, ext, agg)
+
+
+def algorithmic_bytes(x, nn_idx, etype, nou, net, ext, agg):
+    """SURVEY §8d algorithmic HBM bytes of one forward call (for bench.py's roofline)."""
+    y = _alloc_out(x, nou, nn_idx.shape[1]) if x.is_cuda else None
+    d = _hip.make_desc(x, nn_idx, etype, nou, net, ext, agg, False, y)
+    return int(_hip.lib().fgnn_mpconv_algorithmic_bytes(ctypes.byref(d)))

@@ -1,0 +1,96 @@
+/*
+ * fgnn_hip.h — C ABI of libfgnn_hip.so, the MI355X (gfx950) implementation of the
+ * FGNN Variable->Factor / Factor->Variable message operator.
+ *
+ * The reference (zzhang1987/Factor-Graph-Neural-Network) has no FFI for this path: the
+ * operator is a Python nn.Module, `mp_conv_v2.forward(x, nn_idx, etype)`
+ * (lib/model/mpnn/mp_nn.py:115-175), reached through `mp_conv_residual.forward`
+ * (lib/model/mpnn/mp_nn_residual.py:39-56).  This header is the boundary a maintainer of
+ * the reference would bind (ctypes stub in INTEGRATION.md): plain pointers, sizes and a
+ * hipStream_t — no torch types.  Every entry point returns 0 on success and a negative
+ * FGNN_E* code otherwise; fgnn_last_error() gives the message (thread-local).
+ *
+ * Tensor conventions (all strides are in ELEMENTS, so both NCHW and channels-last views of
+ * the reference's [B,C,N,1] tensors can be passed without a copy):
+ *   x      [B, nin, N]      float32 or bf16     element (b,c,n) at x + b*x_sb + c*x_sc + n*x_sn
+ *   nn_idx [B, M, k]        int64 (as the reference passes it), values in [0,N);
+ *                           idx_sb == 0 means "one graph shared by the whole batch"
+ *   etype  [B, net, M, k]   same dtype as x; et_sb == 0 allowed (shared edge weights)
+ *   filters[R, nou*net]     float32, R = nin (NO_EXTENSION) or 2*nin; column = o*net + e
+ *                           (the reference's `filters` parameter, mp_nn.py:41-49)
+ *   y      [B, nou, M]      same dtype as x
+ */
+#ifndef FGNN_HIP_H
+#define FGNN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* fgnn_stream_t; /* a hipStream_t; NULL = the null stream */
+
+enum { FGNN_OK = 0, FGNN_EINVAL = -1, FGNN_ELAUNCH = -2, FGNN_EUNSUPPORTED = -3 };
+
+/* mp_conv_type (mp_nn.py:7-10) */
+enum { FGNN_EXT_NONE = 0, FGNN_EXT_NEIGHBOR = 1, FGNN_EXT_DIFF = 2 };
+/* aggregator strings 'max' / 'softmax' (= (1/3) logsumexp(3 x)) / 'mean' (mp_nn.py:68-90) */
+enum { FGNN_AGG_MAX = 0, FGNN_AGG_LSE = 1, FGNN_AGG_MEAN = 2 };
+enum { FGNN_F32 = 0, FGNN_BF16 = 1 };
+
+typedef struct fgnn_mpconv_desc {
+    int32_t B, nin, nou, net, N, M, k;
+    int32_t ext;    /* FGNN_EXT_*  */
+    int32_t agg;    /* FGNN_AGG_*  */
+    int32_t dtype;  /* FGNN_F32 / FGNN_BF16: storage type of x, etype, y (accumulation is f32) */
+    int32_t relu;   /* apply max(.,0) last (forward only) */
+    int32_t reserved;
+    int64_t x_sb, x_sc, x_sn;
+    int64_t idx_sb, idx_sm, idx_sk;
+    int64_t et_sb, et_se, et_sm, et_sk;
+    int64_t y_sb, y_sc, y_sm;
+} fgnn_mpconv_desc;
+
+/*
+ * Forward: y = act( post_scale * (agg_j sum_e etype[e,m,j] * msg[m,j,:,e] + bias) + post_shift )
+ * Replaces mp_conv_v2.forward steps a-k: gather -> matmul(filters) -> bmm(etype)
+ * -> aggregate -> +bias -> (eval-mode BatchNorm folded into post_scale/post_shift) -> ReLU.
+ *   bias, post_scale, post_shift : float32 [nou] or NULL.
+ *   argmax : uint8 [B, nou, M] (contiguous) or NULL; for FGNN_AGG_MAX receives the winning
+ *            neighbour slot (first occurrence on ties, as torch.max on CPU).
+ */
+int fgnn_mpconv_forward(const fgnn_mpconv_desc* d, const void* x, const int64_t* nn_idx,
+                        const void* etype, const float* filters, const float* bias,
+                        const float* post_scale, const float* post_shift, void* y,
+                        uint8_t* argmax, fgnn_stream_t stream);
+
+/*
+ * Backward of z = agg(...) + bias w.r.t. x, etype, filters, bias (mp_conv_v2 is trained through
+ * autograd in the reference; this is the hand-written counterpart).
+ *   gz      [B, nou, M]  upstream gradient w.r.t. the pre-BN output z (strides y_s* of d)
+ *   z       [B, nou, M]  forward pre-BN output (needed by FGNN_AGG_LSE; NULL otherwise)
+ *   argmax  as written by the forward (FGNN_AGG_MAX; NULL otherwise)
+ *   gx      [B, nin, N]  same strides as x; MUST be zero-filled by the caller
+ *   getype  [B, net, M, k] contiguous, fully written; float32
+ *   gfilters[R, nou*net] float32, ACCUMULATED into (caller zero-fills)
+ *   gbias   [nou] float32 or NULL, ACCUMULATED into
+ */
+int fgnn_mpconv_backward(const fgnn_mpconv_desc* d, const void* x, const int64_t* nn_idx,
+                         const void* etype, const float* filters, const void* gz,
+                         const void* z, const uint8_t* argmax, void* gx, float* getype,
+                         float* gfilters, float* gbias, fgnn_stream_t stream);
+
+/* Bytes of dynamic LDS the forward will request for this descriptor (diagnostics / tests). */
+int64_t fgnn_mpconv_forward_lds_bytes(const fgnn_mpconv_desc* d);
+
+/* Algorithmic HBM bytes of one forward call (SURVEY §8d formula; used by bench.py's roofline). */
+int64_t fgnn_mpconv_algorithmic_bytes(const fgnn_mpconv_desc* d);
+
+const char* fgnn_last_error(void);
+int fgnn_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FGNN_HIP_H */

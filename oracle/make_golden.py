@@ -343,13 +343,17 @@ def make_ldpc(tabs):
     e = max(maxdiff(logits, lo), maxdiff(snr, so))
     assert e <= 1e-5, e
     blob['eval_logits'], blob['eval_snr'] = logits.numpy(), snr.numpy()
-    # train fwd + bwd
+    # train fwd + bwd on a larger batch: batch-statistics BatchNorm over 4 codewords is
+    # ill-conditioned (f32-vs-f64 of the same model differ by 1.5e-3 at B=4, 2e-4 at B=16)
+    inputs = ldpc_inputs(tabs['gen'], 16, 12)
+    for i, v in enumerate(inputs):
+        blob['tin%d' % i] = v.numpy()
     model.train()
     sdo = {k: v.clone() for k, v in model.state_dict().items()}
     logits, snr = model(*inputs)
-    tgt = (torch.arange(4 * 48).reshape(4, 48) % 3 == 0).float()
+    tgt = (torch.arange(16 * 48).reshape(16, 48) % 3 == 0).float()
     loss = torch.nn.functional.binary_cross_entropy_with_logits(logits.view(-1), tgt.view(-1)) \
-        + 0.1 * torch.nn.functional.mse_loss(snr.view(-1), torch.ones(4))
+        + 0.1 * torch.nn.functional.mse_loss(snr.view(-1), torch.ones(16))
     loss.backward()
     lo, so = O.ldpc_model(sdo, *inputs, training=True)
     e2 = max(maxdiff(logits, lo), maxdiff(snr, so))

@@ -1,0 +1,124 @@
+"""GPU parity of the fused HIP message operator (through the C ABI) against
+(a) the golden vectors the real reference produced and (b) the CPU oracle on fresh seeded inputs.
+Tolerance for fp32: 1e-4 (BASELINE.json north_star), tightened to 2e-5 relative where the math
+is a single operator call."""
+import pytest
+import torch
+
+import fgnn_oracle as O
+import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+CASES = H.operator_cases()
+TOL = 2e-5
+
+
+def build_module(c, dev):
+    from fgnn_amd.mpnn import mp_conv_type, mp_conv_v2
+    m = mp_conv_v2(c.nin, c.nou, c.net, bias=c.has_bias, bn=(c.bn != 'off'),
+                   extension=mp_conv_type(c.ext), activation_fn='relu' if c.relu else None,
+                   aggregtor=c.agg)
+    m.load_state_dict(c.sd())
+    m.train(c.bn == 'train')
+    return m.to(dev)
+
+
+@pytest.mark.parametrize('c', CASES, ids=[repr(c) for c in CASES])
+def test_forward_matches_reference_golden(c, dev):
+    m = build_module(c, dev)
+    with torch.no_grad():
+        y = m(c.t['x'].to(dev), c.t['idx'].to(dev), c.t['etype'].to(dev))
+    assert y.shape == c.t['y'].shape
+    assert H.rel_err(y, c.t['y']) <= TOL
+    if c.bn == 'train':
+        assert H.rel_err(m.bn.running_var, c.t['post_running_var']) <= TOL
+
+
+@pytest.mark.parametrize('c', CASES, ids=[repr(c) for c in CASES])
+def test_backward_matches_reference_golden(c, dev):
+    m = build_module(c, dev)
+    x = c.t['x'].to(dev).requires_grad_(True)
+    et = c.t['etype'].to(dev).requires_grad_(True)
+    y = m(x, c.t['idx'].to(dev), et)
+    assert H.rel_err(y, c.t['y']) <= TOL
+    y.backward(c.t['gy'].to(dev))
+    assert H.rel_err(x.grad, c.t['gx']) <= 1e-4
+    assert H.rel_err(et.grad, c.t['getype']) <= 1e-4
+    assert H.rel_err(m.filters.grad, c.t['gfilters']) <= 1e-4
+    if c.has_bias:
+        assert H.rel_err(m.bias.grad, c.t['gbias']) <= 1e-4
+
+
+def _random_problem(seed, B, nin, nou, net, N, M, k, dev, dtype=torch.float32):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, nin, N, 1, generator=g)
+    idx = torch.randint(0, N, (B, M, k), generator=g)
+    et = torch.randn(B, net, M, k, generator=g)
+    return x, idx, et, g
+
+
+@pytest.mark.parametrize('ext,agg', [(0, 'max'), (0, 'softmax'), (2, 'max'), (1, 'mean'), (2, 'softmax')])
+@pytest.mark.parametrize('layout', ['nchw', 'channels_last'])
+def test_layouts_and_shared_graph_vs_oracle(ext, agg, layout, dev):
+    """channels-last views and batch-stride-0 (expanded) graphs / edge weights give the same answer."""
+    from fgnn_amd import _hip, ops
+    B, nin, nou, net, N, k = 5, 12, 10, 4, 20, 3
+    M = N if ext else 13
+    x, idx, et, g = _random_problem(7 + ext, B, nin, nou, net, N, M, k, dev)
+    idx = idx[:1].expand(B, -1, -1)                 # shared graph
+    et = et[:1].expand(B, -1, -1, -1)               # shared edge weights
+    R = nin if ext == 0 else 2 * nin
+    sd = {'filters': torch.randn(R, nou * net, generator=g) * 0.3,
+          'bias': torch.randn(nou, generator=g)}
+    ref = O.mp_conv(sd, '', x, idx.contiguous(), et.contiguous(), nou=nou, net=net,
+                    extension=ext, aggregator=agg, relu=False)
+    xd = x.to(dev)
+    if layout == 'channels_last':
+        xd = xd.contiguous(memory_format=torch.channels_last)
+    y, _ = ops.mpconv_forward_raw(xd, idx[:1].to(dev).expand(B, -1, -1),
+                                  et[:1].to(dev).expand(B, -1, -1, -1), sd['filters'].to(dev),
+                                  sd['bias'].to(dev), nou, net, ext, _hip.AGG_CODES[agg])
+    assert H.rel_err(y, ref) <= TOL
+    if layout == 'channels_last':
+        assert y.stride(1) == 1          # output keeps the input's layout
+
+
+def test_bf16_storage_vs_oracle(dev):
+    """bf16 x / etype / y with f32 accumulation: compare with the oracle run on the SAME
+    bf16-rounded inputs; only the output rounding (2^-9 relative) differs."""
+    from fgnn_amd import _hip, ops
+    B, nin, nou, net, N, M, k = 4, 64, 64, 4, 96, 48, 6
+    x, idx, et, g = _random_problem(3, B, nin, nou, net, N, M, k, dev)
+    x, et = x.bfloat16(), et.bfloat16()
+    sd = {'filters': torch.randn(nin, nou * net, generator=g) * 0.1, 'bias': torch.randn(nou, generator=g)}
+    ref = O.mp_conv(sd, '', x.float(), idx, et.float(), nou=nou, net=net, extension=0,
+                    aggregator='max', relu=True)
+    y, _ = ops.mpconv_forward_raw(x.to(dev), idx.to(dev), et.to(dev), sd['filters'].to(dev),
+                                  sd['bias'].to(dev), nou, net, 0, _hip.AGG_MAX, relu=True)
+    assert y.dtype == torch.bfloat16
+    err = (y.float().cpu() - ref).abs().max() / ref.abs().max()
+    assert err <= 2.0 ** -8
+
+
+def test_ldpc_sized_shapes_vs_oracle(dev):
+    """The four operator shapes of the LDPC model at a batch the oracle finishes in seconds."""
+    from fgnn_amd import _hip, ops
+    shapes = [(64, 64, 4, 96, 48, 6), (64, 64, 4, 48, 96, 3), (64, 64, 1, 96, 1, 96),
+              (64, 64, 1, 1, 96, 1), (64, 128, 4, 96, 48, 6), (128, 64, 4, 48, 96, 3)]
+    for s, (nin, nou, net, N, M, k) in enumerate(shapes):
+        x, idx, et, g = _random_problem(100 + s, 8, nin, nou, net, N, M, k, dev)
+        sd = {'filters': torch.randn(nin, nou * net, generator=g) * 0.1,
+              'bias': torch.randn(nou, generator=g)}
+        ref = O.mp_conv(sd, '', x, idx, et, nou=nou, net=net, extension=0, aggregator='max', relu=False)
+        y, am = ops.mpconv_forward_raw(x.to(dev), idx.to(dev), et.to(dev), sd['filters'].to(dev),
+                                       sd['bias'].to(dev), nou, net, 0, _hip.AGG_MAX, want_argmax=True)
+        assert H.rel_err(y, ref) <= TOL, (nin, nou, net, N, M, k)
+        assert int(am.max()) < k
+
+
+def test_cpu_tensor_raises():
+    from fgnn_amd import _hip, ops
+    with pytest.raises(_hip.FgnnHipError):
+        ops.mpconv_forward_raw(torch.zeros(1, 2, 3, 1), torch.zeros(1, 3, 2, dtype=torch.int64),
+                               torch.zeros(1, 1, 3, 2), torch.zeros(2, 2), None, 2, 1, 0, 0)
