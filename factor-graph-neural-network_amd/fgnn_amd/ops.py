@@ -86,13 +86,12 @@ class _MPConv(torch.autograd.Function):
                                      want_argmax=True)
         ctx.cfg = (nou, net, ext, agg)
         ctx.has_bias = bias is not None
-        ctx.save_for_backward(x, nn_idx, etype, filters, amax,
-                              z if agg == _hip.AGG_LSE else None)
+        ctx.save_for_backward(x, nn_idx, etype, filters, amax)
         return z
 
     @staticmethod
     def backward(ctx, gz):
-        x, nn_idx, etype, filters, amax, z = ctx.saved_tensors
+        x, nn_idx, etype, filters, amax = ctx.saved_tensors
         nou, net, ext, agg = ctx.cfg
         L = _hip.lib()
         B, M, k = nn_idx.shape
@@ -103,7 +102,7 @@ class _MPConv(torch.autograd.Function):
             gz = zl
         dense = x.is_contiguous() or x.permute(0, 2, 3, 1).is_contiguous()
         xx = x if dense else x.contiguous()
-        gx = torch.zeros_like(xx)          # preserve_format keeps xx's (dense) strides
+        gx = torch.empty_like(xx, dtype=torch.float32)   # preserve_format keeps xx's strides
         get = torch.empty((B, net, M, k), device=x.device, dtype=torch.float32)
         gw = torch.zeros(filters.shape, device=x.device, dtype=torch.float32)
         gb = torch.zeros((nou,), device=x.device, dtype=torch.float32) if ctx.has_bias else None
@@ -111,10 +110,12 @@ class _MPConv(torch.autograd.Function):
         d = _hip.make_desc(xx, nn_idx, etype, nou, net, ext, agg, False, gz)
         _hip.check(L.fgnn_mpconv_backward(
             ctypes.byref(d), _hip._ptr(xx), _hip._ptr(nn_idx), _hip._ptr(etype), _hip._ptr(w),
-            _hip._ptr(gz), _hip._ptr(z), _hip._ptr(amax), _hip._ptr(gx), _hip._ptr(get),
+            _hip._ptr(gz), None, _hip._ptr(amax), _hip._ptr(gx), _hip._ptr(get),
             _hip._ptr(gw), _hip._ptr(gb), _hip.stream_ptr()))
         if get.dtype != etype.dtype:
             get = get.to(etype.dtype)
+        if gx.dtype != x.dtype:
+            gx = gx.to(x.dtype)
         return (gx, None, get, gw.to(filters.dtype), gb, None, None, None, None)
 
 

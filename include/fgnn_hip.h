@@ -69,16 +69,16 @@ int fgnn_mpconv_forward(const fgnn_mpconv_desc* d, const void* x, const int64_t*
  * Backward of z = agg(...) + bias w.r.t. x, etype, filters, bias (mp_conv_v2 is trained through
  * autograd in the reference; this is the hand-written counterpart).
  *   gz      [B, nou, M]  upstream gradient w.r.t. the pre-BN output z (strides y_s* of d)
- *   z       [B, nou, M]  forward pre-BN output (needed by FGNN_AGG_LSE; NULL otherwise)
+ *   z       reserved, pass NULL (the softmax weights are recomputed from x)
  *   argmax  as written by the forward (FGNN_AGG_MAX; NULL otherwise)
- *   gx      [B, nin, N]  same strides as x; MUST be zero-filled by the caller
+ *   gx      [B, nin, N]  float32, same ELEMENT strides as x; fully written
  *   getype  [B, net, M, k] contiguous, fully written; float32
  *   gfilters[R, nou*net] float32, ACCUMULATED into (caller zero-fills)
  *   gbias   [nou] float32 or NULL, ACCUMULATED into
  */
 int fgnn_mpconv_backward(const fgnn_mpconv_desc* d, const void* x, const int64_t* nn_idx,
                          const void* etype, const float* filters, const void* gz,
-                         const void* z, const uint8_t* argmax, void* gx, float* getype,
+                         const void* z, const uint8_t* argmax, float* gx, float* getype,
                          float* gfilters, float* gbias, fgnn_stream_t stream);
 
 /* Bytes of dynamic LDS the forward will request for this descriptor (diagnostics / tests). */

@@ -43,11 +43,14 @@ def test_backward_matches_reference_golden(c, dev):
     y = m(x, c.t['idx'].to(dev), et)
     assert H.rel_err(y, c.t['y']) <= TOL
     y.backward(c.t['gy'].to(dev))
-    assert H.rel_err(x.grad, c.t['gx']) <= 1e-4
-    assert H.rel_err(et.grad, c.t['getype']) <= 1e-4
-    assert H.rel_err(m.filters.grad, c.t['gfilters']) <= 1e-4
+    # batch-statistics BatchNorm over B*M < 8 values is degenerate (over 2 values the true
+    # gradient is exactly 0 and what is left is amplified rounding noise): looser bound there
+    tol = 1e-3 if (c.bn == 'train' and c.B * c.M < 8) else 1e-4
+    assert H.rel_err(x.grad, c.t['gx']) <= tol
+    assert H.rel_err(et.grad, c.t['getype']) <= tol
+    assert H.rel_err(m.filters.grad, c.t['gfilters']) <= tol
     if c.has_bias:
-        assert H.rel_err(m.bias.grad, c.t['gbias']) <= 1e-4
+        assert H.rel_err(m.bias.grad, c.t['gbias']) <= tol
 
 
 def _random_problem(seed, B, nin, nou, net, N, M, k, dev, dtype=torch.float32):
