@@ -214,10 +214,10 @@ __global__ __launch_bounds__(FGNN_THREADS) void mpconv_bwd_kernel(const BwdParam
                     for (int j = 0; j < k; ++j) {
                         const float v = 3.0f * bwd_edge_dot<NET>(et_s + (m * k + j) * net,
                                                                   ps + ip[j] * p.PS + ol * net, pself, net);
-                        if (v > mx) { s = s * __expf(mx - v) + 1.0f; mx = v; }
-                        else s += __expf(v - mx);
+                        if (v > mx) { s = s * expf(mx - v) + 1.0f; mx = v; }
+                        else s += expf(v - mx);
                     }
-                    zagg = mx + __logf(s);      // = 3 * agg
+                    zagg = mx + logf(s);      // = 3 * agg
                 }
                 float dq[NET > 0 ? NET : 1];
                 if constexpr (NET > 0) {
@@ -229,7 +229,7 @@ __global__ __launch_bounds__(FGNN_THREADS) void mpconv_bwd_kernel(const BwdParam
                     const float* pn = ps + ip[j] * p.PS + ol * net;
                     float w = g;
                     if (AGG == FGNN_AGG_LSE)
-                        w = g * __expf(3.0f * bwd_edge_dot<NET>(etp, pn, pself, net) - zagg);
+                        w = g * expf(3.0f * bwd_edge_dot<NET>(etp, pn, pself, net) - zagg);
                     else if (AGG == FGNN_AGG_MEAN)
                         w = g / (float)k;
                     float* dpn = dps + ip[j] * p.PS + ol * net;

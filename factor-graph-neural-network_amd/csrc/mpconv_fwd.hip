@@ -207,10 +207,10 @@ __global__ __launch_bounds__(FGNN_THREADS) void mpconv_fwd_kernel(const FwdParam
                     float mx = -INFINITY, s = 0.f;
                     for (int j = 0; j < k; ++j) {
                         const float v = 3.0f * edge_dot<NET>(ep + j * net, ps + ip[j] * p.PS + ol * net, pself, net);
-                        if (v > mx) { s = s * __expf(mx - v) + 1.0f; mx = v; }
-                        else s += __expf(v - mx);
+                        if (v > mx) { s = s * expf(mx - v) + 1.0f; mx = v; }
+                        else s += expf(v - mx);
                     }
-                    res = (1.0f / 3.0f) * (mx + __logf(s));
+                    res = (1.0f / 3.0f) * (mx + logf(s));
                 } else {
                     float s = 0.f;
                     for (int j = 0; j < k; ++j)

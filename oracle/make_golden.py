@@ -81,7 +81,9 @@ def fill_state_dict(sd):
             continue
         n = t.numel()
         i = torch.arange(n, dtype=torch.float64)
-        wave = torch.sin(0.37 * i + 1.3 * rank)
+        # GLSL-style hash in float64: well-spread pseudo-random values in (-1, 1)
+        wave = torch.sin(12.9898 * i + 78.233 * rank) * 43758.5453
+        wave = 2.0 * (wave - torch.floor(wave)) - 1.0
         if key.endswith('running_var'):
             v = 1.0 + 0.5 * wave.abs()
         elif key.endswith('running_mean'):
@@ -105,6 +107,25 @@ def maxdiff(a, b):
     if not a.numel():
         return 0.0
     return float((a - b).abs().max()) / max(1.0, float(a.abs().max()))
+
+
+def to64(obj):
+    if torch.is_tensor(obj):
+        return obj.detach().double() if obj.is_floating_point() else obj.detach()
+    if isinstance(obj, dict):
+        return {k: to64(v) for k, v in obj.items()}
+    if isinstance(obj, (list, tuple)):
+        return [to64(v) for v in obj]
+    return obj
+
+
+def conditioning(ref32, fn64):
+    """rel. distance between the reference's f32 result and the same computation in f64:
+    how much f32 rounding alone moves this output.  Tests accept the HIP path within a small
+    multiple of it (batch-statistics BatchNorm over small batches amplifies rounding)."""
+    with torch.no_grad():
+        y64 = fn64()
+    return maxdiff(ref32.detach().double(), y64)
 
 
 EXT = {0: R.mp_conv_type.NO_EXTENSION, 1: R.mp_conv_type.ORIG_WITH_NEIGHBOR,
@@ -343,6 +364,8 @@ def make_ldpc(tabs):
     e = max(maxdiff(logits, lo), maxdiff(snr, so))
     assert e <= 1e-5, e
     blob['eval_logits'], blob['eval_snr'] = logits.numpy(), snr.numpy()
+    blob['eval_cond'] = np.float64(conditioning(
+        logits, lambda: O.ldpc_model(to64(sdo), *to64(list(inputs)), training=False)[0]))
     # train fwd + bwd on a larger batch: batch-statistics BatchNorm over 4 codewords is
     # ill-conditioned (f32-vs-f64 of the same model differ by 1.5e-3 at B=4, 2e-4 at B=16)
     inputs = ldpc_inputs(tabs['gen'], 16, 12)
@@ -359,6 +382,9 @@ def make_ldpc(tabs):
     e2 = max(maxdiff(logits, lo), maxdiff(snr, so))
     assert e2 <= 1e-5, e2
     blob['train_logits'], blob['train_snr'] = logits.detach().numpy(), snr.detach().numpy()
+    sd_pre = fill_state_dict(model.state_dict())
+    blob['train_cond'] = np.float64(conditioning(
+        logits, lambda: O.ldpc_model(to64(sd_pre), *to64(list(inputs)), training=True)[0]))
     blob['train_loss'] = np.float64(loss.item())
     names = [n for n, _ in sorted(model.named_parameters())]
     blob['grad_digest'] = grad_digest(model.named_parameters())
@@ -370,8 +396,8 @@ def make_ldpc(tabs):
         [float(v.double().sum()) for k, v in sorted(model.state_dict().items())
          if k.endswith('running_var')])
     np.savez_compressed(os.path.join(OUT, 'ldpc_model.npz'), **blob)
-    print('ldpc_model.npz: eval err %.2e train err %.2e, %d state entries' %
-          (e, e2, len(model.state_dict())))
+    print('ldpc_model.npz: eval err %.2e train err %.2e, %d state entries; cond eval %.2e train %.2e' %
+          (e, e2, len(model.state_dict()), blob['eval_cond'], blob['train_cond']))
 
 
 def make_factor_mpnn(tabs):
@@ -411,6 +437,11 @@ def make_factor_mpnn(tabs):
             e = maxdiff(pred, po)
             assert e <= 2e-5, (tag, mode, e)
             blob[mode + '_pred'] = pred.detach().numpy()
+            sd_pre = fill_state_dict(model.state_dict())
+            blob[mode + '_cond'] = np.float64(conditioning(
+                pred, lambda: O.factor_mpnn(to64(sd_pre), '', to64(nfeature), to64([pws, hi_feat]),
+                                            [[a, to64(b)] for a, b in gs], dims=O.SYN_DIMS,
+                                            netypes=[16, 16], training=(mode == 'train'))[0]))
             blob[mode + '_ff0'] = ff[0].detach().numpy()
             blob[mode + '_ff1'] = ff[1].detach().numpy()
             if mode == 'train':
@@ -423,7 +454,7 @@ def make_factor_mpnn(tabs):
                     list(model.named_parameters())
                     + [('emodel_pw.' + n, p) for n, p in emodel_pw.named_parameters()]
                     + [('emodel_hi.' + n, p) for n, p in emodel_hi.named_parameters()])
-            print('factor_mpnn_%s %s: oracle err %.2e' % (tag, mode, e))
+            print('factor_mpnn_%s %s: oracle err %.2e cond %.2e' % (tag, mode, e, blob[mode + '_cond']))
         np.savez_compressed(os.path.join(OUT, 'factor_mpnn_%s.npz' % tag), **blob)
 
 
@@ -460,7 +491,11 @@ def make_sequential(tabs):
         e = maxdiff(y, yo)
         assert e <= 2e-5, (mode, e)
         blob[mode + '_y'] = y.numpy()
-        print('mp_sequential cfg1 %s: oracle err %.2e' % (mode, e))
+        sd_pre = fill_state_dict(model.state_dict())
+        blob[mode + '_cond'] = np.float64(conditioning(
+            y, lambda: O.fixed_pw_hop_net(to64(sd_pre), to64(x), idx.repeat(B, 1, 1),
+                                          to64(et.repeat(B, 1, 1, 1)), training=(mode == 'train'))))
+        print('mp_sequential cfg1 %s: oracle err %.2e cond %.2e' % (mode, e, blob[mode + '_cond']))
     np.savez_compressed(os.path.join(OUT, 'sequential_cfg1.npz'), **blob)
 
 

@@ -23,7 +23,9 @@ def fill_state_dict(sd):
             out[key] = t.clone()
             continue
         i = torch.arange(t.numel(), dtype=torch.float64)
-        wave = torch.sin(0.37 * i + 1.3 * rank)
+        # GLSL-style hash in float64: well-spread pseudo-random values in (-1, 1)
+        wave = torch.sin(12.9898 * i + 78.233 * rank) * 43758.5453
+        wave = 2.0 * (wave - torch.floor(wave)) - 1.0
         if key.endswith('running_var'):
             v = 1.0 + 0.5 * wave.abs()
         elif key.endswith('running_mean'):

@@ -1,0 +1,151 @@
+"""GPU: the reference's model bodies (LDPCModel/FactorNN, factor_mpnn, mp_sequential config 1)
+built from fgnn_amd's drop-in classes with closed-form parameters, against the golden outputs of
+the REAL reference (eval: <= 1e-4, the north-star tolerance; train: conditioning-limited, see
+tests/test_oracle_golden.py) and against the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+import fgnn_oracle as O
+import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+def _tol(z, mode):
+    """eval: the north-star 1e-4.  train: batch-statistics BatchNorm amplifies f32 rounding by
+    up to 1e4 on these small fixtures (a 1e-7 input perturbation moves the REFERENCE's own output
+    by ~1e-3); the fixture stores how far the reference's f32 result is from an f64 run of the same
+    maths (`*_cond`) and the HIP path must stay within 8x of that."""
+    if mode == 'eval':
+        return 1e-4
+    return max(1e-4, 8.0 * float(z['train_cond']))
+
+
+def _ldpc(dev):
+    import fgnn_amd
+    m = fgnn_amd.LDPCModel(2, 6, 4, aggregator='max')
+    m.load_state_dict(H.fill_state_dict(m.state_dict()))
+    return m.to(dev)
+
+
+def test_ldpc_model_eval_matches_reference(dev):
+    z = H.load('ldpc_model.npz')
+    m = _ldpc(dev).eval()
+    inputs = [torch.from_numpy(z['in%d' % i]).to(dev) for i in range(6)]
+    with torch.no_grad():
+        logits, snr = m(*inputs)
+    assert H.rel_err(logits, torch.from_numpy(z['eval_logits'])) <= 1e-4
+    assert H.rel_err(snr, torch.from_numpy(z['eval_snr'])) <= 1e-4
+
+
+def test_ldpc_model_train_step_matches_reference(dev):
+    z = H.load('ldpc_model.npz')
+    m = _ldpc(dev).train()
+    inputs = [torch.from_numpy(z['tin%d' % i]).to(dev) for i in range(6)]
+    logits, snr = m(*inputs)
+    assert H.rel_err(logits, torch.from_numpy(z['train_logits'])) <= _tol(z, 'train')
+    tgt = (torch.arange(16 * 48, device=dev).reshape(16, 48) % 3 == 0).float()
+    loss = torch.nn.functional.binary_cross_entropy_with_logits(logits.view(-1), tgt.view(-1)) \
+        + 0.1 * torch.nn.functional.mse_loss(snr.view(-1), torch.ones(16, device=dev))
+    assert abs(loss.item() - float(z['train_loss'])) <= 1e-3 * max(1.0, abs(float(z['train_loss'])))
+    loss.backward()
+    names = [n for n, _ in sorted(m.named_parameters())]
+    assert names == list(z['param_names'])
+    # Whole-model gradients are not comparable across implementations at these sizes (max-argmax
+    # flips + batch-stat BatchNorm: the reference's own gradient norms move by 25% between two CPU
+    # processes), so gradients are pinned per operator (test_mpconv_gpu.py) and checked here for
+    # self-consistency: the directional derivative along the computed gradient must match a
+    # central finite difference of the loss.
+    params = [p for p in m.parameters() if p.grad is not None]
+    gnorm = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in params)).item()
+    direction = [p.grad / gnorm for p in params]
+
+    def loss_at(eps):
+        with torch.no_grad():
+            for p, dvec in zip(params, direction):
+                p.add_(dvec, alpha=eps)
+            lg, sn = m(*inputs)
+            val = torch.nn.functional.binary_cross_entropy_with_logits(lg.view(-1), tgt.view(-1)) \
+                + 0.1 * torch.nn.functional.mse_loss(sn.view(-1), torch.ones(16, device=dev))
+            for p, dvec in zip(params, direction):
+                p.add_(dvec, alpha=-eps)
+        return val.double().item()
+
+    eps = 1e-4
+    fd = (loss_at(eps) - loss_at(-eps)) / (2 * eps)
+    assert abs(fd - gnorm) <= 0.1 * gnorm, (fd, gnorm)
+
+
+def test_ldpc_model_eval_vs_oracle_bigger_batch(dev):
+    from fgnn_amd.ldpc import synthetic_batch
+    m = _ldpc(dev).eval()
+    batch = synthetic_batch(32, dev, seed=3)
+    with torch.no_grad():
+        logits, snr = m(*batch[:6])
+        sd = {k: v.cpu() for k, v in m.state_dict().items()}
+        lo, so = O.ldpc_model(sd, *[t.cpu().contiguous() for t in batch[:6]], training=False)
+    assert H.rel_err(logits, lo) <= 1e-4
+    assert H.rel_err(snr, so) <= 1e-4
+
+
+@pytest.mark.parametrize('tag', ['pw', 'hop'])
+def test_factor_mpnn_matches_reference(tag, dev):
+    import fgnn_amd
+    from fgnn_amd import tables
+    z = H.load('factor_mpnn_%s.npz' % tag)
+    hop_dim = 1 if tag == 'pw' else 9
+    model = fgnn_amd.factor_mpnn(2, [4, hop_dim], O.SYN_DIMS, [16, 16])
+    model.load_state_dict(H.fill_state_dict(model.state_dict()))
+    pw_idx, pw_ef = tables.pw_factor_table(30)
+    if tag == 'pw':
+        hi_idx, hi_ef, _ = tables.chain_high_table(30, 9)
+    else:
+        hi_idx, hi_ef = tables.ring_hop_table(30, 9)
+    C = torch.nn.Conv2d
+    em_pw = torch.nn.Sequential(C(3, 64, 1), torch.nn.ReLU(), C(64, 16, 1))
+    em_hi = torch.nn.Sequential(C(hi_ef.shape[0], 64, 1), torch.nn.ReLU(), C(64, 16, 1))
+    em_pw.load_state_dict(H.fill_state_dict(em_pw.state_dict()))
+    em_hi.load_state_dict(H.fill_state_dict(em_hi.state_dict()))
+    model, em_pw, em_hi = model.to(dev), em_pw.to(dev), em_hi.to(dev)
+    B = z['nfeature'].shape[0]
+    t = lambda a: torch.from_numpy(a).to(dev)
+    for mode in ('eval', 'train'):
+        model.load_state_dict(H.fill_state_dict(model.state_dict()))
+        model.train(mode == 'train')
+        with torch.no_grad():
+            et_pw = em_pw(t(pw_ef)[None]).expand(B, -1, -1, -1)      # the scripts .repeat(); same values
+            et_hi = em_hi(t(hi_ef)[None]).expand(B, -1, -1, -1)
+            gs = [[t(pw_idx)[None].expand(B, -1, -1), et_pw], [t(hi_idx)[None].expand(B, -1, -1), et_hi]]
+            pred, ff = model(t(z['nfeature']), [t(z['pws']), t(z['hi_feat'])], gs)
+        tol = _tol(z, mode)
+        assert H.rel_err(pred, torch.from_numpy(z[mode + '_pred'])) <= tol, mode
+        assert H.rel_err(ff[1], torch.from_numpy(z[mode + '_ff1'])) <= 4 * tol, mode
+
+
+def test_sequential_config1_matches_reference(dev):
+    from fgnn_amd import tables
+    from fgnn_amd.mpnn import mp_conv_residual, mp_conv_type, mp_conv_v2, mp_sequential
+    z = H.load('sequential_cfg1.npz')
+    C = torch.nn.Conv2d
+    bnrelu = lambda c: (torch.nn.BatchNorm2d(c), torch.nn.ReLU(inplace=True))
+    model = mp_sequential(
+        mp_conv_v2(2, 64, 16, extension=mp_conv_type.ORIG_WITH_NEIGHBOR),
+        mp_conv_residual(64, 64, 16), C(64, 128, 1), *bnrelu(128),
+        mp_conv_residual(128, 64, 16), C(128, 256, 1), *bnrelu(256),
+        mp_conv_residual(256, 64, 16), C(256, 128, 1), *bnrelu(128),
+        mp_conv_residual(128, 64, 16), C(128, 64, 1), *bnrelu(64),
+        mp_conv_residual(64, 64, 16), C(64, 2, 1))
+    emodel = torch.nn.Sequential(C(1, 64, 1), torch.nn.ReLU(), C(64, 16, 1))
+    emodel.load_state_dict(H.fill_state_dict(emodel.state_dict()))
+    model, emodel = model.to(dev), emodel.to(dev)
+    idx, ef = tables.knn_table(30, 8)
+    x = torch.from_numpy(z['x']).to(dev)
+    B = x.shape[0]
+    for mode in ('eval', 'train'):
+        model.load_state_dict(H.fill_state_dict(model.state_dict()))
+        model.train(mode == 'train')
+        with torch.no_grad():
+            et = emodel(torch.from_numpy(ef).to(dev)[None]).repeat(B, 1, 1, 1)
+            y = model(x, torch.from_numpy(idx).to(dev)[None].repeat(B, 1, 1), et)
+        assert H.rel_err(y, torch.from_numpy(z[mode + '_y'])) <= _tol(z, mode), mode
