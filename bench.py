@@ -1,0 +1,210 @@
+#!/usr/bin/env python3
+"""bench.py — VF+FV messages/s of the FGNN hot path on the 96.3.963 LDPC graph (BASELINE.json).
+
+A "step" is one pass of the hot path over one batch of synthetic codewords: by default one
+TRAINING step of LDPCModel (8 FGNN layers, 32 fused message-operator calls = 6144 VF+FV messages
+per codeword; forward + backward + gradient all-reduce + Adam), per-GPU batch 4096, inputs
+resident in HBM.  `--mode fwd` times the inference forward instead.
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W          (N > 1, one rank per GPU)
+
+Rank 0 prints ONE JSON line: the contract fields plus
+  "roofline"     — dominant hand-written kernel: algorithmic bytes (SURVEY §8d formula) / average
+                   launch duration measured live with events on the launch stream, vs 8 TB/s HBM
+  "cpu_baseline" — the CPU oracle (a port of the reference's op order) timed on this host's cores
+                   on a bounded sample of the same workload (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, 'factor-graph-neural-network_amd'))
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=4096, help='codewords per GPU (weak scaling)')
+    ap.add_argument('--mode', choices=['train', 'fwd'], default='train')
+    ap.add_argument('--dtype', choices=['f32', 'bf16'], default='f32')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-batch', type=int, default=32)
+    ap.add_argument('--cpu-threads', type=int, default=16)
+    return ap.parse_args()
+
+
+def loss_fn(logits, snr_pred, label, sigma_b):
+    """train_ldpc.py:222-227: BCE-with-logits + 0.1 * MSE on the burst-noise regressor."""
+    bce = torch.nn.functional.binary_cross_entropy_with_logits(logits.reshape(-1).float(),
+                                                               label.reshape(-1).float())
+    mse = torch.nn.functional.mse_loss(snr_pred.reshape(-1).float(),
+                                       torch.pow(10.0, sigma_b.float() / 20).reshape(-1))
+    return bce + 0.1 * mse
+
+
+def cpu_baseline(batch, mode, threads):
+    """The oracle (reference op order, PyTorch CPU, all host cores) on a bounded sample."""
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    import fgnn_oracle as O
+    from fgnn_amd.ldpc import LDPCModel, synthetic_batch, MESSAGES_PER_CODEWORD
+    # intra-op threads: the operator's tensors are small (<= 4 MB per op at this batch); past ~16
+    # threads PyTorch's CPU backend only adds contention (256 threads ran 200x slower), so the
+    # baseline uses `threads` cores and says so
+    cores = max(1, min(threads, os.cpu_count() or 1))
+    torch.set_num_threads(cores)
+    model = LDPCModel(2, 6, 4, aggregator='max')
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    data = synthetic_batch(batch, torch.device('cpu'), seed=1, shared_graph=False)
+    if mode == 'train':
+        for k, v in sd.items():
+            if v.is_floating_point() and 'running_' not in k and not k.startswith('h'):
+                v.requires_grad_(True)
+
+    def once():
+        if mode == 'train':
+            logits, snr = O.ldpc_model(sd, *data[:6], training=True)
+            loss_fn(logits, snr, data[6], data[7]).backward()
+        else:
+            with torch.no_grad():
+                O.ldpc_model(sd, *data[:6], training=False)
+
+    t0 = time.time()
+    once()
+    times = [time.time() - t0]          # kept only if the budget allows nothing else
+    t_end = time.time() + 20.0
+    fresh = []
+    while len(fresh) < 5 and time.time() + times[0] < t_end:
+        t0 = time.time()
+        once()
+        fresh.append(time.time() - t0)
+    times = fresh or times
+    times.sort()
+    med = times[len(times) // 2]
+    return {'value': MESSAGES_PER_CODEWORD * batch / med, 'unit': 'messages/s', 'cores': cores,
+            'kind': 'port',
+            'sample': 'oracle LDPCModel %s, batch %d, median of %d iterations (%.2f s each), '
+                      '%d of %d host cores, torch %s CPU' % ('train fwd+bwd' if mode == 'train' else 'eval fwd', batch,
+                                        len(times), med, cores, os.cpu_count() or 1,
+                                        torch.__version__)}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world != args.gpus and world > 1:
+        raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a ROCm device: the FGNN hot path has no CPU fallback')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+
+    from fgnn_amd import ops
+    from fgnn_amd.dp import FlatGradBucket, broadcast_parameters
+    from fgnn_amd.ldpc import LDPCModel, MESSAGES_PER_CODEWORD, synthetic_batch
+
+    torch.manual_seed(0)
+    dtype = torch.float32 if args.dtype == 'f32' else torch.bfloat16
+    model = LDPCModel(2, 6, 4, aggregator='max').to(dev)
+    broadcast_parameters(model)
+    data = synthetic_batch(args.batch, dev, seed=100 + rank, dtype=dtype)
+    inputs, label, sigma_b = data[:6], data[6], data[7]
+    train = args.mode == 'train'
+    model.train(train)
+    if train:
+        bucket = FlatGradBucket(model.parameters())
+        opt = torch.optim.Adam(bucket.params, lr=1e-4, weight_decay=1e-8)
+
+    def step():
+        if train:
+            bucket.zero()
+            logits, snr = model(*inputs)
+            loss_fn(logits, snr, label, sigma_b).backward()
+            bucket.all_reduce_mean()
+            opt.step()
+        else:
+            with torch.no_grad():
+                model(*inputs)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # one instrumented step: per-kernel-symbol launch durations on the launch stream
+    roofline = None
+    kernels = {}
+    if rank == 0:
+        ops.TIMER = ops.KernelTimer()
+        step()
+        kernels = ops.TIMER.summary()
+        ops.TIMER = None
+        if kernels:
+            sym, r = max(kernels.items(), key=lambda kv: kv[1]['ms'])
+            avg_ms = r['ms'] / r['launches']
+            achieved = (r['bytes'] / r['launches']) / (avg_ms * 1e-3) / 1e9
+            roofline = {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS,
+                        'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': None,
+                        'kernel': sym, 'launches_per_step': r['launches'],
+                        'avg_launch_us': round(avg_ms * 1e3, 2),
+                        'algorithmic_bytes_per_launch': r['bytes'] // r['launches']}
+    fence()
+
+    if rank == 0:
+        total_msgs = MESSAGES_PER_CODEWORD * args.batch * world * args.steps
+        out = {
+            'metric': 'VF+FV messages/sec on 96.3.963 LDPC graph',
+            'value': total_msgs / elapsed, 'unit': 'messages/s', 'n_gpus': world,
+            'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
+            'config': {'workload': 'LDPC 96.3.963 LDPCModel (8 FGNN layers, 32 fused VF/FV operator '
+                                   'calls, 6144 messages/codeword), %s step, batch %d codewords per GPU'
+                                   % ('training (fwd+bwd+grad all-reduce+Adam)' if train else
+                                      'inference forward', args.batch),
+                       'global_batch': args.batch * world, 'parallelism': 'dp%d' % world,
+                       'mode': args.mode},
+            'roofline': roofline,
+            'kernels': {k: {'launches': v['launches'], 'avg_us': round(v['ms'] / v['launches'] * 1e3, 2),
+                            'total_ms': round(v['ms'], 3)} for k, v in kernels.items()},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(args.cpu_batch, args.mode, args.cpu_threads)
+        else:
+            out['cpu_baseline'] = None
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

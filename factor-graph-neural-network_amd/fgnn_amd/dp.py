@@ -1,0 +1,78 @@
+"""Pure data parallelism for the FGNN models: one process per GPU, one RCCL all-reduce per step.
+
+The reference is single-process (no distributed code at all); BASELINE.json asks for
+graph batches sharded over the 8 GPUs of a node with an all-reduce of the loss gradient only.
+Every sample (codeword / graph) is independent, so the forward and backward need NO data-path
+collective; the only exchange is the parameter-gradient sum.
+
+Design for xGMI (7 point-to-point links x ~153 GB/s per GPU): the whole gradient (1.38 M floats
+= 5.5 MB for LDPCModel) lives in ONE flat fp32 buffer whose slices back every ``param.grad``,
+so a step issues exactly one ``all_reduce`` — the collective is latency-bound at this size and
+bucketing it would only add launches.  BatchNorm statistics stay per-replica (what DDP does
+with the reference's plain BatchNorm2d; its "SyncBatchNorm" is an alias, mp_nn.py:4).
+"""
+import torch
+import torch.distributed as dist
+
+
+class FlatGradBucket:
+    """Owns one contiguous gradient buffer; ``param.grad`` are views into it."""
+
+    def __init__(self, params, process_group=None):
+        self.params = [p for p in params if p.requires_grad]
+        self.group = process_group
+        if not self.params:
+            raise ValueError('no trainable parameters')
+        dev, dt = self.params[0].device, torch.float32
+        self.numel = sum(p.numel() for p in self.params)
+        self.flat = torch.zeros(self.numel, device=dev, dtype=dt)
+        off = 0
+        for p in self.params:
+            n = p.numel()
+            p.grad = self.flat[off:off + n].view_as(p)
+            off += n
+
+    def zero(self):
+        self.flat.zero_()
+
+    @property
+    def world(self):
+        return dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
+
+    def all_reduce_mean(self, async_op=False):
+        """Sum over ranks then divide by world size (mean gradient of the global batch)."""
+        w = self.world
+        if w == 1:
+            return None
+        work = dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
+        if async_op:
+            return work
+        self.flat.div_(w)
+        return None
+
+    def finish(self, work):
+        if work is not None:
+            work.wait()
+            self.flat.div_(self.world)
+
+
+def broadcast_parameters(module, src=0, group=None):
+    """Make every replica start from rank ``src``'s parameters and buffers (one flat broadcast)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return
+    tensors = [t for t in list(module.parameters()) + list(module.buffers()) if t.is_floating_point()]
+    flat = torch.cat([t.detach().reshape(-1).float() for t in tensors])
+    dist.broadcast(flat, src=src, group=group)
+    off = 0
+    with torch.no_grad():
+        for t in tensors:
+            n = t.numel()
+            t.copy_(flat[off:off + n].view_as(t))
+            off += n
+
+
+def shard_range(total, rank, world):
+    """Contiguous [begin, end) of ``total`` samples owned by ``rank`` (sizes differ by at most 1)."""
+    base, rem = divmod(total, world)
+    begin = rank * base + min(rank, rem)
+    return begin, begin + base + (1 if rank < rem else 0)

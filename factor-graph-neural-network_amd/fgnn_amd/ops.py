@@ -15,6 +15,50 @@ import torch
 from . import _hip
 
 
+class KernelTimer:
+    """Optional per-launch timing with events recorded on the stream the kernels are launched on
+    (torch's current stream).  bench.py installs one for a single instrumented step to obtain the
+    average launch duration of each kernel symbol next to its algorithmic bytes."""
+
+    def __init__(self):
+        self.records = []
+
+    def run(self, symbol, nbytes, launch):
+        start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        start.record()
+        launch()
+        end.record()
+        self.records.append((symbol, nbytes, start, end))
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for symbol, nbytes, start, end in self.records:
+            r = out.setdefault(symbol, {'launches': 0, 'ms': 0.0, 'bytes': 0})
+            r['launches'] += 1
+            r['ms'] += start.elapsed_time(end)
+            r['bytes'] += nbytes
+        return out
+
+
+TIMER = None     # set to a KernelTimer to time every launch (bench.py only)
+
+_AGG_NAME = {0: 'max', 1: 'lse', 2: 'mean'}
+
+
+def _symbol(kind, d):
+    net = d.net if d.net in (1, 4, 16) else 0
+    return 'mpconv_%s_kernel<%s, %d, %s>' % (kind, 'bf16' if d.dtype else 'float', net,
+                                             _AGG_NAME[d.agg])
+
+
+def _launch(kind, d, nbytes, fn):
+    if TIMER is None:
+        fn()
+    else:
+        TIMER.run(_symbol(kind, d), nbytes, fn)
+
+
 def _require_device(*tensors):
     for t in tensors:
         if t is not None and not t.is_cuda:
@@ -70,10 +114,11 @@ def mpconv_forward_raw(x, nn_idx, etype, filters, bias, nou, net, ext, agg, *,
     f32 = lambda t: None if t is None else t.detach().float().contiguous()
     bias, post_scale, post_shift = f32(bias), f32(post_scale), f32(post_shift)
     d = _hip.make_desc(x, nn_idx, etype, nou, net, ext, agg, relu, y)
-    _hip.check(L.fgnn_mpconv_forward(
+    nbytes = int(L.fgnn_mpconv_algorithmic_bytes(ctypes.byref(d))) if TIMER is not None else 0
+    _launch('fwd', d, nbytes, lambda: _hip.check(L.fgnn_mpconv_forward(
         ctypes.byref(d), _hip._ptr(x), _hip._ptr(nn_idx), _hip._ptr(etype), _hip._ptr(filters),
         _hip._ptr(bias), _hip._ptr(post_scale), _hip._ptr(post_shift), _hip._ptr(y),
-        _hip._ptr(amax), _hip.stream_ptr()))
+        _hip._ptr(amax), _hip.stream_ptr())))
     return y, amax
 
 
@@ -108,10 +153,21 @@ class _MPConv(torch.autograd.Function):
         gb = torch.zeros((nou,), device=x.device, dtype=torch.float32) if ctx.has_bias else None
         w = filters.detach().float().contiguous()
         d = _hip.make_desc(xx, nn_idx, etype, nou, net, ext, agg, False, gz)
-        _hip.check(L.fgnn_mpconv_backward(
+        nbytes = 0
+        if TIMER is not None:
+            # algorithmic bytes of the backward: x, etype, nn_idx, gz, argmax read once;
+            # gx, getype written once (f32); filters read and gfilters written once
+            shared_et = etype.stride(0) == 0 and B > 1
+            shared_idx = nn_idx.stride(0) == 0 and B > 1
+            nbytes = (xx.element_size() * (xx.numel() + gz.numel())
+                      + etype.element_size() * net * M * k * (1 if shared_et else B)
+                      + 8 * M * k * (1 if shared_idx else B)
+                      + (B * nou * M if amax is not None else 0)
+                      + 4 * (gx.numel() + get.numel()) + 8 * w.numel())
+        _launch('bwd', d, nbytes, lambda: _hip.check(L.fgnn_mpconv_backward(
             ctypes.byref(d), _hip._ptr(xx), _hip._ptr(nn_idx), _hip._ptr(etype), _hip._ptr(w),
             _hip._ptr(gz), None, _hip._ptr(amax), _hip._ptr(gx), _hip._ptr(get),
-            _hip._ptr(gw), _hip._ptr(gb), _hip.stream_ptr()))
+            _hip._ptr(gw), _hip._ptr(gb), _hip.stream_ptr())))
         if get.dtype != etype.dtype:
             get = get.to(etype.dtype)
         if gx.dtype != x.dtype:
