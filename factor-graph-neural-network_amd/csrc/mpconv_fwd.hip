@@ -122,7 +122,9 @@ __global__ __launch_bounds__(FGNN_THREADS) void mpconv_fwd_kernel(const FwdParam
             const T* eb = etg + (int64_t)b * d.et_sb;
             const int mk = M * k;
             for (int f = tid; f < mk * net; f += FGNN_THREADS) {
-                const int e = f / mk, r = f - e * mk;
+                int e, r;
+                if (d.et_se == 1) { r = f / net; e = f - r * net; }         // edge-type fastest in memory
+                else { e = f / mk; r = f - e * mk; }
                 const int m = r / k, j = r - m * k;
                 et_s[r * net + e] =
                     fgnn_ld(eb + (int64_t)e * d.et_se + (int64_t)m * d.et_sm + (int64_t)j * d.et_sk);

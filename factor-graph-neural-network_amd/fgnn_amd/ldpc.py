@@ -10,14 +10,15 @@ import numpy as np
 import torch
 
 from .mpnn.assemblies import FactorNN
+from .mpnn.pointwise import PointwiseConv2d
 from .tables import LdpcGraph
 
 MESSAGES_PER_CODEWORD = 8 * (288 + 288 + 96 + 96)
 
 
 def _edge_mlp(cin, hidden, cout):
-    return torch.nn.Sequential(torch.nn.Conv2d(cin, hidden, 1), torch.nn.ReLU(inplace=True),
-                               torch.nn.Conv2d(hidden, cout, 1))
+    return torch.nn.Sequential(PointwiseConv2d(cin, hidden, 1), torch.nn.ReLU(inplace=True),
+                               PointwiseConv2d(hidden, cout, 1))
 
 
 class LDPCModel(torch.nn.Module):

@@ -9,8 +9,8 @@ message inside runs through the fused HIP operator.
 """
 import torch
 
-from .blocks import (NodeInstanceNorm, iid_mapping, iid_mapping_bn, iid_mapping_in,
-                     mp_conv_residual)
+from .blocks import iid_mapping, iid_mapping_bn, iid_mapping_in, mp_conv_residual
+from .pointwise import NodeInstanceNorm, PointwiseConv2d as _Conv
 from .message_op import base_mp_nn, mp_conv_type, mp_conv_v2
 
 
@@ -68,7 +68,7 @@ class factor_mpnn(torch.nn.Module):
                 elif nin <= max_mpnn_dim and nout <= max_mpnn_dim:
                     m = mp_conv_v2(nin, nout, netype_list[j])
                 else:
-                    m = torch.nn.Sequential(torch.nn.Conv2d(nin, nout, 1), NodeInstanceNorm(),
+                    m = torch.nn.Sequential(_Conv(nin, nout, 1), NodeInstanceNorm(),
                                             torch.nn.ReLU(inplace=True))
                 self.add_module('mp_nn_%d_%d' % (L, j), m)
                 row.append(m)
@@ -78,9 +78,9 @@ class factor_mpnn(torch.nn.Module):
                 merge = iid_mapping_bn(width, nout)
             else:
                 merge = torch.nn.Sequential(
-                    torch.nn.Conv2d(width, 256, 1, bias=True), torch.nn.BatchNorm2d(256),
-                    torch.nn.LeakyReLU(), torch.nn.Conv2d(256, 256, 1, bias=True),
-                    torch.nn.LeakyReLU(), torch.nn.Conv2d(256, nout, 1, bias=True))
+                    _Conv(width, 256, 1, bias=True), torch.nn.BatchNorm2d(256),
+                    torch.nn.LeakyReLU(), _Conv(256, 256, 1, bias=True),
+                    torch.nn.LeakyReLU(), _Conv(256, nout, 1, bias=True))
             self.add_module('merge_module_%d' % L, merge)
             self.mp_merge_modules.append(merge)
 
@@ -160,8 +160,8 @@ class FactorNN(torch.nn.Module):
             self.v2f_modules.append(v2f_row)
         final_dim = nclass if nclass > 2 else 1
         self.final_classifier = torch.nn.Sequential(
-            torch.nn.Conv2d(dim_mapping_list[-1], 128, 1), NodeInstanceNorm(),
-            torch.nn.ReLU(inplace=True), torch.nn.Conv2d(128, final_dim, 1, bias=True))
+            _Conv(dim_mapping_list[-1], 128, 1), NodeInstanceNorm(),
+            torch.nn.ReLU(inplace=True), _Conv(128, final_dim, 1, bias=True))
 
     def mpnn_forward(self, mpnn, node_feature, nn_idx, efeature):
         return _call(mpnn, node_feature, nn_idx, efeature)

@@ -8,26 +8,11 @@ Mirrors (names, constructor signatures, state_dict keys) of
 import torch
 
 from .message_op import base_mp_nn, mp_conv_type, mp_conv_v2
-
-
-class NodeInstanceNorm(torch.nn.Module):
-    """InstanceNorm2d(affine=False, no running stats) over the node axis of [B,C,N,1].
-
-    A single node (the LDPC hyper-factor, factor_mpnn_sp.py:77,140) normalises to exactly 0
-    — (x-mean)/sqrt(0+eps) — which is what the reference's torch-1.0 era computed and what
-    newer torch refuses to compute.  No parameters, so state_dicts match
-    torch.nn.InstanceNorm2d's (empty) contribution.
-    """
-    eps = 1e-5
-
-    def forward(self, x):
-        if x.shape[2] * x.shape[3] == 1:
-            return torch.zeros_like(x)
-        return torch.nn.functional.instance_norm(x, eps=self.eps)
+from .pointwise import NodeInstanceNorm, PointwiseConv2d
 
 
 def _conv_norm_act(cin, cout, norm, act, bias=True):
-    layers = [torch.nn.Conv2d(cin, cout, 1, bias=bias)]
+    layers = [PointwiseConv2d(cin, cout, 1, bias=bias)]
     if norm is not None:
         layers.append(norm)
     layers.append(act)

@@ -13,12 +13,13 @@ pytestmark = pytest.mark.gpu
 
 
 def _tol(z, mode):
-    """eval: the north-star 1e-4.  train: batch-statistics BatchNorm amplifies f32 rounding by
+    """eval: the north-star 1e-4 (4x the fixture's own f32-vs-f64 distance where that is larger:
+    the factor_mpnn fixtures sit at 3.5e-5 / 5.2e-5).  train: batch-statistics BatchNorm amplifies f32 rounding by
     up to 1e4 on these small fixtures (a 1e-7 input perturbation moves the REFERENCE's own output
     by ~1e-3); the fixture stores how far the reference's f32 result is from an f64 run of the same
     maths (`*_cond`) and the HIP path must stay within 8x of that."""
     if mode == 'eval':
-        return 1e-4
+        return max(1e-4, 4.0 * float(z['eval_cond']))
     return max(1e-4, 8.0 * float(z['train_cond']))
 
 

@@ -1,0 +1,105 @@
+"""CPU: host-side logic — tables vs the reference's generators (golden), state_dict surface,
+constructor error behaviour, the C-ABI library loads and exports every declared symbol."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import helpers as H
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_tables_match_reference_generators():
+    from fgnn_amd import tables
+    t = H.load('tables.npz')
+    a, b = tables.knn_table(30, 8)
+    assert (a == t['knn_idx'][0]).all() and (b == t['knn_ef'][0]).all()
+    assert (a[:, 7] == 0).all()                 # the 7-of-8 quirk is reproduced, not fixed
+    a, b = tables.pw_factor_table(30)
+    assert (a == t['pw_idx'][0]).all() and (b == t['pw_ef'][0]).all()
+    a, b, c = tables.chain_high_table(30, 9)
+    assert (a == t['hi_idx'][0]).all() and (b == t['hi_ef'][0]).all() and (c == t['hi_ff'][0]).all()
+    for k in (8, 9):
+        a, b = tables.ring_hop_table(30, k)
+        assert (a == t['hop%d_idx' % k][0]).all() and (b == t['hop%d_ef' % k][0]).all()
+
+
+def test_ldpc_graph_matches_alist_incidence():
+    from fgnn_amd import tables
+    t = H.load('tables.npz')
+    g = tables.LdpcGraph()
+    assert (g.var_to_factors == t['ldpc_f2v']).all() and (g.factor_to_vars == t['ldpc_v2f']).all()
+    # the two incidence tables are transposes of each other: 288 edges, degrees 3 and 6
+    edges = {(v, f) for v in range(96) for f in g.var_to_factors[v]}
+    assert edges == {(v, f) for f in range(48) for v in g.factor_to_vars[f]} and len(edges) == 288
+    n, h, e1, e2 = g.features(t['ldpc_y'], 2.0)
+    assert np.allclose(h[:, :, 0].T, t['ldpc_hop'])
+    assert np.allclose(e1.transpose(1, 2, 0), t['ldpc_ef_f2v'])
+    assert np.allclose(e2.transpose(1, 2, 0), t['ldpc_ef_v2f'])
+
+
+def test_ldpc_model_state_dict_surface():
+    import fgnn_amd
+    z = H.load('ldpc_model.npz')
+    m = fgnn_amd.LDPCModel(2, 6, 4, aggregator='max')
+    keys = sorted(m.state_dict().keys())
+    assert keys == list(z['sd_keys']) and len(keys) == 651
+    assert [str(tuple(m.state_dict()[k].shape)) for k in keys] == list(z['sd_shapes'])
+    from fgnn_amd.ldpc import MESSAGES_PER_CODEWORD
+    assert MESSAGES_PER_CODEWORD == 6144
+
+
+def test_operator_constructor_contract():
+    from fgnn_amd.mpnn import base_mp_nn, mp_conv_residual, mp_conv_type, mp_conv_v2
+    m = mp_conv_v2(5, 7, 3)                      # defaults: ORIG_WITH_DIFF, 'softmax' (sic kwarg)
+    assert isinstance(m, base_mp_nn) and m.is_mp_nn
+    assert m.extension == mp_conv_type.ORIG_WITH_DIFF and m.aggregtor == 'softmax'
+    assert tuple(m.filters.shape) == (10, 21) and tuple(m.bias.shape) == (7,)
+    assert float(m.filters.abs().max()) <= 0.01 and 0 <= float(m.bias.min()) and float(m.bias.max()) <= 0.05
+    assert sorted(m.state_dict()) == sorted(['filters', 'bias', 'bn.weight', 'bn.bias', 'bn.running_mean',
+                                             'bn.running_var', 'bn.num_batches_tracked'])
+    with pytest.raises(ValueError, match='extension must one of mp_conv_type'):
+        mp_conv_v2(2, 2, 1, extension=7)
+    r = mp_conv_residual(8, 4, 3, nout=10)
+    assert r.mp_conv.nin == 4 and r.mp_conv.aggregtor == 'max' and r.conv2[0].out_channels == 10
+
+
+def test_operator_refuses_cpu_tensors():
+    from fgnn_amd import _hip
+    from fgnn_amd.mpnn import mp_conv_type, mp_conv_v2
+    m = mp_conv_v2(2, 2, 1, extension=mp_conv_type.NO_EXTENSION, aggregtor='max')
+    with pytest.raises(_hip.FgnnHipError, match='no CPU fallback'):
+        m(torch.zeros(1, 2, 3, 1), torch.zeros(1, 3, 2, dtype=torch.int64), torch.zeros(1, 1, 3, 2))
+
+
+def test_c_abi_exports_every_declared_symbol():
+    from fgnn_amd import _hip
+    header = open(os.path.join(ROOT, 'include', 'fgnn_hip.h')).read()
+    declared = set(re.findall(r'\b(fgnn_[a-z_]+)\s*\(', header))
+    assert declared == set(_hip.EXPORTS), declared ^ set(_hip.EXPORTS)
+    L = ctypes.CDLL(_hip.LIB_PATH)
+    for name in declared:
+        assert hasattr(L, name), name
+    assert _hip.lib().fgnn_abi_version() >= 1
+
+
+def test_descriptor_checks_without_a_gpu():
+    """Argument validation happens before any device work, so it is testable here."""
+    from fgnn_amd import _hip
+    L = _hip.lib()
+    d = _hip.MPConvDesc()
+    d.B, d.nin, d.nou, d.net, d.N, d.M, d.k = 4, 64, 64, 4, 96, 48, 6
+    d.ext, d.agg, d.dtype = 0, 0, 0
+    assert 0 < L.fgnn_mpconv_forward_lds_bytes(ctypes.byref(d)) <= 160 * 1024
+    # LDPC parity V->F call, fp32, per-sample int64 indices: 43 776 B per codeword + weights
+    d.x_sb, d.idx_sb, d.et_sb = 64 * 96, 288, 4 * 288
+    assert L.fgnn_mpconv_algorithmic_bytes(ctypes.byref(d)) == 4 * 43776 + 4 * (64 * 256 + 5 * 64)
+    d.ext, d.M = 2, 48                           # extension needs N == M
+    assert L.fgnn_mpconv_forward_lds_bytes(ctypes.byref(d)) == -1
+    assert b'N == M' in L.fgnn_last_error()
+    d.ext, d.k = 0, 300
+    assert L.fgnn_mpconv_forward_lds_bytes(ctypes.byref(d)) == -1
