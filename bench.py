@@ -40,6 +40,7 @@ def parse():
     ap.add_argument('--mode', choices=['train', 'fwd'], default='train')
     ap.add_argument('--dtype', choices=['f32', 'bf16'], default='f32')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--miopen-bn', action='store_true', help='let torch route BatchNorm to MIOpen')
     ap.add_argument('--cpu-batch', type=int, default=32)
     ap.add_argument('--cpu-threads', type=int, default=16)
     return ap.parse_args()
@@ -114,6 +115,9 @@ def main():
     if world > 1:
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
 
+    # torch's own channels-last BatchNorm kernels beat MIOpen's spatial BN on these [B,C,N,1]
+    # activations (profiles/r01), so MIOpen is bypassed for the plumbing ops by default
+    torch.backends.cudnn.enabled = bool(args.miopen_bn)
     from fgnn_amd import ops
     from fgnn_amd.dp import FlatGradBucket, broadcast_parameters
     from fgnn_amd.ldpc import LDPCModel, MESSAGES_PER_CODEWORD, synthetic_batch

@@ -165,7 +165,7 @@ __global__ __launch_bounds__(FGNN_THREADS) void mpconv_bwd_kernel(const BwdParam
                     gz_s[ol * M + m] = fgnn_ld(gb + (int64_t)(o0 + ol) * d.y_sc + (int64_t)m * d.y_sm);
                     if (AGG == FGNN_AGG_MAX)
                         reinterpret_cast<int*>(aux_s)[ol * M + m] =
-                            p.argmax[((int64_t)b * nou + o0 + ol) * M + m];
+                            p.argmax[(int64_t)b * d.y_sb + (int64_t)(o0 + ol) * d.y_sc + (int64_t)m * d.y_sm];
                 }
                 for (int f = tid; f < p.Npad * p.PS; f += FGNN_THREADS) dps[f] = 0.f;
             }

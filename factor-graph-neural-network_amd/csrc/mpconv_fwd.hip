@@ -22,6 +22,7 @@
 // HBM traffic per call = x + etype + nn_idx read once, y written once, filters from L2:
 // the algorithmic bytes of SURVEY §8d.
 #include "fgnn_common.h"
+#include <stdlib.h>
 
 struct FwdParams {
     fgnn_mpconv_desc d;
@@ -242,11 +243,11 @@ __global__ __launch_bounds__(FGNN_THREADS) void mpconv_fwd_kernel(const FwdParam
                         fgnn_st(yb + (int64_t)(o0 + ol) * d.y_sc + (int64_t)m * d.y_sm, ys[ol * p.YS + m]);
                     }
                 }
-                if (AGG == FGNN_AGG_MAX && p.argmax) {
-                    uint8_t* ab = p.argmax + ((int64_t)b * nou + o0) * M;
+                if (AGG == FGNN_AGG_MAX && p.argmax) {     // argmax shares y's element strides
+                    uint8_t* ab = p.argmax + (int64_t)b * d.y_sb;
                     for (int it = tid; it < M * otc; it += FGNN_THREADS) {
                         const int ol = it / M, m = it - ol * M;
-                        ab[(int64_t)ol * M + m] = (uint8_t)ya[ol * p.YS + m];
+                        ab[(int64_t)(o0 + ol) * d.y_sc + (int64_t)m * d.y_sm] = (uint8_t)ya[ol * p.YS + m];
                     }
                 }
             }
@@ -303,6 +304,11 @@ static int plan_forward(const fgnn_mpconv_desc* d, FwdParams* p) {
     return off * 4;
 }
 
+int fgnn_mpconv_forward_resident(const fgnn_mpconv_desc* d, const void* x, const int64_t* nn_idx,
+                                 const void* etype, const float* filters, const float* bias,
+                                 const float* post_scale, const float* post_shift, void* y,
+                                 uint8_t* argmax, fgnn_stream_t stream);
+
 int fgnn_check_desc(const fgnn_mpconv_desc* d) {
     if (!d) FGNN_FAIL(FGNN_EINVAL, "null descriptor");
     if (d->B < 0 || d->nin < 1 || d->nou < 1 || d->net < 1 || d->N < 1 || d->M < 1 || d->k < 1)
@@ -351,6 +357,14 @@ extern "C" int fgnn_mpconv_forward(const fgnn_mpconv_desc* d, const void* x, con
     if ((post_scale == nullptr) != (post_shift == nullptr))
         FGNN_FAIL(FGNN_EINVAL, "post_scale and post_shift must be given together");
     if (d->B == 0) return FGNN_OK;
+    {   // LDPC shape family: W-stationary persistent kernel (mpconv_fwd_res.hip)
+        static const bool force_generic = getenv("FGNN_FORCE_GENERIC") != nullptr;
+        if (!force_generic) {
+            rc = fgnn_mpconv_forward_resident(d, x, nn_idx, etype, filters, bias, post_scale, post_shift, y,
+                                              argmax, stream);
+            if (rc != 0) return rc < 0 ? rc : FGNN_OK;
+        }
+    }
     FwdParams p;
     p.d = *d;
     p.x = x; p.idx = nn_idx; p.et = etype; p.W = filters; p.bias = bias;

@@ -1,0 +1,448 @@
+// mpconv_fwd_res.hip — "resident-W" forward of the VF/FV message operator for the LDPC shape family
+// (NO_EXTENSION, nin <= 128, nou*net <= 512): the kernel the headline benchmark spends its time in.
+//
+// Same math as mpconv_fwd.hip (reference: /root/reference/lib/model/mpnn/mp_nn.py:115-134), different
+// schedule, designed around what the first profile showed (profiles/r01: 676 us per call, 8 channel
+// tiles x 3 barriers per sample, W re-staged per sample, LDS-latency-bound gather):
+//
+//   * persistent 512-thread workgroups (8 waves) loop over samples;
+//   * the WHOLE filter matrix lives in registers as MFMA A-fragments for the kernel's lifetime
+//     (W-stationary: wave w owns column slabs w, w+8, ...), so per sample only x moves;
+//   * the next sample's x / etype / nn_idx are prefetched into registers while the current sample is
+//     projected and gathered (issue-early / write-late staging), hiding HBM latency at 1 WG per CU;
+//   * one projection pass covers up to 256 columns: P[N, 256] (f32) sits in LDS, 2 barriers per pass;
+//   * the gather walks neighbours three at a time with independent LDS loads in flight, and for
+//     high-degree destinations (the degree-96 LDPC hyper-factor: M*nou < threads) splits the
+//     neighbour list over up to 8 waves and combines the partial max / log-sum-exp / sum in LDS.
+#include "fgnn_common.h"
+
+#define RES_THREADS 512
+#define RES_WAVES 8
+#define RES_XPT 24      // prefetch registers for x per thread   (nin*N <= 512*24)
+#define RES_EPT 4       // prefetch registers for etype per thread (M*k*net <= 512*4)
+#define RES_PASS_COLS 256
+#define RES_JP_MAX 8
+
+struct ResParams {
+    fgnn_mpconv_desc d;
+    const void* x;
+    const int64_t* idx;
+    const void* et;
+    const float* W;
+    const float* bias;
+    const float* pscale;
+    const float* pshift;
+    void* y;
+    uint8_t* argmax;
+    int Npad, Kpad, pass_cols;           // column passes of <= 256 columns
+    int xs_sn, xs_sk, PS, YS;            // LDS strides: xs[n*xs_sn + c*xs_sk], P row stride, y tile stride
+    int cl_in, cl_out;                   // channel-fastest input / output
+    int JP, items_pad;                   // neighbour-list split (1 = off)
+    unsigned xdiv, xmagic;               // row length of the dense x block (N or nin) and ceil(2^32/xdiv)
+    unsigned mkmagic;                    // ceil(2^32/(M*k))
+    int et_mode;                         // 0: etype dense [net][M][k], 1: dense [M][k][net]
+    int off_xs, off_ps, off_idx, off_et, off_ys, off_ya, off_red;
+};
+
+extern __shared__ __attribute__((aligned(16))) float fgnn_lds_r[];
+
+template <int NET>
+__device__ __forceinline__ float res_dot(const float* __restrict__ etp, const float* __restrict__ pn) {
+    if constexpr (NET == 1) {
+        return etp[0] * pn[0];
+    } else {
+        f32x4 e4 = *reinterpret_cast<const f32x4*>(etp);
+        f32x4 p4 = *reinterpret_cast<const f32x4*>(pn);
+        float v = e4[0] * p4[0];
+        v = fmaf(e4[1], p4[1], v);
+        v = fmaf(e4[2], p4[2], v);
+        v = fmaf(e4[3], p4[3], v);
+        return v;
+    }
+}
+
+// Partial aggregate over neighbours [jlo, jhi): (a, b) = (max, argmax) | (running max, scaled sum) | (sum, -)
+template <int NET, int AGG>
+__device__ __forceinline__ void res_partial(const int* __restrict__ ip, const float* __restrict__ ep,
+                                            const float* __restrict__ pc, int PS, int jlo, int jhi,
+                                            float& a, float& b) {
+    constexpr int net = NET;
+    if constexpr (AGG == FGNN_AGG_MAX) {
+        float best = 0.f;
+        int arg = jlo, j = jlo;
+        for (; j + 3 <= jhi; j += 3) {
+            const int n0 = ip[j], n1 = ip[j + 1], n2 = ip[j + 2];
+            const float v0 = res_dot<NET>(ep + j * net, pc + n0 * PS);
+            const float v1 = res_dot<NET>(ep + (j + 1) * net, pc + n1 * PS);
+            const float v2 = res_dot<NET>(ep + (j + 2) * net, pc + n2 * PS);
+            if (j == jlo || v0 > best) { best = v0; arg = j; }     // strict >: first occurrence wins
+            if (v1 > best) { best = v1; arg = j + 1; }
+            if (v2 > best) { best = v2; arg = j + 2; }
+        }
+        for (; j < jhi; ++j) {
+            const float v = res_dot<NET>(ep + j * net, pc + ip[j] * PS);
+            if (j == jlo || v > best) { best = v; arg = j; }
+        }
+        a = best;
+        b = __int_as_float(arg);
+    } else if constexpr (AGG == FGNN_AGG_LSE) {
+        float mx = -INFINITY, s = 0.f;
+        for (int j = jlo; j < jhi; ++j) {
+            const float v = 3.0f * res_dot<NET>(ep + j * net, pc + ip[j] * PS);
+            if (v > mx) { s = s * expf(mx - v) + 1.0f; mx = v; }
+            else s += expf(v - mx);
+        }
+        a = mx;
+        b = s;
+    } else {
+        float s = 0.f;
+        for (int j = jlo; j < jhi; ++j) s += res_dot<NET>(ep + j * net, pc + ip[j] * PS);
+        a = s;
+        b = 0.f;
+    }
+}
+
+// KS = Kpad/4 MFMA k-steps, SWP = column slabs per wave per pass, NPASS = column passes.
+template <typename T, int NET, int AGG, int KS, int SWP, int NPASS>
+__global__ __launch_bounds__(RES_THREADS) void mpconv_fwd_res_kernel(const ResParams p) {
+    const fgnn_mpconv_desc& d = p.d;
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int li = lane & 15, lk = lane >> 4;
+    const int nin = d.nin, nou = d.nou, N = d.N, M = d.M, k = d.k;
+    constexpr int net = NET;
+    const int ncols = nou * net;
+    const int mk = M * k;
+    const int PS = p.PS;
+
+    float* xs = fgnn_lds_r + p.off_xs;
+    float* ps = fgnn_lds_r + p.off_ps;
+    int* idx_s = reinterpret_cast<int*>(fgnn_lds_r + p.off_idx);
+    float* et_s = fgnn_lds_r + p.off_et;
+    float* ys = fgnn_lds_r + p.off_ys;
+    uint8_t* ya = reinterpret_cast<uint8_t*>(fgnn_lds_r + p.off_ya);
+    float* red = fgnn_lds_r + p.off_red;
+
+    const T* xg = static_cast<const T*>(p.x);
+    const T* etg = static_cast<const T*>(p.et);
+    T* yg = static_cast<T*>(p.y);
+
+    // ---- filters -> registers: areg[pass][q][kk] = W[c = 4kk+lk][col = pass*256 + (wave+8q)*16 + li] ----
+    const int slabs_per_pass = p.pass_cols / 16;
+    float areg[NPASS][SWP][KS];
+#pragma unroll
+    for (int ps_i = 0; ps_i < NPASS; ++ps_i)
+#pragma unroll
+        for (int q = 0; q < SWP; ++q) {
+            const int slab = wave + RES_WAVES * q;
+            const int col = ps_i * p.pass_cols + slab * 16 + li;
+            const bool ok = slab < slabs_per_pass && col < ncols;
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk) {
+                const int c = 4 * kk + lk;
+                areg[ps_i][q][kk] = (ok && c < nin) ? p.W[(int64_t)c * ncols + col] : 0.f;
+            }
+        }
+
+    // ---- prefetch registers ----
+    float xr[RES_XPT];
+    float er[RES_EPT];
+    int ir = 0;
+    const int xtot = nin * N;                 // dense per-sample block in either layout
+    // Per-thread element f = tid + q*512 of the dense x block sits at xs[f + (f / rowlen) * xpad]
+    // (rowlen = N for node-fastest input, nin for channel-fastest; xpad = LDS row padding).  The
+    // quotient is a multiply-high by a host-computed reciprocal; `t` is made opaque per sample so the
+    // compiler recomputes these few instructions instead of pinning 24 offsets in VGPRs.
+    const int xpad = (p.cl_in ? p.xs_sn : p.xs_sk) - (int)p.xdiv;
+    auto prefetch = [&](int b, int t) {
+        const T* xb = xg + (int64_t)b * d.x_sb;
+#pragma unroll
+        for (int q = 0; q < RES_XPT; ++q) {
+            const int f = t + q * RES_THREADS;
+            xr[q] = f < xtot ? fgnn_ld(xb + f) : 0.f;
+        }
+        const T* eb = etg + (int64_t)b * d.et_sb;
+#pragma unroll
+        for (int q = 0; q < RES_EPT; ++q) {
+            const int f = t + q * RES_THREADS;
+            er[q] = f < mk * net ? fgnn_ld(eb + f) : 0.f;
+        }
+        if (t < mk) {
+            const int m = t / k, j = t - m * k;
+            long long v = (p.idx + (int64_t)b * d.idx_sb)[(int64_t)m * d.idx_sm + (int64_t)j * d.idx_sk];
+            v = v < 0 ? 0 : (v >= N ? N - 1 : v);
+            ir = (int)v;
+        }
+    };
+    auto commit = [&](int t) {
+#pragma unroll
+        for (int q = 0; q < RES_XPT; ++q) {
+            const unsigned f = t + q * RES_THREADS;
+            if ((int)f < xtot) xs[f + __umulhi(f, p.xmagic) * xpad] = xr[q];
+        }
+#pragma unroll
+        for (int q = 0; q < RES_EPT; ++q) {
+            const unsigned f = t + q * RES_THREADS;
+            if ((int)f < mk * net) {
+                if (p.et_mode == 1 || net == 1) {
+                    et_s[f] = er[q];                                  // memory order is already [r][e]
+                } else {
+                    const unsigned e = __umulhi(f, p.mkmagic), r = f - e * mk;
+                    et_s[r * net + e] = er[q];
+                }
+            }
+        }
+        if (t < mk) idx_s[t] = ir;
+    };
+
+    // zero the padded part of xs once (rows n >= N, channels c >= nin stay zero forever)
+    for (int f = tid; f < p.Npad * p.Kpad; f += RES_THREADS) {
+        const int n = f / p.Kpad, c = f - n * p.Kpad;
+        if (n >= N || c >= nin) xs[n * p.xs_sn + c * p.xs_sk] = 0.f;
+    }
+
+    int b = blockIdx.x;
+    if (b < d.B) prefetch(b, tid);
+    const int ntile = p.Npad / 16, ntp = (ntile + 1) / 2;
+    const int kstep = 4 * p.xs_sk;
+
+    for (; b < d.B; b += gridDim.x) {
+        int t = tid;
+        asm volatile("" : "+v"(t));          // opaque per sample: no cross-iteration hoisting
+        commit(t);
+        __syncthreads();
+        if (b + (int)gridDim.x < d.B) prefetch(b + gridDim.x, t);
+        T* yb = yg + (int64_t)b * d.y_sb;
+        uint8_t* ab = p.argmax ? p.argmax + (int64_t)b * d.y_sb : nullptr;
+
+#pragma unroll
+        for (int pass = 0; pass < NPASS; ++pass) {
+            const int o0 = pass * p.pass_cols / net;
+            const int otc = min(p.pass_cols / net, nou - o0);
+            // ---- projection: P^T tile = W^T (cols x nin) . x (nin x nodes), exact-f32 MFMA ----
+            for (int tp = 0; tp < ntp; ++tp) {
+                const int t0 = tp * 2;
+                const bool two = (t0 + 1) < ntile;
+                f32x4 acc[SWP][2];
+#pragma unroll
+                for (int q = 0; q < SWP; ++q) { acc[q][0] = (f32x4){0, 0, 0, 0}; acc[q][1] = (f32x4){0, 0, 0, 0}; }
+                const float* bp0 = xs + (t0 * 16 + li) * p.xs_sn + lk * p.xs_sk;
+                const float* bp1 = two ? bp0 + 16 * p.xs_sn : bp0;
+#pragma unroll
+                for (int kk = 0; kk < KS; ++kk) {
+                    const float b0 = bp0[kk * kstep];
+                    const float b1 = bp1[kk * kstep];
+#pragma unroll
+                    for (int q = 0; q < SWP; ++q) {
+                        acc[q][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[pass][q][kk], b0, acc[q][0], 0, 0, 0);
+                        acc[q][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[pass][q][kk], b1, acc[q][1], 0, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < SWP; ++q) {
+                    const int slab = wave + RES_WAVES * q;
+                    if (slab < slabs_per_pass) {
+                        float* dst = ps + (t0 * 16 + li) * PS + slab * 16 + 4 * lk;
+                        *reinterpret_cast<f32x4*>(dst) = acc[q][0];
+                        if (two) *reinterpret_cast<f32x4*>(dst + 16 * PS) = acc[q][1];
+                    }
+                }
+            }
+            __syncthreads();
+
+            // ---- gather + edge-type contraction + aggregation ----
+            const int items = M * otc;
+            auto finish = [&](int it, float a, float bb) {
+                const int m = it / otc, ol = it - m * otc;
+                float res;
+                int arg = 0;
+                if constexpr (AGG == FGNN_AGG_MAX) { res = a; arg = __float_as_int(bb); }
+                else if constexpr (AGG == FGNN_AGG_LSE) res = (1.0f / 3.0f) * (a + logf(bb));
+                else res = a / (float)k;
+                const int o = o0 + ol;
+                if (p.bias) res += p.bias[o];
+                if (p.pscale) res = res * p.pscale[o] + p.pshift[o];
+                if (d.relu) res = fmaxf(res, 0.f);
+                if (p.cl_out) {              // channel-fastest output: lanes walk o, coalesced
+                    fgnn_st(yb + (int64_t)o * d.y_sc + (int64_t)m * d.y_sm, res);
+                    if (AGG == FGNN_AGG_MAX && ab) ab[(int64_t)o * d.y_sc + (int64_t)m * d.y_sm] = (uint8_t)arg;
+                } else {
+                    ys[ol * p.YS + m] = res;
+                    if (AGG == FGNN_AGG_MAX) ya[ol * p.YS + m] = (uint8_t)arg;
+                }
+            };
+            if (p.JP == 1) {
+                for (int it = tid; it < items; it += RES_THREADS) {
+                    const int m = it / otc, ol = it - m * otc;
+                    float a, bb;
+                    res_partial<NET, AGG>(idx_s + m * k, et_s + (m * k) * net, ps + ol * net, PS, 0, k, a, bb);
+                    finish(it, a, bb);
+                }
+            } else {
+                // high-degree destinations: split the neighbour list over JP thread groups
+                const int part = tid / p.items_pad, it = tid - part * p.items_pad;
+                const int chunk = (k + p.JP - 1) / p.JP;
+                if (part < p.JP && it < items) {
+                    const int m = it / otc, ol = it - m * otc;
+                    const int jlo = part * chunk, jhi = min(k, jlo + chunk);
+                    float a = 0.f, bb = 0.f;
+                    if (jlo < jhi)
+                        res_partial<NET, AGG>(idx_s + m * k, et_s + (m * k) * net, ps + ol * net, PS, jlo, jhi, a, bb);
+                    else if (AGG == FGNN_AGG_LSE) a = -INFINITY;
+                    red[(part * p.items_pad + it) * 2] = a;
+                    red[(part * p.items_pad + it) * 2 + 1] = bb;
+                }
+                __syncthreads();
+                if (tid < items) {
+                    float a = red[tid * 2], bb = red[tid * 2 + 1];
+                    for (int q = 1; q < p.JP; ++q) {
+                        if (q * chunk >= k) break;
+                        const float a2 = red[(q * p.items_pad + tid) * 2], b2 = red[(q * p.items_pad + tid) * 2 + 1];
+                        if constexpr (AGG == FGNN_AGG_MAX) {
+                            if (a2 > a) { a = a2; bb = b2; }             // later part wins only if strictly larger
+                        } else if constexpr (AGG == FGNN_AGG_LSE) {
+                            const float mx = fmaxf(a, a2);
+                            bb = bb * expf(a - mx) + b2 * expf(a2 - mx);
+                            a = mx;
+                        } else {
+                            a += a2;
+                        }
+                    }
+                    finish(tid, a, bb);
+                }
+            }
+            __syncthreads();
+            if (!p.cl_out) {                 // node-fastest output: transpose through LDS
+                for (int it = tid; it < items; it += RES_THREADS) {
+                    const int ol = it / M, m = it - ol * M;
+                    fgnn_st(yb + (int64_t)(o0 + ol) * d.y_sc + (int64_t)m * d.y_sm, ys[ol * p.YS + m]);
+                    if (AGG == FGNN_AGG_MAX && ab)
+                        ab[(int64_t)(o0 + ol) * d.y_sc + (int64_t)m * d.y_sm] = ya[ol * p.YS + m];
+                }
+                // ys is rewritten only behind the next pass's projection barrier
+            }
+        }
+        // every read of xs / et_s / idx_s / ps for this sample is behind the last barrier
+    }
+}
+
+// ----------------------------------------------------------------------------------------
+// host side
+// ----------------------------------------------------------------------------------------
+template <typename T, int NET, int AGG>
+static void* res_pick_shape(int KS, int SWP, int NPASS) {
+#define RES_CASE(ks, swp, np) \
+    if (KS == ks && SWP == swp && NPASS == np) return (void*)mpconv_fwd_res_kernel<T, NET, AGG, ks, swp, np>;
+    RES_CASE(16, 1, 1) RES_CASE(16, 2, 1) RES_CASE(16, 2, 2)
+    RES_CASE(32, 1, 1) RES_CASE(32, 2, 1)
+#undef RES_CASE
+    return nullptr;
+}
+template <typename T, int NET>
+static void* res_pick_agg(int agg, int KS, int SWP, int NPASS) {
+    switch (agg) {
+        case FGNN_AGG_MAX: return res_pick_shape<T, NET, FGNN_AGG_MAX>(KS, SWP, NPASS);
+        case FGNN_AGG_LSE: return res_pick_shape<T, NET, FGNN_AGG_LSE>(KS, SWP, NPASS);
+        default: return res_pick_shape<T, NET, FGNN_AGG_MEAN>(KS, SWP, NPASS);
+    }
+}
+template <typename T>
+static void* res_pick(int net, int agg, int KS, int SWP, int NPASS) {
+    if (net == 1) return res_pick_agg<T, 1>(agg, KS, SWP, NPASS);
+    if (net == 4) return res_pick_agg<T, 4>(agg, KS, SWP, NPASS);
+    return nullptr;
+}
+
+// Returns 1 if launched, 0 if the shape is outside this kernel's family, <0 on error.
+int fgnn_mpconv_forward_resident(const fgnn_mpconv_desc* d, const void* x, const int64_t* nn_idx,
+                                 const void* etype, const float* filters, const float* bias,
+                                 const float* post_scale, const float* post_shift, void* y,
+                                 uint8_t* argmax, fgnn_stream_t stream) {
+    if (d->ext != FGNN_EXT_NONE) return 0;
+    if (d->net != 1 && d->net != 4) return 0;
+    const int ncols = d->nou * d->net;
+    if (ncols % 16 != 0 || ncols > 512) return 0;
+    const int Kpad = fgnn_round_up(d->nin, 64);
+    if (Kpad != 64 && Kpad != 128) return 0;
+    const int Npad = fgnn_round_up(d->N, 16);
+    // dense per-sample x block in one of the two layouts
+    const bool nchw = (d->x_sn == 1 && d->x_sc == d->N) || d->N == 1;
+    const bool cl = d->x_sc == 1 && d->x_sn == d->nin;
+    if (!nchw && !cl) return 0;
+    // N == 1 (one source node, e.g. the LDPC hyper-factor F->V call): both layouts coincide; take
+    // the channel-fastest one so the row-length reciprocal below never has to divide by 1
+    const int cl_in = (d->N == 1) ? 1 : (nchw ? 0 : 1);
+    if (d->nin == 1 && cl_in) return 0;
+    if (d->nin * d->N > RES_THREADS * RES_XPT) return 0;
+    const int mk = d->M * d->k;
+    if (mk * d->net > RES_THREADS * RES_EPT || mk > RES_THREADS) return 0;
+    const int cl_out = (d->y_sc == 1 && (d->M == 1 || d->y_sm != 1)) ? 1 : 0;
+    // etype: dense per sample, edge-type slowest ([net][M][k]) or fastest ([M][k][net])
+    int et_mode;
+    if (d->net == 1) {
+        if (!((d->et_sk == 1 || d->k == 1) && (d->et_sm == d->k || d->M == 1))) return 0;
+        et_mode = 1;
+    } else if (mk == 1) {
+        if (d->et_se != 1) return 0;
+        et_mode = 1;
+    } else if ((d->et_sk == 1 || d->k == 1) && (d->et_sm == d->k || d->M == 1) && d->et_se == mk) {
+        et_mode = 0;
+    } else if (d->et_se == 1 && d->et_sk == d->net && (d->et_sm == d->k * d->net || d->M == 1)) {
+        et_mode = 1;
+    } else {
+        return 0;
+    }
+
+    ResParams p;
+    p.d = *d;
+    p.x = x; p.idx = nn_idx; p.et = etype; p.W = filters; p.bias = bias;
+    p.pscale = post_scale; p.pshift = post_shift; p.y = y; p.argmax = argmax;
+    p.Npad = Npad; p.Kpad = Kpad;
+    const int NPASS = (ncols + RES_PASS_COLS - 1) / RES_PASS_COLS;
+    p.pass_cols = NPASS == 1 ? ncols : RES_PASS_COLS;
+    if (NPASS > 1 && ncols % RES_PASS_COLS != 0) return 0;
+    const int slabs_per_pass = p.pass_cols / 16;
+    const int SWP = (slabs_per_pass + RES_WAVES - 1) / RES_WAVES;
+    const int KS = Kpad / 4;
+    p.cl_in = cl_in; p.cl_out = cl_out; p.et_mode = et_mode;
+    p.xdiv = cl_in ? d->nin : d->N;
+    p.xmagic = (unsigned)((0x100000000ULL + p.xdiv - 1) / p.xdiv);
+    p.mkmagic = (unsigned)((0x100000000ULL + mk - 1) / mk);
+    if (cl_in) { p.xs_sn = (Kpad + 29) / 32 * 32 + 2; p.xs_sk = 1; }            // xs[n][c], row == 2 (mod 32)
+    else { p.xs_sk = (Npad % 32 == 0) ? Npad + 16 : Npad; p.xs_sn = 1; }         // xs[c][n], row == 16 (mod 32)
+    p.PS = p.pass_cols + 4;
+    p.YS = d->M + 1;
+    const int otp = p.pass_cols / d->net;
+    // neighbour-list split for few, high-degree destinations
+    const int items = d->M * (otp < d->nou ? otp : d->nou);
+    p.items_pad = fgnn_round_up(items, 64);
+    p.JP = 1;
+    if (d->k >= 16 && p.items_pad * 2 <= RES_THREADS) {
+        p.JP = RES_THREADS / p.items_pad;
+        if (p.JP > RES_JP_MAX) p.JP = RES_JP_MAX;
+    }
+    int off = 0;
+    p.off_xs = off;  off += cl_in ? Npad * p.xs_sn : Kpad * p.xs_sk;  off = fgnn_round_up(off, 4);
+    p.off_ps = off;  off += Npad * p.PS;                                off = fgnn_round_up(off, 4);
+    p.off_idx = off; off += fgnn_round_up(mk, 4);
+    p.off_et = off;  off += fgnn_round_up(mk * d->net, 4);
+    p.off_ys = off;  off += cl_out ? 0 : fgnn_round_up(otp * p.YS, 4);
+    p.off_ya = off;  off += cl_out ? 0 : fgnn_round_up((otp * p.YS + 3) / 4, 4);
+    p.off_red = off; off += p.JP > 1 ? p.JP * p.items_pad * 2 : 0;
+    const int lds = off * 4;
+    if (lds > 160 * 1024) return 0;
+    void* fn = d->dtype == FGNN_F32 ? res_pick<float>(d->net, d->agg, KS, SWP, NPASS)
+                                    : res_pick<bf16_t>(d->net, d->agg, KS, SWP, NPASS);
+    if (!fn) return 0;
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "hipFuncSetAttribute(%d B LDS): %s", lds, hipGetErrorString(e));
+    }
+    const int wg_per_cu = lds <= 76 * 1024 ? 2 : 1;
+    int grid = 256 * wg_per_cu;
+    if (grid > d->B) grid = d->B;
+    void* args[] = {(void*)&p};
+    hipError_t e = hipLaunchKernel(fn, dim3(grid), dim3(RES_THREADS), args, lds, (hipStream_t)stream);
+    if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "mpconv resident forward launch: %s", hipGetErrorString(e));
+    return 1;
+}

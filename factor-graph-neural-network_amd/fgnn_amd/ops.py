@@ -107,7 +107,7 @@ def mpconv_forward_raw(x, nn_idx, etype, filters, bias, nou, net, ext, agg, *,
     y = _alloc_out(x, nou, M)
     amax = None
     if want_argmax and agg == _hip.AGG_MAX:
-        amax = torch.empty((x.shape[0], nou, M), device=x.device, dtype=torch.uint8)
+        amax = torch.empty_like(y, dtype=torch.uint8)        # same element strides as y
     filters = filters.detach()
     if filters.dtype != torch.float32 or not filters.is_contiguous():
         filters = filters.float().contiguous()

@@ -57,8 +57,8 @@ typedef struct fgnn_mpconv_desc {
  * Replaces mp_conv_v2.forward steps a-k: gather -> matmul(filters) -> bmm(etype)
  * -> aggregate -> +bias -> (eval-mode BatchNorm folded into post_scale/post_shift) -> ReLU.
  *   bias, post_scale, post_shift : float32 [nou] or NULL.
- *   argmax : uint8 [B, nou, M] (contiguous) or NULL; for FGNN_AGG_MAX receives the winning
- *            neighbour slot (first occurrence on ties, as torch.max on CPU).
+ *   argmax : uint8 [B, nou, M] with the SAME element strides as y, or NULL; for FGNN_AGG_MAX it
+ *            receives the winning neighbour slot (first occurrence on ties, as torch.max on CPU).
  */
 int fgnn_mpconv_forward(const fgnn_mpconv_desc* d, const void* x, const int64_t* nn_idx,
                         const void* etype, const float* filters, const float* bias,
