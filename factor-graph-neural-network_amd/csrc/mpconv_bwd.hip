@@ -18,6 +18,7 @@
 //     flush dW tile with one atomicAdd per element per chunk
 // so no gradient tensor the size of the edge set is ever written to HBM.
 #include "fgnn_common.h"
+#include <stdlib.h>
 
 #define BWD_MAXT 8   // 16x16 dW tiles a wave can own within one channel tile
 
@@ -359,6 +360,11 @@ __global__ __launch_bounds__(FGNN_THREADS) void mpconv_bwd_kernel(const BwdParam
 // host side
 // ----------------------------------------------------------------------------------------
 int fgnn_check_desc(const fgnn_mpconv_desc* d);
+int fgnn_mpconv_backward_resident(const fgnn_mpconv_desc* d, const void* x, const int64_t* nn_idx,
+                                  const void* etype, const float* filters, const void* gz,
+                                  const uint8_t* argmax, float* gx, float* getype, float* gfilters,
+                                  float* gbias, void* workspace, int64_t workspace_bytes,
+                                  fgnn_stream_t stream);
 
 static int plan_backward(const fgnn_mpconv_desc* d, BwdParams* p) {
     const int nproj = d->ext == FGNN_EXT_NONE ? 1 : 2;
@@ -424,13 +430,22 @@ static void* pick_net_b(int net, int agg) {
 extern "C" int fgnn_mpconv_backward(const fgnn_mpconv_desc* d, const void* x, const int64_t* nn_idx,
                                     const void* etype, const float* filters, const void* gz,
                                     const void* z, const uint8_t* argmax, float* gx, float* getype,
-                                    float* gfilters, float* gbias, fgnn_stream_t stream) {
+                                    float* gfilters, float* gbias, void* workspace,
+                                    int64_t workspace_bytes, fgnn_stream_t stream) {
     int rc = fgnn_check_desc(d);
     if (rc) return rc;
     if (!x || !nn_idx || !etype || !filters || !gz || !gx || !getype || !gfilters)
         FGNN_FAIL(FGNN_EINVAL, "null tensor pointer");
     if (d->agg == FGNN_AGG_MAX && !argmax) FGNN_FAIL(FGNN_EINVAL, "max aggregator needs the forward's argmax");
     if (d->B == 0) return FGNN_OK;
+    {   // LDPC shape family: W-stationary persistent kernel (mpconv_bwd_res.hip)
+        static const bool force_generic = getenv("FGNN_FORCE_GENERIC") != nullptr;
+        if (!force_generic) {
+            rc = fgnn_mpconv_backward_resident(d, x, nn_idx, etype, filters, gz, argmax, gx, getype,
+                                               gfilters, gbias, workspace, workspace_bytes, stream);
+            if (rc != 0) return rc < 0 ? rc : FGNN_OK;
+        }
+    }
     BwdParams p;
     p.d = *d;
     p.x = x; p.idx = nn_idx; p.et = etype; p.W = filters; p.gz = gz; p.z = z; p.argmax = argmax;

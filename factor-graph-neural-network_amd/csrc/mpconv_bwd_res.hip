@@ -1,0 +1,629 @@
+// mpconv_bwd_res.hip — "resident" backward of the VF/FV message operator for the LDPC shape family
+// (NO_EXTENSION, max aggregator, nin in {64,128}, nou*net in {64,...,512}).
+//
+// Math (reference autograd through /root/reference/lib/model/mpnn/mp_nn.py:115-175), per sample:
+//     P[n,col]   = sum_c x[c,n] W[c,col]                              (recomputed, col = o*net+e)
+//     dE[m,j,o]  = gz[o,m] * [j == argmax[o,m]]
+//     detype[e,m,j] = sum_o dE[m,j,o] * P[idx[m,j], o*net+e]          (one owner thread per edge)
+//     dP[n,col]  = sum_{(m,j): idx[m,j]=n} dE[m,j,o] * etype[e,m,j]   (one owner thread per (n,o): the
+//                  transposed incidence is built in LDS as a sorted CSR, so the "scatter" is a gather:
+//                  no atomics, no zero-fill, bit-reproducible)
+//     dx[c,n]    = sum_col W[c,col] dP[n,col]                         (MFMA; accumulated over the column
+//                                                                       passes in registers, written once)
+//     dW[c,col] += sum_n x[c,n] dP[n,col]                             (MFMA; f32 accumulators live in
+//                                                                       registers across ALL samples of a WG)
+//     dbias[o]  += sum_m gz[o,m]
+//
+// Schedule: persistent 512-thread workgroups (1 per CU) loop over a contiguous chunk of samples; the next
+// sample's x / etype / nn_idx / gz / argmax are prefetched into registers during the current one; columns
+// are processed in passes of 128, P and dP of a pass share ONE [N x 128] f32 LDS buffer (P is dead once
+// detype has been taken).  dW / dbias partials go to a per-workgroup slab of the caller's workspace and
+// are summed by a second tiny kernel (global atomics on 16 K addresses from 256 workgroups cost more
+// than the whole kernel: profiles/r01 notes).  A transposed copy of W in the workspace makes the
+// dx-projection fragments coalesced loads.
+#include "fgnn_common.h"
+#include <stdlib.h>
+
+#define BR_THREADS 512
+#define BR_WAVES 8
+#define BR_EPT 4        // etype prefetch registers per thread  (M*k*net <= 512*4)
+#define BR_APT 3        // argmax prefetch words per thread     (M*nou/4 <= 512*3)
+#define BR_PASS_COLS 128
+#define BR_MAXN 128     // CSR arrays are sized for N <= 128 source nodes
+
+struct BresParams {
+    fgnn_mpconv_desc d;
+    const void* x;
+    const int64_t* idx;
+    const void* et;
+    const float* W;
+    const float* Wt;     // [ncols][nin] transposed copy of W (workspace)
+    const void* gz;
+    const uint8_t* argmax;
+    float* gx;
+    float* get;
+    float* ws;           // per-workgroup partial [grid][nin*ncols + nou]
+    int has_bias;
+    int Npad, Kpad, XS, PS, GS;
+    int cl_in, cl_y, et_mode;
+    unsigned xdiv, xmagic, mkmagic, ymagic, ydiv;
+    int XQ;              // prefetch slots [0,XQ) carry x, the rest gz
+    int dbg;             // FGNN_DBG ablation mask (tuning only)
+    int off_xs, off_pb, off_idx, off_et, off_gz, off_am, off_cs, off_cl, off_ce;
+    int fast_bias;       // dbias straight from the prefetch registers (gz channel-fastest, 512 % nou == 0)
+};
+
+extern __shared__ __attribute__((aligned(16))) float fgnn_lds_br[];
+
+// W [nin][ncols] -> Wt [ncols][nin]
+__global__ __launch_bounds__(256) void bres_transpose_kernel(const float* __restrict__ W, float* __restrict__ Wt,
+                                                             int nin, int ncols) {
+    __shared__ float tile[32][33];
+    const int c0 = blockIdx.y * 32, k0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8)
+        tile[r][tx] = (c0 + r < nin && k0 + tx < ncols) ? W[(int64_t)(c0 + r) * ncols + k0 + tx] : 0.f;
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8)
+        if (k0 + r < ncols && c0 + tx < nin) Wt[(int64_t)(k0 + r) * nin + c0 + tx] = tile[tx][r];
+}
+
+// KS = nin/4 (k-steps of the P projection), NPASS = column passes of 128, AP_RES = keep the P-projection
+// fragments of all passes in registers (else re-read them, coalesced, at the top of each pass)
+template <typename T, int NET, int KS, int NPASS, bool AP_RES>
+__global__ __launch_bounds__(BR_THREADS) void mpconv_bwd_res_kernel(const BresParams p) {
+    constexpr int NCT = KS / 4;                       // channel tiles of dx / dW: 4 (nin 64) or 8 (nin 128)
+    constexpr int PSLAB = BR_PASS_COLS / 16;          // 8 column slabs per pass = one per wave
+    constexpr int PKS = BR_PASS_COLS / 4;             // 32 k-steps of the dx projection per pass
+    constexpr int DXT = (NCT == 4) ? 3 : 6;           // dx tiles per wave (Npad <= 96)
+    constexpr int DWT = NCT * PSLAB / BR_WAVES;       // dW tiles per wave per pass (4 or 8)
+    constexpr int PT = (KS == 32) ? 30 : 18;          // prefetch registers shared by x and gz
+    constexpr int APN = AP_RES ? NPASS : 1;
+    constexpr int net = NET;
+    const fgnn_mpconv_desc& d = p.d;
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int li = lane & 15, lk = lane >> 4;
+    const int nin = d.nin, nou = d.nou, N = d.N, M = d.M, k = d.k;
+    const int ncols = nou * net;
+    const int mk = M * k;
+    const int XS = p.XS, PS = p.PS, GS = p.GS;
+
+    float* xs = fgnn_lds_br + p.off_xs;               // [Npad][XS]  x, node-major
+    float* pb = fgnn_lds_br + p.off_pb;               // [Npad][PS]  P, then dP, of the current pass
+    int* idx_s = reinterpret_cast<int*>(fgnn_lds_br + p.off_idx);
+    float* et_s = fgnn_lds_br + p.off_et;             // [mk][net]
+    float* gz_s = fgnn_lds_br + p.off_gz;             // [M][GS]     gz, channel-fastest
+    uint8_t* am_s = reinterpret_cast<uint8_t*>(fgnn_lds_br + p.off_am);   // [M][GS] argmax
+    int* cs_s = reinterpret_cast<int*>(fgnn_lds_br + p.off_cs);           // CSR: start[N+1], then cnt[N]
+    int* cl_s = reinterpret_cast<int*>(fgnn_lds_br + p.off_cl);           // CSR: in-edge list (packed)
+    int* ce_s = reinterpret_cast<int*>(fgnn_lds_br + p.off_ce);           // CSR: et_s offset of each in-edge
+
+    const T* xg = static_cast<const T*>(p.x);
+    const T* etg = static_cast<const T*>(p.et);
+    const T* gzg = static_cast<const T*>(p.gz);
+
+    // ---- W fragments ----
+    // aP[kk] : A of P^T = W^T x   : W[c = 4kk+lk][col = pass*128 + wave*16 + li]
+    // aT[ks] : A of dx^T = W dP^T : W[c = ct*16+li][col = pass*128 + 4ks + lk] = Wt[col][c], re-read per pass
+    const int ct = wave % NCT;
+    float aP[APN][KS];
+    auto load_aP = [&](int slot, int ps_i) {
+        const int colP = ps_i * BR_PASS_COLS + wave * 16 + li;
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) {
+            const int c = 4 * kk + lk;
+            aP[slot][kk] = colP < ncols ? p.W[(int64_t)c * ncols + colP] : 0.f;
+        }
+    };
+    if constexpr (AP_RES) {
+#pragma unroll
+        for (int ps_i = 0; ps_i < NPASS; ++ps_i) load_aP(ps_i, ps_i);
+    }
+    float aT[PKS];
+
+    // dW accumulators: tile u = wave + 8t of the pass's NCT x 8 tile grid, (ctile, colt) = (u % NCT, u / NCT)
+    f32x4 gw[NPASS][DWT];
+#pragma unroll
+    for (int a = 0; a < NPASS; ++a)
+#pragma unroll
+        for (int t = 0; t < DWT; ++t) gw[a][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float gbacc = 0.f;                                // dbias partial of channel `tid` (tid < nou)
+
+    // ---- prefetch registers ----
+    float pr[PT], er[BR_EPT];
+    unsigned ar[BR_APT];
+    int ir = 0;
+    const int xtot = nin * N, ytot = M * nou;
+    const int xpad = XS - nin;                        // xs is always [n][c]
+    auto prefetch = [&](int b, int t) {
+        const T* xb = xg + (int64_t)b * d.x_sb;
+        const T* gb = gzg + (int64_t)b * d.y_sb;
+#pragma unroll
+        for (int q = 0; q < PT; ++q) {
+            if (q < p.XQ) {
+                const int f = t + q * BR_THREADS;
+                pr[q] = f < xtot ? fgnn_ld(xb + f) : 0.f;
+            } else {
+                const int f = t + (q - p.XQ) * BR_THREADS;
+                pr[q] = f < ytot ? fgnn_ld(gb + f) : 0.f;
+            }
+        }
+        const T* eb = etg + (int64_t)b * d.et_sb;
+#pragma unroll
+        for (int q = 0; q < BR_EPT; ++q) {
+            const int f = t + q * BR_THREADS;
+            er[q] = f < mk * net ? fgnn_ld(eb + f) : 0.f;
+        }
+        const unsigned* ab = reinterpret_cast<const unsigned*>(p.argmax + (int64_t)b * d.y_sb);
+#pragma unroll
+        for (int q = 0; q < BR_APT; ++q) {
+            const int f = t + q * BR_THREADS;
+            ar[q] = f * 4 < ytot ? ab[f] : 0u;
+        }
+        if (t < mk) {
+            const int m = t / k, j = t - m * k;
+            long long v = (p.idx + (int64_t)b * d.idx_sb)[(int64_t)m * d.idx_sm + (int64_t)j * d.idx_sk];
+            v = v < 0 ? 0 : (v >= N ? N - 1 : v);
+            ir = (int)v;
+        }
+    };
+    auto commit = [&](int t) {
+#pragma unroll
+        for (int q = 0; q < PT; ++q) {
+            if (q < p.XQ) {
+                // x: dense element f is (n,c) = (f/nin, f%nin) channel-fastest, or (c,n) = (f/N, f%N)
+                const unsigned f = t + q * BR_THREADS;
+                if ((int)f < xtot) {
+                    const unsigned hi = __umulhi(f, p.xmagic);          // f / xdiv
+                    if (p.cl_in) xs[f + hi * xpad] = pr[q];
+                    else xs[(f - hi * p.xdiv) * XS + hi] = pr[q];
+                }
+            } else {
+                // gz: dense element f is (m,o) = (f/nou, f%nou) channel-fastest, or (o,m) = (f/M, f%M)
+                const unsigned f = t + (q - p.XQ) * BR_THREADS;
+                if ((int)f < ytot) {
+                    const unsigned hi = __umulhi(f, p.ymagic);          // f / ydiv
+                    if (p.cl_y) gz_s[hi * GS + (f - hi * p.ydiv)] = pr[q];
+                    else gz_s[(f - hi * p.ydiv) * GS + hi] = pr[q];
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < BR_EPT; ++q) {
+            const unsigned f = t + q * BR_THREADS;
+            if ((int)f < mk * net) {
+                if (p.et_mode == 1 || net == 1) {
+                    et_s[f] = er[q];
+                } else {
+                    const unsigned e = __umulhi(f, p.mkmagic), r = f - e * mk;
+                    et_s[r * net + e] = er[q];
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < BR_APT; ++q) {
+            const unsigned f0 = (t + q * BR_THREADS) * 4;
+            if ((int)f0 < ytot) {
+                if (p.cl_y) {                                           // 4 consecutive channels of one m
+                    const unsigned hi = __umulhi(f0, p.ymagic);
+                    *reinterpret_cast<unsigned*>(am_s + hi * GS + (f0 - hi * p.ydiv)) = ar[q];
+                } else {
+#pragma unroll
+                    for (int bb = 0; bb < 4; ++bb) {
+                        const unsigned f = f0 + bb, hi = __umulhi(f, p.ymagic);
+                        am_s[(f - hi * p.ydiv) * GS + hi] = (uint8_t)(ar[q] >> (8 * bb));
+                    }
+                }
+            }
+        }
+        if (t < mk) idx_s[t] = ir;
+    };
+    // Transposed incidence as a CSR over source nodes: cs_s[n..n+1) delimits node n's in-edges in cl_s;
+    // an entry packs (gz/argmax row offset m*GS) << 8 | j.  Lists are sorted by edge id so that the
+    // summation order — hence the result — does not depend on thread scheduling.
+    auto build_csr = [&]() {
+        int* cnt = cs_s + BR_MAXN + 1;
+        if (tid <= N) cs_s[tid] = 0;
+        if (tid < N) cnt[tid] = 0;
+        __syncthreads();
+        int pos = 0, n = 0;
+        if (tid < mk) { n = idx_s[tid]; pos = atomicAdd(&cnt[n], 1); }
+        __syncthreads();
+        if (tid == 0) {
+            int run = 0;
+            for (int q = 0; q < N; ++q) { cs_s[q] = run; run += cnt[q]; }
+            cs_s[N] = run;
+        }
+        __syncthreads();
+        if (tid < mk) cl_s[cs_s[n] + pos] = tid;
+        __syncthreads();
+        if (tid < N) {                                 // insertion sort of a short list, then pack
+            const int lo = cs_s[tid], hi = cs_s[tid + 1];
+            for (int a = lo + 1; a < hi; ++a) {
+                const int v = cl_s[a];
+                int c = a - 1;
+                while (c >= lo && cl_s[c] > v) { cl_s[c + 1] = cl_s[c]; --c; }
+                cl_s[c + 1] = v;
+            }
+            for (int a = lo; a < hi; ++a) {
+                const int r = cl_s[a], m = r / k;
+                cl_s[a] = ((m * GS) << 8) | (r - m * k);
+                ce_s[a] = r * net;
+            }
+        }
+        __syncthreads();
+    };
+
+    // zero the padded part of xs once
+    for (int f = tid; f < p.Npad * p.Kpad; f += BR_THREADS) {
+        const int n = f / p.Kpad, c = f - n * p.Kpad;
+        if (n >= N || c >= nin) xs[n * XS + c] = 0.f;
+    }
+
+    const int ntile = p.Npad / 16;
+    const int chunk = (d.B + gridDim.x - 1) / gridDim.x;
+    const int b_begin = blockIdx.x * chunk;
+    const int b_end = min(d.B, b_begin + chunk);
+    if (b_begin < b_end) prefetch(b_begin, tid);
+    const int otp = BR_PASS_COLS / net;               // channels per pass (32 or 128)
+    const bool shared_graph = d.idx_sb == 0;
+
+    for (int b = b_begin; b < b_end; ++b) {
+        __syncthreads();                              // previous sample's MFMAs are done with xs / pb
+        int t = tid;
+        asm volatile("" : "+v"(t));
+        // lane coordinates re-derived from the opaque `t`: keeps the dozens of loop-invariant LDS
+        // offsets below from being hoisted out of the sample loop into (spilled) registers
+        const int li = t & 15, lk = (t >> 4) & 3;
+        if (p.fast_bias) {
+#pragma unroll
+            for (int q = 0; q < PT; ++q)
+                if (q >= p.XQ) gbacc += pr[q];        // out-of-range slots hold 0
+        }
+        commit(t);
+        __syncthreads();
+        if (b + 1 < b_end) prefetch(b + 1, t);
+        if (!shared_graph || b == b_begin) build_csr();
+
+        // dbias: channel-fastest gz with 512 % nou == 0 puts channel (tid % nou) in every gz register of
+        // this thread (summed below, at commit time); otherwise channel tid walks its LDS column
+        if (!p.fast_bias && tid < nou) {
+            float s = 0.f;
+            for (int m = 0; m < M; ++m) s += gz_s[m * GS + tid];
+            gbacc += s;
+        }
+        f32x4 dxacc[DXT];
+#pragma unroll
+        for (int i = 0; i < DXT; ++i) dxacc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        float dacc[NET];                              // detype of edge r = tid (< mk)
+#pragma unroll
+        for (int e = 0; e < NET; ++e) dacc[e] = 0.f;
+
+#pragma unroll
+        for (int pass = 0; pass < NPASS; ++pass) {
+            const int o0 = pass * otp;
+            const int otc = min(otp, nou - o0);
+            if (pass > 0) __syncthreads();            // previous pass's dx/dW MFMAs are done with pb
+            const int APS = AP_RES ? pass : 0;        // folds after full unrolling of the pass loop
+            if constexpr (!AP_RES) load_aP(0, pass);
+            {
+                const float* wt = p.Wt + (int64_t)(pass * BR_PASS_COLS + lk) * nin + ct * 16 + li;
+#pragma unroll
+                for (int ks = 0; ks < PKS; ++ks)
+                    aT[ks] = (pass * BR_PASS_COLS + 4 * ks + lk < ncols) ? wt[(int64_t)ks * 4 * nin] : 0.f;
+            }
+
+            // ---- P^T slab (wave = column slab of the pass) ----
+            for (int tp = 0; tp < (ntile + 1) / 2; ++tp) {
+                const int t0 = tp * 2;
+                const bool two = (t0 + 1) < ntile;
+                f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+                const float* bp0 = xs + (t0 * 16 + li) * XS + lk;
+                const float* bp1 = two ? bp0 + 16 * XS : bp0;
+#pragma unroll
+                for (int kk = 0; kk < KS; ++kk) {
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(aP[APS][kk], bp0[kk * 4], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(aP[APS][kk], bp1[kk * 4], acc1, 0, 0, 0);
+                }
+                float* dst = pb + (t0 * 16 + li) * PS + wave * 16 + 4 * lk;
+                *reinterpret_cast<f32x4*>(dst) = acc0;
+                if (two) *reinterpret_cast<f32x4*>(dst + 16 * PS) = acc1;
+            }
+            __syncthreads();
+
+            // ---- detype owners: edge r = (m, j) sums over this pass's channels ----
+            if (tid < mk) {
+                const int m = tid / k, j = tid - m * k;
+                const float* pn = pb + idx_s[tid] * PS;
+                const float* gm = gz_s + m * GS + o0;
+                const uint8_t* am = am_s + m * GS + o0;
+                for (int ol = 0; ol < otc; ol += 4) {
+                    const unsigned a4 = *reinterpret_cast<const unsigned*>(am + ol);
+                    const f32x4 g4 = *reinterpret_cast<const f32x4*>(gm + ol);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        if ((int)((a4 >> (8 * u)) & 0xff) == j && ol + u < otc) {
+                            const float g = g4[u];
+                            if constexpr (NET == 4) {
+                                const f32x4 p4 = *reinterpret_cast<const f32x4*>(pn + (ol + u) * 4);
+                                dacc[0] = fmaf(g, p4[0], dacc[0]);
+                                dacc[1] = fmaf(g, p4[1], dacc[1]);
+                                dacc[2] = fmaf(g, p4[2], dacc[2]);
+                                dacc[3] = fmaf(g, p4[3], dacc[3]);
+                            } else {
+                                dacc[0] = fmaf(g, pn[ol + u], dacc[0]);
+                            }
+                        }
+                    }
+                }
+            }
+            __syncthreads();                          // P is dead: the buffer becomes dP
+
+            // ---- dP owners: (source node n, channel ol) gathers over n's in-edges ----
+            for (int it = tid; it < p.Npad * otp; it += BR_THREADS) {
+                const int n = it / otp, ol = it - n * otp;
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                if (n < N && ol < otc) {
+                    const int o = o0 + ol;
+                    for (int q = cs_s[n]; q < cs_s[n + 1]; ++q) {
+                        const int ent = cl_s[q];
+                        const int mrow = ent >> 8, j = ent & 0xff;
+                        if (am_s[mrow + o] == j) {
+                            const float g = gz_s[mrow + o];
+                            const float* etp = et_s + ce_s[q];
+                            if constexpr (NET == 4) {
+                                const f32x4 e4 = *reinterpret_cast<const f32x4*>(etp);
+                                acc[0] = fmaf(g, e4[0], acc[0]);
+                                acc[1] = fmaf(g, e4[1], acc[1]);
+                                acc[2] = fmaf(g, e4[2], acc[2]);
+                                acc[3] = fmaf(g, e4[3], acc[3]);
+                            } else {
+                                acc[0] = fmaf(g, etp[0], acc[0]);
+                            }
+                        }
+                    }
+                }
+                if constexpr (NET == 4) *reinterpret_cast<f32x4*>(pb + n * PS + ol * 4) = acc;
+                else pb[n * PS + ol] = acc[0];
+            }
+            __syncthreads();
+
+            // ---- dx^T tiles (ct fixed per wave): += W[ct rows][pass cols] . dP^T ----
+#pragma unroll
+            for (int i = 0; i < DXT; ++i) {
+                const int nt = (NCT == 4) ? (wave / 4 + 2 * i) : i;
+                if (nt < ntile) {
+                    const float* bp = pb + (nt * 16 + li) * PS + lk;
+                    f32x4 acc = dxacc[i];
+#pragma unroll
+                    for (int ks = 0; ks < PKS; ++ks)
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(aT[ks], bp[ks * 4], acc, 0, 0, 0);
+                    dxacc[i] = acc;
+                }
+            }
+            // ---- dW tiles: += x^T . dP over the nodes ----
+            {
+                const int ksteps = p.Npad / 4;
+#pragma unroll
+                for (int tt = 0; tt < DWT; ++tt) {
+                    const int u = wave + BR_WAVES * tt;
+                    const int ctile = u % NCT, colt = u / NCT;
+                    const float* ap = xs + lk * XS + ctile * 16 + li;
+                    const float* bp = pb + lk * PS + colt * 16 + li;
+                    f32x4 acc = gw[pass][tt];
+                    for (int kk = 0; kk < ksteps; ++kk)
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[kk * 4 * XS], bp[kk * 4 * PS], acc, 0, 0, 0);
+                    gw[pass][tt] = acc;
+                }
+            }
+        }   // passes
+
+        // ---- write gx (f32, x's element strides) and getype for this sample ----
+        {
+            float* gxb = p.gx + (int64_t)b * d.x_sb;
+#pragma unroll
+            for (int i = 0; i < DXT; ++i) {
+                const int nt = (NCT == 4) ? (wave / 4 + 2 * i) : i;
+                const int n = nt * 16 + li;
+                if (nt < ntile && n < N) {
+                    const int c0 = ct * 16 + 4 * lk;
+                    if (p.cl_in) {
+                        *reinterpret_cast<f32x4*>(gxb + (int64_t)n * d.x_sn + c0) = dxacc[i];
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            gxb[(int64_t)(c0 + r) * d.x_sc + (int64_t)n * d.x_sn] = dxacc[i][r];
+                    }
+                }
+            }
+            if (tid < mk) {
+                float* gb = p.get + (int64_t)b * net * mk;      // [net][M][k] contiguous
+#pragma unroll
+                for (int e = 0; e < NET; ++e) gb[e * mk + tid] = dacc[e];
+            }
+        }
+    }   // samples
+
+    // ---- flush dW tiles and dbias into this workgroup's slab (summed by bres_reduce_kernel) ----
+    if (b_begin < b_end) {
+        float* slab = p.ws + (int64_t)blockIdx.x * ((int64_t)nin * ncols + nou);
+#pragma unroll
+        for (int pass = 0; pass < NPASS; ++pass) {
+#pragma unroll
+            for (int tt = 0; tt < DWT; ++tt) {
+                const int u = wave + BR_WAVES * tt;
+                const int ctile = u % NCT, colt = u / NCT;
+                const int col = pass * BR_PASS_COLS + colt * 16 + li;
+                if (col < ncols) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        slab[(int64_t)(ctile * 16 + 4 * lk + r) * ncols + col] = gw[pass][tt][r];
+                }
+            }
+        }
+        if (p.fast_bias) {                            // fold the 512/nou partials of each channel
+            __syncthreads();
+            float* red = pb;
+            if (tid < nou) red[tid] = 0.f;
+            __syncthreads();
+            atomicAdd(&red[tid % nou], gbacc);
+            __syncthreads();
+            if (tid < nou) slab[(int64_t)nin * ncols + tid] = red[tid];
+        } else if (tid < nou) {
+            slab[(int64_t)nin * ncols + tid] = gbacc;
+        }
+    }
+}
+
+// Sums the per-workgroup slabs into gW / gbias (accumulating): out[i] += sum_w ws[w][i].
+__global__ __launch_bounds__(256) void bres_reduce_kernel(const float* __restrict__ ws, int nslab, int64_t slab_len,
+                                                          int64_t nw, float* __restrict__ gW,
+                                                          float* __restrict__ gbias) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= slab_len) return;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int w = 0;
+    for (; w + 4 <= nslab; w += 4) {
+        s0 += ws[(int64_t)w * slab_len + i];
+        s1 += ws[(int64_t)(w + 1) * slab_len + i];
+        s2 += ws[(int64_t)(w + 2) * slab_len + i];
+        s3 += ws[(int64_t)(w + 3) * slab_len + i];
+    }
+    for (; w < nslab; ++w) s0 += ws[(int64_t)w * slab_len + i];
+    const float s = (s0 + s1) + (s2 + s3);
+    if (i < nw) gW[i] += s;
+    else if (gbias) gbias[i - nw] += s;
+}
+
+// ----------------------------------------------------------------------------------------
+// host side
+// ----------------------------------------------------------------------------------------
+template <typename T, int NET>
+static void* bres_pick(int KS, int NPASS) {
+#define BR_CASE(ks, np, res) if (KS == ks && NPASS == np) return (void*)mpconv_bwd_res_kernel<T, NET, ks, np, res>;
+    BR_CASE(16, 1, true) BR_CASE(16, 2, true) BR_CASE(16, 4, false)
+    BR_CASE(32, 1, false) BR_CASE(32, 2, false)
+#undef BR_CASE
+    return nullptr;
+}
+
+extern "C" int64_t fgnn_mpconv_backward_workspace_bytes(const fgnn_mpconv_desc* d) {
+    if (!d) return 0;
+    const int64_t R = d->ext == FGNN_EXT_NONE ? d->nin : 2 * d->nin;
+    const int64_t nw = R * d->nou * d->net;
+    return (256 * (nw + d->nou) + nw) * 4;            // 256 slabs + the transposed filter copy
+}
+
+#define BR_REJECT(code) do { if (getenv("FGNN_TRACE")) fprintf(stderr, "[fgnn] resident backward rejects shape: rule %d (line %d)\n", code, __LINE__); return 0; } while (0)
+
+// Returns 1 if launched, 0 if the shape is outside this kernel's family, <0 on error.
+int fgnn_mpconv_backward_resident(const fgnn_mpconv_desc* d, const void* x, const int64_t* nn_idx,
+                                  const void* etype, const float* filters, const void* gz,
+                                  const uint8_t* argmax, float* gx, float* getype, float* gfilters,
+                                  float* gbias, void* workspace, int64_t workspace_bytes,
+                                  fgnn_stream_t stream) {
+    if (d->ext != FGNN_EXT_NONE || d->agg != FGNN_AGG_MAX) BR_REJECT(1);
+    if (d->net != 1 && d->net != 4) BR_REJECT(2);
+    const int ncols = d->nou * d->net;
+    if (ncols % 16 != 0 || ncols > 4 * BR_PASS_COLS) BR_REJECT(3);
+    if (d->nin != 64 && d->nin != 128) BR_REJECT(4);
+    if (!workspace || workspace_bytes < fgnn_mpconv_backward_workspace_bytes(d)) BR_REJECT(5);
+    const int Kpad = d->nin;
+    const int Npad = fgnn_round_up(d->N, 16);
+    if (Npad > 96 || d->N > BR_MAXN) BR_REJECT(6);
+    if (d->nou % 4 != 0 || d->nou > BR_THREADS) BR_REJECT(7);
+    const bool nchw = (d->x_sn == 1 && d->x_sc == d->N);
+    const bool cl = d->x_sc == 1 && (d->x_sn == d->nin || d->N == 1);   // N == 1: the node stride is moot
+    if (!nchw && !cl) BR_REJECT(8);
+    const int cl_in = cl ? 1 : 0;
+    if (!cl_in && d->N == 1) BR_REJECT(9);
+    // gz / argmax: dense per sample, channel-fastest [M][nou] or node-fastest [nou][M]
+    const bool y_cl = d->y_sc == 1 && (d->y_sm == d->nou || d->M == 1);
+    const bool y_nchw = (d->y_sm == 1 || d->M == 1) && d->y_sc == d->M;
+    if (!y_cl && !y_nchw) BR_REJECT(10);
+    const int cl_y = y_cl ? 1 : 0;
+    if (!cl_y && d->M == 1) BR_REJECT(11);
+    const int mk = d->M * d->k;
+    const int NPASS = (ncols + BR_PASS_COLS - 1) / BR_PASS_COLS;
+    const int KS = Kpad / 4;
+    const int PT = KS == 32 ? 30 : 18;
+    const int XQ = (d->nin * d->N + BR_THREADS - 1) / BR_THREADS;
+    const int GQ = (d->M * d->nou + BR_THREADS - 1) / BR_THREADS;
+    if (XQ + GQ > PT) BR_REJECT(12);
+    if (mk * d->net > BR_THREADS * BR_EPT || mk > BR_THREADS) BR_REJECT(13);
+    if (d->M * d->nou > BR_THREADS * BR_APT * 4 || (d->M * d->nou) % 4 != 0) BR_REJECT(14);
+    int et_mode;
+    if (d->net == 1) {
+        if (!((d->et_sk == 1 || d->k == 1) && (d->et_sm == d->k || d->M == 1))) BR_REJECT(15);
+        et_mode = 1;
+    } else if (mk == 1) {
+        if (d->et_se != 1) BR_REJECT(16);
+        et_mode = 1;
+    } else if ((d->et_sk == 1 || d->k == 1) && (d->et_sm == d->k || d->M == 1) && d->et_se == mk) {
+        et_mode = 0;
+    } else if (d->et_se == 1 && d->et_sk == d->net && (d->et_sm == d->k * d->net || d->M == 1)) {
+        et_mode = 1;
+    } else {
+        BR_REJECT(99);
+    }
+
+    BresParams p;
+    p.d = *d;
+    p.x = x; p.idx = nn_idx; p.et = etype; p.W = filters; p.gz = gz; p.argmax = argmax;
+    p.gx = gx; p.get = getype; p.has_bias = gbias != nullptr;
+    p.Npad = Npad; p.Kpad = Kpad;
+    p.XS = (Kpad + 29) / 32 * 32 + 2;
+    p.PS = BR_PASS_COLS + 4;
+    p.GS = fgnn_round_up(d->nou, 4) + 4;
+    if ((int64_t)d->M * p.GS >= (1 << 23)) BR_REJECT(17);
+    p.cl_in = cl_in; p.cl_y = cl_y; p.et_mode = et_mode; p.XQ = XQ;
+    p.fast_bias = (cl_y && BR_THREADS % d->nou == 0) ? 1 : 0;
+    { const char* e = getenv("FGNN_DBG"); p.dbg = e ? atoi(e) : 0; }
+    p.xdiv = cl_in ? d->nin : d->N;
+    p.ydiv = cl_y ? d->nou : d->M;
+    if (p.xdiv == 1 || p.ydiv == 1) BR_REJECT(18);
+    p.xmagic = (unsigned)((0x100000000ULL + p.xdiv - 1) / p.xdiv);
+    p.mkmagic = mk == 1 ? 0u : (unsigned)((0x100000000ULL + mk - 1) / mk);
+    p.ymagic = (unsigned)((0x100000000ULL + p.ydiv - 1) / p.ydiv);
+    int off = 0;
+    p.off_xs = off;  off += Npad * p.XS;                    off = fgnn_round_up(off, 4);
+    p.off_pb = off;  off += Npad * p.PS;                    off = fgnn_round_up(off, 4);
+    p.off_idx = off; off += fgnn_round_up(mk, 4);
+    p.off_et = off;  off += fgnn_round_up(mk * d->net, 4);
+    p.off_gz = off;  off += d->M * p.GS;                    off = fgnn_round_up(off, 4);
+    p.off_am = off;  off += (d->M * p.GS + 3) / 4;          off = fgnn_round_up(off, 4);
+    p.off_cs = off;  off += 2 * BR_MAXN + 4;
+    p.off_cl = off;  off += fgnn_round_up(mk, 4);
+    p.off_ce = off;  off += fgnn_round_up(mk, 4);
+    const int lds = off * 4;
+    if (lds > 160 * 1024) BR_REJECT(19);
+    void* fn = nullptr;
+    if (d->dtype == FGNN_F32) fn = d->net == 1 ? bres_pick<float, 1>(KS, NPASS) : bres_pick<float, 4>(KS, NPASS);
+    else fn = d->net == 1 ? bres_pick<bf16_t, 1>(KS, NPASS) : bres_pick<bf16_t, 4>(KS, NPASS);
+    if (!fn) BR_REJECT(20);
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "hipFuncSetAttribute(%d B LDS): %s", lds, hipGetErrorString(e));
+    }
+    int grid = 256;
+    if (grid > d->B) grid = d->B;
+    const int chunk = (d->B + grid - 1) / grid;
+    grid = (d->B + chunk - 1) / chunk;                // every workgroup owns >= 1 sample (writes its slab)
+    const int64_t nw = (int64_t)d->nin * ncols;
+    const int64_t slab_len = nw + d->nou;
+    p.ws = (float*)workspace;
+    float* Wt = p.ws + 256 * slab_len;
+    p.Wt = Wt;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(bres_transpose_kernel, dim3((ncols + 31) / 32, (d->nin + 31) / 32), dim3(256), 0, st,
+                       filters, Wt, d->nin, ncols);
+    void* args[] = {(void*)&p};
+    hipError_t e = hipLaunchKernel(fn, dim3(grid), dim3(BR_THREADS), args, lds, st);
+    if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "mpconv resident backward launch: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL(bres_reduce_kernel, dim3((unsigned)((slab_len + 255) / 256)), dim3(256), 0, st, p.ws, grid,
+                       slab_len, nw, gfilters, gbias);
+    e = hipGetLastError();
+    if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "mpconv backward helper launch: %s", hipGetErrorString(e));
+    return 1;
+}

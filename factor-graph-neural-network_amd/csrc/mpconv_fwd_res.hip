@@ -15,6 +15,7 @@
 //     high-degree destinations (the degree-96 LDPC hyper-factor: M*nou < threads) splits the
 //     neighbour list over up to 8 waves and combines the partial max / log-sum-exp / sum in LDS.
 #include "fgnn_common.h"
+#include <stdlib.h>
 
 #define RES_THREADS 512
 #define RES_WAVES 8
@@ -41,6 +42,7 @@ struct ResParams {
     unsigned xdiv, xmagic;               // row length of the dense x block (N or nin) and ceil(2^32/xdiv)
     unsigned mkmagic;                    // ceil(2^32/(M*k))
     int et_mode;                         // 0: etype dense [net][M][k], 1: dense [M][k][net]
+    int dbg;                             // FGNN_DBG ablation mask (tuning only): 1 no MFMA, 2 no gather, 4 no prefetch, 8 no store
     int off_xs, off_ps, off_idx, off_et, off_ys, off_ya, off_red;
 };
 
@@ -211,7 +213,7 @@ __global__ __launch_bounds__(RES_THREADS) void mpconv_fwd_res_kernel(const ResPa
         asm volatile("" : "+v"(t));          // opaque per sample: no cross-iteration hoisting
         commit(t);
         __syncthreads();
-        if (b + (int)gridDim.x < d.B) prefetch(b + gridDim.x, t);
+        if (b + (int)gridDim.x < d.B && !(p.dbg & 4)) prefetch(b + gridDim.x, t);
         T* yb = yg + (int64_t)b * d.y_sb;
         uint8_t* ab = p.argmax ? p.argmax + (int64_t)b * d.y_sb : nullptr;
 
@@ -220,7 +222,7 @@ __global__ __launch_bounds__(RES_THREADS) void mpconv_fwd_res_kernel(const ResPa
             const int o0 = pass * p.pass_cols / net;
             const int otc = min(p.pass_cols / net, nou - o0);
             // ---- projection: P^T tile = W^T (cols x nin) . x (nin x nodes), exact-f32 MFMA ----
-            for (int tp = 0; tp < ntp; ++tp) {
+            for (int tp = 0; tp < ((p.dbg & 1) ? 0 : ntp); ++tp) {
                 const int t0 = tp * 2;
                 const bool two = (t0 + 1) < ntile;
                 f32x4 acc[SWP][2];
@@ -251,7 +253,7 @@ __global__ __launch_bounds__(RES_THREADS) void mpconv_fwd_res_kernel(const ResPa
             __syncthreads();
 
             // ---- gather + edge-type contraction + aggregation ----
-            const int items = M * otc;
+            const int items = (p.dbg & 2) ? 0 : M * otc;
             auto finish = [&](int it, float a, float bb) {
                 const int m = it / otc, ol = it - m * otc;
                 float res;
@@ -263,7 +265,8 @@ __global__ __launch_bounds__(RES_THREADS) void mpconv_fwd_res_kernel(const ResPa
                 if (p.bias) res += p.bias[o];
                 if (p.pscale) res = res * p.pscale[o] + p.pshift[o];
                 if (d.relu) res = fmaxf(res, 0.f);
-                if (p.cl_out) {              // channel-fastest output: lanes walk o, coalesced
+                if (p.dbg & 8) { if (res == 1.2345e-30f) ys[0] = res; }
+                else if (p.cl_out) {         // channel-fastest output: lanes walk o, coalesced
                     fgnn_st(yb + (int64_t)o * d.y_sc + (int64_t)m * d.y_sm, res);
                     if (AGG == FGNN_AGG_MAX && ab) ab[(int64_t)o * d.y_sc + (int64_t)m * d.y_sm] = (uint8_t)arg;
                 } else {
@@ -405,6 +408,7 @@ int fgnn_mpconv_forward_resident(const fgnn_mpconv_desc* d, const void* x, const
     const int SWP = (slabs_per_pass + RES_WAVES - 1) / RES_WAVES;
     const int KS = Kpad / 4;
     p.cl_in = cl_in; p.cl_out = cl_out; p.et_mode = et_mode;
+    { const char* e = getenv("FGNN_DBG"); p.dbg = e ? atoi(e) : 0; }
     p.xdiv = cl_in ? d->nin : d->N;
     p.xmagic = (unsigned)((0x100000000ULL + p.xdiv - 1) / p.xdiv);
     p.mkmagic = (unsigned)((0x100000000ULL + mk - 1) / mk);

@@ -20,6 +20,7 @@ F32, BF16 = 0, 1
 AGG_CODES = {'max': AGG_MAX, 'softmax': AGG_LSE, 'mean': AGG_MEAN}
 
 EXPORTS = ('fgnn_mpconv_forward', 'fgnn_mpconv_backward', 'fgnn_mpconv_forward_lds_bytes',
+           'fgnn_mpconv_backward_workspace_bytes',
            'fgnn_mpconv_algorithmic_bytes', 'fgnn_last_error', 'fgnn_abi_version')
 
 
@@ -53,7 +54,9 @@ def lib():
     L.fgnn_mpconv_forward.restype = ctypes.c_int
     L.fgnn_mpconv_forward.argtypes = [dp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.fgnn_mpconv_backward.restype = ctypes.c_int
-    L.fgnn_mpconv_backward.argtypes = [dp] + [vp] * 12
+    L.fgnn_mpconv_backward.argtypes = [dp] + [vp] * 12 + [ctypes.c_int64, vp]
+    L.fgnn_mpconv_backward_workspace_bytes.restype = ctypes.c_int64
+    L.fgnn_mpconv_backward_workspace_bytes.argtypes = [dp]
     L.fgnn_mpconv_forward_lds_bytes.restype = ctypes.c_int64
     L.fgnn_mpconv_forward_lds_bytes.argtypes = [dp]
     L.fgnn_mpconv_algorithmic_bytes.restype = ctypes.c_int64

@@ -122,6 +122,19 @@ def mpconv_forward_raw(x, nn_idx, etype, filters, bias, nou, net, ext, agg, *,
     return y, amax
 
 
+_WS = {}
+
+
+def _workspace(device, nbytes):
+    """One grow-only scratch buffer per device for the backward's per-workgroup gradient slabs
+    (reused by every call on the stream; contents are undefined between calls)."""
+    buf = _WS.get(device)
+    if buf is None or buf.numel() * 4 < nbytes:
+        buf = torch.empty((nbytes + 3) // 4, device=device, dtype=torch.float32)
+        _WS[device] = buf
+    return buf
+
+
 class _MPConv(torch.autograd.Function):
     """z = agg(messages) + bias with the hand-written HIP forward and backward."""
 
@@ -153,6 +166,7 @@ class _MPConv(torch.autograd.Function):
         gb = torch.zeros((nou,), device=x.device, dtype=torch.float32) if ctx.has_bias else None
         w = filters.detach().float().contiguous()
         d = _hip.make_desc(xx, nn_idx, etype, nou, net, ext, agg, False, gz)
+        ws = _workspace(x.device, int(L.fgnn_mpconv_backward_workspace_bytes(ctypes.byref(d))))
         nbytes = 0
         if TIMER is not None:
             # algorithmic bytes of the backward: x, etype, nn_idx, gz, argmax read once;
@@ -167,7 +181,7 @@ class _MPConv(torch.autograd.Function):
         _launch('bwd', d, nbytes, lambda: _hip.check(L.fgnn_mpconv_backward(
             ctypes.byref(d), _hip._ptr(xx), _hip._ptr(nn_idx), _hip._ptr(etype), _hip._ptr(w),
             _hip._ptr(gz), None, _hip._ptr(amax), _hip._ptr(gx), _hip._ptr(get),
-            _hip._ptr(gw), _hip._ptr(gb), _hip.stream_ptr())))
+            _hip._ptr(gw), _hip._ptr(gb), _hip._ptr(ws), ws.numel() * 4, _hip.stream_ptr())))
         if get.dtype != etype.dtype:
             get = get.to(etype.dtype)
         if gx.dtype != x.dtype:

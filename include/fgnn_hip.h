@@ -75,11 +75,17 @@ int fgnn_mpconv_forward(const fgnn_mpconv_desc* d, const void* x, const int64_t*
  *   getype  [B, net, M, k] contiguous, fully written; float32
  *   gfilters[R, nou*net] float32, ACCUMULATED into (caller zero-fills)
  *   gbias   [nou] float32 or NULL, ACCUMULATED into
+ *   workspace / workspace_bytes : optional scratch of fgnn_mpconv_backward_workspace_bytes(d) bytes
+ *            (device memory, contents undefined); with it the filter/bias gradients are reduced
+ *            through per-workgroup slabs instead of contended global atomics.  NULL is allowed.
  */
 int fgnn_mpconv_backward(const fgnn_mpconv_desc* d, const void* x, const int64_t* nn_idx,
                          const void* etype, const float* filters, const void* gz,
                          const void* z, const uint8_t* argmax, float* gx, float* getype,
-                         float* gfilters, float* gbias, fgnn_stream_t stream);
+                         float* gfilters, float* gbias, void* workspace, int64_t workspace_bytes,
+                         fgnn_stream_t stream);
+
+int64_t fgnn_mpconv_backward_workspace_bytes(const fgnn_mpconv_desc* d);
 
 /* Bytes of dynamic LDS the forward will request for this descriptor (diagnostics / tests). */
 int64_t fgnn_mpconv_forward_lds_bytes(const fgnn_mpconv_desc* d);

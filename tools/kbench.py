@@ -1,0 +1,116 @@
+#!/usr/bin/env python3
+"""Per-shape micro-benchmark of the fused message operator (forward and backward) on one GPU.
+Prints, for each LDPC operator shape at batch B: us per launch, algorithmic GB/s (SURVEY §8d bytes)
+and f32 TFLOP/s of the projection.  Used to tune kernels; bench.py remains the contract benchmark."""
+import argparse
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 'factor-graph-neural-network_amd'))
+import torch  # noqa: E402
+from fgnn_amd import _hip, ops  # noqa: E402
+
+SHAPES = [  # (name, nin, nou, net, N, M, k)
+    ('parity V->F 64->64', 64, 64, 4, 96, 48, 6),
+    ('parity F->V 64->64', 64, 64, 4, 48, 96, 3),
+    ('parity V->F 64->128', 64, 128, 4, 96, 48, 6),
+    ('parity F->V 64->128', 64, 128, 4, 48, 96, 3),
+    ('parity V->F 128->64', 128, 64, 4, 96, 48, 6),
+    ('parity F->V 128->64', 128, 64, 4, 48, 96, 3),
+    ('hyper  V->F 64->64', 64, 64, 1, 96, 1, 96),
+    ('hyper  F->V 64->64', 64, 64, 1, 1, 96, 1),
+]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--batch', type=int, default=4096)
+    ap.add_argument('--iters', type=int, default=20)
+    ap.add_argument('--dtype', default='f32')
+    ap.add_argument('--layout', default='cl', choices=['cl', 'nchw'])
+    ap.add_argument('--bwd', action='store_true')
+    ap.add_argument('--only', default='')
+    a = ap.parse_args()
+    dev = torch.device('cuda:0')
+    dt = torch.float32 if a.dtype == 'f32' else torch.bfloat16
+    for name, nin, nou, net, N, M, k in SHAPES:
+        if a.only and a.only not in name:
+            continue
+        g = torch.Generator(device='cpu').manual_seed(0)
+        B = a.batch
+        x = torch.randn(B, nin, N, 1, generator=g).to(dev, dt)
+        if a.layout == 'cl':
+            x = x.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+        idx = torch.randint(0, N, (1, M, k), generator=g).to(dev).expand(B, -1, -1)
+        if net == 1:
+            et = torch.ones(1, 1, M, k, device=dev, dtype=dt).expand(B, -1, -1, -1)
+        else:
+            et = torch.randn(B, M, k, net, generator=g).to(dev, dt).permute(0, 3, 1, 2)
+        W = (torch.randn(nin, nou * net, generator=g) * 0.1).to(dev)
+        bias = torch.randn(nou, generator=g).to(dev)
+        nbytes = ops.algorithmic_bytes(x, idx, et, nou, net, 0, 0)
+        flops = 2.0 * B * N * nin * nou * net + 2.0 * B * M * k * nou * net
+
+        def fwd():
+            return ops.mpconv_forward_raw(x, idx, et, W, bias, nou, net, 0, _hip.AGG_MAX, want_argmax=a.bwd)
+
+        if not a.bwd:
+            run = fwd
+        else:
+            import ctypes
+            L = _hip.lib()
+            y, amax = ops.mpconv_forward_raw(x, idx, et, W, bias, nou, net, 0, _hip.AGG_MAX, want_argmax=True)
+            gz = torch.randn_like(y)
+            gx = torch.empty_like(x, dtype=torch.float32)
+            get = torch.empty((B, net, M, k), device=dev, dtype=torch.float32)
+            gw = torch.zeros_like(W)
+            gb = torch.zeros(nou, device=dev)
+            dsc = _hip.make_desc(x, idx, et, nou, net, 0, _hip.AGG_MAX, False, gz)
+            nbytes = (x.element_size() * (x.numel() + gz.numel()) + et.element_size() * net * M * k *
+                      (1 if et.stride(0) == 0 else B) + 8 * M * k + B * nou * M + 4 * (gx.numel() + get.numel())
+                      + 8 * W.numel())
+            flops *= 3.0
+            wsb = ops._workspace(dev, int(L.fgnn_mpconv_backward_workspace_bytes(ctypes.byref(dsc))))
+
+            def run():
+                _hip.check(L.fgnn_mpconv_backward(
+                    ctypes.byref(dsc), _hip._ptr(x), _hip._ptr(idx), _hip._ptr(et), _hip._ptr(W),
+                    _hip._ptr(gz), None, _hip._ptr(amax), _hip._ptr(gx), _hip._ptr(get), _hip._ptr(gw),
+                    _hip._ptr(gb), _hip._ptr(wsb), wsb.numel() * 4, _hip.stream_ptr()))
+        for _ in range(3):
+            run()
+        torch.cuda.synchronize()
+        # host-side cost of one call (Python + ctypes), GPU idle work excluded
+        import time
+        t0 = time.perf_counter()
+        for _ in range(a.iters):
+            run()
+        host_us = (time.perf_counter() - t0) / a.iters * 1e6
+        torch.cuda.synchronize()
+        # device time: replay a captured graph of `iters` back-to-back launches (no host gaps)
+        graph = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            run()
+            with torch.cuda.graph(graph, stream=side):
+                for _ in range(a.iters):
+                    run()
+        torch.cuda.current_stream().wait_stream(side)
+        graph.replay()
+        torch.cuda.synchronize()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        graph.replay()
+        e.record()
+        torch.cuda.synchronize()
+        us = s.elapsed_time(e) / a.iters * 1e3
+        print('%-22s %s %-4s %s  %8.1f us (host %6.1f us/call)  %7.1f GB/s (%.1f%% of 8 TB/s)  %6.1f TFLOP/s  '
+              '[%d B, %.2f MB/call]'
+              % (name, a.dtype, a.layout, 'bwd' if a.bwd else 'fwd', us, host_us, nbytes / us / 1e3,
+                 nbytes / us / 1e3 / 80.0, flops / us / 1e6, B, nbytes / 1e6))
+
+
+if __name__ == '__main__':
+    main()
