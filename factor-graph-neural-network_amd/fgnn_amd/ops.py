@@ -23,21 +23,22 @@ class KernelTimer:
     def __init__(self):
         self.records = []
 
-    def run(self, symbol, nbytes, launch):
+    def run(self, symbol, nbytes, nflops, launch):
         start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         start.record()
         launch()
         end.record()
-        self.records.append((symbol, nbytes, start, end))
+        self.records.append((symbol, nbytes, nflops, start, end))
 
     def summary(self):
         torch.cuda.synchronize()
         out = {}
-        for symbol, nbytes, start, end in self.records:
-            r = out.setdefault(symbol, {'launches': 0, 'ms': 0.0, 'bytes': 0})
+        for symbol, nbytes, nflops, start, end in self.records:
+            r = out.setdefault(symbol, {'launches': 0, 'ms': 0.0, 'bytes': 0, 'flops': 0})
             r['launches'] += 1
             r['ms'] += start.elapsed_time(end)
             r['bytes'] += nbytes
+            r['flops'] += nflops
         return out
 
 
@@ -52,11 +53,17 @@ def _symbol(kind, d):
                                              _AGG_NAME[d.agg])
 
 
+def _flops(d, passes):
+    """SURVEY §8d algorithmic FLOPs: node-level projection(s) + per-edge type contraction."""
+    R = d.nin if d.ext == _hip.EXT_NONE else 2 * d.nin
+    return passes * (2 * d.B * d.N * R * d.nou * d.net + 2 * d.B * d.M * d.k * d.nou * d.net)
+
+
 def _launch(kind, d, nbytes, fn):
     if TIMER is None:
         fn()
     else:
-        TIMER.run(_symbol(kind, d), nbytes, fn)
+        TIMER.run(_symbol(kind, d), nbytes, _flops(d, 3 if kind == 'bwd' else 1), fn)
 
 
 def _require_device(*tensors):
