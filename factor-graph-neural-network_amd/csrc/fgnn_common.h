@@ -22,11 +22,9 @@ __device__ __forceinline__ float fgnn_ld(const bf16_t* p) {
 }
 __device__ __forceinline__ void fgnn_st(float* p, float v) { *p = v; }
 __device__ __forceinline__ void fgnn_st(bf16_t* p, float v) {
-    // round-to-nearest-even, NaN preserved
-    uint32_t u = __float_as_uint(v);
-    if ((u & 0x7fffffffu) > 0x7f800000u) { p->v = (uint16_t)((u >> 16) | 0x40); return; }
-    u += 0x7fffu + ((u >> 16) & 1u);
-    p->v = (uint16_t)(u >> 16);
+    // native fptrunc: v_cvt_pk_bf16_f32 on gfx950 (round-to-nearest-even, NaN preserved)
+    const __bf16 h = (__bf16)v;
+    p->v = __builtin_bit_cast(uint16_t, h);
 }
 
 // ---- host-side error plumbing ---------------------------------------------------------

@@ -1,0 +1,428 @@
+// mpconv_fwd_b16.hip — bf16 forward of the VF/FV message operator for the LDPC shape family: bf16
+// storage AND bf16 matrix cores (v_mfma_f32_16x16x32_bf16, f32 accumulate) — the HBM-bound regime of
+// BASELINE config 3 (AI ~80 FLOP/B << bf16 ridge ~312), where the goal is bytes/s, not FLOP/s.
+//
+// Same math as mpconv_fwd.hip (reference: /root/reference/lib/model/mpnn/mp_nn.py:115-134); rounding
+// points: x, etype, filters and the projected rows P are bf16 (P is rounded once before the gather),
+// every sum is f32, the output is rounded to bf16 once.
+//
+//   * 512-thread workgroups (8 waves), 2 per CU (<= 80 KB LDS, <= 128 VGPRs: 4 waves per SIMD hide the
+//     LDS latency of the gather), persistent over samples;
+//   * filters live in registers as bf16 A-fragments for the kernel's lifetime (W-stationary);
+//   * x is channel-fastest in HBM, so a sample is one dense block moved with 16-byte loads into a
+//     padded LDS image whose rows are MFMA B-fragments (ds_read_b128, conflict-free);
+//   * P[N, 256] sits in LDS as bf16 (half the LDS traffic of the f32 kernel); the gather reads 8 bytes
+//     per (edge, channel), lanes = channels, destinations walk across the 4 waves;
+//   * next sample's x / etype / nn_idx are prefetched into registers during the current sample.
+#include "fgnn_common.h"
+#include <stdlib.h>
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+
+#define B16_THREADS 512
+#define B16_WAVES 8
+#define B16_XPT 3       // 16-byte x chunks per thread     (nin*N/8   <= 512*3)
+#define B16_EPT 3       // etype scalars per thread        (M*k*net   <= 512*3)
+#define B16_IPT 1       // nn_idx entries per thread       (M*k       <= 512)
+#define B16_PASS_COLS 256
+
+struct B16Params {
+    fgnn_mpconv_desc d;
+    const void* x;
+    const int64_t* idx;
+    const void* et;
+    const float* W;
+    const float* bias;
+    const float* pscale;
+    const float* pshift;
+    void* y;
+    uint8_t* argmax;
+    int Npad, pass_cols;
+    int XSB, PSB;                         // LDS row strides in BYTES (x image, P image)
+    int c8shift;                          // log2(nin/8)
+    int et_mode;
+    unsigned mkmagic;
+    int dbg;                              // FGNN_DBG ablation mask (tuning only)
+    int off_xs, off_ps, off_idx, off_et;  // byte offsets into LDS
+};
+
+extern __shared__ __attribute__((aligned(16))) unsigned char fgnn_lds_h[];
+
+__device__ __forceinline__ float bf16_lo(unsigned u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bf16_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {
+    // native fptrunc -> one v_cvt_pk_bf16_f32 (round-to-nearest-even).  NOT inline asm: an asm
+    // statement reading MFMA results directly gets none of the compiler's MFMA->VALU wait states
+    // (observed: one node tile of stale P values once the accumulators stopped living in AGPRs).
+    bf16x2_t r;
+    r[0] = (__bf16)a;
+    r[1] = (__bf16)b;
+    return __builtin_bit_cast(unsigned, r);
+}
+
+// message value of one (edge, channel): sum_e etype[e] * P[n][o*net+e], P in bf16
+template <int NET>
+__device__ __forceinline__ float b16_dot(const float* __restrict__ etp, const unsigned char* __restrict__ prow) {
+    if constexpr (NET == 1) {
+        const unsigned short u = *reinterpret_cast<const unsigned short*>(prow);
+        return etp[0] * __uint_as_float(((unsigned)u) << 16);
+    } else {
+        const uint2 pk = *reinterpret_cast<const uint2*>(prow);
+        const f32x4 e4 = *reinterpret_cast<const f32x4*>(etp);
+        float v = e4[0] * bf16_lo(pk.x);
+        v = fmaf(e4[1], bf16_hi(pk.x), v);
+        v = fmaf(e4[2], bf16_lo(pk.y), v);
+        v = fmaf(e4[3], bf16_hi(pk.y), v);
+        return v;
+    }
+}
+
+// KSB = nin/32 MFMA k-steps, SWP = column slabs per wave per pass, NPASS = column passes of <= 256,
+// KC = neighbours per destination when known at compile time (3 / 6: the LDPC degrees), 0 = runtime k
+template <int NET, int AGG, int KSB, int SWP, int NPASS, int KC>
+__global__ __launch_bounds__(B16_THREADS) void mpconv_fwd_b16_kernel(const B16Params p) {
+    const fgnn_mpconv_desc& d = p.d;
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: scalar index math
+    const int lane = tid & 63;
+    const int li = lane & 15, lk = lane >> 4;
+    const int nin = d.nin, nou = d.nou, N = d.N, M = d.M;
+    const int k = KC > 0 ? KC : d.k;
+    constexpr int net = NET;
+    const int ncols = nou * net;
+    const int mk = M * k;
+    const int XSB = p.XSB, PSB = p.PSB;
+
+    unsigned char* xs = fgnn_lds_h + p.off_xs;        // [Npad][XSB]  bf16 x, node-major
+    unsigned char* ps = fgnn_lds_h + p.off_ps;        // [Npad][PSB]  bf16 P of the current pass
+    int* idx_s = reinterpret_cast<int*>(fgnn_lds_h + p.off_idx);
+    unsigned short* et_h = reinterpret_cast<unsigned short*>(fgnn_lds_h + p.off_et);   // [mk][net] bf16
+
+    const unsigned short* xg = static_cast<const unsigned short*>(p.x);
+    const unsigned short* etg = static_cast<const unsigned short*>(p.et);
+    unsigned short* yg = static_cast<unsigned short*>(p.y);
+
+    // ---- filters -> bf16 A fragments: areg[pass][q][kk] = W[c = 32kk + 8lk + 0..7][col] ----
+    const int slabs_per_pass = p.pass_cols / 16;
+    bf16x8_t areg[NPASS][SWP][KSB];
+#pragma unroll
+    for (int ps_i = 0; ps_i < NPASS; ++ps_i)
+#pragma unroll
+        for (int q = 0; q < SWP; ++q) {
+            const int slab = wave + B16_WAVES * q;
+            const int col = ps_i * p.pass_cols + slab * 16 + li;
+            const bool ok = slab < slabs_per_pass && col < ncols;
+#pragma unroll
+            for (int kk = 0; kk < KSB; ++kk) {
+                unsigned w[4];
+#pragma unroll
+                for (int h = 0; h < 4; ++h) {
+                    const int c = 32 * kk + 8 * lk + 2 * h;
+                    const float f0 = (ok && c < nin) ? p.W[(int64_t)c * ncols + col] : 0.f;
+                    const float f1 = (ok && c + 1 < nin) ? p.W[(int64_t)(c + 1) * ncols + col] : 0.f;
+                    w[h] = pack_bf16(f0, f1);
+                }
+                areg[ps_i][q][kk] = __builtin_bit_cast(bf16x8_t, make_uint4(w[0], w[1], w[2], w[3]));
+            }
+        }
+
+    // ---- prefetch registers ----
+    uint4 xr[B16_XPT];
+    unsigned short er[B16_EPT];
+    int ir[B16_IPT];
+    const int xchunks = (nin * N) >> 3;               // 16-byte chunks of the dense sample block
+    auto prefetch = [&](int b, int t) {
+        const uint4* xb = reinterpret_cast<const uint4*>(xg + (int64_t)b * d.x_sb);
+#pragma unroll
+        for (int q = 0; q < B16_XPT; ++q) {
+            const int f = t + q * B16_THREADS;
+            xr[q] = f < xchunks ? xb[f] : make_uint4(0, 0, 0, 0);
+        }
+        const unsigned short* eb = etg + (int64_t)b * d.et_sb;
+#pragma unroll
+        for (int q = 0; q < B16_EPT; ++q) {
+            const int f = t + q * B16_THREADS;
+            er[q] = f < mk * net ? eb[f] : (unsigned short)0;
+        }
+#pragma unroll
+        for (int q = 0; q < B16_IPT; ++q) {
+            const int f = t + q * B16_THREADS;
+            int v = 0;
+            if (f < mk) {
+                const int m = f / k, j = f - m * k;
+                long long w = (p.idx + (int64_t)b * d.idx_sb)[(int64_t)m * d.idx_sm + (int64_t)j * d.idx_sk];
+                w = w < 0 ? 0 : (w >= N ? N - 1 : w);
+                v = (int)w;
+            }
+            ir[q] = v;
+        }
+    };
+    auto commit = [&](int t) {
+#pragma unroll
+        for (int q = 0; q < B16_XPT; ++q) {
+            const int f = t + q * B16_THREADS;      // chunk f = (n, c8) = (f >> c8shift, f & mask)
+            if (f < xchunks) {
+                const int n = f >> p.c8shift, c8 = f - (n << p.c8shift);
+                *reinterpret_cast<uint4*>(xs + n * XSB + c8 * 16) = xr[q];
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < B16_EPT; ++q) {
+            const unsigned f = t + q * B16_THREADS;
+            if ((int)f < mk * net) {
+                if (p.et_mode == 1 || net == 1) {
+                    et_h[f] = er[q];
+                } else {
+                    const unsigned e = __umulhi(f, p.mkmagic), r = f - e * mk;
+                    et_h[r * net + e] = er[q];
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < B16_IPT; ++q) {
+            const int f = t + q * B16_THREADS;
+            if (f < mk) idx_s[f] = ir[q];
+        }
+    };
+
+    // zero the padded rows of the x image once (n >= N)
+    for (int f = tid; f < (p.Npad - N) * (XSB / 4); f += B16_THREADS)
+        reinterpret_cast<unsigned*>(xs + N * XSB)[f] = 0u;
+
+    int b = blockIdx.x;
+    if (b < d.B) prefetch(b, tid);
+    const int ntile = p.Npad / 16;
+
+    for (; b < d.B; b += gridDim.x) {
+        int t = tid;
+        asm volatile("" : "+v"(t));          // opaque per sample: no cross-iteration hoisting
+        commit(t);
+        __syncthreads();
+        if (b + (int)gridDim.x < d.B && !(p.dbg & 4)) prefetch(b + gridDim.x, t);
+        unsigned short* yb = yg + (int64_t)b * d.y_sb;
+        uint8_t* ab = p.argmax ? p.argmax + (int64_t)b * d.y_sb : nullptr;
+
+#pragma unroll
+        for (int pass = 0; pass < NPASS; ++pass) {
+            const int o0 = pass * p.pass_cols / net;
+            const int otc = min(p.pass_cols / net, nou - o0);
+            // ---- projection: P^T tile = W^T (cols x nin) . x (nin x nodes), bf16 MFMA, f32 accumulate ----
+            for (int tile = 0; tile < ((p.dbg & 1) ? 0 : ntile); ++tile) {
+                f32x4 acc[SWP];
+#pragma unroll
+                for (int q = 0; q < SWP; ++q) acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                const unsigned char* bp = xs + (tile * 16 + li) * XSB + lk * 16;
+#pragma unroll
+                for (int kk = 0; kk < KSB; ++kk) {
+                    const bf16x8_t bfrag = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(bp + kk * 64));
+#pragma unroll
+                    for (int q = 0; q < SWP; ++q)
+                        acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(areg[pass][q][kk], bfrag, acc[q], 0, 0, 0);
+                }
+#pragma unroll
+                for (int q = 0; q < SWP; ++q) {
+                    const int slab = wave + B16_WAVES * q;
+                    if (slab < slabs_per_pass) {
+                        uint2 pk;
+                        pk.x = pack_bf16(acc[q][0], acc[q][1]);
+                        pk.y = pack_bf16(acc[q][2], acc[q][3]);
+                        *reinterpret_cast<uint2*>(ps + (tile * 16 + li) * PSB + (slab * 16 + 4 * lk) * 2) = pk;
+                    }
+                }
+            }
+            __syncthreads();
+
+            // ---- gather + edge-type contraction + aggregation ----
+            // One wave per (destination m, block of 64 channels), lane = channel.  The k neighbour ids and
+            // the k*net edge-type weights of m are wave-uniform: ONE LDS read each per wave (lane j holds
+            // entry j) and v_readlane broadcasts to scalar registers, so the only per-edge LDS traffic
+            // is the 8-byte P row slice per lane; the contraction is two v_dot2c_f32_bf16 per edge with
+            // the weights as scalar operands.
+            {
+                const int nch = (otc + 63) >> 6;
+                const unsigned* et_w = reinterpret_cast<const unsigned*>(et_h);
+                int cc_cached = -1;
+                float c_bias = 0.f, c_scale = 1.f, c_shift = 0.f;
+                for (int u = wave; u < ((p.dbg & 2) ? 0 : M * nch); u += B16_WAVES) {
+                    const int m = u / nch, cc = u - m * nch;
+                    const int ch = cc * 64 + lane;
+                    const bool active = ch < otc;
+                    const unsigned char* pc = ps + (active ? ch : 0) * (net * 2);
+                    const int idxv = lane < k ? idx_s[m * k + lane] : 0;
+                    unsigned etv;
+                    if constexpr (NET == 4) etv = lane < 2 * k ? et_w[m * k * 2 + lane] : 0u;
+                    else etv = lane < k ? (unsigned)et_h[m * k + lane] << 16 : 0u;
+                    float best = 0.f, mx = -INFINITY, ssum = 0.f;
+                    int arg = 0;
+                    auto load_p = [&](int j, uint2& pk) {
+                        const int n = __builtin_amdgcn_readlane(idxv, j);
+                        if constexpr (NET == 4) pk = *reinterpret_cast<const uint2*>(pc + n * PSB);
+                        else pk.x = *reinterpret_cast<const unsigned short*>(pc + n * PSB);
+                    };
+                    auto consume = [&](int j, const uint2& pk) {
+                        float v;
+                        if constexpr (NET == 4) {
+                            const unsigned e01 = __builtin_amdgcn_readlane(etv, 2 * j);
+                            const unsigned e23 = __builtin_amdgcn_readlane(etv, 2 * j + 1);
+                            v = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, pk.x),
+                                                                __builtin_bit_cast(bf16x2_t, e01), 0.f, false);
+                            v = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, pk.y),
+                                                                __builtin_bit_cast(bf16x2_t, e23), v, false);
+                        } else {
+                            const float e = __uint_as_float(__builtin_amdgcn_readlane(etv, j));
+                            v = e * __uint_as_float(pk.x << 16);
+                        }
+                        if constexpr (AGG == FGNN_AGG_MAX) {
+                            if (j == 0 || v > best) { best = v; arg = j; }   // strict >: first occurrence wins
+                        } else if constexpr (AGG == FGNN_AGG_LSE) {
+                            v *= 3.0f;
+                            if (v > mx) { ssum = ssum * expf(mx - v) + 1.0f; mx = v; }
+                            else ssum += expf(v - mx);
+                        } else {
+                            ssum += v;
+                        }
+                    };
+                    if constexpr (KC > 0) {                    // all KC row slices in flight, then reduce
+                        uint2 pk[KC];
+#pragma unroll
+                        for (int j = 0; j < KC; ++j) load_p(j, pk[j]);
+#pragma unroll
+                        for (int j = 0; j < KC; ++j) consume(j, pk[j]);
+                    } else {
+                        int j = 0;
+                        for (; j + 3 <= k; j += 3) {
+                            uint2 p0, p1, p2;
+                            load_p(j, p0); load_p(j + 1, p1); load_p(j + 2, p2);
+                            consume(j, p0); consume(j + 1, p1); consume(j + 2, p2);
+                        }
+                        for (; j < k; ++j) {
+                            uint2 p0;
+                            load_p(j, p0);
+                            consume(j, p0);
+                        }
+                    }
+                    float res;
+                    if constexpr (AGG == FGNN_AGG_MAX) res = best;
+                    else if constexpr (AGG == FGNN_AGG_LSE) res = (1.0f / 3.0f) * (mx + logf(ssum));
+                    else res = ssum / (float)k;
+                    if (active) {
+                        if (cc != cc_cached) {        // per-lane channel constants: reload only when the block changes
+                            cc_cached = cc;
+                            const int o = o0 + ch;
+                            c_bias = p.bias ? p.bias[o] : 0.f;
+                            c_scale = p.pscale ? p.pscale[o] : 1.f;
+                            c_shift = p.pscale ? p.pshift[o] : 0.f;
+                        }
+                        res = (res + c_bias) * c_scale + c_shift;
+                        if (d.relu) res = fmaxf(res, 0.f);
+                        const int off = (o0 + ch) * (int)d.y_sc + m * (int)d.y_sm;
+                        if (!(p.dbg & 8) || res == 1.2345e-30f) yb[off] = (unsigned short)pack_bf16(res, 0.f);
+                        if (AGG == FGNN_AGG_MAX && ab) ab[off] = (uint8_t)arg;
+                    }
+                }
+            }
+            __syncthreads();          // P (and, after the last pass, xs / et_s / idx_s) may be rewritten
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------------------
+// host side
+// ----------------------------------------------------------------------------------------
+template <int NET, int AGG, int KC>
+static void* b16_pick_shape(int KSB, int SWP, int NPASS) {
+#define B16_CASE(ks, swp, np) \
+    if (KSB == ks && SWP == swp && NPASS == np) return (void*)mpconv_fwd_b16_kernel<NET, AGG, ks, swp, np, KC>;
+    B16_CASE(2, 1, 1) B16_CASE(2, 2, 1) B16_CASE(2, 2, 2)
+    B16_CASE(4, 1, 1) B16_CASE(4, 2, 1)
+#undef B16_CASE
+    return nullptr;
+}
+template <int NET>
+static void* b16_pick_agg(int agg, int k, int KSB, int SWP, int NPASS) {
+    switch (agg) {
+        case FGNN_AGG_MAX:
+            if (NET == 4 && k == 3) return b16_pick_shape<NET, FGNN_AGG_MAX, (NET == 4 ? 3 : 0)>(KSB, SWP, NPASS);
+            if (NET == 4 && k == 6) return b16_pick_shape<NET, FGNN_AGG_MAX, (NET == 4 ? 6 : 0)>(KSB, SWP, NPASS);
+            return b16_pick_shape<NET, FGNN_AGG_MAX, 0>(KSB, SWP, NPASS);
+        case FGNN_AGG_LSE: return b16_pick_shape<NET, FGNN_AGG_LSE, 0>(KSB, SWP, NPASS);
+        default: return b16_pick_shape<NET, FGNN_AGG_MEAN, 0>(KSB, SWP, NPASS);
+    }
+}
+
+// Returns 1 if launched, 0 if the shape is outside this kernel's family, <0 on error.
+int fgnn_mpconv_forward_b16(const fgnn_mpconv_desc* d, const void* x, const int64_t* nn_idx,
+                            const void* etype, const float* filters, const float* bias,
+                            const float* post_scale, const float* post_shift, void* y,
+                            uint8_t* argmax, fgnn_stream_t stream) {
+    if (d->dtype != FGNN_BF16 || d->ext != FGNN_EXT_NONE) return 0;
+    if (d->net != 1 && d->net != 4) return 0;
+    const int ncols = d->nou * d->net;
+    if (ncols % 16 != 0 || ncols > 512) return 0;
+    if (d->nin != 64 && d->nin != 128) return 0;
+    if (d->N < 2) return 0;                              // one source node: the f32-MFMA kernel handles it
+    if (d->k >= 16 && d->M * d->nou <= 128) return 0;    // few high-degree destinations: that kernel splits the list
+    if (d->k * (d->net == 4 ? 2 : 1) > 64) return 0;     // neighbour list / weights are held one entry per lane
+    // x: dense channel-fastest sample block, 16-byte aligned; y: channel-fastest
+    if (!(d->x_sc == 1 && d->x_sn == d->nin) || (d->x_sb % 8) != 0) return 0;
+    if (!(d->y_sc == 1 && (d->M == 1 || d->y_sm == d->nou))) return 0;
+    const int Npad = fgnn_round_up(d->N, 16);
+    const int mk = d->M * d->k;
+    if ((d->nin * d->N) / 8 > B16_THREADS * B16_XPT) return 0;
+    if (mk * d->net > B16_THREADS * B16_EPT || mk > B16_THREADS * B16_IPT) return 0;
+    int et_mode;
+    if (d->net == 1) {
+        if (!((d->et_sk == 1 || d->k == 1) && (d->et_sm == d->k || d->M == 1))) return 0;
+        et_mode = 1;
+    } else if (mk == 1) {
+        if (d->et_se != 1) return 0;
+        et_mode = 1;
+    } else if ((d->et_sk == 1 || d->k == 1) && (d->et_sm == d->k || d->M == 1) && d->et_se == mk) {
+        et_mode = 0;
+    } else if (d->et_se == 1 && d->et_sk == d->net && (d->et_sm == d->k * d->net || d->M == 1)) {
+        et_mode = 1;
+    } else {
+        return 0;
+    }
+    B16Params p;
+    p.d = *d;
+    p.x = x; p.idx = nn_idx; p.et = etype; p.W = filters; p.bias = bias;
+    p.pscale = post_scale; p.pshift = post_shift; p.y = y; p.argmax = argmax;
+    p.Npad = Npad;
+    const int NPASS = (ncols + B16_PASS_COLS - 1) / B16_PASS_COLS;
+    p.pass_cols = NPASS == 1 ? ncols : B16_PASS_COLS;
+    if (NPASS > 1 && ncols % B16_PASS_COLS != 0) return 0;
+    const int slabs_per_pass = p.pass_cols / 16;
+    const int SWP = (slabs_per_pass + B16_WAVES - 1) / B16_WAVES;
+    const int KSB = d->nin / 32;
+    p.XSB = d->nin * 2 + 16;                             // +16 B: rows land on distinct 16-byte bank groups
+    p.PSB = p.pass_cols * 2 + 16;
+    p.c8shift = d->nin == 64 ? 3 : 4;
+    p.et_mode = et_mode;
+    { const char* e = getenv("FGNN_DBG"); p.dbg = e ? atoi(e) : 0; }
+    p.mkmagic = mk == 1 ? 0u : (unsigned)((0x100000000ULL + mk - 1) / mk);
+    int off = 0;
+    p.off_xs = off;  off += Npad * p.XSB;                off = fgnn_round_up(off, 16);
+    p.off_ps = off;  off += Npad * p.PSB;                off = fgnn_round_up(off, 16);
+    p.off_idx = off; off += fgnn_round_up(mk, 4) * 4;
+    p.off_et = off;  off += fgnn_round_up(mk * d->net * 2, 16);
+    const int lds = off;
+    if (lds > 160 * 1024) return 0;
+    void* fn = d->net == 1 ? b16_pick_agg<1>(d->agg, d->k, KSB, SWP, NPASS)
+                           : b16_pick_agg<4>(d->agg, d->k, KSB, SWP, NPASS);
+    if (!fn) return 0;
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "hipFuncSetAttribute(%d B LDS): %s", lds, hipGetErrorString(e));
+    }
+    int wg_per_cu = (160 * 1024) / lds;
+    if (wg_per_cu > 4) wg_per_cu = 4;
+    if (wg_per_cu < 1) wg_per_cu = 1;
+    int grid = 256 * wg_per_cu;
+    if (grid > d->B) grid = d->B;
+    void* args[] = {(void*)&p};
+    hipError_t e = hipLaunchKernel(fn, dim3(grid), dim3(B16_THREADS), args, lds, (hipStream_t)stream);
+    if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "mpconv bf16 forward launch: %s", hipGetErrorString(e));
+    return 1;
+}

@@ -125,3 +125,32 @@ def test_cpu_tensor_raises():
     with pytest.raises(_hip.FgnnHipError):
         ops.mpconv_forward_raw(torch.zeros(1, 2, 3, 1), torch.zeros(1, 3, 2, dtype=torch.int64),
                                torch.zeros(1, 1, 3, 2), torch.zeros(2, 2), None, 2, 1, 0, 0)
+
+
+@pytest.mark.parametrize('shape', [(64, 64, 4, 96, 48, 6), (64, 64, 4, 48, 96, 3), (64, 128, 4, 96, 48, 6),
+                                   (128, 64, 4, 48, 96, 3), (64, 64, 1, 96, 8, 12), (128, 64, 4, 96, 48, 6)])
+@pytest.mark.parametrize('agg', ['max', 'softmax'])
+def test_bf16_mfma_kernel_vs_oracle(shape, agg, dev):
+    """Channel-fastest bf16 inputs take the bf16-MFMA kernel (csrc/mpconv_fwd_b16.hip): x, etype,
+    filters and the projected rows are bf16, sums f32.  Checked against the f32 oracle evaluated on the
+    same bf16-rounded x / etype / filters; what remains is the rounding of P and of the output
+    (2^-9 each) — bound 2^-6 of the output range, and the max-aggregator argmax must name a neighbour
+    whose f32 message is within that bound of the true maximum."""
+    from fgnn_amd import _hip, ops
+    nin, nou, net, N, M, k = shape
+    B = 6
+    x, idx, et, g = _random_problem(11, B, nin, nou, net, N, M, k, dev)
+    x, et = x.bfloat16(), et.bfloat16()
+    W = (torch.randn(nin, nou * net, generator=g) * 0.1).bfloat16().float()
+    sd = {'filters': W, 'bias': torch.randn(nou, generator=g)}
+    ref = O.mp_conv(sd, '', x.float(), idx, et.float(), nou=nou, net=net, extension=0,
+                    aggregator=agg, relu=False)
+    xd = x.to(dev).contiguous(memory_format=torch.channels_last)
+    etd = et.to(dev).permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)      # edge-type fastest
+    y, am = ops.mpconv_forward_raw(xd, idx.to(dev), etd, W.to(dev), sd['bias'].to(dev), nou, net, 0,
+                                   _hip.AGG_CODES[agg], want_argmax=True)
+    assert y.dtype == torch.bfloat16 and y.stride(1) == 1
+    err = float((y.float().cpu() - ref).abs().max() / ref.abs().max())
+    assert err <= 2.0 ** -6, err
+    if agg == 'max':
+        assert int(am.max()) < k
