@@ -135,15 +135,20 @@ def main():
         bucket = FlatGradBucket(model.parameters())
         opt = torch.optim.Adam(bucket.params, lr=1e-4, weight_decay=1e-8)
 
+    # bf16: activations / messages are stored in bf16 (the message kernels then use bf16 matrix cores for
+    # the forward), parameters, gradients and optimizer state stay f32 (autocast for the node-wise GEMMs)
+    amp = torch.autocast(device_type='cuda', dtype=torch.bfloat16, enabled=(args.dtype == 'bf16'))
+
     def step():
         if train:
             bucket.zero()
-            logits, snr = model(*inputs)
+            with amp:
+                logits, snr = model(*inputs)
             loss_fn(logits, snr, label, sigma_b).backward()
             bucket.all_reduce_mean()
             opt.step()
         else:
-            with torch.no_grad():
+            with torch.no_grad(), amp:
                 model(*inputs)
 
     def fence():

@@ -44,7 +44,8 @@ struct B16Params {
     int et_mode;
     unsigned mkmagic;
     int dbg;                              // FGNN_DBG ablation mask (tuning only)
-    int off_xs, off_ps, off_idx, off_et;  // byte offsets into LDS
+    int JP;                               // neighbour-list split over waves (1 = off)
+    int off_xs, off_ps, off_idx, off_et, off_red;  // byte offsets into LDS
 };
 
 extern __shared__ __attribute__((aligned(16))) unsigned char fgnn_lds_h[];
@@ -98,6 +99,7 @@ __global__ __launch_bounds__(B16_THREADS) void mpconv_fwd_b16_kernel(const B16Pa
     unsigned char* ps = fgnn_lds_h + p.off_ps;        // [Npad][PSB]  bf16 P of the current pass
     int* idx_s = reinterpret_cast<int*>(fgnn_lds_h + p.off_idx);
     unsigned short* et_h = reinterpret_cast<unsigned short*>(fgnn_lds_h + p.off_et);   // [mk][net] bf16
+    float* red = reinterpret_cast<float*>(fgnn_lds_h + p.off_red);                      // JP partials
 
     const unsigned short* xg = static_cast<const unsigned short*>(p.x);
     const unsigned short* etg = static_cast<const unsigned short*>(p.et);
@@ -234,91 +236,135 @@ __global__ __launch_bounds__(B16_THREADS) void mpconv_fwd_b16_kernel(const B16Pa
             __syncthreads();
 
             // ---- gather + edge-type contraction + aggregation ----
-            // One wave per (destination m, block of 64 channels), lane = channel.  The k neighbour ids and
-            // the k*net edge-type weights of m are wave-uniform: ONE LDS read each per wave (lane j holds
-            // entry j) and v_readlane broadcasts to scalar registers, so the only per-edge LDS traffic
-            // is the 8-byte P row slice per lane; the contraction is two v_dot2c_f32_bf16 per edge with
-            // the weights as scalar operands.
+            // One wave per (destination m, block of 64 channels), lane = channel.  The neighbour ids and
+            // the edge-type weights of m are wave-uniform: ONE LDS read each per block of up to JB
+            // neighbours (lane j holds entry j) and v_readlane broadcasts them to scalar registers, so the
+            // only per-edge LDS traffic is the 8-byte P row slice per lane; the contraction is two
+            // v_dot2c_f32_bf16 per edge with the weights as scalar operands.  Few, high-degree
+            // destinations (the degree-96 hyper-factor) split their neighbour list over JP waves and
+            // combine the partial results through LDS.
             {
+                constexpr int JB = NET == 4 ? 32 : 64;          // neighbours whose ids + weights fit one lane each
                 const int nch = (otc + 63) >> 6;
+                const int JP = p.JP;
+                const int jchunk = (k + JP - 1) / JP;
                 const unsigned* et_w = reinterpret_cast<const unsigned*>(et_h);
                 int cc_cached = -1;
                 float c_bias = 0.f, c_scale = 1.f, c_shift = 0.f;
-                for (int u = wave; u < ((p.dbg & 2) ? 0 : M * nch); u += B16_WAVES) {
-                    const int m = u / nch, cc = u - m * nch;
+                auto finish = [&](int m, int cc, int ch, float a, float bsum, int arg) {
+                    float res;
+                    if constexpr (AGG == FGNN_AGG_MAX) res = a;
+                    else if constexpr (AGG == FGNN_AGG_LSE) res = (1.0f / 3.0f) * (a + logf(bsum));
+                    else res = bsum / (float)k;
+                    if (cc != cc_cached) {            // per-lane channel constants: reload only when the block changes
+                        cc_cached = cc;
+                        const int o = o0 + ch;
+                        c_bias = p.bias ? p.bias[o] : 0.f;
+                        c_scale = p.pscale ? p.pscale[o] : 1.f;
+                        c_shift = p.pscale ? p.pshift[o] : 0.f;
+                    }
+                    res = (res + c_bias) * c_scale + c_shift;
+                    if (d.relu) res = fmaxf(res, 0.f);
+                    const int off = (o0 + ch) * (int)d.y_sc + m * (int)d.y_sm;
+                    if (!(p.dbg & 8) || res == 1.2345e-30f) yb[off] = (unsigned short)pack_bf16(res, 0.f);
+                    if (AGG == FGNN_AGG_MAX && ab) ab[off] = (uint8_t)arg;
+                };
+                for (int u = wave; u < ((p.dbg & 2) ? 0 : M * nch * JP); u += B16_WAVES) {
+                    const int part = u % JP, base = u / JP;
+                    const int m = base / nch, cc = base - m * nch;
                     const int ch = cc * 64 + lane;
                     const bool active = ch < otc;
                     const unsigned char* pc = ps + (active ? ch : 0) * (net * 2);
-                    const int idxv = lane < k ? idx_s[m * k + lane] : 0;
-                    unsigned etv;
-                    if constexpr (NET == 4) etv = lane < 2 * k ? et_w[m * k * 2 + lane] : 0u;
-                    else etv = lane < k ? (unsigned)et_h[m * k + lane] << 16 : 0u;
+                    const int jlo = KC > 0 ? 0 : part * jchunk;
+                    const int jhi = KC > 0 ? KC : min(k, jlo + jchunk);
                     float best = 0.f, mx = -INFINITY, ssum = 0.f;
-                    int arg = 0;
-                    auto load_p = [&](int j, uint2& pk) {
-                        const int n = __builtin_amdgcn_readlane(idxv, j);
-                        if constexpr (NET == 4) pk = *reinterpret_cast<const uint2*>(pc + n * PSB);
-                        else pk.x = *reinterpret_cast<const unsigned short*>(pc + n * PSB);
-                    };
-                    auto consume = [&](int j, const uint2& pk) {
-                        float v;
-                        if constexpr (NET == 4) {
-                            const unsigned e01 = __builtin_amdgcn_readlane(etv, 2 * j);
-                            const unsigned e23 = __builtin_amdgcn_readlane(etv, 2 * j + 1);
-                            v = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, pk.x),
-                                                                __builtin_bit_cast(bf16x2_t, e01), 0.f, false);
-                            v = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, pk.y),
-                                                                __builtin_bit_cast(bf16x2_t, e23), v, false);
-                        } else {
-                            const float e = __uint_as_float(__builtin_amdgcn_readlane(etv, j));
-                            v = e * __uint_as_float(pk.x << 16);
-                        }
-                        if constexpr (AGG == FGNN_AGG_MAX) {
-                            if (j == 0 || v > best) { best = v; arg = j; }   // strict >: first occurrence wins
-                        } else if constexpr (AGG == FGNN_AGG_LSE) {
-                            v *= 3.0f;
-                            if (v > mx) { ssum = ssum * expf(mx - v) + 1.0f; mx = v; }
-                            else ssum += expf(v - mx);
-                        } else {
-                            ssum += v;
-                        }
-                    };
-                    if constexpr (KC > 0) {                    // all KC row slices in flight, then reduce
-                        uint2 pk[KC];
+                    int arg = jlo;
+                    for (int jb = jlo; jb < jhi; jb += JB) {
+                        const int nb = min(JB, jhi - jb);
+                        const int idxv = lane < nb ? idx_s[m * k + jb + lane] : 0;
+                        unsigned etv;
+                        if constexpr (NET == 4) etv = lane < 2 * nb ? et_w[(m * k + jb) * 2 + lane] : 0u;
+                        else etv = lane < nb ? (unsigned)et_h[m * k + jb + lane] << 16 : 0u;
+                        auto load_p = [&](int j, uint2& pk) {
+                            const int n = __builtin_amdgcn_readlane(idxv, j);
+                            if constexpr (NET == 4) pk = *reinterpret_cast<const uint2*>(pc + n * PSB);
+                            else pk.x = *reinterpret_cast<const unsigned short*>(pc + n * PSB);
+                        };
+                        auto consume = [&](int j, const uint2& pk) {
+                            float v;
+                            if constexpr (NET == 4) {
+                                const unsigned e01 = __builtin_amdgcn_readlane(etv, 2 * j);
+                                const unsigned e23 = __builtin_amdgcn_readlane(etv, 2 * j + 1);
+                                v = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, pk.x),
+                                                                    __builtin_bit_cast(bf16x2_t, e01), 0.f, false);
+                                v = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, pk.y),
+                                                                    __builtin_bit_cast(bf16x2_t, e23), v, false);
+                            } else {
+                                const float e = __uint_as_float(__builtin_amdgcn_readlane(etv, j));
+                                v = e * __uint_as_float(pk.x << 16);
+                            }
+                            if constexpr (AGG == FGNN_AGG_MAX) {
+                                if (jb + j == jlo || v > best) { best = v; arg = jb + j; }   // strict >: first occurrence
+                            } else if constexpr (AGG == FGNN_AGG_LSE) {
+                                v *= 3.0f;
+                                if (v > mx) { ssum = ssum * expf(mx - v) + 1.0f; mx = v; }
+                                else ssum += expf(v - mx);
+                            } else {
+                                ssum += v;
+                            }
+                        };
+                        if constexpr (KC > 0) {                // all KC row slices in flight, then reduce
+                            uint2 pk[KC];
 #pragma unroll
-                        for (int j = 0; j < KC; ++j) load_p(j, pk[j]);
+                            for (int j = 0; j < KC; ++j) load_p(j, pk[j]);
 #pragma unroll
-                        for (int j = 0; j < KC; ++j) consume(j, pk[j]);
-                    } else {
-                        int j = 0;
-                        for (; j + 3 <= k; j += 3) {
-                            uint2 p0, p1, p2;
-                            load_p(j, p0); load_p(j + 1, p1); load_p(j + 2, p2);
-                            consume(j, p0); consume(j + 1, p1); consume(j + 2, p2);
-                        }
-                        for (; j < k; ++j) {
-                            uint2 p0;
-                            load_p(j, p0);
-                            consume(j, p0);
+                            for (int j = 0; j < KC; ++j) consume(j, pk[j]);
+                        } else {
+                            int j = 0;
+                            for (; j + 3 <= nb; j += 3) {
+                                uint2 p0, p1, p2;
+                                load_p(j, p0); load_p(j + 1, p1); load_p(j + 2, p2);
+                                consume(j, p0); consume(j + 1, p1); consume(j + 2, p2);
+                            }
+                            for (; j < nb; ++j) {
+                                uint2 p0;
+                                load_p(j, p0);
+                                consume(j, p0);
+                            }
                         }
                     }
-                    float res;
-                    if constexpr (AGG == FGNN_AGG_MAX) res = best;
-                    else if constexpr (AGG == FGNN_AGG_LSE) res = (1.0f / 3.0f) * (mx + logf(ssum));
-                    else res = ssum / (float)k;
-                    if (active) {
-                        if (cc != cc_cached) {        // per-lane channel constants: reload only when the block changes
-                            cc_cached = cc;
-                            const int o = o0 + ch;
-                            c_bias = p.bias ? p.bias[o] : 0.f;
-                            c_scale = p.pscale ? p.pscale[o] : 1.f;
-                            c_shift = p.pscale ? p.pshift[o] : 0.f;
+                    const float a = AGG == FGNN_AGG_MAX ? best : mx;
+                    if (JP == 1) {
+                        if (active) finish(m, cc, ch, a, ssum, arg);
+                    } else {                                   // partial of this wave -> LDS
+                        float* r3 = red + ((base * JP + part) * 64 + lane) * 3;
+                        r3[0] = jlo < jhi ? a : -INFINITY;
+                        r3[1] = ssum;
+                        r3[2] = __int_as_float(arg);
+                    }
+                }
+                if (JP > 1) {
+                    __syncthreads();
+                    for (int base = wave; base < M * nch; base += B16_WAVES) {
+                        const int m = base / nch, cc = base - m * nch;
+                        const int ch = cc * 64 + lane;
+                        const float* r3 = red + (base * JP * 64 + lane) * 3;
+                        float a = r3[0], bsum = r3[1];
+                        int arg = __float_as_int(r3[2]);
+                        for (int q = 1; q < JP; ++q) {
+                            if (q * jchunk >= k) break;
+                            const float a2 = r3[q * 192], b2 = r3[q * 192 + 1];
+                            if constexpr (AGG == FGNN_AGG_MAX) {
+                                if (a2 > a) { a = a2; arg = __float_as_int(r3[q * 192 + 2]); }   // later part: strictly larger only
+                            } else if constexpr (AGG == FGNN_AGG_LSE) {
+                                const float mxx = fmaxf(a, a2);
+                                bsum = bsum * expf(a - mxx) + b2 * expf(a2 - mxx);
+                                a = mxx;
+                            } else {
+                                bsum += b2;
+                            }
                         }
-                        res = (res + c_bias) * c_scale + c_shift;
-                        if (d.relu) res = fmaxf(res, 0.f);
-                        const int off = (o0 + ch) * (int)d.y_sc + m * (int)d.y_sm;
-                        if (!(p.dbg & 8) || res == 1.2345e-30f) yb[off] = (unsigned short)pack_bf16(res, 0.f);
-                        if (AGG == FGNN_AGG_MAX && ab) ab[off] = (uint8_t)arg;
+                        if (ch < otc) finish(m, cc, ch, a, bsum, arg);
                     }
                 }
             }
@@ -361,11 +407,8 @@ int fgnn_mpconv_forward_b16(const fgnn_mpconv_desc* d, const void* x, const int6
     const int ncols = d->nou * d->net;
     if (ncols % 16 != 0 || ncols > 512) return 0;
     if (d->nin != 64 && d->nin != 128) return 0;
-    if (d->N < 2) return 0;                              // one source node: the f32-MFMA kernel handles it
-    if (d->k >= 16 && d->M * d->nou <= 128) return 0;    // few high-degree destinations: that kernel splits the list
-    if (d->k * (d->net == 4 ? 2 : 1) > 64) return 0;     // neighbour list / weights are held one entry per lane
     // x: dense channel-fastest sample block, 16-byte aligned; y: channel-fastest
-    if (!(d->x_sc == 1 && d->x_sn == d->nin) || (d->x_sb % 8) != 0) return 0;
+    if (!(d->x_sc == 1 && (d->x_sn == d->nin || d->N == 1)) || (d->x_sb % 8) != 0) return 0;
     if (!(d->y_sc == 1 && (d->M == 1 || d->y_sm == d->nou))) return 0;
     const int Npad = fgnn_round_up(d->N, 16);
     const int mk = d->M * d->k;
@@ -407,6 +450,15 @@ int fgnn_mpconv_forward_b16(const fgnn_mpconv_desc* d, const void* x, const int6
     p.off_ps = off;  off += Npad * p.PSB;                off = fgnn_round_up(off, 16);
     p.off_idx = off; off += fgnn_round_up(mk, 4) * 4;
     p.off_et = off;  off += fgnn_round_up(mk * d->net * 2, 16);
+    // few high-degree destinations: split each neighbour list over JP waves
+    {
+        const int otp = p.pass_cols / d->net;
+        const int units = d->M * ((otp < d->nou ? otp : d->nou) + 63) / 64;
+        p.JP = 1;
+        if (d->k >= 16 && units * 2 <= B16_WAVES) p.JP = B16_WAVES / units;
+        p.off_red = off;
+        if (p.JP > 1) off += units * p.JP * 64 * 3 * 4;
+    }
     const int lds = off;
     if (lds > 160 * 1024) return 0;
     void* fn = d->net == 1 ? b16_pick_agg<1>(d->agg, d->k, KSB, SWP, NPASS)

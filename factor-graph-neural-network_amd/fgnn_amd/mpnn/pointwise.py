@@ -40,5 +40,6 @@ class NodeInstanceNorm(torch.nn.Module):
     def forward(self, x):
         if x.shape[2] * x.shape[3] == 1:
             return torch.zeros_like(x)
-        var, mean = torch.var_mean(x, dim=(2, 3), unbiased=False, keepdim=True)
-        return (x - mean) * torch.rsqrt(var + self.eps)
+        xf = x.float()                                   # statistics in f32 also for bf16 activations
+        var, mean = torch.var_mean(xf, dim=(2, 3), unbiased=False, keepdim=True)
+        return ((xf - mean) * torch.rsqrt(var + self.eps)).to(x.dtype)

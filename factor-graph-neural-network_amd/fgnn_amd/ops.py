@@ -76,7 +76,7 @@ def _require_device(*tensors):
 
 def _channels_last_like(x):
     """True when x [B,C,N,1] is laid out channel-fastest."""
-    return x.shape[1] > 1 and x.stride(1) == 1 and x.shape[2] > 1 and x.stride(2) != 1
+    return x.shape[1] > 1 and x.stride(1) == 1 and (x.shape[2] == 1 or x.stride(2) != 1)
 
 
 def _alloc_out(x, nou, M, dtype=None):
