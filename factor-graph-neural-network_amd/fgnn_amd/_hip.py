@@ -20,7 +20,7 @@ F32, BF16 = 0, 1
 AGG_CODES = {'max': AGG_MAX, 'softmax': AGG_LSE, 'mean': AGG_MEAN}
 
 EXPORTS = ('fgnn_mpconv_forward', 'fgnn_mpconv_backward', 'fgnn_mpconv_forward_lds_bytes',
-           'fgnn_mpconv_backward_workspace_bytes',
+           'fgnn_mpconv_backward_workspace_bytes', 'fgnn_linear_wgrad', 'fgnn_linear_wgrad_workspace_bytes',
            'fgnn_mpconv_algorithmic_bytes', 'fgnn_last_error', 'fgnn_abi_version')
 
 
@@ -61,6 +61,11 @@ def lib():
     L.fgnn_mpconv_forward_lds_bytes.argtypes = [dp]
     L.fgnn_mpconv_algorithmic_bytes.restype = ctypes.c_int64
     L.fgnn_mpconv_algorithmic_bytes.argtypes = [dp]
+    i32, i64 = ctypes.c_int32, ctypes.c_int64
+    L.fgnn_linear_wgrad.restype = ctypes.c_int
+    L.fgnn_linear_wgrad.argtypes = [vp, vp, i64, i32, i32, i32, vp, vp, vp, i64, vp]
+    L.fgnn_linear_wgrad_workspace_bytes.restype = i64
+    L.fgnn_linear_wgrad_workspace_bytes.argtypes = [i64, i32, i32]
     L.fgnn_last_error.restype = ctypes.c_char_p
     L.fgnn_abi_version.restype = ctypes.c_int
     _lib = L

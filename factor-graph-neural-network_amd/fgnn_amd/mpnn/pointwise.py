@@ -11,6 +11,45 @@ channels-last strides; every consumer in this package is stride-agnostic.
 """
 import torch
 
+from .. import _hip
+
+
+class _RowLinear(torch.autograd.Function):
+    """y = rows @ W^T + b over R = B*N rows.  Forward and grad-input are plain GEMMs (rocBLAS /
+    hipBLASLt do those well); the weight / bias gradient is the tall-skinny product
+    gW = gy^T rows (K = R ~ 4e5, M,N <= 256) that rocBLAS runs 40x off its streaming bound, so it goes
+    to the hand-written split-rows kernel csrc/linear_wgrad.hip (f32 accumulation, one pass over
+    rows and gy)."""
+
+    @staticmethod
+    def forward(ctx, rows, weight, bias):
+        w = weight if weight.dtype == rows.dtype else weight.to(rows.dtype)
+        b = bias if bias is None or bias.dtype == rows.dtype else bias.to(rows.dtype)
+        ctx.save_for_backward(rows, weight)
+        ctx.has_bias = bias is not None
+        return torch.nn.functional.linear(rows, w, b)
+
+    @staticmethod
+    def backward(ctx, gy):
+        rows, weight = ctx.saved_tensors
+        from .. import ops
+        gy = gy.contiguous()
+        if gy.dtype != rows.dtype:
+            gy = gy.to(rows.dtype)
+        grows = None
+        if ctx.needs_input_grad[0]:
+            grows = gy @ (weight if weight.dtype == gy.dtype else weight.to(gy.dtype))
+        R, cin = rows.shape
+        cout = weight.shape[0]
+        L = _hip.lib()
+        gw = torch.zeros((cout, cin), device=rows.device, dtype=torch.float32)
+        gb = torch.zeros((cout,), device=rows.device, dtype=torch.float32) if ctx.has_bias else None
+        ws = ops._workspace(rows.device, int(L.fgnn_linear_wgrad_workspace_bytes(R, cin, cout)))
+        _hip.check(L.fgnn_linear_wgrad(_hip._ptr(rows), _hip._ptr(gy), R, cin, cout, _hip.dtype_code(rows),
+                                       _hip._ptr(gw), _hip._ptr(gb), _hip._ptr(ws), ws.numel() * 4,
+                                       _hip.stream_ptr()))
+        return grows, gw.to(weight.dtype), (gb.to(weight.dtype) if gb is not None else None)
+
 
 class PointwiseConv2d(torch.nn.Conv2d):
     def __init__(self, in_channels, out_channels, kernel_size=1, bias=True):
@@ -22,8 +61,17 @@ class PointwiseConv2d(torch.nn.Conv2d):
         rows = x.permute(0, 2, 3, 1)                    # [B,H,W,C] view; free when channels-last
         if not rows.is_contiguous():
             rows = rows.contiguous()
-        y = torch.nn.functional.linear(rows.view(B * H * W, C),
-                                       self.weight.view(self.out_channels, C), self.bias)
+        rows = rows.view(B * H * W, C)
+        if torch.is_autocast_enabled():
+            rows = rows.to(torch.get_autocast_gpu_dtype())
+        weight = self.weight.view(self.out_channels, C)
+        if rows.is_cuda and rows.dtype in (torch.float32, torch.bfloat16) and torch.is_grad_enabled() and (
+                weight.requires_grad or rows.requires_grad):
+            y = _RowLinear.apply(rows, weight, self.bias)
+        else:
+            w = weight if weight.dtype == rows.dtype else weight.to(rows.dtype)
+            b = self.bias if self.bias is None or self.bias.dtype == rows.dtype else self.bias.to(rows.dtype)
+            y = torch.nn.functional.linear(rows, w, b)
         return y.view(B, H, W, self.out_channels).permute(0, 3, 1, 2)
 
 

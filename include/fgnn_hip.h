@@ -93,6 +93,17 @@ int64_t fgnn_mpconv_forward_lds_bytes(const fgnn_mpconv_desc* d);
 /* Algorithmic HBM bytes of one forward call (SURVEY §8d formula; used by bench.py's roofline). */
 int64_t fgnn_mpconv_algorithmic_bytes(const fgnn_mpconv_desc* d);
 
+/*
+ * Weight / bias gradient of a node-wise linear map y[r,:] = W x[r,:] + b over R = B*N rows
+ * (the 1x1 convolutions around the operator: mp_nn_residual.py:25-35, base_model.py:43-90):
+ *   gW[o][c] += sum_r gy[r][o] x[r][c],  gb[o] += sum_r gy[r][o]      (f32, ACCUMULATED into)
+ * x [R][Cin], gy [R][Cout]: dense row-major, dtype FGNN_F32 / FGNN_BF16.  gb may be NULL.
+ * workspace: fgnn_linear_wgrad_workspace_bytes(R, Cin, Cout) bytes of device scratch.
+ */
+int fgnn_linear_wgrad(const void* x, const void* gy, int64_t R, int32_t Cin, int32_t Cout, int32_t dtype,
+                      float* gW, float* gb, void* workspace, int64_t workspace_bytes, fgnn_stream_t stream);
+int64_t fgnn_linear_wgrad_workspace_bytes(int64_t R, int32_t Cin, int32_t Cout);
+
 const char* fgnn_last_error(void);
 int fgnn_abi_version(void);
 
