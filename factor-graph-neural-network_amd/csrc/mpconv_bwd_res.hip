@@ -27,7 +27,7 @@
 #define BR_THREADS 512
 #define BR_WAVES 8
 #define BR_EPT 4        // etype prefetch registers per thread  (M*k*net <= 512*4)
-#define BR_APT 3        // argmax prefetch words per thread     (M*nou/4 <= 512*3)
+#define BR_APT 3        // argmax prefetch words per thread per pass (M*otcP/4 <= 512*3)
 #define BR_PASS_COLS 128
 #define BR_MAXN 128     // CSR arrays are sized for N <= 128 source nodes
 
@@ -44,9 +44,11 @@ struct BresParams {
     float* get;
     float* ws;           // per-workgroup partial [grid][nin*ncols + nou]
     int has_bias;
-    int Npad, Kpad, XS, PS, GS;
+    int Npad, Kpad, XS, PS, GS;     // GS: row stride of the per-pass gz / argmax images
     int cl_in, cl_y, et_mode;
-    unsigned xdiv, xmagic, mkmagic, ymagic, ydiv;
+    unsigned xdiv, xmagic, mkmagic, ymagic, ydiv;   // ydiv: slice width otcP (channel-fastest gz) or M
+    unsigned y4magic;                               // ceil(2^32 / (otcP/4)): argmax words of a channel-fastest slice
+    int otcP;                                       // channels per pass slice = min(128/net, nou)
     int XQ;              // prefetch slots [0,XQ) carry x, the rest gz
     int dbg;             // FGNN_DBG ablation mask (tuning only)
     int off_xs, off_pb, off_idx, off_et, off_gz, off_am, off_cs, off_cl, off_ce;
@@ -128,25 +130,23 @@ __global__ __launch_bounds__(BR_THREADS) void mpconv_bwd_res_kernel(const BresPa
     for (int a = 0; a < NPASS; ++a)
 #pragma unroll
         for (int t = 0; t < DWT; ++t) gw[a][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float gbacc = 0.f;                                // dbias partial of channel `tid` (tid < nou)
+    float gbacc[NPASS];                               // dbias partials, channel pass*otp + tid % otcP
+#pragma unroll
+    for (int a = 0; a < NPASS; ++a) gbacc[a] = 0.f;
 
     // ---- prefetch registers ----
     float pr[PT], er[BR_EPT];
     unsigned ar[BR_APT];
     int ir = 0;
-    const int xtot = nin * N, ytot = M * nou;
+    const int xtot = nin * N, ytot = M * p.otcP;      // x block of a sample; gz / argmax slice of a pass
     const int xpad = XS - nin;                        // xs is always [n][c]
-    auto prefetch = [&](int b, int t) {
+    auto prefetch_x = [&](int b, int t) {
         const T* xb = xg + (int64_t)b * d.x_sb;
-        const T* gb = gzg + (int64_t)b * d.y_sb;
 #pragma unroll
         for (int q = 0; q < PT; ++q) {
             if (q < p.XQ) {
                 const int f = t + q * BR_THREADS;
                 pr[q] = f < xtot ? fgnn_ld(xb + f) : 0.f;
-            } else {
-                const int f = t + (q - p.XQ) * BR_THREADS;
-                pr[q] = f < ytot ? fgnn_ld(gb + f) : 0.f;
             }
         }
         const T* eb = etg + (int64_t)b * d.et_sb;
@@ -155,12 +155,6 @@ __global__ __launch_bounds__(BR_THREADS) void mpconv_bwd_res_kernel(const BresPa
             const int f = t + q * BR_THREADS;
             er[q] = f < mk * net ? fgnn_ld(eb + f) : 0.f;
         }
-        const unsigned* ab = reinterpret_cast<const unsigned*>(p.argmax + (int64_t)b * d.y_sb);
-#pragma unroll
-        for (int q = 0; q < BR_APT; ++q) {
-            const int f = t + q * BR_THREADS;
-            ar[q] = f * 4 < ytot ? ab[f] : 0u;
-        }
         if (t < mk) {
             const int m = t / k, j = t - m * k;
             long long v = (p.idx + (int64_t)b * d.idx_sb)[(int64_t)m * d.idx_sm + (int64_t)j * d.idx_sk];
@@ -168,7 +162,36 @@ __global__ __launch_bounds__(BR_THREADS) void mpconv_bwd_res_kernel(const BresPa
             ir = (int)v;
         }
     };
-    auto commit = [&](int t) {
+    // gz / argmax slice of (sample b, pass): channels [o0, o0 + otcP).  Channel-fastest tensors: element f
+    // of the slice is (m, ol) = (f / otcP, f % otcP) at m*nou + o0 + ol; node-fastest: one dense block.
+    auto prefetch_g = [&](int b, int pass, int t) {
+        const int o0 = pass * p.otcP;
+        const T* gb = gzg + (int64_t)b * d.y_sb + (p.cl_y ? o0 : o0 * M);
+        const uint8_t* ab = p.argmax + (int64_t)b * d.y_sb + (p.cl_y ? o0 : o0 * M);
+#pragma unroll
+        for (int q = 0; q < PT; ++q) {
+            if (q >= p.XQ) {
+                const unsigned f = t + (q - p.XQ) * BR_THREADS;
+                float v = 0.f;
+                if ((int)f < ytot) {
+                    if (p.cl_y) { const unsigned m = __umulhi(f, p.ymagic); v = fgnn_ld(gb + m * nou + (f - m * p.ydiv)); }
+                    else v = fgnn_ld(gb + f);
+                }
+                pr[q] = v;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < BR_APT; ++q) {
+            const unsigned w = t + q * BR_THREADS;
+            unsigned v = 0u;
+            if ((int)(w * 4) < ytot) {
+                if (p.cl_y) { const unsigned m = __umulhi(w, p.y4magic); v = *reinterpret_cast<const unsigned*>(ab + m * nou + (w * 4 - m * p.ydiv)); }
+                else v = reinterpret_cast<const unsigned*>(ab)[w];
+            }
+            ar[q] = v;
+        }
+    };
+    auto commit_x = [&](int t) {
 #pragma unroll
         for (int q = 0; q < PT; ++q) {
             if (q < p.XQ) {
@@ -178,14 +201,6 @@ __global__ __launch_bounds__(BR_THREADS) void mpconv_bwd_res_kernel(const BresPa
                     const unsigned hi = __umulhi(f, p.xmagic);          // f / xdiv
                     if (p.cl_in) xs[f + hi * xpad] = pr[q];
                     else xs[(f - hi * p.xdiv) * XS + hi] = pr[q];
-                }
-            } else {
-                // gz: dense element f is (m,o) = (f/nou, f%nou) channel-fastest, or (o,m) = (f/M, f%M)
-                const unsigned f = t + (q - p.XQ) * BR_THREADS;
-                if ((int)f < ytot) {
-                    const unsigned hi = __umulhi(f, p.ymagic);          // f / ydiv
-                    if (p.cl_y) gz_s[hi * GS + (f - hi * p.ydiv)] = pr[q];
-                    else gz_s[(f - hi * p.ydiv) * GS + hi] = pr[q];
                 }
             }
         }
@@ -198,6 +213,21 @@ __global__ __launch_bounds__(BR_THREADS) void mpconv_bwd_res_kernel(const BresPa
                 } else {
                     const unsigned e = __umulhi(f, p.mkmagic), r = f - e * mk;
                     et_s[r * net + e] = er[q];
+                }
+            }
+        }
+        if (t < mk) idx_s[t] = ir;
+    };
+    auto commit_g = [&](int t, float& bias_acc) {
+#pragma unroll
+        for (int q = 0; q < PT; ++q) {
+            if (q >= p.XQ) {
+                const unsigned f = t + (q - p.XQ) * BR_THREADS;
+                if ((int)f < ytot) {
+                    const unsigned hi = __umulhi(f, p.ymagic);          // f / ydiv
+                    if (p.cl_y) gz_s[hi * GS + (f - hi * p.ydiv)] = pr[q];     // (m, ol)
+                    else gz_s[(f - hi * p.ydiv) * GS + hi] = pr[q];            // (ol, m) -> [m][ol]
+                    if (p.fast_bias) bias_acc += pr[q];                        // ol == t % otcP for every slot
                 }
             }
         }
@@ -217,7 +247,6 @@ __global__ __launch_bounds__(BR_THREADS) void mpconv_bwd_res_kernel(const BresPa
                 }
             }
         }
-        if (t < mk) idx_s[t] = ir;
     };
     // Transposed incidence as a CSR over source nodes: cs_s[n..n+1) delimits node n's in-edges in cl_s;
     // an entry packs (gz/argmax row offset m*GS) << 8 | j.  Lists are sorted by edge id so that the
@@ -265,7 +294,7 @@ __global__ __launch_bounds__(BR_THREADS) void mpconv_bwd_res_kernel(const BresPa
     const int chunk = (d.B + gridDim.x - 1) / gridDim.x;
     const int b_begin = blockIdx.x * chunk;
     const int b_end = min(d.B, b_begin + chunk);
-    if (b_begin < b_end) prefetch(b_begin, tid);
+    if (b_begin < b_end) { prefetch_x(b_begin, tid); prefetch_g(b_begin, 0, tid); }
     const int otp = BR_PASS_COLS / net;               // channels per pass (32 or 128)
     const bool shared_graph = d.idx_sb == 0;
 
@@ -276,23 +305,14 @@ __global__ __launch_bounds__(BR_THREADS) void mpconv_bwd_res_kernel(const BresPa
         // lane coordinates re-derived from the opaque `t`: keeps the dozens of loop-invariant LDS
         // offsets below from being hoisted out of the sample loop into (spilled) registers
         const int li = t & 15, lk = (t >> 4) & 3;
-        if (p.fast_bias) {
-#pragma unroll
-            for (int q = 0; q < PT; ++q)
-                if (q >= p.XQ) gbacc += pr[q];        // out-of-range slots hold 0
-        }
-        commit(t);
+        commit_x(t);
+        commit_g(t, gbacc[0]);
         __syncthreads();
-        if (b + 1 < b_end) prefetch(b + 1, t);
+        if (b + 1 < b_end) prefetch_x(b + 1, t);
+        if (NPASS > 1) prefetch_g(b, 1, t);
+        else if (b + 1 < b_end) prefetch_g(b + 1, 0, t);
         if (!shared_graph || b == b_begin) build_csr();
 
-        // dbias: channel-fastest gz with 512 % nou == 0 puts channel (tid % nou) in every gz register of
-        // this thread (summed below, at commit time); otherwise channel tid walks its LDS column
-        if (!p.fast_bias && tid < nou) {
-            float s = 0.f;
-            for (int m = 0; m < M; ++m) s += gz_s[m * GS + tid];
-            gbacc += s;
-        }
         f32x4 dxacc[DXT];
 #pragma unroll
         for (int i = 0; i < DXT; ++i) dxacc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -304,7 +324,12 @@ __global__ __launch_bounds__(BR_THREADS) void mpconv_bwd_res_kernel(const BresPa
         for (int pass = 0; pass < NPASS; ++pass) {
             const int o0 = pass * otp;
             const int otc = min(otp, nou - o0);
-            if (pass > 0) __syncthreads();            // previous pass's dx/dW MFMAs are done with pb
+            if (pass > 0) {
+                __syncthreads();                      // previous pass's dx/dW MFMAs are done with pb; gz_s is free
+                commit_g(t, gbacc[pass]);
+                if (pass + 1 < NPASS) prefetch_g(b, pass + 1, t);
+                else if (b + 1 < b_end) prefetch_g(b + 1, 0, t);
+            }
             const int APS = AP_RES ? pass : 0;        // folds after full unrolling of the pass loop
             if constexpr (!AP_RES) load_aP(0, pass);
             {
@@ -332,12 +357,17 @@ __global__ __launch_bounds__(BR_THREADS) void mpconv_bwd_res_kernel(const BresPa
             }
             __syncthreads();
 
+            if (!p.fast_bias && tid < otc) {           // dbias without the register shortcut: walk the LDS column
+                float sgz = 0.f;
+                for (int m = 0; m < M; ++m) sgz += gz_s[m * GS + tid];
+                gbacc[pass] += sgz;
+            }
             // ---- detype owners: edge r = (m, j) sums over this pass's channels ----
             if (tid < mk) {
                 const int m = tid / k, j = tid - m * k;
                 const float* pn = pb + idx_s[tid] * PS;
-                const float* gm = gz_s + m * GS + o0;
-                const uint8_t* am = am_s + m * GS + o0;
+                const float* gm = gz_s + m * GS;
+                const uint8_t* am = am_s + m * GS;
                 for (int ol = 0; ol < otc; ol += 4) {
                     const unsigned a4 = *reinterpret_cast<const unsigned*>(am + ol);
                     const f32x4 g4 = *reinterpret_cast<const f32x4*>(gm + ol);
@@ -365,12 +395,11 @@ __global__ __launch_bounds__(BR_THREADS) void mpconv_bwd_res_kernel(const BresPa
                 const int n = it / otp, ol = it - n * otp;
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f};
                 if (n < N && ol < otc) {
-                    const int o = o0 + ol;
                     for (int q = cs_s[n]; q < cs_s[n + 1]; ++q) {
                         const int ent = cl_s[q];
                         const int mrow = ent >> 8, j = ent & 0xff;
-                        if (am_s[mrow + o] == j) {
-                            const float g = gz_s[mrow + o];
+                        if (am_s[mrow + ol] == j) {
+                            const float g = gz_s[mrow + ol];
                             const float* etp = et_s + ce_s[q];
                             if constexpr (NET == 4) {
                                 const f32x4 e4 = *reinterpret_cast<const f32x4*>(etp);
@@ -462,17 +491,21 @@ __global__ __launch_bounds__(BR_THREADS) void mpconv_bwd_res_kernel(const BresPa
                 }
             }
         }
-        if (p.fast_bias) {                            // fold the 512/nou partials of each channel
-            __syncthreads();
-            float* red = pb;
-            if (tid < nou) red[tid] = 0.f;
-            __syncthreads();
-            atomicAdd(&red[tid % nou], gbacc);
-            __syncthreads();
-            if (tid < nou) slab[(int64_t)nin * ncols + tid] = red[tid];
-        } else if (tid < nou) {
-            slab[(int64_t)nin * ncols + tid] = gbacc;
+        __syncthreads();
+        float* red = pb;                              // P / dP are dead now
+        for (int f = tid; f < nou; f += BR_THREADS) red[f] = 0.f;
+        __syncthreads();
+#pragma unroll
+        for (int pass = 0; pass < NPASS; ++pass) {
+            if (p.fast_bias) {                        // 512/otcP threads hold partials of channel tid % otcP
+                const int o = pass * p.otcP + tid % p.otcP;
+                if (o < nou) atomicAdd(&red[o], gbacc[pass]);
+            } else if (tid < p.otcP && pass * p.otcP + tid < nou) {
+                red[pass * p.otcP + tid] = gbacc[pass];
+            }
         }
+        __syncthreads();
+        for (int f = tid; f < nou; f += BR_THREADS) slab[(int64_t)nin * ncols + f] = red[f];
     }
 }
 
@@ -548,11 +581,14 @@ int fgnn_mpconv_backward_resident(const fgnn_mpconv_desc* d, const void* x, cons
     const int NPASS = (ncols + BR_PASS_COLS - 1) / BR_PASS_COLS;
     const int KS = Kpad / 4;
     const int PT = KS == 32 ? 30 : 18;
+    const int otp = BR_PASS_COLS / d->net;
+    const int otcP = otp < d->nou ? otp : d->nou;                      // channels per pass slice
+    if (NPASS > 1 && d->nou % otp != 0) BR_REJECT(21);
     const int XQ = (d->nin * d->N + BR_THREADS - 1) / BR_THREADS;
-    const int GQ = (d->M * d->nou + BR_THREADS - 1) / BR_THREADS;
+    const int GQ = (d->M * otcP + BR_THREADS - 1) / BR_THREADS;
     if (XQ + GQ > PT) BR_REJECT(12);
     if (mk * d->net > BR_THREADS * BR_EPT || mk > BR_THREADS) BR_REJECT(13);
-    if (d->M * d->nou > BR_THREADS * BR_APT * 4 || (d->M * d->nou) % 4 != 0) BR_REJECT(14);
+    if (d->M * otcP > BR_THREADS * BR_APT * 4 || otcP % 4 != 0 || d->nou % 4 != 0) BR_REJECT(14);
     int et_mode;
     if (d->net == 1) {
         if (!((d->et_sk == 1 || d->k == 1) && (d->et_sm == d->k || d->M == 1))) BR_REJECT(15);
@@ -575,17 +611,20 @@ int fgnn_mpconv_backward_resident(const fgnn_mpconv_desc* d, const void* x, cons
     p.Npad = Npad; p.Kpad = Kpad;
     p.XS = (Kpad + 29) / 32 * 32 + 2;
     p.PS = BR_PASS_COLS + 4;
-    p.GS = fgnn_round_up(d->nou, 4) + 4;
+    p.GS = otcP + 4;
+    p.otcP = otcP;
     if ((int64_t)d->M * p.GS >= (1 << 23)) BR_REJECT(17);
     p.cl_in = cl_in; p.cl_y = cl_y; p.et_mode = et_mode; p.XQ = XQ;
-    p.fast_bias = (cl_y && BR_THREADS % d->nou == 0) ? 1 : 0;
+    p.fast_bias = (cl_y && BR_THREADS % otcP == 0) ? 1 : 0;
     { const char* e = getenv("FGNN_DBG"); p.dbg = e ? atoi(e) : 0; }
     p.xdiv = cl_in ? d->nin : d->N;
-    p.ydiv = cl_y ? d->nou : d->M;
+    p.ydiv = cl_y ? otcP : d->M;
     if (p.xdiv == 1 || p.ydiv == 1) BR_REJECT(18);
     p.xmagic = (unsigned)((0x100000000ULL + p.xdiv - 1) / p.xdiv);
     p.mkmagic = mk == 1 ? 0u : (unsigned)((0x100000000ULL + mk - 1) / mk);
     p.ymagic = (unsigned)((0x100000000ULL + p.ydiv - 1) / p.ydiv);
+    p.y4magic = otcP / 4 == 1 ? 0u : (unsigned)((0x100000000ULL + otcP / 4 - 1) / (otcP / 4));
+    if (cl_y && otcP / 4 == 1) BR_REJECT(22);
     int off = 0;
     p.off_xs = off;  off += Npad * p.XS;                    off = fgnn_round_up(off, 4);
     p.off_pb = off;  off += Npad * p.PS;                    off = fgnn_round_up(off, 4);
