@@ -30,6 +30,7 @@ import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
 F32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_*_f32 = the f32 vector rate (155 TF measured)
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA
 
 
 def parse():
@@ -187,16 +188,23 @@ def main():
                    'frac': round(gbs / HBM_PEAK_GBS, 4), 'traffic': None}
             mfma = {'bound': 'mfma', 'achieved': round(tfs, 2), 'peak': F32_MFMA_PEAK_TFLOPS,
                     'unit': 'TFLOP/s', 'frac': round(tfs / F32_MFMA_PEAK_TFLOPS, 4), 'traffic': None}
-            # The kernels multiply in exact f32 on the matrix cores (v_mfma_f32_16x16x4_f32).  With f32
-            # storage the operator's arithmetic intensity (42 FLOP/B at the LDPC shapes)
-            # is above the f32 ridge (157 TF / 8 TB/s = 20): the MFMA roof binds; with bf16 storage
-            # (AI 80 vs the same f32-MFMA roof... still MFMA) the HBM figure is reported alongside.
-            roofline = dict(mfma)
+            # Which roof binds: the f32-MFMA kernels (exact v_mfma_f32_16x16x4_f32; also used with bf16
+            # storage in the backward) sit above the f32 ridge (AI 42-80 FLOP/B vs 157 TF / 8 TB/s = 20):
+            # MFMA-bound.  The bf16-MFMA forward (mpconv_fwd_b16_kernel, AI ~80 << bf16 ridge ~312) is
+            # HBM-bound.  The other figure is reported alongside.
+            if 'b16' in sym:
+                mfma['peak'] = BF16_MFMA_PEAK_TFLOPS
+                mfma['frac'] = round(tfs / BF16_MFMA_PEAK_TFLOPS, 4)
+                roofline = dict(hbm)
+                other = ('mfma', mfma)
+            else:
+                roofline = dict(mfma)
+                other = ('hbm', hbm)
             roofline.update({'kernel': sym, 'launches_per_step': r['launches'],
                              'avg_launch_us': round(avg_ms * 1e3, 2),
                              'algorithmic_bytes_per_launch': r['bytes'] // r['launches'],
                              'algorithmic_flops_per_launch': r['flops'] // r['launches'],
-                             'hbm': hbm})
+                             other[0]: other[1]})
     fence()
 
     if rank == 0:

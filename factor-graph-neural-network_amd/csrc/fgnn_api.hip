@@ -10,7 +10,17 @@ void fgnn_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
+static thread_local char g_kernel[160] = "";
+
+void fgnn_note_kernel(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_kernel, sizeof(g_kernel), fmt, ap);
+    va_end(ap);
+}
+
 extern "C" const char* fgnn_last_error(void) { return g_err; }
+extern "C" const char* fgnn_last_kernel(void) { return g_kernel; }
 extern "C" int fgnn_abi_version(void) { return 1; }
 
 // x read once, etype read once, indices read once (int64 as passed; a batch-shared

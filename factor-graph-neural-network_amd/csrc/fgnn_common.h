@@ -29,6 +29,7 @@ __device__ __forceinline__ void fgnn_st(bf16_t* p, float v) {
 
 // ---- host-side error plumbing ---------------------------------------------------------
 void fgnn_set_error(const char* fmt, ...);
+void fgnn_note_kernel(const char* fmt, ...);   // records which kernel a dispatch chose (fgnn_last_kernel)
 #define FGNN_FAIL(code, ...) do { fgnn_set_error(__VA_ARGS__); return (code); } while (0)
 
 static inline int fgnn_round_up(int v, int m) { return (v + m - 1) / m * m; }

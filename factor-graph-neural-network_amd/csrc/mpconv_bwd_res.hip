@@ -657,6 +657,8 @@ int fgnn_mpconv_backward_resident(const fgnn_mpconv_desc* d, const void* x, cons
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(bres_transpose_kernel, dim3((ncols + 31) / 32, (d->nin + 31) / 32), dim3(256), 0, st,
                        filters, Wt, d->nin, ncols);
+    fgnn_note_kernel("mpconv_bwd_res_kernel<%s, %d, %d, %d, %s>", d->dtype ? "bf16_t" : "float", d->net, KS, NPASS,
+                     (KS == 16 && NPASS <= 2) ? "true" : "false");
     void* args[] = {(void*)&p};
     hipError_t e = hipLaunchKernel(fn, dim3(grid), dim3(BR_THREADS), args, lds, st);
     if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "mpconv resident backward launch: %s", hipGetErrorString(e));

@@ -384,6 +384,8 @@ extern "C" int fgnn_mpconv_forward(const fgnn_mpconv_desc* d, const void* x, con
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "hipFuncSetAttribute(%d B LDS): %s", lds, hipGetErrorString(e));
     }
+    fgnn_note_kernel("mpconv_fwd_kernel<%s, %d, %d>", d->dtype ? "bf16_t" : "float",
+                     (d->net == 1 || d->net == 4 || d->net == 16) ? d->net : 0, d->agg);
     const int grid = d->B < 4096 ? d->B : 4096;
     void* args[] = {(void*)&p};
     hipError_t e = hipLaunchKernel(fn, dim3(grid), dim3(FGNN_THREADS), args, lds, (hipStream_t)stream);

@@ -473,6 +473,8 @@ int fgnn_mpconv_forward_b16(const fgnn_mpconv_desc* d, const void* x, const int6
     if (wg_per_cu < 1) wg_per_cu = 1;
     int grid = 256 * wg_per_cu;
     if (grid > d->B) grid = d->B;
+    fgnn_note_kernel("mpconv_fwd_b16_kernel<%d, %d, %d, %d, %d, %d>", d->net, d->agg, KSB, SWP, NPASS,
+                     (d->agg == FGNN_AGG_MAX && d->net == 4 && (d->k == 3 || d->k == 6)) ? d->k : 0);
     void* args[] = {(void*)&p};
     hipError_t e = hipLaunchKernel(fn, dim3(grid), dim3(B16_THREADS), args, lds, (hipStream_t)stream);
     if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "mpconv bf16 forward launch: %s", hipGetErrorString(e));

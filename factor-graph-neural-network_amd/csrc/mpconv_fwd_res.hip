@@ -445,6 +445,7 @@ int fgnn_mpconv_forward_resident(const fgnn_mpconv_desc* d, const void* x, const
     const int wg_per_cu = lds <= 76 * 1024 ? 2 : 1;
     int grid = 256 * wg_per_cu;
     if (grid > d->B) grid = d->B;
+    fgnn_note_kernel("mpconv_fwd_res_kernel<%s, %d, %d, %d, %d, %d>", d->dtype ? "bf16_t" : "float", d->net, d->agg, KS, SWP, NPASS);
     void* args[] = {(void*)&p};
     hipError_t e = hipLaunchKernel(fn, dim3(grid), dim3(RES_THREADS), args, lds, (hipStream_t)stream);
     if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "mpconv resident forward launch: %s", hipGetErrorString(e));

@@ -28,7 +28,8 @@ class KernelTimer:
         start.record()
         launch()
         end.record()
-        self.records.append((symbol, nbytes, nflops, start, end))
+        name = _hip.lib().fgnn_last_kernel().decode() or symbol     # the kernel the dispatch chose
+        self.records.append((name, nbytes, nflops, start, end))
 
     def summary(self):
         torch.cuda.synchronize()

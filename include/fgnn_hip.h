@@ -105,6 +105,8 @@ int fgnn_linear_wgrad(const void* x, const void* gy, int64_t R, int32_t Cin, int
 int64_t fgnn_linear_wgrad_workspace_bytes(int64_t R, int32_t Cin, int32_t Cout);
 
 const char* fgnn_last_error(void);
+/* Name (as rocprofv3 prints it) of the kernel the calling thread's last forward/backward dispatched to. */
+const char* fgnn_last_kernel(void);
 int fgnn_abi_version(void);
 
 #ifdef __cplusplus
