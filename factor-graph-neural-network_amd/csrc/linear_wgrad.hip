@@ -10,6 +10,7 @@
 // and x in LDS (row-major, as in memory) and accumulates its partial gW with exact-f32 MFMA; partials go
 // to a workspace slab per workgroup and a second kernel sums them (no contended atomics).
 #include "fgnn_common.h"
+#include <stdlib.h>
 
 #define WG_THREADS 256
 #define WG_WAVES 4
@@ -25,6 +26,8 @@ struct WgradParams {
     int Cip, Cop;        // Cin / Cout-chunk padded to 16
     int oc;              // output channels handled per grid.y slice
     int XS, GS;          // LDS row strides (floats), == 16 (mod 32)
+    int nslab;           // slabs per channel slice the workgroups of the vector kernel add into
+    unsigned gmagic, xmagic, omagic;   // ceil(2^32 / chunks-per-row) for gy / x rows; ceil(2^32 / oc)
 };
 
 extern __shared__ __attribute__((aligned(16))) float wg_lds[];
@@ -107,6 +110,152 @@ __global__ __launch_bounds__(WG_THREADS) void linear_wgrad_kernel(const WgradPar
     }
 }
 
+// Vectorised variant for 16-byte-aligned rows (Cin, Cout multiples of 8 for bf16 / 4 for f32): 64-row tiles,
+// 16-byte global loads, and the NEXT tile is prefetched into registers while the current one feeds the
+// matrix cores (issue-early / write-late), so HBM latency hides behind the MFMAs.
+#define WV_ROWS 64
+#define WV_MAXCH 10      // 16-byte chunks per thread per tile: 64 * (Cin + oc) * elem / 16 / 256 <= 10
+#define WV_NSLAB 32
+
+template <typename T, int TMAX, int MAXCH>
+__global__ __launch_bounds__(WG_THREADS) void linear_wgrad_vec_kernel(const WgradParams p) {
+    constexpr int EPC = 16 / sizeof(T);                // elements per 16-byte chunk (8 bf16 / 4 f32)
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int li = lane & 15, lk = lane >> 4;
+    const int o_base = blockIdx.y * p.oc;
+    float* gs = wg_lds;                                // [WV_ROWS][GS]
+    float* xs = wg_lds + WV_ROWS * p.GS;               // [WV_ROWS][XS]
+    const T* xg = static_cast<const T*>(p.x);
+    const T* gg = static_cast<const T*>(p.gy);
+    const int nct = p.Cip / 16, not_ = p.Cop / 16;
+    const int ntiles = nct * not_;
+    f32x4 acc[TMAX];
+#pragma unroll
+    for (int t = 0; t < TMAX; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float bsum = 0.f;
+    for (int f = tid; f < WV_ROWS * p.GS; f += WG_THREADS) gs[f] = 0.f;
+    for (int f = tid; f < WV_ROWS * p.XS; f += WG_THREADS) xs[f] = 0.f;
+
+    // chunk space of a tile: [0, GCH) are gy chunks (row, o8), [GCH, GCH + XCH) are x chunks (row, c8);
+    // (row, col) of a chunk by multiply-high with host-computed reciprocals (no integer division)
+    const int gpr = p.oc / EPC, xpr = p.Cin / EPC;     // chunks per row
+    const int GCH = WV_ROWS * gpr, XCH = WV_ROWS * xpr;
+    const int r_begin = blockIdx.x * p.rows_per_wg;
+    const int r_end = min(p.R, r_begin + p.rows_per_wg);
+    uint4 pre[MAXCH];
+    auto prefetch = [&](int r0, int t) {
+#pragma unroll
+        for (int q = 0; q < MAXCH; ++q) {
+            const unsigned f = t + q * WG_THREADS;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if ((int)f < GCH) {
+                const unsigned r = gpr == 1 ? f : __umulhi(f, p.gmagic), c = f - r * gpr;
+                if (r0 + (int)r < r_end) v = *reinterpret_cast<const uint4*>(gg + (int64_t)(r0 + r) * p.Cout + o_base + c * EPC);
+            } else if ((int)f < GCH + XCH) {
+                const unsigned g = f - GCH, r = xpr == 1 ? g : __umulhi(g, p.xmagic), c = g - r * xpr;
+                if (r0 + (int)r < r_end) v = *reinterpret_cast<const uint4*>(xg + (int64_t)(r0 + r) * p.Cin + c * EPC);
+            }
+            pre[q] = v;
+        }
+    };
+    auto unpack_store = [&](float* dst, const uint4& v) {
+        if constexpr (sizeof(T) == 2) {
+            f32x4 a = {__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u),
+                       __uint_as_float(v.y << 16), __uint_as_float(v.y & 0xffff0000u)};
+            f32x4 b = {__uint_as_float(v.z << 16), __uint_as_float(v.z & 0xffff0000u),
+                       __uint_as_float(v.w << 16), __uint_as_float(v.w & 0xffff0000u)};
+            *reinterpret_cast<f32x4*>(dst) = a;
+            *reinterpret_cast<f32x4*>(dst + 4) = b;
+        } else {
+            f32x4 a = {__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
+            *reinterpret_cast<f32x4*>(dst) = a;
+        }
+    };
+    auto commit = [&](int t) {
+#pragma unroll
+        for (int q = 0; q < MAXCH; ++q) {
+            const unsigned f = t + q * WG_THREADS;
+            if ((int)f < GCH) {
+                const unsigned r = gpr == 1 ? f : __umulhi(f, p.gmagic), c = f - r * gpr;
+                unpack_store(gs + r * p.GS + c * EPC, pre[q]);
+            } else if ((int)f < GCH + XCH) {
+                const unsigned g = f - GCH, r = xpr == 1 ? g : __umulhi(g, p.xmagic), c = g - r * xpr;
+                unpack_store(xs + r * p.XS + c * EPC, pre[q]);
+            }
+        }
+    };
+    // bias column sums: thread t owns column t % oc and rows t / oc, t / oc + 256 / oc, ... of every tile
+    const int bcol = tid & (p.oc - 1), brow0 = __umulhi((unsigned)tid, p.omagic), brstep = WG_THREADS / p.oc;
+    if (r_begin < r_end) prefetch(r_begin, tid);
+    for (int r0 = r_begin; r0 < r_end; r0 += WV_ROWS) {
+        __syncthreads();                               // the previous tile's MFMAs are done with gs / xs
+        int t = tid;
+        asm volatile("" : "+v"(t));                    // keep the chunk address math out of long-lived registers
+        commit(t);
+        __syncthreads();
+        if (r0 + WV_ROWS < r_end) prefetch(r0 + WV_ROWS, t);
+        if (p.oc >= 1) {
+            float sgy = 0.f;
+            for (int r = (p.oc == 1 ? tid : brow0); r < WV_ROWS; r += brstep) sgy += gs[r * p.GS + bcol];
+            bsum += sgy;
+        }
+        // wave's tiles u = wave + 4t: when nct == 4 they share the x column tile (ctile = wave): the B
+        // fragment is read once per k-step and reused for every accumulator
+        const int li_ = t & 15, lk_ = (t >> 4) & 3;
+        if (nct == WG_WAVES) {
+            const float* bp = xs + lk_ * p.XS + wave * 16 + li_;
+            const float* ap = gs + lk_ * p.GS + li_;
+#pragma unroll 4
+            for (int kk = 0; kk < WV_ROWS / 4; ++kk) {
+                const float bfr = bp[kk * 4 * p.XS];
+#pragma unroll
+                for (int tt = 0; tt < TMAX; ++tt)
+                    if (tt < not_)
+                        acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[kk * 4 * p.GS + tt * 16], bfr, acc[tt], 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int tt = 0; tt < TMAX; ++tt) {
+                const int u = wave + WG_WAVES * tt;
+                if (u < ntiles) {
+                    const int ot = u / nct, ctile = u - ot * nct;
+                    const float* ap = gs + lk_ * p.GS + ot * 16 + li_;
+                    const float* bp = xs + lk_ * p.XS + ctile * 16 + li_;
+                    f32x4 a = acc[tt];
+#pragma unroll
+                    for (int kk = 0; kk < WV_ROWS / 4; ++kk)
+                        a = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[kk * 4 * p.GS], bp[kk * 4 * p.XS], a, 0, 0, 0);
+                    acc[tt] = a;
+                }
+            }
+        }
+    }
+    const int64_t slab_len = (int64_t)p.Cop * p.Cip + p.Cop;
+    // few slabs, many workgroups: workgroup w adds into slab w % nslab (zeroed by the host, 16 workgroups
+    // per address at most), so the second kernel sums 32 slabs instead of 512
+    float* slab = p.ws + ((int64_t)blockIdx.y * p.nslab + blockIdx.x % p.nslab) * slab_len;
+#pragma unroll
+    for (int t = 0; t < TMAX; ++t) {
+        const int u = wave + WG_WAVES * t;
+        if (u < ntiles) {
+            const int ot = u / nct, ctile = u - ot * nct;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                atomicAdd(&slab[(int64_t)(ot * 16 + 4 * lk + r) * p.Cip + ctile * 16 + li], acc[t][r]);
+        }
+    }
+    {   // fold the 256/oc per-thread partials of each bias column
+        __syncthreads();
+        float* red = gs;
+        if (tid < p.Cop) red[tid] = 0.f;
+        __syncthreads();
+        atomicAdd(&red[bcol], bsum);
+        __syncthreads();
+        if (tid < p.oc) atomicAdd(&slab[(int64_t)p.Cop * p.Cip + tid], red[tid]);
+    }
+}
+
 // out[o][c] += sum_w slab[w][o][c]; gb[o] += sum_w slab[w][bias o]
 __global__ __launch_bounds__(256) void linear_wgrad_reduce_kernel(const float* __restrict__ ws, int nslab_x,
                                                                   int Cin, int Cout, int Cip, int Cop, int oc,
@@ -148,10 +297,10 @@ static int wgrad_plan(int R, int Cin, int Cout, WgradParams* p, int* gx, int* gy
     p->XS = (p->Cip % 32 == 0) ? p->Cip + 16 : p->Cip;
     p->GS = (p->Cop % 32 == 0) ? p->Cop + 16 : p->Cop;
     *gy_ = (Cout + oc - 1) / oc;
-    int g = 1024 / *gy_;
+    int g = (getenv("FGNN_WG_GRID") ? atoi(getenv("FGNN_WG_GRID")) : 512) / *gy_;
     if (g < 1) g = 1;
     int rows = (R + g - 1) / g;
-    rows = fgnn_round_up(rows < WG_ROWS ? WG_ROWS : rows, WG_ROWS);
+    rows = fgnn_round_up(rows < 64 ? 64 : rows, 64);      // multiple of both kernels' row tiles
     p->rows_per_wg = rows;
     *gx = (R + rows - 1) / rows;
     return 0;
@@ -180,8 +329,37 @@ extern "C" int fgnn_linear_wgrad(const void* x, const void* gy, int64_t R, int C
     if (workspace_bytes < need) FGNN_FAIL(FGNN_EINVAL, "linear_wgrad: workspace %lld < %lld bytes",
                                           (long long)workspace_bytes, (long long)need);
     p.x = x; p.gy = gy; p.ws = (float*)workspace; p.R = (int)R; p.Cin = Cin; p.Cout = Cout; p.dtype = dtype;
-    const int lds = WG_ROWS * (p.XS + p.GS) * 4;
-    void* fn = dtype == FGNN_F32 ? (void*)linear_wgrad_kernel<float> : (void*)linear_wgrad_kernel<bf16_t>;
+    const int epc = dtype == FGNN_F32 ? 4 : 8;
+    const bool vec = Cin % epc == 0 && Cout % epc == 0 && p.oc % epc == 0 && Cout % p.oc == 0 &&
+                     (WV_ROWS * (Cin + p.oc) / epc) <= WG_THREADS * WV_MAXCH &&
+                     ((uintptr_t)x % 16 == 0) && ((uintptr_t)gy % 16 == 0);
+    const int rows_tile = vec ? WV_ROWS : WG_ROWS;
+    {
+        const unsigned gpr = p.oc / epc > 0 ? p.oc / epc : 1, xpr = Cin / epc > 0 ? Cin / epc : 1;
+        p.gmagic = gpr == 1 ? 0u : (unsigned)((0x100000000ULL + gpr - 1) / gpr);
+        p.xmagic = xpr == 1 ? 0u : (unsigned)((0x100000000ULL + xpr - 1) / xpr);
+        p.omagic = p.oc == 1 ? 0u : (unsigned)((0x100000000ULL + p.oc - 1) / p.oc);
+    }
+    const int lds = rows_tile * (p.XS + p.GS) * 4;
+    void* fn;
+    const int ntiles = (p.Cop / 16) * (p.Cip / 16);
+    const int nchunks = (WV_ROWS * (Cin + p.oc) / epc + WG_THREADS - 1) / WG_THREADS;
+    int nslab_x = gx;
+    if (vec) {
+        const int tm = (ntiles + WG_WAVES - 1) / WG_WAVES;
+#define WV_PICK(T) (tm <= 4 && nchunks <= 4 ? (void*)linear_wgrad_vec_kernel<T, 4, 4> : \
+                                              (void*)linear_wgrad_vec_kernel<T, 16, 10>)
+        fn = dtype == FGNN_F32 ? WV_PICK(float) : WV_PICK(bf16_t);
+#undef WV_PICK
+        p.nslab = gx < WV_NSLAB ? gx : WV_NSLAB;
+        nslab_x = p.nslab;
+        const int64_t slab_len0 = (int64_t)p.Cop * p.Cip + p.Cop;
+        hipError_t em = hipMemsetAsync(p.ws, 0, (size_t)gyn * p.nslab * slab_len0 * 4, (hipStream_t)stream);
+        if (em != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "linear_wgrad memset: %s", hipGetErrorString(em));
+    } else {
+        p.nslab = gx;
+        fn = dtype == FGNN_F32 ? (void*)linear_wgrad_kernel<float> : (void*)linear_wgrad_kernel<bf16_t>;
+    }
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
@@ -191,7 +369,7 @@ extern "C" int fgnn_linear_wgrad(const void* x, const void* gy, int64_t R, int C
     if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "linear_wgrad launch: %s", hipGetErrorString(e));
     const int64_t slab_len = (int64_t)p.Cop * p.Cip + p.Cop;
     hipLaunchKernelGGL(linear_wgrad_reduce_kernel, dim3((unsigned)((slab_len + 255) / 256), gyn), dim3(256), 0,
-                       (hipStream_t)stream, p.ws, gx, Cin, Cout, p.Cip, p.Cop, p.oc, gW, gb);
+                       (hipStream_t)stream, p.ws, nslab_x, Cin, Cout, p.Cip, p.Cop, p.oc, gW, gb);
     e = hipGetLastError();
     if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "linear_wgrad reduce launch: %s", hipGetErrorString(e));
     return FGNN_OK;
