@@ -21,6 +21,7 @@ AGG_CODES = {'max': AGG_MAX, 'softmax': AGG_LSE, 'mean': AGG_MEAN}
 
 EXPORTS = ('fgnn_mpconv_forward', 'fgnn_mpconv_backward', 'fgnn_mpconv_forward_lds_bytes',
            'fgnn_mpconv_backward_workspace_bytes', 'fgnn_linear_wgrad', 'fgnn_linear_wgrad_workspace_bytes',
+           'fgnn_instnorm_forward', 'fgnn_instnorm_backward',
            'fgnn_mpconv_algorithmic_bytes', 'fgnn_last_error', 'fgnn_last_kernel', 'fgnn_abi_version')
 
 
@@ -66,6 +67,10 @@ def lib():
     L.fgnn_linear_wgrad.argtypes = [vp, vp, i64, i32, i32, i32, vp, vp, vp, i64, vp]
     L.fgnn_linear_wgrad_workspace_bytes.restype = i64
     L.fgnn_linear_wgrad_workspace_bytes.argtypes = [i64, i32, i32]
+    L.fgnn_instnorm_forward.restype = ctypes.c_int
+    L.fgnn_instnorm_forward.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp]
+    L.fgnn_instnorm_backward.restype = ctypes.c_int
+    L.fgnn_instnorm_backward.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, vp]
     L.fgnn_last_error.restype = ctypes.c_char_p
     L.fgnn_last_kernel.restype = ctypes.c_char_p
     L.fgnn_abi_version.restype = ctypes.c_int

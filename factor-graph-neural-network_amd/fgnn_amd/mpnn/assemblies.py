@@ -68,8 +68,8 @@ class factor_mpnn(torch.nn.Module):
                 elif nin <= max_mpnn_dim and nout <= max_mpnn_dim:
                     m = mp_conv_v2(nin, nout, netype_list[j])
                 else:
-                    m = torch.nn.Sequential(_Conv(nin, nout, 1), NodeInstanceNorm(),
-                                            torch.nn.ReLU(inplace=True))
+                    m = torch.nn.Sequential(_Conv(nin, nout, 1), NodeInstanceNorm(relu=True),
+                                            torch.nn.Identity())
                 self.add_module('mp_nn_%d_%d' % (L, j), m)
                 row.append(m)
             self.mp_nn_modules.append(row)
@@ -160,8 +160,8 @@ class FactorNN(torch.nn.Module):
             self.v2f_modules.append(v2f_row)
         final_dim = nclass if nclass > 2 else 1
         self.final_classifier = torch.nn.Sequential(
-            _Conv(dim_mapping_list[-1], 128, 1), NodeInstanceNorm(),
-            torch.nn.ReLU(inplace=True), _Conv(128, final_dim, 1, bias=True))
+            _Conv(dim_mapping_list[-1], 128, 1), NodeInstanceNorm(relu=True),
+            torch.nn.Identity(), _Conv(128, final_dim, 1, bias=True))
 
     def mpnn_forward(self, mpnn, node_feature, nn_idx, efeature):
         return _call(mpnn, node_feature, nn_idx, efeature)

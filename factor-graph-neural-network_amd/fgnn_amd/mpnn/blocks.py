@@ -41,7 +41,8 @@ class iid_mapping_bn(torch.nn.Module):
 class iid_mapping_in(torch.nn.Module):
     def __init__(self, nin, nout, bias=True):
         super().__init__()
-        self.main = _conv_norm_act(nin, nout, NodeInstanceNorm(), torch.nn.ReLU(), bias)
+        # InstanceNorm and the ReLU behind it run as one kernel; Identity keeps the Sequential's indices
+        self.main = _conv_norm_act(nin, nout, NodeInstanceNorm(relu=True), torch.nn.Identity(), bias)
 
     def forward(self, x):
         return self.main(x)

@@ -41,6 +41,10 @@ class _RowLinear(torch.autograd.Function):
             grows = gy @ (weight if weight.dtype == gy.dtype else weight.to(gy.dtype))
         R, cin = rows.shape
         cout = weight.shape[0]
+        if cin * cout >= 256 * 256:                     # square 256-wide maps: rocBLAS is ahead there
+            gw = (gy.t() @ rows).float()
+            gb = gy.float().sum(0) if ctx.has_bias else None
+            return grows, gw.to(weight.dtype), (gb.to(weight.dtype) if gb is not None else None)
         L = _hip.lib()
         gw = torch.zeros((cout, cin), device=rows.device, dtype=torch.float32)
         gb = torch.zeros((cout,), device=rows.device, dtype=torch.float32) if ctx.has_bias else None
@@ -75,8 +79,39 @@ class PointwiseConv2d(torch.nn.Conv2d):
         return y.view(B, H, W, self.out_channels).permute(0, 3, 1, 2)
 
 
+class _InstNormAct(torch.autograd.Function):
+    """act(InstanceNorm(x)) over the node axis of a channel-fastest [B,C,N,1] tensor: one HIP kernel
+    forward, one backward (csrc/instnorm.hip); only x is saved."""
+
+    @staticmethod
+    def forward(ctx, x, relu):
+        B, C, N, _ = x.shape
+        rows = x.permute(0, 2, 3, 1)                    # [B,N,1,C]
+        if not rows.is_contiguous():
+            rows = rows.contiguous()
+        y = torch.empty_like(rows)
+        _hip.check(_hip.lib().fgnn_instnorm_forward(_hip._ptr(rows), _hip._ptr(y), B, N, C,
+                                                    _hip.dtype_code(rows), int(relu), _hip.stream_ptr()))
+        ctx.save_for_backward(rows)
+        ctx.relu = relu
+        return y.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, gy):
+        (rows,) = ctx.saved_tensors
+        B, N, _, C = rows.shape
+        g = gy.permute(0, 2, 3, 1)
+        if not g.is_contiguous() or g.dtype != rows.dtype:
+            g = g.to(rows.dtype).contiguous()
+        gx = torch.empty_like(rows)
+        _hip.check(_hip.lib().fgnn_instnorm_backward(_hip._ptr(rows), _hip._ptr(g), _hip._ptr(gx), B, N, C,
+                                                     _hip.dtype_code(rows), int(ctx.relu), _hip.stream_ptr()))
+        return gx.permute(0, 3, 1, 2), None
+
+
 class NodeInstanceNorm(torch.nn.Module):
-    """InstanceNorm2d(affine=False, no running stats) over the node axis of [B,C,N,1], any strides.
+    """InstanceNorm2d(affine=False, no running stats) over the node axis of [B,C,N,1], any strides,
+    optionally fused with the ReLU that follows it in every reference use (``relu=True``).
 
     A single node (the LDPC hyper-factor, factor_mpnn_sp.py:77,140) normalises to exactly 0
     — (x-mean)/sqrt(0+eps) — which is what the reference's torch-1.0 era computed and what
@@ -85,9 +120,16 @@ class NodeInstanceNorm(torch.nn.Module):
     """
     eps = 1e-5
 
+    def __init__(self, relu=False):
+        super().__init__()
+        self.relu = relu
+
     def forward(self, x):
         if x.shape[2] * x.shape[3] == 1:
             return torch.zeros_like(x)
+        if x.is_cuda and x.shape[3] == 1 and x.dtype in (torch.float32, torch.bfloat16):
+            return _InstNormAct.apply(x, self.relu)
         xf = x.float()                                   # statistics in f32 also for bf16 activations
         var, mean = torch.var_mean(xf, dim=(2, 3), unbiased=False, keepdim=True)
-        return ((xf - mean) * torch.rsqrt(var + self.eps)).to(x.dtype)
+        y = ((xf - mean) * torch.rsqrt(var + self.eps)).to(x.dtype)
+        return torch.relu(y) if self.relu else y

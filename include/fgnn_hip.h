@@ -104,6 +104,16 @@ int fgnn_linear_wgrad(const void* x, const void* gy, int64_t R, int32_t Cin, int
                       float* gW, float* gb, void* workspace, int64_t workspace_bytes, fgnn_stream_t stream);
 int64_t fgnn_linear_wgrad_workspace_bytes(int64_t R, int32_t Cin, int32_t Cout);
 
+/*
+ * InstanceNorm2d(affine=False, eps 1e-5, biased variance) over the node axis, optionally fused with ReLU,
+ * on dense channel-fastest activations x[B][N][C] (the norm of iid_mapping_in, base_model.py:82-90).
+ * backward: gx = d/dx of act(norm(x)) given gy; only x is needed (statistics are recomputed).
+ */
+int fgnn_instnorm_forward(const void* x, void* y, int32_t B, int32_t N, int32_t C, int32_t dtype, int32_t relu,
+                          fgnn_stream_t stream);
+int fgnn_instnorm_backward(const void* x, const void* gy, void* gx, int32_t B, int32_t N, int32_t C,
+                           int32_t dtype, int32_t relu, fgnn_stream_t stream);
+
 const char* fgnn_last_error(void);
 /* Name (as rocprofv3 prints it) of the kernel the calling thread's last forward/backward dispatched to. */
 const char* fgnn_last_kernel(void);

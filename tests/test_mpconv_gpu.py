@@ -181,3 +181,27 @@ def test_pointwise_conv_gradients_vs_torch(cin, cout, dtype, dev):
     assert H.rel_err(mine.weight.grad, ref.weight.grad) <= tol
     assert H.rel_err(mine.bias.grad, ref.bias.grad) <= tol
     assert H.rel_err(xm.grad.float(), xr.grad) <= tol
+
+
+@pytest.mark.parametrize('C,N', [(64, 96), (256, 48), (128, 96), (10, 7), (64, 2)])
+@pytest.mark.parametrize('relu', [False, True])
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_instance_norm_kernel_vs_torch(C, N, relu, dtype, dev):
+    """Fused InstanceNorm(+ReLU) kernel (csrc/instnorm.hip) forward and backward against
+    torch.nn.functional.instance_norm in f32 on the same inputs."""
+    from fgnn_amd.mpnn import NodeInstanceNorm
+    g = torch.Generator().manual_seed(C * 100 + N)
+    B = 5
+    x = (torch.randn(B, C, N, 1, generator=g) * 2 + 0.5).to(dtype)
+    gy = torch.randn(B, C, N, 1, generator=g).to(dtype)
+    xr = x.detach().float().clone().requires_grad_(True)
+    ref = torch.nn.functional.instance_norm(xr, eps=1e-5)
+    if relu:
+        ref = torch.relu(ref)
+    ref.backward(gy.float())
+    xm = x.detach().clone().to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    y = NodeInstanceNorm(relu=relu)(xm)
+    y.backward(gy.to(dev))
+    tol = 2e-5 if dtype == torch.float32 else 2e-2
+    assert H.rel_err(y.float(), ref) <= tol
+    assert H.rel_err(xm.grad.float(), xr.grad) <= tol * 5
