@@ -8,7 +8,7 @@ Mirrors (names, constructor signatures, state_dict keys) of
 import torch
 
 from .message_op import base_mp_nn, mp_conv_type, mp_conv_v2
-from .pointwise import NodeInstanceNorm, PointwiseConv2d
+from .pointwise import BatchNormAct2d, NodeInstanceNorm, PointwiseConv2d
 
 
 def _conv_norm_act(cin, cout, norm, act, bias=True):
@@ -31,8 +31,8 @@ class iid_mapping(torch.nn.Module):
 class iid_mapping_bn(torch.nn.Module):
     def __init__(self, nin, nout, bias=True, bn=True):
         super().__init__()
-        self.main = _conv_norm_act(nin, nout, torch.nn.BatchNorm2d(nout),
-                                   torch.nn.ReLU(inplace=True), bias)
+        # BatchNorm and its ReLU run fused; Identity keeps the Sequential's indices (main.0 conv, main.1 bn)
+        self.main = _conv_norm_act(nin, nout, BatchNormAct2d(nout, slope=0.0), torch.nn.Identity(), bias)
 
     def forward(self, x):
         return self.main(x)
@@ -70,10 +70,10 @@ class mp_conv_residual(base_mp_nn):
                  with_residual=True, with_hop=False, aggregator='max', nout=None):
         super().__init__()
         nout = nin if nout is None else nout
-        leaky = lambda: torch.nn.LeakyReLU(inplace=True)
-        self.conv1 = _conv_norm_act(nin, nmed, torch.nn.BatchNorm2d(nmed), leaky())
+        # conv + (BatchNorm + LeakyReLU fused) ; Identity keeps the reference's Sequential indices
+        self.conv1 = _conv_norm_act(nin, nmed, BatchNormAct2d(nmed, slope=0.01), torch.nn.Identity())
         self.mp_conv = mp_conv_v2(nmed, nmed, netype, extension=extension, aggregtor=aggregator)
-        self.conv2 = _conv_norm_act(nmed, nout, torch.nn.BatchNorm2d(nout), leaky())
+        self.conv2 = _conv_norm_act(nmed, nout, BatchNormAct2d(nout, slope=0.01), torch.nn.Identity())
         self.with_residual = with_residual
         self.with_hop = with_hop
 

@@ -60,7 +60,9 @@ class mp_conv_v2(base_mp_nn):
         self.filters = torch.nn.Parameter(
             torch.empty(rows, nou * nedge_types, dtype=torch.float32).uniform_(-0.01, 0.01))
         self.bias = torch.nn.Parameter(torch.empty(nou).uniform_(0, 0.05)) if bias else None
-        self.bn = torch.nn.BatchNorm2d(nou) if bn else None
+        from .pointwise import BatchNormAct2d
+        # slope 1.0 = plain BatchNorm2d; forward() switches the fused ReLU on when the activation is ReLU
+        self.bn = BatchNormAct2d(nou, slope=1.0) if bn else None
         if isinstance(activation_fn, torch.nn.Module):
             self.activation_fn = activation_fn
         elif activation_fn == 'relu':
@@ -101,6 +103,11 @@ class mp_conv_v2(base_mp_nn):
         z = ops.mpconv(x, nn_idx, etype, self.filters, self.bias, self.nou,
                        self.nedge_types, ext, agg)
         if self.bn is not None:
+            if plain_relu:                      # BatchNorm + ReLU in one fused kernel pair
+                self.bn.slope = 0.0
+                z = self.bn(z)
+                self.bn.slope = 1.0
+                return z
             z = self.bn(z)
         if self.activation_fn is not None:
             z = self.activation_fn(z)

@@ -133,3 +133,80 @@ class NodeInstanceNorm(torch.nn.Module):
         var, mean = torch.var_mean(xf, dim=(2, 3), unbiased=False, keepdim=True)
         y = ((xf - mean) * torch.rsqrt(var + self.eps)).to(x.dtype)
         return torch.relu(y) if self.relu else y
+
+
+class _BatchNormAct(torch.autograd.Function):
+    """Train-mode BatchNorm + LeakyReLU(slope) on channel-fastest rows [R, C] (csrc/bnact.hip)."""
+
+    @staticmethod
+    def forward(ctx, rows, weight, bias, running_mean, running_var, momentum, eps, slope):
+        from .. import ops
+        L = _hip.lib()
+        R, C = rows.shape
+        dev = rows.device
+        stats = torch.empty((4, C), device=dev, dtype=torch.float32)      # mean, invstd, scale, shift
+        ws = ops._workspace(dev, int(L.fgnn_bn_workspace_bytes(R, C)))
+        dt = _hip.dtype_code(rows)
+        _hip.check(L.fgnn_bn_stats(_hip._ptr(rows), R, C, dt, _hip._ptr(weight), _hip._ptr(bias),
+                                   _hip._ptr(running_mean), _hip._ptr(running_var), momentum, eps,
+                                   _hip._ptr(stats[0]), _hip._ptr(stats[1]), _hip._ptr(stats[2]),
+                                   _hip._ptr(stats[3]), _hip._ptr(ws), ws.numel() * 4, _hip.stream_ptr()))
+        y = torch.empty_like(rows)
+        _hip.check(L.fgnn_bn_apply(_hip._ptr(rows), _hip._ptr(y), R, C, dt, _hip._ptr(stats[2]),
+                                   _hip._ptr(stats[3]), slope, _hip.stream_ptr()))
+        ctx.save_for_backward(rows, weight, bias, stats)
+        ctx.slope = slope
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        from .. import ops
+        rows, weight, bias, stats = ctx.saved_tensors
+        L = _hip.lib()
+        R, C = rows.shape
+        gy = gy.contiguous()
+        if gy.dtype != rows.dtype:
+            gy = gy.to(rows.dtype)
+        gx = torch.empty_like(rows)
+        gw = torch.zeros(C, device=rows.device, dtype=torch.float32)
+        gb = torch.zeros(C, device=rows.device, dtype=torch.float32)
+        ws = ops._workspace(rows.device, int(L.fgnn_bn_workspace_bytes(R, C)))
+        _hip.check(L.fgnn_bn_backward(_hip._ptr(rows), _hip._ptr(gy), _hip._ptr(gx), R, C, _hip.dtype_code(rows),
+                                      _hip._ptr(stats[0]), _hip._ptr(stats[1]), _hip._ptr(weight),
+                                      _hip._ptr(bias), ctx.slope, _hip._ptr(gw), _hip._ptr(gb), _hip._ptr(ws),
+                                      ws.numel() * 4, _hip.stream_ptr()))
+        return gx, gw, gb, None, None, None, None, None
+
+
+class BatchNormAct2d(torch.nn.BatchNorm2d):
+    """``BatchNorm2d`` (same parameters / buffers / state_dict keys) that also applies the activation the
+    reference puts right behind it — ``slope`` 0.01 = LeakyReLU (conv1/conv2 of mp_conv_residual), 0 = ReLU
+    (iid_mapping_bn, mp_conv_v2's own bn) — in one fused HIP kernel pair when training on a ROCm device;
+    everything else (eval mode, CPU, odd channel counts) goes through torch's batch_norm + activation."""
+
+    def __init__(self, num_features, slope=0.0):
+        super().__init__(num_features)
+        self.slope = float(slope)
+
+    def _activate(self, y):
+        if self.slope == 0.0:
+            return torch.relu(y)
+        if self.slope == 1.0:
+            return y
+        return torch.nn.functional.leaky_relu(y, self.slope)
+
+    def forward(self, x):
+        B, C, H, W = x.shape
+        fused = (self.training and x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and
+                 self.track_running_stats and self.affine and
+                 _hip.lib().fgnn_bn_supported(B * H * W, C, _hip.dtype_code(x)))
+        if not fused:
+            return self._activate(super().forward(x))
+        rows = x.permute(0, 2, 3, 1)
+        if not rows.is_contiguous():
+            rows = rows.contiguous()
+        with torch.no_grad():
+            self.num_batches_tracked += 1
+        y = _BatchNormAct.apply(rows.view(B * H * W, C), self.weight, self.bias, self.running_mean,
+                                self.running_var, self.momentum, self.eps, self.slope)
+        return y.view(B, H, W, C).permute(0, 3, 1, 2)

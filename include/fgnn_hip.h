@@ -114,6 +114,25 @@ int fgnn_instnorm_forward(const void* x, void* y, int32_t B, int32_t N, int32_t 
 int fgnn_instnorm_backward(const void* x, const void* gy, void* gx, int32_t B, int32_t N, int32_t C,
                            int32_t dtype, int32_t relu, fgnn_stream_t stream);
 
+/*
+ * Train-mode BatchNorm fused with the LeakyReLU(slope) behind it (slope 0 = ReLU, 1 = none) on dense
+ * channel-fastest x[R][C] (conv1/conv2 blocks mp_nn_residual.py:25-35, mp_conv_v2.bn mp_nn.py:57-58,170-173,
+ * iid_mapping_bn base_model.py:62-79).  torch.nn.BatchNorm2d semantics: biased variance normalises, running
+ * statistics take the unbiased one with `momentum`.  All per-channel vectors are float32 [C].
+ */
+int fgnn_bn_supported(int64_t R, int32_t C, int32_t dtype);
+int64_t fgnn_bn_workspace_bytes(int64_t R, int32_t C);
+int fgnn_bn_stats(const void* x, int64_t R, int32_t C, int32_t dtype, const float* gamma, const float* beta,
+                  float* running_mean, float* running_var, float momentum, float eps, float* mean,
+                  float* invstd, float* scale, float* shift, void* workspace, int64_t workspace_bytes,
+                  fgnn_stream_t stream);
+int fgnn_bn_apply(const void* x, void* y, int64_t R, int32_t C, int32_t dtype, const float* scale,
+                  const float* shift, float slope, fgnn_stream_t stream);
+int fgnn_bn_backward(const void* x, const void* gy, void* gx, int64_t R, int32_t C, int32_t dtype,
+                     const float* mean, const float* invstd, const float* gamma, const float* beta, float slope,
+                     float* gweight, float* gbias, void* workspace, int64_t workspace_bytes,
+                     fgnn_stream_t stream);
+
 const char* fgnn_last_error(void);
 /* Name (as rocprofv3 prints it) of the kernel the calling thread's last forward/backward dispatched to. */
 const char* fgnn_last_kernel(void);

@@ -205,3 +205,39 @@ def test_instance_norm_kernel_vs_torch(C, N, relu, dtype, dev):
     tol = 2e-5 if dtype == torch.float32 else 2e-2
     assert H.rel_err(y.float(), ref) <= tol
     assert H.rel_err(xm.grad.float(), xr.grad) <= tol * 5
+
+
+@pytest.mark.parametrize('C', [64, 128, 256, 8, 96])
+@pytest.mark.parametrize('slope', [0.0, 0.01, 1.0])
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_batchnorm_act_kernel_vs_torch(C, slope, dtype, dev):
+    """Fused train-mode BatchNorm + (Leaky)ReLU (csrc/bnact.hip; C=96 takes the torch fallback) against
+    torch.nn.BatchNorm2d + activation in f32: output, input/affine gradients, running statistics."""
+    from fgnn_amd.mpnn import BatchNormAct2d
+    g = torch.Generator().manual_seed(C)
+    B, N = 9, 40
+    x = (torch.randn(B, C, N, 1, generator=g) * 1.5 + 0.7).to(dtype)
+    gy = torch.randn(B, C, N, 1, generator=g).to(dtype)
+    ref = torch.nn.BatchNorm2d(C)
+    with torch.no_grad():
+        ref.weight.copy_(1 + 0.3 * torch.randn(C, generator=g))
+        ref.bias.copy_(0.3 * torch.randn(C, generator=g))
+    mine = BatchNormAct2d(C, slope=slope)
+    mine.load_state_dict(ref.state_dict())
+    act = (lambda t: t) if slope == 1.0 else (torch.relu if slope == 0.0 else
+                                              (lambda t: torch.nn.functional.leaky_relu(t, slope)))
+    xr = x.detach().float().clone().requires_grad_(True)
+    yr = act(ref(xr))
+    yr.backward(gy.float())
+    mine = mine.to(dev).train()
+    xm = x.detach().clone().to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    ym = mine(xm)
+    ym.backward(gy.to(dev))
+    tol = 5e-5 if dtype == torch.float32 else 2e-2
+    assert H.rel_err(ym.float(), yr) <= tol
+    assert H.rel_err(xm.grad.float(), xr.grad) <= tol * 4
+    assert H.rel_err(mine.weight.grad, ref.weight.grad) <= tol * 4
+    assert H.rel_err(mine.bias.grad, ref.bias.grad) <= tol * 4
+    assert H.rel_err(mine.running_mean, ref.running_mean) <= tol
+    assert H.rel_err(mine.running_var, ref.running_var) <= tol * 2
+    assert int(mine.num_batches_tracked) == 1
