@@ -40,7 +40,9 @@ def parse():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--batch', type=int, default=4096, help='codewords per GPU (weak scaling)')
     ap.add_argument('--mode', choices=['train', 'fwd'], default='train')
-    ap.add_argument('--dtype', choices=['f32', 'bf16'], default='f32')
+    ap.add_argument('--dtype', choices=['f32', 'bf16'], default='bf16',
+                    help='bf16 (BASELINE config 3): bf16 activations/messages + bf16 matrix cores in the forward, '
+                         'f32 parameters / gradients / optimizer; f32: everything f32 (the 1e-4 parity path)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--miopen-bn', action='store_true', help='let torch route BatchNorm to MIOpen')
     ap.add_argument('--cpu-batch', type=int, default=32)
@@ -200,6 +202,15 @@ def main():
             else:
                 roofline = dict(mfma)
                 other = ('hbm', hbm)
+            # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r01/pmc_traffic.json:
+            # FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE), measured at the kernel's LDPC 64->64
+            # shape; null when this kernel symbol has no committed PMC pass
+            try:
+                pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r01', 'pmc_traffic.json')))['kernels']
+                traffic = pmc.get(sym, {}).get('traffic_bytes_per_launch')
+            except (OSError, ValueError, KeyError):
+                traffic = None
+            roofline['traffic'] = traffic
             roofline.update({'kernel': sym, 'launches_per_step': r['launches'],
                              'avg_launch_us': round(avg_ms * 1e3, 2),
                              'algorithmic_bytes_per_launch': r['bytes'] // r['launches'],

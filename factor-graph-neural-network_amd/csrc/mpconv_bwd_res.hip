@@ -305,12 +305,13 @@ __global__ __launch_bounds__(BR_THREADS) void mpconv_bwd_res_kernel(const BresPa
         // lane coordinates re-derived from the opaque `t`: keeps the dozens of loop-invariant LDS
         // offsets below from being hoisted out of the sample loop into (spilled) registers
         const int li = t & 15, lk = (t >> 4) & 3;
-        commit_x(t);
-        commit_g(t, gbacc[0]);
+        if (!(p.dbg & 128)) { commit_x(t); commit_g(t, gbacc[0]); }
         __syncthreads();
-        if (b + 1 < b_end) prefetch_x(b + 1, t);
-        if (NPASS > 1) prefetch_g(b, 1, t);
-        else if (b + 1 < b_end) prefetch_g(b + 1, 0, t);
+        if (!(p.dbg & 512)) {
+            if (b + 1 < b_end) prefetch_x(b + 1, t);
+            if (NPASS > 1) prefetch_g(b, 1, t);
+            else if (b + 1 < b_end) prefetch_g(b + 1, 0, t);
+        }
         if (!shared_graph || b == b_begin) build_csr();
 
         f32x4 dxacc[DXT];
@@ -336,11 +337,11 @@ __global__ __launch_bounds__(BR_THREADS) void mpconv_bwd_res_kernel(const BresPa
                 const float* wt = p.Wt + (int64_t)(pass * BR_PASS_COLS + lk) * nin + ct * 16 + li;
 #pragma unroll
                 for (int ks = 0; ks < PKS; ++ks)
-                    aT[ks] = (pass * BR_PASS_COLS + 4 * ks + lk < ncols) ? wt[(int64_t)ks * 4 * nin] : 0.f;
+                    aT[ks] = (pass * BR_PASS_COLS + 4 * ks + lk < ncols && !(p.dbg & 64)) ? wt[(int64_t)ks * 4 * nin] : 0.f;
             }
 
             // ---- P^T slab (wave = column slab of the pass) ----
-            for (int tp = 0; tp < (ntile + 1) / 2; ++tp) {
+            for (int tp = 0; tp < ((p.dbg & 1) ? 0 : (ntile + 1) / 2); ++tp) {
                 const int t0 = tp * 2;
                 const bool two = (t0 + 1) < ntile;
                 f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
@@ -363,7 +364,7 @@ __global__ __launch_bounds__(BR_THREADS) void mpconv_bwd_res_kernel(const BresPa
                 gbacc[pass] += sgz;
             }
             // ---- detype owners: edge r = (m, j) sums over this pass's channels ----
-            if (tid < mk) {
+            if (tid < mk && !(p.dbg & 4)) {
                 const int m = tid / k, j = tid - m * k;
                 const float* pn = pb + idx_s[tid] * PS;
                 const float* gm = gz_s + m * GS;
@@ -391,7 +392,7 @@ __global__ __launch_bounds__(BR_THREADS) void mpconv_bwd_res_kernel(const BresPa
             __syncthreads();                          // P is dead: the buffer becomes dP
 
             // ---- dP owners: (source node n, channel ol) gathers over n's in-edges ----
-            for (int it = tid; it < p.Npad * otp; it += BR_THREADS) {
+            for (int it = tid; it < ((p.dbg & 2) ? 0 : p.Npad * otp); it += BR_THREADS) {
                 const int n = it / otp, ol = it - n * otp;
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f};
                 if (n < N && ol < otc) {
@@ -422,7 +423,7 @@ __global__ __launch_bounds__(BR_THREADS) void mpconv_bwd_res_kernel(const BresPa
 #pragma unroll
             for (int i = 0; i < DXT; ++i) {
                 const int nt = (NCT == 4) ? (wave / 4 + 2 * i) : i;
-                if (nt < ntile) {
+                if (nt < ntile && !(p.dbg & 8)) {
                     const float* bp = pb + (nt * 16 + li) * PS + lk;
                     f32x4 acc = dxacc[i];
 #pragma unroll
@@ -433,7 +434,7 @@ __global__ __launch_bounds__(BR_THREADS) void mpconv_bwd_res_kernel(const BresPa
             }
             // ---- dW tiles: += x^T . dP over the nodes ----
             {
-                const int ksteps = p.Npad / 4;
+                const int ksteps = (p.dbg & 16) ? 0 : p.Npad / 4;
 #pragma unroll
                 for (int tt = 0; tt < DWT; ++tt) {
                     const int u = wave + BR_WAVES * tt;
@@ -449,7 +450,7 @@ __global__ __launch_bounds__(BR_THREADS) void mpconv_bwd_res_kernel(const BresPa
         }   // passes
 
         // ---- write gx (f32, x's element strides) and getype for this sample ----
-        {
+        if (!(p.dbg & 256)) {
             float* gxb = p.gx + (int64_t)b * d.x_sb;
 #pragma unroll
             for (int i = 0; i < DXT; ++i) {

@@ -150,3 +150,31 @@ def test_sequential_config1_matches_reference(dev):
             et = emodel(torch.from_numpy(ef).to(dev)[None]).repeat(B, 1, 1, 1)
             y = model(x, torch.from_numpy(idx).to(dev)[None].repeat(B, 1, 1), et)
         assert H.rel_err(y, torch.from_numpy(z[mode + '_y'])) <= _tol(z, mode), mode
+
+
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+def test_ldpc_training_reduces_loss(dtype, dev):
+    """A dozen Adam steps of the full LDPCModel on one fixed synthetic batch must drive the loss down in
+    both precisions (f32, and bf16 activations + bf16 matrix cores under autocast) — an end-to-end check
+    that every hand-written backward (message operator, node-wise maps, norms) descends."""
+    import fgnn_amd
+    from fgnn_amd.dp import FlatGradBucket
+    from fgnn_amd.ldpc import synthetic_batch
+    torch.manual_seed(0)
+    m = fgnn_amd.LDPCModel(2, 6, 4, aggregator='max').to(dev).train()
+    dt = torch.float32 if dtype == 'f32' else torch.bfloat16
+    data = synthetic_batch(64, dev, seed=5, dtype=dt)
+    bucket = FlatGradBucket(m.parameters())
+    opt = torch.optim.Adam(bucket.params, lr=2e-3)
+    amp = torch.autocast(device_type='cuda', dtype=torch.bfloat16, enabled=(dtype == 'bf16'))
+    losses = []
+    for _ in range(12):
+        bucket.zero()
+        with amp:
+            logits, snr = m(*data[:6])
+        loss = torch.nn.functional.binary_cross_entropy_with_logits(logits.float().view(-1), data[6].view(-1))
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+    assert all(l == l for l in losses), losses          # no NaN
+    assert losses[-1] < 0.8 * losses[0], losses
