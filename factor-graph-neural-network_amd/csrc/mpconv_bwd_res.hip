@@ -51,7 +51,8 @@ struct BresParams {
     int otcP;                                       // channels per pass slice = min(128/net, nou)
     int XQ;              // prefetch slots [0,XQ) carry x, the rest gz
     int dbg;             // FGNN_DBG ablation mask (tuning only)
-    int off_xs, off_pb, off_idx, off_et, off_gz, off_am, off_cs, off_cl, off_ce;
+    int off_xs, off_pb, off_idx, off_et, off_gz, off_am, off_cs, off_cl, off_ce, off_red;
+    int JS;              // in-edge list split of the dP owners (1 = off)
     int fast_bias;       // dbias straight from the prefetch registers (gz channel-fastest, 512 % nou == 0)
 };
 
@@ -391,31 +392,78 @@ __global__ __launch_bounds__(BR_THREADS) void mpconv_bwd_res_kernel(const BresPa
             }
             __syncthreads();                          // P is dead: the buffer becomes dP
 
-            // ---- dP owners: (source node n, channel ol) gathers over n's in-edges ----
-            for (int it = tid; it < ((p.dbg & 2) ? 0 : p.Npad * otp); it += BR_THREADS) {
-                const int n = it / otp, ol = it - n * otp;
-                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-                if (n < N && ol < otc) {
-                    for (int q = cs_s[n]; q < cs_s[n + 1]; ++q) {
-                        const int ent = cl_s[q];
-                        const int mrow = ent >> 8, j = ent & 0xff;
-                        if (am_s[mrow + ol] == j) {
-                            const float g = gz_s[mrow + ol];
-                            const float* etp = et_s + ce_s[q];
-                            if constexpr (NET == 4) {
-                                const f32x4 e4 = *reinterpret_cast<const f32x4*>(etp);
-                                acc[0] = fmaf(g, e4[0], acc[0]);
-                                acc[1] = fmaf(g, e4[1], acc[1]);
-                                acc[2] = fmaf(g, e4[2], acc[2]);
-                                acc[3] = fmaf(g, e4[3], acc[3]);
-                            } else {
-                                acc[0] = fmaf(g, etp[0], acc[0]);
-                            }
+            // ---- dP owners: (source node n, group of 4 channels) gathers over n's in-edges ----
+            // One 32-bit read gives the argmax of 4 channels of a destination; weights and gz are only
+            // fetched when one of them routes through this edge.  Few owners with long in-edge lists (one
+            // source node feeding every destination: the LDPC hyper-factor F->V call) split each list over
+            // JS thread groups and fold the partials, in a fixed order, through LDS.
+            {
+                constexpr int NA = 4 * NET;                    // accumulators per owner: 4 channels x net
+                const int ogp = otp / 4;                       // channel groups per pass row
+                const int ogv = (otc + 3) / 4;                 // ... that hold valid channels
+                auto edge_into = [&](int q, int og, float (&acc)[NA]) {
+                    const int ent = cl_s[q];
+                    const int mrow = ent >> 8, j = ent & 0xff;
+                    const unsigned a4 = *reinterpret_cast<const unsigned*>(am_s + mrow + og * 4);
+                    const unsigned jj = (unsigned)j * 0x01010101u;
+                    const unsigned x4 = a4 ^ jj;               // a zero byte <=> that channel routes through edge j
+                    if (((x4 - 0x01010101u) & ~x4 & 0x80808080u) != 0u) {
+                        const f32x4 g4 = *reinterpret_cast<const f32x4*>(gz_s + mrow + og * 4);
+                        const float* etp = et_s + ce_s[q];
+                        float e[NET];
+                        if constexpr (NET == 4) {
+                            const f32x4 e4 = *reinterpret_cast<const f32x4*>(etp);
+                            e[0] = e4[0]; e[1] = e4[1]; e[2] = e4[2]; e[3] = e4[3];
+                        } else {
+                            e[0] = etp[0];
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const float g = ((x4 >> (8 * u)) & 0xffu) == 0u ? g4[u] : 0.f;
+#pragma unroll
+                            for (int t2 = 0; t2 < NET; ++t2) acc[u * NET + t2] = fmaf(g, e[t2], acc[u * NET + t2]);
                         }
                     }
+                };
+                auto store_owner = [&](int n, int og, const float (&acc)[NA]) {
+                    float* dst = pb + n * PS + og * 4 * NET;
+#pragma unroll
+                    for (int u = 0; u < NA; u += 4)
+                        *reinterpret_cast<f32x4*>(dst + u) = (f32x4){acc[u], acc[u + 1], acc[u + 2], acc[u + 3]};
+                };
+                if (p.JS == 1) {
+                    for (int it = tid; it < ((p.dbg & 2) ? 0 : p.Npad * ogp); it += BR_THREADS) {
+                        const int n = it / ogp, og = it - n * ogp;
+                        float acc[NA];
+#pragma unroll
+                        for (int u = 0; u < NA; ++u) acc[u] = 0.f;
+                        if (n < N && og < ogv)
+                            for (int q = cs_s[n]; q < cs_s[n + 1]; ++q) edge_into(q, og, acc);
+                        store_owner(n, og, acc);
+                    }
+                } else {
+                    for (int f = tid; f < p.Npad * (PS / 4); f += BR_THREADS)
+                        reinterpret_cast<f32x4*>(pb)[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    const int owners = N * ogv;                // <= 64 by construction of JS
+                    const int part = tid / owners, own = tid - part * owners;
+                    float* red = fgnn_lds_br + p.off_red;
+                    float acc[NA];
+#pragma unroll
+                    for (int u = 0; u < NA; ++u) acc[u] = 0.f;
+                    if (part < p.JS && !(p.dbg & 2)) {
+                        const int n = own / ogv, og = own - n * ogv;
+                        for (int q = cs_s[n] + part; q < cs_s[n + 1]; q += p.JS) edge_into(q, og, acc);
+#pragma unroll
+                        for (int u = 0; u < NA; ++u) red[(part * owners + own) * NA + u] = acc[u];
+                    }
+                    __syncthreads();
+                    if (part == 0) {
+                        for (int q = 1; q < p.JS; ++q)
+#pragma unroll
+                            for (int u = 0; u < NA; ++u) acc[u] += red[(q * owners + own) * NA + u];
+                        store_owner(own / ogv, own - (own / ogv) * ogv, acc);
+                    }
                 }
-                if constexpr (NET == 4) *reinterpret_cast<f32x4*>(pb + n * PS + ol * 4) = acc;
-                else pb[n * PS + ol] = acc[0];
             }
             __syncthreads();
 
@@ -636,6 +684,13 @@ int fgnn_mpconv_backward_resident(const fgnn_mpconv_desc* d, const void* x, cons
     p.off_cs = off;  off += 2 * BR_MAXN + 4;
     p.off_cl = off;  off += fgnn_round_up(mk, 4);
     p.off_ce = off;  off += fgnn_round_up(mk, 4);
+    {   // few owners (N * channel groups <= 64): split their in-edge lists over up to 32 thread groups
+        const int ogv = (otcP + 3) / 4, owners = d->N * ogv;
+        p.JS = 1;
+        if (owners <= 64 && mk >= 4 * owners) { p.JS = BR_THREADS / owners; if (p.JS > 32) p.JS = 32; }
+        p.off_red = off;
+        if (p.JS > 1) off += p.JS * owners * 4 * d->net;
+    }
     const int lds = off * 4;
     if (lds > 160 * 1024) BR_REJECT(19);
     void* fn = nullptr;
