@@ -10,7 +10,8 @@ void fgnn_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
-static thread_local char g_kernel[160] = "";
+// process-wide (diagnostic only): autograd runs the backward on its own thread and tests ask from the main one
+static char g_kernel[160] = "";
 
 void fgnn_note_kernel(const char* fmt, ...) {
     va_list ap;
@@ -21,7 +22,7 @@ void fgnn_note_kernel(const char* fmt, ...) {
 
 extern "C" const char* fgnn_last_error(void) { return g_err; }
 extern "C" const char* fgnn_last_kernel(void) { return g_kernel; }
-extern "C" int fgnn_abi_version(void) { return 1; }
+extern "C" int fgnn_abi_version(void) { return 2; }
 
 // x read once, etype read once, indices read once (int64 as passed; a batch-shared
 // graph is read once), y written once, filters + bias/BN vectors once.

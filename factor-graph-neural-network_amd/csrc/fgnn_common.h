@@ -27,6 +27,20 @@ __device__ __forceinline__ void fgnn_st(bf16_t* p, float v) {
     p->v = __builtin_bit_cast(uint16_t, h);
 }
 
+// four consecutive elements (16-B / 8-B aligned)
+__device__ __forceinline__ void fgnn_st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+__device__ __forceinline__ void fgnn_st4(bf16_t* p, f32x4 v) {
+    typedef __bf16 bf16x4_n __attribute__((ext_vector_type(4)));
+    const bf16x4_n h = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+    *reinterpret_cast<bf16x4_n*>(p) = h;
+}
+__device__ __forceinline__ f32x4 fgnn_ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ f32x4 fgnn_ld4(const bf16_t* p) {
+    const uint2 u = *reinterpret_cast<const uint2*>(p);
+    return (f32x4){__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u),
+                   __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u)};
+}
+
 // ---- host-side error plumbing ---------------------------------------------------------
 void fgnn_set_error(const char* fmt, ...);
 void fgnn_note_kernel(const char* fmt, ...);   // records which kernel a dispatch chose (fgnn_last_kernel)

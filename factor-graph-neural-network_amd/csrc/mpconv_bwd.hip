@@ -31,8 +31,8 @@ struct BwdParams {
     const void* gz;
     const void* z;
     const uint8_t* argmax;
-    float* gx;
-    float* get;
+    void* gx;            // dtype T, x's element strides
+    void* get;           // dtype T, [net][M][k] contiguous per sample, or NULL
     float* gW;
     float* gbias;
     const float* bias;   // unused (z - bias is recovered from gz-side data only for LSE via zagg)
@@ -264,18 +264,18 @@ __global__ __launch_bounds__(FGNN_THREADS) void mpconv_bwd_kernel(const BwdParam
             __syncthreads();
 
             // ---- detype: owners add this channel tile's contribution (first tile writes) ----
-            {
-                float* gb = p.get + (int64_t)b * net * mk;
+            if (p.get) {
+                T* gb = reinterpret_cast<T*>(p.get) + (int64_t)b * net * mk;
                 for (int f = tid; f < mk * net; f += FGNN_THREADS) {
                     const int e = f / mk, r = f - e * mk;
                     const float v = det_s[r * net + e];
-                    gb[f] = (o0 == 0) ? v : gb[f] + v;
+                    fgnn_st(gb + f, (o0 == 0) ? v : fgnn_ld(gb + f) + v);
                 }
             }
 
             // ---- dx^T[c][n] (+)= sum_col W[c][col] dP[n][col]; this WG owns sample b's gx ----
             {
-                float* gxb = p.gx + (int64_t)b * d.x_sb;
+                T* gxb = reinterpret_cast<T*>(p.gx) + (int64_t)b * d.x_sb;
                 const int ksteps = CTT / 4;
                 for (int u = wave; u < nct * ntile; u += FGNN_WAVES) {
                     const int ctile = u % nct, nt = u / nct;
@@ -290,8 +290,8 @@ __global__ __launch_bounds__(FGNN_THREADS) void mpconv_bwd_kernel(const BwdParam
                         for (int r = 0; r < 4; ++r) {
                             const int c = ctile * 16 + 4 * lk + r;
                             if (c < nin) {
-                                float* q = gxb + (int64_t)c * d.x_sc + (int64_t)n * d.x_sn;
-                                *q = (o0 == 0) ? acc[r] : *q + acc[r];
+                                T* q = gxb + (int64_t)c * d.x_sc + (int64_t)n * d.x_sn;
+                                fgnn_st(q, (o0 == 0) ? acc[r] : fgnn_ld(q) + acc[r]);
                             }
                         }
                     }
@@ -362,9 +362,14 @@ __global__ __launch_bounds__(FGNN_THREADS) void mpconv_bwd_kernel(const BwdParam
 int fgnn_check_desc(const fgnn_mpconv_desc* d);
 int fgnn_mpconv_backward_resident(const fgnn_mpconv_desc* d, const void* x, const int64_t* nn_idx,
                                   const void* etype, const float* filters, const void* gz,
-                                  const uint8_t* argmax, float* gx, float* getype, float* gfilters,
+                                  const uint8_t* argmax, void* gx, void* getype, float* gfilters,
                                   float* gbias, void* workspace, int64_t workspace_bytes,
                                   fgnn_stream_t stream);
+
+int fgnn_mpconv_backward_hyper(const fgnn_mpconv_desc* d, const void* x, const int64_t* nn_idx, const void* etype,
+                               const float* filters, const void* gz, const uint8_t* argmax, void* gx, void* getype,
+                               float* gfilters, float* gbias, void* workspace, int64_t workspace_bytes,
+                               fgnn_stream_t stream);
 
 static int plan_backward(const fgnn_mpconv_desc* d, BwdParams* p) {
     const int nproj = d->ext == FGNN_EXT_NONE ? 1 : 2;
@@ -429,18 +434,21 @@ static void* pick_net_b(int net, int agg) {
 
 extern "C" int fgnn_mpconv_backward(const fgnn_mpconv_desc* d, const void* x, const int64_t* nn_idx,
                                     const void* etype, const float* filters, const void* gz,
-                                    const void* z, const uint8_t* argmax, float* gx, float* getype,
+                                    const void* z, const uint8_t* argmax, void* gx, void* getype,
                                     float* gfilters, float* gbias, void* workspace,
                                     int64_t workspace_bytes, fgnn_stream_t stream) {
     int rc = fgnn_check_desc(d);
     if (rc) return rc;
-    if (!x || !nn_idx || !etype || !filters || !gz || !gx || !getype || !gfilters)
+    if (!x || !nn_idx || !etype || !filters || !gz || !gx || !gfilters)
         FGNN_FAIL(FGNN_EINVAL, "null tensor pointer");
     if (d->agg == FGNN_AGG_MAX && !argmax) FGNN_FAIL(FGNN_EINVAL, "max aggregator needs the forward's argmax");
     if (d->B == 0) return FGNN_OK;
     {   // LDPC shape family: W-stationary persistent kernel (mpconv_bwd_res.hip)
         static const bool force_generic = getenv("FGNN_FORCE_GENERIC") != nullptr;
         if (!force_generic) {
+            rc = fgnn_mpconv_backward_hyper(d, x, nn_idx, etype, filters, gz, argmax, gx, getype, gfilters, gbias,
+                                            workspace, workspace_bytes, stream);
+            if (rc != 0) return rc < 0 ? rc : FGNN_OK;
             rc = fgnn_mpconv_backward_resident(d, x, nn_idx, etype, filters, gz, argmax, gx, getype,
                                                gfilters, gbias, workspace, workspace_bytes, stream);
             if (rc != 0) return rc < 0 ? rc : FGNN_OK;

@@ -40,8 +40,8 @@ struct BresParams {
     const float* Wt;     // [ncols][nin] transposed copy of W (workspace)
     const void* gz;
     const uint8_t* argmax;
-    float* gx;
-    float* get;
+    void* gx;            // dtype T, x's element strides
+    void* get;           // dtype T, or NULL (edge-weight gradient not wanted)
     float* ws;           // per-workgroup partial [grid][nin*ncols + nou]
     int has_bias;
     int Npad, Kpad, XS, PS, GS;     // GS: row stride of the per-pass gz / argmax images
@@ -497,9 +497,9 @@ __global__ __launch_bounds__(BR_THREADS) void mpconv_bwd_res_kernel(const BresPa
             }
         }   // passes
 
-        // ---- write gx (f32, x's element strides) and getype for this sample ----
+        // ---- write gx (x's dtype and element strides) and getype for this sample ----
         if (!(p.dbg & 256)) {
-            float* gxb = p.gx + (int64_t)b * d.x_sb;
+            T* gxb = reinterpret_cast<T*>(p.gx) + (int64_t)b * d.x_sb;
 #pragma unroll
             for (int i = 0; i < DXT; ++i) {
                 const int nt = (NCT == 4) ? (wave / 4 + 2 * i) : i;
@@ -507,18 +507,18 @@ __global__ __launch_bounds__(BR_THREADS) void mpconv_bwd_res_kernel(const BresPa
                 if (nt < ntile && n < N) {
                     const int c0 = ct * 16 + 4 * lk;
                     if (p.cl_in) {
-                        *reinterpret_cast<f32x4*>(gxb + (int64_t)n * d.x_sn + c0) = dxacc[i];
+                        fgnn_st4(gxb + (int64_t)n * d.x_sn + c0, dxacc[i]);
                     } else {
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
-                            gxb[(int64_t)(c0 + r) * d.x_sc + (int64_t)n * d.x_sn] = dxacc[i][r];
+                            fgnn_st(gxb + (int64_t)(c0 + r) * d.x_sc + (int64_t)n * d.x_sn, dxacc[i][r]);
                     }
                 }
             }
-            if (tid < mk) {
-                float* gb = p.get + (int64_t)b * net * mk;      // [net][M][k] contiguous
+            if (tid < mk && p.get) {
+                T* gb = reinterpret_cast<T*>(p.get) + (int64_t)b * net * mk;      // [net][M][k] contiguous
 #pragma unroll
-                for (int e = 0; e < NET; ++e) gb[e * mk + tid] = dacc[e];
+                for (int e = 0; e < NET; ++e) fgnn_st(gb + e * mk + tid, dacc[e]);
             }
         }
     }   // samples
@@ -578,6 +578,13 @@ __global__ __launch_bounds__(256) void bres_reduce_kernel(const float* __restric
     else if (gbias) gbias[i - nw] += s;
 }
 
+// Shared with mpconv_bwd_hyper.hip: fold `nslab` slabs of [nw + nou] floats into gW / gbias.
+void fgnn_launch_slab_reduce(const float* ws, int nslab, int64_t slab_len, int64_t nw, float* gW, float* gbias,
+                             hipStream_t st) {
+    hipLaunchKernelGGL(bres_reduce_kernel, dim3((unsigned)((slab_len + 255) / 256)), dim3(256), 0, st, ws, nslab,
+                       slab_len, nw, gW, gbias);
+}
+
 // ----------------------------------------------------------------------------------------
 // host side
 // ----------------------------------------------------------------------------------------
@@ -602,7 +609,7 @@ extern "C" int64_t fgnn_mpconv_backward_workspace_bytes(const fgnn_mpconv_desc* 
 // Returns 1 if launched, 0 if the shape is outside this kernel's family, <0 on error.
 int fgnn_mpconv_backward_resident(const fgnn_mpconv_desc* d, const void* x, const int64_t* nn_idx,
                                   const void* etype, const float* filters, const void* gz,
-                                  const uint8_t* argmax, float* gx, float* getype, float* gfilters,
+                                  const uint8_t* argmax, void* gx, void* getype, float* gfilters,
                                   float* gbias, void* workspace, int64_t workspace_bytes,
                                   fgnn_stream_t stream) {
     if (d->ext != FGNN_EXT_NONE || d->agg != FGNN_AGG_MAX) BR_REJECT(1);

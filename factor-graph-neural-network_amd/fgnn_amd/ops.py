@@ -168,8 +168,9 @@ class _MPConv(torch.autograd.Function):
             gz = zl
         dense = x.is_contiguous() or x.permute(0, 2, 3, 1).is_contiguous()
         xx = x if dense else x.contiguous()
-        gx = torch.empty_like(xx, dtype=torch.float32)   # preserve_format keeps xx's strides
-        get = torch.empty((B, net, M, k), device=x.device, dtype=torch.float32)
+        gx = torch.empty_like(xx)                        # preserve_format keeps xx's strides
+        want_get = ctx.needs_input_grad[2]
+        get = torch.empty((B, net, M, k), device=x.device, dtype=etype.dtype) if want_get else None
         gw = torch.zeros(filters.shape, device=x.device, dtype=torch.float32)
         gb = torch.zeros((nou,), device=x.device, dtype=torch.float32) if ctx.has_bias else None
         w = filters.detach().float().contiguous()
@@ -178,22 +179,18 @@ class _MPConv(torch.autograd.Function):
         nbytes = 0
         if TIMER is not None:
             # algorithmic bytes of the backward: x, etype, nn_idx, gz, argmax read once;
-            # gx, getype written once (f32); filters read and gfilters written once
+            # gx, getype written once; filters read and gfilters written once
             shared_et = etype.stride(0) == 0 and B > 1
             shared_idx = nn_idx.stride(0) == 0 and B > 1
-            nbytes = (xx.element_size() * (xx.numel() + gz.numel())
+            nbytes = (xx.element_size() * (2 * xx.numel() + gz.numel())
                       + etype.element_size() * net * M * k * (1 if shared_et else B)
                       + 8 * M * k * (1 if shared_idx else B)
                       + (B * nou * M if amax is not None else 0)
-                      + 4 * (gx.numel() + get.numel()) + 8 * w.numel())
+                      + (get.element_size() * get.numel() if want_get else 0) + 8 * w.numel())
         _launch('bwd', d, nbytes, lambda: _hip.check(L.fgnn_mpconv_backward(
             ctypes.byref(d), _hip._ptr(xx), _hip._ptr(nn_idx), _hip._ptr(etype), _hip._ptr(w),
             _hip._ptr(gz), None, _hip._ptr(amax), _hip._ptr(gx), _hip._ptr(get),
             _hip._ptr(gw), _hip._ptr(gb), _hip._ptr(ws), ws.numel() * 4, _hip.stream_ptr())))
-        if get.dtype != etype.dtype:
-            get = get.to(etype.dtype)
-        if gx.dtype != x.dtype:
-            gx = gx.to(x.dtype)
         return (gx, None, get, gw.to(filters.dtype), gb, None, None, None, None)
 
 

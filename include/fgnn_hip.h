@@ -71,8 +71,10 @@ int fgnn_mpconv_forward(const fgnn_mpconv_desc* d, const void* x, const int64_t*
  *   gz      [B, nou, M]  upstream gradient w.r.t. the pre-BN output z (strides y_s* of d)
  *   z       reserved, pass NULL (the softmax weights are recomputed from x)
  *   argmax  as written by the forward (FGNN_AGG_MAX; NULL otherwise)
- *   gx      [B, nin, N]  float32, same ELEMENT strides as x; fully written
- *   getype  [B, net, M, k] contiguous, fully written; float32
+ *   gx      [B, nin, N]  same dtype and ELEMENT strides as x; fully written
+ *   getype  [B, net, M, k] contiguous, same dtype as etype, fully written; NULL = not wanted (the
+ *            caller's etype is a constant: skips the edge-weight gradient and unlocks the
+ *            hyper-edge kernels of mpconv_bwd_hyper.hip)
  *   gfilters[R, nou*net] float32, ACCUMULATED into (caller zero-fills)
  *   gbias   [nou] float32 or NULL, ACCUMULATED into
  *   workspace / workspace_bytes : optional scratch of fgnn_mpconv_backward_workspace_bytes(d) bytes
@@ -81,7 +83,7 @@ int fgnn_mpconv_forward(const fgnn_mpconv_desc* d, const void* x, const int64_t*
  */
 int fgnn_mpconv_backward(const fgnn_mpconv_desc* d, const void* x, const int64_t* nn_idx,
                          const void* etype, const float* filters, const void* gz,
-                         const void* z, const uint8_t* argmax, float* gx, float* getype,
+                         const void* z, const uint8_t* argmax, void* gx, void* getype,
                          float* gfilters, float* gbias, void* workspace, int64_t workspace_bytes,
                          fgnn_stream_t stream);
 

@@ -156,6 +156,63 @@ def test_bf16_mfma_kernel_vs_oracle(shape, agg, dev):
         assert int(am.max()) < k
 
 
+HYPER_SHAPES = [(64, 64, 96, 1, 96), (64, 64, 1, 96, 1), (64, 128, 96, 1, 96), (64, 128, 1, 96, 1),
+                (128, 64, 96, 1, 96), (128, 64, 1, 96, 1), (64, 64, 40, 1, 130), (64, 64, 1, 7, 1)]
+
+
+@pytest.mark.parametrize('shape', HYPER_SHAPES, ids=lambda s: 'x'.join(map(str, s)))
+@pytest.mark.parametrize('layout', ['nchw', 'channels_last'])
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16], ids=['f32', 'bf16'])
+def test_hyper_edge_backward_vs_routed_reference(shape, layout, dtype, dev):
+    """Constant-etype hyper-factor calls (one destination of high degree / one source fanned out) take
+    csrc/mpconv_bwd_hyper.hip.  Checked against torch autograd through the same routing: the forward's
+    own argmax selects the neighbour (so a bf16 forward that picks another near-tie winner than the f32
+    oracle does not blur what is being tested), and — in f32 — against the oracle's autograd too.
+    Duplicate neighbours, non-unit edge weights and a batch that is not a multiple of the 8 waves of a
+    workgroup are all in."""
+    from fgnn_amd import _hip, ops
+    nin, nou, N, M, k = shape
+    B = 19
+    g = torch.Generator().manual_seed(5 + N + k)
+    x = torch.randn(B, nin, N, 1, generator=g).to(dtype)
+    idx = torch.randint(0, N, (B, M, k), generator=g)
+    et = (torch.rand(B, 1, M, k, generator=g) + 0.5).to(dtype)
+    W = torch.randn(nin, nou, generator=g) * 0.1
+    bias = torch.randn(nou, generator=g)
+    gz = torch.randn(B, nou, M, 1, generator=g).to(dtype)
+    xd = x.to(dev)
+    if layout == 'channels_last':
+        xd = xd.contiguous(memory_format=torch.channels_last)
+    xd.requires_grad_(True)
+    Wd, bd = W.to(dev).requires_grad_(True), bias.to(dev).requires_grad_(True)
+    z = ops.mpconv(xd, idx.to(dev), et.to(dev), Wd, bd, nou, 1, 0, _hip.AGG_MAX)
+    # the argmax the forward recorded (re-run raw: the autograd Function keeps its own copy)
+    _, am = ops.mpconv_forward_raw(xd.detach(), idx.to(dev), et.to(dev), W.to(dev), bias.to(dev), nou, 1, 0,
+                                   _hip.AGG_MAX, want_argmax=True)
+    z.backward(gz.to(dev))
+    assert ('fanin' if M == 1 else 'fanout') in _hip.lib().fgnn_last_kernel().decode()
+    # routed reference in f32 on the CPU
+    xr = x.float().detach().clone().requires_grad_(True)
+    Wr, br = W.clone().requires_grad_(True), bias.clone().requires_grad_(True)
+    P = torch.einsum('bcn,co->bno', xr[..., 0], Wr)                                 # [B,N,nou]
+    E = P[torch.arange(B)[:, None, None], idx] * et.float()[:, 0, :, :, None]       # [B,M,k,nou]
+    sel = am.cpu().long()[..., 0].permute(0, 2, 1)[:, :, None, :]                   # [B,M,1,nou]
+    zr = E.gather(2, sel)[:, :, 0, :].permute(0, 2, 1)[..., None] + br[None, :, None, None]
+    zr.backward(gz.float())
+    tol = 2e-5 if dtype == torch.float32 else 2.0 ** -7
+    assert H.rel_err(xd.grad.float(), xr.grad) <= tol
+    assert H.rel_err(Wd.grad, Wr.grad) <= tol
+    assert H.rel_err(bd.grad, br.grad) <= tol
+    if dtype == torch.float32:
+        xo = x.detach().clone().requires_grad_(True)
+        sd = {'filters': W.clone().requires_grad_(True), 'bias': bias.clone().requires_grad_(True)}
+        zo = O.mp_conv(sd, '', xo, idx, et, nou=nou, net=1, extension=0, aggregator='max', relu=False)
+        assert H.rel_err(z, zo) <= TOL
+        zo.backward(gz)
+        assert H.rel_err(xd.grad, xo.grad) <= 1e-4
+        assert H.rel_err(Wd.grad, sd['filters'].grad) <= 1e-4
+
+
 @pytest.mark.parametrize('cin,cout', [(64, 64), (2, 64), (7, 64), (96, 64), (64, 256), (256, 64), (256, 256),
                                       (128, 1), (64, 4), (100, 12)])
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])

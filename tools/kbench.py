@@ -20,6 +20,10 @@ SHAPES = [  # (name, nin, nou, net, N, M, k)
     ('parity F->V 128->64', 128, 64, 4, 48, 96, 3),
     ('hyper  V->F 64->64', 64, 64, 1, 96, 1, 96),
     ('hyper  F->V 64->64', 64, 64, 1, 1, 96, 1),
+    ('hyper  V->F 64->128', 64, 128, 1, 96, 1, 96),
+    ('hyper  F->V 64->128', 64, 128, 1, 1, 96, 1),
+    ('hyper  V->F 128->64', 128, 64, 1, 96, 1, 96),
+    ('hyper  F->V 128->64', 128, 64, 1, 1, 96, 1),
 ]
 
 
@@ -31,6 +35,7 @@ def main():
     ap.add_argument('--layout', default='cl', choices=['cl', 'nchw'])
     ap.add_argument('--bwd', action='store_true')
     ap.add_argument('--only', default='')
+    ap.add_argument('--etgrad', action='store_true', help='hyper shapes: also ask for the edge-weight gradient')
     a = ap.parse_args()
     dev = torch.device('cuda:0')
     dt = torch.float32 if a.dtype == 'f32' else torch.bfloat16
@@ -62,13 +67,13 @@ def main():
             L = _hip.lib()
             y, amax = ops.mpconv_forward_raw(x, idx, et, W, bias, nou, net, 0, _hip.AGG_MAX, want_argmax=True)
             gz = torch.randn_like(y)
-            gx = torch.empty_like(x, dtype=torch.float32)
-            get = torch.empty((B, net, M, k), device=dev, dtype=torch.float32)
+            gx = torch.empty_like(x)
+            get = None if (net == 1 and not a.etgrad) else torch.empty((B, net, M, k), device=dev, dtype=dt)
             gw = torch.zeros_like(W)
             gb = torch.zeros(nou, device=dev)
             dsc = _hip.make_desc(x, idx, et, nou, net, 0, _hip.AGG_MAX, False, gz)
             nbytes = (x.element_size() * (x.numel() + gz.numel()) + et.element_size() * net * M * k *
-                      (1 if et.stride(0) == 0 else B) + 8 * M * k + B * nou * M + 4 * (gx.numel() + get.numel())
+                      (1 if et.stride(0) == 0 else B) + 8 * M * k + B * nou * M + x.element_size() * (gx.numel() + (get.numel() if get is not None else 0))
                       + 8 * W.numel())
             flops *= 3.0
             wsb = ops._workspace(dev, int(L.fgnn_mpconv_backward_workspace_bytes(ctypes.byref(dsc))))
@@ -107,9 +112,10 @@ def main():
         torch.cuda.synchronize()
         us = s.elapsed_time(e) / a.iters * 1e3
         print('%-22s %s %-4s %s  %8.1f us (host %6.1f us/call)  %7.1f GB/s (%.1f%% of 8 TB/s)  %6.1f TFLOP/s  '
-              '[%d B, %.2f MB/call]'
+              '[%d B, %.2f MB/call] %s'
               % (name, a.dtype, a.layout, 'bwd' if a.bwd else 'fwd', us, host_us, nbytes / us / 1e3,
-                 nbytes / us / 1e3 / 80.0, flops / us / 1e6, B, nbytes / 1e6))
+                 nbytes / us / 1e3 / 80.0, flops / us / 1e6, B, nbytes / 1e6,
+                 _hip.lib().fgnn_last_kernel().decode()))
 
 
 if __name__ == '__main__':
