@@ -306,11 +306,18 @@ static int wgrad_plan(int R, int Cin, int Cout, WgradParams* p, int* gx, int* gy
     return 0;
 }
 
+// bf16, channel counts in multiples of 64: the LDS-free kernel of linear_wgrad_b16.hip
+int64_t fgnn_linear_wgrad_b16_workspace_bytes(int64_t R, int Cin, int Cout);
+int fgnn_linear_wgrad_b16(const void* x, const void* gy, int64_t R, int Cin, int Cout, float* gW, float* gb,
+                          void* workspace, int64_t workspace_bytes, fgnn_stream_t stream);
+
 extern "C" int64_t fgnn_linear_wgrad_workspace_bytes(int64_t R, int Cin, int Cout) {
     WgradParams p;
     int gx, gy;
     if (R <= 0 || Cin <= 0 || Cout <= 0 || wgrad_plan((int)R, Cin, Cout, &p, &gx, &gy)) return -1;
-    return (int64_t)gx * gy * ((int64_t)p.Cop * p.Cip + p.Cop) * 4;
+    const int64_t a = (int64_t)gx * gy * ((int64_t)p.Cop * p.Cip + p.Cop) * 4;
+    const int64_t b = fgnn_linear_wgrad_b16_workspace_bytes(R, Cin, Cout);
+    return a > b ? a : b;
 }
 
 // gW [Cout][Cin] f32 and gb [Cout] f32 (or NULL) are ACCUMULATED into.  x [R][Cin], gy [R][Cout] dense
@@ -321,6 +328,10 @@ extern "C" int fgnn_linear_wgrad(const void* x, const void* gy, int64_t R, int C
     if (!x || !gy || !gW || !workspace) FGNN_FAIL(FGNN_EINVAL, "linear_wgrad: null pointer");
     if (R <= 0 || R > 0x7fffffff || Cin <= 0 || Cout <= 0) FGNN_FAIL(FGNN_EINVAL, "linear_wgrad: bad sizes");
     if (dtype != FGNN_F32 && dtype != FGNN_BF16) FGNN_FAIL(FGNN_EINVAL, "linear_wgrad: unknown dtype %d", dtype);
+    if (dtype == FGNN_BF16) {
+        const int rc = fgnn_linear_wgrad_b16(x, gy, R, Cin, Cout, gW, gb, workspace, workspace_bytes, stream);
+        if (rc != 0) return rc < 0 ? rc : FGNN_OK;
+    }
     WgradParams p;
     int gx, gyn;
     if (wgrad_plan((int)R, Cin, Cout, &p, &gx, &gyn))

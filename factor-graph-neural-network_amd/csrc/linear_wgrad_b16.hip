@@ -1,0 +1,243 @@
+// linear_wgrad_b16.hip — weight / bias gradient of the node-wise (1x1) maps for bf16 activations with
+// channel counts that are multiples of 64 (every map of the LDPC model's main path; reference
+// /root/reference/lib/model/mpnn/mp_nn_residual.py:25-35, base_model.py:43-90):
+//
+//     gW[o][c] += sum_r gy[r][o] * x[r][c]        gb[o] += sum_r gy[r][o]          r over R = B*N rows
+//
+// The contraction runs over ROWS, so both MFMA operands want "8 consecutive rows of one channel" per lane
+// while memory is row-major.  Instead of staging through LDS, every lane loads 4 channels (8 bytes) of each
+// of its 8 rows straight from global memory and transposes the 8x4 block in registers with v_perm_b32: the
+// result is four v_mfma_f32_16x16x32_bf16 fragments, one per channel, whose 16 lanes cover channels
+// {4*i + p}.  The channel permutation is harmless (it is undone when the partials are summed) and the
+// k-slot order inside a fragment is irrelevant as long as gy and x agree on it, which they do by construction.
+//
+// One wave owns one 64x64 slice of gW (16 MFMA tiles = 64 accumulator registers) and a share of the rows.
+// A 1024-thread workgroup holds S = (Cout/64)*(Cin/64) <= 16 slices x 16/S row-waves; the waves of different
+// slices walk the SAME 32-row blocks at the same time, so x / gy lines are fetched from HBM once and re-hit in
+// L1/L2.  No LDS, no barriers in the streaming loop.  The op is HBM-bound (bf16 matrix cores are ~5x faster than the stream).  dbias: v_dot2 of
+// each fragment dword against (1, 1).  Partials: the row-waves of a slice fold through LDS as a binary tree
+// (fixed order), the workgroup writes its slab in REGISTER order (coalesced), and wgb_reduce_kernel sums the
+// slabs and undoes the permutation: deterministic, no atomics.
+#include "fgnn_common.h"
+#include <stdlib.h>
+
+#define WB_THREADS 1024
+#define WB_WAVES 16
+#define WB_NACC 68       // 64 gW accumulators + 4 dbias partials per lane
+
+typedef __bf16 wb_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 wb_bf16x2 __attribute__((ext_vector_type(2)));
+
+struct WgbParams {
+    const uint16_t* x;   // [R][Cin]  bf16
+    const uint16_t* gy;  // [R][Cout] bf16
+    float* ws;           // [gridDim.x][S][WB_NACC][64]
+    int R, Cin, Cout;
+    int nso, S, RW;      // output-channel slices, slices per workgroup, row-waves per slice (S * RW == 16)
+};
+
+extern __shared__ __attribute__((aligned(16))) float wb_lds[];
+
+// rows r0..r7 each hold channels (c0 c1 | c2 c3) as two dwords: gather channel P's eight values
+template <int P>
+__device__ __forceinline__ uint4 wb_pack(const uint2 (&r)[8]) {
+    constexpr unsigned sel = (P & 1) ? 0x07060302u : 0x05040100u;     // high / low halves of (hi:b, lo:a)
+    unsigned w[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const unsigned a = P < 2 ? r[2 * q].x : r[2 * q].y, b = P < 2 ? r[2 * q + 1].x : r[2 * q + 1].y;
+        w[q] = __builtin_amdgcn_perm(b, a, sel);
+    }
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+__device__ __forceinline__ float wb_sum8(const uint4& f, float acc) {
+    const wb_bf16x2 one = {(__bf16)1.0f, (__bf16)1.0f};
+    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(wb_bf16x2, f.x), one, acc, false);
+    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(wb_bf16x2, f.y), one, acc, false);
+    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(wb_bf16x2, f.z), one, acc, false);
+    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(wb_bf16x2, f.w), one, acc, false);
+    return acc;
+}
+
+__global__ __launch_bounds__(WB_THREADS) void linear_wgrad_b16_kernel(const WgbParams p) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lk = lane >> 4;
+    const int slice = wave % p.S, rw = wave / p.S;     // slice = sc * nso + so
+    const int so = slice % p.nso, sc = slice / p.nso;
+    const int R = p.R, Cin = p.Cin, Cout = p.Cout;
+    const uint16_t* gyp = p.gy + so * 64 + 4 * li;
+    const uint16_t* xp = p.x + sc * 64 + 4 * li;
+
+    f32x4 acc[4][4];
+    float bs[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nblk = (R + 31) / 32;
+    const int stride = gridDim.x * p.RW;
+    uint2 rg[8], rx[8];
+    auto load = [&](int blk) {
+        const int row0 = blk * 32 + 8 * lk;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int row = row0 + j;
+            const bool ok = row < R;
+            rg[j] = ok ? *reinterpret_cast<const uint2*>(gyp + (int64_t)row * Cout) : make_uint2(0, 0);
+            rx[j] = ok ? *reinterpret_cast<const uint2*>(xp + (int64_t)row * Cin) : make_uint2(0, 0);
+        }
+    };
+    // no software prefetch: 16 waves per CU with 8 KB of loads each keep ~128 KB in flight per CU, and a
+    // second register set would not fit the 128-VGPR budget of a 1024-thread workgroup
+    for (int blk = blockIdx.x * p.RW + rw; blk < nblk; blk += stride) {
+        load(blk);
+        uint4 A[4], Bf[4];
+        A[0] = wb_pack<0>(rg); A[1] = wb_pack<1>(rg); A[2] = wb_pack<2>(rg); A[3] = wb_pack<3>(rg);
+        Bf[0] = wb_pack<0>(rx); Bf[1] = wb_pack<1>(rx); Bf[2] = wb_pack<2>(rx); Bf[3] = wb_pack<3>(rx);
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            bs[a] = wb_sum8(A[a], bs[a]);
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+                acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(wb_bf16x8, A[a]),
+                                                                    __builtin_bit_cast(wb_bf16x8, Bf[b]), acc[a][b], 0, 0, 0);
+        }
+    }
+
+    // ---- binary-tree fold of the RW row-waves of each slice (fixed order) ----
+    // slot (slice, t) for t < RW/2 holds WB_NACC x 64 floats, thread-private positions
+    for (int half = p.RW >> 1; half >= 1; half >>= 1) {
+        float* slot = wb_lds + ((int64_t)(slice * (p.RW >> 1) + (rw - half)) * WB_NACC) * 64 + lane;
+        if (rw >= half && rw < 2 * half) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) slot[((a * 4 + b) * 4 + r) * 64] = acc[a][b][r];
+                slot[(64 + a) * 64] = bs[a];
+            }
+        }
+        __syncthreads();
+        if (rw < half) {
+            const float* src = wb_lds + ((int64_t)(slice * (p.RW >> 1) + rw) * WB_NACC) * 64 + lane;
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[a][b][r] += src[((a * 4 + b) * 4 + r) * 64];
+                bs[a] += src[(64 + a) * 64];
+            }
+        }
+        __syncthreads();
+    }
+    if (rw == 0) {                                     // register-order slab: [slice][q][lane], coalesced
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {                  // dbias: fold the 4 row-group lanes of a channel
+            bs[a] += __shfl_xor(bs[a], 16);
+            bs[a] += __shfl_xor(bs[a], 32);
+        }
+        float* slab = p.ws + (((int64_t)blockIdx.x * p.S + slice) * WB_NACC) * 64 + lane;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) slab[((a * 4 + b) * 4 + r) * 64] = acc[a][b][r];
+            slab[(64 + a) * 64] = bs[a];
+        }
+    }
+}
+
+// gW[o][c] += sum over slabs; gb[o] += sum over slabs.  One thread per
+// (slice, q, lane) element of a slab; 256 threads = 16 consecutive elements x 16 slab groups (fixed fold order).
+__global__ __launch_bounds__(256) void wgb_reduce_kernel(const float* __restrict__ ws, int nslab, int S, int nso,
+                                                         int Cin, int Cout, float* __restrict__ gW,
+                                                         float* __restrict__ gb) {
+    __shared__ float part[16][17];
+    const int e = threadIdx.x & 15, g = threadIdx.x >> 4;
+    const int64_t slab_len = (int64_t)S * WB_NACC * 64;
+    const int64_t i = (int64_t)blockIdx.x * 16 + e;    // i < slab_len (slab_len % 16 == 0)
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    {
+        const float* base = ws + i;
+        int w = g;
+        for (; w + 48 < nslab; w += 64) {
+            s0 += base[(int64_t)w * slab_len];
+            s1 += base[(int64_t)(w + 16) * slab_len];
+            s2 += base[(int64_t)(w + 32) * slab_len];
+            s3 += base[(int64_t)(w + 48) * slab_len];
+        }
+        for (; w < nslab; w += 16) s0 += base[(int64_t)w * slab_len];
+    }
+    part[g][e] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (g != 0) return;
+    float s = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) s += part[q][e];
+    const int l = (int)(i & 63), q = (int)((i >> 6) % WB_NACC), slice = (int)(i / (WB_NACC * 64));
+    const int so = slice % nso, sc = slice / nso;
+    const int li = l & 15, lk = l >> 4;
+    if (q < 64) {
+        const int r = q & 3, b = (q >> 2) & 3, a = q >> 4;            // D row = 4*lk + r (tile a), D col = li (tile b)
+        const int o = so * 64 + 4 * (4 * lk + r) + a, c = sc * 64 + 4 * li + b;
+        gW[(int64_t)o * Cin + c] += s;
+    } else if (gb && sc == 0 && lk == 0) {
+        gb[so * 64 + 4 * li + (q - 64)] += s;          // the main kernel already folded the 4 row-group lanes
+    }
+}
+
+static bool wb_plan(int64_t R, int Cin, int Cout, int* nso, int* S, int* RW, int* gx) {
+    if (Cin % 64 || Cout % 64) return false;
+    *nso = Cout / 64;
+    *S = *nso * (Cin / 64);
+    if (*S > 16 || (*S & (*S - 1))) return false;
+    *RW = 16 / *S;
+    static const int wgs = getenv("FGNN_WB_GRID") ? atoi(getenv("FGNN_WB_GRID")) : 256;
+    const int64_t nblk = (R + 31) / 32;
+    int64_t g = (nblk + 2 * *RW - 1) / (2 * *RW);                      // >= 2 blocks per row-wave
+    if (g > wgs) g = wgs;
+    if (g < 1) g = 1;
+    *gx = (int)g;
+    return true;
+}
+
+int64_t fgnn_linear_wgrad_b16_workspace_bytes(int64_t R, int Cin, int Cout) {
+    int nso, S, RW, gx;
+    if (!wb_plan(R, Cin, Cout, &nso, &S, &RW, &gx)) return 0;
+    return (int64_t)gx * S * WB_NACC * 64 * 4;
+}
+
+// Returns 1 if launched, 0 if the shape is outside this kernel's family, <0 on error.
+int fgnn_linear_wgrad_b16(const void* x, const void* gy, int64_t R, int Cin, int Cout, float* gW, float* gb,
+                          void* workspace, int64_t workspace_bytes, fgnn_stream_t stream) {
+    int nso, S, RW, gx;
+    if (!wb_plan(R, Cin, Cout, &nso, &S, &RW, &gx)) return 0;
+    if (((uintptr_t)x & 7) || ((uintptr_t)gy & 7)) return 0;
+    if (getenv("FGNN_WG_OLD")) return 0;
+    if (workspace_bytes < (int64_t)gx * S * WB_NACC * 64 * 4) return 0;
+    WgbParams p;
+    p.x = (const uint16_t*)x; p.gy = (const uint16_t*)gy; p.ws = (float*)workspace;
+    p.R = (int)R; p.Cin = Cin; p.Cout = Cout; p.nso = nso; p.S = S; p.RW = RW;
+    const int lds = S * (RW / 2) * WB_NACC * 64 * 4;                   // 0 when every slice has one row-wave
+    void* fn = (void*)linear_wgrad_b16_kernel;
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+    }
+    void* args[] = {(void*)&p};
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipLaunchKernel(fn, dim3(gx), dim3(WB_THREADS), args, lds, st);
+    if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "linear_wgrad_b16 launch: %s", hipGetErrorString(e));
+    const int64_t slab_len = (int64_t)S * WB_NACC * 64;
+    hipLaunchKernelGGL(wgb_reduce_kernel, dim3((unsigned)(slab_len / 16)), dim3(256), 0, st, p.ws, gx, S, nso, Cin,
+                       Cout, gW, gb);
+    e = hipGetLastError();
+    if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "linear_wgrad_b16 reduce launch: %s", hipGetErrorString(e));
+    return 1;
+}

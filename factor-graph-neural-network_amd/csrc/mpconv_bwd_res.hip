@@ -559,29 +559,41 @@ __global__ __launch_bounds__(BR_THREADS) void mpconv_bwd_res_kernel(const BresPa
 }
 
 // Sums the per-workgroup slabs into gW / gbias (accumulating): out[i] += sum_w ws[w][i].
+// 256 threads = 16 consecutive elements x 16 slab groups: group g walks slabs g, g+16, ... (4 loads in flight),
+// the 16 partials of an element are folded in a fixed order through LDS (bit-reproducible).
 __global__ __launch_bounds__(256) void bres_reduce_kernel(const float* __restrict__ ws, int nslab, int64_t slab_len,
                                                           int64_t nw, float* __restrict__ gW,
                                                           float* __restrict__ gbias) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= slab_len) return;
+    __shared__ float part[16][17];
+    const int e = threadIdx.x & 15, g = threadIdx.x >> 4;
+    const int64_t i = (int64_t)blockIdx.x * 16 + e;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int w = 0;
-    for (; w + 4 <= nslab; w += 4) {
-        s0 += ws[(int64_t)w * slab_len + i];
-        s1 += ws[(int64_t)(w + 1) * slab_len + i];
-        s2 += ws[(int64_t)(w + 2) * slab_len + i];
-        s3 += ws[(int64_t)(w + 3) * slab_len + i];
+    if (i < slab_len) {
+        const float* base = ws + i;
+        int w = g;
+        for (; w + 48 < nslab; w += 64) {
+            s0 += base[(int64_t)w * slab_len];
+            s1 += base[(int64_t)(w + 16) * slab_len];
+            s2 += base[(int64_t)(w + 32) * slab_len];
+            s3 += base[(int64_t)(w + 48) * slab_len];
+        }
+        for (; w < nslab; w += 16) s0 += base[(int64_t)w * slab_len];
     }
-    for (; w < nslab; ++w) s0 += ws[(int64_t)w * slab_len + i];
-    const float s = (s0 + s1) + (s2 + s3);
-    if (i < nw) gW[i] += s;
-    else if (gbias) gbias[i - nw] += s;
+    part[g][e] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (g == 0 && i < slab_len) {
+        float s = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) s += part[q][e];
+        if (i < nw) gW[i] += s;
+        else if (gbias) gbias[i - nw] += s;
+    }
 }
 
 // Shared with mpconv_bwd_hyper.hip: fold `nslab` slabs of [nw + nou] floats into gW / gbias.
 void fgnn_launch_slab_reduce(const float* ws, int nslab, int64_t slab_len, int64_t nw, float* gW, float* gbias,
                              hipStream_t st) {
-    hipLaunchKernelGGL(bres_reduce_kernel, dim3((unsigned)((slab_len + 255) / 256)), dim3(256), 0, st, ws, nslab,
+    hipLaunchKernelGGL(bres_reduce_kernel, dim3((unsigned)((slab_len + 15) / 16)), dim3(256), 0, st, ws, nslab,
                        slab_len, nw, gW, gbias);
 }
 
@@ -725,8 +737,7 @@ int fgnn_mpconv_backward_resident(const fgnn_mpconv_desc* d, const void* x, cons
     void* args[] = {(void*)&p};
     hipError_t e = hipLaunchKernel(fn, dim3(grid), dim3(BR_THREADS), args, lds, st);
     if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "mpconv resident backward launch: %s", hipGetErrorString(e));
-    hipLaunchKernelGGL(bres_reduce_kernel, dim3((unsigned)((slab_len + 255) / 256)), dim3(256), 0, st, p.ws, grid,
-                       slab_len, nw, gfilters, gbias);
+    fgnn_launch_slab_reduce(p.ws, grid, slab_len, nw, gfilters, gbias, st);
     e = hipGetLastError();
     if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "mpconv backward helper launch: %s", hipGetErrorString(e));
     return 1;

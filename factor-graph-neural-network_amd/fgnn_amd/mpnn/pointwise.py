@@ -41,8 +41,9 @@ class _RowLinear(torch.autograd.Function):
             grows = gy @ (weight if weight.dtype == gy.dtype else weight.to(gy.dtype))
         R, cin = rows.shape
         cout = weight.shape[0]
-        if cin * cout >= 256 * 256:                     # square 256-wide maps: rocBLAS is ahead there
-            gw = (gy.t() @ rows).float()
+        if cin * cout >= 256 * 256 and not (rows.dtype == torch.bfloat16 and cin % 64 == 0 and cout % 64 == 0
+                                            and cin <= 256 and cout <= 256):
+            gw = (gy.t() @ rows).float()                # f32 square 256-wide maps: rocBLAS is ahead there
             gb = gy.float().sum(0) if ctx.has_bias else None
             return grows, gw.to(weight.dtype), (gb.to(weight.dtype) if gb is not None else None)
         L = _hip.lib()
