@@ -27,6 +27,7 @@ class _RowLinear(torch.autograd.Function):
         b = bias if bias is None or bias.dtype == rows.dtype else bias.to(rows.dtype)
         ctx.save_for_backward(rows, weight)
         ctx.has_bias = bias is not None
+        ctx.params = (weight, bias)                     # leaf tensors (ops.grad_sink)
         return torch.nn.functional.linear(rows, w, b)
 
     @staticmethod
@@ -47,13 +48,20 @@ class _RowLinear(torch.autograd.Function):
             gb = gy.float().sum(0) if ctx.has_bias else None
             return grows, gw.to(weight.dtype), (gb.to(weight.dtype) if gb is not None else None)
         L = _hip.lib()
-        gw = torch.zeros((cout, cin), device=rows.device, dtype=torch.float32)
-        gb = torch.zeros((cout,), device=rows.device, dtype=torch.float32) if ctx.has_bias else None
+        wparam, bparam = ctx.params
+        # weight may be a [cout,cin,1,1] Conv2d parameter viewed as [cout,cin]: its .grad lives on the base
+        base = wparam._base if wparam._base is not None and wparam._base.numel() == wparam.numel() else wparam
+        gw_sink, gb_sink = ops.grad_sink(base), ops.grad_sink(bparam)
+        gw = gw_sink if gw_sink is not None else torch.zeros((cout, cin), device=rows.device, dtype=torch.float32)
+        gb = None
+        if ctx.has_bias:
+            gb = gb_sink if gb_sink is not None else torch.zeros((cout,), device=rows.device, dtype=torch.float32)
         ws = ops._workspace(rows.device, int(L.fgnn_linear_wgrad_workspace_bytes(R, cin, cout)))
         _hip.check(L.fgnn_linear_wgrad(_hip._ptr(rows), _hip._ptr(gy), R, cin, cout, _hip.dtype_code(rows),
                                        _hip._ptr(gw), _hip._ptr(gb), _hip._ptr(ws), ws.numel() * 4,
                                        _hip.stream_ptr()))
-        return grows, gw.to(weight.dtype), (gb.to(weight.dtype) if gb is not None else None)
+        return (grows, None if gw_sink is not None else gw.to(weight.dtype),
+                None if (gb is None or gb_sink is not None) else gb.to(weight.dtype))
 
 
 class PointwiseConv2d(torch.nn.Conv2d):
@@ -68,7 +76,7 @@ class PointwiseConv2d(torch.nn.Conv2d):
             rows = rows.contiguous()
         rows = rows.view(B * H * W, C)
         if torch.is_autocast_enabled():
-            rows = rows.to(torch.get_autocast_gpu_dtype())
+            rows = rows.to(torch.get_autocast_dtype('cuda'))
         weight = self.weight.view(self.out_channels, C)
         if rows.is_cuda and rows.dtype in (torch.float32, torch.bfloat16) and torch.is_grad_enabled() and (
                 weight.requires_grad or rows.requires_grad):
@@ -157,6 +165,7 @@ class _BatchNormAct(torch.autograd.Function):
                                    _hip._ptr(stats[3]), slope, _hip.stream_ptr()))
         ctx.save_for_backward(rows, weight, bias, stats)
         ctx.slope = slope
+        ctx.params = (weight, bias)
         return y
 
     @staticmethod
@@ -169,14 +178,16 @@ class _BatchNormAct(torch.autograd.Function):
         if gy.dtype != rows.dtype:
             gy = gy.to(rows.dtype)
         gx = torch.empty_like(rows)
-        gw = torch.zeros(C, device=rows.device, dtype=torch.float32)
-        gb = torch.zeros(C, device=rows.device, dtype=torch.float32)
+        gw_sink, gb_sink = ops.grad_sink(ctx.params[0]), ops.grad_sink(ctx.params[1])
+        gw = gw_sink if gw_sink is not None else torch.zeros(C, device=rows.device, dtype=torch.float32)
+        gb = gb_sink if gb_sink is not None else torch.zeros(C, device=rows.device, dtype=torch.float32)
         ws = ops._workspace(rows.device, int(L.fgnn_bn_workspace_bytes(R, C)))
         _hip.check(L.fgnn_bn_backward(_hip._ptr(rows), _hip._ptr(gy), _hip._ptr(gx), R, C, _hip.dtype_code(rows),
                                       _hip._ptr(stats[0]), _hip._ptr(stats[1]), _hip._ptr(weight),
                                       _hip._ptr(bias), ctx.slope, _hip._ptr(gw), _hip._ptr(gb), _hip._ptr(ws),
                                       ws.numel() * 4, _hip.stream_ptr()))
-        return gx, gw, gb, None, None, None, None, None
+        return (gx, None if gw_sink is not None else gw, None if gb_sink is not None else gb,
+                None, None, None, None, None)
 
 
 class BatchNormAct2d(torch.nn.BatchNorm2d):

@@ -130,6 +130,25 @@ def mpconv_forward_raw(x, nn_idx, etype, filters, bias, nou, net, ext, agg, *,
     return y, amax
 
 
+def grad_sink(param):
+    """``param.grad`` when a kernel may accumulate straight into it, else None.
+
+    Every gradient kernel of this package ACCUMULATES into its filter / bias outputs.  When a leaf
+    parameter already owns a dense f32 ``.grad`` (a slice of ``dp.FlatGradBucket``, or last step's
+    gradient under plain accumulation) the kernel adds into it directly and the autograd Function
+    returns None for that input — same value autograd's AccumulateGrad would produce, minus one
+    zero-fill, one add and one cast per parameter per step.  (Tensor hooks on such a parameter do not
+    fire; set ``ops.ACCUMULATE_INTO_GRAD = False`` to get ordinary returned gradients.)"""
+    if not ACCUMULATE_INTO_GRAD or param is None or not param.is_leaf or not param.requires_grad:
+        return None
+    g = param.grad
+    if (g is None or g.dtype != torch.float32 or not g.is_contiguous() or g.device != param.device
+            or g.shape != param.shape or g.requires_grad):
+        return None
+    return g
+
+
+ACCUMULATE_INTO_GRAD = True
 _WS = {}
 
 
@@ -152,6 +171,7 @@ class _MPConv(torch.autograd.Function):
                                      want_argmax=True)
         ctx.cfg = (nou, net, ext, agg)
         ctx.has_bias = bias is not None
+        ctx.params = (filters, bias)                     # the leaf tensors themselves (for grad_sink)
         ctx.save_for_backward(x, nn_idx, etype, filters, amax)
         return z
 
@@ -171,8 +191,12 @@ class _MPConv(torch.autograd.Function):
         gx = torch.empty_like(xx)                        # preserve_format keeps xx's strides
         want_get = ctx.needs_input_grad[2]
         get = torch.empty((B, net, M, k), device=x.device, dtype=etype.dtype) if want_get else None
-        gw = torch.zeros(filters.shape, device=x.device, dtype=torch.float32)
-        gb = torch.zeros((nou,), device=x.device, dtype=torch.float32) if ctx.has_bias else None
+        fparam, bparam = ctx.params
+        gw_sink, gb_sink = grad_sink(fparam), grad_sink(bparam)
+        gw = gw_sink if gw_sink is not None else torch.zeros(filters.shape, device=x.device, dtype=torch.float32)
+        gb = None
+        if ctx.has_bias:
+            gb = gb_sink if gb_sink is not None else torch.zeros((nou,), device=x.device, dtype=torch.float32)
         w = filters.detach().float().contiguous()
         d = _hip.make_desc(xx, nn_idx, etype, nou, net, ext, agg, False, gz)
         ws = _workspace(x.device, int(L.fgnn_mpconv_backward_workspace_bytes(ctypes.byref(d))))
@@ -191,7 +215,8 @@ class _MPConv(torch.autograd.Function):
             ctypes.byref(d), _hip._ptr(xx), _hip._ptr(nn_idx), _hip._ptr(etype), _hip._ptr(w),
             _hip._ptr(gz), None, _hip._ptr(amax), _hip._ptr(gx), _hip._ptr(get),
             _hip._ptr(gw), _hip._ptr(gb), _hip._ptr(ws), ws.numel() * 4, _hip.stream_ptr())))
-        return (gx, None, get, gw.to(filters.dtype), gb, None, None, None, None)
+        return (gx, None, get, None if gw_sink is not None else gw.to(filters.dtype),
+                None if gb_sink is not None else gb, None, None, None, None)
 
 
 def mpconv(x, nn_idx, etype, filters, bias, nou, net, ext, agg):

@@ -178,3 +178,44 @@ def test_ldpc_training_reduces_loss(dtype, dev):
         losses.append(loss.item())
     assert all(l == l for l in losses), losses          # no NaN
     assert losses[-1] < 0.8 * losses[0], losses
+
+
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+def test_gradients_accumulated_in_place_equal_returned_gradients(dtype, dev):
+    """With a pre-allocated ``param.grad`` (dp.FlatGradBucket) the weight / bias gradient kernels add
+    straight into it and autograd gets None (ops.grad_sink); the result must be what ordinary returned
+    gradients give — and a second backward must accumulate, exactly like AccumulateGrad."""
+    import fgnn_amd
+    from fgnn_amd import ops
+    from fgnn_amd.dp import FlatGradBucket
+    from fgnn_amd.ldpc import synthetic_batch
+    torch.manual_seed(1)
+    m = fgnn_amd.LDPCModel(2, 6, 4, aggregator='max').to(dev).train()
+    dt = torch.float32 if dtype == 'f32' else torch.bfloat16
+    data = synthetic_batch(16, dev, seed=9, dtype=dt)
+    amp = torch.autocast(device_type='cuda', dtype=torch.bfloat16, enabled=(dtype == 'bf16'))
+    state = {k: v.clone() for k, v in m.state_dict().items()}
+
+    def backward():
+        m.load_state_dict(state)                        # BatchNorm running stats back to the start
+        with amp:
+            logits, snr = m(*data[:6])
+        loss = torch.nn.functional.binary_cross_entropy_with_logits(logits.float().view(-1), data[6].view(-1))
+        (loss + snr.mean()).backward()
+
+    ops.ACCUMULATE_INTO_GRAD = False
+    try:
+        backward()
+    finally:
+        ops.ACCUMULATE_INTO_GRAD = True
+    want = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1)
+                      for p in m.parameters() if p.requires_grad]).clone()
+    for p in m.parameters():
+        p.grad = None
+    bucket = FlatGradBucket(m.parameters())
+    backward()
+    assert float(bucket.flat.abs().max()) > 0
+    tol = 1e-6 if dtype == 'f32' else 1e-5             # same kernels, same data: only 0 + s vs s
+    assert float((bucket.flat - want).abs().max()) <= tol * float(want.abs().max())
+    backward()                                          # accumulates
+    assert float((bucket.flat - 2 * want).abs().max()) <= 2 * tol * float(want.abs().max())
