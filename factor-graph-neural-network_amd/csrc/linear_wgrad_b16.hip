@@ -192,6 +192,145 @@ __global__ __launch_bounds__(256) void wgb_reduce_kernel(const float* __restrict
     }
 }
 
+// ----------------------------------------------------------------------------------------
+// one NARROW operand (<= 16 channels: the edge-feature / input maps 2|6|7 -> 64 and the edge-type head 64 -> 4)
+// against a 64-channel one.  The narrow side is a single MFMA tile whose lane li carries channel li (8 two-byte
+// loads per lane, zero for li >= C); the wide side uses the 8x4 in-register transpose above.  All 16 waves of a
+// workgroup are row-waves.  NARROW_X: x is the narrow operand (gW [64][Cin]); else gy is (gW [Cout][64]).
+// ----------------------------------------------------------------------------------------
+#define WN_NACC 20       // 16 gW accumulators + 4 dbias partials per lane
+
+__device__ __forceinline__ uint4 wb_pack_narrow(const unsigned (&v)[8]) {
+    return make_uint4(v[0] | (v[1] << 16), v[2] | (v[3] << 16), v[4] | (v[5] << 16), v[6] | (v[7] << 16));
+}
+
+template <bool NARROW_X>
+__global__ __launch_bounds__(WB_THREADS) void linear_wgrad_b16_narrow_kernel(const WgbParams p) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int rw = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lk = lane >> 4;
+    const int R = p.R, Cin = p.Cin, Cout = p.Cout;
+    const int Cn = NARROW_X ? Cin : Cout, Cw = NARROW_X ? Cout : Cin;      // Cw == 64
+    const uint16_t* wide = (NARROW_X ? p.gy : p.x) + 4 * li;
+    const uint16_t* nar = (NARROW_X ? p.x : p.gy) + li;
+    const bool nar_ok = li < Cn;
+
+    f32x4 acc[4];
+    float bs[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int nblk = (R + 31) / 32;
+    const int stride = gridDim.x * WB_WAVES;
+    for (int blk = blockIdx.x * WB_WAVES + rw; blk < nblk; blk += stride) {
+        uint2 rwd[8];
+        unsigned rn[8];
+        const int row0 = blk * 32 + 8 * lk;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int row = row0 + j;
+            const bool ok = row < R;
+            rwd[j] = ok ? *reinterpret_cast<const uint2*>(wide + (int64_t)row * Cw) : make_uint2(0, 0);
+            rn[j] = (ok && nar_ok) ? (unsigned)nar[(int64_t)row * Cn] : 0u;
+        }
+        const uint4 N = wb_pack_narrow(rn);
+        uint4 Wd[4];
+        Wd[0] = wb_pack<0>(rwd); Wd[1] = wb_pack<1>(rwd); Wd[2] = wb_pack<2>(rwd); Wd[3] = wb_pack<3>(rwd);
+        if (NARROW_X) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {              // D[i][j]: o = 4 i + t, c = j
+                bs[t] = wb_sum8(Wd[t], bs[t]);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(wb_bf16x8, Wd[t]),
+                                                                 __builtin_bit_cast(wb_bf16x8, N), acc[t], 0, 0, 0);
+            }
+        } else {
+            bs[0] = wb_sum8(N, bs[0]);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)                // D[i][j]: o = i, c = 4 j + t
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(wb_bf16x8, N),
+                                                                 __builtin_bit_cast(wb_bf16x8, Wd[t]), acc[t], 0, 0, 0);
+        }
+    }
+    // tree fold of the 16 row-waves
+    for (int half = WB_WAVES >> 1; half >= 1; half >>= 1) {
+        if (rw >= half && rw < 2 * half) {
+            float* slot = wb_lds + (rw - half) * WN_NACC * 64 + lane;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) slot[(t * 4 + r) * 64] = acc[t][r];
+                slot[(16 + t) * 64] = bs[t];
+            }
+        }
+        __syncthreads();
+        if (rw < half) {
+            const float* src = wb_lds + rw * WN_NACC * 64 + lane;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[t][r] += src[(t * 4 + r) * 64];
+                bs[t] += src[(16 + t) * 64];
+            }
+        }
+        __syncthreads();
+    }
+    if (rw == 0) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            bs[t] += __shfl_xor(bs[t], 16);
+            bs[t] += __shfl_xor(bs[t], 32);
+        }
+        float* slab = p.ws + (int64_t)blockIdx.x * WN_NACC * 64 + lane;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) slab[(t * 4 + r) * 64] = acc[t][r];
+            slab[(16 + t) * 64] = bs[t];
+        }
+    }
+}
+
+template <bool NARROW_X>
+__global__ __launch_bounds__(256) void wgn_reduce_kernel(const float* __restrict__ ws, int nslab, int Cin, int Cout,
+                                                         float* __restrict__ gW, float* __restrict__ gb) {
+    __shared__ float part[16][17];
+    const int e = threadIdx.x & 15, g = threadIdx.x >> 4;
+    const int slab_len = WN_NACC * 64;
+    const int i = blockIdx.x * 16 + e;
+    float s0 = 0.f, s1 = 0.f;
+    for (int w = g; w < nslab; w += 32) {
+        s0 += ws[(int64_t)w * slab_len + i];
+        if (w + 16 < nslab) s1 += ws[(int64_t)(w + 16) * slab_len + i];
+    }
+    part[g][e] = s0 + s1;
+    __syncthreads();
+    if (g != 0) return;
+    float s = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) s += part[q][e];
+    const int l = i & 63, q = i >> 6, li = l & 15, lk = l >> 4;
+    if (q < 16) {
+        const int r = q & 3, t = q >> 2, row = 4 * lk + r;
+        const int o = NARROW_X ? 4 * row + t : row, c = NARROW_X ? li : 4 * li + t;
+        if (o < Cout && c < Cin) gW[(int64_t)o * Cin + c] += s;
+    } else if (gb && lk == 0) {
+        const int t = q - 16;
+        if (NARROW_X) gb[4 * li + t] += s;
+        else if (t == 0 && li < Cout) gb[li] += s;
+    }
+}
+
+static bool wn_plan(int64_t R, int Cin, int Cout, bool* narrow_x, int* gx) {
+    if (Cin <= 16 && Cout == 64) *narrow_x = true;
+    else if (Cout <= 16 && Cin == 64) *narrow_x = false;
+    else return false;
+    const int64_t nblk = (R + 31) / 32;
+    int64_t g = (nblk + 2 * WB_WAVES - 1) / (2 * WB_WAVES);
+    if (g > 256) g = 256;
+    if (g < 1) g = 1;
+    *gx = (int)g;
+    return true;
+}
+
 static bool wb_plan(int64_t R, int Cin, int Cout, int* nso, int* S, int* RW, int* gx) {
     if (Cin % 64 || Cout % 64) return false;
     *nso = Cout / 64;
@@ -209,6 +348,8 @@ static bool wb_plan(int64_t R, int Cin, int Cout, int* nso, int* S, int* RW, int
 
 int64_t fgnn_linear_wgrad_b16_workspace_bytes(int64_t R, int Cin, int Cout) {
     int nso, S, RW, gx;
+    bool nx;
+    if (wn_plan(R, Cin, Cout, &nx, &gx)) return (int64_t)gx * WN_NACC * 64 * 4;
     if (!wb_plan(R, Cin, Cout, &nso, &S, &RW, &gx)) return 0;
     return (int64_t)gx * S * WB_NACC * 64 * 4;
 }
@@ -217,9 +358,29 @@ int64_t fgnn_linear_wgrad_b16_workspace_bytes(int64_t R, int Cin, int Cout) {
 int fgnn_linear_wgrad_b16(const void* x, const void* gy, int64_t R, int Cin, int Cout, float* gW, float* gb,
                           void* workspace, int64_t workspace_bytes, fgnn_stream_t stream) {
     int nso, S, RW, gx;
+    if (getenv("FGNN_WG_OLD")) return 0;
+    bool nx;
+    if (wn_plan(R, Cin, Cout, &nx, &gx)) {
+        if (((uintptr_t)(nx ? gy : x) & 7) || ((uintptr_t)(nx ? x : gy) & 1)) return 0;
+        if (workspace_bytes < (int64_t)gx * WN_NACC * 64 * 4) return 0;
+        WgbParams p;
+        p.x = (const uint16_t*)x; p.gy = (const uint16_t*)gy; p.ws = (float*)workspace;
+        p.R = (int)R; p.Cin = Cin; p.Cout = Cout; p.nso = 1; p.S = 1; p.RW = WB_WAVES;
+        const int lds = (WB_WAVES / 2) * WN_NACC * 64 * 4;
+        hipStream_t st = (hipStream_t)stream;
+        if (nx) {
+            hipLaunchKernelGGL(linear_wgrad_b16_narrow_kernel<true>, dim3(gx), dim3(WB_THREADS), lds, st, p);
+            hipLaunchKernelGGL(wgn_reduce_kernel<true>, dim3(WN_NACC * 4), dim3(256), 0, st, p.ws, gx, Cin, Cout, gW, gb);
+        } else {
+            hipLaunchKernelGGL(linear_wgrad_b16_narrow_kernel<false>, dim3(gx), dim3(WB_THREADS), lds, st, p);
+            hipLaunchKernelGGL(wgn_reduce_kernel<false>, dim3(WN_NACC * 4), dim3(256), 0, st, p.ws, gx, Cin, Cout, gW, gb);
+        }
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "linear_wgrad_b16 narrow launch: %s", hipGetErrorString(e));
+        return 1;
+    }
     if (!wb_plan(R, Cin, Cout, &nso, &S, &RW, &gx)) return 0;
     if (((uintptr_t)x & 7) || ((uintptr_t)gy & 7)) return 0;
-    if (getenv("FGNN_WG_OLD")) return 0;
     if (workspace_bytes < (int64_t)gx * S * WB_NACC * 64 * 4) return 0;
     WgbParams p;
     p.x = (const uint16_t*)x; p.gy = (const uint16_t*)gy; p.ws = (float*)workspace;
