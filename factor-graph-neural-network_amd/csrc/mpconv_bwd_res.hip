@@ -597,6 +597,11 @@ void fgnn_launch_slab_reduce(const float* ws, int nslab, int64_t slab_len, int64
                        slab_len, nw, gW, gbias);
 }
 
+void fgnn_launch_w_transpose(const float* W, float* Wt, int nin, int ncols, hipStream_t st) {
+    hipLaunchKernelGGL(bres_transpose_kernel, dim3((ncols + 31) / 32, (nin + 31) / 32), dim3(256), 0, st, W, Wt, nin,
+                       ncols);
+}
+
 // ----------------------------------------------------------------------------------------
 // host side
 // ----------------------------------------------------------------------------------------

@@ -156,6 +156,51 @@ def test_bf16_mfma_kernel_vs_oracle(shape, agg, dev):
         assert int(am.max()) < k
 
 
+@pytest.mark.parametrize('shape', [(64, 64, 96, 48, 6), (64, 64, 48, 96, 3), (64, 128, 96, 48, 6), (64, 128, 48, 96, 3),
+                                   (128, 64, 96, 48, 6), (128, 64, 48, 96, 3), (64, 64, 40, 20, 5)],
+                         ids=lambda s: 'x'.join(map(str, s)))
+@pytest.mark.parametrize('shared', [False, True], ids=['pergraph', 'sharedgraph'])
+def test_bf16_mfma_backward_vs_routed_reference(shape, shared, dev):
+    """bf16 channel-fastest parity-check calls (4 edge types) take csrc/mpconv_bwd_b16.hip: bf16 matrix cores
+    for the P / dx / dW projections, P and dP rounded to bf16 in LDS.  Checked against torch autograd through
+    the SAME routing (the forward's own argmax) on the same bf16-rounded x / etype / gz, f32 arithmetic:
+    what remains is the bf16 rounding of P, dP and of the bf16 outputs -> 2^-6 of each gradient's range."""
+    from fgnn_amd import _hip, ops
+    nin, nou, N, M, k = shape
+    net, B = 4, 11
+    g = torch.Generator().manual_seed(21 + N + nou)
+    x = torch.randn(B, nin, N, 1, generator=g).bfloat16()
+    idx = torch.randint(0, N, (1 if shared else B, M, k), generator=g)
+    if shared:
+        idx = idx.expand(B, -1, -1)
+    et = torch.randn(B, M, k, net, generator=g).bfloat16()                  # edge-type fastest in memory
+    W = torch.randn(nin, nou * net, generator=g) * 0.1
+    bias = torch.randn(nou, generator=g)
+    gz = torch.randn(B, nou, M, 1, generator=g).bfloat16()
+    xd = x.to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    etd = et.to(dev).permute(0, 3, 1, 2).requires_grad_(True)               # logical [B,net,M,k]
+    idxd = idx.to(dev) if not shared else idx[:1].to(dev).expand(B, -1, -1)
+    Wd, bd = W.to(dev).requires_grad_(True), bias.to(dev).requires_grad_(True)
+    z = ops.mpconv(xd, idxd, etd, Wd, bd, nou, net, 0, _hip.AGG_MAX)
+    _, am = ops.mpconv_forward_raw(xd.detach(), idxd, etd.detach(), W.to(dev), bias.to(dev), nou, net, 0,
+                                   _hip.AGG_MAX, want_argmax=True)
+    z.backward(gz.to(dev))
+    assert 'mpconv_bwd_b16' in _hip.lib().fgnn_last_kernel().decode()
+    xr = x.float().detach().clone().requires_grad_(True)
+    er = et.float().detach().clone().requires_grad_(True)                    # [B,M,k,net]
+    Wr, br = W.clone().requires_grad_(True), bias.clone().requires_grad_(True)
+    P = torch.einsum('bcn,cq->bnq', xr[..., 0], Wr).reshape(B, N, nou, net)
+    E = (P[torch.arange(B)[:, None, None], idx] * er[:, :, :, None, :]).sum(-1)          # [B,M,k,nou]
+    sel = am.cpu().long()[..., 0].permute(0, 2, 1)[:, :, None, :]                        # [B,M,1,nou]
+    zr = E.gather(2, sel)[:, :, 0, :].permute(0, 2, 1)[..., None] + br[None, :, None, None]
+    zr.backward(gz.float())
+    tol = 2.0 ** -6
+    assert H.rel_err(xd.grad.float(), xr.grad) <= tol
+    assert H.rel_err(etd.grad.float(), er.grad.permute(0, 3, 1, 2)) <= tol
+    assert H.rel_err(Wd.grad, Wr.grad) <= tol
+    assert H.rel_err(bd.grad, br.grad) <= tol
+
+
 HYPER_SHAPES = [(64, 64, 96, 1, 96), (64, 64, 1, 96, 1), (64, 128, 96, 1, 96), (64, 128, 1, 96, 1),
                 (128, 64, 96, 1, 96), (128, 64, 1, 96, 1), (64, 64, 40, 1, 130), (64, 64, 1, 7, 1)]
 
