@@ -26,7 +26,8 @@ struct BnParams {
     const float* b;            // forward apply: shift   | backward: invstd
     const float* gamma;
     const float* beta;
-    const float* ref;          // per-channel shift K for the variance accumulation (row 0 of x)
+    const float* ref;          // per-channel shift K for the variance accumulation (row 0 of x), or NULL = 0
+    const void* addend;        // forward apply: y = act(...) + addend (same layout as y), or NULL
     int64_t R;
     int C, cshift;             // cshift = log2(C / EPC)
     int rows_per_wg;
@@ -86,7 +87,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_reduce_kernel(const BnParams p)
 #pragma unroll
     for (int e = 0; e < EPC; ++e) {
         s0[e] = 0.f; s1[e] = 0.f;
-        if (MODE == 0) { ka[e] = p.ref[c0 + e]; kb[e] = 0.f; kc[e] = 0.f; kd[e] = 0.f; }
+        if (MODE == 0) { ka[e] = p.ref ? p.ref[c0 + e] : 0.f; kb[e] = 0.f; kc[e] = 0.f; kd[e] = 0.f; }
         else {
             ka[e] = p.a[c0 + e];                          // mean
             kb[e] = p.b[c0 + e];                          // invstd
@@ -132,17 +133,29 @@ __global__ __launch_bounds__(BN_THREADS) void bn_reduce_kernel(const BnParams p)
 }
 
 // Sum of the workgroup partials of one channel: 16 channels x 16 partial groups per block, folded in LDS.
+// 4 channels x 64 partial groups per block (grid = C/4 blocks: enough workgroups in flight to cover the
+// cross-die latency of partials written on all 8 XCDs); folded in f64 through LDS in a fixed order.
+#define BN_FC 4
 __device__ __forceinline__ void bn_fold(const float* ws, int nwg, int C, int c, int pg, bool ok, double& s0, double& s1) {
     __shared__ double red0[256], red1[256];
     double a = 0.0, b = 0.0;
-    if (ok)
-        for (int w = pg; w < nwg; w += 16) { a += ws[(int64_t)w * 2 * C + c]; b += ws[(int64_t)w * 2 * C + C + c]; }
+    if (ok) {
+#pragma unroll 4
+        for (int w = pg; w < nwg; w += 256 / BN_FC) { a += (double)ws[(int64_t)w * 2 * C + c]; b += (double)ws[(int64_t)w * 2 * C + C + c]; }
+    }
     red0[threadIdx.x] = a;
     red1[threadIdx.x] = b;
     __syncthreads();
+    const int cc = threadIdx.x & (BN_FC - 1);
+    a = 0.0; b = 0.0;
+    if (pg < 8)                                           // two-level fold: 8 x 8 partial groups
+        for (int q = pg * 8; q < pg * 8 + 8; ++q) { a += red0[q * BN_FC + cc]; b += red1[q * BN_FC + cc]; }
+    __syncthreads();
+    if (pg < 8) { red0[threadIdx.x] = a; red1[threadIdx.x] = b; }
+    __syncthreads();
     s0 = 0.0; s1 = 0.0;
     if (pg == 0)
-        for (int q = 0; q < 16; ++q) { s0 += red0[q * 16 + (threadIdx.x & 15)]; s1 += red1[q * 16 + (threadIdx.x & 15)]; }
+        for (int q = 0; q < 8; ++q) { s0 += red0[q * BN_FC + cc]; s1 += red1[q * BN_FC + cc]; }
 }
 
 // forward finaliser: mean / invstd / scale / shift and the running statistics
@@ -151,7 +164,7 @@ __global__ __launch_bounds__(256) void bn_stats_final_kernel(const float* ws, in
                                                              const float* beta, float* rmean, float* rvar,
                                                              float momentum, float eps, float* mean,
                                                              float* invstd, float* scale, float* shift) {
-    const int c = blockIdx.x * 16 + (threadIdx.x & 15), pg = threadIdx.x >> 4;
+    const int c = blockIdx.x * BN_FC + (threadIdx.x & (BN_FC - 1)), pg = threadIdx.x / BN_FC;
     double s0, s1;
     bn_fold(ws, nwg, C, c, pg, c < C, s0, s1);
     if (pg != 0 || c >= C) return;
@@ -159,7 +172,7 @@ __global__ __launch_bounds__(256) void bn_stats_final_kernel(const float* ws, in
     const double m0 = s0 / n;                             // mean of (x - K)
     double var = s1 / n - m0 * m0;
     if (var < 0.0) var = 0.0;
-    const float mu = (float)(m0 + (double)ref[c]);
+    const float mu = (float)(m0 + (ref ? (double)ref[c] : 0.0));
     const float is = (float)(1.0 / sqrt(var + (double)eps));
     mean[c] = mu;
     invstd[c] = is;
@@ -176,7 +189,7 @@ __global__ __launch_bounds__(256) void bn_stats_final_kernel(const float* ws, in
 // backward finaliser: dgamma = sum g xhat, dbeta = sum g (also written to the caller's gradient buffers)
 __global__ __launch_bounds__(256) void bn_bwd_final_kernel(const float* ws, int nwg, int C, float* dsum,
                                                            float* gweight, float* gbias) {
-    const int c = blockIdx.x * 16 + (threadIdx.x & 15), pg = threadIdx.x >> 4;
+    const int c = blockIdx.x * BN_FC + (threadIdx.x & (BN_FC - 1)), pg = threadIdx.x / BN_FC;
     double s0, s1;
     bn_fold(ws, nwg, C, c, pg, c < C, s0, s1);
     if (pg != 0 || c >= C) return;
@@ -221,6 +234,12 @@ __global__ __launch_bounds__(BN_THREADS) void bn_apply_kernel(const BnParams p) 
         if (MODE == 0) {
 #pragma unroll
             for (int e = 0; e < EPC; ++e) { const float pre = fmaf(v[e], ka[e], kb[e]); o[e] = pre > 0.f ? pre : pre * p.slope; }
+            if (p.addend) {
+                float ad[EPC];
+                Chunk<T>::load(static_cast<const T*>(p.addend) + r * p.C + c0, ad);
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) o[e] += ad[e];
+            }
         } else {
             float g[EPC];
             Chunk<T>::load(gg + r * p.C + c0, g);
@@ -278,15 +297,11 @@ extern "C" int fgnn_bn_stats(const void* x, int64_t R, int C, int dtype, const f
     hipStream_t st = (hipStream_t)stream;
     // K: copy row 0 as f32 (tiny) — reuse the apply kernel's chunk loader through a 1-row reduce is overkill
     if (dtype == FGNN_F32) (void)hipMemcpyAsync(ref, x, (size_t)C * 4, hipMemcpyDeviceToDevice, st);
-    else {
-        // bf16 row -> f32 via a one-block identity apply: scale 1, shift 0 cannot be used (needs arrays), so
-        // accumulate against K = 0 for bf16 (values are O(1) after the preceding conv; f32 sums, f64 finaliser)
-        (void)hipMemsetAsync(ref, 0, (size_t)C * 4, st);
-    }
+    else ref = nullptr;      // bf16: accumulate against K = 0 (values are O(1) after the preceding map; f32 sums, f64 finaliser)
     p.x = x; p.ws = ws; p.ref = ref;
     if (dtype == FGNN_F32) hipLaunchKernelGGL((bn_reduce_kernel<float, 0>), dim3(grid), dim3(BN_THREADS), 0, st, p);
     else hipLaunchKernelGGL((bn_reduce_kernel<bf16_t, 0>), dim3(grid), dim3(BN_THREADS), 0, st, p);
-    hipLaunchKernelGGL(bn_stats_final_kernel, dim3((C + 15) / 16), dim3(256), 0, st, ws, grid, C, R, ref, gamma,
+    hipLaunchKernelGGL(bn_stats_final_kernel, dim3((C + BN_FC - 1) / BN_FC), dim3(256), 0, st, ws, grid, C, R, ref, gamma,
                        beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "bn_stats launch: %s", hipGetErrorString(e));
@@ -295,12 +310,12 @@ extern "C" int fgnn_bn_stats(const void* x, int64_t R, int C, int dtype, const f
 
 // y = act(x * scale + shift), act = LeakyReLU(slope) (slope 0: ReLU, slope 1: identity)
 extern "C" int fgnn_bn_apply(const void* x, void* y, int64_t R, int C, int dtype, const float* scale,
-                             const float* shift, float slope, fgnn_stream_t stream) {
+                             const float* shift, float slope, const void* addend, fgnn_stream_t stream) {
     BnParams p = {};
     int grid;
     if (!x || !y || !scale || !shift) FGNN_FAIL(FGNN_EINVAL, "bn_apply: null pointer");
     if (bn_plan(R, C, dtype, &p, &grid)) FGNN_FAIL(FGNN_EUNSUPPORTED, "bn: C=%d not a supported channel count", C);
-    p.x = x; p.out = y; p.a = scale; p.b = shift; p.slope = slope;
+    p.x = x; p.out = y; p.a = scale; p.b = shift; p.slope = slope; p.addend = addend;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == FGNN_F32) hipLaunchKernelGGL((bn_apply_kernel<float, 0>), dim3(grid), dim3(BN_THREADS), 0, st, p);
     else hipLaunchKernelGGL((bn_apply_kernel<bf16_t, 0>), dim3(grid), dim3(BN_THREADS), 0, st, p);
@@ -327,7 +342,7 @@ extern "C" int fgnn_bn_backward(const void* x, const void* gy, void* gx, int64_t
     p.slope = slope; p.dsum_scale = 1.0f / (float)R; p.dbeta = dsum; p.dgamma = dsum + C;
     if (dtype == FGNN_F32) hipLaunchKernelGGL((bn_reduce_kernel<float, 1>), dim3(grid), dim3(BN_THREADS), 0, st, p);
     else hipLaunchKernelGGL((bn_reduce_kernel<bf16_t, 1>), dim3(grid), dim3(BN_THREADS), 0, st, p);
-    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((C + 15) / 16), dim3(256), 0, st, ws, grid, C, dsum, gweight, gbias);
+    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((C + BN_FC - 1) / BN_FC), dim3(256), 0, st, ws, grid, C, dsum, gweight, gbias);
     if (dtype == FGNN_F32) hipLaunchKernelGGL((bn_apply_kernel<float, 1>), dim3(grid), dim3(BN_THREADS), 0, st, p);
     else hipLaunchKernelGGL((bn_apply_kernel<bf16_t, 1>), dim3(grid), dim3(BN_THREADS), 0, st, p);
     hipError_t e = hipGetLastError();

@@ -14,11 +14,14 @@ from .pointwise import NodeInstanceNorm, PointwiseConv2d as _Conv
 from .message_op import base_mp_nn, mp_conv_type, mp_conv_v2
 
 
-def _call(module, x, nn_idx, etype):
-    """The reference's dispatch contract: graph-aware modules get (x, nn_idx, etype)."""
-    if isinstance(module, base_mp_nn):
-        return module(x, nn_idx, etype)
-    return module(x)
+def _call(module, x, nn_idx, etype, addend=None):
+    """The reference's dispatch contract: graph-aware modules get (x, nn_idx, etype).  ``addend`` is this
+    build's extra: blocks that end in a fused BatchNorm+activation kernel add it there (``acc + block(x)``
+    without a separate elementwise pass); for every other module it is added explicitly."""
+    if isinstance(module, (mp_conv_v2, mp_conv_residual)):
+        return module(x, nn_idx, etype, addend=addend)
+    y = module(x, nn_idx, etype) if isinstance(module, base_mp_nn) else module(x)
+    return y if addend is None else addend + y
 
 
 class mp_sequential(base_mp_nn):
@@ -175,10 +178,10 @@ class FactorNN(torch.nn.Module):
             new_var = self.v2v_modules[L](var)
             new_fac = [m(f) for f, m in zip(fac, self.f2f_modules[L])]
             for j in range(self.nfactor_types):
-                new_var = new_var + _call(self.f2v_modules[L][j], fac[j],
-                                          nn_idx_f2v[j].long(), etype_f2v[j])
-                new_fac[j] = new_fac[j] + self.v2f_modules[L][j](
-                    var, nn_idx_v2f[j].long(), etype_v2f[j])
+                new_var = _call(self.f2v_modules[L][j], fac[j], nn_idx_f2v[j].long(), etype_f2v[j],
+                                addend=new_var)
+                new_fac[j] = _call(self.v2f_modules[L][j], var, nn_idx_v2f[j].long(), etype_v2f[j],
+                                   addend=new_fac[j])
             if same_width:
                 var = var + new_var
                 fac = [a + b for a, b in zip(new_fac, fac)]

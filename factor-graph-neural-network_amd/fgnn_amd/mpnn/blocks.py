@@ -77,6 +77,9 @@ class mp_conv_residual(base_mp_nn):
         self.with_residual = with_residual
         self.with_hop = with_hop
 
-    def forward(self, node_feature, nn_idx, etype):
-        h = self.conv2(self.mp_conv(self.conv1(node_feature), nn_idx, etype))
+    def forward(self, node_feature, nn_idx, etype, addend=None):
+        """``addend`` (optional, the caller's running sum of the same shape as the output) is added by conv2's
+        fused BatchNorm+activation kernel instead of a separate elementwise pass."""
+        h = self.mp_conv(self.conv1(node_feature), nn_idx, etype)
+        h = self.conv2[1](self.conv2[0](h), addend=addend)
         return h + node_feature if self.with_residual else h

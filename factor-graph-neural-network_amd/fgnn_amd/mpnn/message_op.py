@@ -83,7 +83,9 @@ class mp_conv_v2(base_mp_nn):
         return 'nin=%d, nou=%d, nedge_types=%d, %s, aggregtor=%s' % (
             self.nin, self.nou, self.nedge_types, self.extension.name, self.aggregtor)
 
-    def forward(self, x, nn_idx, etype):
+    def forward(self, x, nn_idx, etype, addend=None):
+        """``addend``: optional tensor of the output's shape added after the activation (fused into the
+        BatchNorm kernel when training with the plain ReLU)."""
         ext, agg = _EXT_CODE[self.extension], _hip.AGG_CODES[self.aggregtor]
         needs_grad = torch.is_grad_enabled() and (
             x.requires_grad or etype.requires_grad or self.filters.requires_grad)
@@ -99,16 +101,16 @@ class mp_conv_v2(base_mp_nn):
                                           post_shift=shift, relu=plain_relu)
             if self.activation_fn is not None and not plain_relu:
                 y = self.activation_fn(y)
-            return y
+            return y if addend is None else y + addend
         z = ops.mpconv(x, nn_idx, etype, self.filters, self.bias, self.nou,
                        self.nedge_types, ext, agg)
         if self.bn is not None:
-            if plain_relu:                      # BatchNorm + ReLU in one fused kernel pair
+            if plain_relu:                      # BatchNorm + ReLU (+ addend) in one fused kernel pair
                 self.bn.slope = 0.0
-                z = self.bn(z)
+                z = self.bn(z, addend=addend)
                 self.bn.slope = 1.0
                 return z
             z = self.bn(z)
         if self.activation_fn is not None:
             z = self.activation_fn(z)
-        return z
+        return z if addend is None else z + addend

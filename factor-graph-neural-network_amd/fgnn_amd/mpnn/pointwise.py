@@ -14,6 +14,23 @@ import torch
 from .. import _hip
 
 
+_CAST_CACHE = {}
+
+
+def cast_cached(t, dtype):
+    """``t.to(dtype)`` remembered until ``t`` is modified in place (optimizer step, load_state_dict):
+    inference re-uses the bf16 copies of the weights instead of re-casting ~170 tensors per forward."""
+    if t is None or t.dtype == dtype:
+        return t
+    key = id(t)
+    hit = _CAST_CACHE.get(key)
+    if hit is not None and hit[0] is t and hit[1] == t._version and hit[2].dtype == dtype and hit[2].device == t.device:
+        return hit[2]
+    out = t.detach().to(dtype)
+    _CAST_CACHE[key] = (t, t._version, out)
+    return out
+
+
 class _RowLinear(torch.autograd.Function):
     """y = rows @ W^T + b over R = B*N rows.  Forward and grad-input are plain GEMMs (rocBLAS /
     hipBLASLt do those well); the weight / bias gradient is the tall-skinny product
@@ -23,8 +40,8 @@ class _RowLinear(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, rows, weight, bias):
-        w = weight if weight.dtype == rows.dtype else weight.to(rows.dtype)
-        b = bias if bias is None or bias.dtype == rows.dtype else bias.to(rows.dtype)
+        w = cast_cached(weight._base if weight._base is not None else weight, rows.dtype).view(weight.shape)
+        b = cast_cached(bias, rows.dtype)
         ctx.save_for_backward(rows, weight)
         ctx.has_bias = bias is not None
         ctx.params = (weight, bias)                     # leaf tensors (ops.grad_sink)
@@ -39,7 +56,7 @@ class _RowLinear(torch.autograd.Function):
             gy = gy.to(rows.dtype)
         grows = None
         if ctx.needs_input_grad[0]:
-            grows = gy @ (weight if weight.dtype == gy.dtype else weight.to(gy.dtype))
+            grows = gy @ cast_cached(weight._base if weight._base is not None else weight, gy.dtype).view(weight.shape)
         R, cin = rows.shape
         cout = weight.shape[0]
         if cin * cout >= 256 * 256 and not (rows.dtype == torch.bfloat16 and cin % 64 == 0 and cout % 64 == 0
@@ -82,8 +99,8 @@ class PointwiseConv2d(torch.nn.Conv2d):
                 weight.requires_grad or rows.requires_grad):
             y = _RowLinear.apply(rows, weight, self.bias)
         else:
-            w = weight if weight.dtype == rows.dtype else weight.to(rows.dtype)
-            b = self.bias if self.bias is None or self.bias.dtype == rows.dtype else self.bias.to(rows.dtype)
+            w = cast_cached(self.weight, rows.dtype).view(self.out_channels, C)
+            b = cast_cached(self.bias, rows.dtype)
             y = torch.nn.functional.linear(rows, w, b)
         return y.view(B, H, W, self.out_channels).permute(0, 3, 1, 2)
 
@@ -148,7 +165,7 @@ class _BatchNormAct(torch.autograd.Function):
     """Train-mode BatchNorm + LeakyReLU(slope) on channel-fastest rows [R, C] (csrc/bnact.hip)."""
 
     @staticmethod
-    def forward(ctx, rows, weight, bias, running_mean, running_var, momentum, eps, slope):
+    def forward(ctx, rows, weight, bias, running_mean, running_var, momentum, eps, slope, addend=None):
         from .. import ops
         L = _hip.lib()
         R, C = rows.shape
@@ -162,7 +179,8 @@ class _BatchNormAct(torch.autograd.Function):
                                    _hip._ptr(stats[3]), _hip._ptr(ws), ws.numel() * 4, _hip.stream_ptr()))
         y = torch.empty_like(rows)
         _hip.check(L.fgnn_bn_apply(_hip._ptr(rows), _hip._ptr(y), R, C, dt, _hip._ptr(stats[2]),
-                                   _hip._ptr(stats[3]), slope, _hip.stream_ptr()))
+                                   _hip._ptr(stats[3]), slope, _hip._ptr(addend), _hip.stream_ptr()))
+        ctx.has_addend = addend is not None
         ctx.save_for_backward(rows, weight, bias, stats)
         ctx.slope = slope
         ctx.params = (weight, bias)
@@ -187,7 +205,7 @@ class _BatchNormAct(torch.autograd.Function):
                                       _hip._ptr(bias), ctx.slope, _hip._ptr(gw), _hip._ptr(gb), _hip._ptr(ws),
                                       ws.numel() * 4, _hip.stream_ptr()))
         return (gx, None if gw_sink is not None else gw, None if gb_sink is not None else gb,
-                None, None, None, None, None)
+                None, None, None, None, None, gy if ctx.has_addend else None)
 
 
 class BatchNormAct2d(torch.nn.BatchNorm2d):
@@ -207,18 +225,47 @@ class BatchNormAct2d(torch.nn.BatchNorm2d):
             return y
         return torch.nn.functional.leaky_relu(y, self.slope)
 
-    def forward(self, x):
+    def forward(self, x, addend=None):
+        """``addend`` (same shape) is added AFTER the activation — the ``acc = acc + block(x)`` that follows
+        every block in FactorNN rides in the apply kernel instead of being a separate pass."""
         B, C, H, W = x.shape
-        fused = (self.training and x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and
-                 self.track_running_stats and self.affine and
-                 _hip.lib().fgnn_bn_supported(B * H * W, C, _hip.dtype_code(x)))
-        if not fused:
-            return self._activate(super().forward(x))
+        ok = (x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and self.track_running_stats and
+              self.affine and _hip.lib().fgnn_bn_supported(B * H * W, C, _hip.dtype_code(x)))
+        wants_grad = torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad or
+                                                  (addend is not None and addend.requires_grad))
+        if not ok or (not self.training and wants_grad):
+            y = self._activate(super().forward(x))
+            return y if addend is None else y + addend
         rows = x.permute(0, 2, 3, 1)
         if not rows.is_contiguous():
             rows = rows.contiguous()
-        with torch.no_grad():
-            self.num_batches_tracked += 1
-        y = _BatchNormAct.apply(rows.view(B * H * W, C), self.weight, self.bias, self.running_mean,
-                                self.running_var, self.momentum, self.eps, self.slope)
+        rows = rows.view(B * H * W, C)
+        arows = None
+        if addend is not None:
+            arows = addend.permute(0, 2, 3, 1)
+            if arows.dtype != rows.dtype or not arows.is_contiguous():
+                arows = arows.to(rows.dtype).contiguous()
+            arows = arows.view(B * H * W, C)
+        if self.training:
+            with torch.no_grad():
+                self.num_batches_tracked += 1
+            y = _BatchNormAct.apply(rows, self.weight, self.bias, self.running_mean, self.running_var,
+                                    self.momentum, self.eps, self.slope, arows)
+        else:                                           # eval: folded affine + activation in one pass
+            scale, shift = self._folded()
+            y = torch.empty_like(rows)
+            _hip.check(_hip.lib().fgnn_bn_apply(_hip._ptr(rows), _hip._ptr(y), B * H * W, C, _hip.dtype_code(rows),
+                                                _hip._ptr(scale), _hip._ptr(shift), self.slope, _hip._ptr(arows),
+                                                _hip.stream_ptr()))
         return y.view(B, H, W, C).permute(0, 3, 1, 2)
+
+    def _folded(self):
+        """Eval-mode BatchNorm as (scale, shift); recomputed only when a parameter / buffer changed."""
+        key = (self.weight._version, self.bias._version, self.running_mean._version, self.running_var._version,
+               self.weight.device)
+        if getattr(self, '_fold_key', None) != key:
+            with torch.no_grad():
+                scale = self.weight.float() * torch.rsqrt(self.running_var.float() + self.eps)
+                shift = self.bias.float() - self.running_mean.float() * scale
+            self._fold_key, self._fold = key, (scale.contiguous(), shift.contiguous())
+        return self._fold

@@ -129,7 +129,7 @@ int fgnn_bn_stats(const void* x, int64_t R, int32_t C, int32_t dtype, const floa
                   float* invstd, float* scale, float* shift, void* workspace, int64_t workspace_bytes,
                   fgnn_stream_t stream);
 int fgnn_bn_apply(const void* x, void* y, int64_t R, int32_t C, int32_t dtype, const float* scale,
-                  const float* shift, float slope, fgnn_stream_t stream);
+                  const float* shift, float slope, const void* addend, fgnn_stream_t stream);
 int fgnn_bn_backward(const void* x, const void* gy, void* gx, int64_t R, int32_t C, int32_t dtype,
                      const float* mean, const float* invstd, const float* gamma, const float* beta, float slope,
                      float* gweight, float* gbias, void* workspace, int64_t workspace_bytes,
