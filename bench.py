@@ -45,6 +45,7 @@ def parse():
                          'f32 parameters / gradients / optimizer; f32: everything f32 (the 1e-4 parity path)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--miopen-bn', action='store_true', help='let torch route BatchNorm to MIOpen')
+    ap.add_argument('--no-graph', action='store_true', help='launch every kernel from Python instead of replaying a hipGraph')
     ap.add_argument('--cpu-batch', type=int, default=32)
     ap.add_argument('--cpu-threads', type=int, default=16)
     return ap.parse_args()
@@ -142,17 +143,36 @@ def main():
     # the forward), parameters, gradients and optimizer state stay f32 (autocast for the node-wise GEMMs)
     amp = torch.autocast(device_type='cuda', dtype=torch.bfloat16, enabled=(args.dtype == 'bf16'))
 
-    def step():
+    def compute():                      # everything but the collective and the optimizer: graph-capturable
         if train:
             bucket.zero()
             with amp:
                 logits, snr = model(*inputs)
             loss_fn(logits, snr, label, sigma_b).backward()
-            bucket.all_reduce_mean()
-            opt.step()
         else:
             with torch.no_grad(), amp:
                 model(*inputs)
+
+    # The step is launch-bound at this batch (~1500 launches): record it once into a hipGraph and replay it.
+    # The gradient all-reduce and Adam stay outside the graph (one collective + a few foreach kernels).
+    graphed = None
+    if not args.no_graph:
+        try:
+            from fgnn_amd.graph import StepGraph
+            graphed = StepGraph(compute)
+        except Exception as e:           # noqa: BLE001 — report and fall back to eager launches
+            print('bench.py: hipGraph capture failed (%s: %s); running eagerly' % (type(e).__name__, e),
+                  file=sys.stderr)
+            graphed = None
+
+    def step(eager=False):
+        if graphed is not None and not eager:
+            graphed.replay()
+        else:
+            compute()
+        if train:
+            bucket.all_reduce_mean()
+            opt.step()
 
     def fence():
         torch.cuda.synchronize()
@@ -178,7 +198,7 @@ def main():
     kernels = {}
     if rank == 0:
         ops.TIMER = ops.KernelTimer()
-        step()
+        step(eager=True)
         kernels = ops.TIMER.summary()
         ops.TIMER = None
         if kernels:
@@ -231,7 +251,7 @@ def main():
                                    % ('training (fwd+bwd+grad all-reduce+Adam)' if train else
                                       'inference forward', args.batch),
                        'global_batch': args.batch * world, 'parallelism': 'dp%d' % world,
-                       'mode': args.mode},
+                       'mode': args.mode, 'hip_graph': graphed is not None},
             'roofline': roofline,
             'kernels': {k: {'launches': v['launches'], 'avg_us': round(v['ms'] / v['launches'] * 1e3, 2),
                             'total_ms': round(v['ms'], 3)} for k, v in kernels.items()},

@@ -1,0 +1,31 @@
+"""hipGraph capture of a launch-bound step.
+
+One LDPCModel training step is ~1500 kernel launches of 5-250 us each; at the reference batch sizes the
+Python / HIP launch path (~20 us per launch) costs as much as the kernels themselves.  ``StepGraph`` records
+the step once on a capture stream (every kernel of this package launches on torch's current stream, so the
+hand-written HIP kernels, rocBLAS GEMMs and ATen elementwise ops all land in the same graph) and replays it
+with a single launch.  Requirements are torch.cuda.graphs' usual ones: static input tensors (copy new data
+into them), no host synchronisation inside the step, and no collectives (keep the gradient all-reduce outside).
+"""
+import torch
+
+
+class StepGraph:
+    def __init__(self, fn, warmup=2):
+        """``fn()`` is run ``warmup`` times on a side stream (allocator / workspace / autotune warm-up),
+        then captured."""
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                fn()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            fn()
+
+    def replay(self):
+        self.graph.replay()
+
+    __call__ = replay
