@@ -124,7 +124,7 @@ def main():
     # activations (profiles/r01), so MIOpen is bypassed for the plumbing ops by default
     torch.backends.cudnn.enabled = bool(args.miopen_bn)
     from fgnn_amd import ops
-    from fgnn_amd.dp import FlatGradBucket, broadcast_parameters
+    from fgnn_amd.dp import FlatAdam, FlatGradBucket, broadcast_parameters
     from fgnn_amd.ldpc import LDPCModel, MESSAGES_PER_CODEWORD, synthetic_batch
 
     torch.manual_seed(0)
@@ -136,8 +136,10 @@ def main():
     train = args.mode == 'train'
     model.train(train)
     if train:
-        bucket = FlatGradBucket(model.parameters())
-        opt = torch.optim.Adam(bucket.params, lr=1e-4, weight_decay=1e-8)
+        # parameters and gradients live in two flat f32 buffers: one all-reduce, and Adam (the reference's
+        # lr / weight_decay, train_ldpc.py) is eight elementwise kernels instead of a 330-tensor sweep
+        bucket = FlatGradBucket(model.parameters(), flatten_params=True)
+        opt = FlatAdam(bucket, lr=1e-4, weight_decay=1e-8)
 
     # bf16: activations / messages are stored in bf16 (the message kernels then use bf16 matrix cores for
     # the forward), parameters, gradients and optimizer state stay f32 (autocast for the node-wise GEMMs)

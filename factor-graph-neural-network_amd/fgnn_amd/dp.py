@@ -18,7 +18,10 @@ import torch.distributed as dist
 class FlatGradBucket:
     """Owns one contiguous gradient buffer; ``param.grad`` are views into it."""
 
-    def __init__(self, params, process_group=None):
+    def __init__(self, params, process_group=None, flatten_params=False):
+        """``flatten_params=True`` also moves the parameters themselves into one flat f32 buffer
+        (``flat_param``; every ``p.data`` becomes a view of it) so that the optimizer is a handful of
+        kernels over 5.5 MB instead of a multi-tensor sweep over ~330 tensors — see ``FlatAdam``."""
         self.params = [p for p in params if p.requires_grad]
         self.group = process_group
         if not self.params:
@@ -26,10 +29,19 @@ class FlatGradBucket:
         dev, dt = self.params[0].device, torch.float32
         self.numel = sum(p.numel() for p in self.params)
         self.flat = torch.zeros(self.numel, device=dev, dtype=dt)
+        self.flat_param = None
+        if flatten_params:
+            if any(p.dtype != dt for p in self.params):
+                raise ValueError('flatten_params needs float32 parameters')
+            self.flat_param = torch.empty(self.numel, device=dev, dtype=dt)
         off = 0
         for p in self.params:
             n = p.numel()
             p.grad = self.flat[off:off + n].view_as(p)
+            if self.flat_param is not None:
+                view = self.flat_param[off:off + n].view_as(p)
+                view.copy_(p.data)
+                p.data = view
             off += n
 
     def zero(self):
@@ -54,6 +66,40 @@ class FlatGradBucket:
         if work is not None:
             work.wait()
             self.flat.div_(self.world)
+
+
+class FlatAdam:
+    """Adam (torch.optim.Adam's update, no amsgrad) on the flat parameter / gradient buffers of a
+    ``FlatGradBucket(..., flatten_params=True)``: eight elementwise kernels per step, whatever the number of
+    parameter tensors.  In-place updates of the flat buffer do not bump the per-parameter version counters,
+    so the step also invalidates this package's cached low-precision weight copies."""
+
+    def __init__(self, bucket, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        if bucket.flat_param is None:
+            raise ValueError('FlatAdam needs FlatGradBucket(..., flatten_params=True)')
+        self.bucket = bucket
+        self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
+        self.exp_avg = torch.zeros_like(bucket.flat_param)
+        self.exp_avg_sq = torch.zeros_like(bucket.flat_param)
+        self.t = 0
+
+    @torch.no_grad()
+    def step(self):
+        p, g = self.bucket.flat_param, self.bucket.flat
+        b1, b2 = self.betas
+        self.t += 1
+        if self.weight_decay:
+            g = g.add(p, alpha=self.weight_decay)
+        self.exp_avg.lerp_(g, 1.0 - b1)
+        self.exp_avg_sq.mul_(b2).addcmul_(g, g, value=1.0 - b2)
+        bc1, bc2 = 1.0 - b1 ** self.t, 1.0 - b2 ** self.t
+        denom = (self.exp_avg_sq.sqrt() / (bc2 ** 0.5)).add_(self.eps)
+        p.addcdiv_(self.exp_avg, denom, value=-self.lr / bc1)
+        from .mpnn import pointwise
+        pointwise.invalidate_casts()
+
+    def zero_grad(self, set_to_none=False):
+        self.bucket.zero()
 
 
 def broadcast_parameters(module, src=0, group=None):

@@ -17,7 +17,7 @@ MESSAGES_PER_CODEWORD = 8 * (288 + 288 + 96 + 96)
 
 
 def _edge_mlp(cin, hidden, cout):
-    return torch.nn.Sequential(PointwiseConv2d(cin, hidden, 1), torch.nn.ReLU(inplace=True),
+    return torch.nn.Sequential(PointwiseConv2d(cin, hidden, 1), torch.nn.ReLU(),
                                PointwiseConv2d(hidden, cout, 1))
 
 

@@ -22,7 +22,7 @@ def _conv_norm_act(cin, cout, norm, act, bias=True):
 class iid_mapping(torch.nn.Module):
     def __init__(self, nin, nout, bias=True):
         super().__init__()
-        self.main = _conv_norm_act(nin, nout, None, torch.nn.LeakyReLU(inplace=True), bias)
+        self.main = _conv_norm_act(nin, nout, None, torch.nn.LeakyReLU(), bias)
 
     def forward(self, x):
         return self.main(x)

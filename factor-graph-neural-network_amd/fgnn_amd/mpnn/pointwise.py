@@ -15,6 +15,16 @@ from .. import _hip
 
 
 _CAST_CACHE = {}
+_CAST_EPOCH = 0
+
+
+def invalidate_casts():
+    """Forget every cached low-precision copy (call after updating parameters through an alias that does not
+    bump their version counters, e.g. a flat parameter buffer; dp.FlatAdam does)."""
+    global _CAST_EPOCH
+    _CAST_EPOCH += 1
+    _CAST_CACHE.clear()
+
 
 
 def cast_cached(t, dtype):
