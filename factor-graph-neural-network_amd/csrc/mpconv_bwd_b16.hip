@@ -24,7 +24,7 @@
 #define BB_THREADS 512
 #define BB_WAVES 8
 #define BB_MAXN 128
-#define BB_GS 36         // gz_s / am_s row stride (32 channels of a pass + 4)
+#define BB_GS 40         // gz_s / am_s row stride (32 channels of a pass + 8: rows stay 8-byte aligned)
 #define BB_PSB 136       // P / dP row stride in bf16 elements (128 columns of a pass + 8)
 
 typedef __bf16 bb_bf16x8 __attribute__((ext_vector_type(8)));
@@ -43,8 +43,10 @@ struct Bb16Params {
     uint16_t* get;       // or NULL
     float* ws;           // per-workgroup slabs [grid][nin*ncols + nou]
     int Npad16, Npad32;
-    int off_xb, off_pb, off_gz, off_am, off_et, off_idx, off_cs, off_cl, off_ce;   // byte offsets
+    int off_xb, off_pb, off_db, off_gz, off_am, off_et, off_det, off_idx, off_cs, off_cl, off_ce;   // byte offsets
     unsigned kmagic;     // ceil(2^32 / k)
+    long long* prof;     // FGNN_PROF: wave 0 of workgroup 0 stamps s_memtime at the phase boundaries of its 3rd sample
+    int dbg;             // FGNN_DBG ablation mask (tuning only): 1 P, 2 dP, 4 det, 8 dx, 16 dW, 32 commit, 64 prefetch, 128 aT
 };
 
 extern __shared__ __attribute__((aligned(16))) unsigned char fgnn_lds_bb[];
@@ -86,6 +88,14 @@ __device__ __forceinline__ bb_bf16x8 bb_tr_dyn(const uint2 (&r)[8], int P) {
     }
 }
 
+#define BB_STAMP(slot) do { if (p.prof && blockIdx.x == 0 && tid == 0 && b == b_begin + 2) p.prof[slot] = __builtin_readcyclecounter(); } while (0)
+
+__device__ __forceinline__ float bb_quad_sum(float v) {       // sum over the 4 lanes of a quad (all lanes get it)
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+    return v;
+}
+
 // KS2 = nin / 32 (k-steps of the P projection), NPASS = ncols / 128 (column passes, 32 output channels each)
 template <int KS2, int NPASS>
 __global__ __launch_bounds__(BB_THREADS) void mpconv_bwd_b16_kernel(const Bb16Params p) {
@@ -97,48 +107,60 @@ __global__ __launch_bounds__(BB_THREADS) void mpconv_bwd_b16_kernel(const Bb16Pa
     constexpr int DXT = (NCT == 4) ? 3 : 6;           // dx tiles per wave (Npad16 <= 96)
     constexpr int HX = NIN / 64;                      // 64-channel groups of x for the dW transposes
     constexpr int XQ = (96 * NIN / 8 + BB_THREADS - 1) / BB_THREADS;   // 16-byte x chunks per thread
+    constexpr bool AT_RES = NPASS == 2;               // dx-projection fragments of both passes stay in registers
     const fgnn_mpconv_desc& d = p.d;
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int N = d.N, M = d.M, k = d.k;
     const int mk = M * k;
 
-    uint16_t* xb = reinterpret_cast<uint16_t*>(fgnn_lds_bb + p.off_xb);     // [Npad32][XSB]   bf16
-    uint16_t* pb = reinterpret_cast<uint16_t*>(fgnn_lds_bb + p.off_pb);     // [Npad32][PSB]   bf16: P then dP
+    uint16_t* xb = reinterpret_cast<uint16_t*>(fgnn_lds_bb + p.off_xb);     // [Npad32][XSB]   bf16 x
+    uint16_t* pb = reinterpret_cast<uint16_t*>(fgnn_lds_bb + p.off_pb);     // [Npad32][PSB]   bf16 P of the pass
+    uint16_t* db = reinterpret_cast<uint16_t*>(fgnn_lds_bb + p.off_db);     // [Npad32][PSB]   bf16 dP of the pass
     float* gz_s = reinterpret_cast<float*>(fgnn_lds_bb + p.off_gz);         // [M][GS]         f32
     uint8_t* am_s = fgnn_lds_bb + p.off_am;                                 // [M][GS]         argmax
     float* et_s = reinterpret_cast<float*>(fgnn_lds_bb + p.off_et);         // [mk][4]
+    float* det_s = reinterpret_cast<float*>(fgnn_lds_bb + p.off_det);       // [mk][4]         detype of the sample
     int* idx_s = reinterpret_cast<int*>(fgnn_lds_bb + p.off_idx);
     int* cs_s = reinterpret_cast<int*>(fgnn_lds_bb + p.off_cs);             // CSR: start[N+1], then cnt[N]
     int* cl_s = reinterpret_cast<int*>(fgnn_lds_bb + p.off_cl);             // CSR: in-edge list (packed)
     int* ce_s = reinterpret_cast<int*>(fgnn_lds_bb + p.off_ce);             // CSR: et_s offset of each in-edge
 
-    // ---- resident W fragments of the P projection: A[i = col][k = c] = Wt[col][c], 8 consecutive c ----
+    const int ct = wave % NCT;                        // this wave's channel tile of dx
+    // ---- resident W fragments ----
+    // aP: A of P^T = W^T x   : A[i = col][k = c] = Wt[col][c], 8 consecutive c
+    // aT: A of dx^T = W dP^T : A[i = c][k = col] = W[c][col],  8 consecutive cols
     bb_bf16x8 aP[NPASS][KS2];
+    bb_bf16x8 aT[AT_RES ? NPASS : 1][4];
     {
         const int li0 = lane & 15, lk0 = lane >> 4;
 #pragma unroll
-        for (int ps = 0; ps < NPASS; ++ps)
+        for (int ps = 0; ps < NPASS; ++ps) {
 #pragma unroll
             for (int ks = 0; ks < KS2; ++ks)
                 aP[ps][ks] = bb_frag_f32(p.Wt + (int64_t)(ps * 128 + wave * 16 + li0) * NIN + 32 * ks + 8 * lk0);
+            if constexpr (AT_RES) {
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks)
+                    aT[ps][ks] = bb_frag_f32(p.W + (int64_t)(ct * 16 + li0) * NCOLS + ps * 128 + 32 * ks + 8 * lk0);
+            }
+        }
     }
-    const int ct = wave % NCT;                        // this wave's channel tile of dx
 
     f32x4 gw[NPASS][4 * HX];                          // dW accumulators: (pass, x group h, column slot p)
 #pragma unroll
     for (int a = 0; a < NPASS; ++a)
 #pragma unroll
         for (int t = 0; t < 4 * HX; ++t) gw[a][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float gbacc[NPASS];                               // dbias of channel pass*32 + (tid - 448), wave 7 only
+    float gbacc[NPASS];                               // dbias of channel pass*32 + (tid & 31), one partial per 16 rows
 #pragma unroll
     for (int a = 0; a < NPASS; ++a) gbacc[a] = 0.f;
 
-    // ---- prefetch registers (raw bf16 chunks) ----
+    // ---- prefetch registers (raw bf16 chunks; nothing is decoded before the commit) ----
     uint4 px[XQ], pg;
     unsigned pa[2];
     uint2 pe;
-    int ir = 0;
+    long long ir = 0;
     const int xchunks = N * (NIN / 8);
     auto prefetch_x = [&](int b, int t) {
         const uint4* xg = reinterpret_cast<const uint4*>(p.x + (int64_t)b * d.x_sb);
@@ -151,9 +173,7 @@ __global__ __launch_bounds__(BB_THREADS) void mpconv_bwd_b16_kernel(const Bb16Pa
         if (t < mk) {
             pe = *reinterpret_cast<const uint2*>(p.et + (int64_t)b * d.et_sb + (int64_t)t * 4);
             const unsigned m = __umulhi((unsigned)t, p.kmagic), j = t - m * k;
-            long long v = (p.idx + (int64_t)b * d.idx_sb)[(int64_t)m * d.idx_sm + (int64_t)j * d.idx_sk];
-            v = v < 0 ? 0 : (v >= N ? N - 1 : v);
-            ir = (int)v;
+            ir = (p.idx + (int64_t)b * d.idx_sb)[(int64_t)m * d.idx_sm + (int64_t)j * d.idx_sk];
         }
     };
     // gz / argmax slice of (sample b, pass): 32 channels [pass*32, pass*32+32) of every destination m
@@ -178,7 +198,9 @@ __global__ __launch_bounds__(BB_THREADS) void mpconv_bwd_b16_kernel(const Bb16Pa
         }
         if (t < mk) {
             *reinterpret_cast<f32x4*>(et_s + t * 4) = (f32x4){bb_lo(pe.x), bb_hi(pe.x), bb_lo(pe.y), bb_hi(pe.y)};
-            idx_s[t] = ir;
+            *reinterpret_cast<f32x4*>(det_s + t * 4) = (f32x4){0.f, 0.f, 0.f, 0.f};
+            const long long v = ir;
+            idx_s[t] = (int)(v < 0 ? 0 : (v >= N ? N - 1 : v));
         }
     };
     auto commit_g = [&](int t) {
@@ -229,7 +251,10 @@ __global__ __launch_bounds__(BB_THREADS) void mpconv_bwd_b16_kernel(const Bb16Pa
 
     // zero the LDS images once: padding rows / columns are read by the matrix cores and never written again
     for (int f = tid; f < p.Npad32 * XSB / 2; f += BB_THREADS) reinterpret_cast<unsigned*>(xb)[f] = 0u;
-    for (int f = tid; f < p.Npad32 * BB_PSB / 2; f += BB_THREADS) reinterpret_cast<unsigned*>(pb)[f] = 0u;
+    for (int f = tid; f < p.Npad32 * BB_PSB / 2; f += BB_THREADS) {
+        reinterpret_cast<unsigned*>(pb)[f] = 0u;
+        reinterpret_cast<unsigned*>(db)[f] = 0u;
+    }
 
     const int ntile = p.Npad16 / 16;
     const int nkst = p.Npad32 / 32;
@@ -238,40 +263,51 @@ __global__ __launch_bounds__(BB_THREADS) void mpconv_bwd_b16_kernel(const Bb16Pa
     const int b_end = min(d.B, b_begin + chunk);
     if (b_begin < b_end) { prefetch_x(b_begin, tid); prefetch_g(b_begin, 0, tid); }
     const bool shared_graph = d.idx_sb == 0;
+    const int ndet = p.get ? 4 * mk : 0;              // detype work items: (edge, 8-channel octet)
+    const int ngath = ndet + p.Npad16 * 8;            // + dP work items: (source node, 4-channel group)
 
     for (int b = b_begin; b < b_end; ++b) {
-        __syncthreads();                              // previous sample's MFMAs are done with xb / pb
+        __syncthreads();                              // previous sample's MFMAs are done with xb / db, its writers with det_s
+        BB_STAMP(0);
         int t = tid;
         asm volatile("" : "+v"(t));                   // keep per-lane offsets out of long-lived registers
         const int li = t & 15, lk = (t >> 4) & 3;
-        commit_x(t);
-        commit_g(t);
+        if (!(p.dbg & 32)) { commit_x(t); commit_g(t); }
+        BB_STAMP(1);
         __syncthreads();
-        if (b + 1 < b_end) prefetch_x(b + 1, t);
-        prefetch_g(b, 1, t);                          // NPASS >= 2
+        BB_STAMP(2);
+        if (!(p.dbg & 64)) {
+            if (b + 1 < b_end) prefetch_x(b + 1, t);
+            BB_STAMP(20);
+            prefetch_g(b, 1, t);                      // NPASS >= 2
+            BB_STAMP(21);
+        }
         if (!shared_graph || b == b_begin) build_csr();
+        BB_STAMP(3);
 
         f32x4 dxacc[DXT];
 #pragma unroll
         for (int i = 0; i < DXT; ++i) dxacc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        float dacc[4] = {0.f, 0.f, 0.f, 0.f};         // detype of edge r = tid (< mk)
 
 #pragma unroll
         for (int pass = 0; pass < NPASS; ++pass) {
             if (pass > 0) {
-                __syncthreads();                      // previous pass's dx / dW MFMAs are done with pb
-                commit_g(t);
-                if (pass + 1 < NPASS) prefetch_g(b, pass + 1, t);
-                else if (b + 1 < b_end) prefetch_g(b + 1, 0, t);
+                // gz_s / am_s were last read by the previous pass's gather, which ended at a barrier
+                if (!(p.dbg & 32)) commit_g(t);
+                if (!(p.dbg & 64)) {
+                    if (pass + 1 < NPASS) prefetch_g(b, pass + 1, t);
+                    else if (b + 1 < b_end) prefetch_g(b + 1, 0, t);
+                }
             }
-            // W fragments of the dx projection: A[i = c][k = col] = W[c][col], 8 consecutive cols (L2-resident)
-            bb_bf16x8 aT[4];
+            const int APS = AT_RES ? pass : 0;
+            if constexpr (!AT_RES) {
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
-                aT[ks] = bb_frag_f32(p.W + (int64_t)(ct * 16 + li) * NCOLS + pass * 128 + 32 * ks + 8 * lk);
-
+                for (int ks = 0; ks < 4; ++ks)
+                    aT[0][ks] = bb_frag_f32(p.W + (int64_t)(ct * 16 + li) * NCOLS + pass * 128 + 32 * ks + 8 * lk);
+            }
+            BB_STAMP(5 + 8 * pass);
             // ---- P^T slab (wave = 16-column slab of the pass): D[i = col][j = n]; only detype needs P ----
-            for (int nt = 0; nt < (p.get ? ntile : 0); ++nt) {
+            for (int nt = 0; nt < ((p.get && !(p.dbg & 1)) ? ntile : 0); ++nt) {
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f};
                 const uint16_t* bp = xb + (nt * 16 + li) * XSB + 8 * lk;
 #pragma unroll
@@ -281,97 +317,122 @@ __global__ __launch_bounds__(BB_THREADS) void mpconv_bwd_b16_kernel(const Bb16Pa
                 *reinterpret_cast<uint2*>(pb + (nt * 16 + li) * BB_PSB + wave * 16 + 4 * lk) =
                     make_uint2(bb_pack2(acc[0], acc[1]), bb_pack2(acc[2], acc[3]));
             }
+            // dbias: thread (row group t >> 5, channel t & 31) sums rows t >> 5, +16, ... of this pass's gz slice
+            // (gz_s of this pass was committed before the previous barrier or, for pass 0, before the sample's)
             __syncthreads();
-
-            // ---- dbias (one idle half-wave) and detype owners: edge r = (m, j) sums over this pass's channels ----
-            if (t >= 448 && t < 480) {
+            BB_STAMP(6 + 8 * pass);
+            {
                 float sgz = 0.f;
-                for (int m = 0; m < M; ++m) sgz += gz_s[m * BB_GS + (t - 448)];
+                for (int m = t >> 5; m < M; m += BB_THREADS / 32) sgz += gz_s[m * BB_GS + (t & 31)];
                 gbacc[pass] += sgz;
             }
-            if (p.get) {
-                if (t < mk) {
-                    const unsigned m = __umulhi((unsigned)t, p.kmagic), j = t - m * k;
-                    const uint16_t* pn = pb + idx_s[t] * BB_PSB;
-                    const float* gm = gz_s + m * BB_GS;
-                    const uint8_t* am = am_s + m * BB_GS;
-#pragma unroll 2
-                    for (int ol = 0; ol < 32; ol += 4) {
-                        const unsigned a4 = *reinterpret_cast<const unsigned*>(am + ol);
-                        const unsigned x4 = a4 ^ (j * 0x01010101u);
-                        if (((x4 - 0x01010101u) & ~x4 & 0x80808080u) != 0u) {
-                            const f32x4 g4 = *reinterpret_cast<const f32x4*>(gm + ol);
+
+            // ---- gather phase: one work list, no barrier inside.  Items [0, ndet) are detype partials of
+            //      (edge r, channel octet q) — the 4 octets of an edge sit in one quad and fold by DPP;
+            //      items [ndet, ngath) are dP owners (source node n, 4-channel group og) gathering over n's
+            //      in-edges.  All LDS reads of an item are issued before its arithmetic (masked, branch-free).
+            for (int it = t; it < ngath; it += BB_THREADS) {
+                if (it < ndet) {
+                    if (p.dbg & 4) continue;
+                    const int r = it >> 2, q = it & 3;
+                    const unsigned m = __umulhi((unsigned)r, p.kmagic), j = r - m * k;
+                    const uint2 a8 = *reinterpret_cast<const uint2*>(am_s + m * BB_GS + 8 * q);
+                    const f32x4 g0 = *reinterpret_cast<const f32x4*>(gz_s + m * BB_GS + 8 * q);
+                    const f32x4 g1 = *reinterpret_cast<const f32x4*>(gz_s + m * BB_GS + 8 * q + 4);
+                    const uint4* pp = reinterpret_cast<const uint4*>(pb + idx_s[r] * BB_PSB + 32 * q);
+                    const uint4 p0 = pp[0], p1 = pp[1], p2 = pp[2], p3 = pp[3];    // channels 8q..8q+7, 4 edge types each
+                    const unsigned jj = j * 0x01010101u;
+                    const unsigned xa = a8.x ^ jj, xb4 = a8.y ^ jj;                // zero byte <=> routed through edge j
+                    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+                    auto one = [&](unsigned x4, int u, float g, unsigned lo2, unsigned hi2) {
+                        const float gg = ((x4 >> (8 * u)) & 0xffu) == 0u ? g : 0.f;
+                        acc[0] = fmaf(gg, bb_lo(lo2), acc[0]);
+                        acc[1] = fmaf(gg, bb_hi(lo2), acc[1]);
+                        acc[2] = fmaf(gg, bb_lo(hi2), acc[2]);
+                        acc[3] = fmaf(gg, bb_hi(hi2), acc[3]);
+                    };
+                    one(xa, 0, g0[0], p0.x, p0.y); one(xa, 1, g0[1], p0.z, p0.w);
+                    one(xa, 2, g0[2], p1.x, p1.y); one(xa, 3, g0[3], p1.z, p1.w);
+                    one(xb4, 0, g1[0], p2.x, p2.y); one(xb4, 1, g1[1], p2.z, p2.w);
+                    one(xb4, 2, g1[2], p3.x, p3.y); one(xb4, 3, g1[3], p3.z, p3.w);
 #pragma unroll
-                            for (int u = 0; u < 4; ++u) {
-                                if (((x4 >> (8 * u)) & 0xffu) == 0u) {
-                                    const uint2 p4 = *reinterpret_cast<const uint2*>(pn + (ol + u) * 4);
-                                    const float g = g4[u];
-                                    dacc[0] = fmaf(g, bb_lo(p4.x), dacc[0]);
-                                    dacc[1] = fmaf(g, bb_hi(p4.x), dacc[1]);
-                                    dacc[2] = fmaf(g, bb_lo(p4.y), dacc[2]);
-                                    dacc[3] = fmaf(g, bb_hi(p4.y), dacc[3]);
+                    for (int e = 0; e < 4; ++e) acc[e] = bb_quad_sum(acc[e]);
+                    if (q == 0) {
+                        f32x4* dsl = reinterpret_cast<f32x4*>(det_s + r * 4);
+                        const f32x4 old = *dsl;
+                        *dsl = (f32x4){old[0] + acc[0], old[1] + acc[1], old[2] + acc[2], old[3] + acc[3]};
+                    }
+                } else {
+                    if (p.dbg & 2) continue;
+                    const int o = it - ndet;
+                    const int n = o >> 3, og = o & 7;
+                    float acc[16];
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) acc[u] = 0.f;
+                    if (n < N) {
+                        const int q1 = cs_s[n + 1];
+                        for (int q0 = cs_s[n]; q0 < q1; q0 += 3) {
+                            int ent[3], ceo[3];
+#pragma unroll
+                            for (int u = 0; u < 3; ++u) {
+                                const bool ok = q0 + u < q1;
+                                ent[u] = ok ? cl_s[q0 + u] : 0xff;          // slot 255 never matches an argmax
+                                ceo[u] = ok ? ce_s[q0 + u] : 0;
+                            }
+                            unsigned a4[3];
+                            f32x4 g4[3], e4[3];
+#pragma unroll
+                            for (int u = 0; u < 3; ++u) {
+                                const int mrow = ent[u] >> 8;
+                                a4[u] = *reinterpret_cast<const unsigned*>(am_s + mrow + og * 4);
+                                g4[u] = *reinterpret_cast<const f32x4*>(gz_s + mrow + og * 4);
+                                e4[u] = *reinterpret_cast<const f32x4*>(et_s + ceo[u]);
+                            }
+#pragma unroll
+                            for (int u = 0; u < 3; ++u) {
+                                const unsigned x4 = a4[u] ^ ((unsigned)(ent[u] & 0xff) * 0x01010101u);
+#pragma unroll
+                                for (int c = 0; c < 4; ++c) {
+                                    const float g = ((x4 >> (8 * c)) & 0xffu) == 0u ? g4[u][c] : 0.f;
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) acc[c * 4 + e] = fmaf(g, e4[u][e], acc[c * 4 + e]);
                                 }
                             }
                         }
                     }
+                    uint4* dst = reinterpret_cast<uint4*>(db + n * BB_PSB + og * 16);
+                    dst[0] = make_uint4(bb_pack2(acc[0], acc[1]), bb_pack2(acc[2], acc[3]),
+                                        bb_pack2(acc[4], acc[5]), bb_pack2(acc[6], acc[7]));
+                    dst[1] = make_uint4(bb_pack2(acc[8], acc[9]), bb_pack2(acc[10], acc[11]),
+                                        bb_pack2(acc[12], acc[13]), bb_pack2(acc[14], acc[15]));
                 }
-                __syncthreads();                      // P is dead: the buffer becomes dP
-            }
-
-            // ---- dP owners: (source node n, group of 4 channels = 16 columns) gathers over n's in-edges ----
-            for (int it = t; it < p.Npad16 * 8; it += BB_THREADS) {
-                const int n = it >> 3, og = it & 7;
-                float acc[16];
-#pragma unroll
-                for (int u = 0; u < 16; ++u) acc[u] = 0.f;
-                if (n < N) {
-                    for (int q = cs_s[n]; q < cs_s[n + 1]; ++q) {
-                        const int ent = cl_s[q];
-                        const int mrow = ent >> 8, j = ent & 0xff;
-                        const unsigned a4 = *reinterpret_cast<const unsigned*>(am_s + mrow + og * 4);
-                        const unsigned x4 = a4 ^ ((unsigned)j * 0x01010101u);   // zero byte <=> routed through edge j
-                        if (((x4 - 0x01010101u) & ~x4 & 0x80808080u) != 0u) {
-                            const f32x4 g4 = *reinterpret_cast<const f32x4*>(gz_s + mrow + og * 4);
-                            const f32x4 e4 = *reinterpret_cast<const f32x4*>(et_s + ce_s[q]);
-#pragma unroll
-                            for (int u = 0; u < 4; ++u) {
-                                const float g = ((x4 >> (8 * u)) & 0xffu) == 0u ? g4[u] : 0.f;
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) acc[u * 4 + e] = fmaf(g, e4[e], acc[u * 4 + e]);
-                            }
-                        }
-                    }
-                }
-                uint4* dst = reinterpret_cast<uint4*>(pb + n * BB_PSB + og * 16);
-                dst[0] = make_uint4(bb_pack2(acc[0], acc[1]), bb_pack2(acc[2], acc[3]),
-                                    bb_pack2(acc[4], acc[5]), bb_pack2(acc[6], acc[7]));
-                dst[1] = make_uint4(bb_pack2(acc[8], acc[9]), bb_pack2(acc[10], acc[11]),
-                                    bb_pack2(acc[12], acc[13]), bb_pack2(acc[14], acc[15]));
             }
             __syncthreads();
+            BB_STAMP(8 + 8 * pass);
 
             // ---- dx^T tiles (ct fixed per wave): D[i = c][j = n] += W[c][pass cols] . dP^T ----
 #pragma unroll
             for (int i = 0; i < DXT; ++i) {
                 const int nt = (NCT == 4) ? (wave / 4 + 2 * i) : i;
-                if (nt < ntile) {
-                    const uint16_t* bp = pb + (nt * 16 + li) * BB_PSB + 8 * lk;
+                if (nt < ntile && !(p.dbg & 8)) {
+                    const uint16_t* bp = db + (nt * 16 + li) * BB_PSB + 8 * lk;
                     f32x4 acc = dxacc[i];
 #pragma unroll
                     for (int ks = 0; ks < 4; ++ks)
                         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                            aT[ks], __builtin_bit_cast(bb_bf16x8, *reinterpret_cast<const uint4*>(bp + 32 * ks)), acc, 0, 0, 0);
+                            aT[APS][ks], __builtin_bit_cast(bb_bf16x8, *reinterpret_cast<const uint4*>(bp + 32 * ks)), acc, 0, 0, 0);
                     dxacc[i] = acc;
                 }
             }
+            BB_STAMP(9 + 8 * pass);
             // ---- dW: contraction over nodes.  A = x^T (4 column slots per 64-channel group), B = dP^T slot
             //      (h', p') = (wave / 4, wave % 4) of this pass's 128 columns ----
-            for (int kst = 0; kst < nkst; ++kst) {
+            for (int kst = 0; kst < ((p.dbg & 16) ? 0 : nkst); ++kst) {
                 const int row0 = 32 * kst + 8 * lk;
                 uint2 rd[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j)
-                    rd[j] = *reinterpret_cast<const uint2*>(pb + (row0 + j) * BB_PSB + 64 * (wave >> 2) + 4 * li);
+                    rd[j] = *reinterpret_cast<const uint2*>(db + (row0 + j) * BB_PSB + 64 * (wave >> 2) + 4 * li);
                 const bb_bf16x8 bfr = bb_tr_dyn(rd, wave & 3);
 #pragma unroll
                 for (int h = 0; h < HX; ++h) {
@@ -385,6 +446,7 @@ __global__ __launch_bounds__(BB_THREADS) void mpconv_bwd_b16_kernel(const Bb16Pa
                     gw[pass][4 * h + 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bb_tr<3>(rx), bfr, gw[pass][4 * h + 3], 0, 0, 0);
                 }
             }
+            BB_STAMP(10 + 8 * pass);
         }   // passes
 
         // ---- write gx (bf16, channel-fastest) and getype for this sample ----
@@ -398,21 +460,25 @@ __global__ __launch_bounds__(BB_THREADS) void mpconv_bwd_b16_kernel(const Bb16Pa
                     *reinterpret_cast<uint2*>(gxb + (int64_t)n * NIN + ct * 16 + 4 * lk) =
                         make_uint2(bb_pack2(dxacc[i][0], dxacc[i][1]), bb_pack2(dxacc[i][2], dxacc[i][3]));
             }
-            if (p.get && t < mk) {
+            if (p.get && t < mk) {                     // det_s is complete since the last pass's gather barrier
+                const f32x4 dv = *reinterpret_cast<const f32x4*>(det_s + t * 4);
                 uint16_t* gb = p.get + (int64_t)b * 4 * mk;          // [4][M][k] contiguous
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const __bf16 h = (__bf16)dacc[e];
+                    const __bf16 h = (__bf16)dv[e];
                     gb[e * mk + t] = __builtin_bit_cast(uint16_t, h);
                 }
             }
         }
+        BB_STAMP(40);
     }   // samples
 
     // ---- flush dW tiles and dbias into this workgroup's slab (summed by the slab reduce) ----
     if (b_begin < b_end) {
         const int li = lane & 15, lk = lane >> 4;
         float* slab = p.ws + (int64_t)blockIdx.x * ((int64_t)NIN * NCOLS + NOU);
+        float* red = gz_s;                             // 16 row-group partials per dbias channel, folded in order
+        __syncthreads();
 #pragma unroll
         for (int pass = 0; pass < NPASS; ++pass) {
             const int col = pass * 128 + 64 * (wave >> 2) + 4 * li + (wave & 3);
@@ -423,7 +489,14 @@ __global__ __launch_bounds__(BB_THREADS) void mpconv_bwd_b16_kernel(const Bb16Pa
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
                         slab[(int64_t)(64 * h + 4 * (4 * lk + r) + pp) * NCOLS + col] = gw[pass][4 * h + pp][r];
-            if (tid >= 448 && tid < 480) slab[(int64_t)NIN * NCOLS + pass * 32 + (tid - 448)] = gbacc[pass];
+            red[tid] = gbacc[pass];
+            __syncthreads();
+            if (tid < 32) {
+                float sgz = 0.f;
+                for (int g = 0; g < BB_THREADS / 32; ++g) sgz += red[g * 32 + tid];
+                slab[(int64_t)NIN * NCOLS + pass * 32 + tid] = sgz;
+            }
+            __syncthreads();
         }
     }
 }
@@ -470,15 +543,25 @@ int fgnn_mpconv_backward_b16(const fgnn_mpconv_desc* d, const void* x, const int
     p.Wt = p.ws + 256 * slab_len;
     p.Npad16 = fgnn_round_up(d->N, 16);
     p.Npad32 = fgnn_round_up(d->N, 32);
+    { const char* e = getenv("FGNN_DBG"); p.dbg = e ? atoi(e) : 0; }
+    p.prof = nullptr;
+    static long long* prof_buf = nullptr;
+    if (getenv("FGNN_PROF")) {
+        if (!prof_buf) { (void)hipMalloc(&prof_buf, 64 * 8); }
+        (void)hipMemset(prof_buf, 0, 64 * 8);
+        p.prof = prof_buf;
+    }
     p.kmagic = d->k == 1 ? 0u : (unsigned)((0x100000000ULL + d->k - 1) / d->k);
     if (d->k == 1) BB_REJECT(10);
     int off_b = 0;
     auto take = [&](int bytes) { const int o = off_b; off_b = fgnn_round_up(off_b + bytes, 16); return o; };
     p.off_xb = take(p.Npad32 * (d->nin + 8) * 2);
     p.off_pb = take(p.Npad32 * BB_PSB * 2);
-    p.off_gz = take(d->M * BB_GS * 4);
+    p.off_db = take(p.Npad32 * BB_PSB * 2);
+    p.off_gz = take((d->M * BB_GS > BB_THREADS ? d->M * BB_GS : BB_THREADS) * 4);
     p.off_am = take(d->M * BB_GS);
     p.off_et = take(mk * 16);
+    p.off_det = take(mk * 16);
     p.off_idx = take(mk * 4);
     p.off_cs = take((2 * BB_MAXN + 4) * 4);
     p.off_cl = take(mk * 4);
@@ -502,5 +585,13 @@ int fgnn_mpconv_backward_b16(const fgnn_mpconv_desc* d, const void* x, const int
     fgnn_launch_slab_reduce(p.ws, grid, slab_len, nw, gfilters, gbias, st);
     e = hipGetLastError();
     if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "mpconv backward helper launch: %s", hipGetErrorString(e));
+    if (p.prof) {                                     // tuning aid: phase timeline of one sample (cycles at 100 MHz s_memtime)
+        long long h[64];
+        (void)hipDeviceSynchronize();
+        (void)hipMemcpy(h, p.prof, sizeof(h), hipMemcpyDeviceToHost);
+        fprintf(stderr, "[fgnn prof]");
+        for (int i = 0; i < 41; ++i) if (h[i]) fprintf(stderr, " %d:%lld", i, h[i] - h[0]);
+        fprintf(stderr, "\n");
+    }
     return 1;
 }
