@@ -309,6 +309,9 @@ int fgnn_mpconv_forward_resident(const fgnn_mpconv_desc* d, const void* x, const
                                  const float* post_scale, const float* post_shift, void* y,
                                  uint8_t* argmax, fgnn_stream_t stream);
 
+int fgnn_mpconv_forward_hyper(const fgnn_mpconv_desc* d, const void* x, const int64_t* nn_idx, const void* etype,
+                              const float* filters, const float* bias, const float* post_scale,
+                              const float* post_shift, void* y, uint8_t* argmax, fgnn_stream_t stream);
 int fgnn_mpconv_forward_b16(const fgnn_mpconv_desc* d, const void* x, const int64_t* nn_idx,
                             const void* etype, const float* filters, const float* bias,
                             const float* post_scale, const float* post_shift, void* y,
@@ -365,6 +368,9 @@ extern "C" int fgnn_mpconv_forward(const fgnn_mpconv_desc* d, const void* x, con
     {   // LDPC shape family: W-stationary persistent kernel (mpconv_fwd_res.hip)
         static const bool force_generic = getenv("FGNN_FORCE_GENERIC") != nullptr;
         if (!force_generic) {
+            rc = fgnn_mpconv_forward_hyper(d, x, nn_idx, etype, filters, bias, post_scale, post_shift, y, argmax,
+                                           stream);
+            if (rc != 0) return rc < 0 ? rc : FGNN_OK;
             rc = fgnn_mpconv_forward_b16(d, x, nn_idx, etype, filters, bias, post_scale, post_shift, y, argmax,
                                          stream);
             if (rc != 0) return rc < 0 ? rc : FGNN_OK;

@@ -205,6 +205,39 @@ HYPER_SHAPES = [(64, 64, 96, 1, 96), (64, 64, 1, 96, 1), (64, 128, 96, 1, 96), (
                 (128, 64, 96, 1, 96), (128, 64, 1, 96, 1), (64, 64, 40, 1, 130), (64, 64, 1, 7, 1)]
 
 
+@pytest.mark.parametrize('shape', [(64, 64, 96, 1, 96), (64, 64, 1, 96, 1), (64, 128, 96, 1, 96), (64, 128, 1, 96, 1),
+                                   (128, 64, 96, 1, 96), (128, 64, 1, 96, 1), (64, 64, 40, 1, 130), (64, 64, 1, 7, 1)],
+                         ids=lambda s: 'x'.join(map(str, s)))
+@pytest.mark.parametrize('agg', ['max', 'softmax', 'mean'])
+def test_bf16_hyper_edge_forward_vs_oracle(shape, agg, dev):
+    """bf16 channel-fastest hyper-factor calls take csrc/mpconv_fwd_hyper.hip (one wave per sample).  Same
+    check as the bf16-MFMA kernel: f32 oracle on the same bf16-rounded x / etype / filters, bound 2^-6 of the
+    output range (P and the output are rounded to bf16); bias, folded affine and ReLU are exercised too."""
+    from fgnn_amd import _hip, ops
+    nin, nou, N, M, k = shape
+    B = 13
+    g = torch.Generator().manual_seed(31 + N + nou)
+    x = torch.randn(B, nin, N, 1, generator=g).bfloat16()
+    idx = torch.randint(0, N, (B, M, k), generator=g)
+    et = (torch.rand(B, 1, M, k, generator=g) + 0.5).bfloat16()
+    W = (torch.randn(nin, nou, generator=g) * 0.1).bfloat16().float()
+    bias = torch.randn(nou, generator=g)
+    scale, shift = torch.rand(nou, generator=g) + 0.5, torch.randn(nou, generator=g)
+    ref = O.mp_conv({'filters': W, 'bias': bias}, '', x.float(), idx, et.float(), nou=nou, net=1, extension=0,
+                    aggregator=agg, relu=False)
+    ref = torch.relu(ref * scale[None, :, None, None] + shift[None, :, None, None])
+    xd = x.to(dev).contiguous(memory_format=torch.channels_last)
+    y, am = ops.mpconv_forward_raw(xd, idx.to(dev), et.to(dev), W.to(dev), bias.to(dev), nou, 1, 0,
+                                   _hip.AGG_CODES[agg], post_scale=scale.to(dev), post_shift=shift.to(dev),
+                                   relu=True, want_argmax=True)
+    assert ('fanin' if M == 1 else 'fanout') in _hip.lib().fgnn_last_kernel().decode()
+    assert y.dtype == torch.bfloat16 and y.shape == ref.shape
+    err = float((y.float().cpu() - ref).abs().max() / ref.abs().max())
+    assert err <= 2.0 ** -6, err
+    if agg == 'max':
+        assert int(am.max()) < k
+
+
 @pytest.mark.parametrize('shape', HYPER_SHAPES, ids=lambda s: 'x'.join(map(str, s)))
 @pytest.mark.parametrize('layout', ['nchw', 'channels_last'])
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16], ids=['f32', 'bf16'])
