@@ -74,6 +74,55 @@ def test_two_rank_dp_equals_single_process(tmp_path):
     assert torch.allclose(a, ref, atol=1e-6), float((a - ref).abs().max())
 
 
+def _worker_adam(rank, world, port, out):
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.join(os.path.dirname(here), 'factor-graph-neural-network_amd'))
+    from fgnn_amd.dp import FlatAdam, FlatGradBucket, broadcast_parameters, shard_range
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    net = _net()
+    if rank == 1:
+        with torch.no_grad():
+            for p in net.parameters():
+                p.mul_(0.5)
+    broadcast_parameters(net)
+    g = torch.Generator().manual_seed(7)
+    X, Y = torch.randn(10, 6, generator=g), torch.randn(10, 3, generator=g)
+    lo, hi = shard_range(10, rank, world)
+    bucket = FlatGradBucket(net.parameters(), flatten_params=True)      # what bench.py builds
+    opt = FlatAdam(bucket, lr=1e-2, weight_decay=1e-3)
+    for _ in range(4):
+        bucket.zero()
+        (((net(X[lo:hi]) - Y[lo:hi]) ** 2).sum() * (world / 10.0)).backward()
+        bucket.all_reduce_mean()
+        opt.step()
+    torch.save(bucket.flat_param.clone(), os.path.join(out, 'adam%d.pt' % rank))
+    dist.destroy_process_group()
+
+
+def test_two_rank_flat_adam_equals_single_process_adam(tmp_path):
+    """The exact training plumbing of bench.py (flat parameter + gradient buffers, one all-reduce, FlatAdam)
+    on 2 gloo ranks == torch.optim.Adam on the whole batch in one process."""
+    port = _free_port()
+    mp.spawn(_worker_adam, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    a = torch.load(os.path.join(str(tmp_path), 'adam0.pt'))
+    b = torch.load(os.path.join(str(tmp_path), 'adam1.pt'))
+    assert torch.equal(a, b), 'replicas diverged'
+    net = _net()
+    g = torch.Generator().manual_seed(7)
+    X, Y = torch.randn(10, 6, generator=g), torch.randn(10, 3, generator=g)
+    opt = torch.optim.Adam(net.parameters(), lr=1e-2, weight_decay=1e-3)
+    for _ in range(4):
+        opt.zero_grad()
+        (((net(X) - Y) ** 2).sum() / 10.0).backward()
+        opt.step()
+    ref = torch.cat([p.detach().reshape(-1) for p in net.parameters()])
+    assert torch.allclose(a, ref, atol=2e-6), float((a - ref).abs().max())
+
+
 def test_shard_range_covers_everything():
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
