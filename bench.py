@@ -46,7 +46,7 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--miopen-bn', action='store_true', help='let torch route BatchNorm to MIOpen')
     ap.add_argument('--no-graph', action='store_true', help='launch every kernel from Python instead of replaying a hipGraph')
-    ap.add_argument('--cpu-batch', type=int, default=32)
+    ap.add_argument('--cpu-batch', type=int, default=512)
     ap.add_argument('--cpu-threads', type=int, default=16)
     return ap.parse_args()
 

@@ -308,6 +308,22 @@ extern "C" int fgnn_bn_stats(const void* x, int64_t R, int C, int dtype, const f
     return FGNN_OK;
 }
 
+// Forward statistics from per-workgroup partials somebody else produced (fgnn_linear_forward's epilogue):
+// partials[w][0][c] = sum y, partials[w][1][c] = sum y^2 over that workgroup's rows.  Same outputs as fgnn_bn_stats.
+extern "C" int fgnn_bn_finalize(const float* partials, int npartials, int64_t R, int C, const float* gamma,
+                                const float* beta, float* running_mean, float* running_var, float momentum,
+                                float eps, float* mean, float* invstd, float* scale, float* shift,
+                                fgnn_stream_t stream) {
+    if (!partials || !mean || !invstd || !scale || !shift) FGNN_FAIL(FGNN_EINVAL, "bn_finalize: null pointer");
+    if (npartials < 1 || npartials > BN_GRID || R < 1 || C < 1) FGNN_FAIL(FGNN_EINVAL, "bn_finalize: bad sizes");
+    hipLaunchKernelGGL(bn_stats_final_kernel, dim3((C + BN_FC - 1) / BN_FC), dim3(256), 0, (hipStream_t)stream, partials,
+                       npartials, C, R, (const float*)nullptr, gamma, beta, running_mean, running_var, momentum, eps,
+                       mean, invstd, scale, shift);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "bn_finalize launch: %s", hipGetErrorString(e));
+    return FGNN_OK;
+}
+
 // y = act(x * scale + shift), act = LeakyReLU(slope) (slope 0: ReLU, slope 1: identity)
 extern "C" int fgnn_bn_apply(const void* x, void* y, int64_t R, int C, int dtype, const float* scale,
                              const float* shift, float slope, const void* addend, fgnn_stream_t stream) {

@@ -1,0 +1,180 @@
+// linear_fwd_b16.hip — forward of the node-wise (1x1) maps around the message operator for bf16 activations:
+//
+//     y[r][o] = sum_c x[r][c] W[o][c] + b[o]          r over R = B*N rows, Cin / Cout multiples of 64, <= 256
+//
+// (`Conv2d(cin, cout, 1)` in mp_conv_residual / iid_mapping*, /root/reference/lib/model/mpnn/mp_nn_residual.py:25-35,
+// base_model.py:43-90), optionally with the per-channel batch statistics of y for the BatchNorm that follows it
+// in the reference (sum and sum of squares per workgroup, in the partial layout csrc/bnact.hip folds), so that
+// the BatchNorm needs no statistics pass of its own.
+//
+// A skinny GEMM (K, N <= 256, M ~ 4e5) is a pure stream: 2*R*(Cin+Cout) bytes against 2*R*Cin*Cout flops on the
+// bf16 matrix cores.  W^T lives in LDS as bf16 (register-resident when it is at most 16 fragments); a wave walks
+// 16-row tiles, takes the x operand straight from global memory (8 consecutive channels of a row = one 16-byte
+// load per lane, each byte fetched once) and writes 4 consecutive output channels of a row per lane.  Wide
+// outputs are split over the waves of a workgroup (<= 64 output channels per wave), which then share the x rows
+// through L1.  No barriers in the streaming loop.
+#include "fgnn_common.h"
+#include <stdlib.h>
+
+#define LF_THREADS 512
+#define LF_WAVES 8
+#define LF_MAXGRID 512   // == BN_GRID of bnact.hip: the statistics partials reuse its workspace layout
+
+typedef __bf16 lf_bf16x8 __attribute__((ext_vector_type(8)));
+
+struct LfParams {
+    const uint16_t* x;   // [R][Cin] bf16
+    const float* W;      // [Cout][Cin] f32
+    const float* bias;   // [Cout] or NULL
+    uint16_t* y;         // [R][Cout] bf16
+    float* part;         // [grid][2][Cout] per-workgroup (sum, sum of squares) of y, or NULL
+    int R, Cin, Cout;
+    int CG;              // output-channel groups per workgroup (waves = CG x 8/CG row groups)
+};
+
+extern __shared__ __attribute__((aligned(16))) unsigned char lf_lds[];
+
+__device__ __forceinline__ unsigned lf_pack2(float a, float b) {
+    typedef __bf16 v2 __attribute__((ext_vector_type(2)));
+    const v2 h = {(__bf16)a, (__bf16)b};
+    return __builtin_bit_cast(unsigned, h);
+}
+
+// KS = Cin / 32 k-steps, OTW = 16-channel output tiles per wave (Cout / 16 / CG), WREG: W fragments in registers
+template <int KS, int OTW, bool WREG>
+__global__ __launch_bounds__(LF_THREADS) void linear_fwd_b16_kernel(const LfParams p) {
+    constexpr int CIN = 32 * KS, WS = CIN + 8;            // LDS row stride of W (bf16 elements)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lk = lane >> 4;
+    const int Cout = p.Cout, R = p.R;
+    const int cg = wave % p.CG, rg = wave / p.CG, nrg = LF_WAVES / p.CG;
+    uint16_t* Wl = reinterpret_cast<uint16_t*>(lf_lds);                    // [Cout][WS] bf16
+    float* bl = reinterpret_cast<float*>(lf_lds + (size_t)Cout * WS * 2);    // [Cout] bias
+    float* red = bl + Cout;                                                // [nrg][2][Cout] statistics fold
+    for (int f = tid; f < Cout * (CIN / 2); f += LF_THREADS) {
+        const int o = f / (CIN / 2), c2 = f - o * (CIN / 2);
+        const float2 w = *reinterpret_cast<const float2*>(p.W + (int64_t)o * CIN + 2 * c2);
+        *reinterpret_cast<unsigned*>(Wl + o * WS + 2 * c2) = lf_pack2(w.x, w.y);
+    }
+    for (int f = tid; f < Cout; f += LF_THREADS) bl[f] = p.bias ? p.bias[f] : 0.f;
+    __syncthreads();
+
+    const int o_base = cg * OTW * 16;                     // this wave's first output channel
+    lf_bf16x8 aW[WREG ? OTW : 1][WREG ? KS : 1];
+    if constexpr (WREG) {
+#pragma unroll
+        for (int ot = 0; ot < OTW; ++ot)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+                aW[ot][ks] = __builtin_bit_cast(lf_bf16x8, *reinterpret_cast<const uint4*>(Wl + (o_base + ot * 16 + li) * WS + 32 * ks + 8 * lk));
+    }
+    f32x4 bv[OTW];
+#pragma unroll
+    for (int ot = 0; ot < OTW; ++ot) bv[ot] = *reinterpret_cast<const f32x4*>(bl + o_base + ot * 16 + 4 * lk);
+    f32x4 s0[OTW], s1[OTW];
+#pragma unroll
+    for (int ot = 0; ot < OTW; ++ot) { s0[ot] = (f32x4){0.f, 0.f, 0.f, 0.f}; s1[ot] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+
+    const int ntile = (R + 15) / 16;
+    const int stride = gridDim.x * nrg;
+    for (int tile = blockIdx.x * nrg + rg; tile < ntile; tile += stride) {
+        const int row = tile * 16 + li;
+        const bool ok = row < R;
+        uint4 bx[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+            bx[ks] = ok ? *reinterpret_cast<const uint4*>(p.x + (int64_t)row * CIN + 32 * ks + 8 * lk) : make_uint4(0, 0, 0, 0);
+#pragma unroll
+        for (int ot = 0; ot < OTW; ++ot) {
+            f32x4 acc = bv[ot];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                lf_bf16x8 a;
+                if constexpr (WREG) a = aW[ot][ks];
+                else a = __builtin_bit_cast(lf_bf16x8, *reinterpret_cast<const uint4*>(Wl + (o_base + ot * 16 + li) * WS + 32 * ks + 8 * lk));
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, __builtin_bit_cast(lf_bf16x8, bx[ks]), acc, 0, 0, 0);
+            }
+            // D[i = o 4lk+r][j = row]: four consecutive output channels of this lane's row
+            if (ok) {
+                *reinterpret_cast<uint2*>(p.y + (int64_t)row * Cout + o_base + ot * 16 + 4 * lk) =
+                    make_uint2(lf_pack2(acc[0], acc[1]), lf_pack2(acc[2], acc[3]));
+                if (p.part) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { s0[ot][r] += acc[r]; s1[ot][r] = fmaf(acc[r], acc[r], s1[ot][r]); }
+                }
+            }
+        }
+    }
+    if (p.part) {                                         // per-workgroup (sum, sum of squares) of every channel
+#pragma unroll
+        for (int ot = 0; ot < OTW; ++ot)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float a = s0[ot][r], b = s1[ot][r];
+#pragma unroll
+                for (int m = 1; m < 16; m <<= 1) { a += __shfl_xor(a, m); b += __shfl_xor(b, m); }   // the 16 rows of a tile
+                if (li == 0) {
+                    const int o = o_base + ot * 16 + 4 * lk + r;
+                    red[(rg * 2) * Cout + o] = a;
+                    red[(rg * 2 + 1) * Cout + o] = b;
+                }
+            }
+        __syncthreads();
+        for (int f = tid; f < 2 * Cout; f += LF_THREADS) {
+            float s = 0.f;
+            for (int g = 0; g < nrg; ++g) s += red[g * 2 * Cout + f];
+            p.part[(int64_t)blockIdx.x * 2 * Cout + f] = s;
+        }
+    }
+}
+
+static int lf_plan(int64_t R, int Cin, int Cout, int* CG, int* grid) {
+    if (Cin % 64 || Cout % 64 || Cin > 256 || Cout > 256 || R <= 0 || R > 0x7fffffff) return -1;
+    *CG = Cout / 64;                                      // <= 64 output channels (4 tiles) per wave
+    if (*CG == 3) return -1;
+    const int nrg = LF_WAVES / *CG;
+    const int64_t ntile = (R + 15) / 16;
+    int64_t g = (ntile + 2 * nrg - 1) / (2 * nrg);         // >= 2 tiles per wave
+    if (g > LF_MAXGRID) g = LF_MAXGRID;
+    if (g < 1) g = 1;
+    *grid = (int)g;
+    return 0;
+}
+
+// Number of per-workgroup statistics partials a call with these sizes writes (0 = shape not supported).
+extern "C" int fgnn_linear_forward_partials(int64_t R, int Cin, int Cout) {
+    int CG, grid;
+    return lf_plan(R, Cin, Cout, &CG, &grid) ? 0 : grid;
+}
+
+// y = x W^T + b for bf16 x / y, f32 W / b.  stats_partials: NULL, or device scratch of
+// fgnn_linear_forward_partials(..) * 2 * Cout floats receiving per-workgroup (sum y, sum y^2) per channel —
+// feed it to fgnn_bn_finalize.  Returns FGNN_EUNSUPPORTED for other shapes (callers fall back to a library GEMM).
+extern "C" int fgnn_linear_forward(const void* x, const float* W, const float* bias, void* y, int64_t R, int Cin,
+                                   int Cout, float* stats_partials, fgnn_stream_t stream) {
+    if (!x || !W || !y) FGNN_FAIL(FGNN_EINVAL, "linear_forward: null pointer");
+    int CG, grid;
+    if (lf_plan(R, Cin, Cout, &CG, &grid) || ((uintptr_t)x & 15) || ((uintptr_t)y & 7) || ((uintptr_t)W & 7))
+        FGNN_FAIL(FGNN_EUNSUPPORTED, "linear_forward: Cin=%d Cout=%d outside the bf16 streaming kernel's family", Cin, Cout);
+    LfParams p;
+    p.x = (const uint16_t*)x; p.W = W; p.bias = bias; p.y = (uint16_t*)y; p.part = stats_partials;
+    p.R = (int)R; p.Cin = Cin; p.Cout = Cout; p.CG = CG;
+    const int KS = Cin / 32;
+    void* fn;
+    switch (KS) {       // OTW == 4 always (64 output channels per wave); fragments stay in registers up to Cin 128
+        case 2: fn = (void*)linear_fwd_b16_kernel<2, 4, true>; break;
+        case 4: fn = (void*)linear_fwd_b16_kernel<4, 4, true>; break;
+        case 6: fn = (void*)linear_fwd_b16_kernel<6, 4, false>; break;
+        default: fn = (void*)linear_fwd_b16_kernel<8, 4, false>; break;
+    }
+    const int lds = Cout * (Cin + 8) * 2 + Cout * 4 + (LF_WAVES / CG) * 2 * Cout * 4;
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "hipFuncSetAttribute(%d B LDS): %s", lds, hipGetErrorString(e));
+    }
+    void* args[] = {(void*)&p};
+    hipError_t e = hipLaunchKernel(fn, dim3(grid), dim3(LF_THREADS), args, lds, (hipStream_t)stream);
+    if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "linear_forward launch: %s", hipGetErrorString(e));
+    return FGNN_OK;
+}

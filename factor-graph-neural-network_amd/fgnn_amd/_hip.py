@@ -22,7 +22,8 @@ AGG_CODES = {'max': AGG_MAX, 'softmax': AGG_LSE, 'mean': AGG_MEAN}
 EXPORTS = ('fgnn_mpconv_forward', 'fgnn_mpconv_backward', 'fgnn_mpconv_forward_lds_bytes',
            'fgnn_mpconv_backward_workspace_bytes', 'fgnn_linear_wgrad', 'fgnn_linear_wgrad_workspace_bytes',
            'fgnn_instnorm_forward', 'fgnn_instnorm_backward', 'fgnn_bn_supported', 'fgnn_bn_workspace_bytes',
-           'fgnn_bn_stats', 'fgnn_bn_apply', 'fgnn_bn_backward',
+           'fgnn_bn_stats', 'fgnn_bn_finalize', 'fgnn_bn_apply', 'fgnn_bn_backward',
+           'fgnn_linear_forward', 'fgnn_linear_forward_partials',
            'fgnn_mpconv_algorithmic_bytes', 'fgnn_last_error', 'fgnn_last_kernel', 'fgnn_abi_version')
 
 
@@ -79,6 +80,12 @@ def lib():
     L.fgnn_bn_workspace_bytes.argtypes = [i64, i32]
     L.fgnn_bn_stats.restype = ctypes.c_int
     L.fgnn_bn_stats.argtypes = [vp, i64, i32, i32, vp, vp, vp, vp, f32, f32, vp, vp, vp, vp, vp, i64, vp]
+    L.fgnn_bn_finalize.restype = ctypes.c_int
+    L.fgnn_bn_finalize.argtypes = [vp, i32, i64, i32, vp, vp, vp, vp, f32, f32, vp, vp, vp, vp, vp]
+    L.fgnn_linear_forward.restype = ctypes.c_int
+    L.fgnn_linear_forward.argtypes = [vp, vp, vp, vp, i64, i32, i32, vp, vp]
+    L.fgnn_linear_forward_partials.restype = ctypes.c_int
+    L.fgnn_linear_forward_partials.argtypes = [i64, i32, i32]
     L.fgnn_bn_apply.restype = ctypes.c_int
     L.fgnn_bn_apply.argtypes = [vp, vp, i64, i32, i32, vp, vp, f32, vp, vp]
     L.fgnn_bn_backward.restype = ctypes.c_int

@@ -35,7 +35,7 @@ class iid_mapping_bn(torch.nn.Module):
         self.main = _conv_norm_act(nin, nout, BatchNormAct2d(nout, slope=0.0), torch.nn.Identity(), bias)
 
     def forward(self, x):
-        return self.main(x)
+        return self.main[1](self.main[0](x, want_stats=self.training))
 
 
 class iid_mapping_in(torch.nn.Module):
@@ -80,6 +80,8 @@ class mp_conv_residual(base_mp_nn):
     def forward(self, node_feature, nn_idx, etype, addend=None):
         """``addend`` (optional, the caller's running sum of the same shape as the output) is added by conv2's
         fused BatchNorm+activation kernel instead of a separate elementwise pass."""
-        h = self.mp_conv(self.conv1(node_feature), nn_idx, etype)
-        h = self.conv2[1](self.conv2[0](h), addend=addend)
+        fuse = self.training            # BatchNorm statistics ride in the 1x1 map's epilogue when training
+        h = self.conv1[1](self.conv1[0](node_feature, want_stats=fuse))
+        h = self.mp_conv(h, nn_idx, etype)
+        h = self.conv2[1](self.conv2[0](h, want_stats=fuse), addend=addend)
         return h + node_feature if self.with_residual else h

@@ -41,6 +41,54 @@ def cast_cached(t, dtype):
     return out
 
 
+_PENDING_STATS = None     # (rows tensor, number of partials) of the last hip_linear(..., want_stats=True)
+
+
+def hip_linear(rows, weight, bias, want_stats=False):
+    """``rows @ weight.T + bias`` through csrc/linear_fwd_b16.hip (bf16 rows, f32 parameters, channel counts in
+    multiples of 64): one pass over rows and the output at HBM rate, no cast of the weights.  With
+    ``want_stats`` the kernel's epilogue also leaves the per-channel batch statistics of the output in the
+    shared workspace for the BatchNorm that follows (``take_pending_stats``).  None = shape not handled."""
+    global _PENDING_STATS
+    _PENDING_STATS = None
+    if not (rows.is_cuda and rows.dtype == torch.bfloat16 and weight.dtype == torch.float32 and rows.is_contiguous()):
+        return None
+    R, cin = rows.shape
+    cout = weight.shape[0]
+    # measured on MI355X (scratch lbench, R = 393 k rows): the streaming kernel beats rocBLAS up to 64x128 maps
+    # (21 vs 32 us at 64x64); with the statistics epilogue it also wins at 64x256 / 256x64 because it saves the
+    # BatchNorm's own pass over the output; wider maps stay with rocBLAS (4 TB/s there)
+    if cin * cout > (16384 if want_stats else 8192):
+        return None
+    L = _hip.lib()
+    npart = L.fgnn_linear_forward_partials(R, cin, cout)
+    if npart == 0:
+        return None
+    from .. import ops
+    w = weight.detach()
+    if not w.is_contiguous():
+        w = w.contiguous()
+    b = None if bias is None else bias.detach().float().contiguous()
+    y = torch.empty((R, cout), device=rows.device, dtype=rows.dtype)
+    ws = None
+    if want_stats:
+        ws = ops._workspace(rows.device, int(L.fgnn_bn_workspace_bytes(R, cout)))
+    _hip.check(L.fgnn_linear_forward(_hip._ptr(rows), _hip._ptr(w), _hip._ptr(b), _hip._ptr(y), R, cin, cout,
+                                     _hip._ptr(ws), _hip.stream_ptr()))
+    if want_stats:
+        _PENDING_STATS = (y, npart)
+    return y
+
+
+def take_pending_stats(rows):
+    """Number of statistics partials waiting in the shared workspace for exactly this tensor, else 0."""
+    global _PENDING_STATS
+    pend, _PENDING_STATS = _PENDING_STATS, None
+    if pend is not None and pend[0].data_ptr() == rows.data_ptr() and pend[0].shape == rows.shape:
+        return pend[1]
+    return 0
+
+
 class _RowLinear(torch.autograd.Function):
     """y = rows @ W^T + b over R = B*N rows.  Forward and grad-input are plain GEMMs (rocBLAS /
     hipBLASLt do those well); the weight / bias gradient is the tall-skinny product
@@ -49,12 +97,15 @@ class _RowLinear(torch.autograd.Function):
     rows and gy)."""
 
     @staticmethod
-    def forward(ctx, rows, weight, bias):
-        w = cast_cached(weight._base if weight._base is not None else weight, rows.dtype).view(weight.shape)
-        b = cast_cached(bias, rows.dtype)
+    def forward(ctx, rows, weight, bias, want_stats=False):
         ctx.save_for_backward(rows, weight)
         ctx.has_bias = bias is not None
         ctx.params = (weight, bias)                     # leaf tensors (ops.grad_sink)
+        y = hip_linear(rows, weight, bias, want_stats)
+        if y is not None:
+            return y
+        w = cast_cached(weight._base if weight._base is not None else weight, rows.dtype).view(weight.shape)
+        b = cast_cached(bias, rows.dtype)
         return torch.nn.functional.linear(rows, w, b)
 
     @staticmethod
@@ -73,7 +124,7 @@ class _RowLinear(torch.autograd.Function):
                                             and cin <= 256 and cout <= 256):
             gw = (gy.t() @ rows).float()                # f32 square 256-wide maps: rocBLAS is ahead there
             gb = gy.float().sum(0) if ctx.has_bias else None
-            return grows, gw.to(weight.dtype), (gb.to(weight.dtype) if gb is not None else None)
+            return grows, gw.to(weight.dtype), (gb.to(weight.dtype) if gb is not None else None), None
         L = _hip.lib()
         wparam, bparam = ctx.params
         # weight may be a [cout,cin,1,1] Conv2d parameter viewed as [cout,cin]: its .grad lives on the base
@@ -88,7 +139,7 @@ class _RowLinear(torch.autograd.Function):
                                        _hip._ptr(gw), _hip._ptr(gb), _hip._ptr(ws), ws.numel() * 4,
                                        _hip.stream_ptr()))
         return (grows, None if gw_sink is not None else gw.to(weight.dtype),
-                None if (gb is None or gb_sink is not None) else gb.to(weight.dtype))
+                None if (gb is None or gb_sink is not None) else gb.to(weight.dtype), None)
 
 
 class PointwiseConv2d(torch.nn.Conv2d):
@@ -96,7 +147,9 @@ class PointwiseConv2d(torch.nn.Conv2d):
         assert kernel_size in (1, (1, 1)), 'PointwiseConv2d is a 1x1 map'
         super().__init__(in_channels, out_channels, 1, bias=bias)
 
-    def forward(self, x):
+    def forward(self, x, want_stats=False):
+        """``want_stats``: the caller promises to hand the result straight to a training-mode BatchNormAct2d,
+        which then takes its batch statistics from this map's epilogue instead of re-reading the tensor."""
         B, C, H, W = x.shape
         rows = x.permute(0, 2, 3, 1)                    # [B,H,W,C] view; free when channels-last
         if not rows.is_contiguous():
@@ -107,11 +160,13 @@ class PointwiseConv2d(torch.nn.Conv2d):
         weight = self.weight.view(self.out_channels, C)
         if rows.is_cuda and rows.dtype in (torch.float32, torch.bfloat16) and torch.is_grad_enabled() and (
                 weight.requires_grad or rows.requires_grad):
-            y = _RowLinear.apply(rows, weight, self.bias)
+            y = _RowLinear.apply(rows, weight, self.bias, want_stats)
         else:
-            w = cast_cached(self.weight, rows.dtype).view(self.out_channels, C)
-            b = cast_cached(self.bias, rows.dtype)
-            y = torch.nn.functional.linear(rows, w, b)
+            y = hip_linear(rows, weight, self.bias) if rows.is_cuda else None
+            if y is None:
+                w = cast_cached(self.weight, rows.dtype).view(self.out_channels, C)
+                b = cast_cached(self.bias, rows.dtype)
+                y = torch.nn.functional.linear(rows, w, b)
         return y.view(B, H, W, self.out_channels).permute(0, 3, 1, 2)
 
 
@@ -183,10 +238,17 @@ class _BatchNormAct(torch.autograd.Function):
         stats = torch.empty((4, C), device=dev, dtype=torch.float32)      # mean, invstd, scale, shift
         ws = ops._workspace(dev, int(L.fgnn_bn_workspace_bytes(R, C)))
         dt = _hip.dtype_code(rows)
-        _hip.check(L.fgnn_bn_stats(_hip._ptr(rows), R, C, dt, _hip._ptr(weight), _hip._ptr(bias),
-                                   _hip._ptr(running_mean), _hip._ptr(running_var), momentum, eps,
-                                   _hip._ptr(stats[0]), _hip._ptr(stats[1]), _hip._ptr(stats[2]),
-                                   _hip._ptr(stats[3]), _hip._ptr(ws), ws.numel() * 4, _hip.stream_ptr()))
+        npart = take_pending_stats(rows)
+        if npart:       # the producing map's epilogue already left (sum, sum of squares) partials in the workspace
+            _hip.check(L.fgnn_bn_finalize(_hip._ptr(ws), npart, R, C, _hip._ptr(weight), _hip._ptr(bias),
+                                          _hip._ptr(running_mean), _hip._ptr(running_var), momentum, eps,
+                                          _hip._ptr(stats[0]), _hip._ptr(stats[1]), _hip._ptr(stats[2]),
+                                          _hip._ptr(stats[3]), _hip.stream_ptr()))
+        else:
+            _hip.check(L.fgnn_bn_stats(_hip._ptr(rows), R, C, dt, _hip._ptr(weight), _hip._ptr(bias),
+                                       _hip._ptr(running_mean), _hip._ptr(running_var), momentum, eps,
+                                       _hip._ptr(stats[0]), _hip._ptr(stats[1]), _hip._ptr(stats[2]),
+                                       _hip._ptr(stats[3]), _hip._ptr(ws), ws.numel() * 4, _hip.stream_ptr()))
         y = torch.empty_like(rows)
         _hip.check(L.fgnn_bn_apply(_hip._ptr(rows), _hip._ptr(y), R, C, dt, _hip._ptr(stats[2]),
                                    _hip._ptr(stats[3]), slope, _hip._ptr(addend), _hip.stream_ptr()))

@@ -96,6 +96,17 @@ int64_t fgnn_mpconv_forward_lds_bytes(const fgnn_mpconv_desc* d);
 int64_t fgnn_mpconv_algorithmic_bytes(const fgnn_mpconv_desc* d);
 
 /*
+ * Forward of the node-wise (1x1) maps, `Conv2d(cin, cout, 1)` of mp_conv_residual / iid_mapping*
+ * (reference mp_nn_residual.py:25-35, base_model.py:43-90), as a streaming bf16 GEMM: y[R][Cout] = x[R][Cin] W^T + b
+ * with bf16 x / y, f32 W [Cout][Cin] / b, Cin and Cout multiples of 64 up to 256 (FGNN_EUNSUPPORTED otherwise).
+ * stats_partials: NULL, or fgnn_linear_forward_partials(R, Cin, Cout) * 2 * Cout floats of device scratch that
+ * receive per-workgroup (sum y, sum y^2) for fgnn_bn_finalize.
+ */
+int fgnn_linear_forward(const void* x, const float* W, const float* bias, void* y, int64_t R, int32_t Cin,
+                        int32_t Cout, float* stats_partials, fgnn_stream_t stream);
+int fgnn_linear_forward_partials(int64_t R, int32_t Cin, int32_t Cout);
+
+/*
  * Weight / bias gradient of a node-wise linear map y[r,:] = W x[r,:] + b over R = B*N rows
  * (the 1x1 convolutions around the operator: mp_nn_residual.py:25-35, base_model.py:43-90):
  *   gW[o][c] += sum_r gy[r][o] x[r][c],  gb[o] += sum_r gy[r][o]      (f32, ACCUMULATED into)
@@ -128,6 +139,11 @@ int fgnn_bn_stats(const void* x, int64_t R, int32_t C, int32_t dtype, const floa
                   float* running_mean, float* running_var, float momentum, float eps, float* mean,
                   float* invstd, float* scale, float* shift, void* workspace, int64_t workspace_bytes,
                   fgnn_stream_t stream);
+/* Same outputs as fgnn_bn_stats from per-workgroup (sum, sum of squares) partials [npartials][2][C] written by
+ * fgnn_linear_forward's epilogue: the BatchNorm behind a node-wise map needs no statistics pass of its own. */
+int fgnn_bn_finalize(const float* partials, int32_t npartials, int64_t R, int32_t C, const float* gamma,
+                     const float* beta, float* running_mean, float* running_var, float momentum, float eps,
+                     float* mean, float* invstd, float* scale, float* shift, fgnn_stream_t stream);
 int fgnn_bn_apply(const void* x, void* y, int64_t R, int32_t C, int32_t dtype, const float* scale,
                   const float* shift, float slope, const void* addend, fgnn_stream_t stream);
 int fgnn_bn_backward(const void* x, const void* gy, void* gx, int64_t R, int32_t C, int32_t dtype,

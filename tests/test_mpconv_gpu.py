@@ -318,6 +318,46 @@ def test_pointwise_conv_gradients_vs_torch(cin, cout, dtype, dev):
     assert H.rel_err(xm.grad.float(), xr.grad) <= tol
 
 
+@pytest.mark.parametrize('cin,cout', [(64, 64), (64, 128), (128, 64), (64, 256), (256, 64), (256, 256), (192, 128)])
+@pytest.mark.parametrize('rows', [(3, 37), (64, 96)], ids=['r111', 'r6144'])
+def test_linear_forward_with_fused_batch_statistics(cin, cout, rows, dev):
+    """bf16 node-wise map through csrc/linear_fwd_b16.hip, alone and with the BatchNorm statistics taken from
+    its epilogue: (a) the GEMM against torch in f32 on the same bf16 inputs (only the output rounding differs),
+    (b) conv -> BatchNorm+LeakyReLU with the fused statistics against the same modules with the statistics pass
+    (identical up to computing mean / variance from the unrounded f32 accumulators)."""
+    from fgnn_amd.mpnn import PointwiseConv2d
+    from fgnn_amd.mpnn.pointwise import BatchNormAct2d
+    B, N = rows
+    g = torch.Generator().manual_seed(cin + 7 * cout + N)
+    x = torch.randn(B, cin, N, 1, generator=g).bfloat16().to(dev).contiguous(memory_format=torch.channels_last)
+    conv = PointwiseConv2d(cin, cout, 1).to(dev)
+    with torch.no_grad():
+        y = conv(x)
+    assert y.dtype == torch.bfloat16
+    ref = torch.nn.functional.conv2d(x.float(), conv.weight, conv.bias)
+    assert H.rel_err(y.float(), ref) <= 2.0 ** -7
+    bn_a, bn_b = BatchNormAct2d(cout, slope=0.01).to(dev).train(), BatchNormAct2d(cout, slope=0.01).to(dev).train()
+    with torch.no_grad():
+        bn_a.weight.uniform_(0.5, 1.5); bn_a.bias.uniform_(-0.5, 0.5)
+    bn_b.load_state_dict(bn_a.state_dict())
+    xa = x.detach().clone().requires_grad_(True)
+    xb = x.detach().clone().requires_grad_(True)
+    ya = bn_a(conv(xa, want_stats=True))                 # statistics from the GEMM epilogue
+    yb = bn_b(conv(xb))                                  # statistics pass over the bf16 output
+    assert H.rel_err(ya.float(), yb.float()) <= 2.0 ** -6
+    assert H.rel_err(bn_a.running_mean, bn_b.running_mean) <= 1e-3
+    assert H.rel_err(bn_a.running_var, bn_b.running_var) <= 1e-3
+    gy = torch.randn_like(ya)
+    conv.zero_grad()
+    ya.backward(gy)
+    ga = xa.grad.float().clone()
+    yb.backward(gy)
+    # elements whose pre-activation sits within rounding of the LeakyReLU kink take the other slope in one of
+    # the two runs (their gradient then differs by O(1)): compare in the mean, not the max
+    gb = xb.grad.float()
+    assert float((ga - gb).abs().mean()) <= 1e-2 * float(gb.abs().mean())
+
+
 @pytest.mark.parametrize('C,N', [(64, 96), (256, 48), (128, 96), (10, 7), (64, 2)])
 @pytest.mark.parametrize('relu', [False, True])
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
