@@ -30,6 +30,7 @@ struct LfParams {
     float* part;         // [grid][2][Cout] per-workgroup (sum, sum of squares) of y, or NULL
     int R, Cin, Cout;
     int CG;              // output-channel groups per workgroup (waves = CG x 8/CG row groups)
+    int wt;              // W is stored transposed, [Cin][Cout] (the grad-input product gy W of a [Cout'][Cin'] weight)
 };
 
 extern __shared__ __attribute__((aligned(16))) unsigned char lf_lds[];
@@ -52,10 +53,18 @@ __global__ __launch_bounds__(LF_THREADS) void linear_fwd_b16_kernel(const LfPara
     uint16_t* Wl = reinterpret_cast<uint16_t*>(lf_lds);                    // [Cout][WS] bf16
     float* bl = reinterpret_cast<float*>(lf_lds + (size_t)Cout * WS * 2);    // [Cout] bias
     float* red = bl + Cout;                                                // [nrg][2][Cout] statistics fold
-    for (int f = tid; f < Cout * (CIN / 2); f += LF_THREADS) {
-        const int o = f / (CIN / 2), c2 = f - o * (CIN / 2);
-        const float2 w = *reinterpret_cast<const float2*>(p.W + (int64_t)o * CIN + 2 * c2);
-        *reinterpret_cast<unsigned*>(Wl + o * WS + 2 * c2) = lf_pack2(w.x, w.y);
+    if (!p.wt) {
+        for (int f = tid; f < Cout * (CIN / 2); f += LF_THREADS) {
+            const int o = f / (CIN / 2), c2 = f - o * (CIN / 2);
+            const float2 w = *reinterpret_cast<const float2*>(p.W + (int64_t)o * CIN + 2 * c2);
+            *reinterpret_cast<unsigned*>(Wl + o * WS + 2 * c2) = lf_pack2(w.x, w.y);
+        }
+    } else {                                              // memory is [c][o]: coalesced reads, 2-byte LDS writes
+        for (int f = tid; f < Cout * CIN; f += LF_THREADS) {
+            const int c = f / Cout, o = f - c * Cout;
+            const __bf16 h = (__bf16)p.W[f];
+            Wl[o * WS + c] = __builtin_bit_cast(uint16_t, h);
+        }
     }
     for (int f = tid; f < Cout; f += LF_THREADS) bl[f] = p.bias ? p.bias[f] : 0.f;
     __syncthreads();
@@ -150,16 +159,17 @@ extern "C" int fgnn_linear_forward_partials(int64_t R, int Cin, int Cout) {
 
 // y = x W^T + b for bf16 x / y, f32 W / b.  stats_partials: NULL, or device scratch of
 // fgnn_linear_forward_partials(..) * 2 * Cout floats receiving per-workgroup (sum y, sum y^2) per channel —
-// feed it to fgnn_bn_finalize.  Returns FGNN_EUNSUPPORTED for other shapes (callers fall back to a library GEMM).
+// feed it to fgnn_bn_finalize.  w_transposed: W is [Cin][Cout] in memory (y = x W; the grad-input product of a
+// map whose weight is [Cin][Cout] = [cout'][cin']).  Returns FGNN_EUNSUPPORTED for other shapes (callers fall back to a library GEMM).
 extern "C" int fgnn_linear_forward(const void* x, const float* W, const float* bias, void* y, int64_t R, int Cin,
-                                   int Cout, float* stats_partials, fgnn_stream_t stream) {
+                                   int Cout, float* stats_partials, int w_transposed, fgnn_stream_t stream) {
     if (!x || !W || !y) FGNN_FAIL(FGNN_EINVAL, "linear_forward: null pointer");
     int CG, grid;
     if (lf_plan(R, Cin, Cout, &CG, &grid) || ((uintptr_t)x & 15) || ((uintptr_t)y & 7) || ((uintptr_t)W & 7))
         FGNN_FAIL(FGNN_EUNSUPPORTED, "linear_forward: Cin=%d Cout=%d outside the bf16 streaming kernel's family", Cin, Cout);
     LfParams p;
     p.x = (const uint16_t*)x; p.W = W; p.bias = bias; p.y = (uint16_t*)y; p.part = stats_partials;
-    p.R = (int)R; p.Cin = Cin; p.Cout = Cout; p.CG = CG;
+    p.R = (int)R; p.Cin = Cin; p.Cout = Cout; p.CG = CG; p.wt = w_transposed;
     const int KS = Cin / 32;
     void* fn;
     switch (KS) {       // OTW == 4 always (64 output channels per wave); fragments stay in registers up to Cin 128

@@ -83,7 +83,7 @@ def lib():
     L.fgnn_bn_finalize.restype = ctypes.c_int
     L.fgnn_bn_finalize.argtypes = [vp, i32, i64, i32, vp, vp, vp, vp, f32, f32, vp, vp, vp, vp, vp]
     L.fgnn_linear_forward.restype = ctypes.c_int
-    L.fgnn_linear_forward.argtypes = [vp, vp, vp, vp, i64, i32, i32, vp, vp]
+    L.fgnn_linear_forward.argtypes = [vp, vp, vp, vp, i64, i32, i32, vp, i32, vp]
     L.fgnn_linear_forward_partials.restype = ctypes.c_int
     L.fgnn_linear_forward_partials.argtypes = [i64, i32, i32]
     L.fgnn_bn_apply.restype = ctypes.c_int

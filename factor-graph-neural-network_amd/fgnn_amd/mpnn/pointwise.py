@@ -44,7 +44,7 @@ def cast_cached(t, dtype):
 _PENDING_STATS = None     # (rows tensor, number of partials) of the last hip_linear(..., want_stats=True)
 
 
-def hip_linear(rows, weight, bias, want_stats=False):
+def hip_linear(rows, weight, bias, want_stats=False, transposed=False):
     """``rows @ weight.T + bias`` through csrc/linear_fwd_b16.hip (bf16 rows, f32 parameters, channel counts in
     multiples of 64): one pass over rows and the output at HBM rate, no cast of the weights.  With
     ``want_stats`` the kernel's epilogue also leaves the per-channel batch statistics of the output in the
@@ -54,7 +54,7 @@ def hip_linear(rows, weight, bias, want_stats=False):
     if not (rows.is_cuda and rows.dtype == torch.bfloat16 and weight.dtype == torch.float32 and rows.is_contiguous()):
         return None
     R, cin = rows.shape
-    cout = weight.shape[0]
+    cout = weight.shape[1] if transposed else weight.shape[0]      # transposed: weight is [cin, cout] (y = rows @ weight)
     # measured on MI355X (scratch lbench, R = 393 k rows): the streaming kernel beats rocBLAS up to 64x128 maps
     # (21 vs 32 us at 64x64); with the statistics epilogue it also wins at 64x256 / 256x64 because it saves the
     # BatchNorm's own pass over the output; wider maps stay with rocBLAS (4 TB/s there)
@@ -74,7 +74,7 @@ def hip_linear(rows, weight, bias, want_stats=False):
     if want_stats:
         ws = ops._workspace(rows.device, int(L.fgnn_bn_workspace_bytes(R, cout)))
     _hip.check(L.fgnn_linear_forward(_hip._ptr(rows), _hip._ptr(w), _hip._ptr(b), _hip._ptr(y), R, cin, cout,
-                                     _hip._ptr(ws), _hip.stream_ptr()))
+                                     _hip._ptr(ws), int(transposed), _hip.stream_ptr()))
     if want_stats:
         _PENDING_STATS = (y, npart)
     return y
@@ -117,7 +117,9 @@ class _RowLinear(torch.autograd.Function):
             gy = gy.to(rows.dtype)
         grows = None
         if ctx.needs_input_grad[0]:
-            grows = gy @ cast_cached(weight._base if weight._base is not None else weight, gy.dtype).view(weight.shape)
+            grows = hip_linear(gy, weight, None, transposed=True)      # gy [R,cout] @ weight [cout,cin]
+            if grows is None:
+                grows = gy @ cast_cached(weight._base if weight._base is not None else weight, gy.dtype).view(weight.shape)
         R, cin = rows.shape
         cout = weight.shape[0]
         if cin * cout >= 256 * 256 and not (rows.dtype == torch.bfloat16 and cin % 64 == 0 and cout % 64 == 0

@@ -100,10 +100,11 @@ int64_t fgnn_mpconv_algorithmic_bytes(const fgnn_mpconv_desc* d);
  * (reference mp_nn_residual.py:25-35, base_model.py:43-90), as a streaming bf16 GEMM: y[R][Cout] = x[R][Cin] W^T + b
  * with bf16 x / y, f32 W [Cout][Cin] / b, Cin and Cout multiples of 64 up to 256 (FGNN_EUNSUPPORTED otherwise).
  * stats_partials: NULL, or fgnn_linear_forward_partials(R, Cin, Cout) * 2 * Cout floats of device scratch that
- * receive per-workgroup (sum y, sum y^2) for fgnn_bn_finalize.
+ * receive per-workgroup (sum y, sum y^2) for fgnn_bn_finalize.  w_transposed != 0: W is [Cin][Cout] in memory
+ * (y = x W) — the grad-input product gy W of a map whose own weight is stored [cout'][cin'].
  */
 int fgnn_linear_forward(const void* x, const float* W, const float* bias, void* y, int64_t R, int32_t Cin,
-                        int32_t Cout, float* stats_partials, fgnn_stream_t stream);
+                        int32_t Cout, float* stats_partials, int32_t w_transposed, fgnn_stream_t stream);
 int fgnn_linear_forward_partials(int64_t R, int32_t Cin, int32_t Cout);
 
 /*
