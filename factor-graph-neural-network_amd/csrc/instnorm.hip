@@ -100,6 +100,158 @@ __global__ __launch_bounds__(IN_THREADS) void instnorm_bwd_kernel(const InParams
         }
 }
 
+// ----------------------------------------------------------------------------------------
+// Vectorised variants for C % 64 == 0 and N <= 128 (every InstanceNorm of the LDPC model): one workgroup owns
+// (sample, 64-channel block); a thread owns one 16-byte channel chunk of up to MAXR rows and keeps it in
+// registers, so x (and gy) are read from memory exactly once — the kernels above re-read the tile 3-4 times
+// with 2-byte loads and ran at ~1.8 TB/s.  Per-channel sums fold over the row groups of a wave with xor-shuffles
+// and over the 4 waves through LDS.
+// ----------------------------------------------------------------------------------------
+template <typename T> struct InChunk;
+template <> struct InChunk<float> {
+    static constexpr int EPC = 4;
+    __device__ static void load(const float* p, float (&v)[4]) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(p);
+        v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
+    }
+    __device__ static void store(float* p, const float (&v)[4]) { *reinterpret_cast<f32x4*>(p) = (f32x4){v[0], v[1], v[2], v[3]}; }
+};
+template <> struct InChunk<bf16_t> {
+    static constexpr int EPC = 8;
+    __device__ static void load(const bf16_t* p, float (&v)[8]) {
+        const uint4 t = *reinterpret_cast<const uint4*>(p);
+        v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u);
+        v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
+        v[4] = __uint_as_float(t.z << 16); v[5] = __uint_as_float(t.z & 0xffff0000u);
+        v[6] = __uint_as_float(t.w << 16); v[7] = __uint_as_float(t.w & 0xffff0000u);
+    }
+    __device__ static void store(bf16_t* p, const float (&v)[8]) {
+        typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+        uint4 t;
+        b2 q;
+        q[0] = (__bf16)v[0]; q[1] = (__bf16)v[1]; t.x = __builtin_bit_cast(unsigned, q);
+        q[0] = (__bf16)v[2]; q[1] = (__bf16)v[3]; t.y = __builtin_bit_cast(unsigned, q);
+        q[0] = (__bf16)v[4]; q[1] = (__bf16)v[5]; t.z = __builtin_bit_cast(unsigned, q);
+        q[0] = (__bf16)v[6]; q[1] = (__bf16)v[7]; t.w = __builtin_bit_cast(unsigned, q);
+        *reinterpret_cast<uint4*>(p) = t;
+    }
+};
+
+// Sum of v[e] over all row groups of the workgroup, per channel chunk; every thread gets the totals of its chunk.
+template <int EPC, int CPR>
+__device__ __forceinline__ void in_fold(float (&v)[EPC], float* red, int cg, int wave) {
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+#pragma unroll
+        for (int m = CPR; m < 64; m <<= 1) v[e] += __shfl_xor(v[e], m);       // row groups inside the wave
+    }
+    if ((threadIdx.x & 63) < CPR) {
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) red[wave * IN_CH + cg * EPC + e] = v[e];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+        const int c = cg * EPC + e;
+        v[e] = (red[c] + red[IN_CH + c]) + (red[2 * IN_CH + c] + red[3 * IN_CH + c]);
+    }
+    __syncthreads();
+}
+
+template <typename T, bool BWD>
+__global__ __launch_bounds__(IN_THREADS) void instnorm_vec_kernel(const InParams p) {
+    constexpr int EPC = InChunk<T>::EPC, CPR = IN_CH / EPC, RG = IN_THREADS / CPR, MAXR = 128 / RG;
+    __shared__ float red[4 * IN_CH];
+    const int tid = threadIdx.x, wave = tid >> 6;
+    const int cg = tid & (CPR - 1), rg = tid / CPR;
+    const int nblk = p.C / IN_CH;
+    const int b = blockIdx.x / nblk, c0 = (blockIdx.x - b * nblk) * IN_CH + cg * EPC;
+    const int64_t base = (int64_t)b * p.N * p.C + c0;
+    const T* xb = static_cast<const T*>(p.x) + base;
+    const T* gb = static_cast<const T*>(p.gy) + base;
+    T* ob = static_cast<T*>(p.out) + base;
+    const int N = p.N;
+    float x[MAXR][EPC], g[BWD ? MAXR : 1][EPC];
+#pragma unroll
+    for (int i = 0; i < MAXR; ++i) {
+        const int n = rg + i * RG;
+        if (n < N) {
+            InChunk<T>::load(xb + (int64_t)n * p.C, x[i]);
+            if constexpr (BWD) InChunk<T>::load(gb + (int64_t)n * p.C, g[i]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) { x[i][e] = 0.f; if constexpr (BWD) g[i][e] = 0.f; }
+        }
+    }
+    const float invn = 1.0f / (float)N;
+    float mean[EPC], rstd[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+        mean[e] = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXR; ++i) mean[e] += x[i][e];
+    }
+    in_fold<EPC, CPR>(mean, red, cg, wave);
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) mean[e] *= invn;
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+        float ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXR; ++i) {
+            const float dv = (rg + i * RG < N) ? x[i][e] - mean[e] : 0.f;
+            x[i][e] = dv;                                  // centred from here on
+            ss = fmaf(dv, dv, ss);
+        }
+        rstd[e] = ss;
+    }
+    in_fold<EPC, CPR>(rstd, red, cg, wave);
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) rstd[e] = rsqrtf(rstd[e] * invn + IN_EPS);
+    if constexpr (!BWD) {
+#pragma unroll
+        for (int i = 0; i < MAXR; ++i) {
+            const int n = rg + i * RG;
+            if (n < N) {
+                float o[EPC];
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) { const float v = x[i][e] * rstd[e]; o[e] = p.relu ? fmaxf(v, 0.f) : v; }
+                InChunk<T>::store(ob + (int64_t)n * p.C, o);
+            }
+        }
+    } else {
+        float sg[EPC], sgx[EPC];
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            sg[e] = 0.f; sgx[e] = 0.f;
+#pragma unroll
+            for (int i = 0; i < MAXR; ++i) {
+                const float xh = x[i][e] * rstd[e];
+                x[i][e] = xh;                              // xhat from here on
+                if (p.relu && xh <= 0.f) g[i][e] = 0.f;    // y = relu(xhat): y > 0  <=>  xhat > 0
+                sg[e] += g[i][e];
+                sgx[e] = fmaf(g[i][e], xh, sgx[e]);
+            }
+        }
+        in_fold<EPC, CPR>(sg, red, cg, wave);
+        in_fold<EPC, CPR>(sgx, red, cg, wave);
+#pragma unroll
+        for (int i = 0; i < MAXR; ++i) {
+            const int n = rg + i * RG;
+            if (n < N) {
+                float o[EPC];
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) o[e] = rstd[e] * (g[i][e] - sg[e] * invn - x[i][e] * sgx[e] * invn);
+                InChunk<T>::store(ob + (int64_t)n * p.C, o);
+            }
+        }
+    }
+}
+
+static bool in_vec_ok(const void* a, const void* b, const void* c, int N, int C) {
+    return C % IN_CH == 0 && N <= 128 && !(((uintptr_t)a | (uintptr_t)b | (uintptr_t)c) & 15);
+}
+
 static int in_check(const void* a, const void* b, int B, int N, int C, int dtype) {
     if (!a || !b) FGNN_FAIL(FGNN_EINVAL, "instnorm: null pointer");
     if (B < 0 || N < 1 || C < 1) FGNN_FAIL(FGNN_EINVAL, "instnorm: bad sizes B=%d N=%d C=%d", B, N, C);
@@ -114,7 +266,10 @@ extern "C" int fgnn_instnorm_forward(const void* x, void* y, int B, int N, int C
     if (B == 0) return FGNN_OK;
     InParams p = {x, nullptr, nullptr, y, B, N, C, relu};
     const int grid = B * ((C + IN_CH - 1) / IN_CH);
-    if (dtype == FGNN_F32) hipLaunchKernelGGL(instnorm_fwd_kernel<float>, dim3(grid), dim3(IN_THREADS), 0, (hipStream_t)stream, p);
+    if (in_vec_ok(x, y, nullptr, N, C)) {
+        if (dtype == FGNN_F32) hipLaunchKernelGGL((instnorm_vec_kernel<float, false>), dim3(grid), dim3(IN_THREADS), 0, (hipStream_t)stream, p);
+        else hipLaunchKernelGGL((instnorm_vec_kernel<bf16_t, false>), dim3(grid), dim3(IN_THREADS), 0, (hipStream_t)stream, p);
+    } else if (dtype == FGNN_F32) hipLaunchKernelGGL(instnorm_fwd_kernel<float>, dim3(grid), dim3(IN_THREADS), 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL(instnorm_fwd_kernel<bf16_t>, dim3(grid), dim3(IN_THREADS), 0, (hipStream_t)stream, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "instnorm forward launch: %s", hipGetErrorString(e));
@@ -129,7 +284,10 @@ extern "C" int fgnn_instnorm_backward(const void* x, const void* gy, void* gx, i
     if (B == 0) return FGNN_OK;
     InParams p = {x, nullptr, gy, gx, B, N, C, relu};
     const int grid = B * ((C + IN_CH - 1) / IN_CH);
-    if (dtype == FGNN_F32) hipLaunchKernelGGL(instnorm_bwd_kernel<float>, dim3(grid), dim3(IN_THREADS), 0, (hipStream_t)stream, p);
+    if (in_vec_ok(x, gy, gx, N, C)) {
+        if (dtype == FGNN_F32) hipLaunchKernelGGL((instnorm_vec_kernel<float, true>), dim3(grid), dim3(IN_THREADS), 0, (hipStream_t)stream, p);
+        else hipLaunchKernelGGL((instnorm_vec_kernel<bf16_t, true>), dim3(grid), dim3(IN_THREADS), 0, (hipStream_t)stream, p);
+    } else if (dtype == FGNN_F32) hipLaunchKernelGGL(instnorm_bwd_kernel<float>, dim3(grid), dim3(IN_THREADS), 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL(instnorm_bwd_kernel<bf16_t>, dim3(grid), dim3(IN_THREADS), 0, (hipStream_t)stream, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "instnorm backward launch: %s", hipGetErrorString(e));
