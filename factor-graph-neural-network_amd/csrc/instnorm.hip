@@ -137,23 +137,24 @@ template <> struct InChunk<bf16_t> {
     }
 };
 
-// Sum of v[e] over all row groups of the workgroup, per channel chunk; every thread gets the totals of its chunk.
+// Sums of a[e] and b[e] over all row groups of the workgroup, per channel; every thread gets the totals of its chunk.
 template <int EPC, int CPR>
-__device__ __forceinline__ void in_fold(float (&v)[EPC], float* red, int cg, int wave) {
+__device__ __forceinline__ void in_fold2(float (&a)[EPC], float (&b)[EPC], float* red, int cg, int wave) {
 #pragma unroll
     for (int e = 0; e < EPC; ++e) {
 #pragma unroll
-        for (int m = CPR; m < 64; m <<= 1) v[e] += __shfl_xor(v[e], m);       // row groups inside the wave
+        for (int m = CPR; m < 64; m <<= 1) { a[e] += __shfl_xor(a[e], m); b[e] += __shfl_xor(b[e], m); }   // row groups inside the wave
     }
     if ((threadIdx.x & 63) < CPR) {
 #pragma unroll
-        for (int e = 0; e < EPC; ++e) red[wave * IN_CH + cg * EPC + e] = v[e];
+        for (int e = 0; e < EPC; ++e) { red[wave * IN_CH + cg * EPC + e] = a[e]; red[(4 + wave) * IN_CH + cg * EPC + e] = b[e]; }
     }
     __syncthreads();
 #pragma unroll
     for (int e = 0; e < EPC; ++e) {
         const int c = cg * EPC + e;
-        v[e] = (red[c] + red[IN_CH + c]) + (red[2 * IN_CH + c] + red[3 * IN_CH + c]);
+        a[e] = (red[c] + red[IN_CH + c]) + (red[2 * IN_CH + c] + red[3 * IN_CH + c]);
+        b[e] = (red[4 * IN_CH + c] + red[5 * IN_CH + c]) + (red[6 * IN_CH + c] + red[7 * IN_CH + c]);
     }
     __syncthreads();
 }
@@ -161,7 +162,7 @@ __device__ __forceinline__ void in_fold(float (&v)[EPC], float* red, int cg, int
 template <typename T, bool BWD>
 __global__ __launch_bounds__(IN_THREADS) void instnorm_vec_kernel(const InParams p) {
     constexpr int EPC = InChunk<T>::EPC, CPR = IN_CH / EPC, RG = IN_THREADS / CPR, MAXR = 128 / RG;
-    __shared__ float red[4 * IN_CH];
+    __shared__ float red[8 * IN_CH];
     const int tid = threadIdx.x, wave = tid >> 6;
     const int cg = tid & (CPR - 1), rg = tid / CPR;
     const int nblk = p.C / IN_CH;
@@ -171,7 +172,8 @@ __global__ __launch_bounds__(IN_THREADS) void instnorm_vec_kernel(const InParams
     const T* gb = static_cast<const T*>(p.gy) + base;
     T* ob = static_cast<T*>(p.out) + base;
     const int N = p.N;
-    float x[MAXR][EPC], g[BWD ? MAXR : 1][EPC];
+    float x[MAXR][EPC], g[BWD ? MAXR : 1][EPC], K[EPC];
+    InChunk<T>::load(xb, K);                               // row 0 of the sample: the shift of the one-pass variance
 #pragma unroll
     for (int i = 0; i < MAXR; ++i) {
         const int n = rg + i * RG;
@@ -180,34 +182,28 @@ __global__ __launch_bounds__(IN_THREADS) void instnorm_vec_kernel(const InParams
             if constexpr (BWD) InChunk<T>::load(gb + (int64_t)n * p.C, g[i]);
         } else {
 #pragma unroll
-            for (int e = 0; e < EPC; ++e) { x[i][e] = 0.f; if constexpr (BWD) g[i][e] = 0.f; }
+            for (int e = 0; e < EPC; ++e) { x[i][e] = K[e]; if constexpr (BWD) g[i][e] = 0.f; }
         }
     }
+    // shifted one-pass statistics: sums of (x - K) and (x - K)^2 with K a member of the population, so
+    // |mean - K| ~ std and var = E[(x-K)^2] - (E[x-K])^2 loses at most a few bits (padding rows contribute 0)
     const float invn = 1.0f / (float)N;
     float mean[EPC], rstd[EPC];
 #pragma unroll
     for (int e = 0; e < EPC; ++e) {
-        mean[e] = 0.f;
+        float s = 0.f, ss = 0.f;
 #pragma unroll
-        for (int i = 0; i < MAXR; ++i) mean[e] += x[i][e];
+        for (int i = 0; i < MAXR; ++i) { const float dv = x[i][e] - K[e]; x[i][e] = dv; s += dv; ss = fmaf(dv, dv, ss); }
+        mean[e] = s; rstd[e] = ss;
     }
-    in_fold<EPC, CPR>(mean, red, cg, wave);
-#pragma unroll
-    for (int e = 0; e < EPC; ++e) mean[e] *= invn;
+    in_fold2<EPC, CPR>(mean, rstd, red, cg, wave);
 #pragma unroll
     for (int e = 0; e < EPC; ++e) {
-        float ss = 0.f;
-#pragma unroll
-        for (int i = 0; i < MAXR; ++i) {
-            const float dv = (rg + i * RG < N) ? x[i][e] - mean[e] : 0.f;
-            x[i][e] = dv;                                  // centred from here on
-            ss = fmaf(dv, dv, ss);
-        }
-        rstd[e] = ss;
+        const float m = mean[e] * invn;
+        const float var = fmaxf(rstd[e] * invn - m * m, 0.f);
+        mean[e] = m;                                       // mean of (x - K)
+        rstd[e] = rsqrtf(var + IN_EPS);
     }
-    in_fold<EPC, CPR>(rstd, red, cg, wave);
-#pragma unroll
-    for (int e = 0; e < EPC; ++e) rstd[e] = rsqrtf(rstd[e] * invn + IN_EPS);
     if constexpr (!BWD) {
 #pragma unroll
         for (int i = 0; i < MAXR; ++i) {
@@ -215,7 +211,7 @@ __global__ __launch_bounds__(IN_THREADS) void instnorm_vec_kernel(const InParams
             if (n < N) {
                 float o[EPC];
 #pragma unroll
-                for (int e = 0; e < EPC; ++e) { const float v = x[i][e] * rstd[e]; o[e] = p.relu ? fmaxf(v, 0.f) : v; }
+                for (int e = 0; e < EPC; ++e) { const float v = (x[i][e] - mean[e]) * rstd[e]; o[e] = p.relu ? fmaxf(v, 0.f) : v; }
                 InChunk<T>::store(ob + (int64_t)n * p.C, o);
             }
         }
@@ -226,15 +222,14 @@ __global__ __launch_bounds__(IN_THREADS) void instnorm_vec_kernel(const InParams
             sg[e] = 0.f; sgx[e] = 0.f;
 #pragma unroll
             for (int i = 0; i < MAXR; ++i) {
-                const float xh = x[i][e] * rstd[e];
+                const float xh = (x[i][e] - mean[e]) * rstd[e];
                 x[i][e] = xh;                              // xhat from here on
                 if (p.relu && xh <= 0.f) g[i][e] = 0.f;    // y = relu(xhat): y > 0  <=>  xhat > 0
-                sg[e] += g[i][e];
+                sg[e] += g[i][e];                          // padding rows carry g = 0
                 sgx[e] = fmaf(g[i][e], xh, sgx[e]);
             }
         }
-        in_fold<EPC, CPR>(sg, red, cg, wave);
-        in_fold<EPC, CPR>(sgx, red, cg, wave);
+        in_fold2<EPC, CPR>(sg, sgx, red, cg, wave);
 #pragma unroll
         for (int i = 0; i < MAXR; ++i) {
             const int n = rg + i * RG;
