@@ -163,7 +163,9 @@ __global__ __launch_bounds__(256) void bn_stats_final_kernel(const float* ws, in
                                                              const float* ref, const float* gamma,
                                                              const float* beta, float* rmean, float* rvar,
                                                              float momentum, float eps, float* mean,
-                                                             float* invstd, float* scale, float* shift) {
+                                                             float* invstd, float* scale, float* shift,
+                                                             long long* nbt) {
+    if (nbt && blockIdx.x == 0 && threadIdx.x == 0) *nbt += 1;      // BatchNorm2d.num_batches_tracked
     const int c = blockIdx.x * BN_FC + (threadIdx.x & (BN_FC - 1)), pg = threadIdx.x / BN_FC;
     double s0, s1;
     bn_fold(ws, nwg, C, c, pg, c < C, s0, s1);
@@ -285,8 +287,8 @@ extern "C" int64_t fgnn_bn_workspace_bytes(int64_t R, int C) { return (int64_t)B
 // Forward statistics: fills mean, invstd, scale, shift [C]; updates running_mean / running_var when given.
 extern "C" int fgnn_bn_stats(const void* x, int64_t R, int C, int dtype, const float* gamma, const float* beta,
                              float* running_mean, float* running_var, float momentum, float eps, float* mean,
-                             float* invstd, float* scale, float* shift, void* workspace,
-                             int64_t workspace_bytes, fgnn_stream_t stream) {
+                             float* invstd, float* scale, float* shift, int64_t* num_batches_tracked,
+                             void* workspace, int64_t workspace_bytes, fgnn_stream_t stream) {
     BnParams p = {};
     int grid;
     if (!x || !mean || !invstd || !scale || !shift || !workspace) FGNN_FAIL(FGNN_EINVAL, "bn_stats: null pointer");
@@ -302,7 +304,8 @@ extern "C" int fgnn_bn_stats(const void* x, int64_t R, int C, int dtype, const f
     if (dtype == FGNN_F32) hipLaunchKernelGGL((bn_reduce_kernel<float, 0>), dim3(grid), dim3(BN_THREADS), 0, st, p);
     else hipLaunchKernelGGL((bn_reduce_kernel<bf16_t, 0>), dim3(grid), dim3(BN_THREADS), 0, st, p);
     hipLaunchKernelGGL(bn_stats_final_kernel, dim3((C + BN_FC - 1) / BN_FC), dim3(256), 0, st, ws, grid, C, R, ref, gamma,
-                       beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift);
+                       beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift,
+                       (long long*)num_batches_tracked);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "bn_stats launch: %s", hipGetErrorString(e));
     return FGNN_OK;
@@ -313,12 +316,12 @@ extern "C" int fgnn_bn_stats(const void* x, int64_t R, int C, int dtype, const f
 extern "C" int fgnn_bn_finalize(const float* partials, int npartials, int64_t R, int C, const float* gamma,
                                 const float* beta, float* running_mean, float* running_var, float momentum,
                                 float eps, float* mean, float* invstd, float* scale, float* shift,
-                                fgnn_stream_t stream) {
+                                int64_t* num_batches_tracked, fgnn_stream_t stream) {
     if (!partials || !mean || !invstd || !scale || !shift) FGNN_FAIL(FGNN_EINVAL, "bn_finalize: null pointer");
     if (npartials < 1 || npartials > BN_GRID || R < 1 || C < 1) FGNN_FAIL(FGNN_EINVAL, "bn_finalize: bad sizes");
     hipLaunchKernelGGL(bn_stats_final_kernel, dim3((C + BN_FC - 1) / BN_FC), dim3(256), 0, (hipStream_t)stream, partials,
                        npartials, C, R, (const float*)nullptr, gamma, beta, running_mean, running_var, momentum, eps,
-                       mean, invstd, scale, shift);
+                       mean, invstd, scale, shift, (long long*)num_batches_tracked);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "bn_finalize launch: %s", hipGetErrorString(e));
     return FGNN_OK;

@@ -79,9 +79,9 @@ def lib():
     L.fgnn_bn_workspace_bytes.restype = i64
     L.fgnn_bn_workspace_bytes.argtypes = [i64, i32]
     L.fgnn_bn_stats.restype = ctypes.c_int
-    L.fgnn_bn_stats.argtypes = [vp, i64, i32, i32, vp, vp, vp, vp, f32, f32, vp, vp, vp, vp, vp, i64, vp]
+    L.fgnn_bn_stats.argtypes = [vp, i64, i32, i32, vp, vp, vp, vp, f32, f32, vp, vp, vp, vp, vp, vp, i64, vp]
     L.fgnn_bn_finalize.restype = ctypes.c_int
-    L.fgnn_bn_finalize.argtypes = [vp, i32, i64, i32, vp, vp, vp, vp, f32, f32, vp, vp, vp, vp, vp]
+    L.fgnn_bn_finalize.argtypes = [vp, i32, i64, i32, vp, vp, vp, vp, f32, f32, vp, vp, vp, vp, vp, vp]
     L.fgnn_linear_forward.restype = ctypes.c_int
     L.fgnn_linear_forward.argtypes = [vp, vp, vp, vp, i64, i32, i32, vp, i32, vp]
     L.fgnn_linear_forward_partials.restype = ctypes.c_int

@@ -232,7 +232,7 @@ class _BatchNormAct(torch.autograd.Function):
     """Train-mode BatchNorm + LeakyReLU(slope) on channel-fastest rows [R, C] (csrc/bnact.hip)."""
 
     @staticmethod
-    def forward(ctx, rows, weight, bias, running_mean, running_var, momentum, eps, slope, addend=None):
+    def forward(ctx, rows, weight, bias, running_mean, running_var, momentum, eps, slope, addend=None, nbt=None):
         from .. import ops
         L = _hip.lib()
         R, C = rows.shape
@@ -245,12 +245,13 @@ class _BatchNormAct(torch.autograd.Function):
             _hip.check(L.fgnn_bn_finalize(_hip._ptr(ws), npart, R, C, _hip._ptr(weight), _hip._ptr(bias),
                                           _hip._ptr(running_mean), _hip._ptr(running_var), momentum, eps,
                                           _hip._ptr(stats[0]), _hip._ptr(stats[1]), _hip._ptr(stats[2]),
-                                          _hip._ptr(stats[3]), _hip.stream_ptr()))
+                                          _hip._ptr(stats[3]), _hip._ptr(nbt), _hip.stream_ptr()))
         else:
             _hip.check(L.fgnn_bn_stats(_hip._ptr(rows), R, C, dt, _hip._ptr(weight), _hip._ptr(bias),
                                        _hip._ptr(running_mean), _hip._ptr(running_var), momentum, eps,
                                        _hip._ptr(stats[0]), _hip._ptr(stats[1]), _hip._ptr(stats[2]),
-                                       _hip._ptr(stats[3]), _hip._ptr(ws), ws.numel() * 4, _hip.stream_ptr()))
+                                       _hip._ptr(stats[3]), _hip._ptr(nbt), _hip._ptr(ws), ws.numel() * 4,
+                                       _hip.stream_ptr()))
         y = torch.empty_like(rows)
         _hip.check(L.fgnn_bn_apply(_hip._ptr(rows), _hip._ptr(y), R, C, dt, _hip._ptr(stats[2]),
                                    _hip._ptr(stats[3]), slope, _hip._ptr(addend), _hip.stream_ptr()))
@@ -279,7 +280,7 @@ class _BatchNormAct(torch.autograd.Function):
                                       _hip._ptr(bias), ctx.slope, _hip._ptr(gw), _hip._ptr(gb), _hip._ptr(ws),
                                       ws.numel() * 4, _hip.stream_ptr()))
         return (gx, None if gw_sink is not None else gw, None if gb_sink is not None else gb,
-                None, None, None, None, None, gy if ctx.has_addend else None)
+                None, None, None, None, None, gy if ctx.has_addend else None, None)
 
 
 class BatchNormAct2d(torch.nn.BatchNorm2d):
@@ -320,11 +321,9 @@ class BatchNormAct2d(torch.nn.BatchNorm2d):
             if arows.dtype != rows.dtype or not arows.is_contiguous():
                 arows = arows.to(rows.dtype).contiguous()
             arows = arows.view(B * H * W, C)
-        if self.training:
-            with torch.no_grad():
-                self.num_batches_tracked += 1
+        if self.training:                               # num_batches_tracked += 1 rides in the statistics finaliser
             y = _BatchNormAct.apply(rows, self.weight, self.bias, self.running_mean, self.running_var,
-                                    self.momentum, self.eps, self.slope, arows)
+                                    self.momentum, self.eps, self.slope, arows, self.num_batches_tracked)
         else:                                           # eval: folded affine + activation in one pass
             scale, shift = self._folded()
             y = torch.empty_like(rows)

@@ -138,13 +138,14 @@ int fgnn_bn_supported(int64_t R, int32_t C, int32_t dtype);
 int64_t fgnn_bn_workspace_bytes(int64_t R, int32_t C);
 int fgnn_bn_stats(const void* x, int64_t R, int32_t C, int32_t dtype, const float* gamma, const float* beta,
                   float* running_mean, float* running_var, float momentum, float eps, float* mean,
-                  float* invstd, float* scale, float* shift, void* workspace, int64_t workspace_bytes,
-                  fgnn_stream_t stream);
+                  float* invstd, float* scale, float* shift, int64_t* num_batches_tracked, void* workspace,
+                  int64_t workspace_bytes, fgnn_stream_t stream);
 /* Same outputs as fgnn_bn_stats from per-workgroup (sum, sum of squares) partials [npartials][2][C] written by
  * fgnn_linear_forward's epilogue: the BatchNorm behind a node-wise map needs no statistics pass of its own. */
 int fgnn_bn_finalize(const float* partials, int32_t npartials, int64_t R, int32_t C, const float* gamma,
                      const float* beta, float* running_mean, float* running_var, float momentum, float eps,
-                     float* mean, float* invstd, float* scale, float* shift, fgnn_stream_t stream);
+                     float* mean, float* invstd, float* scale, float* shift, int64_t* num_batches_tracked,
+                     fgnn_stream_t stream);
 int fgnn_bn_apply(const void* x, void* y, int64_t R, int32_t C, int32_t dtype, const float* scale,
                   const float* shift, float slope, const void* addend, fgnn_stream_t stream);
 int fgnn_bn_backward(const void* x, const void* gy, void* gx, int64_t R, int32_t C, int32_t dtype,
