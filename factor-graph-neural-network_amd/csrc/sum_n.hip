@@ -1,0 +1,74 @@
+// sum_n.hip — out = a_0 + a_1 + ... + a_{n-1} over dense same-layout tensors (n <= 8), one pass.
+// The FGNN layer feeds every variable / factor state into 3-5 consumers (v2v map, two V->F blocks, the residual,
+// a skip link: /root/reference/lib/model/mpnn/factor_mpnn_sp.py:139-170), so its gradient is a sum of 3-5 tensors;
+// autograd adds them pairwise (n-1 kernels, 3(n-1) passes over memory), this kernel reads n and writes 1.
+#include "fgnn_common.h"
+
+#define SN_MAX 8
+struct SnParams {
+    const void* in[SN_MAX];
+    void* out;
+    int64_t nchunks;     // 16-byte chunks
+    int n;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void sum_n_kernel(const SnParams p) {
+    constexpr int EPC = 16 / sizeof(T);
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < p.nchunks; i += stride) {
+        float acc[EPC];
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) acc[e] = 0.f;
+#pragma unroll
+        for (int q = 0; q < SN_MAX; ++q) {
+            if (q < p.n) {
+                const uint4 v = reinterpret_cast<const uint4*>(p.in[q])[i];
+                if constexpr (sizeof(T) == 2) {
+                    acc[0] += __uint_as_float(v.x << 16); acc[1] += __uint_as_float(v.x & 0xffff0000u);
+                    acc[2] += __uint_as_float(v.y << 16); acc[3] += __uint_as_float(v.y & 0xffff0000u);
+                    acc[4] += __uint_as_float(v.z << 16); acc[5] += __uint_as_float(v.z & 0xffff0000u);
+                    acc[6] += __uint_as_float(v.w << 16); acc[7] += __uint_as_float(v.w & 0xffff0000u);
+                } else {
+                    acc[0] += __uint_as_float(v.x); acc[1] += __uint_as_float(v.y);
+                    acc[2] += __uint_as_float(v.z); acc[3] += __uint_as_float(v.w);
+                }
+            }
+        }
+        uint4 o;
+        if constexpr (sizeof(T) == 2) {
+            typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+            b2 h;
+            h[0] = (__bf16)acc[0]; h[1] = (__bf16)acc[1]; o.x = __builtin_bit_cast(unsigned, h);
+            h[0] = (__bf16)acc[2]; h[1] = (__bf16)acc[3]; o.y = __builtin_bit_cast(unsigned, h);
+            h[0] = (__bf16)acc[4]; h[1] = (__bf16)acc[5]; o.z = __builtin_bit_cast(unsigned, h);
+            h[0] = (__bf16)acc[6]; h[1] = (__bf16)acc[7]; o.w = __builtin_bit_cast(unsigned, h);
+        } else {
+            o = make_uint4(__float_as_uint(acc[0]), __float_as_uint(acc[1]), __float_as_uint(acc[2]), __float_as_uint(acc[3]));
+        }
+        reinterpret_cast<uint4*>(p.out)[i] = o;
+    }
+}
+
+// out = sum of n dense arrays of `numel` elements (numel * elem size a multiple of 16, 16-byte aligned pointers).
+extern "C" int fgnn_sum_n(const void* const* inputs, int n, int64_t numel, int dtype, void* out, fgnn_stream_t stream) {
+    if (!inputs || !out || n < 1 || n > SN_MAX) FGNN_FAIL(FGNN_EINVAL, "sum_n: 1..%d inputs", SN_MAX);
+    if (dtype != FGNN_F32 && dtype != FGNN_BF16) FGNN_FAIL(FGNN_EINVAL, "sum_n: unknown dtype %d", dtype);
+    const int64_t bytes = numel * (dtype == FGNN_F32 ? 4 : 2);
+    if (numel < 0 || bytes % 16) FGNN_FAIL(FGNN_EUNSUPPORTED, "sum_n: size must be a multiple of 16 bytes");
+    if (numel == 0) return FGNN_OK;
+    SnParams p;
+    for (int q = 0; q < SN_MAX; ++q) {
+        p.in[q] = q < n ? inputs[q] : nullptr;
+        if (q < n && (!inputs[q] || ((uintptr_t)inputs[q] & 15))) FGNN_FAIL(FGNN_EINVAL, "sum_n: null / unaligned input %d", q);
+    }
+    if ((uintptr_t)out & 15) FGNN_FAIL(FGNN_EINVAL, "sum_n: unaligned output");
+    p.out = out; p.nchunks = bytes / 16; p.n = n;
+    int64_t g = (p.nchunks + 255) / 256;
+    if (g > 4096) g = 4096;
+    if (dtype == FGNN_F32) hipLaunchKernelGGL(sum_n_kernel<float>, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(sum_n_kernel<bf16_t>, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "sum_n launch: %s", hipGetErrorString(e));
+    return FGNN_OK;
+}

@@ -23,7 +23,7 @@ EXPORTS = ('fgnn_mpconv_forward', 'fgnn_mpconv_backward', 'fgnn_mpconv_forward_l
            'fgnn_mpconv_backward_workspace_bytes', 'fgnn_linear_wgrad', 'fgnn_linear_wgrad_workspace_bytes',
            'fgnn_instnorm_forward', 'fgnn_instnorm_backward', 'fgnn_bn_supported', 'fgnn_bn_workspace_bytes',
            'fgnn_bn_stats', 'fgnn_bn_finalize', 'fgnn_bn_apply', 'fgnn_bn_backward',
-           'fgnn_linear_forward', 'fgnn_linear_forward_partials',
+           'fgnn_linear_forward', 'fgnn_linear_forward_partials', 'fgnn_sum_n',
            'fgnn_mpconv_algorithmic_bytes', 'fgnn_last_error', 'fgnn_last_kernel', 'fgnn_abi_version')
 
 
@@ -86,6 +86,8 @@ def lib():
     L.fgnn_linear_forward.argtypes = [vp, vp, vp, vp, i64, i32, i32, vp, i32, vp]
     L.fgnn_linear_forward_partials.restype = ctypes.c_int
     L.fgnn_linear_forward_partials.argtypes = [i64, i32, i32]
+    L.fgnn_sum_n.restype = ctypes.c_int
+    L.fgnn_sum_n.argtypes = [vp, i32, i64, i32, vp, vp]
     L.fgnn_bn_apply.restype = ctypes.c_int
     L.fgnn_bn_apply.argtypes = [vp, vp, i64, i32, i32, vp, vp, f32, vp, vp]
     L.fgnn_bn_backward.restype = ctypes.c_int

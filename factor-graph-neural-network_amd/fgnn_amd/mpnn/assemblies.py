@@ -173,24 +173,26 @@ class FactorNN(torch.nn.Module):
         var = self.node_mapping_module(node_feature)
         fac = [m(f) for f, m in zip(hop_features, self.factor_mapping_modules)]
         history = []
+        from ..ops import add_n, fan_out
+        nft = self.nfactor_types
         for L in range(len(self.v2f_modules)):
             same_width = self.dim_mapping_list[L] == self.dim_mapping_list[L + 1]
-            new_var = self.v2v_modules[L](var)
-            new_fac = [m(f) for f, m in zip(fac, self.f2f_modules[L])]
-            for j in range(self.nfactor_types):
-                new_var = _call(self.f2v_modules[L][j], fac[j], nn_idx_f2v[j].long(), etype_f2v[j],
+            res = 1 if same_width else 0
+            # every state feeds several consumers (v2v / f2f map, the message blocks, the residual): hand each its
+            # own alias so that the backward sums their gradients in one kernel (ops.fan_out)
+            var_c = fan_out(var, 1 + nft + res)
+            fac_c = [fan_out(f, 2 + res) for f in fac]
+            new_var = self.v2v_modules[L](var_c[0])
+            new_fac = [m(fc[0]) for fc, m in zip(fac_c, self.f2f_modules[L])]
+            for j in range(nft):
+                new_var = _call(self.f2v_modules[L][j], fac_c[j][1], nn_idx_f2v[j].long(), etype_f2v[j],
                                 addend=new_var)
-                new_fac[j] = _call(self.v2f_modules[L][j], var, nn_idx_v2f[j].long(), etype_v2f[j],
+                new_fac[j] = _call(self.v2f_modules[L][j], var_c[1 + j], nn_idx_v2f[j].long(), etype_v2f[j],
                                    addend=new_fac[j])
-            if same_width:
-                var = var + new_var
-                fac = [a + b for a, b in zip(new_fac, fac)]
-            else:
-                var, fac = new_var, new_fac
-            if L in self.skip_link:
-                pv, pf = history[self.skip_link[L]]
-                var = var + pv
-                fac = [a + b for a, b in zip(pf, fac)]
+            skip = history[self.skip_link[L]] if L in self.skip_link else None
+            var = add_n([var_c[-1] if same_width else None, new_var, skip[0] if skip else None])
+            fac = [add_n([fac_c[j][-1] if same_width else None, new_fac[j], skip[1][j] if skip else None])
+                   for j in range(nft)]
             history.append([var, fac])
         out = self.final_classifier(var)
         if self.final_filter is not None:

@@ -224,6 +224,76 @@ def mpconv(x, nn_idx, etype, filters, bias, nou, net, ext, agg):
     return _MPConv.apply(x, nn_idx, etype, filters, bias, nou, net, ext, agg)
 
 
+def _dense_same_layout(ts):
+    t0 = ts[0]
+    if not (t0.is_cuda and t0.dtype in (torch.float32, torch.bfloat16) and 2 <= len(ts) <= 8):
+        return False
+    if (t0.numel() * t0.element_size()) % 16 or t0.numel() == 0:
+        return False
+    dense = t0.is_contiguous() or (t0.dim() == 4 and t0.permute(0, 2, 3, 1).is_contiguous())
+    return dense and all(t.dtype == t0.dtype and t.shape == t0.shape and t.stride() == t0.stride() and
+                         t.data_ptr() % 16 == 0 for t in ts)
+
+
+def sum_tensors(ts):
+    """Sum of same-shape tensors in ONE pass (csrc/sum_n.hip) when they share a dense layout; pairwise adds else."""
+    ts = [t for t in ts if t is not None]
+    if len(ts) == 1:
+        return ts[0]
+    if not _dense_same_layout(ts):
+        out = ts[0]
+        for t in ts[1:]:
+            out = out + t
+        return out
+    out = torch.empty_like(ts[0])                        # preserve_format: same strides as the inputs
+    arr = (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+    _hip.check(_hip.lib().fgnn_sum_n(arr, len(ts), ts[0].numel(), _hip.dtype_code(ts[0]), _hip._ptr(out),
+                                     _hip.stream_ptr()))
+    return out
+
+
+class _FanOut(torch.autograd.Function):
+    """n aliases of x whose gradients come back TOGETHER: one n-input sum instead of autograd's n-1 adds."""
+
+    @staticmethod
+    def forward(ctx, x, n):
+        return tuple(x.view_as(x) for _ in range(n))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        return sum_tensors([g for g in grads if g is not None]), None
+
+
+class _SumN(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, *ts):
+        return sum_tensors([t.detach() for t in ts])
+
+    @staticmethod
+    def backward(ctx, g):
+        return tuple(g for _ in ctx.needs_input_grad)
+
+
+def fan_out(x, n):
+    """``n`` handles on ``x`` for ``n`` consumers (a single fused gradient sum in the backward)."""
+    if n <= 1 or not (torch.is_grad_enabled() and x.requires_grad and x.is_cuda):
+        return [x] * n
+    return list(_FanOut.apply(x, n))
+
+
+def add_n(ts):
+    """Differentiable sum of tensors, one kernel when the layouts allow."""
+    ts = [t for t in ts if t is not None]
+    if len(ts) == 1:
+        return ts[0]
+    if not (ts[0].is_cuda and _dense_same_layout([t.detach() for t in ts])):
+        out = ts[0]
+        for t in ts[1:]:
+            out = out + t
+        return out
+    return _SumN.apply(*ts)
+
+
 def algorithmic_bytes(x, nn_idx, etype, nou, net, ext, agg):
     """SURVEY §8d algorithmic HBM bytes of one forward call (for bench.py's roofline)."""
     y = _alloc_out(x, nou, nn_idx.shape[1]) if x.is_cuda else None

@@ -153,6 +153,12 @@ int fgnn_bn_backward(const void* x, const void* gy, void* gx, int64_t R, int32_t
                      float* gweight, float* gbias, void* workspace, int64_t workspace_bytes,
                      fgnn_stream_t stream);
 
+/*
+ * out = inputs[0] + ... + inputs[n-1] (n <= 8) over dense arrays of `numel` elements in one pass — the gradient of
+ * a state that fans out into several consumers (factor_mpnn_sp.py:139-170) instead of autograd's pairwise adds.
+ */
+int fgnn_sum_n(const void* const* inputs, int32_t n, int64_t numel, int32_t dtype, void* out, fgnn_stream_t stream);
+
 const char* fgnn_last_error(void);
 /* Name (as rocprofv3 prints it) of the kernel the calling thread's last forward/backward dispatched to. */
 const char* fgnn_last_kernel(void);

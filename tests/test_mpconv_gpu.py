@@ -416,3 +416,30 @@ def test_batchnorm_act_kernel_vs_torch(C, slope, dtype, dev):
     assert H.rel_err(mine.running_mean, ref.running_mean) <= tol
     assert H.rel_err(mine.running_var, ref.running_var) <= tol * 2
     assert int(mine.num_batches_tracked) == 1
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16], ids=['f32', 'bf16'])
+@pytest.mark.parametrize('layout', ['nchw', 'channels_last'])
+def test_fan_out_and_add_n_match_plain_autograd(dtype, layout, dev):
+    """ops.fan_out / ops.add_n (csrc/sum_n.hip: one n-input pass) against ordinary autograd on the same graph:
+    forward sum identical in f32 (same left-to-right order), gradients equal up to the summation order."""
+    from fgnn_amd import ops
+    g = torch.Generator().manual_seed(4)
+    mk = lambda: torch.randn(5, 64, 12, 1, generator=g).to(dtype).to(dev)
+    x, p, q = mk(), mk(), mk()
+    if layout == 'channels_last':
+        x, p, q = [t.contiguous(memory_format=torch.channels_last) for t in (x, p, q)]
+    xa = x.clone().requires_grad_(True)
+    xb = x.clone().requires_grad_(True)
+    w = [mk() for _ in range(4)]
+    if layout == 'channels_last':
+        w = [t.contiguous(memory_format=torch.channels_last) for t in w]
+    c = ops.fan_out(xa, 4)
+    ya = ops.add_n([c[0] * w[0], c[1] * w[1], c[2] * w[2] + p, c[3]])
+    yb = ((xb * w[0] + xb * w[1]) + (xb * w[2] + p)) + xb
+    tol = 0.0 if dtype == torch.float32 else 2.0 ** -7
+    assert H.rel_err(ya.float(), yb.float()) <= tol
+    gy = mk()
+    ya.backward(gy)
+    yb.backward(gy)
+    assert H.rel_err(xa.grad.float(), xb.grad.float()) <= (1e-6 if dtype == torch.float32 else 2.0 ** -6)
