@@ -44,6 +44,7 @@ struct B16Params {
     int et_mode;
     unsigned mkmagic;
     int dbg;                              // FGNN_DBG ablation mask (tuning only)
+    long long* prof;                      // FGNN_PROF: phase timeline of one sample of workgroup 0 (tuning only)
     int JP;                               // neighbour-list split over waves (1 = off)
     int off_xs, off_ps, off_idx, off_et, off_red;  // byte offsets into LDS
 };
@@ -78,6 +79,8 @@ __device__ __forceinline__ float b16_dot(const float* __restrict__ etp, const un
         return v;
     }
 }
+
+#define B16_STAMP(slot) do { if (p.prof && blockIdx.x == 0 && tid == 0 && b == 2 * (int)gridDim.x) p.prof[slot] = __builtin_readcyclecounter(); } while (0)
 
 // KSB = nin/32 MFMA k-steps, SWP = column slabs per wave per pass, NPASS = column passes of <= 256,
 // KC = neighbours per destination when known at compile time (3 / 6: the LDPC degrees), 0 = runtime k
@@ -132,7 +135,7 @@ __global__ __launch_bounds__(B16_THREADS) void mpconv_fwd_b16_kernel(const B16Pa
     // ---- prefetch registers ----
     uint4 xr[B16_XPT];
     unsigned short er[B16_EPT];
-    int ir[B16_IPT];
+    long long ir[B16_IPT];                            // raw: clamped at the commit, so the load is not waited for here
     const int xchunks = (nin * N) >> 3;               // 16-byte chunks of the dense sample block
     auto prefetch = [&](int b, int t) {
         const uint4* xb = reinterpret_cast<const uint4*>(xg + (int64_t)b * d.x_sb);
@@ -150,12 +153,10 @@ __global__ __launch_bounds__(B16_THREADS) void mpconv_fwd_b16_kernel(const B16Pa
 #pragma unroll
         for (int q = 0; q < B16_IPT; ++q) {
             const int f = t + q * B16_THREADS;
-            int v = 0;
+            long long v = 0;
             if (f < mk) {
                 const int m = f / k, j = f - m * k;
-                long long w = (p.idx + (int64_t)b * d.idx_sb)[(int64_t)m * d.idx_sm + (int64_t)j * d.idx_sk];
-                w = w < 0 ? 0 : (w >= N ? N - 1 : w);
-                v = (int)w;
+                v = (p.idx + (int64_t)b * d.idx_sb)[(int64_t)m * d.idx_sm + (int64_t)j * d.idx_sk];
             }
             ir[q] = v;
         }
@@ -184,7 +185,7 @@ __global__ __launch_bounds__(B16_THREADS) void mpconv_fwd_b16_kernel(const B16Pa
 #pragma unroll
         for (int q = 0; q < B16_IPT; ++q) {
             const int f = t + q * B16_THREADS;
-            if (f < mk) idx_s[f] = ir[q];
+            if (f < mk) { const long long w = ir[q]; idx_s[f] = (int)(w < 0 ? 0 : (w >= N ? N - 1 : w)); }
         }
     };
 
@@ -195,13 +196,21 @@ __global__ __launch_bounds__(B16_THREADS) void mpconv_fwd_b16_kernel(const B16Pa
     int b = blockIdx.x;
     if (b < d.B) prefetch(b, tid);
     const int ntile = p.Npad / 16;
+    // per-lane epilogue constants of the channel block last finished: survive across samples, so a call whose
+    // lanes always finish the same channel (one pass, <= 64 channels per pass) loads them once
+    int cc_cached = -1;
+    float c_bias = 0.f, c_scale = 1.f, c_shift = 0.f;
 
     for (; b < d.B; b += gridDim.x) {
         int t = tid;
         asm volatile("" : "+v"(t));          // opaque per sample: no cross-iteration hoisting
+        B16_STAMP(0);
         commit(t);
+        B16_STAMP(1);
         __syncthreads();
+        B16_STAMP(2);
         if (b + (int)gridDim.x < d.B && !(p.dbg & 4)) prefetch(b + gridDim.x, t);
+        B16_STAMP(3);
         unsigned short* yb = yg + (int64_t)b * d.y_sb;
         uint8_t* ab = p.argmax ? p.argmax + (int64_t)b * d.y_sb : nullptr;
 
@@ -209,6 +218,7 @@ __global__ __launch_bounds__(B16_THREADS) void mpconv_fwd_b16_kernel(const B16Pa
         for (int pass = 0; pass < NPASS; ++pass) {
             const int o0 = pass * p.pass_cols / net;
             const int otc = min(p.pass_cols / net, nou - o0);
+            B16_STAMP(4 + 4 * pass);
             // ---- projection: P^T tile = W^T (cols x nin) . x (nin x nodes), bf16 MFMA, f32 accumulate ----
             for (int tile = 0; tile < ((p.dbg & 1) ? 0 : ntile); ++tile) {
                 f32x4 acc[SWP];
@@ -234,6 +244,7 @@ __global__ __launch_bounds__(B16_THREADS) void mpconv_fwd_b16_kernel(const B16Pa
                 }
             }
             __syncthreads();
+            B16_STAMP(5 + 4 * pass);
 
             // ---- gather + edge-type contraction + aggregation ----
             // One wave per (destination m, block of 64 channels), lane = channel.  The neighbour ids and
@@ -249,15 +260,13 @@ __global__ __launch_bounds__(B16_THREADS) void mpconv_fwd_b16_kernel(const B16Pa
                 const int JP = p.JP;
                 const int jchunk = (k + JP - 1) / JP;
                 const unsigned* et_w = reinterpret_cast<const unsigned*>(et_h);
-                int cc_cached = -1;
-                float c_bias = 0.f, c_scale = 1.f, c_shift = 0.f;
                 auto finish = [&](int m, int cc, int ch, float a, float bsum, int arg) {
                     float res;
                     if constexpr (AGG == FGNN_AGG_MAX) res = a;
                     else if constexpr (AGG == FGNN_AGG_LSE) res = (1.0f / 3.0f) * (a + logf(bsum));
                     else res = bsum / (float)k;
-                    if (cc != cc_cached) {            // per-lane channel constants: reload only when the block changes
-                        cc_cached = cc;
+                    if (pass * 8 + cc != cc_cached) { // per-lane channel constants: reload only when the block changes
+                        cc_cached = pass * 8 + cc;
                         const int o = o0 + ch;
                         c_bias = p.bias ? p.bias[o] : 0.f;
                         c_scale = p.pscale ? p.pscale[o] : 1.f;
@@ -269,7 +278,48 @@ __global__ __launch_bounds__(B16_THREADS) void mpconv_fwd_b16_kernel(const B16Pa
                     if (!(p.dbg & 8) || res == 1.2345e-30f) yb[off] = (unsigned short)pack_bf16(res, 0.f);
                     if (AGG == FGNN_AGG_MAX && ab) ab[off] = (uint8_t)arg;
                 };
-                for (int u = wave; u < ((p.dbg & 2) ? 0 : M * nch * JP); u += B16_WAVES) {
+                bool paired = false;
+                if constexpr (KC > 0 && NET == 4 && AGG == FGNN_AGG_MAX) {
+                    // LDPC parity calls (fixed degree, <= 64 channels per pass): two destinations per wave at a
+                    // time, so that the id / weight reads of one overlap the row reads of the other
+                    if (JP == 1 && nch == 1) {
+                        paired = true;
+                        constexpr int UN = 2;                        // destinations in flight per wave (3-4 measured no better)
+                        const bool active = lane < otc;
+                        const unsigned char* pc = ps + (active ? lane : 0) * 8;
+                        for (int m0 = wave; m0 < ((p.dbg & 2) ? 0 : M); m0 += UN * B16_WAVES) {
+                            int id[UN];
+                            unsigned ew[UN];
+#pragma unroll
+                            for (int u = 0; u < UN; ++u) {
+                                const int m = m0 + u * B16_WAVES < M ? m0 + u * B16_WAVES : m0;
+                                id[u] = lane < KC ? idx_s[m * KC + lane] : 0;
+                                ew[u] = lane < 2 * KC ? et_w[m * KC * 2 + lane] : 0u;
+                            }
+                            uint2 pk[UN][KC];
+#pragma unroll
+                            for (int u = 0; u < UN; ++u)
+#pragma unroll
+                                for (int j = 0; j < KC; ++j)
+                                    pk[u][j] = *reinterpret_cast<const uint2*>(pc + __builtin_amdgcn_readlane(id[u], j) * PSB);
+#pragma unroll
+                            for (int u = 0; u < UN; ++u) {
+                                float best = 0.f;
+                                int arg = 0;
+#pragma unroll
+                                for (int j = 0; j < KC; ++j) {
+                                    float v = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, pk[u][j].x),
+                                        __builtin_bit_cast(bf16x2_t, (unsigned)__builtin_amdgcn_readlane(ew[u], 2 * j)), 0.f, false);
+                                    v = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, pk[u][j].y),
+                                        __builtin_bit_cast(bf16x2_t, (unsigned)__builtin_amdgcn_readlane(ew[u], 2 * j + 1)), v, false);
+                                    if (j == 0 || v > best) { best = v; arg = j; }      // strict >: first occurrence
+                                }
+                                if (active && m0 + u * B16_WAVES < M) finish(m0 + u * B16_WAVES, 0, lane, best, 0.f, arg);
+                            }
+                        }
+                    }
+                }
+                for (int u = wave; u < ((p.dbg & 2) || paired ? 0 : M * nch * JP); u += B16_WAVES) {
                     const int part = u % JP, base = u / JP;
                     const int m = base / nch, cc = base - m * nch;
                     const int ch = cc * 64 + lane;
@@ -368,7 +418,9 @@ __global__ __launch_bounds__(B16_THREADS) void mpconv_fwd_b16_kernel(const B16Pa
                     }
                 }
             }
+            B16_STAMP(6 + 4 * pass);
             __syncthreads();          // P (and, after the last pass, xs / et_s / idx_s) may be rewritten
+            B16_STAMP(7 + 4 * pass);
         }
     }
 }
@@ -444,6 +496,13 @@ int fgnn_mpconv_forward_b16(const fgnn_mpconv_desc* d, const void* x, const int6
     p.c8shift = d->nin == 64 ? 3 : 4;
     p.et_mode = et_mode;
     { const char* e = getenv("FGNN_DBG"); p.dbg = e ? atoi(e) : 0; }
+    p.prof = nullptr;
+    static long long* prof_buf = nullptr;
+    if (getenv("FGNN_PROF")) {
+        if (!prof_buf) (void)hipMalloc(&prof_buf, 64 * 8);
+        (void)hipMemset(prof_buf, 0, 64 * 8);
+        p.prof = prof_buf;
+    }
     p.mkmagic = mk == 1 ? 0u : (unsigned)((0x100000000ULL + mk - 1) / mk);
     int off = 0;
     p.off_xs = off;  off += Npad * p.XSB;                off = fgnn_round_up(off, 16);
@@ -478,5 +537,13 @@ int fgnn_mpconv_forward_b16(const fgnn_mpconv_desc* d, const void* x, const int6
     void* args[] = {(void*)&p};
     hipError_t e = hipLaunchKernel(fn, dim3(grid), dim3(B16_THREADS), args, lds, (hipStream_t)stream);
     if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "mpconv bf16 forward launch: %s", hipGetErrorString(e));
+    if (p.prof) {                                     // tuning aid: phase timeline of one sample (shader clocks)
+        long long h[64];
+        (void)hipDeviceSynchronize();
+        (void)hipMemcpy(h, p.prof, sizeof(h), hipMemcpyDeviceToHost);
+        fprintf(stderr, "[fgnn prof fwd]");
+        for (int i = 0; i < 20; ++i) if (h[i]) fprintf(stderr, " %d:%lld", i, h[i] - h[0]);
+        fprintf(stderr, "\n");
+    }
     return 1;
 }
