@@ -281,7 +281,8 @@ int fgnn_mpconv_forward_hyper(const fgnn_mpconv_desc* d, const void* x, const in
     p.waves = waves;
     int grid = (d->B + waves - 1) / waves;
     if (grid > 1024) grid = 1024;
-    fgnn_note_kernel("mpconv_fwd_%s_kernel<%d, %d, %d>", fanin ? "fanin" : "fanout", d->agg, d->nin, d->nou);
+    if (fanin) fgnn_note_kernel("mpconv_fwd_fanin_kernel<%d, %d, %d>", d->agg, d->nin / 32, d->nou / 16);
+    else fgnn_note_kernel("mpconv_fwd_fanout_kernel<%d, %d>", d->nin / 64, d->nou / 16);
     void* args[] = {(void*)&p};
     hipError_t e = hipLaunchKernel(fn, dim3(grid), dim3(64 * waves), args, lds, (hipStream_t)stream);
     if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "mpconv hyper-edge forward launch: %s", hipGetErrorString(e));
