@@ -128,7 +128,8 @@ def test_cpu_tensor_raises():
 
 
 @pytest.mark.parametrize('shape', [(64, 64, 4, 96, 48, 6), (64, 64, 4, 48, 96, 3), (64, 128, 4, 96, 48, 6),
-                                   (128, 64, 4, 48, 96, 3), (64, 64, 1, 96, 8, 12), (128, 64, 4, 96, 48, 6)])
+                                   (128, 64, 4, 48, 96, 3), (64, 64, 1, 96, 8, 12), (128, 64, 4, 96, 48, 6),
+                                   (64, 64, 4, 91, 47, 6), (64, 64, 4, 37, 95, 3), (64, 64, 4, 96, 1, 6)])
 @pytest.mark.parametrize('agg', ['max', 'softmax'])
 def test_bf16_mfma_kernel_vs_oracle(shape, agg, dev):
     """Channel-fastest bf16 inputs take the bf16-MFMA kernel (csrc/mpconv_fwd_b16.hip): x, etype,
@@ -157,7 +158,8 @@ def test_bf16_mfma_kernel_vs_oracle(shape, agg, dev):
 
 
 @pytest.mark.parametrize('shape', [(64, 64, 96, 48, 6), (64, 64, 48, 96, 3), (64, 128, 96, 48, 6), (64, 128, 48, 96, 3),
-                                   (128, 64, 96, 48, 6), (128, 64, 48, 96, 3), (64, 64, 40, 20, 5)],
+                                   (128, 64, 96, 48, 6), (128, 64, 48, 96, 3), (64, 64, 40, 20, 5), (64, 64, 91, 47, 6),
+                                   (64, 64, 37, 95, 3), (64, 128, 50, 33, 4)],
                          ids=lambda s: 'x'.join(map(str, s)))
 @pytest.mark.parametrize('shared', [False, True], ids=['pergraph', 'sharedgraph'])
 def test_bf16_mfma_backward_vs_routed_reference(shape, shared, dev):
