@@ -106,6 +106,11 @@ def cpu_baseline(batch, mode, threads):
                                         torch.__version__)}
 
 
+def _trace(msg):
+    if os.environ.get('FGNN_BENCH_TRACE'):
+        print('[bench rank %s] %s' % (os.environ.get('RANK', '0'), msg), file=sys.stderr, flush=True)
+
+
 def main():
     args = parse()
     rank = int(os.environ.get('RANK', '0'))
@@ -115,10 +120,17 @@ def main():
         raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a ROCm device: the FGNN hot path has no CPU fallback')
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
+    # FGNN_BENCH_DEVICE / FGNN_DIST_BACKEND: test hooks (e.g. 2 ranks sharing one GPU over gloo); the driver
+    # launches one rank per GPU over RCCL (backend "nccl")
+    dev_index = int(os.environ.get('FGNN_BENCH_DEVICE', local_rank))
+    torch.cuda.set_device(dev_index)
+    dev = torch.device('cuda', dev_index)
     if world > 1:
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        backend = os.environ.get('FGNN_DIST_BACKEND', 'nccl')
+        if backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     # torch's own channels-last BatchNorm kernels beat MIOpen's spatial BN on these [B,C,N,1]
     # activations (profiles/r01), so MIOpen is bypassed for the plumbing ops by default
@@ -127,10 +139,12 @@ def main():
     from fgnn_amd.dp import FlatAdam, FlatGradBucket, broadcast_parameters
     from fgnn_amd.ldpc import LDPCModel, MESSAGES_PER_CODEWORD, synthetic_batch
 
+    _trace('process group up')
     torch.manual_seed(0)
     dtype = torch.float32 if args.dtype == 'f32' else torch.bfloat16
     model = LDPCModel(2, 6, 4, aggregator='max').to(dev)
     broadcast_parameters(model)
+    _trace('parameters broadcast')
     data = synthetic_batch(args.batch, dev, seed=100 + rank, dtype=dtype)
     inputs, label, sigma_b = data[:6], data[6], data[7]
     train = args.mode == 'train'
@@ -167,6 +181,8 @@ def main():
                   file=sys.stderr)
             graphed = None
 
+    _trace('graph captured: %s' % (graphed is not None))
+
     def step(eager=False):
         if graphed is not None and not eager:
             graphed.replay()
@@ -184,12 +200,15 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    _trace('warmup enqueued')
     fence()
+    _trace('warmup done')
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     fence()
     elapsed = time.perf_counter() - t0
+    _trace('timed steps done')
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -200,7 +219,7 @@ def main():
     kernels = {}
     if rank == 0:
         ops.TIMER = ops.KernelTimer()
-        step(eager=True)
+        compute()        # eager, WITHOUT the collective / optimizer: the other ranks are not taking part
         kernels = ops.TIMER.summary()
         ops.TIMER = None
         if kernels:
