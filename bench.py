@@ -223,7 +223,9 @@ def main():
         kernels = ops.TIMER.summary()
         ops.TIMER = None
         if kernels:
-            sym, r = max(kernels.items(), key=lambda kv: kv[1]['ms'])
+            # the roofline object describes the VF/FV message operator (the hot path of BASELINE.json): its kernel
+            # with the largest total time; every other hand-written kernel is listed under "kernels" with its GB/s
+            sym, r = max(((k, v) for k, v in kernels.items() if k.startswith('mpconv_')), key=lambda kv: kv[1]['ms'])
             avg_ms = r['ms'] / r['launches']
             gbs = (r['bytes'] / r['launches']) / (avg_ms * 1e-3) / 1e9
             tfs = (r['flops'] / r['launches']) / (avg_ms * 1e-3) / 1e12
@@ -275,7 +277,9 @@ def main():
                        'mode': args.mode, 'hip_graph': graphed is not None},
             'roofline': roofline,
             'kernels': {k: {'launches': v['launches'], 'avg_us': round(v['ms'] / v['launches'] * 1e3, 2),
-                            'total_ms': round(v['ms'], 3)} for k, v in kernels.items()},
+                            'total_ms': round(v['ms'], 3),
+                            'algorithmic_GBs': round(v['bytes'] / max(v['ms'], 1e-9) / 1e6, 1)}
+                        for k, v in sorted(kernels.items(), key=lambda kv: -kv[1]['ms'])},
         }
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args.cpu_batch, args.mode, args.cpu_threads)

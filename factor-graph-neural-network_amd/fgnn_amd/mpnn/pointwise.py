@@ -73,8 +73,10 @@ def hip_linear(rows, weight, bias, want_stats=False, transposed=False):
     ws = None
     if want_stats:
         ws = ops._workspace(rows.device, int(L.fgnn_bn_workspace_bytes(R, cout)))
-    _hip.check(L.fgnn_linear_forward(_hip._ptr(rows), _hip._ptr(w), _hip._ptr(b), _hip._ptr(y), R, cin, cout,
-                                     _hip._ptr(ws), int(transposed), _hip.stream_ptr()))
+    ops.timed('linear_fwd_b16_kernel', 2 * R * (cin + cout),
+              lambda: _hip.check(L.fgnn_linear_forward(_hip._ptr(rows), _hip._ptr(w), _hip._ptr(b), _hip._ptr(y), R, cin,
+                                                       cout, _hip._ptr(ws), int(transposed), _hip.stream_ptr())),
+              nflops=2 * R * cin * cout)
     if want_stats:
         _PENDING_STATS = (y, npart)
     return y
@@ -137,9 +139,12 @@ class _RowLinear(torch.autograd.Function):
         if ctx.has_bias:
             gb = gb_sink if gb_sink is not None else torch.zeros((cout,), device=rows.device, dtype=torch.float32)
         ws = ops._workspace(rows.device, int(L.fgnn_linear_wgrad_workspace_bytes(R, cin, cout)))
-        _hip.check(L.fgnn_linear_wgrad(_hip._ptr(rows), _hip._ptr(gy), R, cin, cout, _hip.dtype_code(rows),
-                                       _hip._ptr(gw), _hip._ptr(gb), _hip._ptr(ws), ws.numel() * 4,
-                                       _hip.stream_ptr()))
+        ops.timed('linear_wgrad_b16_kernel' if rows.dtype == torch.bfloat16 else 'linear_wgrad_kernel',
+                  rows.element_size() * R * (cin + cout),
+                  lambda: _hip.check(L.fgnn_linear_wgrad(_hip._ptr(rows), _hip._ptr(gy), R, cin, cout,
+                                                         _hip.dtype_code(rows), _hip._ptr(gw), _hip._ptr(gb),
+                                                         _hip._ptr(ws), ws.numel() * 4, _hip.stream_ptr())),
+                  nflops=2 * R * cin * cout)
         return (grows, None if gw_sink is not None else gw.to(weight.dtype),
                 None if (gb is None or gb_sink is not None) else gb.to(weight.dtype), None)
 
@@ -183,8 +188,11 @@ class _InstNormAct(torch.autograd.Function):
         if not rows.is_contiguous():
             rows = rows.contiguous()
         y = torch.empty_like(rows)
-        _hip.check(_hip.lib().fgnn_instnorm_forward(_hip._ptr(rows), _hip._ptr(y), B, N, C,
-                                                    _hip.dtype_code(rows), int(relu), _hip.stream_ptr()))
+        from .. import ops
+        ops.timed('instnorm_fwd_kernel', 2 * rows.numel() * rows.element_size(),
+                  lambda: _hip.check(_hip.lib().fgnn_instnorm_forward(_hip._ptr(rows), _hip._ptr(y), B, N, C,
+                                                                      _hip.dtype_code(rows), int(relu),
+                                                                      _hip.stream_ptr())))
         ctx.save_for_backward(rows)
         ctx.relu = relu
         return y.permute(0, 3, 1, 2)
@@ -197,8 +205,11 @@ class _InstNormAct(torch.autograd.Function):
         if not g.is_contiguous() or g.dtype != rows.dtype:
             g = g.to(rows.dtype).contiguous()
         gx = torch.empty_like(rows)
-        _hip.check(_hip.lib().fgnn_instnorm_backward(_hip._ptr(rows), _hip._ptr(g), _hip._ptr(gx), B, N, C,
-                                                     _hip.dtype_code(rows), int(ctx.relu), _hip.stream_ptr()))
+        from .. import ops
+        ops.timed('instnorm_bwd_kernel', 3 * rows.numel() * rows.element_size(),
+                  lambda: _hip.check(_hip.lib().fgnn_instnorm_backward(_hip._ptr(rows), _hip._ptr(g), _hip._ptr(gx), B, N,
+                                                                       C, _hip.dtype_code(rows), int(ctx.relu),
+                                                                       _hip.stream_ptr())))
         return gx.permute(0, 3, 1, 2), None
 
 
@@ -247,14 +258,17 @@ class _BatchNormAct(torch.autograd.Function):
                                           _hip._ptr(stats[0]), _hip._ptr(stats[1]), _hip._ptr(stats[2]),
                                           _hip._ptr(stats[3]), _hip._ptr(nbt), _hip.stream_ptr()))
         else:
-            _hip.check(L.fgnn_bn_stats(_hip._ptr(rows), R, C, dt, _hip._ptr(weight), _hip._ptr(bias),
-                                       _hip._ptr(running_mean), _hip._ptr(running_var), momentum, eps,
-                                       _hip._ptr(stats[0]), _hip._ptr(stats[1]), _hip._ptr(stats[2]),
-                                       _hip._ptr(stats[3]), _hip._ptr(nbt), _hip._ptr(ws), ws.numel() * 4,
-                                       _hip.stream_ptr()))
+            ops.timed('bn_stats (reduce + finalise)', rows.numel() * rows.element_size(),
+                      lambda: _hip.check(L.fgnn_bn_stats(
+                          _hip._ptr(rows), R, C, dt, _hip._ptr(weight), _hip._ptr(bias), _hip._ptr(running_mean),
+                          _hip._ptr(running_var), momentum, eps, _hip._ptr(stats[0]), _hip._ptr(stats[1]),
+                          _hip._ptr(stats[2]), _hip._ptr(stats[3]), _hip._ptr(nbt), _hip._ptr(ws), ws.numel() * 4,
+                          _hip.stream_ptr())))
         y = torch.empty_like(rows)
-        _hip.check(L.fgnn_bn_apply(_hip._ptr(rows), _hip._ptr(y), R, C, dt, _hip._ptr(stats[2]),
-                                   _hip._ptr(stats[3]), slope, _hip._ptr(addend), _hip.stream_ptr()))
+        ops.timed('bn_apply (forward)', (3 if addend is not None else 2) * rows.numel() * rows.element_size(),
+                  lambda: _hip.check(L.fgnn_bn_apply(_hip._ptr(rows), _hip._ptr(y), R, C, dt, _hip._ptr(stats[2]),
+                                                     _hip._ptr(stats[3]), slope, _hip._ptr(addend),
+                                                     _hip.stream_ptr())))
         ctx.has_addend = addend is not None
         ctx.save_for_backward(rows, weight, bias, stats)
         ctx.slope = slope
@@ -275,10 +289,11 @@ class _BatchNormAct(torch.autograd.Function):
         gw = gw_sink if gw_sink is not None else torch.zeros(C, device=rows.device, dtype=torch.float32)
         gb = gb_sink if gb_sink is not None else torch.zeros(C, device=rows.device, dtype=torch.float32)
         ws = ops._workspace(rows.device, int(L.fgnn_bn_workspace_bytes(R, C)))
-        _hip.check(L.fgnn_bn_backward(_hip._ptr(rows), _hip._ptr(gy), _hip._ptr(gx), R, C, _hip.dtype_code(rows),
-                                      _hip._ptr(stats[0]), _hip._ptr(stats[1]), _hip._ptr(weight),
-                                      _hip._ptr(bias), ctx.slope, _hip._ptr(gw), _hip._ptr(gb), _hip._ptr(ws),
-                                      ws.numel() * 4, _hip.stream_ptr()))
+        ops.timed('bn_backward (reduce + finalise + apply)', 5 * rows.numel() * rows.element_size(),
+                  lambda: _hip.check(L.fgnn_bn_backward(
+                      _hip._ptr(rows), _hip._ptr(gy), _hip._ptr(gx), R, C, _hip.dtype_code(rows), _hip._ptr(stats[0]),
+                      _hip._ptr(stats[1]), _hip._ptr(weight), _hip._ptr(bias), ctx.slope, _hip._ptr(gw), _hip._ptr(gb),
+                      _hip._ptr(ws), ws.numel() * 4, _hip.stream_ptr())))
         return (gx, None if gw_sink is not None else gw, None if gb_sink is not None else gb,
                 None, None, None, None, None, gy if ctx.has_addend else None, None)
 

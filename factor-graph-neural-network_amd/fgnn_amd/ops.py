@@ -23,12 +23,13 @@ class KernelTimer:
     def __init__(self):
         self.records = []
 
-    def run(self, symbol, nbytes, nflops, launch):
+    def run(self, symbol, nbytes, nflops, launch, use_note=True):
         start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         start.record()
         launch()
         end.record()
-        name = _hip.lib().fgnn_last_kernel().decode() or symbol     # the kernel the dispatch chose
+        # message-operator calls: the kernel the C dispatch chose; other entry points: the symbol given
+        name = (_hip.lib().fgnn_last_kernel().decode() or symbol) if use_note else symbol
         self.records.append((name, nbytes, nflops, start, end))
 
     def summary(self):
@@ -65,6 +66,15 @@ def _launch(kind, d, nbytes, fn):
         fn()
     else:
         TIMER.run(_symbol(kind, d), nbytes, _flops(d, 3 if kind == 'bwd' else 1), fn)
+
+
+def timed(symbol, nbytes, fn, nflops=0):
+    """Run one C-ABI call of a non-operator kernel (node-wise maps, norms, sums); with bench.py's KernelTimer
+    installed, also record its duration against its algorithmic bytes."""
+    if TIMER is None:
+        fn()
+    else:
+        TIMER.run(symbol, nbytes, nflops, fn, use_note=False)
 
 
 def _require_device(*tensors):
@@ -247,8 +257,9 @@ def sum_tensors(ts):
         return out
     out = torch.empty_like(ts[0])                        # preserve_format: same strides as the inputs
     arr = (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
-    _hip.check(_hip.lib().fgnn_sum_n(arr, len(ts), ts[0].numel(), _hip.dtype_code(ts[0]), _hip._ptr(out),
-                                     _hip.stream_ptr()))
+    timed('sum_n_kernel', (len(ts) + 1) * ts[0].numel() * ts[0].element_size(),
+          lambda: _hip.check(_hip.lib().fgnn_sum_n(arr, len(ts), ts[0].numel(), _hip.dtype_code(ts[0]),
+                                                   _hip._ptr(out), _hip.stream_ptr())))
     return out
 
 
