@@ -88,7 +88,12 @@ __device__ __forceinline__ bb_bf16x8 bb_tr_dyn(const uint2 (&r)[8], int P) {
     }
 }
 
+// phase-timeline stamps (tuning aid): compiled in only with -DFGNN_ENABLE_PROF, read with FGNN_PROF=1
+#ifdef FGNN_ENABLE_PROF
 #define BB_STAMP(slot) do { if (p.prof && blockIdx.x == 0 && tid == 0 && b == b_begin + 2) p.prof[slot] = __builtin_readcyclecounter(); } while (0)
+#else
+#define BB_STAMP(slot) do { } while (0)
+#endif
 
 __device__ __forceinline__ float bb_quad_sum(float v) {       // sum over the 4 lanes of a quad (all lanes get it)
     v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]

@@ -80,7 +80,12 @@ __device__ __forceinline__ float b16_dot(const float* __restrict__ etp, const un
     }
 }
 
+// phase-timeline stamps (tuning aid): compiled in only with -DFGNN_ENABLE_PROF, read with FGNN_PROF=1
+#ifdef FGNN_ENABLE_PROF
 #define B16_STAMP(slot) do { if (p.prof && blockIdx.x == 0 && tid == 0 && b == 2 * (int)gridDim.x) p.prof[slot] = __builtin_readcyclecounter(); } while (0)
+#else
+#define B16_STAMP(slot) do { } while (0)
+#endif
 
 // KSB = nin/32 MFMA k-steps, SWP = column slabs per wave per pass, NPASS = column passes of <= 256,
 // KC = neighbours per destination when known at compile time (3 / 6: the LDPC degrees), 0 = runtime k
