@@ -1,0 +1,317 @@
+// mpconv_block_fwd.hip — inference forward of a whole `mp_conv_residual` block in ONE kernel:
+//
+//     a1  = LeakyReLU( BN1( Conv1x1(x) ) )                         on the SOURCE nodes      [N, 64]
+//     z   = max_j sum_e etype[e,m,j] * (a1 W)[idx[m,j], o, e] + bias                         [M, 64]
+//     a2  = ReLU( BN2(z) )
+//     out = LeakyReLU( BN3( Conv1x1(a2) ) ) (+ addend)             on the DESTINATION nodes [M, 64]
+//
+// (/root/reference/lib/model/mpnn/mp_nn_residual.py:39-56 with the message operator of mp_nn.py:115-175).  In
+// eval mode every BatchNorm is a per-channel affine, so the three stages of a sample depend on nothing but that
+// sample: a persistent workgroup keeps x -> a1 -> P -> a2 in LDS and only `out` goes back to HBM.  The unfused
+// inference path runs 5 kernels over these tensors (two streaming GEMMs, two affine+activation passes, the
+// operator) and moves each intermediate through HBM twice.
+//
+// Family: bf16 channel-fastest tensors, 4 edge types (edge-type-fastest etype), max aggregator, NO_EXTENSION,
+// nmed = 64, nin and nout in {64, 128, 256}, fixed degree k in {3, 6} (the parity-check calls of the LDPC model).  Schedule: as
+// mpconv_fwd_b16.hip (512 threads, next sample prefetched into registers, W fragments of all three products
+// resident in registers, two destinations in flight per wave in the gather) plus one MFMA phase in front and one
+// behind; the a2 image re-uses the x image's LDS, so the 64-wide block stays under 80 KB (2 workgroups per CU).
+#include "fgnn_common.h"
+#include <stdlib.h>
+
+#define KB_THREADS 512
+#define KB_WAVES 8
+#define KB_XSB 72        // row stride (bf16 elements) of the a1 / a2 images: 64 channels + 8 (x image: nin + 8)
+#define KB_PSB 264       // row stride of the P image: 256 columns + 8
+
+typedef __bf16 kb_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 kb_bf16x2 __attribute__((ext_vector_type(2)));
+
+struct KbParams {
+    fgnn_mpconv_desc d;  // of the message operator inside the block (nin = nou = 64, net = 4)
+    const uint16_t* x;   // [B][N][nin]
+    const int64_t* idx;
+    const uint16_t* et;  // [B][M][k][4]
+    const float* W1;     // [64][nin]  conv1 weight [out][in]
+    const float* s1;     // [64] folded scale / shift of conv1 bias + BN1
+    const float* t1;
+    const float* F;      // [64][256] operator filters
+    const float* s2;     // [64] folded (bias, BN2)
+    const float* t2;
+    const float* W2;     // [nout][64] conv2 weight [out][in]
+    const float* s3;
+    const float* t3;
+    const uint16_t* addend;   // [B][M][nout] or NULL
+    uint16_t* y;         // [B][M][nout]
+    float slope;         // LeakyReLU slope of conv1 / conv2
+    int Npad, Mpad;
+    int off_a1, off_ps, off_idx, off_et;   // byte offsets (x / a2 image at 0)
+};
+
+extern __shared__ __attribute__((aligned(16))) unsigned char fgnn_lds_kb[];
+
+__device__ __forceinline__ unsigned kb_pack2(float a, float b) {
+    const kb_bf16x2 h = {(__bf16)a, (__bf16)b};
+    return __builtin_bit_cast(unsigned, h);
+}
+__device__ __forceinline__ kb_bf16x8 kb_frag8(const float* p8) {          // 8 consecutive f32 -> one fragment
+    const f32x4 a = *reinterpret_cast<const f32x4*>(p8), b = *reinterpret_cast<const f32x4*>(p8 + 4);
+    return __builtin_bit_cast(kb_bf16x8, make_uint4(kb_pack2(a[0], a[1]), kb_pack2(a[2], a[3]),
+                                                    kb_pack2(b[0], b[1]), kb_pack2(b[2], b[3])));
+}
+
+// KC = degree, NI = nin / 64, NO = nout / 64
+template <int KC, int NI, int NO>
+__global__ __launch_bounds__(KB_THREADS) void mpconv_block_fwd_kernel(const KbParams p) {
+    constexpr int NIN = 64 * NI, NOUT = 64 * NO, XS1 = NIN + 8, KS1 = 2 * NI, XQ = (96 * NIN / 8 + KB_THREADS - 1) / KB_THREADS;
+    const fgnn_mpconv_desc& d = p.d;
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int N = d.N, M = d.M;
+    constexpr int k = KC;
+    const int mk = M * k;
+    uint16_t* xs = reinterpret_cast<uint16_t*>(fgnn_lds_kb);                 // [Npad][XS1] x, later [Mpad][XSB] a2
+    uint16_t* a1s = reinterpret_cast<uint16_t*>(fgnn_lds_kb + p.off_a1);     // [Npad][XSB] a1
+    uint16_t* ps = reinterpret_cast<uint16_t*>(fgnn_lds_kb + p.off_ps);      // [Npad][PSB] P
+    int* idx_s = reinterpret_cast<int*>(fgnn_lds_kb + p.off_idx);
+    uint2* et_s = reinterpret_cast<uint2*>(fgnn_lds_kb + p.off_et);          // [mk] 4 x bf16
+
+    // ---- resident fragments ----
+    const int li0 = lane & 15, lk0 = lane >> 4;
+    const int ot = wave & 3;                           // this wave's 16-channel output tile of conv1 / conv2
+    kb_bf16x8 aW1[KS1], aW2[NO][2], aF[2][2];
+    f32x4 c1s, c1t, c3s[NO], c3t[NO];                  // per-lane affine of the wave's conv tiles: channels tile*16 + 4lk + r
+#pragma unroll
+    for (int ks = 0; ks < KS1; ++ks) aW1[ks] = kb_frag8(p.W1 + (ot * 16 + li0) * NIN + 32 * ks + 8 * lk0);   // A[i = o][k = c] = W1[o][c]
+    c1s = *reinterpret_cast<const f32x4*>(p.s1 + ot * 16 + 4 * lk0);
+    c1t = *reinterpret_cast<const f32x4*>(p.t1 + ot * 16 + 4 * lk0);
+#pragma unroll
+    for (int q = 0; q < NO; ++q) {                     // conv2 output tiles ot + 4q of the 4*NO
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) aW2[q][ks] = kb_frag8(p.W2 + ((ot + 4 * q) * 16 + li0) * 64 + 32 * ks + 8 * lk0);
+        c3s[q] = *reinterpret_cast<const f32x4*>(p.s3 + (ot + 4 * q) * 16 + 4 * lk0);
+        c3t[q] = *reinterpret_cast<const f32x4*>(p.t3 + (ot + 4 * q) * 16 + 4 * lk0);
+    }
+    // operator filters: A[i = col][k = c] = F[c][col]; slabs wave and wave + 8 of the 16 column slabs
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            float w8[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) w8[u] = p.F[(32 * ks + 8 * lk0 + u) * 256 + (wave + 8 * q) * 16 + li0];
+            aF[q][ks] = __builtin_bit_cast(kb_bf16x8, make_uint4(kb_pack2(w8[0], w8[1]), kb_pack2(w8[2], w8[3]),
+                                                                 kb_pack2(w8[4], w8[5]), kb_pack2(w8[6], w8[7])));
+        }
+    const float c2s = p.s2[lane], c2t = p.t2[lane];   // gather epilogue: lane <-> channel
+
+    // ---- prefetch registers ----
+    uint4 xr[XQ];
+    uint2 er;
+    long long ir = 0;
+    const int xchunks = N * (NIN / 8);
+    auto prefetch = [&](int b, int t) {
+        const uint4* xb = reinterpret_cast<const uint4*>(p.x + (int64_t)b * d.x_sb);
+#pragma unroll
+        for (int q = 0; q < XQ; ++q) {
+            const int f = t + q * KB_THREADS;
+            xr[q] = f < xchunks ? xb[f] : make_uint4(0, 0, 0, 0);
+        }
+        er = make_uint2(0, 0);
+        if (t < mk) {
+            er = *reinterpret_cast<const uint2*>(p.et + (int64_t)b * d.et_sb + (int64_t)t * 4);
+            const int m = t / k, j = t - m * k;
+            ir = (p.idx + (int64_t)b * d.idx_sb)[(int64_t)m * d.idx_sm + (int64_t)j * d.idx_sk];
+        }
+    };
+    auto commit = [&](int t) {
+#pragma unroll
+        for (int q = 0; q < XQ; ++q) {
+            const int f = t + q * KB_THREADS;
+            if (f < xchunks) *reinterpret_cast<uint4*>(xs + (f / (NIN / 8)) * XS1 + (f % (NIN / 8)) * 8) = xr[q];
+        }
+        if (t < mk) {
+            et_s[t] = er;
+            const long long v = ir;
+            idx_s[t] = (int)(v < 0 ? 0 : (v >= N ? N - 1 : v));
+        }
+    };
+    // rows N..Npad of the a1 image are read by the projection and never written by conv1's stores (n < N only)
+    for (int f = tid; f < p.Npad * KB_XSB / 2; f += KB_THREADS) reinterpret_cast<unsigned*>(a1s)[f] = 0u;
+
+    int b = blockIdx.x;
+    if (b < d.B) prefetch(b, tid);
+    const int ntile = p.Npad / 16, mtile = p.Mpad / 16;
+    for (; b < d.B; b += gridDim.x) {
+        int t = tid;
+        asm volatile("" : "+v"(t));
+        const int li = t & 15, lk = (t >> 4) & 3;
+        __syncthreads();                               // previous sample's conv2 is done with the a2 (= x) image
+        commit(t);
+        __syncthreads();
+        if (b + (int)gridDim.x < d.B) prefetch(b + gridDim.x, t);
+
+        // ---- conv1 + BN1 + LeakyReLU on the sources: D[i = o][j = n], tile (ot, nt), nt = wave/4 + 2 i ----
+        for (int nt = wave >> 2; nt < ntile; nt += 2) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            const uint16_t* bp = xs + (nt * 16 + li) * XS1 + 8 * lk;
+#pragma unroll
+            for (int ks = 0; ks < KS1; ++ks)
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aW1[ks], __builtin_bit_cast(kb_bf16x8, *reinterpret_cast<const uint4*>(bp + 32 * ks)), acc, 0, 0, 0);
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const float u = fmaf(acc[r], c1s[r], c1t[r]); v[r] = u > 0.f ? u : u * p.slope; }
+            if (nt * 16 + li < N)
+                *reinterpret_cast<uint2*>(a1s + (nt * 16 + li) * KB_XSB + ot * 16 + 4 * lk) = make_uint2(kb_pack2(v[0], v[1]), kb_pack2(v[2], v[3]));
+        }
+        __syncthreads();
+
+        // ---- projection P^T = F^T a1: wave's slabs w and w + 8, all node tiles ----
+        for (int nt = 0; nt < ntile; ++nt) {
+            const uint16_t* bp = a1s + (nt * 16 + li) * KB_XSB + 8 * lk;
+            const kb_bf16x8 b0 = __builtin_bit_cast(kb_bf16x8, *reinterpret_cast<const uint4*>(bp));
+            const kb_bf16x8 b1 = __builtin_bit_cast(kb_bf16x8, *reinterpret_cast<const uint4*>(bp + 32));
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aF[q][0], b0, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aF[q][1], b1, acc, 0, 0, 0);
+                *reinterpret_cast<uint2*>(ps + (nt * 16 + li) * KB_PSB + (wave + 8 * q) * 16 + 4 * lk) =
+                    make_uint2(kb_pack2(acc[0], acc[1]), kb_pack2(acc[2], acc[3]));
+            }
+        }
+        __syncthreads();                               // P complete; the x image is dead: it becomes a2
+
+        // ---- gather + edge-type contraction + max, two destinations in flight per wave; a2 = ReLU(BN2(z)) -> LDS ----
+        {
+            const unsigned* et_w = reinterpret_cast<const unsigned*>(et_s);
+            const uint16_t* pc = ps + lane * 4;
+            for (int m0 = wave; m0 < M; m0 += 2 * KB_WAVES) {
+                const bool two = m0 + KB_WAVES < M;
+                const int m1 = two ? m0 + KB_WAVES : m0;
+                const int id0 = lane < KC ? idx_s[m0 * KC + lane] : 0;
+                const int id1 = lane < KC ? idx_s[m1 * KC + lane] : 0;
+                const unsigned e0 = lane < 2 * KC ? et_w[m0 * KC * 2 + lane] : 0u;
+                const unsigned e1 = lane < 2 * KC ? et_w[m1 * KC * 2 + lane] : 0u;
+                uint2 pk0[KC], pk1[KC];
+#pragma unroll
+                for (int j = 0; j < KC; ++j) {
+                    pk0[j] = *reinterpret_cast<const uint2*>(pc + __builtin_amdgcn_readlane(id0, j) * KB_PSB);
+                    pk1[j] = *reinterpret_cast<const uint2*>(pc + __builtin_amdgcn_readlane(id1, j) * KB_PSB);
+                }
+                float b0 = 0.f, b1 = 0.f;
+#pragma unroll
+                for (int j = 0; j < KC; ++j) {
+                    float v0 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(kb_bf16x2, pk0[j].x),
+                        __builtin_bit_cast(kb_bf16x2, (unsigned)__builtin_amdgcn_readlane(e0, 2 * j)), 0.f, false);
+                    v0 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(kb_bf16x2, pk0[j].y),
+                        __builtin_bit_cast(kb_bf16x2, (unsigned)__builtin_amdgcn_readlane(e0, 2 * j + 1)), v0, false);
+                    float v1 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(kb_bf16x2, pk1[j].x),
+                        __builtin_bit_cast(kb_bf16x2, (unsigned)__builtin_amdgcn_readlane(e1, 2 * j)), 0.f, false);
+                    v1 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(kb_bf16x2, pk1[j].y),
+                        __builtin_bit_cast(kb_bf16x2, (unsigned)__builtin_amdgcn_readlane(e1, 2 * j + 1)), v1, false);
+                    b0 = j == 0 ? v0 : fmaxf(b0, v0);
+                    b1 = j == 0 ? v1 : fmaxf(b1, v1);
+                }
+                const __bf16 h0 = (__bf16)fmaxf(fmaf(b0, c2s, c2t), 0.f);
+                xs[m0 * KB_XSB + lane] = __builtin_bit_cast(uint16_t, h0);
+                if (two) {
+                    const __bf16 h1 = (__bf16)fmaxf(fmaf(b1, c2s, c2t), 0.f);
+                    xs[m1 * KB_XSB + lane] = __builtin_bit_cast(uint16_t, h1);
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---- conv2 + BN3 + LeakyReLU (+ addend) on the destinations: tile (ot, mt), mt = wave/4 + 2 i ----
+        {
+            uint16_t* yb = p.y + (int64_t)b * M * NOUT;
+            const uint16_t* adb = p.addend ? p.addend + (int64_t)b * M * NOUT : nullptr;
+            for (int mt = wave >> 2; mt < mtile; mt += 2) {
+                const uint16_t* bp = xs + (mt * 16 + li) * KB_XSB + 8 * lk;
+                const kb_bf16x8 b0 = __builtin_bit_cast(kb_bf16x8, *reinterpret_cast<const uint4*>(bp));
+                const kb_bf16x8 b1 = __builtin_bit_cast(kb_bf16x8, *reinterpret_cast<const uint4*>(bp + 32));
+                const int m = mt * 16 + li;
+#pragma unroll
+                for (int q = 0; q < NO; ++q) {
+                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aW2[q][0], b0, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aW2[q][1], b1, acc, 0, 0, 0);
+                    if (m < M) {
+                        float v[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { const float u = fmaf(acc[r], c3s[q][r], c3t[q][r]); v[r] = u > 0.f ? u : u * p.slope; }
+                        const int64_t off = (int64_t)m * NOUT + (ot + 4 * q) * 16 + 4 * lk;
+                        if (adb) {
+                            const uint2 a = *reinterpret_cast<const uint2*>(adb + off);
+                            v[0] += __uint_as_float(a.x << 16); v[1] += __uint_as_float(a.x & 0xffff0000u);
+                            v[2] += __uint_as_float(a.y << 16); v[3] += __uint_as_float(a.y & 0xffff0000u);
+                        }
+                        *reinterpret_cast<uint2*>(yb + off) = make_uint2(kb_pack2(v[0], v[1]), kb_pack2(v[2], v[3]));
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------------------
+// host side
+// ----------------------------------------------------------------------------------------
+// Inference forward of conv1+BN1+LeakyReLU -> message operator (+bias, BN2, ReLU) -> conv2+BN3+LeakyReLU (+addend).
+// s1/t1, s2/t2: per-channel float32 [64] affines, s3/t3: [nout], with the conv / operator biases folded in;
+// W1 is [64][nin], W2 is [nout][64].  Returns FGNN_EUNSUPPORTED
+// outside the family described at the top of this file (callers then run the stages separately).
+extern "C" int fgnn_mpconv_block_forward(const fgnn_mpconv_desc* d, const void* x, const int64_t* nn_idx,
+                                         const void* etype, const float* W1, const float* s1, const float* t1,
+                                         const float* filters, const float* s2, const float* t2, const float* W2,
+                                         const float* s3, const float* t3, float slope, int nin, int nout,
+                                         const void* addend, void* y, fgnn_stream_t stream) {
+    if (!d || !x || !nn_idx || !etype || !W1 || !s1 || !t1 || !filters || !s2 || !t2 || !W2 || !s3 || !t3 || !y)
+        FGNN_FAIL(FGNN_EINVAL, "mpconv_block_forward: null pointer");
+    const bool ok = d->dtype == FGNN_BF16 && d->ext == FGNN_EXT_NONE && d->agg == FGNN_AGG_MAX && d->net == 4 &&
+                    d->nin == 64 && d->nou == 64 && (d->k == 3 || d->k == 6) && d->N >= 1 && d->N <= 96 &&
+                    d->M >= 1 && d->M <= 96 && d->M * d->k <= KB_THREADS &&
+                    (nin == 64 || nin == 128 || nin == 256) && (nout == 64 || nout == 128 || nout == 256) &&
+                    d->x_sc == 1 && d->x_sn == nin && d->x_sb % 8 == 0 &&
+                    d->y_sc == 1 && d->y_sm == nout && d->y_sb == (int64_t)d->M * nout &&
+                    d->et_se == 1 && d->et_sk == 4 && d->et_sm == 4 * d->k && d->et_sb % 4 == 0 &&
+                    !((uintptr_t)x & 15) && !((uintptr_t)etype & 7) && !((uintptr_t)y & 7) && !((uintptr_t)addend & 7);
+    if (!ok) FGNN_FAIL(FGNN_EUNSUPPORTED, "mpconv_block_forward: outside the fused block's family");
+    if (d->B == 0) return FGNN_OK;
+    KbParams p;
+    p.d = *d;
+    p.x = (const uint16_t*)x; p.idx = nn_idx; p.et = (const uint16_t*)etype;
+    p.W1 = W1; p.s1 = s1; p.t1 = t1; p.F = filters; p.s2 = s2; p.t2 = t2; p.W2 = W2; p.s3 = s3; p.t3 = t3;
+    p.addend = (const uint16_t*)addend; p.y = (uint16_t*)y; p.slope = slope;
+    p.Npad = fgnn_round_up(d->N, 16);
+    p.Mpad = fgnn_round_up(d->M, 16);
+    const int img0 = p.Npad * (nin + 8) > p.Mpad * KB_XSB ? p.Npad * (nin + 8) : p.Mpad * KB_XSB;   // x, later a2
+    int off = fgnn_round_up(img0 * 2, 16);
+    p.off_a1 = off; off += fgnn_round_up(p.Npad * KB_XSB * 2, 16);
+    p.off_ps = off; off += fgnn_round_up(p.Npad * KB_PSB * 2, 16);
+    p.off_idx = off; off += fgnn_round_up(d->M * d->k * 4, 16);
+    p.off_et = off; off += fgnn_round_up(d->M * d->k * 8, 16);
+    const int lds = off;
+    void* fn = nullptr;
+#define KB_CASE(kc, ni, no) if (d->k == kc && nin == 64 * ni && nout == 64 * no) fn = (void*)mpconv_block_fwd_kernel<kc, ni, no>;
+    KB_CASE(3, 1, 1) KB_CASE(6, 1, 1) KB_CASE(3, 2, 4) KB_CASE(6, 2, 4) KB_CASE(3, 4, 4) KB_CASE(6, 4, 4) KB_CASE(3, 4, 2) KB_CASE(6, 4, 2)
+    KB_CASE(3, 1, 2) KB_CASE(6, 1, 2) KB_CASE(3, 2, 1) KB_CASE(6, 2, 1)
+#undef KB_CASE
+    if (!fn) FGNN_FAIL(FGNN_EUNSUPPORTED, "mpconv_block_forward: nin=%d nout=%d not instantiated", nin, nout);
+    if (lds > 160 * 1024) FGNN_FAIL(FGNN_EUNSUPPORTED, "mpconv_block_forward: %d B of LDS", lds);
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "hipFuncSetAttribute(%d B LDS): %s", lds, hipGetErrorString(e));
+    }
+    int wg_per_cu = (160 * 1024) / lds;
+    if (wg_per_cu > 2) wg_per_cu = 2;
+    if (wg_per_cu < 1) wg_per_cu = 1;
+    int grid = 256 * wg_per_cu;
+    if (grid > d->B) grid = d->B;
+    fgnn_note_kernel("mpconv_block_fwd_kernel<%d, %d, %d>", d->k, nin / 64, nout / 64);
+    void* args[] = {(void*)&p};
+    hipError_t e = hipLaunchKernel(fn, dim3(grid), dim3(KB_THREADS), args, lds, (hipStream_t)stream);
+    if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "mpconv_block_forward launch: %s", hipGetErrorString(e));
+    return FGNN_OK;
+}

@@ -19,6 +19,9 @@ def _conv_norm_act(cin, cout, norm, act, bias=True):
     return torch.nn.Sequential(*layers)
 
 
+FUSE_EVAL_BLOCKS = True      # inference: run a 64-wide bf16 mp_conv_residual as one kernel when possible
+
+
 class iid_mapping(torch.nn.Module):
     def __init__(self, nin, nout, bias=True):
         super().__init__()
@@ -77,9 +80,68 @@ class mp_conv_residual(base_mp_nn):
         self.with_residual = with_residual
         self.with_hop = with_hop
 
+    def _fused_eval(self, x, nn_idx, etype, addend):
+        """Inference: the whole block as ONE kernel (csrc/mpconv_block_fwd.hip) when it is the 64-wide bf16
+        parity-check shape; None otherwise."""
+        import ctypes
+        from .. import _hip, ops
+        mp = self.mp_conv
+        bn1, bn2, bn3 = self.conv1[1], mp.bn, self.conv2[1]
+        if (not FUSE_EVAL_BLOCKS or self.with_residual or self.training or torch.is_grad_enabled() or not x.is_cuda
+                or x.dtype != torch.bfloat16 or x.shape[1] not in (64, 128, 256) or mp.nin != 64 or mp.nou != 64
+                or mp.nedge_types != 4 or mp.aggregtor != 'max' or mp.extension != mp_conv_type.NO_EXTENSION
+                or bn2 is None or mp.bias is None or not isinstance(mp.activation_fn, torch.nn.ReLU)
+                or self.conv2[0].out_channels not in (64, 128, 256) or nn_idx.shape[2] not in (3, 6)
+                or not isinstance(bn1, BatchNormAct2d) or not isinstance(bn3, BatchNormAct2d)
+                or bn1.slope != bn3.slope or etype.dtype != torch.bfloat16):
+            return None
+        B, nin, N, _ = x.shape
+        nout = self.conv2[0].out_channels
+        M, k = nn_idx.shape[1:]
+        xr = x.permute(0, 2, 3, 1)
+        et = etype.permute(0, 2, 3, 1)                                   # [B, M, k, 4]
+        if not xr.is_contiguous() or not (et.is_contiguous() or (etype.stride(0) == 0 and et[0].is_contiguous())):
+            return None
+        if addend is not None:
+            ar = addend.permute(0, 2, 3, 1)
+            if addend.dtype != x.dtype or not ar.is_contiguous():
+                return None
+        key = tuple(t._version for t in (self.conv1[0].weight, self.conv1[0].bias, bn1.weight, bn1.bias, bn1.running_mean,
+                                         bn1.running_var, mp.filters, mp.bias, bn2.weight, bn2.bias, bn2.running_mean,
+                                         bn2.running_var, self.conv2[0].weight, self.conv2[0].bias, bn3.weight, bn3.bias,
+                                         bn3.running_mean, bn3.running_var)) + (x.device,)
+        if getattr(self, '_fuse_key', None) != key:
+            def fold(bn, bias):
+                s = bn.weight.float() * torch.rsqrt(bn.running_var.float() + bn.eps)
+                t = bn.bias.float() - bn.running_mean.float() * s
+                return s.contiguous(), (t + (bias.float() * s if bias is not None else 0)).contiguous()
+            s1, t1 = fold(bn1, self.conv1[0].bias)
+            s2, t2 = fold(bn2, mp.bias)
+            s3, t3 = fold(bn3, self.conv2[0].bias)
+            self._fuse = (self.conv1[0].weight.detach().float().reshape(64, nin).contiguous(), s1, t1,
+                          mp.filters.detach().float().contiguous(), s2, t2,
+                          self.conv2[0].weight.detach().float().reshape(nout, 64).contiguous(), s3, t3)
+            self._fuse_key = key
+        W1, s1, t1, F, s2, t2, W2, s3, t3 = self._fuse
+        y = torch.empty((B, M, 1, nout), device=x.device, dtype=x.dtype).permute(0, 3, 1, 2)
+        d = _hip.make_desc(x, nn_idx, etype, 64, 4, _hip.EXT_NONE, _hip.AGG_MAX, True, y)
+        d.nin = 64                      # the inner operator's width; x / y strides stay the block's
+        P = _hip._ptr
+        rc = _hip.lib().fgnn_mpconv_block_forward(ctypes.byref(d), P(x), P(nn_idx), P(etype), P(W1), P(s1), P(t1), P(F),
+                                                  P(s2), P(t2), P(W2), P(s3), P(t3), float(bn1.slope), nin, nout, P(addend),
+                                                  P(y),
+                                                  _hip.stream_ptr())
+        if rc == _hip.EUNSUPPORTED:
+            return None
+        _hip.check(rc)
+        return y
+
     def forward(self, node_feature, nn_idx, etype, addend=None):
         """``addend`` (optional, the caller's running sum of the same shape as the output) is added by conv2's
         fused BatchNorm+activation kernel instead of a separate elementwise pass."""
+        y = self._fused_eval(node_feature, nn_idx, etype, addend)
+        if y is not None:
+            return y
         fuse = self.training            # BatchNorm statistics ride in the 1x1 map's epilogue when training
         h = self.conv1[1](self.conv1[0](node_feature, want_stats=fuse))
         h = self.mp_conv(h, nn_idx, etype)

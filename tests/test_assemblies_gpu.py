@@ -219,3 +219,44 @@ def test_gradients_accumulated_in_place_equal_returned_gradients(dtype, dev):
     assert float((bucket.flat - want).abs().max()) <= tol * float(want.abs().max())
     backward()                                          # accumulates
     assert float((bucket.flat - 2 * want).abs().max()) <= 2 * tol * float(want.abs().max())
+
+
+@pytest.mark.parametrize('shape', [(96, 48, 6), (48, 96, 3), (91, 47, 6), (37, 95, 3)], ids=lambda s: 'x'.join(map(str, s)))
+@pytest.mark.parametrize('width', [(64, 64), (128, 256), (256, 256), (256, 128), (64, 128), (128, 64)], ids=lambda w: '%dto%d' % w)
+@pytest.mark.parametrize('with_addend', [False, True], ids=['plain', 'addend'])
+def test_fused_inference_block_matches_staged_path(shape, width, with_addend, dev):
+    """Eval-mode bf16 mp_conv_residual(64, 64) as ONE kernel (csrc/mpconv_block_fwd.hip) against the same block
+    run stage by stage (streaming GEMM, affine+activation, operator kernel, ...), non-trivial BatchNorm running
+    statistics; both round every intermediate to bf16, the fused one skips the HBM round trips."""
+    from fgnn_amd import _hip
+    from fgnn_amd.mpnn import blocks, mp_conv_residual, mp_conv_type
+    N, M, k = shape
+    nin, nout = width
+    B = 9
+    g = torch.Generator().manual_seed(N + 3 * M + nin)
+    blk = mp_conv_residual(nin, 64, 4, extension=mp_conv_type.NO_EXTENSION, with_residual=False, aggregator='max',
+                           nout=nout)
+    with torch.no_grad():
+        for bn in (blk.conv1[1], blk.mp_conv.bn, blk.conv2[1]):
+            C = bn.num_features
+            bn.running_mean.copy_(torch.randn(C, generator=g) * 0.1)
+            bn.running_var.copy_(torch.rand(C, generator=g) + 0.5)
+            bn.weight.copy_(torch.rand(C, generator=g) + 0.5)
+            bn.bias.copy_(torch.randn(C, generator=g) * 0.2)
+        blk.mp_conv.filters.copy_(torch.randn(64, 256, generator=g) * 0.1)
+    blk = blk.to(dev).eval()
+    x = torch.randn(B, N, 1, nin, generator=g).bfloat16().to(dev).permute(0, 3, 1, 2)
+    idx = torch.randint(0, N, (B, M, k), generator=g).to(dev)
+    et = torch.randn(B, M, k, 4, generator=g).bfloat16().to(dev).permute(0, 3, 1, 2)
+    add = torch.randn(B, M, 1, nout, generator=g).bfloat16().to(dev).permute(0, 3, 1, 2) if with_addend else None
+    with torch.no_grad():
+        y = blk(x, idx, et, addend=add)
+        assert 'mpconv_block_fwd' in _hip.lib().fgnn_last_kernel().decode()
+        blocks.FUSE_EVAL_BLOCKS = False
+        try:
+            ref = blk(x, idx, et, addend=add)
+        finally:
+            blocks.FUSE_EVAL_BLOCKS = True
+    assert y.shape == ref.shape and y.dtype == torch.bfloat16
+    err = float((y.float() - ref.float()).abs().max() / ref.float().abs().max())
+    assert err <= 2.0 ** -5, err
