@@ -260,3 +260,31 @@ def test_fused_inference_block_matches_staged_path(shape, width, with_addend, de
     assert y.shape == ref.shape and y.dtype == torch.bfloat16
     err = float((y.float() - ref.float()).abs().max() / ref.float().abs().max())
     assert err <= 2.0 ** -5, err
+
+
+def test_ldpc_model_bf16_inference_fused_blocks_vs_staged(dev):
+    """Whole LDPCModel, eval mode, bf16 autocast: the run that takes the one-kernel residual blocks against the
+    same model with them disabled (every stage a separate kernel).  Both are bf16 pipelines that round at
+    different points, so they are compared in the mean over a batch, not bit for bit."""
+    import fgnn_amd
+    from fgnn_amd.ldpc import synthetic_batch
+    from fgnn_amd.mpnn import blocks
+    torch.manual_seed(3)
+    m = fgnn_amd.LDPCModel(2, 6, 4, aggregator='max').to(dev)
+    data = synthetic_batch(64, dev, seed=11, dtype=torch.bfloat16)
+    m.train()
+    with torch.no_grad(), torch.autocast(device_type='cuda', dtype=torch.bfloat16):
+        for _ in range(3):
+            m(*data[:6])                                # populate the BatchNorm running statistics
+    m.eval()
+    with torch.no_grad(), torch.autocast(device_type='cuda', dtype=torch.bfloat16):
+        a, sa = m(*data[:6])
+        blocks.FUSE_EVAL_BLOCKS = False
+        try:
+            b, sb = m(*data[:6])
+        finally:
+            blocks.FUSE_EVAL_BLOCKS = True
+    a, b = a.float(), b.float()
+    assert torch.isfinite(a).all()
+    assert float((a - b).abs().mean()) <= 0.03 * float(b.abs().mean()) + 1e-3
+    assert float((sa.float() - sb.float()).abs().mean()) <= 0.03 * float(sb.float().abs().mean()) + 1e-3
