@@ -210,7 +210,7 @@ __global__ __launch_bounds__(WB_THREADS) void linear_wgrad_b16_narrow_kernel(con
     const int rw = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, lk = lane >> 4;
     const int R = p.R, Cin = p.Cin, Cout = p.Cout;
-    const int Cn = NARROW_X ? Cin : Cout, Cw = NARROW_X ? Cout : Cin;      // Cw == 64
+    const int Cn = NARROW_X ? Cin : Cout, Cw = NARROW_X ? Cout : Cin;      // Cw: row stride of the wide operand (64 channels used)
     const uint16_t* wide = (NARROW_X ? p.gy : p.x) + 4 * li;
     const uint16_t* nar = (NARROW_X ? p.x : p.gy) + li;
     const bool nar_ok = li < Cn;
@@ -289,9 +289,10 @@ __global__ __launch_bounds__(WB_THREADS) void linear_wgrad_b16_narrow_kernel(con
     }
 }
 
+// woff: first channel of the wide operand's 64-channel group this launch covered
 template <bool NARROW_X>
 __global__ __launch_bounds__(256) void wgn_reduce_kernel(const float* __restrict__ ws, int nslab, int Cin, int Cout,
-                                                         float* __restrict__ gW, float* __restrict__ gb) {
+                                                         int woff, float* __restrict__ gW, float* __restrict__ gb) {
     __shared__ float part[16][17];
     const int e = threadIdx.x & 15, g = threadIdx.x >> 4;
     const int slab_len = WN_NACC * 64;
@@ -310,18 +311,18 @@ __global__ __launch_bounds__(256) void wgn_reduce_kernel(const float* __restrict
     const int l = i & 63, q = i >> 6, li = l & 15, lk = l >> 4;
     if (q < 16) {
         const int r = q & 3, t = q >> 2, row = 4 * lk + r;
-        const int o = NARROW_X ? 4 * row + t : row, c = NARROW_X ? li : 4 * li + t;
+        const int o = NARROW_X ? woff + 4 * row + t : row, c = NARROW_X ? li : woff + 4 * li + t;
         if (o < Cout && c < Cin) gW[(int64_t)o * Cin + c] += s;
     } else if (gb && lk == 0) {
         const int t = q - 16;
-        if (NARROW_X) gb[4 * li + t] += s;
-        else if (t == 0 && li < Cout) gb[li] += s;
+        if (NARROW_X) gb[woff + 4 * li + t] += s;
+        else if (t == 0 && li < Cout && woff == 0) gb[li] += s;      // the narrow side's bias: once
     }
 }
 
 static bool wn_plan(int64_t R, int Cin, int Cout, bool* narrow_x, int* gx) {
-    if (Cin <= 16 && Cout == 64) *narrow_x = true;
-    else if (Cout <= 16 && Cin == 64) *narrow_x = false;
+    if (Cin <= 16 && Cout % 64 == 0 && Cout <= 256) *narrow_x = true;          // wide side: 64-channel groups, one launch each
+    else if (Cout <= 16 && Cin % 64 == 0 && Cin <= 256) *narrow_x = false;
     else return false;
     const int64_t nblk = (R + 31) / 32;
     int64_t g = (nblk + 2 * WB_WAVES - 1) / (2 * WB_WAVES);
@@ -368,12 +369,17 @@ int fgnn_linear_wgrad_b16(const void* x, const void* gy, int64_t R, int Cin, int
         p.R = (int)R; p.Cin = Cin; p.Cout = Cout; p.nso = 1; p.S = 1; p.RW = WB_WAVES;
         const int lds = (WB_WAVES / 2) * WN_NACC * 64 * 4;
         hipStream_t st = (hipStream_t)stream;
-        if (nx) {
-            hipLaunchKernelGGL(linear_wgrad_b16_narrow_kernel<true>, dim3(gx), dim3(WB_THREADS), lds, st, p);
-            hipLaunchKernelGGL(wgn_reduce_kernel<true>, dim3(WN_NACC * 4), dim3(256), 0, st, p.ws, gx, Cin, Cout, gW, gb);
-        } else {
-            hipLaunchKernelGGL(linear_wgrad_b16_narrow_kernel<false>, dim3(gx), dim3(WB_THREADS), lds, st, p);
-            hipLaunchKernelGGL(wgn_reduce_kernel<false>, dim3(WN_NACC * 4), dim3(256), 0, st, p.ws, gx, Cin, Cout, gW, gb);
+        const int wide_c = nx ? Cout : Cin;
+        for (int woff = 0; woff < wide_c; woff += 64) {     // the kernel reads 64 channels from the pointer, rows at the full stride
+            if (nx) {
+                p.gy = (const uint16_t*)gy + woff;
+                hipLaunchKernelGGL(linear_wgrad_b16_narrow_kernel<true>, dim3(gx), dim3(WB_THREADS), lds, st, p);
+                hipLaunchKernelGGL(wgn_reduce_kernel<true>, dim3(WN_NACC * 4), dim3(256), 0, st, p.ws, gx, Cin, Cout, woff, gW, gb);
+            } else {
+                p.x = (const uint16_t*)x + woff;
+                hipLaunchKernelGGL(linear_wgrad_b16_narrow_kernel<false>, dim3(gx), dim3(WB_THREADS), lds, st, p);
+                hipLaunchKernelGGL(wgn_reduce_kernel<false>, dim3(WN_NACC * 4), dim3(256), 0, st, p.ws, gx, Cin, Cout, woff, gW, gb);
+            }
         }
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "linear_wgrad_b16 narrow launch: %s", hipGetErrorString(e));

@@ -294,7 +294,7 @@ def test_hyper_edge_backward_vs_routed_reference(shape, layout, dtype, dev):
 
 
 @pytest.mark.parametrize('cin,cout', [(64, 64), (2, 64), (7, 64), (96, 64), (64, 256), (256, 64), (256, 256),
-                                      (128, 1), (64, 4), (100, 12)])
+                                      (128, 1), (64, 4), (100, 12), (7, 128), (256, 3)])
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 def test_pointwise_conv_gradients_vs_torch(cin, cout, dtype, dev):
     """PointwiseConv2d (GEMM forward, hand-written split-rows weight-gradient kernel) against
