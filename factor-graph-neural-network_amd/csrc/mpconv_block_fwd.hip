@@ -315,3 +315,146 @@ extern "C" int fgnn_mpconv_block_forward(const fgnn_mpconv_desc* d, const void* 
     if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "mpconv_block_forward launch: %s", hipGetErrorString(e));
     return FGNN_OK;
 }
+
+// ========================================================================================
+// The same block around the hyper-factor FAN-OUT call (one source node feeding M destinations through k = 1
+// edges, single edge type: /root/reference/train_ldpc.py:60-75): per sample the sources are ONE nin-vector, so
+// conv1 and the projection are two matrix-vector products (lane <-> channel, weights in LDS), the operator is
+// z[m,o] = etype[m] * P[o], and only conv2 is GEMM-shaped: its B fragments (8 consecutive channels of a2 for one
+// destination) are built in registers from P, so a2 never exists in memory.  One wave per sample, no barriers.
+// ========================================================================================
+struct KfParams {
+    fgnn_mpconv_desc d;
+    const uint16_t* x;   // [B][nin]
+    const uint16_t* et;  // [B][M] (strides from d)
+    const float* W1;     // [64][nin]
+    const float* s1; const float* t1;
+    const float* F;      // [64][64]
+    const float* s2; const float* t2;
+    const float* W2;     // [nout][64]
+    const float* s3; const float* t3;
+    const uint16_t* addend;
+    uint16_t* y;         // [B][M][nout]
+    float slope;
+    int nin, nout, Mpad;
+};
+
+template <int NI>
+__global__ __launch_bounds__(512) void mpconv_block_fanout_kernel(const KfParams p) {
+    constexpr int NIN = 64 * NI;
+    const fgnn_mpconv_desc& d = p.d;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lk = lane >> 4;
+    const int nout = p.nout, M = d.M;
+    float* W1t = reinterpret_cast<float*>(fgnn_lds_kb);                    // [NIN][64]: W1t[c][o] = W1[o][c]
+    float* Fl = W1t + NIN * 64;                                            // [64][64] as in memory: F[o][o2]
+    uint16_t* W2l = reinterpret_cast<uint16_t*>(Fl + 64 * 64);             // [nout][XSB] bf16
+    float* pw = reinterpret_cast<float*>(W2l + nout * KB_XSB) + wave * 128; // per wave: s2*P [64], t2 [64]
+    for (int f = tid; f < NIN * 64; f += 512) { const int o = f / NIN, c = f - o * NIN; W1t[c * 64 + o] = p.W1[f]; }
+    for (int f = tid; f < 64 * 64; f += 512) Fl[f] = p.F[f];
+    for (int f = tid; f < nout * 32; f += 512) {
+        const int q = f >> 5, c2 = f & 31;
+        const float2 w = *reinterpret_cast<const float2*>(p.W2 + q * 64 + 2 * c2);
+        *reinterpret_cast<unsigned*>(W2l + q * KB_XSB + 2 * c2) = kb_pack2(w.x, w.y);
+    }
+    __syncthreads();
+    const float c1s = p.s1[lane], c1t = p.t1[lane], c2s = p.s2[lane], c2t = p.t2[lane];
+    const int mtile = p.Mpad / 16, qtile = nout / 16;
+    const int nwaves = gridDim.x * 8;
+    for (int b = blockIdx.x * 8 + wave; b < d.B; b += nwaves) {
+        float xv[NI];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) xv[i] = __uint_as_float((unsigned)p.x[(int64_t)b * d.x_sb + lane + 64 * i] << 16);
+        // conv1 + BN1 + LeakyReLU (lane <-> channel o), rounded to bf16 like the staged path's a1
+        float a1 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll 8
+            for (int c = 0; c < 64; ++c)
+                a1 = fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(xv[i]), c)), W1t[(64 * i + c) * 64 + lane], a1);
+        a1 = fmaf(a1, c1s, c1t);
+        a1 = a1 > 0.f ? a1 : a1 * p.slope;
+        { const __bf16 h = (__bf16)a1; a1 = __uint_as_float((unsigned)__builtin_bit_cast(uint16_t, h) << 16); }
+        // projection (lane <-> o2), bf16-rounded like the P of mpconv_fwd_hyper.hip
+        float P = 0.f;
+#pragma unroll 8
+        for (int o = 0; o < 64; ++o) P = fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(a1), o)), Fl[o * 64 + lane], P);
+        { const __bf16 h = (__bf16)P; P = __uint_as_float((unsigned)__builtin_bit_cast(uint16_t, h) << 16); }
+        pw[lane] = c2s * P;                             // a2[m][o2] = ReLU(et[m] * (s2 P)[o2] + t2[o2])
+        pw[64 + lane] = c2t;
+        const uint16_t* eb = p.et + (int64_t)b * d.et_sb;
+        uint16_t* yb = p.y + (int64_t)b * M * nout;
+        const uint16_t* adb = p.addend ? p.addend + (int64_t)b * M * nout : nullptr;
+        for (int mt = 0; mt < mtile; ++mt) {
+            const int m = mt * 16 + li;
+            const float e = m < M ? __uint_as_float((unsigned)eb[(int64_t)m * d.et_sm] << 16) : 0.f;
+            kb_bf16x8 bf[2];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const f32x4 p0 = *reinterpret_cast<const f32x4*>(pw + 32 * ks + 8 * lk), p1 = *reinterpret_cast<const f32x4*>(pw + 32 * ks + 8 * lk + 4);
+                const f32x4 t0 = *reinterpret_cast<const f32x4*>(pw + 64 + 32 * ks + 8 * lk), t1 = *reinterpret_cast<const f32x4*>(pw + 64 + 32 * ks + 8 * lk + 4);
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { v[u] = fmaxf(fmaf(e, p0[u], t0[u]), 0.f); v[4 + u] = fmaxf(fmaf(e, p1[u], t1[u]), 0.f); }
+                bf[ks] = __builtin_bit_cast(kb_bf16x8, make_uint4(kb_pack2(v[0], v[1]), kb_pack2(v[2], v[3]), kb_pack2(v[4], v[5]), kb_pack2(v[6], v[7])));
+            }
+            for (int q = 0; q < qtile; ++q) {
+                const uint16_t* wr = W2l + (q * 16 + li) * KB_XSB + 8 * lk;
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(kb_bf16x8, *reinterpret_cast<const uint4*>(wr)), bf[0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(kb_bf16x8, *reinterpret_cast<const uint4*>(wr + 32)), bf[1], acc, 0, 0, 0);
+                if (m < M) {
+                    const f32x4 s3 = *reinterpret_cast<const f32x4*>(p.s3 + q * 16 + 4 * lk), t3 = *reinterpret_cast<const f32x4*>(p.t3 + q * 16 + 4 * lk);
+                    float v[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { const float u = fmaf(acc[r], s3[r], t3[r]); v[r] = u > 0.f ? u : u * p.slope; }
+                    const int64_t off = (int64_t)m * nout + q * 16 + 4 * lk;
+                    if (adb) {
+                        const uint2 a = *reinterpret_cast<const uint2*>(adb + off);
+                        v[0] += __uint_as_float(a.x << 16); v[1] += __uint_as_float(a.x & 0xffff0000u);
+                        v[2] += __uint_as_float(a.y << 16); v[3] += __uint_as_float(a.y & 0xffff0000u);
+                    }
+                    *reinterpret_cast<uint2*>(yb + off) = make_uint2(kb_pack2(v[0], v[1]), kb_pack2(v[2], v[3]));
+                }
+            }
+        }
+    }
+}
+
+// Fan-out form of fgnn_mpconv_block_forward: d describes the inner operator with N = 1, k = 1, net = 1, nin = nou = 64
+// (x strides: the block's input [B, nin]; y: [B, M, nout]); F is [64][64].
+extern "C" int fgnn_mpconv_block_forward_fanout(const fgnn_mpconv_desc* d, const void* x, const void* etype,
+                                                const float* W1, const float* s1, const float* t1, const float* filters,
+                                                const float* s2, const float* t2, const float* W2, const float* s3,
+                                                const float* t3, float slope, int nin, int nout, const void* addend,
+                                                void* y, fgnn_stream_t stream) {
+    if (!d || !x || !etype || !W1 || !s1 || !t1 || !filters || !s2 || !t2 || !W2 || !s3 || !t3 || !y)
+        FGNN_FAIL(FGNN_EINVAL, "mpconv_block_forward_fanout: null pointer");
+    const bool ok = d->dtype == FGNN_BF16 && d->ext == FGNN_EXT_NONE && d->net == 1 && d->nin == 64 && d->nou == 64 &&
+                    d->N == 1 && d->k == 1 && d->M >= 1 && d->M <= 256 &&
+                    (nin == 64 || nin == 128 || nin == 256) && (nout == 64 || nout == 128 || nout == 256) &&
+                    d->x_sc == 1 && d->y_sc == 1 && d->y_sm == nout && d->y_sb == (int64_t)d->M * nout &&
+                    !((uintptr_t)y & 7) && !((uintptr_t)addend & 7);
+    if (!ok) FGNN_FAIL(FGNN_EUNSUPPORTED, "mpconv_block_forward_fanout: outside the fused block's family");
+    if (d->B == 0) return FGNN_OK;
+    KfParams p;
+    p.d = *d;
+    p.x = (const uint16_t*)x; p.et = (const uint16_t*)etype; p.W1 = W1; p.s1 = s1; p.t1 = t1; p.F = filters;
+    p.s2 = s2; p.t2 = t2; p.W2 = W2; p.s3 = s3; p.t3 = t3; p.addend = (const uint16_t*)addend; p.y = (uint16_t*)y;
+    p.slope = slope; p.nin = nin; p.nout = nout; p.Mpad = fgnn_round_up(d->M, 16);
+    const int lds = nin * 64 * 4 + 64 * 64 * 4 + nout * KB_XSB * 2 + 8 * 128 * 4;
+    void* fn = nin == 64 ? (void*)mpconv_block_fanout_kernel<1> : nin == 128 ? (void*)mpconv_block_fanout_kernel<2>
+                                                                             : (void*)mpconv_block_fanout_kernel<4>;
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "hipFuncSetAttribute(%d B LDS): %s", lds, hipGetErrorString(e));
+    }
+    int grid = (d->B + 7) / 8;
+    if (grid > 512) grid = 512;
+    fgnn_note_kernel("mpconv_block_fanout_kernel<%d>", nin / 64);
+    void* args[] = {(void*)&p};
+    hipError_t e = hipLaunchKernel(fn, dim3(grid), dim3(512), args, lds, (hipStream_t)stream);
+    if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "mpconv_block_forward_fanout launch: %s", hipGetErrorString(e));
+    return FGNN_OK;
+}

@@ -89,17 +89,20 @@ class mp_conv_residual(base_mp_nn):
         bn1, bn2, bn3 = self.conv1[1], mp.bn, self.conv2[1]
         if (not FUSE_EVAL_BLOCKS or self.with_residual or self.training or torch.is_grad_enabled() or not x.is_cuda
                 or x.dtype != torch.bfloat16 or x.shape[1] not in (64, 128, 256) or mp.nin != 64 or mp.nou != 64
-                or mp.nedge_types != 4 or mp.aggregtor != 'max' or mp.extension != mp_conv_type.NO_EXTENSION
+                or mp.nedge_types not in (1, 4) or mp.aggregtor != 'max' or mp.extension != mp_conv_type.NO_EXTENSION
                 or bn2 is None or mp.bias is None or not isinstance(mp.activation_fn, torch.nn.ReLU)
-                or self.conv2[0].out_channels not in (64, 128, 256) or nn_idx.shape[2] not in (3, 6)
+                or self.conv2[0].out_channels not in (64, 128, 256)
                 or not isinstance(bn1, BatchNormAct2d) or not isinstance(bn3, BatchNormAct2d)
                 or bn1.slope != bn3.slope or etype.dtype != torch.bfloat16):
             return None
         B, nin, N, _ = x.shape
         nout = self.conv2[0].out_channels
         M, k = nn_idx.shape[1:]
+        fanout = mp.nedge_types == 1 and N == 1 and k == 1          # the hyper-factor -> variables call
+        if not fanout and not (mp.nedge_types == 4 and k in (3, 6)):
+            return None
         xr = x.permute(0, 2, 3, 1)
-        et = etype.permute(0, 2, 3, 1)                                   # [B, M, k, 4]
+        et = etype.permute(0, 2, 3, 1)                                   # [B, M, k, net]
         if not xr.is_contiguous() or not (et.is_contiguous() or (etype.stride(0) == 0 and et[0].is_contiguous())):
             return None
         if addend is not None:
@@ -124,9 +127,17 @@ class mp_conv_residual(base_mp_nn):
             self._fuse_key = key
         W1, s1, t1, F, s2, t2, W2, s3, t3 = self._fuse
         y = torch.empty((B, M, 1, nout), device=x.device, dtype=x.dtype).permute(0, 3, 1, 2)
-        d = _hip.make_desc(x, nn_idx, etype, 64, 4, _hip.EXT_NONE, _hip.AGG_MAX, True, y)
+        d = _hip.make_desc(x, nn_idx, etype, 64, mp.nedge_types, _hip.EXT_NONE, _hip.AGG_MAX, True, y)
         d.nin = 64                      # the inner operator's width; x / y strides stay the block's
         P = _hip._ptr
+        if fanout:
+            rc = _hip.lib().fgnn_mpconv_block_forward_fanout(ctypes.byref(d), P(x), P(etype), P(W1), P(s1), P(t1), P(F),
+                                                             P(s2), P(t2), P(W2), P(s3), P(t3), float(bn1.slope), nin, nout,
+                                                             P(addend), P(y), _hip.stream_ptr())
+            if rc == _hip.EUNSUPPORTED:
+                return None
+            _hip.check(rc)
+            return y
         rc = _hip.lib().fgnn_mpconv_block_forward(ctypes.byref(d), P(x), P(nn_idx), P(etype), P(W1), P(s1), P(t1), P(F),
                                                   P(s2), P(t2), P(W2), P(s3), P(t3), float(bn1.slope), nin, nout, P(addend),
                                                   P(y),

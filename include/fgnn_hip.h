@@ -169,6 +169,13 @@ int fgnn_mpconv_block_forward(const fgnn_mpconv_desc* d, const void* x, const in
                               float slope, int32_t nin, int32_t nout, const void* addend, void* y,
                               fgnn_stream_t stream);
 
+/* The same block around the hyper-factor FAN-OUT call: inner operator with N = 1 source, k = 1, one edge type
+ * (filters [64][64]); x is the block's input [B, nin], y its output [B, M, nout]. */
+int fgnn_mpconv_block_forward_fanout(const fgnn_mpconv_desc* d, const void* x, const void* etype, const float* W1,
+                                     const float* s1, const float* t1, const float* filters, const float* s2,
+                                     const float* t2, const float* W2, const float* s3, const float* t3, float slope,
+                                     int32_t nin, int32_t nout, const void* addend, void* y, fgnn_stream_t stream);
+
 /*
  * out = inputs[0] + ... + inputs[n-1] (n <= 8) over dense arrays of `numel` elements in one pass — the gradient of
  * a state that fans out into several consumers (factor_mpnn_sp.py:139-170) instead of autograd's pairwise adds.

@@ -288,3 +288,41 @@ def test_ldpc_model_bf16_inference_fused_blocks_vs_staged(dev):
     assert torch.isfinite(a).all()
     assert float((a - b).abs().mean()) <= 0.03 * float(b.abs().mean()) + 1e-3
     assert float((sa.float() - sb.float()).abs().mean()) <= 0.03 * float(sb.float().abs().mean()) + 1e-3
+
+
+@pytest.mark.parametrize('width', [(64, 64), (128, 256), (256, 256), (256, 128)], ids=lambda w: '%dto%d' % w)
+@pytest.mark.parametrize('M', [96, 37])
+@pytest.mark.parametrize('with_addend', [False, True], ids=['plain', 'addend'])
+def test_fused_inference_fanout_block_matches_staged_path(width, M, with_addend, dev):
+    """The one-kernel inference block around the hyper-factor fan-out call (one source, M destinations, k = 1, one
+    edge type) against the staged path."""
+    from fgnn_amd import _hip
+    from fgnn_amd.mpnn import blocks, mp_conv_residual, mp_conv_type
+    nin, nout = width
+    B = 21
+    g = torch.Generator().manual_seed(M + nin)
+    blk = mp_conv_residual(nin, 64, 1, extension=mp_conv_type.NO_EXTENSION, with_residual=False, aggregator='max',
+                           nout=nout)
+    with torch.no_grad():
+        for bn in (blk.conv1[1], blk.mp_conv.bn, blk.conv2[1]):
+            C = bn.num_features
+            bn.running_mean.copy_(torch.randn(C, generator=g) * 0.1)
+            bn.running_var.copy_(torch.rand(C, generator=g) + 0.5)
+            bn.weight.copy_(torch.rand(C, generator=g) + 0.5)
+            bn.bias.copy_(torch.randn(C, generator=g) * 0.2)
+        blk.mp_conv.filters.copy_(torch.randn(64, 64, generator=g) * 0.2)
+    blk = blk.to(dev).eval()
+    x = torch.randn(B, 1, 1, nin, generator=g).bfloat16().to(dev).permute(0, 3, 1, 2)
+    idx = torch.zeros(B, M, 1, dtype=torch.int64, device=dev)
+    et = (torch.rand(B, M, 1, 1, generator=g) + 0.5).bfloat16().to(dev).permute(0, 3, 1, 2)
+    add = torch.randn(B, M, 1, nout, generator=g).bfloat16().to(dev).permute(0, 3, 1, 2) if with_addend else None
+    with torch.no_grad():
+        y = blk(x, idx, et, addend=add)
+        assert 'mpconv_block_fanout' in _hip.lib().fgnn_last_kernel().decode()
+        blocks.FUSE_EVAL_BLOCKS = False
+        try:
+            ref = blk(x, idx, et, addend=add)
+        finally:
+            blocks.FUSE_EVAL_BLOCKS = True
+    err = float((y.float() - ref.float()).abs().max() / ref.float().abs().max())
+    assert err <= 2.0 ** -5, err
