@@ -10,15 +10,14 @@ import numpy as np
 import torch
 
 from .mpnn.assemblies import FactorNN
-from .mpnn.pointwise import PointwiseConv2d
+from .edge_mlp import EdgeMLP
 from .tables import LdpcGraph
 
 MESSAGES_PER_CODEWORD = 8 * (288 + 288 + 96 + 96)
 
 
 def _edge_mlp(cin, hidden, cout):
-    return torch.nn.Sequential(PointwiseConv2d(cin, hidden, 1), torch.nn.ReLU(),
-                               PointwiseConv2d(hidden, cout, 1))
+    return EdgeMLP(cin, hidden, cout)
 
 
 class LDPCModel(torch.nn.Module):

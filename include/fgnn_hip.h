@@ -182,6 +182,24 @@ int fgnn_mpconv_block_forward_fanout(const fgnn_mpconv_desc* d, const void* x, c
  */
 int fgnn_sum_n(const void* const* inputs, int32_t n, int64_t numel, int32_t dtype, void* out, fgnn_stream_t stream);
 
+/*
+ * The edge-type MLP in front of the operator, etype = W2 ReLU(W1 efeature + b1) + b2 with Cin <= 8 -> 64 -> net <= 4
+ * (`emodel_f2v / emodel_v2f`, /root/reference/train_ldpc.py:32-38,68-69), without the 64-channel hidden tensor ever
+ * reaching memory.  x is bf16 with element (b, c, r) at b*x_sb + c*x_sc + r*x_sr (r one of the E = M*k edge rows of
+ * sample b); y is [B][E][net] bf16 (edge-type-fastest, what the operator kernels read); parameters are f32.  The
+ * backward recomputes the hidden units and ACCUMULATES the parameter gradients (any may be NULL); gy element (b, e, r)
+ * sits at b*gy_sb + e*gy_se + r*gy_sr so either layout of the operator's getype is read in place.  Edge features
+ * take no gradient.
+ */
+int fgnn_edge_mlp_forward(const void* x, int64_t x_sb, int64_t x_sc, int64_t x_sr, const float* W1, const float* b1,
+                          const float* W2, const float* b2, void* y, int64_t B, int32_t E, int32_t Cin, int32_t net,
+                          fgnn_stream_t stream);
+int64_t fgnn_edge_mlp_workspace_bytes(int64_t B, int32_t E);
+int fgnn_edge_mlp_backward(const void* x, int64_t x_sb, int64_t x_sc, int64_t x_sr, const void* gy, int64_t gy_sb,
+                           int64_t gy_se, int64_t gy_sr, const float* W1, const float* b1, const float* W2, int64_t B, int32_t E, int32_t Cin, int32_t net, float* gW1,
+                           float* gb1, float* gW2, float* gb2, void* workspace, int64_t workspace_bytes,
+                           fgnn_stream_t stream);
+
 const char* fgnn_last_error(void);
 /* Name (as rocprofv3 prints it) of the kernel the calling thread's last forward/backward dispatched to. */
 const char* fgnn_last_kernel(void);

@@ -326,3 +326,52 @@ def test_fused_inference_fanout_block_matches_staged_path(width, M, with_addend,
             blocks.FUSE_EVAL_BLOCKS = True
     err = float((y.float() - ref.float()).abs().max() / ref.float().abs().max())
     assert err <= 2.0 ** -5, err
+
+
+@pytest.mark.parametrize('shape', [(5, 7, 96, 3, 4), (3, 7, 48, 6, 4), (2, 5, 7, 2, 3), (4, 8, 1, 96, 1), (70, 7, 96, 3, 4)])
+@pytest.mark.parametrize('layout', ['nchw', 'channels_last'])
+@pytest.mark.parametrize('glayout', ['edge_major', 'type_major'])
+def test_fused_edge_mlp_matches_fp32_reference(shape, layout, glayout, dev):
+    """emodel_f2v / emodel_v2f (train_ldpc.py:32-38) as one forward kernel + one recomputing backward: output within
+    bf16 rounding of the fp32 MLP on the same bf16 inputs, parameter gradients within 1e-4 (f32 accumulation) of
+    autograd's on the fp32 MLP — for either memory layout of the inputs and of the incoming gradient."""
+    import fgnn_amd
+    from fgnn_amd import _hip
+    from fgnn_amd.edge_mlp import EdgeMLP
+    B, cin, M, k, net = shape
+    g = torch.Generator().manual_seed(B * 131 + cin)
+    mlp = EdgeMLP(cin, 64, net).to(dev)
+    x = torch.randn(B, cin, M, k, generator=g).to(dev).bfloat16()
+    if layout == 'channels_last':
+        x = x.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+    gy = torch.randn(B, net, M, k, generator=g).to(dev).bfloat16()
+    if glayout == 'type_major':
+        gy = gy.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+    y = mlp(x)
+    assert _hip.lib().fgnn_last_kernel().decode() == 'edge_mlp_fwd_kernel'
+    assert y.shape == (B, net, M, k) and y.permute(0, 2, 3, 1).is_contiguous()
+    y.backward(gy)
+    got = [p.grad.clone() for p in mlp.parameters()]
+    # fp32 reference of the same three ops
+    w1, b1, w2, b2 = [p.detach().clone().requires_grad_(True) for p in mlp.parameters()]
+    xr = x.float().permute(0, 2, 3, 1).reshape(-1, cin)
+    yr = torch.relu(xr @ w1.view(64, cin).t() + b1) @ w2.view(net, 64).t() + b2
+    yr4 = yr.view(B, M, k, net).permute(0, 3, 1, 2)
+    assert (y.float() - yr4).abs().max().item() <= 2.0 ** -8 * max(1.0, yr4.abs().max().item())
+    yr4.backward(gy.float())
+    for a, r in zip(got, (w1, b1, w2, b2)):
+        assert H.rel_err(a.view(-1), r.grad.view(-1)) <= 1e-4
+    # a second backward accumulates into the existing .grad in place
+    mlp(x).backward(gy)
+    for a, p in zip(got, mlp.parameters()):
+        assert H.rel_err(p.grad.view(-1), 2 * a.view(-1)) <= 1e-5
+
+
+def test_edge_mlp_keeps_reference_state_dict_and_staged_fallback(dev):
+    from fgnn_amd.edge_mlp import EdgeMLP
+    mlp = EdgeMLP(7, 64, 4).to(dev)
+    assert list(mlp.state_dict().keys()) == ['0.weight', '0.bias', '2.weight', '2.bias']
+    x = torch.randn(3, 7, 96, 3, device=dev)
+    y32 = mlp(x)                                        # f32 inputs: the three children as written
+    y16 = mlp(x.bfloat16())
+    assert H.rel_err(y16.float(), y32) <= 2e-2
