@@ -172,28 +172,35 @@ class FactorNN(torch.nn.Module):
     def forward(self, node_feature, hop_features, nn_idx_f2v, nn_idx_v2f, etype_f2v, etype_v2f):
         var = self.node_mapping_module(node_feature)
         fac = [m(f) for f, m in zip(hop_features, self.factor_mapping_modules)]
-        history = []
         from ..ops import add_n, fan_out
         nft = self.nfactor_types
-        for L in range(len(self.v2f_modules)):
+        nL = len(self.v2f_modules)
+        # the edge types feed every layer: one alias per layer, so their gradients meet in one n-way sum
+        etype_f2v = [fan_out(e, nL) for e in etype_f2v]
+        etype_v2f = [fan_out(e, nL) for e in etype_v2f]
+        skip_src = set(self.skip_link.values())
+        history = {}
+        for L in range(nL):
             same_width = self.dim_mapping_list[L] == self.dim_mapping_list[L + 1]
             res = 1 if same_width else 0
-            # every state feeds several consumers (v2v / f2f map, the message blocks, the residual): hand each its
-            # own alias so that the backward sums their gradients in one kernel (ops.fan_out)
-            var_c = fan_out(var, 1 + nft + res)
-            fac_c = [fan_out(f, 2 + res) for f in fac]
+            keep = 1 if (L - 1) in skip_src else 0       # the incoming state is also a later layer's skip input
+            # every state feeds several consumers (v2v / f2f map, the message blocks, the residual, a skip link):
+            # hand each its own alias so that the backward sums their gradients in one kernel (ops.fan_out)
+            var_c = fan_out(var, 1 + nft + res + keep)
+            fac_c = [fan_out(f, 2 + res + keep) for f in fac]
+            if keep:
+                history[L - 1] = [var_c.pop(), [fc.pop() for fc in fac_c]]
             new_var = self.v2v_modules[L](var_c[0])
             new_fac = [m(fc[0]) for fc, m in zip(fac_c, self.f2f_modules[L])]
             for j in range(nft):
-                new_var = _call(self.f2v_modules[L][j], fac_c[j][1], nn_idx_f2v[j].long(), etype_f2v[j],
+                new_var = _call(self.f2v_modules[L][j], fac_c[j][1], nn_idx_f2v[j].long(), etype_f2v[j][L],
                                 addend=new_var)
-                new_fac[j] = _call(self.v2f_modules[L][j], var_c[1 + j], nn_idx_v2f[j].long(), etype_v2f[j],
+                new_fac[j] = _call(self.v2f_modules[L][j], var_c[1 + j], nn_idx_v2f[j].long(), etype_v2f[j][L],
                                    addend=new_fac[j])
             skip = history[self.skip_link[L]] if L in self.skip_link else None
             var = add_n([var_c[-1] if same_width else None, new_var, skip[0] if skip else None])
             fac = [add_n([fac_c[j][-1] if same_width else None, new_fac[j], skip[1][j] if skip else None])
                    for j in range(nft)]
-            history.append([var, fac])
         out = self.final_classifier(var)
         if self.final_filter is not None:
             out = self.final_filter(out, node_feature)

@@ -241,7 +241,9 @@ def _dense_same_layout(ts):
     if (t0.numel() * t0.element_size()) % 16 or t0.numel() == 0:
         return False
     dense = t0.is_contiguous() or (t0.dim() == 4 and t0.permute(0, 2, 3, 1).is_contiguous())
-    return dense and all(t.dtype == t0.dtype and t.shape == t0.shape and t.stride() == t0.stride() and
+    order = lambda t: tuple(st for st, n in zip(t.stride(), t.shape) if n > 1)      # strides of size-1 axes are moot
+    o0 = order(t0)
+    return dense and all(t.dtype == t0.dtype and t.shape == t0.shape and order(t) == o0 and
                          t.data_ptr() % 16 == 0 for t in ts)
 
 
@@ -268,11 +270,13 @@ class _FanOut(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, n):
+        ctx.set_materialize_grads(False)                 # an unused alias contributes nothing, not a zero tensor
         return tuple(x.view_as(x) for _ in range(n))
 
     @staticmethod
     def backward(ctx, *grads):
-        return sum_tensors([g for g in grads if g is not None]), None
+        grads = [g for g in grads if g is not None]
+        return (sum_tensors(grads) if grads else None), None
 
 
 class _SumN(torch.autograd.Function):
