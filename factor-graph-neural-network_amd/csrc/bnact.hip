@@ -27,7 +27,9 @@ struct BnParams {
     const float* gamma;
     const float* beta;
     const float* ref;          // per-channel shift K for the variance accumulation (row 0 of x), or NULL = 0
-    const void* addend;        // forward apply: y = act(...) + addend (same layout as y), or NULL
+    const void* addend;        // forward apply: y = act(...) + addend (+ addend2 + addend3), each y's layout or NULL
+    const void* addend2;
+    const void* addend3;
     int64_t R;
     int C, cshift;             // cshift = log2(C / EPC)
     int rows_per_wg;
@@ -236,11 +238,15 @@ __global__ __launch_bounds__(BN_THREADS) void bn_apply_kernel(const BnParams p) 
         if (MODE == 0) {
 #pragma unroll
             for (int e = 0; e < EPC; ++e) { const float pre = fmaf(v[e], ka[e], kb[e]); o[e] = pre > 0.f ? pre : pre * p.slope; }
-            if (p.addend) {
-                float ad[EPC];
-                Chunk<T>::load(static_cast<const T*>(p.addend) + r * p.C + c0, ad);
+            const void* const ads[3] = {p.addend, p.addend2, p.addend3};
 #pragma unroll
-                for (int e = 0; e < EPC; ++e) o[e] += ad[e];
+            for (int a = 0; a < 3; ++a) {
+                if (ads[a]) {
+                    float ad[EPC];
+                    Chunk<T>::load(static_cast<const T*>(ads[a]) + r * p.C + c0, ad);
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) o[e] += ad[e];
+                }
             }
         } else {
             float g[EPC];
@@ -327,14 +333,15 @@ extern "C" int fgnn_bn_finalize(const float* partials, int npartials, int64_t R,
     return FGNN_OK;
 }
 
-// y = act(x * scale + shift), act = LeakyReLU(slope) (slope 0: ReLU, slope 1: identity)
+// y = act(x * scale + shift) [+ addend + addend2 + addend3], act = LeakyReLU(slope) (slope 0: ReLU, slope 1: identity)
 extern "C" int fgnn_bn_apply(const void* x, void* y, int64_t R, int C, int dtype, const float* scale,
-                             const float* shift, float slope, const void* addend, fgnn_stream_t stream) {
+                             const float* shift, float slope, const void* addend, const void* addend2,
+                             const void* addend3, fgnn_stream_t stream) {
     BnParams p = {};
     int grid;
     if (!x || !y || !scale || !shift) FGNN_FAIL(FGNN_EINVAL, "bn_apply: null pointer");
     if (bn_plan(R, C, dtype, &p, &grid)) FGNN_FAIL(FGNN_EUNSUPPORTED, "bn: C=%d not a supported channel count", C);
-    p.x = x; p.out = y; p.a = scale; p.b = shift; p.slope = slope; p.addend = addend;
+    p.x = x; p.out = y; p.a = scale; p.b = shift; p.slope = slope; p.addend = addend; p.addend2 = addend2; p.addend3 = addend3;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == FGNN_F32) hipLaunchKernelGGL((bn_apply_kernel<float, 0>), dim3(grid), dim3(BN_THREADS), 0, st, p);
     else hipLaunchKernelGGL((bn_apply_kernel<bf16_t, 0>), dim3(grid), dim3(BN_THREADS), 0, st, p);

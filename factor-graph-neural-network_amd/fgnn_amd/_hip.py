@@ -100,7 +100,7 @@ def lib():
     L.fgnn_edge_mlp_backward.restype = ctypes.c_int
     L.fgnn_edge_mlp_backward.argtypes = [vp, i64, i64, i64, vp, i64, i64, i64, vp, vp, vp, i64, i32, i32, i32, vp, vp, vp, vp, vp, i64, vp]
     L.fgnn_bn_apply.restype = ctypes.c_int
-    L.fgnn_bn_apply.argtypes = [vp, vp, i64, i32, i32, vp, vp, f32, vp, vp]
+    L.fgnn_bn_apply.argtypes = [vp, vp, i64, i32, i32, vp, vp, f32, vp, vp, vp, vp]
     L.fgnn_bn_backward.restype = ctypes.c_int
     L.fgnn_bn_backward.argtypes = [vp, vp, vp, i64, i32, i32, vp, vp, vp, vp, f32, vp, vp, vp, i64, vp]
     L.fgnn_last_error.restype = ctypes.c_char_p

@@ -10,7 +10,7 @@ message inside runs through the fused HIP operator.
 import torch
 
 from .blocks import iid_mapping, iid_mapping_bn, iid_mapping_in, mp_conv_residual
-from .pointwise import NodeInstanceNorm, PointwiseConv2d as _Conv
+from .pointwise import NodeInstanceNorm, PointwiseConv2d as _Conv, add_all
 from .message_op import base_mp_nn, mp_conv_type, mp_conv_v2
 
 
@@ -21,7 +21,7 @@ def _call(module, x, nn_idx, etype, addend=None):
     if isinstance(module, (mp_conv_v2, mp_conv_residual)):
         return module(x, nn_idx, etype, addend=addend)
     y = module(x, nn_idx, etype) if isinstance(module, base_mp_nn) else module(x)
-    return y if addend is None else addend + y
+    return add_all(y, addend)
 
 
 class mp_sequential(base_mp_nn):
@@ -172,7 +172,7 @@ class FactorNN(torch.nn.Module):
     def forward(self, node_feature, hop_features, nn_idx_f2v, nn_idx_v2f, etype_f2v, etype_v2f):
         var = self.node_mapping_module(node_feature)
         fac = [m(f) for f, m in zip(hop_features, self.factor_mapping_modules)]
-        from ..ops import add_n, fan_out
+        from ..ops import fan_out
         nft = self.nfactor_types
         nL = len(self.v2f_modules)
         # the edge types feed every layer: one alias per layer, so their gradients meet in one n-way sum
@@ -192,15 +192,19 @@ class FactorNN(torch.nn.Module):
                 history[L - 1] = [var_c.pop(), [fc.pop() for fc in fac_c]]
             new_var = self.v2v_modules[L](var_c[0])
             new_fac = [m(fc[0]) for fc, m in zip(fac_c, self.f2f_modules[L])]
-            for j in range(nft):
-                new_var = _call(self.f2v_modules[L][j], fac_c[j][1], nn_idx_f2v[j].long(), etype_f2v[j][L],
-                                addend=new_var)
-                new_fac[j] = _call(self.v2f_modules[L][j], var_c[1 + j], nn_idx_v2f[j].long(), etype_v2f[j][L],
-                                   addend=new_fac[j])
+            # new state = node-wise map + every block's messages (+ old state when the width is kept) (+ skip link):
+            # the running sum, and on the last block of a chain the residual and skip terms too, are added by that
+            # block's closing BatchNorm+activation kernel
             skip = history[self.skip_link[L]] if L in self.skip_link else None
-            var = add_n([var_c[-1] if same_width else None, new_var, skip[0] if skip else None])
-            fac = [add_n([fac_c[j][-1] if same_width else None, new_fac[j], skip[1][j] if skip else None])
-                   for j in range(nft)]
+            for j in range(nft):
+                last = j == nft - 1
+                new_var = _call(self.f2v_modules[L][j], fac_c[j][1], nn_idx_f2v[j].long(), etype_f2v[j][L],
+                                addend=[new_var, var_c[-1] if same_width and last else None,
+                                        skip[0] if skip and last else None])
+                new_fac[j] = _call(self.v2f_modules[L][j], var_c[1 + j], nn_idx_v2f[j].long(), etype_v2f[j][L],
+                                   addend=[new_fac[j], fac_c[j][-1] if same_width else None,
+                                           skip[1][j] if skip else None])
+            var, fac = new_var, new_fac
         out = self.final_classifier(var)
         if self.final_filter is not None:
             out = self.final_filter(out, node_feature)

@@ -8,7 +8,8 @@ Mirrors (names, constructor signatures, state_dict keys) of
 import torch
 
 from .message_op import base_mp_nn, mp_conv_type, mp_conv_v2
-from .pointwise import BatchNormAct2d, NodeInstanceNorm, PointwiseConv2d
+from .. import ops
+from .pointwise import BatchNormAct2d, NodeInstanceNorm, PointwiseConv2d, as_addends
 
 
 def _conv_norm_act(cin, cout, norm, act, bias=True):
@@ -150,6 +151,10 @@ class mp_conv_residual(base_mp_nn):
     def forward(self, node_feature, nn_idx, etype, addend=None):
         """``addend`` (optional, the caller's running sum of the same shape as the output) is added by conv2's
         fused BatchNorm+activation kernel instead of a separate elementwise pass."""
+        if isinstance(addend, (list, tuple)):
+            addend = as_addends(addend)
+            if not (self.training and torch.is_grad_enabled()):          # the one-kernel block takes one addend
+                addend = ops.add_n(addend) if addend else None
         y = self._fused_eval(node_feature, nn_idx, etype, addend)
         if y is not None:
             return y

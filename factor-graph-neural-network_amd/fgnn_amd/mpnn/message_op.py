@@ -15,6 +15,7 @@ from enum import Enum
 import torch
 
 from .. import _hip, ops
+from .pointwise import add_all
 
 
 class mp_conv_type(Enum):       # mp_nn.py:7-10
@@ -84,8 +85,8 @@ class mp_conv_v2(base_mp_nn):
             self.nin, self.nou, self.nedge_types, self.extension.name, self.aggregtor)
 
     def forward(self, x, nn_idx, etype, addend=None):
-        """``addend``: optional tensor of the output's shape added after the activation (fused into the
-        BatchNorm kernel when training with the plain ReLU)."""
+        """``addend``: optional tensor of the output's shape (or a list of them) added after the activation (fused
+        into the BatchNorm kernel when training with the plain ReLU)."""
         ext, agg = _EXT_CODE[self.extension], _hip.AGG_CODES[self.aggregtor]
         needs_grad = torch.is_grad_enabled() and (
             x.requires_grad or etype.requires_grad or self.filters.requires_grad)
@@ -101,7 +102,7 @@ class mp_conv_v2(base_mp_nn):
                                           post_shift=shift, relu=plain_relu)
             if self.activation_fn is not None and not plain_relu:
                 y = self.activation_fn(y)
-            return y if addend is None else y + addend
+            return add_all(y, addend)
         z = ops.mpconv(x, nn_idx, etype, self.filters, self.bias, self.nou,
                        self.nedge_types, ext, agg)
         if self.bn is not None:
@@ -113,4 +114,4 @@ class mp_conv_v2(base_mp_nn):
             z = self.bn(z)
         if self.activation_fn is not None:
             z = self.activation_fn(z)
-        return z if addend is None else z + addend
+        return add_all(z, addend)

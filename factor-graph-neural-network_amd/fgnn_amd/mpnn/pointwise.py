@@ -239,11 +239,27 @@ class NodeInstanceNorm(torch.nn.Module):
         return torch.relu(y) if self.relu else y
 
 
+def as_addends(addend):
+    """``addend`` arguments are one tensor, None, or a list of tensors / Nones: the list of tensors."""
+    if addend is None:
+        return []
+    if isinstance(addend, (list, tuple)):
+        return [a for a in addend if a is not None]
+    return [addend]
+
+
+def add_all(y, addend):
+    for a in as_addends(addend):
+        y = y + a
+    return y
+
+
 class _BatchNormAct(torch.autograd.Function):
     """Train-mode BatchNorm + LeakyReLU(slope) on channel-fastest rows [R, C] (csrc/bnact.hip)."""
 
     @staticmethod
-    def forward(ctx, rows, weight, bias, running_mean, running_var, momentum, eps, slope, addend=None, nbt=None):
+    def forward(ctx, rows, weight, bias, running_mean, running_var, momentum, eps, slope, addend=None, nbt=None,
+                addend2=None, addend3=None):
         from .. import ops
         L = _hip.lib()
         R, C = rows.shape
@@ -265,11 +281,11 @@ class _BatchNormAct(torch.autograd.Function):
                           _hip._ptr(stats[2]), _hip._ptr(stats[3]), _hip._ptr(nbt), _hip._ptr(ws), ws.numel() * 4,
                           _hip.stream_ptr())))
         y = torch.empty_like(rows)
-        ops.timed('bn_apply (forward)', (3 if addend is not None else 2) * rows.numel() * rows.element_size(),
+        ctx.has_addend = tuple(a is not None for a in (addend, addend2, addend3))
+        ops.timed('bn_apply (forward)', (2 + sum(ctx.has_addend)) * rows.numel() * rows.element_size(),
                   lambda: _hip.check(L.fgnn_bn_apply(_hip._ptr(rows), _hip._ptr(y), R, C, dt, _hip._ptr(stats[2]),
                                                      _hip._ptr(stats[3]), slope, _hip._ptr(addend),
-                                                     _hip.stream_ptr())))
-        ctx.has_addend = addend is not None
+                                                     _hip._ptr(addend2), _hip._ptr(addend3), _hip.stream_ptr())))
         ctx.save_for_backward(rows, weight, bias, stats)
         ctx.slope = slope
         ctx.params = (weight, bias)
@@ -295,7 +311,8 @@ class _BatchNormAct(torch.autograd.Function):
                       _hip._ptr(stats[1]), _hip._ptr(weight), _hip._ptr(bias), ctx.slope, _hip._ptr(gw), _hip._ptr(gb),
                       _hip._ptr(ws), ws.numel() * 4, _hip.stream_ptr())))
         return (gx, None if gw_sink is not None else gw, None if gb_sink is not None else gb,
-                None, None, None, None, None, gy if ctx.has_addend else None, None)
+                None, None, None, None, None, gy if ctx.has_addend[0] else None, None,
+                gy if ctx.has_addend[1] else None, gy if ctx.has_addend[2] else None)
 
 
 class BatchNormAct2d(torch.nn.BatchNorm2d):
@@ -316,35 +333,40 @@ class BatchNormAct2d(torch.nn.BatchNorm2d):
         return torch.nn.functional.leaky_relu(y, self.slope)
 
     def forward(self, x, addend=None):
-        """``addend`` (same shape) is added AFTER the activation — the ``acc = acc + block(x)`` that follows
-        every block in FactorNN rides in the apply kernel instead of being a separate pass."""
+        """``addend`` (a tensor of the output's shape, or a list of up to three) is added AFTER the activation — the
+        ``acc + block(x) (+ residual + skip)`` that follows every block in FactorNN rides in the apply kernel
+        instead of being separate passes."""
         B, C, H, W = x.shape
+        addends = as_addends(addend)
+        if len(addends) > 3:
+            from ..ops import add_n
+            addends = addends[:2] + [add_n(addends[2:])]
         ok = (x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and self.track_running_stats and
               self.affine and _hip.lib().fgnn_bn_supported(B * H * W, C, _hip.dtype_code(x)))
         wants_grad = torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad or
-                                                  (addend is not None and addend.requires_grad))
+                                                  any(a.requires_grad for a in addends))
         if not ok or (not self.training and wants_grad):
-            y = self._activate(super().forward(x))
-            return y if addend is None else y + addend
+            return add_all(self._activate(super().forward(x)), addends)
         rows = x.permute(0, 2, 3, 1)
         if not rows.is_contiguous():
             rows = rows.contiguous()
         rows = rows.view(B * H * W, C)
-        arows = None
-        if addend is not None:
-            arows = addend.permute(0, 2, 3, 1)
-            if arows.dtype != rows.dtype or not arows.is_contiguous():
-                arows = arows.to(rows.dtype).contiguous()
-            arows = arows.view(B * H * W, C)
+        arows = [None, None, None]
+        for i, a in enumerate(addends):
+            ar = a.permute(0, 2, 3, 1)
+            if ar.dtype != rows.dtype or not ar.is_contiguous():
+                ar = ar.to(rows.dtype).contiguous()
+            arows[i] = ar.view(B * H * W, C)
         if self.training:                               # num_batches_tracked += 1 rides in the statistics finaliser
             y = _BatchNormAct.apply(rows, self.weight, self.bias, self.running_mean, self.running_var,
-                                    self.momentum, self.eps, self.slope, arows, self.num_batches_tracked)
+                                    self.momentum, self.eps, self.slope, arows[0], self.num_batches_tracked,
+                                    arows[1], arows[2])
         else:                                           # eval: folded affine + activation in one pass
             scale, shift = self._folded()
             y = torch.empty_like(rows)
             _hip.check(_hip.lib().fgnn_bn_apply(_hip._ptr(rows), _hip._ptr(y), B * H * W, C, _hip.dtype_code(rows),
-                                                _hip._ptr(scale), _hip._ptr(shift), self.slope, _hip._ptr(arows),
-                                                _hip.stream_ptr()))
+                                                _hip._ptr(scale), _hip._ptr(shift), self.slope, _hip._ptr(arows[0]),
+                                                _hip._ptr(arows[1]), _hip._ptr(arows[2]), _hip.stream_ptr()))
         return y.view(B, H, W, C).permute(0, 3, 1, 2)
 
     def _folded(self):

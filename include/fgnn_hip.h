@@ -146,8 +146,11 @@ int fgnn_bn_finalize(const float* partials, int32_t npartials, int64_t R, int32_
                      const float* beta, float* running_mean, float* running_var, float momentum, float eps,
                      float* mean, float* invstd, float* scale, float* shift, int64_t* num_batches_tracked,
                      fgnn_stream_t stream);
+/* y = act(x*scale + shift) + addend + addend2 + addend3: up to three tensors of y's layout (NULL = absent) ride in
+ * the apply pass — the `acc + block(x) + residual + skip` sums of factor_mpnn_sp.py:139-170. */
 int fgnn_bn_apply(const void* x, void* y, int64_t R, int32_t C, int32_t dtype, const float* scale,
-                  const float* shift, float slope, const void* addend, fgnn_stream_t stream);
+                  const float* shift, float slope, const void* addend, const void* addend2, const void* addend3,
+                  fgnn_stream_t stream);
 int fgnn_bn_backward(const void* x, const void* gy, void* gx, int64_t R, int32_t C, int32_t dtype,
                      const float* mean, const float* invstd, const float* gamma, const float* beta, float slope,
                      float* gweight, float* gbias, void* workspace, int64_t workspace_bytes,

@@ -375,3 +375,43 @@ def test_edge_mlp_keeps_reference_state_dict_and_staged_fallback(dev):
     y32 = mlp(x)                                        # f32 inputs: the three children as written
     y16 = mlp(x.bfloat16())
     assert H.rel_err(y16.float(), y32) <= 2e-2
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16], ids=['f32', 'bf16'])
+@pytest.mark.parametrize('nadd', [1, 2, 3, 4])
+@pytest.mark.parametrize('training', [True, False], ids=['train', 'eval'])
+def test_batchnorm_act_with_several_addends(dtype, nadd, training, dev):
+    """act(BN(x)) + a1 + a2 + a3 in the apply kernel (FactorNN's `messages + old state + skip link`,
+    factor_mpnn_sp.py:139-170) == torch's batch_norm + activation + explicit adds; each addend's gradient is the
+    output gradient."""
+    from fgnn_amd.mpnn.pointwise import BatchNormAct2d
+    g = torch.Generator().manual_seed(11 * nadd)
+    B, C, N = 6, 64, 96
+    bn = BatchNormAct2d(C, slope=0.01).to(dev).train(training)
+    ref = torch.nn.BatchNorm2d(C).to(dev).train(training)
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(C, generator=g) + 0.5); bn.bias.copy_(torch.randn(C, generator=g) * 0.1)
+        bn.running_mean.copy_(torch.randn(C, generator=g) * 0.1); bn.running_var.copy_(torch.rand(C, generator=g) + 0.5)
+    ref.load_state_dict(bn.state_dict())
+    cl = lambda t: t.to(dev).to(dtype).permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+    x = cl(torch.randn(B, C, N, 1, generator=g)).requires_grad_(training)
+    adds = [cl(torch.randn(B, C, N, 1, generator=g)).requires_grad_(training) for _ in range(nadd)]
+    if training:
+        y = bn(x, addend=adds)
+    else:
+        with torch.no_grad():
+            y = bn(x, addend=adds)
+    xr = x.detach().float().requires_grad_(training)
+    ar = [a.detach().float().requires_grad_(training) for a in adds]
+    yr = torch.nn.functional.leaky_relu(ref(xr), 0.01)
+    for a in ar:
+        yr = yr + a
+    tol = 1e-5 if dtype == torch.float32 else 2.0 ** -7
+    assert H.rel_err(y.float(), yr) <= tol
+    if training:
+        gy = cl(torch.randn(B, C, N, 1, generator=g))
+        y.backward(gy)
+        yr.backward(gy.float())
+        assert H.rel_err(x.grad.float(), xr.grad) <= (1e-4 if dtype == torch.float32 else 2.0 ** -6)
+        for a in adds:
+            assert torch.equal(a.grad, gy)
