@@ -46,6 +46,9 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--miopen-bn', action='store_true', help='let torch route BatchNorm to MIOpen')
     ap.add_argument('--no-graph', action='store_true', help='launch every kernel from Python instead of replaying a hipGraph')
+    ap.add_argument('--inputs', choices=['channel', 'features'], default='channel',
+                    help='channel: encoded codewords through the reference channel (fgnn_amd/datapath.py); '
+                         'features: random bits + unit-gain AWGN built with torch ops (ldpc.synthetic_batch)')
     ap.add_argument('--cpu-batch', type=int, default=512)
     ap.add_argument('--cpu-threads', type=int, default=16)
     return ap.parse_args()
@@ -145,7 +148,14 @@ def main():
     model = LDPCModel(2, 6, 4, aggregator='max').to(dev)
     broadcast_parameters(model)
     _trace('parameters broadcast')
-    data = synthetic_batch(args.batch, dev, seed=100 + rank, dtype=dtype)
+    if args.inputs == 'channel':
+        # the GPU data path (fgnn_amd/datapath.py): random messages, the reference's G encode, its AWGN + burst
+        # channel at 0..4 dB, features gathered on the device — generated once, resident before the timed region
+        from fgnn_amd.datapath import LdpcDataPath
+        data = LdpcDataPath(dev).sample(args.batch, seed=100 + rank, dtype=dtype)
+        data = data[:6] + (data[6][:, :48].float().contiguous(), data[7])
+    else:
+        data = synthetic_batch(args.batch, dev, seed=100 + rank, dtype=dtype)
     inputs, label, sigma_b = data[:6], data[6], data[7]
     train = args.mode == 'train'
     model.train(train)
@@ -274,6 +284,8 @@ def main():
                                    % ('training (fwd+bwd+grad all-reduce+Adam)' if train else
                                       'inference forward', args.batch),
                        'global_batch': args.batch * world, 'parallelism': 'dp%d' % world,
+                       'inputs': ('random messages -> reference G encode -> AWGN+burst channel, on the GPU'
+                                  if args.inputs == 'channel' else 'random bits + AWGN (torch ops)'),
                        'mode': args.mode, 'hip_graph': graphed is not None},
             'roofline': roofline,
             'kernels': {k: {'launches': v['launches'], 'avg_us': round(v['ms'] / v['launches'] * 1e3, 2),

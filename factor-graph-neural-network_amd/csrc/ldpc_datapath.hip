@@ -1,0 +1,135 @@
+// ldpc_datapath.hip — the LDPC data path in front of the decoder model, on the GPU:
+//
+//   encode            codeword = [s | G s mod 2]        `s2t(s, 48, 48, Gfile, smn=True)`,
+//                                                        /root/reference/lib/data/MNC/MNC_py.cpp:22-83
+//   channel           y = 2 gcx (t - 1/2) + z1 (+ gcx sigma_b z2 where u < rho),  gcx = 10^(snr_db/20)
+//                                                        `t2y`, MNC_py.cpp:86-102
+//   model inputs      node / hop / edge features gathered from y along the code's incidence lists
+//                                                        lib/data/ldpc_dataset.py:92-106,222-236
+//
+// The reference does this per codeword on the host (a pybind11 call per item, numpy takes, a DataLoader); at
+// B = 4096 codewords per step per GPU that is the input bottleneck.  Here a batch is two launches of byte / gather
+// work, written once, coalesced, in the storage dtype the model kernels read.  The random draws (z1, u, z2) are
+// inputs: the transform is deterministic and is checked bit-for-bit (encode) / to f32 rounding (channel) against
+// the oracle.
+#include "fgnn_common.h"
+#include <stdint.h>
+
+#define LD_THREADS 256
+#define LD_CW_PER_WG 64
+
+// gmask[r] = row r of G packed over the K (<= 64) message bits: parity bit r = popcount(gmask[r] & s) & 1
+__global__ __launch_bounds__(LD_THREADS) void ldpc_encode_kernel(const uint8_t* __restrict__ s,
+                                                                 const unsigned long long* __restrict__ gmask,
+                                                                 int64_t B, int K, int P, uint8_t* __restrict__ cw) {
+    __shared__ unsigned long long msg[LD_CW_PER_WG];
+    __shared__ unsigned long long gm[64];
+    const int64_t b0 = (int64_t)blockIdx.x * LD_CW_PER_WG;
+    const int tid = threadIdx.x;
+    if (tid < LD_CW_PER_WG) {
+        unsigned long long m = 0;
+        if (b0 + tid < B) {
+            const uint8_t* sp = s + (b0 + tid) * K;
+            for (int c = 0; c < K; ++c) m |= (unsigned long long)(sp[c] & 1) << c;
+        }
+        msg[tid] = m;
+    } else if (tid - LD_CW_PER_WG < P) {
+        gm[tid - LD_CW_PER_WG] = gmask[tid - LD_CW_PER_WG];
+    }
+    __syncthreads();
+    const int N = K + P;
+    const int64_t nb = B - b0 < LD_CW_PER_WG ? B - b0 : LD_CW_PER_WG;
+    for (int o = tid; o < nb * N; o += LD_THREADS) {
+        const int w = o / N, n = o - w * N;
+        const unsigned long long m = msg[w];
+        const unsigned bit = n < K ? (unsigned)((m >> n) & 1ull) : (unsigned)(__popcll(m & gm[n - K]) & 1);
+        cw[b0 * N + o] = (uint8_t)bit;
+    }
+}
+
+struct LdFeatParams {
+    const uint8_t* cw;           // [B][nvar]
+    const float *snr_db, *sigma_b, *z1, *u, *z2;
+    const int* var_to_factors;   // [nvar][dv]   (nn_idx_f2v)
+    const int* factor_to_vars;   // [nchk][dc]   (nn_idx_v2f)
+    float* y;                    // [B][nvar] f32
+    void *node, *hop, *ef_f2v, *ef_v2f;
+    float rho;
+    int nvar, nchk, dv, dc;
+};
+
+// One workgroup per codeword: y into LDS, then every output array is written by flat index (coalesced).
+template <typename T>
+__global__ __launch_bounds__(LD_THREADS) void ldpc_features_kernel(const LdFeatParams p) {
+    __shared__ float ys[1024];
+    const int64_t b = blockIdx.x;
+    const int tid = threadIdx.x, nvar = p.nvar, nchk = p.nchk, dv = p.dv, dc = p.dc;
+    const float snr = p.snr_db[b], sb = p.sigma_b[b];
+    const float gcx = exp2f(snr * 0.16609640474436813f);          // 10^(snr/20) = 2^(snr log2(10)/20)
+    for (int n = tid; n < nvar; n += LD_THREADS) {
+        const int64_t i = b * nvar + n;
+        float v = 2.f * gcx * ((float)p.cw[i] - 0.5f) + p.z1[i];
+        if (sb >= 1e-20f && p.u[i] < p.rho) v += gcx * sb * p.z2[i];
+        ys[n] = v;
+        p.y[i] = v;
+    }
+    __syncthreads();
+    T* node = static_cast<T*>(p.node) + b * 2 * nvar;                       // [2][nvar]
+    for (int o = tid; o < 2 * nvar; o += LD_THREADS) fgnn_st(node + o, o < nvar ? ys[o] : snr);
+    T* hop = static_cast<T*>(p.hop) + b * dc * nchk;                        // [dc][nchk] = hop^T
+    for (int o = tid; o < dc * nchk; o += LD_THREADS) {
+        const int j = o / nchk, f = o - j * nchk;
+        fgnn_st(hop + o, ys[p.factor_to_vars[f * dc + j]]);
+    }
+    T* e1 = static_cast<T*>(p.ef_f2v) + b * (int64_t)(dc + 1) * nvar * dv;  // [dc+1][nvar][dv]
+    for (int o = tid; o < (dc + 1) * nvar * dv; o += LD_THREADS) {
+        const int c = o / (nvar * dv), r = o - c * nvar * dv, n = r / dv, j = r - n * dv;
+        const float v = c < dc ? ys[p.factor_to_vars[p.var_to_factors[n * dv + j] * dc + c]] : ys[n];
+        fgnn_st(e1 + o, v);
+    }
+    T* e2 = static_cast<T*>(p.ef_v2f) + b * (int64_t)(dc + 1) * nchk * dc;  // [dc+1][nchk][dc]
+    for (int o = tid; o < (dc + 1) * nchk * dc; o += LD_THREADS) {
+        const int c = o / (nchk * dc), r = o - c * nchk * dc, f = r / dc, j = r - f * dc;
+        fgnn_st(e2 + o, ys[p.factor_to_vars[f * dc + (c < dc ? c : j)]]);
+    }
+}
+
+// cw [B][K+P] (bytes 0/1) = [s | G s]; s [B][K] bytes, gmask [P] 64-bit rows of G over the K <= 64 message bits.
+extern "C" int fgnn_ldpc_encode(const uint8_t* s, const uint64_t* gmask, int64_t B, int K, int P, uint8_t* cw,
+                                fgnn_stream_t stream) {
+    if (B < 0 || K < 1 || K > 64 || P < 0 || P > 64) FGNN_FAIL(FGNN_EUNSUPPORTED, "ldpc_encode: K=%d P=%d (each <= 64)", K, P);
+    if (B == 0) return FGNN_OK;
+    if (!s || !gmask || !cw) FGNN_FAIL(FGNN_EINVAL, "ldpc_encode: null pointer");
+    const int64_t grid = (B + LD_CW_PER_WG - 1) / LD_CW_PER_WG;
+    fgnn_note_kernel("ldpc_encode_kernel");
+    hipLaunchKernelGGL(ldpc_encode_kernel, dim3((unsigned)grid), dim3(LD_THREADS), 0, (hipStream_t)stream, s,
+                       (const unsigned long long*)gmask, B, K, P, cw);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "ldpc_encode launch: %s", hipGetErrorString(e));
+    return FGNN_OK;
+}
+
+// Received words and the model's inputs for B codewords of a (nvar, nchk) code with dv checks per variable and dc
+// variables per check: y [B][nvar] f32; node [B][2][nvar], hop [B][dc][nchk], ef_f2v [B][dc+1][nvar][dv],
+// ef_v2f [B][dc+1][nchk][dc] in `dtype` (FGNN_F32 / FGNN_BF16).
+extern "C" int fgnn_ldpc_channel_features(const uint8_t* cw, const float* snr_db, const float* sigma_b, float rho,
+                                          const float* z1, const float* u, const float* z2,
+                                          const int32_t* var_to_factors, const int32_t* factor_to_vars, int64_t B,
+                                          int nvar, int nchk, int dv, int dc, int dtype, float* y, void* node,
+                                          void* hop, void* ef_f2v, void* ef_v2f, fgnn_stream_t stream) {
+    if (B < 0 || nvar < 1 || nvar > 1024 || nchk < 1 || dv < 1 || dc < 1 || (dtype != FGNN_F32 && dtype != FGNN_BF16))
+        FGNN_FAIL(FGNN_EUNSUPPORTED, "ldpc_channel_features: nvar=%d (<= 1024) nchk=%d dv=%d dc=%d dtype=%d", nvar, nchk, dv,
+                  dc, dtype);
+    if (B == 0) return FGNN_OK;
+    if (!cw || !snr_db || !sigma_b || !z1 || !u || !z2 || !var_to_factors || !factor_to_vars || !y || !node || !hop ||
+        !ef_f2v || !ef_v2f)
+        FGNN_FAIL(FGNN_EINVAL, "ldpc_channel_features: null pointer");
+    LdFeatParams p = {cw, snr_db, sigma_b, z1, u, z2, var_to_factors, factor_to_vars, y, node, hop, ef_f2v, ef_v2f,
+                      rho, nvar, nchk, dv, dc};
+    fgnn_note_kernel("ldpc_features_kernel");
+    if (dtype == FGNN_F32) hipLaunchKernelGGL(ldpc_features_kernel<float>, dim3((unsigned)B), dim3(LD_THREADS), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(ldpc_features_kernel<bf16_t>, dim3((unsigned)B), dim3(LD_THREADS), 0, (hipStream_t)stream, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "ldpc_channel_features launch: %s", hipGetErrorString(e));
+    return FGNN_OK;
+}

@@ -203,6 +203,26 @@ int fgnn_edge_mlp_backward(const void* x, int64_t x_sb, int64_t x_sc, int64_t x_
                            float* gb1, float* gW2, float* gb2, void* workspace, int64_t workspace_bytes,
                            fgnn_stream_t stream);
 
+/*
+ * The LDPC data path in front of the decoder (the reference's only native code, lib/data/MNC, plus the numpy feature
+ * construction of lib/data/ldpc_dataset.py:92-106,222-236), per batch instead of per codeword:
+ *   fgnn_ldpc_encode            cw [B][K+P] = [s | G s mod 2] for messages s [B][K] (bytes 0/1) — what
+ *                               `s2t(s, K, P, Gfile, smn=True)` returns (MNC_py.cpp:22-83); gmask[r] is row r of G
+ *                               packed over the K <= 64 message bits.
+ *   fgnn_ldpc_channel_features  `t2y` (MNC_py.cpp:86-102) with its random draws as inputs (z1, z2 ~ N(0,1), u ~ U[0,1)):
+ *                               y = 2 gcx (cw - 1/2) + z1, plus gcx sigma_b z2 where sigma_b >= 1e-20 and u < rho,
+ *                               gcx = 10^(snr_db/20); then the model inputs gathered from y along the incidence lists
+ *                               var_to_factors [nvar][dv] / factor_to_vars [nchk][dc]: node [B][2][nvar] (y, snr_db),
+ *                               hop [B][dc][nchk], ef_f2v [B][dc+1][nvar][dv], ef_v2f [B][dc+1][nchk][dc] in `dtype`.
+ */
+int fgnn_ldpc_encode(const uint8_t* s, const uint64_t* gmask, int64_t B, int32_t K, int32_t P, uint8_t* cw,
+                     fgnn_stream_t stream);
+int fgnn_ldpc_channel_features(const uint8_t* cw, const float* snr_db, const float* sigma_b, float rho, const float* z1,
+                               const float* u, const float* z2, const int32_t* var_to_factors,
+                               const int32_t* factor_to_vars, int64_t B, int32_t nvar, int32_t nchk, int32_t dv,
+                               int32_t dc, int32_t dtype, float* y, void* node, void* hop, void* ef_f2v, void* ef_v2f,
+                               fgnn_stream_t stream);
+
 const char* fgnn_last_error(void);
 /* Name (as rocprofv3 prints it) of the kernel the calling thread's last forward/backward dispatched to. */
 const char* fgnn_last_kernel(void);

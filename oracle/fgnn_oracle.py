@@ -328,3 +328,33 @@ def fixed_pw_hop_net(sd, x, nn_idx, etype, *, net=16, training=False):
             return h
         h = torch.relu(batch_norm(h, sd, '%d.' % (i + 2), training))
         i += 4
+
+
+# --------------------------------------------------------------------------
+# §8f rank 4: the LDPC data path in front of the model (numpy)
+# --------------------------------------------------------------------------
+def ldpc_encode(G, s):
+    """Systematic encode of K-bit messages s [..., K] with the (N x K) GF(2) matrix G: [s | G s mod 2] — what
+    `s2t(s, 48, 48, Gfile, smn=True)` returns per message (/root/reference/lib/data/MNC/MNC_py.cpp:22-83,
+    `mod2mat_multiply`, radford/mod2mat.cpp:353).  Pinned against the reference's own compiled code by
+    oracle/make_ldpc_datapath_golden.py (tests/golden/ldpc_datapath.npz)."""
+    import numpy as np
+    G = np.asarray(G, np.int64)
+    s = np.asarray(s, np.int64)
+    t = (s @ G.T) % 2
+    return np.concatenate([s, t], axis=-1).astype(np.uint8)
+
+
+def ldpc_channel(t, snr_db, sigma_b, rho, z1, u, z2):
+    """`t2y` (/root/reference/lib/data/MNC/MNC_py.cpp:86-102) with the random draws made explicit:
+    gcx = 10^(snr_db/20);  y = 2 gcx (t - 0.5) + z1;  where sigma_b >= 1e-20 and u < rho: y += gcx sigma_b z2.
+    t [B,N] bits, snr_db / sigma_b [B], z1 / z2 ~ N(0,1), u ~ U[0,1) of t's shape.  float64 like the reference
+    (`T` = double when called from Python).  PARITY UNPINNED for the RNG stream itself (xtensor's generator is
+    not reproducible here) — the arithmetic above is what is checked."""
+    import numpy as np
+    t = np.asarray(t, np.float64)
+    gcx = np.power(10.0, np.asarray(snr_db, np.float64) / 20.0)[:, None]
+    sb = np.asarray(sigma_b, np.float64)[:, None]
+    y = 2.0 * gcx * (t - 0.5) + z1
+    burst = (sb >= 1e-20) & (np.asarray(u) < rho)
+    return y + np.where(burst, gcx * sb * np.asarray(z2), 0.0)

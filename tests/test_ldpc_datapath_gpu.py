@@ -1,0 +1,90 @@
+"""GPU: csrc/ldpc_datapath.hip (encode + channel + model inputs for a whole batch) through the C ABI against the
+oracle and the reference-generated vectors — bit-exact for the GF(2) work, f32 rounding for the channel, exact
+copies for the gathered features."""
+import numpy as np
+import pytest
+import torch
+
+import fgnn_oracle as O
+import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def path(dev):
+    from fgnn_amd.datapath import LdpcDataPath
+    return LdpcDataPath(dev)
+
+
+def test_encode_matches_reference_vectors(path):
+    from fgnn_amd import _hip
+    z = H.load('ldpc_datapath.npz')
+    cw = path.encode(torch.from_numpy(z['s']))
+    assert _hip.lib().fgnn_last_kernel().decode() == 'ldpc_encode_kernel'
+    assert cw.dtype == torch.uint8 and np.array_equal(cw.cpu().numpy(), z['codewords'])
+
+
+@pytest.mark.parametrize('B', [1, 63, 64, 65, 4096, 50001])
+def test_encode_bit_exact_vs_oracle_and_parity_checks(B, path):
+    z = H.load('ldpc_datapath.npz')
+    s = np.random.default_rng(B).integers(0, 2, (B, 48)).astype(np.uint8)
+    cw = path.encode(torch.from_numpy(s)).cpu().numpy()
+    assert np.array_equal(cw, O.ldpc_encode(z['G'], s))
+    # size-independent property: zero syndrome under the parity-check matrix the reference pairs with its G (A2)
+    assert not ((cw.astype(np.int64) @ z['H_A2'].T.astype(np.int64)) % 2).any()
+
+
+def test_encode_rejects_bad_shapes(path):
+    with pytest.raises(ValueError):
+        path.encode(torch.zeros(4, 47, dtype=torch.uint8))
+    assert path.encode(torch.zeros(0, 48, dtype=torch.uint8)).shape == (0, 96)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16], ids=['f32', 'bf16'])
+def test_channel_and_features_match_oracle(dtype, path):
+    from fgnn_amd.tables import LdpcGraph
+    z = H.load('ldpc_datapath.npz')
+    t = lambda k: torch.from_numpy(z[k])
+    y, node, hop, e1, e2 = path.channel_features(t('codewords'), t('snr_db'), t('sigma_b'), 0.05,
+                                                 noise=(t('z1'), t('u'), t('z2')), dtype=dtype)
+    assert y.dtype == torch.float32 and node.dtype == dtype
+    # channel: float64 reference arithmetic vs f32 on the device
+    assert np.abs(y.cpu().numpy() - z['y']).max() <= 4e-6 * np.abs(z['y']).max()
+    # model inputs: pure gathers of the device's own y (ldpc_dataset.py:92-106,222-236), rounded once to `dtype`
+    g = LdpcGraph()
+    yh = y.cpu().numpy()
+    for b in range(64):
+        ref = g.features(yh[b], z['snr_db'][b])
+        for got, want in zip((node[b], hop[b], e1[b], e2[b]), ref):
+            assert torch.equal(got.cpu(), torch.from_numpy(want).to(dtype))
+
+
+def test_channel_without_noise_is_bpsk_at_the_snr_gain(path):
+    z = H.load('ldpc_datapath.npz')
+    B = 64
+    zero = torch.zeros(B, 96)
+    y = path.channel_features(torch.from_numpy(z['codewords']), torch.from_numpy(z['snr_db']), torch.zeros(B), 0.05,
+                              noise=(zero, zero, zero))[0].cpu().numpy()
+    gcx = 10.0 ** (z['snr_db'] / 20.0)
+    assert np.allclose(y, (2.0 * z['codewords'] - 1.0) * gcx[:, None], rtol=2e-6)
+
+
+def test_sample_is_a_training_batch_the_model_accepts(path, dev):
+    import fgnn_amd
+    a = path.sample(256, seed=3, dtype=torch.bfloat16)
+    b = path.sample(256, seed=3, dtype=torch.bfloat16)
+    c = path.sample(256, seed=4, dtype=torch.bfloat16)
+    assert all(torch.equal(x, y) for x, y in zip(a, b)) and not torch.equal(a[6], c[6])
+    node, hop, i1, i2, e1, e2, label, sigma_b = a
+    assert node.shape == (256, 2, 96, 1) and hop.shape == (256, 6, 48, 1) and e1.shape == (256, 7, 96, 3)
+    assert e2.shape == (256, 7, 48, 6) and i1.shape == (256, 96, 3) and i2.shape == (256, 48, 6)
+    assert label.dtype == torch.int64 and label.shape == (256, 96) and set(label.unique().tolist()) <= {0, 1}
+    assert set(sigma_b.unique().tolist()) <= {0., 1., 2., 3., 4., 5.}
+    # received words lean towards their bits: sign(y) recovers most of the codeword at 0..4 dB
+    agree = ((node[:, 0, :, 0].float() > 0).long() == label).float().mean().item()
+    assert 0.80 < agree < 1.0
+    m = fgnn_amd.LDPCModel(2, 6, 4).to(dev).eval()
+    with torch.no_grad(), torch.autocast('cuda', dtype=torch.bfloat16):
+        logits, snr = m(node, hop, i1, i2, e1, e2)
+    assert logits.shape == (256, 48) and torch.isfinite(logits.float()).all()
