@@ -26,7 +26,7 @@ struct WgradParams {
     int Cip, Cop;        // Cin / Cout-chunk padded to 16
     int oc;              // output channels handled per grid.y slice
     int XS, GS;          // LDS row strides (floats), == 16 (mod 32)
-    int nslab;           // slabs per channel slice the workgroups of the vector kernel add into
+    int nslab;           // slabs per channel slice (one per workgroup)
     unsigned gmagic, xmagic, omagic;   // ceil(2^32 / chunks-per-row) for gy / x rows; ceil(2^32 / oc)
 };
 
@@ -99,14 +99,17 @@ __global__ __launch_bounds__(WG_THREADS) void linear_wgrad_kernel(const WgradPar
                 slab[(int64_t)(ot * 16 + 4 * lk + r) * p.Cip + ctile * 16 + li] = acc[t][r];
         }
     }
-    {
+    {   // fold the 256/oc per-thread partials of each bias column in a fixed order
         __syncthreads();
-        float* red = gs;
-        if (tid < p.Cop) red[tid] = 0.f;
+        float* red = gs;                              // WG_ROWS * GS >= WG_THREADS floats
+        red[tid] = bsum;
         __syncthreads();
-        atomicAdd(&red[tid % p.oc], bsum);
-        __syncthreads();
-        if (tid < p.Cop) slab[(int64_t)p.Cop * p.Cip + tid] = tid < oc ? red[tid] : 0.f;
+        if (tid < p.Cop) {
+            float s = 0.f;
+            if (tid < oc)
+                for (int j = tid; j < WG_THREADS; j += p.oc) s += red[j];
+            slab[(int64_t)p.Cop * p.Cip + tid] = s;
+        }
     }
 }
 
@@ -232,9 +235,8 @@ __global__ __launch_bounds__(WG_THREADS) void linear_wgrad_vec_kernel(const Wgra
         }
     }
     const int64_t slab_len = (int64_t)p.Cop * p.Cip + p.Cop;
-    // few slabs, many workgroups: workgroup w adds into slab w % nslab (zeroed by the host, 16 workgroups
-    // per address at most), so the second kernel sums 32 slabs instead of 512
-    float* slab = p.ws + ((int64_t)blockIdx.y * p.nslab + blockIdx.x % p.nslab) * slab_len;
+    // one slab per workgroup, plain stores; the reduce kernel sums them 16 groups wide in a fixed order
+    float* slab = p.ws + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * slab_len;
 #pragma unroll
     for (int t = 0; t < TMAX; ++t) {
         const int u = wave + WG_WAVES * t;
@@ -242,44 +244,49 @@ __global__ __launch_bounds__(WG_THREADS) void linear_wgrad_vec_kernel(const Wgra
             const int ot = u / nct, ctile = u - ot * nct;
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                atomicAdd(&slab[(int64_t)(ot * 16 + 4 * lk + r) * p.Cip + ctile * 16 + li], acc[t][r]);
+                slab[(int64_t)(ot * 16 + 4 * lk + r) * p.Cip + ctile * 16 + li] = acc[t][r];
         }
     }
-    {   // fold the 256/oc per-thread partials of each bias column
+    {   // fold the 256/oc per-thread partials of each bias column in a fixed order
         __syncthreads();
-        float* red = gs;
-        if (tid < p.Cop) red[tid] = 0.f;
+        float* red = gs;                              // WV_ROWS * GS >= WG_THREADS floats
+        red[tid] = bsum;
         __syncthreads();
-        atomicAdd(&red[bcol], bsum);
-        __syncthreads();
-        if (tid < p.oc) atomicAdd(&slab[(int64_t)p.Cop * p.Cip + tid], red[tid]);
+        if (tid < p.Cop) {
+            float s = 0.f;
+            if (tid < p.oc)
+                for (int j = tid; j < WG_THREADS; j += p.oc) s += red[j];
+            slab[(int64_t)p.Cop * p.Cip + tid] = s;
+        }
     }
 }
 
-// out[o][c] += sum_w slab[w][o][c]; gb[o] += sum_w slab[w][bias o]
+// out[o][c] += sum_w slab[w][o][c]; gb[o] += sum_w slab[w][bias o].  16 elements x 16 slab groups per workgroup:
+// group g sums slabs g, g+16, ..., the 16 group sums fold through LDS in a fixed order (deterministic, no atomics).
 __global__ __launch_bounds__(256) void linear_wgrad_reduce_kernel(const float* __restrict__ ws, int nslab_x,
                                                                   int Cin, int Cout, int Cip, int Cop, int oc,
                                                                   float* __restrict__ gW, float* __restrict__ gb) {
+    __shared__ float part[16][17];
     const int64_t slab_len = (int64_t)Cop * Cip + Cop;
     const int slice = blockIdx.y;                      // channel slice
-    const int i = blockIdx.x * 256 + threadIdx.x;      // element of the slice's slab
-    if (i >= slab_len) return;
-    const float* base = ws + (int64_t)slice * nslab_x * slab_len + i;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int w = 0;
-    for (; w + 4 <= nslab_x; w += 4) {
-        s0 += base[(int64_t)w * slab_len];
-        s1 += base[(int64_t)(w + 1) * slab_len];
-        s2 += base[(int64_t)(w + 2) * slab_len];
-        s3 += base[(int64_t)(w + 3) * slab_len];
+    const int e = threadIdx.x & 15, g = threadIdx.x >> 4;
+    const int64_t i = (int64_t)blockIdx.x * 16 + e;    // element of the slice's slab
+    float s = 0.f;
+    if (i < slab_len) {
+        const float* base = ws + (int64_t)slice * nslab_x * slab_len + i;
+        for (int w = g; w < nslab_x; w += 16) s += base[(int64_t)w * slab_len];
     }
-    for (; w < nslab_x; ++w) s0 += base[(int64_t)w * slab_len];
-    const float s = (s0 + s1) + (s2 + s3);
+    part[g][e] = s;
+    __syncthreads();
+    if (g != 0 || i >= slab_len) return;
+    s = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) s += part[q][e];
     if (i < (int64_t)Cop * Cip) {
-        const int ol = i / Cip, c = i - ol * Cip, o = slice * oc + ol;
+        const int ol = (int)(i / Cip), c = (int)(i - (int64_t)ol * Cip), o = slice * oc + ol;
         if (ol < oc && o < Cout && c < Cin) gW[(int64_t)o * Cin + c] += s;
     } else if (gb) {
-        const int ol = i - Cop * Cip, o = slice * oc + ol;
+        const int ol = (int)(i - (int64_t)Cop * Cip), o = slice * oc + ol;
         if (ol < oc && o < Cout) gb[o] += s;
     }
 }
@@ -362,11 +369,7 @@ extern "C" int fgnn_linear_wgrad(const void* x, const void* gy, int64_t R, int C
                                               (void*)linear_wgrad_vec_kernel<T, 16, 10>)
         fn = dtype == FGNN_F32 ? WV_PICK(float) : WV_PICK(bf16_t);
 #undef WV_PICK
-        p.nslab = gx < WV_NSLAB ? gx : WV_NSLAB;
-        nslab_x = p.nslab;
-        const int64_t slab_len0 = (int64_t)p.Cop * p.Cip + p.Cop;
-        hipError_t em = hipMemsetAsync(p.ws, 0, (size_t)gyn * p.nslab * slab_len0 * 4, (hipStream_t)stream);
-        if (em != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "linear_wgrad memset: %s", hipGetErrorString(em));
+        p.nslab = gx;                                  // one slab per workgroup: plain stores, no atomics
     } else {
         p.nslab = gx;
         fn = dtype == FGNN_F32 ? (void*)linear_wgrad_kernel<float> : (void*)linear_wgrad_kernel<bf16_t>;
@@ -379,7 +382,7 @@ extern "C" int fgnn_linear_wgrad(const void* x, const void* gy, int64_t R, int C
     hipError_t e = hipLaunchKernel(fn, dim3(gx, gyn), dim3(WG_THREADS), args, lds, (hipStream_t)stream);
     if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "linear_wgrad launch: %s", hipGetErrorString(e));
     const int64_t slab_len = (int64_t)p.Cop * p.Cip + p.Cop;
-    hipLaunchKernelGGL(linear_wgrad_reduce_kernel, dim3((unsigned)((slab_len + 255) / 256), gyn), dim3(256), 0,
+    hipLaunchKernelGGL(linear_wgrad_reduce_kernel, dim3((unsigned)((slab_len + 15) / 16), gyn), dim3(256), 0,
                        (hipStream_t)stream, p.ws, nslab_x, Cin, Cout, p.Cip, p.Cop, p.oc, gW, gb);
     e = hipGetLastError();
     if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "linear_wgrad reduce launch: %s", hipGetErrorString(e));

@@ -7,6 +7,8 @@ Same constructor signatures, ``forward`` signatures and state_dict keys as
 so the reference's train_*.py scripts construct and call them unchanged; every VF/FV
 message inside runs through the fused HIP operator.
 """
+import contextlib
+
 import torch
 
 from .blocks import iid_mapping, iid_mapping_bn, iid_mapping_in, mp_conv_residual
@@ -173,6 +175,7 @@ class FactorNN(torch.nn.Module):
         var = self.node_mapping_module(node_feature)
         fac = [m(f) for f, m in zip(hop_features, self.factor_mapping_modules)]
         from ..ops import fan_out
+        from .. import ops as _ops
         nft = self.nfactor_types
         nL = len(self.v2f_modules)
         # the edge types feed every layer: one alias per layer, so their gradients meet in one n-way sum
@@ -190,20 +193,31 @@ class FactorNN(torch.nn.Module):
             fac_c = [fan_out(f, 2 + res + keep) for f in fac]
             if keep:
                 history[L - 1] = [var_c.pop(), [fc.pop() for fc in fac_c]]
-            new_var = self.v2v_modules[L](var_c[0])
-            new_fac = [m(fc[0]) for fc, m in zip(fac_c, self.f2f_modules[L])]
-            # new state = node-wise map + every block's messages (+ old state when the width is kept) (+ skip link):
-            # the running sum, and on the last block of a chain the residual and skip terms too, are added by that
-            # block's closing BatchNorm+activation kernel
             skip = history[self.skip_link[L]] if L in self.skip_link else None
-            for j in range(nft):
-                last = j == nft - 1
-                new_var = _call(self.f2v_modules[L][j], fac_c[j][1], nn_idx_f2v[j].long(), etype_f2v[j][L],
-                                addend=[new_var, var_c[-1] if same_width and last else None,
-                                        skip[0] if skip and last else None])
-                new_fac[j] = _call(self.v2f_modules[L][j], var_c[1 + j], nn_idx_v2f[j].long(), etype_v2f[j][L],
-                                   addend=[new_fac[j], fac_c[j][-1] if same_width else None,
-                                           skip[1][j] if skip else None])
+            # new state = node-wise map + every block's messages (+ old state when the width is kept) (+ skip link);
+            # the running sum, residual and skip terms are added by the closing BatchNorm+activation kernel of the
+            # last block of each chain.  The chains of the factor types beyond the first (the hyper-factor: ~200 short
+            # launches per layer) touch only their own state and the shared variables, so they are issued on a side
+            # stream and overlap the parity-check chain; their messages to the variables (h) join as extra addends.
+            two = _ops.SIDE_STREAM and nft > 1 and var.is_cuda
+            new_fac, h = [None] * nft, []
+            if two:
+                main, side = torch.cuda.current_stream(var.device), _ops.side_stream(var.device)
+                side.wait_stream(main)
+            for j in range(1, nft):
+                with (torch.cuda.stream(side) if two else contextlib.nullcontext()):
+                    nf = self.f2f_modules[L][j](fac_c[j][0])
+                    new_fac[j] = _call(self.v2f_modules[L][j], var_c[1 + j], nn_idx_v2f[j].long(), etype_v2f[j][L],
+                                       addend=[nf, fac_c[j][-1] if same_width else None, skip[1][j] if skip else None])
+                    h.append(_call(self.f2v_modules[L][j], fac_c[j][1], nn_idx_f2v[j].long(), etype_f2v[j][L]))
+            new_var = self.v2v_modules[L](var_c[0])
+            nf = self.f2f_modules[L][0](fac_c[0][0])
+            new_fac[0] = _call(self.v2f_modules[L][0], var_c[1], nn_idx_v2f[0].long(), etype_v2f[0][L],
+                               addend=[nf, fac_c[0][-1] if same_width else None, skip[1][0] if skip else None])
+            if two:
+                main.wait_stream(side)
+            new_var = _call(self.f2v_modules[L][0], fac_c[0][1], nn_idx_f2v[0].long(), etype_f2v[0][L],
+                            addend=[new_var] + h + [var_c[-1] if same_width else None, skip[0] if skip else None])
             var, fac = new_var, new_fac
         out = self.final_classifier(var)
         if self.final_filter is not None:

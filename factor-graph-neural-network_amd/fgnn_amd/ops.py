@@ -163,13 +163,27 @@ _WS = {}
 
 
 def _workspace(device, nbytes):
-    """One grow-only scratch buffer per device for the backward's per-workgroup gradient slabs
-    (reused by every call on the stream; contents are undefined between calls)."""
-    buf = _WS.get(device)
+    """One grow-only scratch buffer per (device, stream) for the per-workgroup gradient slabs and statistics
+    partials (reused by every call on that stream; contents are undefined between calls).  Per stream because
+    FactorNN runs the hyper-factor branch of a layer on a side stream next to the parity-check branch."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    buf = _WS.get(key)
     if buf is None or buf.numel() * 4 < nbytes:
         buf = torch.empty((nbytes + 3) // 4, device=device, dtype=torch.float32)
-        _WS[device] = buf
+        _WS[key] = buf
     return buf
+
+
+_SIDE = {}
+SIDE_STREAM = True      # FactorNN: factor types beyond the first run on a second stream (captured as parallel graph branches)
+
+
+def side_stream(device):
+    """The second stream FactorNN issues its hyper-factor branch on (one per device, created on first use)."""
+    st = _SIDE.get(device)
+    if st is None:
+        st = _SIDE[device] = torch.cuda.Stream(device)
+    return st
 
 
 class _MPConv(torch.autograd.Function):

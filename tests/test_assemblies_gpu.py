@@ -415,3 +415,41 @@ def test_batchnorm_act_with_several_addends(dtype, nadd, training, dev):
         assert H.rel_err(x.grad.float(), xr.grad) <= (1e-4 if dtype == torch.float32 else 2.0 ** -6)
         for a in adds:
             assert torch.equal(a.grad, gy)
+
+
+@pytest.mark.parametrize('side_stream', [True, False], ids=['two_streams', 'one_stream'])
+def test_training_steps_are_bitwise_reproducible(side_stream, dev):
+    """No atomics anywhere on the path and every cross-stream hand-over ordered: two runs of the same three bf16
+    training steps (same seed, same data) end in bit-identical parameters — also with the hyper-factor branch of
+    each layer on its side stream — and both stream layouts agree to rounding."""
+    import fgnn_amd
+    from fgnn_amd import ops
+    from fgnn_amd.dp import FlatAdam, FlatGradBucket
+    from fgnn_amd.ldpc import synthetic_batch
+
+    def run(two):
+        old = ops.SIDE_STREAM
+        ops.SIDE_STREAM = two
+        try:
+            torch.manual_seed(1234)
+            m = fgnn_amd.LDPCModel(2, 6, 4).to(dev).train()
+            bucket = FlatGradBucket(m.parameters(), flatten_params=True)
+            opt = FlatAdam(bucket, lr=1e-3, weight_decay=1e-8)
+            data = synthetic_batch(512, dev, seed=21, dtype=torch.bfloat16)
+            for _ in range(3):
+                bucket.zero()
+                with torch.autocast('cuda', dtype=torch.bfloat16):
+                    logits, snr = m(*data[:6])
+                loss = torch.nn.functional.binary_cross_entropy_with_logits(logits.float(), data[6]) + 0.1 * snr.float().pow(2).mean()
+                loss.backward()
+                opt.step()
+            torch.cuda.synchronize()
+            return bucket.flat_param.detach().clone(), float(loss)
+        finally:
+            ops.SIDE_STREAM = old
+
+    a, la = run(side_stream)
+    b, lb = run(side_stream)
+    assert torch.equal(a, b) and la == lb
+    c, lc = run(not side_stream)
+    assert abs(la - lc) <= 2e-2 * max(1.0, abs(lc))
