@@ -229,7 +229,9 @@ def main():
     kernels = {}
     if rank == 0:
         ops.TIMER = ops.KernelTimer()
+        ops.SIDE_STREAM = False   # per-kernel durations: one stream, so that no other branch's kernels share the chip
         compute()        # eager, WITHOUT the collective / optimizer: the other ranks are not taking part
+        ops.SIDE_STREAM = True
         kernels = ops.TIMER.summary()
         ops.TIMER = None
         if kernels:
