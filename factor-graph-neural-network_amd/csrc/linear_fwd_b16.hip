@@ -18,7 +18,7 @@
 
 #define LF_THREADS 512
 #define LF_WAVES 8
-#define LF_MAXGRID 512   // == BN_GRID of bnact.hip: the statistics partials reuse its workspace layout
+#define LF_MAXGRID 512   // <= BN_MAXPART of bnact.hip: the statistics partials reuse its workspace layout (256 / 1024 measured level / slower)
 
 typedef __bf16 lf_bf16x8 __attribute__((ext_vector_type(8)));
 
@@ -145,7 +145,8 @@ static int lf_plan(int64_t R, int Cin, int Cout, int* CG, int* grid) {
     const int nrg = LF_WAVES / *CG;
     const int64_t ntile = (R + 15) / 16;
     int64_t g = (ntile + 2 * nrg - 1) / (2 * nrg);         // >= 2 tiles per wave
-    if (g > LF_MAXGRID) g = LF_MAXGRID;
+    static const int maxg = getenv("FGNN_LF_GRID") ? atoi(getenv("FGNN_LF_GRID")) : LF_MAXGRID;
+    if (g > maxg) g = maxg;
     if (g < 1) g = 1;
     *grid = (int)g;
     return 0;
