@@ -10,6 +10,7 @@
 // tile that stays in L1/L2, statistics in f32, nothing but x is kept for the backward
 //   gx = rstd * ( g - mean_n g - xhat * mean_n (g * xhat) ),   g = gy * [y > 0].
 #include "fgnn_common.h"
+#include <stdlib.h>
 
 #define IN_THREADS 256
 #define IN_CH 64
@@ -138,7 +139,7 @@ template <> struct InChunk<bf16_t> {
 };
 
 // Sums of a[e] and b[e] over all row groups of the workgroup, per channel; every thread gets the totals of its chunk.
-template <int EPC, int CPR>
+template <int EPC, int CPR, int CH>
 __device__ __forceinline__ void in_fold2(float (&a)[EPC], float (&b)[EPC], float* red, int cg, int wave) {
 #pragma unroll
     for (int e = 0; e < EPC; ++e) {
@@ -147,26 +148,26 @@ __device__ __forceinline__ void in_fold2(float (&a)[EPC], float (&b)[EPC], float
     }
     if ((threadIdx.x & 63) < CPR) {
 #pragma unroll
-        for (int e = 0; e < EPC; ++e) { red[wave * IN_CH + cg * EPC + e] = a[e]; red[(4 + wave) * IN_CH + cg * EPC + e] = b[e]; }
+        for (int e = 0; e < EPC; ++e) { red[wave * CH + cg * EPC + e] = a[e]; red[(4 + wave) * CH + cg * EPC + e] = b[e]; }
     }
     __syncthreads();
 #pragma unroll
     for (int e = 0; e < EPC; ++e) {
         const int c = cg * EPC + e;
-        a[e] = (red[c] + red[IN_CH + c]) + (red[2 * IN_CH + c] + red[3 * IN_CH + c]);
-        b[e] = (red[4 * IN_CH + c] + red[5 * IN_CH + c]) + (red[6 * IN_CH + c] + red[7 * IN_CH + c]);
+        a[e] = (red[c] + red[CH + c]) + (red[2 * CH + c] + red[3 * CH + c]);
+        b[e] = (red[4 * CH + c] + red[5 * CH + c]) + (red[6 * CH + c] + red[7 * CH + c]);
     }
     __syncthreads();
 }
 
-template <typename T, bool BWD>
+template <typename T, bool BWD, int CH, int MAXR>
 __global__ __launch_bounds__(IN_THREADS) void instnorm_vec_kernel(const InParams p) {
-    constexpr int EPC = InChunk<T>::EPC, CPR = IN_CH / EPC, RG = IN_THREADS / CPR, MAXR = 128 / RG;
-    __shared__ float red[8 * IN_CH];
+    constexpr int EPC = InChunk<T>::EPC, CPR = CH / EPC, RG = IN_THREADS / CPR;    // MAXR >= ceil(N / RG) rows per thread
+    __shared__ float red[8 * CH];
     const int tid = threadIdx.x, wave = tid >> 6;
     const int cg = tid & (CPR - 1), rg = tid / CPR;
-    const int nblk = p.C / IN_CH;
-    const int b = blockIdx.x / nblk, c0 = (blockIdx.x - b * nblk) * IN_CH + cg * EPC;
+    const int nblk = p.C / CH;
+    const int b = blockIdx.x / nblk, c0 = (blockIdx.x - b * nblk) * CH + cg * EPC;
     const int64_t base = (int64_t)b * p.N * p.C + c0;
     const T* xb = static_cast<const T*>(p.x) + base;
     const T* gb = static_cast<const T*>(p.gy) + base;
@@ -196,7 +197,7 @@ __global__ __launch_bounds__(IN_THREADS) void instnorm_vec_kernel(const InParams
         for (int i = 0; i < MAXR; ++i) { const float dv = x[i][e] - K[e]; x[i][e] = dv; s += dv; ss = fmaf(dv, dv, ss); }
         mean[e] = s; rstd[e] = ss;
     }
-    in_fold2<EPC, CPR>(mean, rstd, red, cg, wave);
+    in_fold2<EPC, CPR, CH>(mean, rstd, red, cg, wave);
 #pragma unroll
     for (int e = 0; e < EPC; ++e) {
         const float m = mean[e] * invn;
@@ -229,7 +230,7 @@ __global__ __launch_bounds__(IN_THREADS) void instnorm_vec_kernel(const InParams
                 sgx[e] = fmaf(g[i][e], xh, sgx[e]);
             }
         }
-        in_fold2<EPC, CPR>(sg, sgx, red, cg, wave);
+        in_fold2<EPC, CPR, CH>(sg, sgx, red, cg, wave);
 #pragma unroll
         for (int i = 0; i < MAXR; ++i) {
             const int n = rg + i * RG;
@@ -243,6 +244,11 @@ __global__ __launch_bounds__(IN_THREADS) void instnorm_vec_kernel(const InParams
     }
 }
 
+static bool in_wide() {
+    static const bool off = getenv("FGNN_IN_NARROW") != nullptr;
+    return !off;
+}
+
 static bool in_vec_ok(const void* a, const void* b, const void* c, int N, int C) {
     return C % IN_CH == 0 && N <= 128 && !(((uintptr_t)a | (uintptr_t)b | (uintptr_t)c) & 15);
 }
@@ -254,6 +260,28 @@ static int in_check(const void* a, const void* b, int B, int N, int C, int dtype
     return FGNN_OK;
 }
 
+// rows a thread holds = ceil(N / row groups), rounded up to an instantiated count: fewer registers -> more workgroups
+// per CU -> more bytes in flight (N = 96 at 64 channels needs 3 of the 4 rows N = 128 would)
+template <typename T, bool BWD, int CH>
+static void in_launch_rows(int grid, int N, hipStream_t st, const InParams& p) {
+    constexpr int RG = IN_THREADS / (CH / InChunk<T>::EPC), FULL = 128 / RG;
+    const int need = (N + RG - 1) / RG;
+    if (need * 4 <= FULL) hipLaunchKernelGGL((instnorm_vec_kernel<T, BWD, CH, (FULL / 4 > 0 ? FULL / 4 : 1)>), dim3(grid), dim3(IN_THREADS), 0, st, p);
+    else if (need * 2 <= FULL) hipLaunchKernelGGL((instnorm_vec_kernel<T, BWD, CH, (FULL / 2 > 0 ? FULL / 2 : 1)>), dim3(grid), dim3(IN_THREADS), 0, st, p);
+    else if (need * 4 <= FULL * 3) hipLaunchKernelGGL((instnorm_vec_kernel<T, BWD, CH, (FULL * 3 / 4 > 0 ? FULL * 3 / 4 : 1)>), dim3(grid), dim3(IN_THREADS), 0, st, p);
+    else hipLaunchKernelGGL((instnorm_vec_kernel<T, BWD, CH, FULL>), dim3(grid), dim3(IN_THREADS), 0, st, p);
+}
+
+template <bool BWD>
+static void in_launch_vec(int grid64, int N, int C, int dtype, hipStream_t st, const InParams& p) {
+    // 128 channels per workgroup where the width allows: 256-byte row pieces and every thread busy at N = 48
+    if (C % 128 == 0 && in_wide()) {
+        if (dtype == FGNN_F32) in_launch_rows<float, BWD, 128>(grid64 / 2, N, st, p);
+        else in_launch_rows<bf16_t, BWD, 128>(grid64 / 2, N, st, p);
+    } else if (dtype == FGNN_F32) in_launch_rows<float, BWD, 64>(grid64, N, st, p);
+    else in_launch_rows<bf16_t, BWD, 64>(grid64, N, st, p);
+}
+
 extern "C" int fgnn_instnorm_forward(const void* x, void* y, int B, int N, int C, int dtype, int relu,
                                      fgnn_stream_t stream) {
     int rc = in_check(x, y, B, N, C, dtype);
@@ -262,8 +290,7 @@ extern "C" int fgnn_instnorm_forward(const void* x, void* y, int B, int N, int C
     InParams p = {x, nullptr, nullptr, y, B, N, C, relu};
     const int grid = B * ((C + IN_CH - 1) / IN_CH);
     if (in_vec_ok(x, y, nullptr, N, C)) {
-        if (dtype == FGNN_F32) hipLaunchKernelGGL((instnorm_vec_kernel<float, false>), dim3(grid), dim3(IN_THREADS), 0, (hipStream_t)stream, p);
-        else hipLaunchKernelGGL((instnorm_vec_kernel<bf16_t, false>), dim3(grid), dim3(IN_THREADS), 0, (hipStream_t)stream, p);
+        in_launch_vec<false>(grid, N, C, dtype, (hipStream_t)stream, p);
     } else if (dtype == FGNN_F32) hipLaunchKernelGGL(instnorm_fwd_kernel<float>, dim3(grid), dim3(IN_THREADS), 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL(instnorm_fwd_kernel<bf16_t>, dim3(grid), dim3(IN_THREADS), 0, (hipStream_t)stream, p);
     hipError_t e = hipGetLastError();
@@ -280,8 +307,7 @@ extern "C" int fgnn_instnorm_backward(const void* x, const void* gy, void* gx, i
     InParams p = {x, nullptr, gy, gx, B, N, C, relu};
     const int grid = B * ((C + IN_CH - 1) / IN_CH);
     if (in_vec_ok(x, gy, gx, N, C)) {
-        if (dtype == FGNN_F32) hipLaunchKernelGGL((instnorm_vec_kernel<float, true>), dim3(grid), dim3(IN_THREADS), 0, (hipStream_t)stream, p);
-        else hipLaunchKernelGGL((instnorm_vec_kernel<bf16_t, true>), dim3(grid), dim3(IN_THREADS), 0, (hipStream_t)stream, p);
+        in_launch_vec<true>(grid, N, C, dtype, (hipStream_t)stream, p);
     } else if (dtype == FGNN_F32) hipLaunchKernelGGL(instnorm_bwd_kernel<float>, dim3(grid), dim3(IN_THREADS), 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL(instnorm_bwd_kernel<bf16_t>, dim3(grid), dim3(IN_THREADS), 0, (hipStream_t)stream, p);
     hipError_t e = hipGetLastError();
