@@ -28,7 +28,9 @@ class LdpcDataPath:
         if self.device.type != 'cuda':
             raise RuntimeError('LdpcDataPath runs on a ROCm device (no CPU fallback)')
         g = LdpcGraph()
-        G = np.load(os.path.join(_DATA, 'ldpc_96_3_963_G.npz'))['G'].astype(np.uint64)       # [P, K]
+        z = np.load(os.path.join(_DATA, 'ldpc_96_3_963_G.npz'))
+        G = z['G'].astype(np.uint64)                                                            # [P, K]
+        self._decode_tables = self._incidence_tables(z['A2_nlist'], 48)
         masks = (G << np.arange(self.K, dtype=np.uint64)[None, :]).sum(1).astype(np.uint64)
         self.gmask = torch.from_numpy(masks.view(np.int64)).to(self.device)
         self.var_to_factors = torch.from_numpy(g.var_to_factors.astype(np.int32)).to(self.device)
@@ -77,6 +79,46 @@ class LdpcDataPath:
             P(self.factor_to_vars), B, 96, 48, 3, 6, _hip.dtype_code(node), P(y), P(node), P(hop), P(ef_f2v), P(ef_v2f),
             _hip.stream_ptr()))
         return y, node, hop, ef_f2v, ef_v2f
+
+    def _incidence_tables(self, nlist, nchk):
+        """alist column lists (each variable's checks in file order, -1 = padding) -> the device tables of
+        `fgnn_ldpc_decode`: col_ptr, row_ptr, row_edge, row_var."""
+        cols = [[int(m) for m in row if m >= 0] for row in nlist]
+        col_ptr = np.concatenate([[0], np.cumsum([len(c) for c in cols])]).astype(np.int32)
+        rows = [[] for _ in range(nchk)]
+        for n, c in enumerate(cols):
+            for u, m in enumerate(c):
+                rows[m].append((int(col_ptr[n]) + u, n))
+        if max(len(c) for c in cols) > 16 or max(len(r) for r in rows) > 16:
+            raise ValueError('at most 16 checks per variable / variables per check')
+        row_ptr = np.concatenate([[0], np.cumsum([len(r) for r in rows])]).astype(np.int32)
+        row_edge = np.array([e for r in rows for e, _ in r], np.int32)
+        row_var = np.array([n for r in rows for _, n in r], np.int32)
+        dev = lambda a: torch.from_numpy(a).to(self.device)
+        return dev(col_ptr), dev(row_ptr), dev(row_edge), dev(row_var), len(cols), nchk, int(col_ptr[-1])
+
+    def bit_prior(self, y, snr_db):
+        """`y2b` (MNC_py.cpp:104-108): P(bit = 1 | y) = 1 / (1 + exp(-2 gcx y)), float64."""
+        gcx = torch.pow(10.0, snr_db.to(self.device, torch.float64) / 20.0)[:, None]
+        return 1.0 / (1.0 + torch.exp(-2.0 * gcx * y.to(self.device, torch.float64)))
+
+    def decode(self, bias, loops=100, want_posteriors=False):
+        """The reference's sum-product baseline `zb2x(bias, 48, 48, A2, 1, loops)` (lib/data/ldpc.py:18-24) for a
+        batch: bias [B,96] float64 = P(bit = 1) (see ``bit_prior``).  Returns (x [B,96] uint8 hard decisions — the
+        message is x[:, :48] —, violated checks [B] int32, iterations [B] int32[, q1 [B,96] float64])."""
+        col_ptr, row_ptr, row_edge, row_var, N, M, E = self._decode_tables
+        if bias.dim() != 2 or bias.shape[1] != N:
+            raise ValueError('bias must be [B, %d], got %s' % (N, tuple(bias.shape)))
+        bias = bias.to(self.device, torch.float64).contiguous()
+        B = bias.shape[0]
+        x = torch.empty((B, N), device=self.device, dtype=torch.uint8)
+        q1 = torch.empty((B, N), device=self.device, dtype=torch.float64) if want_posteriors else None
+        viol = torch.empty((B,), device=self.device, dtype=torch.int32)
+        iters = torch.empty((B,), device=self.device, dtype=torch.int32)
+        P = _hip._ptr
+        _hip.check(_hip.lib().fgnn_ldpc_decode(P(bias), P(col_ptr), P(row_ptr), P(row_edge), P(row_var), B, N, M, E,
+                                               int(loops), P(x), P(q1), P(viol), P(iters), _hip.stream_ptr()))
+        return (x, viol, iters, q1) if want_posteriors else (x, viol, iters)
 
     def sample(self, B, seed=0, dtype=torch.float32, snr_db=None, burst_prob=0.05):
         """A batch of B training items (ldpc_dataset.py:222-236): random messages, encoded, sent through the

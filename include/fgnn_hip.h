@@ -223,6 +223,19 @@ int fgnn_ldpc_channel_features(const uint8_t* cw, const float* snr_db, const flo
                                int32_t dc, int32_t dtype, float* y, void* node, void* hop, void* ef_f2v, void* ef_v2f,
                                fgnn_stream_t stream);
 
+/*
+ * The reference's classical baseline: MacKay's sum-product decoder `zb2x(z, k, n, Afile, 1, loops)` ->
+ * `bndecode` (lib/data/MNC/MNC_py.cpp:110-183, bnd/bnd.cpp:150-371; defaults clip 0.9999999999, tinydiv 1e-40, target
+ * syndrome 0) for B words at once, float64, reference operation order: results equal the compiled reference's bit for
+ * bit.  bias [B][N] = P(bit = 1) (`y2b`).  Incidence as device tables: col_ptr [N+1] (edge col_ptr[n]+u = variable n's
+ * u-th check in the alist file's order), row_ptr [M+1], row_edge / row_var [E] (a check's edges / variables in
+ * increasing variable order).  <= 16 edges per variable and per check, N, E <= 1024.  Outputs: x [B][N] hard
+ * decisions, q1 [B][N] pseudo-posteriors (or NULL), viol [B] violated checks at exit, iters [B] iterations run.
+ */
+int fgnn_ldpc_decode(const double* bias, const int32_t* col_ptr, const int32_t* row_ptr, const int32_t* row_edge,
+                     const int32_t* row_var, int64_t B, int32_t N, int32_t M, int32_t E, int32_t loops, uint8_t* x,
+                     double* q1, int32_t* viol, int32_t* iters, fgnn_stream_t stream);
+
 const char* fgnn_last_error(void);
 /* Name (as rocprofv3 prints it) of the kernel the calling thread's last forward/backward dispatched to. */
 const char* fgnn_last_kernel(void);

@@ -358,3 +358,77 @@ def ldpc_channel(t, snr_db, sigma_b, rho, z1, u, z2):
     y = 2.0 * gcx * (t - 0.5) + z1
     burst = (sb >= 1e-20) & (np.asarray(u) < rho)
     return y + np.where(burst, gcx * sb * np.asarray(z2), 0.0)
+
+
+def ldpc_sum_product(nlist, nchk, bias, loops=100, tinydiv=1e-40, clip=0.9999999999):
+    """MacKay's probability-domain sum-product decoder as the reference runs it for its classical baseline
+    (`zb2x(z, 48, 48, A2, 1, 100)`, /root/reference/lib/data/ldpc.py:20-24 -> `bndecode`,
+    lib/data/MNC/bnd/bnd.cpp:150-173): priors `bias[n]` = P(bit n = 1), target syndrome 0, defaults doclip = 1 /
+    clip = 0.9999999999 / tinydiv = 1e-40 / dofudge = 0 (`bnd_defaults`).  One codeword, pure-Python float64 with the
+    reference's operation order (horizontal_pass :217-291, vertical_pass :294-371, bnd_score_state :196-214), so the
+    pseudo-posteriors are bit-identical to the compiled reference (pinned by oracle/make_ldpc_datapath_golden.py).
+    ``nlist[n]`` = the checks of variable n in the alist file's order (-1 = padding).
+    Returns (x [N] hard decisions, q1 [N], violated checks, iterations run)."""
+    N = len(nlist)
+    cols = [[int(m) for m in row if m >= 0] for row in nlist]
+    rows = [[] for _ in range(nchk)]
+    for n in range(N):                                    # bnd.cpp:239-251: a row's entries are met in increasing n
+        for u, m in enumerate(cols[n]):
+            rows[m].append((n, u))
+    bias = [float(b) for b in bias]
+    dqc = [[1.0 - 2.0 * bias[n]] * len(cols[n]) for n in range(N)]          # bnd_load_dqc :139-147
+    pc0 = [[0.0] * len(c) for c in cols]
+    pc1 = [[0.0] * len(c) for c in cols]
+    q1 = [0.0] * N
+    x = [0] * N
+    viol, it = nchk, 0
+    for it in range(1, loops + 1):
+        for m in range(nchk):                             # horizontal pass
+            ent = rows[m]
+            L = len(ent)
+            dpf = [1.0] * (L + 2)
+            dpr = [1.0] * (L + 2)
+            for l in range(1, L + 1):
+                n, u = ent[l - 1]
+                dpf[l] = dqc[n][u] * dpf[l - 1]
+            for l in range(L, 0, -1):
+                n, u = ent[l - 1]
+                dpr[l] = dqc[n][u] * dpr[l + 1]
+                dpc = dpf[l - 1] * dpr[l + 1] * 0.5
+                pc0[n][u] = 0.5 + dpc
+                pc1[n][u] = 0.5 - dpc
+        for n in range(N):                                # vertical pass
+            U = len(cols[n])
+            qt0 = [1.0 - bias[n]] + [0.0] * U
+            qt1 = [bias[n]] + [0.0] * U
+            for u in range(1, U + 1):
+                qt0[u] = qt0[u - 1] * pc0[n][u - 1]
+                qt1[u] = qt1[u - 1] * pc1[n][u - 1]
+            s = qt0[U] + qt1[U]
+            if s > tinydiv:
+                q1[n] = qt1[U] / s
+            qb0, qb1 = 1.0, 1.0
+            for u in range(U, 0, -1):
+                nb0, nb1 = qb0 * pc0[n][u - 1], qb1 * pc1[n][u - 1]
+                qc0, qc1 = qt0[u - 1] * qb0, qt1[u - 1] * qb1
+                qb0, qb1 = nb0, nb1
+                s, d = qc0 + qc1, qc0 - qc1
+                if s > tinydiv:
+                    v = d / s
+                    v = clip if v > clip else (-clip if v < -clip else v)
+                else:
+                    v = 0.0
+                dqc[n][u - 1] = v
+        x = [1 if q >= 0.5 else 0 for q in q1]            # score
+        viol = sum(1 for m in range(nchk) if sum(x[n] for n, _ in rows[m]) % 2)
+        if viol == 0:
+            break
+    import numpy as np
+    return np.array(x, np.uint8), np.array(q1, np.float64), viol, it
+
+
+def ldpc_bit_prior(y, snr_db):
+    """`y2b` (/root/reference/lib/data/MNC/MNC_py.cpp:104-108): P(bit = 1 | y) = 1 / (1 + exp(-2 gcx y))."""
+    import numpy as np
+    gcx = np.power(10.0, np.asarray(snr_db, np.float64) / 20.0)
+    return 1.0 / (1.0 + np.exp(-2.0 * gcx[..., None] * np.asarray(y, np.float64)))

@@ -78,3 +78,20 @@ def test_oracle_encode_matches_compiled_reference_when_present():
         assert L.ref_encode(gfile.encode(), row.ctypes.data_as(ctypes.c_void_p), 48, 48,
                             out.ctypes.data_as(ctypes.c_void_p)) == 0
         assert np.array_equal(out, O.ldpc_encode(G, row))
+
+
+def test_oracle_decoder_matches_compiled_reference_vectors():
+    """`ldpc_sum_product` (the restated `bndecode`) against outputs of the reference's own compiled decoder on 96
+    received words: hard decisions, float64 pseudo-posteriors bit for bit, violated checks, iteration counts."""
+    z = H.load('ldpc_datapath.npz')
+    assert (z['dec_viol'] == 0).sum() >= 40 and (z['dec_viol'] > 0).sum() >= 20 and len(set(z['dec_loops'])) >= 5
+    for i in list(range(0, 96, 7)) + [53, 55, 59]:
+        x, q1, viol, it = O.ldpc_sum_product(z['A2_nlist'], 48, z['dec_bias'][i])
+        assert np.array_equal(x, z['dec_x'][i]) and np.array_equal(q1, z['dec_q1'][i])
+        assert viol == z['dec_viol'][i] and it == z['dec_loops'][i]
+    # a decoded word is a codeword of A2, and on the burst-free words it is the transmitted one
+    ok = z['dec_viol'] == 0
+    assert not ((z['dec_x'][ok].astype(np.int64) @ z['H_A2'].T.astype(np.int64)) % 2).any()
+    easy = np.arange(64, 96)[ok[64:]]
+    assert len(easy) >= 24 and np.array_equal(z['dec_x'][easy], z['codewords'][easy - 64])
+    assert np.allclose(O.ldpc_bit_prior(z['y'], z['snr_db']), z['dec_bias'][:64], rtol=0, atol=0)

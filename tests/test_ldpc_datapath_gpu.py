@@ -88,3 +88,51 @@ def test_sample_is_a_training_batch_the_model_accepts(path, dev):
     with torch.no_grad(), torch.autocast('cuda', dtype=torch.bfloat16):
         logits, snr = m(node, hop, i1, i2, e1, e2)
     assert logits.shape == (256, 48) and torch.isfinite(logits.float()).all()
+
+
+def test_sum_product_decoder_matches_compiled_reference_bit_for_bit(path):
+    """csrc/ldpc_decode.hip against the outputs of the reference's own compiled `bndecode` (fixture made by
+    oracle/make_ldpc_datapath_golden.py): hard decisions, float64 pseudo-posteriors, violated checks and iteration
+    counts are EQUAL on all 96 words (successes after 1..97 iterations and failures at the 100-iteration cap)."""
+    from fgnn_amd import _hip
+    z = H.load('ldpc_datapath.npz')
+    x, viol, iters, q1 = path.decode(torch.from_numpy(z['dec_bias']), loops=100, want_posteriors=True)
+    assert _hip.lib().fgnn_last_kernel().decode() == 'ldpc_decode_kernel'
+    assert np.array_equal(viol.cpu().numpy(), z['dec_viol']) and np.array_equal(iters.cpu().numpy(), z['dec_loops'])
+    assert np.array_equal(x.cpu().numpy(), z['dec_x'])
+    assert np.array_equal(q1.cpu().numpy(), z['dec_q1'])
+
+
+@pytest.mark.parametrize('B', [1, 4096])
+def test_sum_product_decoder_vs_oracle_and_properties(B, path):
+    z = H.load('ldpc_datapath.npz')
+    rng = np.random.default_rng(B)
+    s = rng.integers(0, 2, (B, 48)).astype(np.uint8)
+    cw = O.ldpc_encode(z['G'], s)
+    snr = rng.integers(2, 5, B).astype(np.float64)
+    y = O.ldpc_channel(cw, snr, np.zeros(B), 0.0, rng.standard_normal((B, 96)), rng.random((B, 96)), rng.standard_normal((B, 96)))
+    bias = O.ldpc_bit_prior(y, snr)
+    x, viol, iters = path.decode(torch.from_numpy(bias), loops=50)
+    x, viol, iters = x.cpu().numpy(), viol.cpu().numpy(), iters.cpu().numpy()
+    for i in range(0, B, max(1, B // 12)):                       # the (slow, pure-Python) oracle on a sample
+        xo, _, vo, io = O.ldpc_sum_product(z['A2_nlist'], 48, bias[i], loops=50)
+        assert np.array_equal(x[i], xo) and viol[i] == vo and iters[i] == io
+    # size-independent properties: zero reported violations <=> zero syndrome under A2; most words are recovered
+    syn = ((x.astype(np.int64) @ z['H_A2'].T.astype(np.int64)) % 2).sum(1)
+    assert np.array_equal(syn, viol)
+    ok = viol == 0
+    assert ok.mean() > (0.5 if B > 1 else -1) and (x[ok] == cw[ok]).mean() > 0.999
+    assert iters.min() >= 1 and iters.max() <= 50 and np.all(iters[~ok] == 50)
+    # the decoder must beat hard decisions on y
+    if B > 1:
+        assert (x != cw).mean() < ((y > 0) != cw).mean()
+
+
+def test_decode_from_received_words(path):
+    """End to end on the device: sample -> y2b -> decode."""
+    node, hop, i1, i2, e1, e2, label, sigma_b = path.sample(512, seed=8, snr_db=4.0)
+    y = node[:, 0, :, 0]
+    bias = path.bit_prior(y, torch.full((512,), 4.0))
+    x, viol, iters = path.decode(bias)
+    ok = (viol == 0)
+    assert ok.float().mean().item() > 0.3 and (x[ok].long() == label[ok]).float().mean().item() > 0.98
