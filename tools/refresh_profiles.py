@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Copies the outputs of scratch/prof4.sh (rocprofv3 --kernel-trace --stats over `bench.py`, merged back under
+"""Copies the outputs of tools/profile_bench.sh (rocprofv3 --kernel-trace --stats over `bench.py`, merged back under
 gpurun_out/prof4/) into profiles/r01/final_* and prints the live-vs-rocprof agreement table for its README."""
 import csv
 import json
