@@ -105,6 +105,29 @@ def test_descriptor_checks_without_a_gpu():
     assert L.fgnn_mpconv_forward_lds_bytes(ctypes.byref(d)) == -1
 
 
+def test_side_entry_points_validate_their_arguments_without_a_gpu():
+    """Size / pointer checks of the entry points either side of the operator run before any device work: unsupported
+    shapes come back as FGNN_EUNSUPPORTED (-3), missing buffers as FGNN_EINVAL (-1), with a message."""
+    from fgnn_amd import _hip
+    L = _hip.lib()
+    one = ctypes.c_void_p(16)                      # a non-NULL pointer that is never dereferenced on these paths
+    assert L.fgnn_edge_mlp_forward(one, 0, 0, 0, one, one, one, one, one, 8, 288, 9, 4, None) == _hip.EUNSUPPORTED
+    assert b'Cin=9' in L.fgnn_last_error()
+    assert L.fgnn_edge_mlp_forward(one, 0, 0, 0, one, one, one, one, one, 8, 288, 7, 5, None) == _hip.EUNSUPPORTED
+    assert L.fgnn_edge_mlp_forward(None, 0, 0, 0, one, one, one, one, one, 8, 288, 7, 4, None) == -1
+    assert L.fgnn_edge_mlp_workspace_bytes(4096, 288) > 0
+    assert L.fgnn_ldpc_encode(one, one, 4, 65, 48, one, None) == _hip.EUNSUPPORTED
+    assert L.fgnn_ldpc_encode(None, None, 0, 48, 48, None, None) == 0          # empty batch: nothing to do
+    assert L.fgnn_ldpc_encode(None, one, 4, 48, 48, one, None) == -1
+    assert L.fgnn_ldpc_decode(one, one, one, one, one, 4, 2000, 48, 291, 100, one, None, one, one, None) == _hip.EUNSUPPORTED
+    assert L.fgnn_ldpc_decode(None, one, one, one, one, 4, 96, 48, 291, 100, one, None, one, one, None) == -1
+    assert L.fgnn_ldpc_channel_features(one, one, one, 0.05, one, one, one, one, one, 4, 4096, 48, 3, 6, 0, one, one, one,
+                                        one, one, None) == _hip.EUNSUPPORTED
+    assert L.fgnn_bn_supported(393216, 64, 1) == 1 and L.fgnn_bn_supported(393216, 60, 1) == 0
+    assert L.fgnn_linear_forward_partials(393216, 64, 64) > 0 and L.fgnn_linear_forward_partials(393216, 96, 64) <= 0
+    assert L.fgnn_abi_version() == 3
+
+
 def test_flat_adam_matches_torch_adam():
     """dp.FlatAdam on flattened parameters == torch.optim.Adam on the separate tensors (same update rule,
     same op order up to the multi-tensor batching), including weight decay."""
