@@ -66,6 +66,22 @@ class flatten(torch.nn.Module):
         return input.view(input.size(0), -1)
 
 
+def _is_identity_list(nn_idx):
+    """nn_idx [B, 1, k] lists nodes 0..k-1 in order for every sample (the hyper-factor's neighbour table).  Checked on
+    the device once per table — the fused fan-in block does not read the table at all.  The verdict is remembered ON the
+    tensor that owns the memory (the view's base, e.g. LDPCModel's frozen `hnn_idx_v2f` behind its per-call `expand`),
+    keyed by version and view geometry, so it can never outlive or be confused with another table."""
+    owner = nn_idx._base if nn_idx._base is not None else nn_idx
+    key = (nn_idx._version, nn_idx.storage_offset(), tuple(nn_idx.shape), tuple(nn_idx.stride()))
+    memo = getattr(owner, '_fgnn_identity_list', None)
+    if memo is None or memo[0] != key:
+        k = nn_idx.shape[-1]
+        hit = bool((nn_idx == torch.arange(k, device=nn_idx.device, dtype=nn_idx.dtype)).all().item())
+        memo = (key, hit)
+        owner._fgnn_identity_list = memo
+    return memo[1]
+
+
 class mp_conv_residual(base_mp_nn):
     """Bottleneck: 1x1 conv+BN+LeakyReLU on the sources -> message operator ->
     1x1 conv+BN+LeakyReLU on the destinations (+ input when ``with_residual``)."""
@@ -100,7 +116,8 @@ class mp_conv_residual(base_mp_nn):
         nout = self.conv2[0].out_channels
         M, k = nn_idx.shape[1:]
         fanout = mp.nedge_types == 1 and N == 1 and k == 1          # the hyper-factor -> variables call
-        if not fanout and not (mp.nedge_types == 4 and k in (3, 6)):
+        fanin = mp.nedge_types == 1 and M == 1 and k == N and N > 1 and _is_identity_list(nn_idx)   # variables -> it
+        if not (fanout or fanin) and not (mp.nedge_types == 4 and k in (3, 6)):
             return None
         xr = x.permute(0, 2, 3, 1)
         et = etype.permute(0, 2, 3, 1)                                   # [B, M, k, net]
@@ -131,6 +148,14 @@ class mp_conv_residual(base_mp_nn):
         d = _hip.make_desc(x, nn_idx, etype, 64, mp.nedge_types, _hip.EXT_NONE, _hip.AGG_MAX, True, y)
         d.nin = 64                      # the inner operator's width; x / y strides stay the block's
         P = _hip._ptr
+        if fanin:
+            rc = _hip.lib().fgnn_mpconv_block_forward_fanin(ctypes.byref(d), P(x), P(etype), P(W1), P(s1), P(t1), P(F),
+                                                            P(s2), P(t2), P(W2), P(s3), P(t3), float(bn1.slope), nin, nout,
+                                                            P(addend), P(y), _hip.stream_ptr())
+            if rc == _hip.EUNSUPPORTED:
+                return None
+            _hip.check(rc)
+            return y
         if fanout:
             rc = _hip.lib().fgnn_mpconv_block_forward_fanout(ctypes.byref(d), P(x), P(etype), P(W1), P(s1), P(t1), P(F),
                                                              P(s2), P(t2), P(W2), P(s3), P(t3), float(bn1.slope), nin, nout,

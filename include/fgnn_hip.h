@@ -178,6 +178,13 @@ int fgnn_mpconv_block_forward_fanout(const fgnn_mpconv_desc* d, const void* x, c
                                      const float* s1, const float* t1, const float* filters, const float* s2,
                                      const float* t2, const float* W2, const float* s3, const float* t3, float slope,
                                      int32_t nin, int32_t nout, const void* addend, void* y, fgnn_stream_t stream);
+/* Fan-in form (variables -> one factor listening to ALL N nodes in order): d has M = 1, k = N, net = 1, nin = nou = 64
+ * and the neighbour list must be the identity (the kernel does not read nn_idx; the caller checks); etype [B][k]
+ * (et_sb / et_sk strides, et_sb may be 0); x [B][N][nin] channel-fastest; y / addend [B][nout]. */
+int fgnn_mpconv_block_forward_fanin(const fgnn_mpconv_desc* d, const void* x, const void* etype, const float* W1,
+                                     const float* s1, const float* t1, const float* filters, const float* s2,
+                                     const float* t2, const float* W2, const float* s3, const float* t3, float slope,
+                                     int32_t nin, int32_t nout, const void* addend, void* y, fgnn_stream_t stream);
 
 /*
  * out = inputs[0] + ... + inputs[n-1] (n <= 8) over dense arrays of `numel` elements in one pass — the gradient of

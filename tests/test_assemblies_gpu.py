@@ -453,3 +453,58 @@ def test_training_steps_are_bitwise_reproducible(side_stream, dev):
     assert torch.equal(a, b) and la == lb
     c, lc = run(not side_stream)
     assert abs(la - lc) <= 2e-2 * max(1.0, abs(lc))
+
+
+@pytest.mark.parametrize('width', [(64, 64), (128, 256), (256, 256), (256, 128), (64, 128)])
+@pytest.mark.parametrize('N', [96, 50, 16])
+@pytest.mark.parametrize('with_addend', [False, True], ids=['plain', 'addend'])
+@pytest.mark.parametrize('shared', [True, False], ids=['shared_tables', 'per_sample_tables'])
+def test_fused_inference_fanin_block_matches_staged_path(width, N, with_addend, shared, dev):
+    """The one-kernel inference block around the hyper-factor fan-in call (one destination listening to all N nodes in
+    order, one edge type with per-neighbour weights) against the staged path; a neighbour table that is not the identity
+    must take the staged path."""
+    from fgnn_amd import _hip
+    from fgnn_amd.mpnn import blocks, mp_conv_residual, mp_conv_type
+    nin, nout = width
+    B = 37
+    g = torch.Generator().manual_seed(N + nin + nout)
+    blk = mp_conv_residual(nin, 64, 1, extension=mp_conv_type.NO_EXTENSION, with_residual=False, aggregator='max',
+                           nout=nout)
+    with torch.no_grad():
+        for bn in (blk.conv1[1], blk.mp_conv.bn, blk.conv2[1]):
+            C = bn.num_features
+            bn.running_mean.copy_(torch.randn(C, generator=g) * 0.1)
+            bn.running_var.copy_(torch.rand(C, generator=g) + 0.5)
+            bn.weight.copy_(torch.rand(C, generator=g) + 0.5)
+            bn.bias.copy_(torch.randn(C, generator=g) * 0.2)
+        blk.mp_conv.filters.copy_(torch.randn(64, 64, generator=g) * 0.2)
+    blk = blk.to(dev).eval()
+    x = torch.randn(B, N, 1, nin, generator=g).bfloat16().to(dev).permute(0, 3, 1, 2)
+    if shared:
+        idx = torch.arange(N, device=dev).reshape(1, 1, N).expand(B, -1, -1)
+        et = (torch.rand(1, 1, 1, N, generator=g) + 0.5).bfloat16().to(dev).expand(B, -1, -1, -1)
+    else:
+        idx = torch.arange(N, device=dev).reshape(1, 1, N).repeat(B, 1, 1)
+        et = (torch.rand(B, 1, N, 1, generator=g) + 0.5).bfloat16().to(dev).permute(0, 3, 1, 2)
+    add = torch.randn(B, 1, 1, nout, generator=g).bfloat16().to(dev).permute(0, 3, 1, 2) if with_addend else None
+    with torch.no_grad():
+        y = blk(x, idx, et, addend=add)
+        assert 'mpconv_block_fanin' in _hip.lib().fgnn_last_kernel().decode()
+        blocks.FUSE_EVAL_BLOCKS = False
+        try:
+            ref = blk(x, idx, et, addend=add)
+        finally:
+            blocks.FUSE_EVAL_BLOCKS = True
+        assert y.shape == ref.shape == (B, nout, 1, 1)
+        err = float((y.float() - ref.float()).abs().max() / ref.float().abs().max())
+        assert err <= 2.0 ** -5, err
+        if N > 2 and with_addend and shared:
+            perm = idx.flip(-1).contiguous()                       # not the identity: must not take the fused kernel
+            y2 = blk(x, perm, et, addend=add)
+            assert 'mpconv_block_fanin' not in _hip.lib().fgnn_last_kernel().decode()
+            blocks.FUSE_EVAL_BLOCKS = False
+            try:
+                ref2 = blk(x, perm, et, addend=add)
+            finally:
+                blocks.FUSE_EVAL_BLOCKS = True
+            assert torch.equal(y2, ref2)
