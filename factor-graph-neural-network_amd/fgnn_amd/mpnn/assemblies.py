@@ -23,7 +23,7 @@ def _call(module, x, nn_idx, etype, addend=None):
     if isinstance(module, (mp_conv_v2, mp_conv_residual)):
         return module(x, nn_idx, etype, addend=addend)
     y = module(x, nn_idx, etype) if isinstance(module, base_mp_nn) else module(x)
-    return add_all(y, addend)
+    return add_all(y, addend() if callable(addend) else addend)
 
 
 class mp_sequential(base_mp_nn):
@@ -217,10 +217,13 @@ class FactorNN(torch.nn.Module):
             nf = self.f2f_modules[L][0](fac_c[0][0])
             new_fac[0] = _call(self.v2f_modules[L][0], var_c[1], nn_idx_v2f[0].long(), etype_v2f[0][L],
                                addend=[nf, fac_c[0][-1] if same_width else None, skip[1][0] if skip else None])
-            if two:
-                main.wait_stream(side)
-            new_var = _call(self.f2v_modules[L][0], fac_c[0][1], nn_idx_f2v[0].long(), etype_f2v[0][L],
-                            addend=[new_var] + h + [var_c[-1] if same_width else None, skip[0] if skip else None])
+            def joined(new_var=new_var, h=h, L=L, same_width=same_width, skip=skip, var_c=var_c):
+                # called by the block right before its closing BatchNorm consumes the addends: only there does the main
+                # stream wait for the side branch
+                if two:
+                    main.wait_stream(side)
+                return [new_var] + h + [var_c[-1] if same_width else None, skip[0] if skip else None]
+            new_var = _call(self.f2v_modules[L][0], fac_c[0][1], nn_idx_f2v[0].long(), etype_f2v[0][L], addend=joined)
             var, fac = new_var, new_fac
         out = self.final_classifier(var)
         if self.final_filter is not None:

@@ -174,17 +174,25 @@ class mp_conv_residual(base_mp_nn):
         return y
 
     def forward(self, node_feature, nn_idx, etype, addend=None):
-        """``addend`` (optional, the caller's running sum of the same shape as the output) is added by conv2's
-        fused BatchNorm+activation kernel instead of a separate elementwise pass."""
+        """``addend`` (optional, the caller's running sum of the same shape as the output — a tensor, a list of tensors,
+        or a callable returning either, evaluated right before it is consumed) is added by conv2's fused
+        BatchNorm+activation kernel instead of a separate elementwise pass."""
+        staged = self.training and torch.is_grad_enabled()
+        if callable(addend) and not staged:
+            addend = addend()                                            # the one-kernel block needs it up front
         if isinstance(addend, (list, tuple)):
             addend = as_addends(addend)
-            if not (self.training and torch.is_grad_enabled()):          # the one-kernel block takes one addend
+            if not staged:                                               # ... and takes one addend
                 addend = ops.add_n(addend) if addend else None
-        y = self._fused_eval(node_feature, nn_idx, etype, addend)
-        if y is not None:
-            return y
+        if not staged:
+            y = self._fused_eval(node_feature, nn_idx, etype, addend)
+            if y is not None:
+                return y
         fuse = self.training            # BatchNorm statistics ride in the 1x1 map's epilogue when training
         h = self.conv1[1](self.conv1[0](node_feature, want_stats=fuse))
         h = self.mp_conv(h, nn_idx, etype)
-        h = self.conv2[1](self.conv2[0](h, want_stats=fuse), addend=addend)
+        h = self.conv2[0](h, want_stats=fuse)
+        if callable(addend):            # produced on another stream: asked for (and waited on) only where it is consumed
+            addend = addend()
+        h = self.conv2[1](h, addend=addend)
         return h + node_feature if self.with_residual else h

@@ -102,9 +102,11 @@ class mp_conv_v2(base_mp_nn):
                                           post_shift=shift, relu=plain_relu)
             if self.activation_fn is not None and not plain_relu:
                 y = self.activation_fn(y)
-            return add_all(y, addend)
+            return add_all(y, addend() if callable(addend) else addend)
         z = ops.mpconv(x, nn_idx, etype, self.filters, self.bias, self.nou,
                        self.nedge_types, ext, agg)
+        if callable(addend):
+            addend = addend()
         if self.bn is not None:
             if plain_relu:                      # BatchNorm + ReLU (+ addend) in one fused kernel pair
                 self.bn.slope = 0.0
