@@ -133,7 +133,7 @@ __global__ __launch_bounds__(BB_THREADS) void mpconv_bwd_b16_kernel(const Bb16Pa
 
     const int ct = wave % NCT;                        // this wave's channel tile of dx
     // ---- resident W fragments ----
-    // aP: A of P^T = W^T x   : A[i = col][k = c] = Wt[col][c], 8 consecutive c
+    // aP: A of P^T = W^T x   : A[i = col][k = c] = W[c][col], 8 consecutive c (stride NCOLS)
     // aT: A of dx^T = W dP^T : A[i = c][k = col] = W[c][col],  8 consecutive cols
     bb_bf16x8 aP[NPASS][KS2];
     bb_bf16x8 aT[AT_RES ? NPASS : 1][4];
@@ -143,7 +143,13 @@ __global__ __launch_bounds__(BB_THREADS) void mpconv_bwd_b16_kernel(const Bb16Pa
         for (int ps = 0; ps < NPASS; ++ps) {
 #pragma unroll
             for (int ks = 0; ks < KS2; ++ks)
-                aP[ps][ks] = bb_frag_f32(p.Wt + (int64_t)(ps * 128 + wave * 16 + li0) * NIN + 32 * ks + 8 * lk0);
+                {   // W^T read in place (8 strided loads, once per kernel): no separate transpose launch
+                    const float* wp = p.W + (int64_t)(32 * ks + 8 * lk0) * NCOLS + ps * 128 + wave * 16 + li0;
+                    alignas(16) float w8[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) w8[u] = wp[(int64_t)u * NCOLS];
+                    aP[ps][ks] = bb_frag_f32(w8);
+                }
             if constexpr (AT_RES) {
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks)
@@ -582,7 +588,6 @@ int fgnn_mpconv_backward_b16(const fgnn_mpconv_desc* d, const void* x, const int
     const int chunk = (d->B + grid - 1) / grid;
     grid = (d->B + chunk - 1) / chunk;
     hipStream_t st = (hipStream_t)stream;
-    fgnn_launch_w_transpose(filters, (float*)p.Wt, d->nin, d->nou * 4, st);
     fgnn_note_kernel("mpconv_bwd_b16_kernel<%d, %d>", KS2, NPASS);
     void* args[] = {(void*)&p};
     hipError_t e = hipLaunchKernel(fn, dim3(grid), dim3(BB_THREADS), args, lds, st);
