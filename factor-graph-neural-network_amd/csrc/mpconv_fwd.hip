@@ -315,7 +315,7 @@ int fgnn_mpconv_forward_hyper(const fgnn_mpconv_desc* d, const void* x, const in
 int fgnn_mpconv_forward_b16(const fgnn_mpconv_desc* d, const void* x, const int64_t* nn_idx,
                             const void* etype, const float* filters, const float* bias,
                             const float* post_scale, const float* post_shift, void* y,
-                            uint8_t* argmax, fgnn_stream_t stream);
+                            uint8_t* argmax, fgnn_stream_t stream, float* stats, int* plan_grid);
 
 int fgnn_check_desc(const fgnn_mpconv_desc* d) {
     if (!d) FGNN_FAIL(FGNN_EINVAL, "null descriptor");
@@ -372,7 +372,7 @@ extern "C" int fgnn_mpconv_forward(const fgnn_mpconv_desc* d, const void* x, con
                                            stream);
             if (rc != 0) return rc < 0 ? rc : FGNN_OK;
             rc = fgnn_mpconv_forward_b16(d, x, nn_idx, etype, filters, bias, post_scale, post_shift, y, argmax,
-                                         stream);
+                                         stream, nullptr, nullptr);
             if (rc != 0) return rc < 0 ? rc : FGNN_OK;
             rc = fgnn_mpconv_forward_resident(d, x, nn_idx, etype, filters, bias, post_scale, post_shift, y,
                                               argmax, stream);
@@ -397,4 +397,31 @@ extern "C" int fgnn_mpconv_forward(const fgnn_mpconv_desc* d, const void* x, con
     hipError_t e = hipLaunchKernel(fn, dim3(grid), dim3(FGNN_THREADS), args, lds, (hipStream_t)stream);
     if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "mpconv forward launch: %s", hipGetErrorString(e));
     return FGNN_OK;
+}
+
+// Training form of fgnn_mpconv_forward whose epilogue also leaves the BatchNorm batch statistics of the stored output:
+// per-workgroup partials [rows][2][nou] (sum, sum of squares) for fgnn_bn_finalize — the BatchNorm behind the operator
+// (mp_nn.py:170) then needs no pass of its own over z.  fgnn_mpconv_forward_stats_partials: the number of partial rows
+// this descriptor's launch writes, or 0 when the shape has no statistics epilogue (use fgnn_mpconv_forward + fgnn_bn_stats).
+extern "C" int fgnn_mpconv_forward_stats_partials(const fgnn_mpconv_desc* d) {
+    if (fgnn_check_desc(d) || d->B == 0) return 0;
+    if (d->net == 1 && (d->M == 1 || (d->N == 1 && d->k == 1))) return 0;       // the hyper-edge kernels take these
+    int grid = 0;
+    return fgnn_mpconv_forward_b16(d, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                                   nullptr, nullptr, &grid) == 1 ? grid : 0;
+}
+
+extern "C" int fgnn_mpconv_forward_stats(const fgnn_mpconv_desc* d, const void* x, const int64_t* nn_idx,
+                                         const void* etype, const float* filters, const float* bias, void* y,
+                                         uint8_t* argmax, float* stats_partials, fgnn_stream_t stream) {
+    int rc = fgnn_check_desc(d);
+    if (rc) return rc;
+    if (!x || !nn_idx || !etype || !filters || !y || !stats_partials) FGNN_FAIL(FGNN_EINVAL, "null tensor pointer");
+    if (fgnn_mpconv_forward_stats_partials(d) == 0)
+        FGNN_FAIL(FGNN_EUNSUPPORTED, "mpconv_forward_stats: this shape has no statistics epilogue");
+    rc = fgnn_mpconv_forward_b16(d, x, nn_idx, etype, filters, bias, nullptr, nullptr, y, argmax, stream, stats_partials,
+                                 nullptr);
+    if (rc == 1) return FGNN_OK;
+    if (rc == 0) FGNN_FAIL(FGNN_EUNSUPPORTED, "mpconv_forward_stats: this shape has no statistics epilogue");
+    return rc;
 }

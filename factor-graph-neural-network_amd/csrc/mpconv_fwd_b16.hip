@@ -38,6 +38,7 @@ struct B16Params {
     const float* pshift;
     void* y;
     uint8_t* argmax;
+    float* stats;                         // [grid][2][nou] per-workgroup (sum, sum of squares) of the stored output, or NULL
     int Npad, pass_cols;
     int XSB, PSB;                         // LDS row strides in BYTES (x image, P image)
     int c8shift;                          // log2(nin/8)
@@ -205,6 +206,7 @@ __global__ __launch_bounds__(B16_THREADS) void mpconv_fwd_b16_kernel(const B16Pa
     // lanes always finish the same channel (one pass, <= 64 channels per pass) loads them once
     int cc_cached = -1;
     float c_bias = 0.f, c_scale = 1.f, c_shift = 0.f;
+    float st0 = 0.f, st1 = 0.f;          // BatchNorm statistics of this lane's channel (stats runs: one channel block)
 
     for (; b < d.B; b += gridDim.x) {
         int t = tid;
@@ -280,7 +282,9 @@ __global__ __launch_bounds__(B16_THREADS) void mpconv_fwd_b16_kernel(const B16Pa
                     res = (res + c_bias) * c_scale + c_shift;
                     if (d.relu) res = fmaxf(res, 0.f);
                     const int off = (o0 + ch) * (int)d.y_sc + m * (int)d.y_sm;
-                    if (!(p.dbg & 8) || res == 1.2345e-30f) yb[off] = (unsigned short)pack_bf16(res, 0.f);
+                    const unsigned packed = pack_bf16(res, 0.f);
+                    if (!(p.dbg & 8) || res == 1.2345e-30f) yb[off] = (unsigned short)packed;
+                    if (p.stats) { const float zr = bf16_lo(packed); st0 += zr; st1 = fmaf(zr, zr, st1); }     // of the value as stored
                     if (AGG == FGNN_AGG_MAX && ab) ab[off] = (uint8_t)arg;
                 };
                 bool paired = false;
@@ -428,6 +432,21 @@ __global__ __launch_bounds__(B16_THREADS) void mpconv_fwd_b16_kernel(const B16Pa
             B16_STAMP(7 + 4 * pass);
         }
     }
+    if (p.stats) {
+        // BatchNorm statistics epilogue (host: one pass, <= 64 output channels, lane <-> channel): fold the 8 waves'
+        // per-channel sums in a fixed order and leave this workgroup's partial row for fgnn_bn_finalize
+        float* red = reinterpret_cast<float*>(ps);      // P image is free: the loop ended on a barrier
+        red[(wave * 2) * 64 + lane] = st0;
+        red[(wave * 2 + 1) * 64 + lane] = st1;
+        __syncthreads();
+        if (tid < 128) {
+            const int c = tid & 63, which = tid >> 6;
+            float sum = 0.f;
+#pragma unroll
+            for (int w = 0; w < B16_WAVES; ++w) sum += red[(w * 2 + which) * 64 + c];
+            if (c < nou) p.stats[((int64_t)blockIdx.x * 2 + which) * nou + c] = sum;
+        }
+    }
 }
 
 // ----------------------------------------------------------------------------------------
@@ -455,10 +474,12 @@ static void* b16_pick_agg(int agg, int k, int KSB, int SWP, int NPASS) {
 }
 
 // Returns 1 if launched, 0 if the shape is outside this kernel's family, <0 on error.
+// stats != NULL: also write per-workgroup BatchNorm partials (only one-pass shapes with <= 64 output channels: returns 0
+// otherwise).  plan_grid != NULL: no launch, *plan_grid = the grid (= number of partial rows) the launch would use.
 int fgnn_mpconv_forward_b16(const fgnn_mpconv_desc* d, const void* x, const int64_t* nn_idx,
                             const void* etype, const float* filters, const float* bias,
                             const float* post_scale, const float* post_shift, void* y,
-                            uint8_t* argmax, fgnn_stream_t stream) {
+                            uint8_t* argmax, fgnn_stream_t stream, float* stats, int* plan_grid) {
     if (d->dtype != FGNN_BF16 || d->ext != FGNN_EXT_NONE) return 0;
     if (d->net != 1 && d->net != 4) return 0;
     const int ncols = d->nou * d->net;
@@ -488,11 +509,12 @@ int fgnn_mpconv_forward_b16(const fgnn_mpconv_desc* d, const void* x, const int6
     B16Params p;
     p.d = *d;
     p.x = x; p.idx = nn_idx; p.et = etype; p.W = filters; p.bias = bias;
-    p.pscale = post_scale; p.pshift = post_shift; p.y = y; p.argmax = argmax;
+    p.pscale = post_scale; p.pshift = post_shift; p.y = y; p.argmax = argmax; p.stats = stats;
     p.Npad = Npad;
     const int NPASS = (ncols + B16_PASS_COLS - 1) / B16_PASS_COLS;
     p.pass_cols = NPASS == 1 ? ncols : B16_PASS_COLS;
     if (NPASS > 1 && ncols % B16_PASS_COLS != 0) return 0;
+    if ((stats || plan_grid) && (NPASS != 1 || d->nou > 64 || d->M * ((d->nou + 63) / 64) * 2 <= B16_WAVES)) return 0;
     const int slabs_per_pass = p.pass_cols / 16;
     const int SWP = (slabs_per_pass + B16_WAVES - 1) / B16_WAVES;
     const int KSB = d->nin / 32;
@@ -528,15 +550,16 @@ int fgnn_mpconv_forward_b16(const fgnn_mpconv_desc* d, const void* x, const int6
     void* fn = d->net == 1 ? b16_pick_agg<1>(d->agg, d->k, KSB, SWP, NPASS)
                            : b16_pick_agg<4>(d->agg, d->k, KSB, SWP, NPASS);
     if (!fn) return 0;
-    if (lds > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "hipFuncSetAttribute(%d B LDS): %s", lds, hipGetErrorString(e));
-    }
     int wg_per_cu = (160 * 1024) / lds;
     if (wg_per_cu > 4) wg_per_cu = 4;
     if (wg_per_cu < 1) wg_per_cu = 1;
     int grid = 256 * wg_per_cu;
     if (grid > d->B) grid = d->B;
+    if (plan_grid) { *plan_grid = grid; return 1; }
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "hipFuncSetAttribute(%d B LDS): %s", lds, hipGetErrorString(e));
+    }
     fgnn_note_kernel("mpconv_fwd_b16_kernel<%d, %d, %d, %d, %d, %d>", d->net, d->agg, KSB, SWP, NPASS,
                      (d->agg == FGNN_AGG_MAX && d->net == 4 && (d->k == 3 || d->k == 6)) ? d->k : 0);
     void* args[] = {(void*)&p};

@@ -24,7 +24,7 @@ EXPORTS = ('fgnn_mpconv_forward', 'fgnn_mpconv_backward', 'fgnn_mpconv_forward_l
            'fgnn_mpconv_backward_workspace_bytes', 'fgnn_linear_wgrad', 'fgnn_linear_wgrad_workspace_bytes',
            'fgnn_instnorm_forward', 'fgnn_instnorm_backward', 'fgnn_bn_supported', 'fgnn_bn_workspace_bytes',
            'fgnn_bn_stats', 'fgnn_bn_finalize', 'fgnn_bn_apply', 'fgnn_bn_backward',
-           'fgnn_linear_forward', 'fgnn_linear_forward_partials', 'fgnn_sum_n', 'fgnn_edge_mlp_forward', 'fgnn_edge_mlp_workspace_bytes', 'fgnn_edge_mlp_backward', 'fgnn_ldpc_encode', 'fgnn_ldpc_channel_features', 'fgnn_ldpc_decode', 'fgnn_mpconv_block_forward', 'fgnn_mpconv_block_forward_fanout', 'fgnn_mpconv_block_forward_fanin',
+           'fgnn_linear_forward', 'fgnn_linear_forward_partials', 'fgnn_sum_n', 'fgnn_edge_mlp_forward', 'fgnn_edge_mlp_workspace_bytes', 'fgnn_edge_mlp_backward', 'fgnn_ldpc_encode', 'fgnn_ldpc_channel_features', 'fgnn_ldpc_decode', 'fgnn_mpconv_block_forward', 'fgnn_mpconv_block_forward_fanout', 'fgnn_mpconv_block_forward_fanin', 'fgnn_mpconv_forward_stats', 'fgnn_mpconv_forward_stats_partials',
            'fgnn_mpconv_algorithmic_bytes', 'fgnn_last_error', 'fgnn_last_kernel', 'fgnn_abi_version')
 
 
@@ -57,6 +57,10 @@ def lib():
     vp, dp = ctypes.c_void_p, ctypes.POINTER(MPConvDesc)
     L.fgnn_mpconv_forward.restype = ctypes.c_int
     L.fgnn_mpconv_forward.argtypes = [dp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.fgnn_mpconv_forward_stats.restype = ctypes.c_int
+    L.fgnn_mpconv_forward_stats.argtypes = [dp] + [vp] * 9
+    L.fgnn_mpconv_forward_stats_partials.restype = ctypes.c_int
+    L.fgnn_mpconv_forward_stats_partials.argtypes = [dp]
     L.fgnn_mpconv_backward.restype = ctypes.c_int
     L.fgnn_mpconv_backward.argtypes = [dp] + [vp] * 12 + [ctypes.c_int64, vp]
     L.fgnn_mpconv_backward_workspace_bytes.restype = ctypes.c_int64

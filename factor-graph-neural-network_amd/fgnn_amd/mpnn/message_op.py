@@ -103,8 +103,9 @@ class mp_conv_v2(base_mp_nn):
             if self.activation_fn is not None and not plain_relu:
                 y = self.activation_fn(y)
             return add_all(y, addend() if callable(addend) else addend)
+        # a training-mode BatchNorm right behind the operator takes its batch statistics from the kernel's epilogue
         z = ops.mpconv(x, nn_idx, etype, self.filters, self.bias, self.nou,
-                       self.nedge_types, ext, agg)
+                       self.nedge_types, ext, agg, want_stats=bn_batch_stats and self.bn is not None and self.bn.training)
         if callable(addend):
             addend = addend()
         if self.bn is not None:

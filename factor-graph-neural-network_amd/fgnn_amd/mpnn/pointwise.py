@@ -82,6 +82,12 @@ def hip_linear(rows, weight, bias, want_stats=False, transposed=False):
     return y
 
 
+def set_pending_stats(rows, npart):
+    """A kernel just left ``npart`` statistics partials of ``rows`` ([R, C]) in the current stream's workspace."""
+    global _PENDING_STATS
+    _PENDING_STATS = (rows, npart)
+
+
 def take_pending_stats(rows):
     """Number of statistics partials waiting in the shared workspace for exactly this tensor, else 0."""
     global _PENDING_STATS

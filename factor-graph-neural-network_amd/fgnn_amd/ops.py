@@ -116,8 +116,10 @@ def _check_shapes(x, nn_idx, etype, filters, nou, net, ext):
 
 
 def mpconv_forward_raw(x, nn_idx, etype, filters, bias, nou, net, ext, agg, *,
-                       post_scale=None, post_shift=None, relu=False, want_argmax=False):
-    """One launch of fgnn_mpconv_forward.  Returns (y, argmax-or-None)."""
+                       post_scale=None, post_shift=None, relu=False, want_argmax=False, want_stats=False):
+    """One launch of fgnn_mpconv_forward.  Returns (y, argmax-or-None).  ``want_stats``: where the shape has a
+    statistics epilogue, the launch also leaves the BatchNorm batch statistics of y in the stream's workspace and
+    announces them to the BatchNorm that follows (pointwise.set_pending_stats)."""
     _require_device(x, nn_idx, etype, filters, bias)
     _check_shapes(x, nn_idx, etype, filters, nou, net, ext)
     L = _hip.lib()
@@ -133,6 +135,17 @@ def mpconv_forward_raw(x, nn_idx, etype, filters, bias, nou, net, ext, agg, *,
     bias, post_scale, post_shift = f32(bias), f32(post_scale), f32(post_shift)
     d = _hip.make_desc(x, nn_idx, etype, nou, net, ext, agg, relu, y)
     nbytes = int(L.fgnn_mpconv_algorithmic_bytes(ctypes.byref(d))) if TIMER is not None else 0
+    npart = 0
+    if want_stats and STATS_EPILOGUE and post_scale is None and not relu:
+        npart = int(L.fgnn_mpconv_forward_stats_partials(ctypes.byref(d)))
+    if npart > 0:
+        ws = _workspace(x.device, int(L.fgnn_bn_workspace_bytes(x.shape[0] * M, nou)))
+        _launch('fwd', d, nbytes, lambda: _hip.check(L.fgnn_mpconv_forward_stats(
+            ctypes.byref(d), _hip._ptr(x), _hip._ptr(nn_idx), _hip._ptr(etype), _hip._ptr(filters),
+            _hip._ptr(bias), _hip._ptr(y), _hip._ptr(amax), _hip._ptr(ws), _hip.stream_ptr())))
+        from .mpnn import pointwise
+        pointwise.set_pending_stats(y.permute(0, 2, 3, 1).reshape(x.shape[0] * M, nou), npart)
+        return y, amax
     _launch('fwd', d, nbytes, lambda: _hip.check(L.fgnn_mpconv_forward(
         ctypes.byref(d), _hip._ptr(x), _hip._ptr(nn_idx), _hip._ptr(etype), _hip._ptr(filters),
         _hip._ptr(bias), _hip._ptr(post_scale), _hip._ptr(post_shift), _hip._ptr(y),
@@ -159,6 +172,7 @@ def grad_sink(param):
 
 
 ACCUMULATE_INTO_GRAD = True
+STATS_EPILOGUE = True    # the operator's forward leaves the following BatchNorm's batch statistics
 _WS = {}
 
 
@@ -190,8 +204,8 @@ class _MPConv(torch.autograd.Function):
     """z = agg(messages) + bias with the hand-written HIP forward and backward."""
 
     @staticmethod
-    def forward(ctx, x, nn_idx, etype, filters, bias, nou, net, ext, agg):
-        z, amax = mpconv_forward_raw(x, nn_idx, etype, filters, bias, nou, net, ext, agg,
+    def forward(ctx, x, nn_idx, etype, filters, bias, nou, net, ext, agg, want_stats=False):
+        z, amax = mpconv_forward_raw(x, nn_idx, etype, filters, bias, nou, net, ext, agg, want_stats=want_stats,
                                      want_argmax=True)
         ctx.cfg = (nou, net, ext, agg)
         ctx.has_bias = bias is not None
@@ -240,12 +254,12 @@ class _MPConv(torch.autograd.Function):
             _hip._ptr(gz), None, _hip._ptr(amax), _hip._ptr(gx), _hip._ptr(get),
             _hip._ptr(gw), _hip._ptr(gb), _hip._ptr(ws), ws.numel() * 4, _hip.stream_ptr())))
         return (gx, None, get, None if gw_sink is not None else gw.to(filters.dtype),
-                None if gb_sink is not None else gb, None, None, None, None)
+                None if gb_sink is not None else gb, None, None, None, None, None)
 
 
-def mpconv(x, nn_idx, etype, filters, bias, nou, net, ext, agg):
+def mpconv(x, nn_idx, etype, filters, bias, nou, net, ext, agg, want_stats=False):
     """Differentiable pre-BatchNorm operator output z [B, nou, M, 1]."""
-    return _MPConv.apply(x, nn_idx, etype, filters, bias, nou, net, ext, agg)
+    return _MPConv.apply(x, nn_idx, etype, filters, bias, nou, net, ext, agg, want_stats)
 
 
 def _dense_same_layout(ts):

@@ -90,6 +90,18 @@ int fgnn_mpconv_backward(const fgnn_mpconv_desc* d, const void* x, const int64_t
 int64_t fgnn_mpconv_backward_workspace_bytes(const fgnn_mpconv_desc* d);
 
 /* Bytes of dynamic LDS the forward will request for this descriptor (diagnostics / tests). */
+/*
+ * Training form of fgnn_mpconv_forward (no post-affine, no ReLU) whose epilogue also leaves the batch statistics of
+ * the stored output for the BatchNorm that follows the operator (mp_nn.py:170): per-workgroup partials
+ * [rows][2][nou] (sum, sum of squares) in fgnn_bn_finalize's layout, so that BatchNorm needs no pass of its own over z.
+ * fgnn_mpconv_forward_stats_partials(d) = the number of partial rows the launch writes (<= 1024), or 0 when this shape
+ * has no statistics epilogue (bf16 one-pass parity shapes with <= 64 output channels have one).
+ */
+int fgnn_mpconv_forward_stats_partials(const fgnn_mpconv_desc* d);
+int fgnn_mpconv_forward_stats(const fgnn_mpconv_desc* d, const void* x, const int64_t* nn_idx, const void* etype,
+                              const float* filters, const float* bias, void* y, uint8_t* argmax, float* stats_partials,
+                              fgnn_stream_t stream);
+
 int64_t fgnn_mpconv_forward_lds_bytes(const fgnn_mpconv_desc* d);
 
 /* Algorithmic HBM bytes of one forward call (SURVEY §8d formula; used by bench.py's roofline). */

@@ -445,3 +445,45 @@ def test_fan_out_and_add_n_match_plain_autograd(dtype, layout, dev):
     ya.backward(gy)
     yb.backward(gy)
     assert H.rel_err(xa.grad.float(), xb.grad.float()) <= (1e-6 if dtype == torch.float32 else 2.0 ** -6)
+
+
+@pytest.mark.parametrize('shape', [(96, 48, 6), (48, 96, 3)], ids=['v2f', 'f2v'])
+@pytest.mark.parametrize('B', [5, 300, 1100])
+def test_bf16_forward_statistics_epilogue_feeds_batchnorm(shape, B, dev):
+    """Training-mode mp_conv_v2 (64 -> 64, 4 edge types): the operator's forward kernel leaves the batch statistics of
+    its stored output for the BatchNorm behind it (mp_nn.py:170) — same output, running statistics and gradients as
+    with BatchNorm's own reduction pass over z."""
+    import fgnn_amd
+    from fgnn_amd import _hip, ops
+    from fgnn_amd.mpnn import mp_conv_type, mp_conv_v2
+    N, M, k = shape
+    g = torch.Generator().manual_seed(B + N)
+    x = torch.randn(B, N, 1, 64, generator=g).bfloat16().to(dev).permute(0, 3, 1, 2)
+    idx = torch.randint(0, N, (B, M, k), generator=g).to(dev)
+    et = torch.randn(B, M, k, 4, generator=g).bfloat16().to(dev).permute(0, 3, 1, 2)
+    gy = torch.randn(B, M, 1, 64, generator=g).bfloat16().to(dev).permute(0, 3, 1, 2)
+
+    def run(epilogue):
+        torch.manual_seed(7)
+        m = mp_conv_v2(64, 64, 4, extension=mp_conv_type.NO_EXTENSION, aggregtor='max').to(dev).train()
+        xx = x.detach().clone().requires_grad_(True)
+        ops.STATS_EPILOGUE = epilogue
+        try:
+            y = m(xx, idx, et)
+        finally:
+            ops.STATS_EPILOGUE = True
+        y.backward(gy)
+        return y.detach().float(), m.bn.running_mean.clone(), m.bn.running_var.clone(), xx.grad.float(), m.filters.grad.clone()
+
+    a = run(True)
+    b = run(False)
+    assert H.rel_err(a[0], b[0]) <= 2.0 ** -7 and H.rel_err(a[3], b[3]) <= 2.0 ** -6
+    assert H.rel_err(a[1], b[1]) <= 1e-5 and H.rel_err(a[2], b[2]) <= 1e-4 and H.rel_err(a[4], b[4]) <= 2e-3
+    # the epilogue is really what ran: no bn_stats launch for this BatchNorm
+    ops.TIMER = ops.KernelTimer()
+    try:
+        run(True)
+        names = set(ops.TIMER.summary())
+    finally:
+        ops.TIMER = None
+    assert not any(n.startswith('bn_stats') for n in names), names
