@@ -1,0 +1,100 @@
+"""GPU, BASELINE.json's full size (batch 4096 codewords, the four operator shapes of the 96.3.963 LDPC model): the
+oracle is too slow to check every output there, so the kernels are checked through properties the operator has by
+construction (mp_nn.py:115-175: samples are independent; max-product aggregation is positively homogeneous and blind
+to the order of a destination's neighbours), all BIT-EXACT, plus the oracle on a random sample of the batch."""
+import pytest
+import torch
+
+import fgnn_oracle as O
+import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+B = 4096
+SHAPES = {                      # name: (nin, nou, net, N, M, k)
+    'parity_v2f': (64, 64, 4, 96, 48, 6),
+    'parity_f2v': (64, 64, 4, 48, 96, 3),
+    'hyper_v2f': (64, 64, 1, 96, 1, 96),
+    'hyper_f2v': (64, 64, 1, 1, 96, 1),
+}
+
+
+def _problem(name, dtype, dev, seed=0):
+    nin, nou, net, N, M, k = SHAPES[name]
+    g = torch.Generator().manual_seed(seed + N + k)
+    cl = lambda t: t.to(dtype).to(dev).permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+    x = cl(torch.randn(B, nin, N, 1, generator=g))
+    idx = torch.randint(0, N, (B, M, k), generator=g).to(dev)
+    et = cl(torch.randn(B, net, M, k, generator=g))
+    W = (torch.randn(nin, nou * net, generator=g) * 0.1).to(dev)
+    return x, idx, et, W
+
+
+def _fwd(x, idx, et, W, bias=None, name=None):
+    from fgnn_amd import _hip, ops
+    nin, nou, net, N, M, k = SHAPES[name]
+    y, am = ops.mpconv_forward_raw(x, idx, et, W, bias, nou, net, _hip.EXT_NONE, _hip.AGG_MAX, want_argmax=True)
+    return y, am
+
+
+@pytest.mark.parametrize('name', list(SHAPES))
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16], ids=['f32', 'bf16'])
+def test_forward_properties_at_full_batch(name, dtype, dev):
+    nin, nou, net, N, M, k = SHAPES[name]
+    x, idx, et, W = _problem(name, dtype, dev)
+    y, am = _fwd(x, idx, et, W, name=name)
+    # samples are independent and the kernel is deterministic: any slice of the batch run alone gives the same bits
+    for lo, hi in ((0, 64), (1000, 1003), (4095, 4096)):
+        ys, ams = _fwd(x[lo:hi], idx[lo:hi], et[lo:hi], W, name=name)
+        assert torch.equal(ys, y[lo:hi]) and torch.equal(ams, am[lo:hi])
+    # ... and permuting the samples permutes the outputs
+    perm = torch.randperm(B, generator=torch.Generator().manual_seed(1)).to(dev)
+    yp, _ = _fwd(x[perm], idx[perm], et[perm], W, name=name)
+    assert torch.equal(yp, y[perm])
+    # positive homogeneity without bias: scaling the features by 2 scales the messages by exactly 2
+    y2, am2 = _fwd(x * 2, idx, et, W, name=name)
+    assert torch.equal(y2, y * 2) and torch.equal(am2, am)
+    # the max does not care in which order a destination lists its neighbours (the argmax index follows the order)
+    if k > 1:
+        order = torch.randperm(k, generator=torch.Generator().manual_seed(2)).to(dev)
+        eo = et[:, :, :, order].permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)     # same memory layout as et
+        yo, amo = _fwd(x, idx[:, :, order].contiguous(), eo, W, name=name)
+        assert torch.equal(yo, y)
+    # the oracle on a random sample of the batch
+    pick = torch.randperm(B, generator=torch.Generator().manual_seed(3))[:24]
+    sd = {'filters': W.cpu(), 'bias': torch.zeros(nou)}
+    ref = O.mp_conv(sd, '', x[pick.to(dev)].float().cpu(), idx[pick.to(dev)].cpu(), et[pick.to(dev)].float().cpu(), nou=nou,
+                    net=net, extension=0, aggregator='max', relu=False)
+    tol = 2e-5 if dtype == torch.float32 else 2.0 ** -6
+    assert H.rel_err(y[pick.to(dev)].float(), ref) <= tol
+
+
+@pytest.mark.parametrize('name', ['parity_v2f', 'parity_f2v'])
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16], ids=['f32', 'bf16'])
+def test_backward_properties_at_full_batch(name, dtype, dev):
+    """Gradients at the full batch: input gradients of a slice of samples equal those of the slice run alone (bit-exact),
+    the bias gradient is the plain sum of the output gradient, and the filter gradient is additive over a split of the
+    batch (f32 accumulation: to rounding)."""
+    from fgnn_amd import _hip, ops
+    nin, nou, net, N, M, k = SHAPES[name]
+    x, idx, et, W = _problem(name, dtype, dev, seed=5)
+    bias = torch.zeros(nou, device=dev)
+    g = torch.Generator().manual_seed(9)
+    gz = torch.randn(B, M, 1, nou, generator=g).to(dtype).to(dev).permute(0, 3, 1, 2)
+
+    def grads(sl):
+        xx = x[sl].detach().clone().requires_grad_(True)
+        ee = et[sl].detach().clone().requires_grad_(True)
+        ww = W.detach().clone().requires_grad_(True)
+        bb = bias.detach().clone().requires_grad_(True)
+        z = ops.mpconv(xx, idx[sl], ee, ww, bb, nou, net, _hip.EXT_NONE, _hip.AGG_MAX)
+        z.backward(gz[sl])
+        return xx.grad, ee.grad, ww.grad, bb.grad
+
+    full = grads(slice(0, B))
+    for sl in (slice(0, 32), slice(2048, 2051)):
+        part = grads(sl)
+        assert torch.equal(part[0], full[0][sl]) and torch.equal(part[1], full[1][sl])
+    assert H.rel_err(full[3], gz.float().sum((0, 2, 3))) <= 1e-5
+    a, b = grads(slice(0, 2048)), grads(slice(2048, B))
+    assert H.rel_err(a[2] + b[2], full[2]) <= 1e-5 and H.rel_err(a[3] + b[3], full[3]) <= 1e-5
