@@ -98,3 +98,30 @@ def test_backward_properties_at_full_batch(name, dtype, dev):
     assert H.rel_err(full[3], gz.float().sum((0, 2, 3))) <= 1e-5
     a, b = grads(slice(0, 2048)), grads(slice(2048, B))
     assert H.rel_err(a[2] + b[2], full[2]) <= 1e-5 and H.rel_err(a[3] + b[3], full[3]) <= 1e-5
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16], ids=['f32', 'bf16'])
+def test_ldpc_model_inference_at_full_batch(dtype, dev):
+    """The whole decoder (LDPCModel, eval mode: 32 operator calls per forward) on 4096 codewords from the GPU data
+    path: every codeword is decoded independently, so slices of the batch run alone reproduce the full run (to rounding
+    only: the wide node-wise maps go through rocBLAS, whose tiling — hence summation order — depends on the row count);
+    in f32 a random sample of the batch matches the CPU oracle within the north-star 1e-4."""
+    import fgnn_amd
+    from fgnn_amd.datapath import LdpcDataPath
+    m = fgnn_amd.LDPCModel(2, 6, 4, aggregator='max')
+    m.load_state_dict(H.fill_state_dict(m.state_dict()))
+    m = m.to(dev).eval()
+    data = LdpcDataPath(dev).sample(B, seed=12, dtype=dtype)[:6]
+    amp = torch.autocast('cuda', dtype=torch.bfloat16, enabled=dtype == torch.bfloat16)
+    with torch.no_grad(), amp:
+        logits, snr = m(*data)
+        assert logits.shape == (B, 48) and torch.isfinite(logits.float()).all()
+        for lo, hi in ((0, 128), (4000, 4096)):
+            l2, s2 = m(*[t[lo:hi] for t in data])
+            tol = 1e-5 if dtype == torch.float32 else 2.0 ** -5
+            assert H.rel_err(l2.float(), logits[lo:hi].float()) <= tol and H.rel_err(s2.float(), snr[lo:hi].float()) <= tol
+    if dtype == torch.float32:
+        pick = torch.randperm(B, generator=torch.Generator().manual_seed(4))[:8].to(dev)
+        sd = {k: v.cpu() for k, v in m.state_dict().items()}
+        lo_, so_ = O.ldpc_model(sd, *[t[pick].cpu().contiguous() for t in data], training=False)
+        assert H.rel_err(logits[pick], lo_) <= 1e-4 and H.rel_err(snr[pick], so_) <= 1e-4
