@@ -43,6 +43,9 @@ class FlatGradBucket:
                 view.copy_(p.data)
                 p.data = view
             off += n
+        if self.flat_param is not None:
+            from .mpnn import pointwise
+            pointwise.register_flat_parameters(self.flat_param)       # one low-precision mirror, one cast kernel per step
 
     def zero(self):
         self.flat.zero_()

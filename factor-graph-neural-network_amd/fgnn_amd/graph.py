@@ -21,6 +21,10 @@ class StepGraph:
                 fn()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        # cached low-precision weight copies are refreshed in place where they are stale: make them stale now, so the
+        # refresh kernels are captured and every replay casts the parameters as they are at that moment
+        from .mpnn import pointwise
+        pointwise.invalidate_casts()
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             fn()

@@ -14,30 +14,66 @@ import torch
 from .. import _hip
 
 
-_CAST_CACHE = {}
+_CAST_CACHE = {}          # id(tensor) -> [tensor, version, epoch, low-precision copy]
 _CAST_EPOCH = 0
+_FLAT_MIRRORS = []        # [flat f32 buffer, {dtype: low-precision mirror}, version, epoch, {id(param): version}]
 
 
 def invalidate_casts():
-    """Forget every cached low-precision copy (call after updating parameters through an alias that does not
-    bump their version counters, e.g. a flat parameter buffer; dp.FlatAdam does)."""
+    """Mark every cached low-precision copy stale (call after updating parameters through an alias that does not
+    bump their version counters, e.g. a flat parameter buffer; dp.FlatAdam does).  The copies are refreshed IN
+    PLACE at their next use — their storage is never replaced, because a captured hipGraph may hold its address;
+    graph.StepGraph calls this right before capturing, so the refresh kernels are part of the graph and every
+    replay casts the current parameters."""
     global _CAST_EPOCH
     _CAST_EPOCH += 1
-    _CAST_CACHE.clear()
 
+
+def register_flat_parameters(flat):
+    """``flat`` (f32) backs many parameters (dp.FlatGradBucket(flatten_params=True)): their low-precision copies
+    become views of ONE mirror buffer that is refreshed by a single cast kernel per step instead of one per tensor."""
+    _FLAT_MIRRORS.append([flat, {}, -1, -1, {}])
+
+
+def _from_flat_mirror(t, dtype):
+    for ent in _FLAT_MIRRORS:
+        flat = ent[0]
+        off = t.data_ptr() - flat.data_ptr()
+        if 0 <= off < flat.numel() * 4 and t.dtype == flat.dtype and t.device == flat.device and t.is_contiguous() \
+                and off % 4 == 0 and off // 4 + t.numel() <= flat.numel():
+            mirror = ent[1].get(dtype)
+            if mirror is None:
+                mirror = ent[1][dtype] = torch.empty_like(flat, dtype=dtype)
+                ent[2] = -1
+            if ent[2] != flat._version or ent[3] != _CAST_EPOCH or ent[4].get(id(t), t._version) != t._version:
+                for mm in ent[1].values():
+                    mm.copy_(flat)                               # one kernel for every parameter of the model
+                ent[2], ent[3] = flat._version, _CAST_EPOCH
+                ent[4].clear()
+            ent[4][id(t)] = t._version                           # load_state_dict writes through the parameter, not flat
+            return mirror[off // 4: off // 4 + t.numel()].view(t.shape)
+    return None
 
 
 def cast_cached(t, dtype):
     """``t.to(dtype)`` remembered until ``t`` is modified in place (optimizer step, load_state_dict):
-    inference re-uses the bf16 copies of the weights instead of re-casting ~170 tensors per forward."""
+    the forward re-uses the bf16 copies of the weights instead of re-casting ~170 tensors.  A stale copy is
+    refreshed in place (same storage — see invalidate_casts)."""
     if t is None or t.dtype == dtype:
         return t
+    if _FLAT_MIRRORS:
+        v = _from_flat_mirror(t, dtype)
+        if v is not None:
+            return v
     key = id(t)
     hit = _CAST_CACHE.get(key)
-    if hit is not None and hit[0] is t and hit[1] == t._version and hit[2].dtype == dtype and hit[2].device == t.device:
-        return hit[2]
+    if hit is not None and hit[0] is t and hit[3].dtype == dtype and hit[3].device == t.device and hit[3].shape == t.shape:
+        if hit[1] != t._version or hit[2] != _CAST_EPOCH:
+            hit[3].copy_(t.detach())
+            hit[1], hit[2] = t._version, _CAST_EPOCH
+        return hit[3]
     out = t.detach().to(dtype)
-    _CAST_CACHE[key] = (t, t._version, out)
+    _CAST_CACHE[key] = [t, t._version, _CAST_EPOCH, out]
     return out
 
 

@@ -508,3 +508,87 @@ def test_fused_inference_fanin_block_matches_staged_path(width, N, with_addend, 
             finally:
                 blocks.FUSE_EVAL_BLOCKS = True
             assert torch.equal(y2, ref2)
+
+
+def test_graph_replay_reproduces_eager_gradients_bitwise(dev):
+    """A captured training step (graph.StepGraph: the hyper-factor branch of every layer is a parallel branch of the
+    hipGraph, backward included) leaves exactly the gradients of the same step launched eagerly — replayed twice, with
+    the inputs changed in place in between."""
+    import fgnn_amd
+    from fgnn_amd.dp import FlatGradBucket
+    from fgnn_amd.graph import StepGraph
+    from fgnn_amd.ldpc import synthetic_batch
+    torch.manual_seed(99)
+    m = fgnn_amd.LDPCModel(2, 6, 4).to(dev).train()
+    bucket = FlatGradBucket(m.parameters(), flatten_params=True)
+    data = [t.clone() if t.is_floating_point() else t for t in synthetic_batch(384, dev, seed=31, dtype=torch.bfloat16)]
+    other = synthetic_batch(384, dev, seed=32, dtype=torch.bfloat16)
+
+    def compute():
+        bucket.zero()
+        with torch.autocast('cuda', dtype=torch.bfloat16):
+            logits, snr = m(*data[:6])
+        (torch.nn.functional.binary_cross_entropy_with_logits(logits.float(), data[6]) + 0.1 * snr.float().pow(2).mean()).backward()
+
+    def eager_reference():
+        state = {k: v.clone() for k, v in m.state_dict().items()}          # BatchNorm running statistics move per step
+        compute()
+        torch.cuda.synchronize()
+        g = bucket.flat.clone()
+        m.load_state_dict(state)
+        return g
+
+    g1 = eager_reference()
+    state = {k: v.clone() for k, v in m.state_dict().items()}
+    graph = StepGraph(compute)                                                  # 2 warm-up steps + capture (one more step)
+    m.load_state_dict(state)
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(bucket.flat, g1)
+    for i in (0, 1, 4, 5, 6):                                                   # new inputs, same static buffers
+        data[i].copy_(other[i])
+    m.load_state_dict(state)
+    g2 = eager_reference()
+    assert not torch.equal(g2, g1)
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(bucket.flat, g2)
+
+
+def test_graph_replayed_training_equals_eager_training_bitwise(dev):
+    """Three optimizer steps driven by graph replays end in exactly the parameters of three eager steps: the replay
+    reads the parameters as they are at that moment (the low-precision weight copies of the library GEMMs are refreshed
+    by a captured kernel, not frozen at capture time)."""
+    import fgnn_amd
+    from fgnn_amd.dp import FlatAdam, FlatGradBucket
+    from fgnn_amd.graph import StepGraph
+    from fgnn_amd.ldpc import synthetic_batch
+    data = synthetic_batch(384, dev, seed=41, dtype=torch.bfloat16)
+
+    def train(use_graph):
+        torch.manual_seed(123)
+        m = fgnn_amd.LDPCModel(2, 6, 4).to(dev).train()
+        bucket = FlatGradBucket(m.parameters(), flatten_params=True)
+        opt = FlatAdam(bucket, lr=1e-3, weight_decay=1e-8)
+
+        def compute():
+            bucket.zero()
+            with torch.autocast('cuda', dtype=torch.bfloat16):
+                logits, snr = m(*data[:6])
+            (torch.nn.functional.binary_cross_entropy_with_logits(logits.float(), data[6]) + 0.1 * snr.float().pow(2).mean()).backward()
+
+        start = {k: v.clone() for k, v in m.state_dict().items()}
+        step = compute
+        if use_graph:
+            step = StepGraph(compute).replay                  # warm-up + capture advance the BatchNorm buffers: reset
+            m.load_state_dict(start)
+        for _ in range(3):
+            step()
+            opt.step()
+        torch.cuda.synchronize()
+        return bucket.flat_param.detach().clone(), {k: v.clone() for k, v in m.state_dict().items() if 'running' in k}
+
+    pe, be = train(False)
+    pg, bg = train(True)
+    assert torch.equal(pe, pg)
+    assert all(torch.equal(be[k], bg[k]) for k in be)
