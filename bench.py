@@ -288,6 +288,7 @@ def main():
                        'global_batch': args.batch * world, 'parallelism': 'dp%d' % world,
                        'inputs': ('random messages -> reference G encode -> AWGN+burst channel, on the GPU'
                                   if args.inputs == 'channel' else 'random bits + AWGN (torch ops)'),
+                       'peak_hbm_GB': round(torch.cuda.max_memory_allocated(dev) / 1e9, 2),
                        'mode': args.mode, 'hip_graph': graphed is not None},
             'roofline': roofline,
             'kernels': {k: {'launches': v['launches'], 'avg_us': round(v['ms'] / v['launches'] * 1e3, 2),
