@@ -165,6 +165,10 @@ def main():
         bucket = FlatGradBucket(model.parameters(), flatten_params=True)
         opt = FlatAdam(bucket, lr=1e-4, weight_decay=1e-8)
 
+    if not train:
+        from fgnn_amd.dp import flatten_parameters
+        flatten_parameters(p for p in model.parameters() if p.dtype == torch.float32)     # one weight-cast kernel per forward
+
     # bf16: activations / messages are stored in bf16 (the message kernels then use bf16 matrix cores for
     # the forward), parameters, gradients and optimizer state stay f32 (autocast for the node-wise GEMMs)
     amp = torch.autocast(device_type='cuda', dtype=torch.bfloat16, enabled=(args.dtype == 'bf16'))

@@ -15,6 +15,29 @@ import torch
 import torch.distributed as dist
 
 
+def flatten_parameters(params):
+    """Move float32 parameters into ONE flat buffer (every ``p.data`` becomes a view of it) and register it with the
+    low-precision weight cache: the bf16 copies the library GEMMs read are then views of one mirror that a single cast
+    kernel refreshes (pointwise.register_flat_parameters).  Returns the flat buffer."""
+    params = list(params)
+    if not params:
+        raise ValueError('no parameters')
+    if any(p.dtype != torch.float32 for p in params):
+        raise ValueError('flatten_parameters needs float32 parameters')
+    flat = torch.empty(sum(p.numel() for p in params), device=params[0].device, dtype=torch.float32)
+    off = 0
+    with torch.no_grad():
+        for p in params:
+            n = p.numel()
+            view = flat[off:off + n].view_as(p)
+            view.copy_(p.data)
+            p.data = view
+            off += n
+    from .mpnn import pointwise
+    pointwise.register_flat_parameters(flat)
+    return flat
+
+
 class FlatGradBucket:
     """Owns one contiguous gradient buffer; ``param.grad`` are views into it."""
 
@@ -29,23 +52,12 @@ class FlatGradBucket:
         dev, dt = self.params[0].device, torch.float32
         self.numel = sum(p.numel() for p in self.params)
         self.flat = torch.zeros(self.numel, device=dev, dtype=dt)
-        self.flat_param = None
-        if flatten_params:
-            if any(p.dtype != dt for p in self.params):
-                raise ValueError('flatten_params needs float32 parameters')
-            self.flat_param = torch.empty(self.numel, device=dev, dtype=dt)
+        self.flat_param = flatten_parameters(self.params) if flatten_params else None
         off = 0
         for p in self.params:
             n = p.numel()
             p.grad = self.flat[off:off + n].view_as(p)
-            if self.flat_param is not None:
-                view = self.flat_param[off:off + n].view_as(p)
-                view.copy_(p.data)
-                p.data = view
             off += n
-        if self.flat_param is not None:
-            from .mpnn import pointwise
-            pointwise.register_flat_parameters(self.flat_param)       # one low-precision mirror, one cast kernel per step
 
     def zero(self):
         self.flat.zero_()
