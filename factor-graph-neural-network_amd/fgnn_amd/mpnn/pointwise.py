@@ -9,6 +9,8 @@ dominate the step).  ``PointwiseConv2d`` keeps Conv2d's parameters / state_dict 
 kernel reads and writes without a transpose.  Outputs are logical [B,C,N,W] with
 channels-last strides; every consumer in this package is stride-agnostic.
 """
+import weakref
+
 import torch
 
 from .. import _hip
@@ -32,12 +34,15 @@ def invalidate_casts():
 def register_flat_parameters(flat):
     """``flat`` (f32) backs many parameters (dp.FlatGradBucket(flatten_params=True)): their low-precision copies
     become views of ONE mirror buffer that is refreshed by a single cast kernel per step instead of one per tensor."""
-    _FLAT_MIRRORS.append([flat, {}, -1, -1, {}])
+    _FLAT_MIRRORS[:] = [e for e in _FLAT_MIRRORS if e[0]() is not None]      # buffers that are gone take their mirrors along
+    _FLAT_MIRRORS.append([weakref.ref(flat), {}, -1, -1, {}])
 
 
 def _from_flat_mirror(t, dtype):
     for ent in _FLAT_MIRRORS:
-        flat = ent[0]
+        flat = ent[0]()
+        if flat is None:
+            continue
         off = t.data_ptr() - flat.data_ptr()
         if 0 <= off < flat.numel() * 4 and t.dtype == flat.dtype and t.device == flat.device and t.is_contiguous() \
                 and off % 4 == 0 and off // 4 + t.numel() <= flat.numel():
