@@ -34,7 +34,7 @@ def flatten_parameters(params):
             p.data = view
             off += n
     from .mpnn import pointwise
-    pointwise.register_flat_parameters(flat)
+    pointwise.register_flat_parameters(flat, params)
     return flat
 
 

@@ -18,7 +18,7 @@ from .. import _hip
 
 _CAST_CACHE = {}          # id(tensor) -> [tensor, version, epoch, low-precision copy]
 _CAST_EPOCH = 0
-_FLAT_MIRRORS = []        # [flat f32 buffer, {dtype: low-precision mirror}, version, epoch, {id(param): version}]
+_FLAT_MIRRORS = []        # [flat f32 buffer (weak), {dtype: mirror}, version, epoch, {id(param): version}, params (weak)]
 
 
 def invalidate_casts():
@@ -31,11 +31,11 @@ def invalidate_casts():
     _CAST_EPOCH += 1
 
 
-def register_flat_parameters(flat):
+def register_flat_parameters(flat, params=()):
     """``flat`` (f32) backs many parameters (dp.FlatGradBucket(flatten_params=True)): their low-precision copies
     become views of ONE mirror buffer that is refreshed by a single cast kernel per step instead of one per tensor."""
     _FLAT_MIRRORS[:] = [e for e in _FLAT_MIRRORS if e[0]() is not None]      # buffers that are gone take their mirrors along
-    _FLAT_MIRRORS.append([weakref.ref(flat), {}, -1, -1, {}])
+    _FLAT_MIRRORS.append([weakref.ref(flat), {}, -1, -1, {}, [weakref.ref(q) for q in params]])
 
 
 def _from_flat_mirror(t, dtype):
@@ -50,12 +50,13 @@ def _from_flat_mirror(t, dtype):
             if mirror is None:
                 mirror = ent[1][dtype] = torch.empty_like(flat, dtype=dtype)
                 ent[2] = -1
-            if ent[2] != flat._version or ent[3] != _CAST_EPOCH or ent[4].get(id(t), t._version) != t._version:
+            if ent[2] != flat._version or ent[3] != _CAST_EPOCH or ent[4].get(id(t)) != t._version:
                 for mm in ent[1].values():
                     mm.copy_(flat)                               # one kernel for every parameter of the model
                 ent[2], ent[3] = flat._version, _CAST_EPOCH
-                ent[4].clear()
-            ent[4][id(t)] = t._version                           # load_state_dict writes through the parameter, not flat
+                # load_state_dict writes through the parameters, not through flat: remember every version as of now
+                ent[4] = {id(q()): q()._version for q in ent[5] if q() is not None}
+                ent[4][id(t)] = t._version
             return mirror[off // 4: off // 4 + t.numel()].view(t.shape)
     return None
 

@@ -157,3 +157,40 @@ def test_flat_adam_matches_torch_adam():
     assert all(p.data_ptr() >= bucket.flat_param.data_ptr() for p in b.parameters())
     b.load_state_dict(a.state_dict())
     assert torch.equal(bucket.flat_param[:35].view(7, 5), a[0].weight)
+
+
+def test_low_precision_weight_copies_are_refreshed_in_place():
+    """pointwise.cast_cached: a cached bf16 copy keeps its storage for life (a captured hipGraph may hold the address)
+    and is re-cast in place when the source changed or after invalidate_casts(); parameters moved into one flat buffer
+    (dp.flatten_parameters) get views of ONE mirror refreshed as a whole."""
+    from fgnn_amd.dp import flatten_parameters
+    from fgnn_amd.mpnn import pointwise
+    w = torch.nn.Parameter(torch.randn(8, 4))
+    c1 = pointwise.cast_cached(w, torch.bfloat16)
+    assert c1.dtype == torch.bfloat16 and torch.equal(c1, w.detach().bfloat16())
+    assert pointwise.cast_cached(w, torch.bfloat16) is c1 and pointwise.cast_cached(w, torch.float32) is w
+    ptr = c1.data_ptr()
+    with torch.no_grad():
+        w.mul_(2)                                             # version bump
+    c2 = pointwise.cast_cached(w, torch.bfloat16)
+    assert c2 is c1 and c2.data_ptr() == ptr and torch.equal(c2, w.detach().bfloat16())
+    w.data.add_(1)                                            # no version bump: needs the explicit invalidation
+    pointwise.invalidate_casts()
+    c3 = pointwise.cast_cached(w, torch.bfloat16)
+    assert c3 is c1 and torch.equal(c3, w.detach().bfloat16())
+    # flat mirror
+    lin = torch.nn.Sequential(torch.nn.Linear(4, 3), torch.nn.Linear(3, 2))
+    flat = flatten_parameters(lin.parameters())
+    ps = list(lin.parameters())
+    assert flat.numel() == sum(p.numel() for p in ps) and all(p.data_ptr() >= flat.data_ptr() for p in ps)
+    m0 = pointwise.cast_cached(ps[0], torch.bfloat16)
+    m2 = pointwise.cast_cached(ps[2], torch.bfloat16)
+    assert m0.shape == ps[0].shape and torch.equal(m0, ps[0].detach().bfloat16()) and torch.equal(m2, ps[2].detach().bfloat16())
+    assert m2.data_ptr() - m0.data_ptr() == (ps[2].data_ptr() - ps[0].data_ptr()) // 2      # views of one mirror
+    with torch.no_grad():
+        flat.mul_(3)                                          # what a flat optimizer does
+    pointwise.invalidate_casts()
+    m0b = pointwise.cast_cached(ps[0], torch.bfloat16)
+    assert m0b.data_ptr() == m0.data_ptr() and torch.equal(m0b, ps[0].detach().bfloat16()) and torch.equal(m2, ps[2].detach().bfloat16())
+    lin.load_state_dict({k: v * 0 + 1 for k, v in lin.state_dict().items()})             # writes through the parameters
+    assert torch.equal(pointwise.cast_cached(ps[1], torch.bfloat16), torch.ones_like(ps[1]).bfloat16())
