@@ -31,5 +31,7 @@ class StepGraph:
 
     def replay(self):
         self.graph.replay()
+        from .mpnn import pointwise
+        pointwise.note_state_change()       # the replayed kernels may have changed parameters / BatchNorm buffers
 
     __call__ = replay

@@ -10,6 +10,7 @@ import torch
 from .message_op import base_mp_nn, mp_conv_type, mp_conv_v2
 from .. import ops
 from .pointwise import BatchNormAct2d, NodeInstanceNorm, PointwiseConv2d, as_addends
+from .pointwise import state_epoch as pointwise_state_epoch
 
 
 def _conv_norm_act(cin, cout, norm, act, bias=True):
@@ -130,7 +131,7 @@ class mp_conv_residual(base_mp_nn):
         key = tuple(t._version for t in (self.conv1[0].weight, self.conv1[0].bias, bn1.weight, bn1.bias, bn1.running_mean,
                                          bn1.running_var, mp.filters, mp.bias, bn2.weight, bn2.bias, bn2.running_mean,
                                          bn2.running_var, self.conv2[0].weight, self.conv2[0].bias, bn3.weight, bn3.bias,
-                                         bn3.running_mean, bn3.running_var)) + (x.device,)
+                                         bn3.running_mean, bn3.running_var)) + (x.device, pointwise_state_epoch())
         if getattr(self, '_fuse_key', None) != key:
             def fold(bn, bias):
                 s = bn.weight.float() * torch.rsqrt(bn.running_var.float() + bn.eps)

@@ -29,6 +29,22 @@ def invalidate_casts():
     replay casts the current parameters."""
     global _CAST_EPOCH
     _CAST_EPOCH += 1
+    note_state_change()
+
+
+_STATE_EPOCH = 0          # bumped whenever this package changes parameters / buffers behind torch's version counters
+
+
+def note_state_change():
+    """Kernels write BatchNorm running statistics through raw pointers and flat optimizers update parameters through
+    an alias: neither bumps the tensors' version counters.  Everything derived from them and cached across calls
+    (folded eval-mode BatchNorm affines, the one-kernel inference block's weights) keys on this counter as well."""
+    global _STATE_EPOCH
+    _STATE_EPOCH += 1
+
+
+def state_epoch():
+    return _STATE_EPOCH
 
 
 def register_flat_parameters(flat, params=()):
@@ -329,6 +345,7 @@ class _BatchNormAct(torch.autograd.Function):
                           _hip._ptr(stats[2]), _hip._ptr(stats[3]), _hip._ptr(nbt), _hip._ptr(ws), ws.numel() * 4,
                           _hip.stream_ptr())))
         y = torch.empty_like(rows)
+        note_state_change()                             # running statistics / num_batches_tracked were just updated in place
         ctx.has_addend = tuple(a is not None for a in (addend, addend2, addend3))
         ops.timed('bn_apply (forward)', (2 + sum(ctx.has_addend)) * rows.numel() * rows.element_size(),
                   lambda: _hip.check(L.fgnn_bn_apply(_hip._ptr(rows), _hip._ptr(y), R, C, dt, _hip._ptr(stats[2]),
@@ -420,7 +437,7 @@ class BatchNormAct2d(torch.nn.BatchNorm2d):
     def _folded(self):
         """Eval-mode BatchNorm as (scale, shift); recomputed only when a parameter / buffer changed."""
         key = (self.weight._version, self.bias._version, self.running_mean._version, self.running_var._version,
-               self.weight.device)
+               self.weight.device, state_epoch())
         if getattr(self, '_fold_key', None) != key:
             with torch.no_grad():
                 scale = self.weight.float() * torch.rsqrt(self.running_var.float() + self.eps)

@@ -592,3 +592,56 @@ def test_graph_replayed_training_equals_eager_training_bitwise(dev):
     pg, bg = train(True)
     assert torch.equal(pe, pg)
     assert all(torch.equal(be[k], bg[k]) for k in be)
+
+
+def test_inference_after_training_sees_the_trained_state(dev):
+    """eval -> train -> eval on one model: the second evaluation must use the updated parameters and BatchNorm running
+    statistics although kernels and the flat optimizer changed them behind torch's version counters (cached folded
+    BatchNorm affines / one-kernel block weights key on pointwise.state_epoch()).  Checked against a fresh copy of the
+    model that loads the trained state_dict."""
+    import fgnn_amd
+    from fgnn_amd.dp import FlatAdam, FlatGradBucket
+    from fgnn_amd.graph import StepGraph
+    from fgnn_amd.ldpc import synthetic_batch
+    data = synthetic_batch(256, dev, seed=51, dtype=torch.bfloat16)
+    torch.manual_seed(5)
+    m = fgnn_amd.LDPCModel(2, 6, 4).to(dev)
+    bucket = FlatGradBucket(m.parameters(), flatten_params=True)
+    opt = FlatAdam(bucket, lr=1e-2)
+
+    def infer(model):
+        model.eval()
+        with torch.no_grad(), torch.autocast('cuda', dtype=torch.bfloat16):
+            return model(*data[:6])[0].float().clone()
+
+    def compute():
+        bucket.zero()
+        with torch.autocast('cuda', dtype=torch.bfloat16):
+            logits, snr = m(*data[:6])
+        (torch.nn.functional.binary_cross_entropy_with_logits(logits.float(), data[6]) + 0.1 * snr.float().pow(2).mean()).backward()
+
+    y0 = infer(m)
+    m.train()
+    for _ in range(2):
+        compute()
+        opt.step()
+    y1 = infer(m)
+    assert not torch.equal(y1, y0)
+    fresh = fgnn_amd.LDPCModel(2, 6, 4).to(dev)
+    fresh.load_state_dict(m.state_dict())
+    assert torch.equal(infer(fresh), y1)
+    # ... also when the training steps are graph replays
+    m.train()
+    graph = StepGraph(compute)
+    for _ in range(2):
+        graph.replay()
+        opt.step()
+    y2 = infer(m)
+    fresh.load_state_dict(m.state_dict())
+    assert not torch.equal(y2, y1) and torch.equal(infer(fresh), y2)
+    m.train()
+    graph.replay()
+    opt.step()
+    y3 = infer(m)
+    fresh.load_state_dict(m.state_dict())
+    assert torch.equal(infer(fresh), y3) and not torch.equal(y3, y2)
