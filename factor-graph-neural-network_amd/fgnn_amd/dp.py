@@ -112,6 +112,7 @@ class FlatAdam:
         p.addcdiv_(self.exp_avg, denom, value=-self.lr / bc1)
         from .mpnn import pointwise
         pointwise.invalidate_casts()
+        pointwise.note_state_change()
 
     def zero_grad(self, set_to_none=False):
         self.bucket.zero()

@@ -29,7 +29,6 @@ def invalidate_casts():
     replay casts the current parameters."""
     global _CAST_EPOCH
     _CAST_EPOCH += 1
-    note_state_change()
 
 
 _STATE_EPOCH = 0          # bumped whenever this package changes parameters / buffers behind torch's version counters
