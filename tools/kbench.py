@@ -11,7 +11,7 @@ sys.path.insert(0, os.path.join(ROOT, 'factor-graph-neural-network_amd'))
 import torch  # noqa: E402
 from fgnn_amd import _hip, ops  # noqa: E402
 
-SHAPES = [  # (name, nin, nou, net, N, M, k)
+SHAPES = [  # (name, nin, nou, net, N, M, k[, extension, aggregator])
     ('parity V->F 64->64', 64, 64, 4, 96, 48, 6),
     ('parity F->V 64->64', 64, 64, 4, 48, 96, 3),
     ('parity V->F 64->128', 64, 128, 4, 96, 48, 6),
@@ -24,6 +24,12 @@ SHAPES = [  # (name, nin, nou, net, N, M, k)
     ('hyper  F->V 64->128', 64, 128, 1, 1, 96, 1),
     ('hyper  V->F 128->64', 128, 64, 1, 96, 1, 96),
     ('hyper  F->V 128->64', 128, 64, 1, 1, 96, 1),
+    # BASELINE configs 2 / 5: factor_mpnn on 30-node synthetic PGMs (30 variables + 30 factors per graph, 16 edge types,
+    # ORIG_WITH_DIFF extension; pairwise factors k = 2, degree-9 high-order factors k = 9); run with --dtype f32 --batch 256 / 1024
+    ('syn pw  64->64 max', 64, 64, 16, 60, 60, 2, 2, 0),
+    ('syn pw  64->128 lse', 64, 128, 16, 60, 60, 2, 2, 1),
+    ('syn hop 64->64 max', 64, 64, 16, 60, 60, 9, 2, 0),
+    ('syn hop 128->128 max', 128, 128, 16, 60, 60, 9, 2, 0),
 ]
 
 
@@ -35,12 +41,17 @@ def main():
     ap.add_argument('--layout', default='cl', choices=['cl', 'nchw'])
     ap.add_argument('--bwd', action='store_true')
     ap.add_argument('--only', default='')
+    ap.add_argument('--syn', action='store_true', help='the synthetic-PGM shapes instead of the LDPC ones')
     ap.add_argument('--etgrad', action='store_true', help='hyper shapes: also ask for the edge-weight gradient')
     a = ap.parse_args()
     dev = torch.device('cuda:0')
     dt = torch.float32 if a.dtype == 'f32' else torch.bfloat16
-    for name, nin, nou, net, N, M, k in SHAPES:
+    for shape in SHAPES:
+        name, nin, nou, net, N, M, k = shape[:7]
+        ext, agg = (shape[7], shape[8]) if len(shape) > 7 else (0, _hip.AGG_MAX)
         if a.only and a.only not in name:
+            continue
+        if not a.only and (name.startswith('syn') != a.syn):
             continue
         g = torch.Generator(device='cpu').manual_seed(0)
         B = a.batch
@@ -52,26 +63,26 @@ def main():
             et = torch.ones(1, 1, M, k, device=dev, dtype=dt).expand(B, -1, -1, -1)
         else:
             et = torch.randn(B, M, k, net, generator=g).to(dev, dt).permute(0, 3, 1, 2)
-        W = (torch.randn(nin, nou * net, generator=g) * 0.1).to(dev)
+        W = (torch.randn(nin * (1 if ext == 0 else 2), nou * net, generator=g) * 0.1).to(dev)
         bias = torch.randn(nou, generator=g).to(dev)
-        nbytes = ops.algorithmic_bytes(x, idx, et, nou, net, 0, 0)
+        nbytes = ops.algorithmic_bytes(x, idx, et, nou, net, ext, agg)
         flops = 2.0 * B * N * nin * nou * net + 2.0 * B * M * k * nou * net
 
         def fwd():
-            return ops.mpconv_forward_raw(x, idx, et, W, bias, nou, net, 0, _hip.AGG_MAX, want_argmax=a.bwd)
+            return ops.mpconv_forward_raw(x, idx, et, W, bias, nou, net, ext, agg, want_argmax=a.bwd)
 
         if not a.bwd:
             run = fwd
         else:
             import ctypes
             L = _hip.lib()
-            y, amax = ops.mpconv_forward_raw(x, idx, et, W, bias, nou, net, 0, _hip.AGG_MAX, want_argmax=True)
+            y, amax = ops.mpconv_forward_raw(x, idx, et, W, bias, nou, net, ext, agg, want_argmax=True)
             gz = torch.randn_like(y)
             gx = torch.empty_like(x)
             get = None if (net == 1 and not a.etgrad) else torch.empty((B, net, M, k), device=dev, dtype=dt)
             gw = torch.zeros_like(W)
             gb = torch.zeros(nou, device=dev)
-            dsc = _hip.make_desc(x, idx, et, nou, net, 0, _hip.AGG_MAX, False, gz)
+            dsc = _hip.make_desc(x, idx, et, nou, net, ext, agg, False, gz)
             nbytes = (x.element_size() * (x.numel() + gz.numel()) + et.element_size() * net * M * k *
                       (1 if et.stride(0) == 0 else B) + 8 * M * k + B * nou * M + x.element_size() * (gx.numel() + (get.numel() if get is not None else 0))
                       + 8 * W.numel())
