@@ -58,6 +58,10 @@ class FlatGradBucket:
             n = p.numel()
             p.grad = self.flat[off:off + n].view_as(p)
             off += n
+        # the gradient kernels may add straight into these slices (ops.grad_sink): the bucket's contract is a plain
+        # loss.backward() per step, which is what makes that safe
+        from . import ops
+        ops.enable_grad_sink(self.params)
 
     def zero(self):
         self.flat.zero_()

@@ -33,5 +33,6 @@ class StepGraph:
         self.graph.replay()
         from .mpnn import pointwise
         pointwise.note_state_change()       # the replayed kernels may have changed parameters / BatchNorm buffers
+        pointwise.invalidate_casts()        # ... and with them the low-precision weight copies eager code reads next
 
     __call__ = replay

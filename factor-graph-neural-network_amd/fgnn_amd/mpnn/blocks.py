@@ -9,7 +9,7 @@ import torch
 
 from .message_op import base_mp_nn, mp_conv_type, mp_conv_v2
 from .. import ops
-from .pointwise import BatchNormAct2d, NodeInstanceNorm, PointwiseConv2d, as_addends
+from .pointwise import BatchNormAct2d, NodeInstanceNorm, PointwiseConv2d, as_addends, refresh_in_place
 from .pointwise import state_epoch as pointwise_state_epoch
 
 
@@ -140,9 +140,10 @@ class mp_conv_residual(base_mp_nn):
             s1, t1 = fold(bn1, self.conv1[0].bias)
             s2, t2 = fold(bn2, mp.bias)
             s3, t3 = fold(bn3, self.conv2[0].bias)
-            self._fuse = (self.conv1[0].weight.detach().float().reshape(64, nin).contiguous(), s1, t1,
-                          mp.filters.detach().float().contiguous(), s2, t2,
-                          self.conv2[0].weight.detach().float().reshape(nout, 64).contiguous(), s3, t3)
+            self._fuse = refresh_in_place(getattr(self, '_fuse', None), (
+                self.conv1[0].weight.detach().float().reshape(64, nin), s1, t1,
+                mp.filters.detach().float(), s2, t2,
+                self.conv2[0].weight.detach().float().reshape(nout, 64), s3, t3))
             self._fuse_key = key
         W1, s1, t1, F, s2, t2, W2, s3, t3 = self._fuse
         y = torch.empty((B, M, 1, nout), device=x.device, dtype=x.dtype).permute(0, 3, 1, 2)

@@ -74,10 +74,8 @@ class mp_conv_v2(base_mp_nn):
             print('aggregator = ', aggregtor)           # the reference announces it too
             if aggregtor not in _hip.AGG_CODES:
                 raise ValueError("aggregator must be 'max', 'softmax' or 'mean', got %r" % aggregtor)
-        else:
-            raise NotImplementedError(
-                'the fused HIP operator implements the string aggregators max/softmax/mean; '
-                'callable or None aggregators (mp_nn.py:89-90) are outside the MI355X hot path')
+        elif aggregtor is not None and not callable(aggregtor):
+            raise ValueError('aggregtor must be a string, a callable on [B, nou, M, k] or None, got %r' % (aggregtor,))
         self.aggregtor = aggregtor
 
     def extra_repr(self):
@@ -87,6 +85,8 @@ class mp_conv_v2(base_mp_nn):
     def forward(self, x, nn_idx, etype, addend=None):
         """``addend``: optional tensor of the output's shape (or a list of them) added after the activation (fused
         into the BatchNorm kernel when training with the plain ReLU)."""
+        if not isinstance(self.aggregtor, str):
+            return self._forward_custom_aggregator(x, nn_idx, etype, addend)
         ext, agg = _EXT_CODE[self.extension], _hip.AGG_CODES[self.aggregtor]
         needs_grad = torch.is_grad_enabled() and (
             x.requires_grad or etype.requires_grad or self.filters.requires_grad)
@@ -118,3 +118,39 @@ class mp_conv_v2(base_mp_nn):
         if self.activation_fn is not None:
             z = self.activation_fn(z)
         return add_all(z, addend)
+
+    def edge_messages(self, x, nn_idx, etype):
+        """Un-aggregated messages E [B, nou, M, k] (mp_nn.py:127-160) through the HIP operator: every edge becomes
+        its own single-neighbour destination (an aggregate over one neighbour is the message itself).  The
+        self / neighbour split of the two extensions turns into two such calls on slices of ``filters``:
+        NEIGHBOR  E = et.(x_i W_top + x_j W_bot);   DIFF  E = et.(x_i (W_top + W_bot) - x_j W_bot)."""
+        B, M, k = nn_idx.shape
+        net, nou, nin = self.nedge_types, self.nou, self.nin
+        flat_idx = nn_idx.reshape(B, M * k, 1)
+        flat_et = etype.reshape(B, net, M * k, 1)
+        one = lambda idx, W: ops.mpconv(x, idx, flat_et, W, None, nou, net, _hip.EXT_NONE, _hip.AGG_MAX)
+        if self.extension == mp_conv_type.NO_EXTENSION:
+            e = one(flat_idx, self.filters)
+        else:
+            own = torch.arange(M, device=x.device, dtype=nn_idx.dtype).repeat_interleave(k).reshape(1, M * k, 1)
+            own = own.expand(B, -1, -1)
+            top, bot = self.filters[:nin], self.filters[nin:]
+            if self.extension == mp_conv_type.ORIG_WITH_NEIGHBOR:
+                e = one(own, top) + one(flat_idx, bot)
+            else:
+                e = one(own, top + bot) - one(flat_idx, bot)
+        return e.reshape(B, nou, M, k)
+
+    def _forward_custom_aggregator(self, x, nn_idx, etype, addend=None):
+        """``aggregtor`` given as a callable on [B, nou, M, k], or None = no aggregation (mp_nn.py:89-90,162-163): the
+        messages come from the HIP operator, the user's reduction and the epilogue are torch ops."""
+        z = self.edge_messages(x, nn_idx, etype)
+        if self.aggregtor is not None:
+            z = self.aggregtor(z)
+        if self.bias is not None:
+            z = z + self.bias.view(1, self.nou, 1, 1).to(z.dtype)
+        if self.bn is not None:
+            z = self.bn(z)
+        if self.activation_fn is not None:
+            z = self.activation_fn(z)
+        return add_all(z, addend() if callable(addend) else addend)

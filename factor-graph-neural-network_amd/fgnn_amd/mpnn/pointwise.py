@@ -16,7 +16,7 @@ import torch
 from .. import _hip
 
 
-_CAST_CACHE = {}          # id(tensor) -> [tensor, version, epoch, low-precision copy]
+_CAST_CACHE = {}          # id(tensor) -> [weakref(tensor), version, epoch, low-precision copy]
 _CAST_EPOCH = 0
 _FLAT_MIRRORS = []        # [flat f32 buffer (weak), {dtype: mirror}, version, epoch, {id(param): version}, params (weak)]
 
@@ -44,6 +44,19 @@ def note_state_change():
 
 def state_epoch():
     return _STATE_EPOCH
+
+
+def refresh_in_place(old, new):
+    """Derived constants cached across calls (folded BatchNorm affines, the one-kernel blocks' weight images) keep their
+    STORAGE when they are recomputed: an inference hipGraph captured earlier holds these addresses, so a refresh must
+    land in the same memory instead of freeing it.  Returns the tuple to keep."""
+    new = tuple(t.contiguous() for t in new)
+    if old is not None and len(old) == len(new) and all(
+            o.shape == n.shape and o.dtype == n.dtype and o.device == n.device for o, n in zip(old, new)):
+        for o, n in zip(old, new):
+            o.copy_(n)
+        return old
+    return new
 
 
 def register_flat_parameters(flat, params=()):
@@ -88,13 +101,14 @@ def cast_cached(t, dtype):
             return v
     key = id(t)
     hit = _CAST_CACHE.get(key)
-    if hit is not None and hit[0] is t and hit[3].dtype == dtype and hit[3].device == t.device and hit[3].shape == t.shape:
+    if hit is not None and hit[0]() is t and hit[3].dtype == dtype and hit[3].device == t.device and hit[3].shape == t.shape:
         if hit[1] != t._version or hit[2] != _CAST_EPOCH:
             hit[3].copy_(t.detach())
             hit[1], hit[2] = t._version, _CAST_EPOCH
         return hit[3]
     out = t.detach().to(dtype)
-    _CAST_CACHE[key] = [t, t._version, _CAST_EPOCH, out]
+    # the source is held weakly: when the parameter dies its entry (and the copy) goes with it
+    _CAST_CACHE[key] = [weakref.ref(t, lambda _, key=key: _CAST_CACHE.pop(key, None)), t._version, _CAST_EPOCH, out]
     return out
 
 
@@ -232,8 +246,14 @@ class PointwiseConv2d(torch.nn.Conv2d):
                 weight.requires_grad or rows.requires_grad):
             y = _RowLinear.apply(rows, weight, self.bias, want_stats)
         else:
-            y = hip_linear(rows, weight, self.bias) if rows.is_cuda else None
-            if y is None:
+            needs_grad = torch.is_grad_enabled() and (weight.requires_grad or rows.requires_grad)
+            y = hip_linear(rows, weight, self.bias) if rows.is_cuda and not needs_grad else None
+            if y is None and needs_grad:
+                # dtypes / devices outside the hand-written path (f64 gradcheck, fp16 autocast, CPU bf16): a plain
+                # differentiable cast — never the detached cached copies, which would train with zero weight gradients
+                b = None if self.bias is None else self.bias.to(rows.dtype)
+                y = torch.nn.functional.linear(rows, weight.to(rows.dtype), b)
+            elif y is None:
                 w = cast_cached(self.weight, rows.dtype).view(self.out_channels, C)
                 b = cast_cached(self.bias, rows.dtype)
                 y = torch.nn.functional.linear(rows, w, b)
@@ -405,8 +425,10 @@ class BatchNormAct2d(torch.nn.BatchNorm2d):
         if len(addends) > 3:
             from ..ops import add_n
             addends = addends[:2] + [add_n(addends[2:])]
+        # momentum=None (cumulative average) and a one-value batch in training mode (torch raises) stay with torch
         ok = (x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and self.track_running_stats and
-              self.affine and _hip.lib().fgnn_bn_supported(B * H * W, C, _hip.dtype_code(x)))
+              self.affine and self.momentum is not None and (not self.training or B * H * W > 1) and
+              _hip.lib().fgnn_bn_supported(B * H * W, C, _hip.dtype_code(x)))
         wants_grad = torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad or
                                                   any(a.requires_grad for a in addends))
         if not ok or (not self.training and wants_grad):
@@ -441,5 +463,6 @@ class BatchNormAct2d(torch.nn.BatchNorm2d):
             with torch.no_grad():
                 scale = self.weight.float() * torch.rsqrt(self.running_var.float() + self.eps)
                 shift = self.bias.float() - self.running_mean.float() * scale
-            self._fold_key, self._fold = key, (scale.contiguous(), shift.contiguous())
+            self._fold_key = key
+            self._fold = refresh_in_place(getattr(self, '_fold', None), (scale, shift))
         return self._fold

@@ -9,6 +9,7 @@ ReLU) in one kernel launch through the C ABI, and differentiates through a hand-
 backward kernel.  Reference semantics: /root/reference/lib/model/mpnn/mp_nn.py:115-175.
 """
 import ctypes
+import os
 
 import torch
 
@@ -113,6 +114,27 @@ def _check_shapes(x, nn_idx, etype, filters, nou, net, ext):
         raise ValueError('filters must be [%d, %d], got %s' % (R, nou * net, tuple(filters.shape)))
     if etype.dtype != x.dtype:
         raise ValueError('x and etype must share a dtype (%s vs %s)' % (x.dtype, etype.dtype))
+    if CHECK_INDICES:
+        _check_index_range(nn_idx, x.shape[2])
+
+
+CHECK_INDICES = bool(int(os.environ.get('FGNN_CHECK_INDICES', '0')))
+
+
+def _check_index_range(nn_idx, N):
+    """Debug aid (FGNN_CHECK_INDICES=1): the kernels CLAMP neighbour ids into [0, N) so that a bad table can never
+    fault; the reference's ``torch.gather`` raises instead (CPU) or device-asserts (CUDA).  With the check on, an
+    out-of-range table raises IndexError here — one device reduction + host sync per distinct table, remembered on the
+    tensor that owns the memory (same scheme as blocks._is_identity_list)."""
+    owner = nn_idx._base if nn_idx._base is not None else nn_idx
+    key = (nn_idx._version, nn_idx.storage_offset(), tuple(nn_idx.shape), tuple(nn_idx.stride()), N)
+    memo = getattr(owner, '_fgnn_index_range', None)
+    if memo is None or memo[0] != key:
+        lo, hi = (int(v) for v in torch.aminmax(nn_idx)) if nn_idx.numel() else (0, 0)
+        memo = (key, lo, hi)
+        owner._fgnn_index_range = memo
+    if memo[1] < 0 or memo[2] >= N:
+        raise IndexError('nn_idx holds neighbour ids in [%d, %d] but x has %d nodes' % (memo[1], memo[2], N))
 
 
 def mpconv_forward_raw(x, nn_idx, etype, filters, bias, nou, net, ext, agg, *,
@@ -156,13 +178,16 @@ def mpconv_forward_raw(x, nn_idx, etype, filters, bias, nou, net, ext, agg, *,
 def grad_sink(param):
     """``param.grad`` when a kernel may accumulate straight into it, else None.
 
-    Every gradient kernel of this package ACCUMULATES into its filter / bias outputs.  When a leaf
-    parameter already owns a dense f32 ``.grad`` (a slice of ``dp.FlatGradBucket``, or last step's
-    gradient under plain accumulation) the kernel adds into it directly and the autograd Function
-    returns None for that input — same value autograd's AccumulateGrad would produce, minus one
-    zero-fill, one add and one cast per parameter per step.  (Tensor hooks on such a parameter do not
-    fire; set ``ops.ACCUMULATE_INTO_GRAD = False`` to get ordinary returned gradients.)"""
-    if not ACCUMULATE_INTO_GRAD or param is None or not param.is_leaf or not param.requires_grad:
+    Every gradient kernel of this package ACCUMULATES into its filter / bias outputs.  For a parameter that has
+    been OPTED IN (``enable_grad_sink``; ``dp.FlatGradBucket`` does it for the parameters whose ``.grad`` are slices
+    of its flat buffer) the kernel adds into ``.grad`` directly and the autograd Function returns None for that
+    input — the value autograd's AccumulateGrad would produce, minus one zero-fill, one add and one cast per
+    parameter per step.  The price of opting in: gradients reach such a parameter only through a plain
+    ``loss.backward()`` — ``torch.autograd.grad``, ``backward(inputs=...)`` and tensor hooks do not see them.  Without
+    the opt-in (the default for a bare module) gradients are returned to autograd like any other Function's."""
+    if not ACCUMULATE_INTO_GRAD or param is None or not getattr(param, '_fgnn_grad_sink', False):
+        return None
+    if not param.is_leaf or not param.requires_grad:
         return None
     g = param.grad
     if (g is None or g.dtype != torch.float32 or not g.is_contiguous() or g.device != param.device
@@ -171,7 +196,13 @@ def grad_sink(param):
     return g
 
 
-ACCUMULATE_INTO_GRAD = True
+def enable_grad_sink(params, on=True):
+    """Opt parameters in to (or out of) in-place gradient accumulation by the kernels (see ``grad_sink``)."""
+    for q in params:
+        q._fgnn_grad_sink = bool(on)
+
+
+ACCUMULATE_INTO_GRAD = True      # master switch for the opted-in parameters (False: always return gradients)
 STATS_EPILOGUE = True    # the operator's forward leaves the following BatchNorm's batch statistics
 _WS = {}
 
@@ -179,13 +210,22 @@ _WS = {}
 def _workspace(device, nbytes):
     """One grow-only scratch buffer per (device, stream) for the per-workgroup gradient slabs and statistics
     partials (reused by every call on that stream; contents are undefined between calls).  Per stream because
-    FactorNN runs the hyper-factor branch of a layer on a side stream next to the parity-check branch."""
+    FactorNN runs the hyper-factor branch of a layer on a side stream next to the parity-check branch.  A buffer
+    that was handed out while a hipGraph was being captured is never freed: the graph holds its address, so when a
+    later, larger request outgrows it the old block is retired to ``_WS_CAPTURED`` (kept alive) instead of released."""
     key = (device, torch.cuda.current_stream(device).cuda_stream)
-    buf = _WS.get(key)
-    if buf is None or buf.numel() * 4 < nbytes:
-        buf = torch.empty((nbytes + 3) // 4, device=device, dtype=torch.float32)
-        _WS[key] = buf
-    return buf
+    ent = _WS.get(key)
+    capturing = torch.cuda.is_current_stream_capturing()
+    if ent is None or ent[0].numel() * 4 < nbytes:
+        if ent is not None and ent[1]:
+            _WS_CAPTURED.append(ent[0])
+        ent = _WS[key] = [torch.empty((nbytes + 3) // 4, device=device, dtype=torch.float32), capturing]
+    elif capturing:
+        ent[1] = True
+    return ent[0]
+
+
+_WS_CAPTURED = []       # workspaces whose addresses live in captured graphs
 
 
 _SIDE = {}

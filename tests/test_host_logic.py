@@ -194,3 +194,100 @@ def test_low_precision_weight_copies_are_refreshed_in_place():
     assert m0b.data_ptr() == m0.data_ptr() and torch.equal(m0b, ps[0].detach().bfloat16()) and torch.equal(m2, ps[2].detach().bfloat16())
     lin.load_state_dict({k: v * 0 + 1 for k, v in lin.state_dict().items()})             # writes through the parameters
     assert torch.equal(pointwise.cast_cached(ps[1], torch.bfloat16), torch.ones_like(ps[1]).bfloat16())
+
+
+# ---------------------------------------------------------------------------------------------
+# drop-in shim: the import lines of the reference's four scripts, executed against lib.model.mpnn
+# ---------------------------------------------------------------------------------------------
+SCRIPT_IMPORT_LINES = [
+    # train_ldpc.py:13
+    'from lib.model.mpnn import factor_mpnn, FactorNN',
+    # train_syn_fixed_pw_hop.py:9
+    'from lib.model.mpnn import mp_sequential, mp_conv_residual, mp_conv_type, mp_conv_v2, global_pooling',
+    # train_syn_hop_factor.py:8, train_syn_pw_factor.py:8
+    'from lib.model.mpnn import factor_mpnn',
+    # lib/model/mpnn/__init__.py:1-7, the package's full export list
+    'from lib.model.mpnn import (mp_conv_v2, mp_conv_type, mp_conv_residual, mp_ensemble, mp_sequential, '
+    'global_pooling, factor_mpnn, FactorNN)',
+]
+
+
+@pytest.mark.parametrize('line', SCRIPT_IMPORT_LINES)
+def test_reference_script_import_lines_resolve_through_the_shim(line):
+    import fgnn_amd.mpnn as native
+    scope = {}
+    exec(line, scope)                                   # noqa: S102 — the literal import statement of the script
+    names = [n for n in scope if not n.startswith('__')]
+    assert names
+    for n in names:
+        assert scope[n] is getattr(native, n), n        # the MI355X-native class, not a stand-in
+
+
+def test_global_pooling_and_ensemble_follow_the_reference_contract():
+    """pooling.py:11-47 / ensemble.py:8-19: pooled feature of the INPUT broadcast to every node and concatenated on
+    the channel axis; the ensemble concatenates two graph branches.  (Glue modules: torch ops, CPU-testable.)"""
+    from fgnn_amd.mpnn import base_mp_nn, global_pooling, mp_ensemble, parallel_net, identity_module
+    torch.manual_seed(0)
+    x = torch.randn(3, 5, 7, 1)
+    idx, et = torch.zeros(3, 7, 2, dtype=torch.int64), torch.zeros(3, 1, 7, 2)
+    gp = global_pooling()
+    assert isinstance(gp, base_mp_nn) and gp.is_mp_nn
+    y = gp(x, idx, et)
+    assert y.shape == (3, 10, 7, 1) and torch.equal(y[:, :5], x)
+    assert torch.equal(y[:, 5:], x.max(dim=2, keepdim=True)[0].repeat(1, 1, 7, 1))
+
+    class Twice(base_mp_nn):
+        def forward(self, x, nn_idx, etype):
+            return 2 * x
+
+    gmap = torch.nn.Conv2d(5, 4, 1)
+    gp = global_pooling(orig_mapper=Twice(), gfeature_mapper=gmap)
+    assert sorted(k.split('.')[0] for k in gp.state_dict()) == ['gfeature_mapper', 'gfeature_mapper']
+    y = gp(x, idx, et)
+    assert torch.equal(y[:, :5], 2 * x)
+    assert torch.allclose(y[:, 5:], gmap(x.max(dim=2, keepdim=True)[0]).repeat(1, 1, 7, 1))
+    ens = mp_ensemble(Twice(), Twice(), torch.nn.Conv2d(10, 3, 1))
+    assert ens(x, idx, et, idx, et).shape == (3, 3, 7, 1)
+    par = parallel_net(Twice(), identity_module())
+    assert torch.equal(par(x, idx, et), 3 * x)
+
+
+def test_callable_and_none_aggregators_are_accepted():
+    """mp_nn.py:89-90: any callable (or None) is a legal aggregator; construction must not raise."""
+    from fgnn_amd.mpnn import mp_conv_type, mp_conv_v2
+    m = mp_conv_v2(4, 4, 2, extension=mp_conv_type.NO_EXTENSION, aggregtor=lambda e: e.sum(dim=3, keepdim=True))
+    assert callable(m.aggregtor)
+    assert mp_conv_v2(4, 4, 2, aggregtor=None).aggregtor is None
+    with pytest.raises(ValueError):
+        mp_conv_v2(4, 4, 2, aggregtor=3)
+
+
+def test_gradient_sink_is_opt_in():
+    """ops.grad_sink: kernels add into ``param.grad`` only for parameters a FlatGradBucket (or enable_grad_sink) opted in;
+    a bare module with a leftover dense .grad gets ordinary returned gradients (hooks, autograd.grad keep working)."""
+    from fgnn_amd import ops
+    from fgnn_amd.dp import FlatGradBucket
+    lin = torch.nn.Linear(3, 2)
+    lin.weight.grad = torch.zeros_like(lin.weight)
+    assert ops.grad_sink(lin.weight) is None
+    bucket = FlatGradBucket(lin.parameters())
+    assert ops.grad_sink(lin.weight) is lin.weight.grad and lin.weight.grad.data_ptr() == bucket.flat.data_ptr()
+    ops.enable_grad_sink([lin.weight], False)
+    assert ops.grad_sink(lin.weight) is None and ops.grad_sink(lin.bias) is lin.bias.grad
+
+
+def test_pointwise_map_outside_the_hip_path_keeps_weight_gradients():
+    """PointwiseConv2d on a dtype / device the hand-written path does not take (here: float64 on CPU) must stay
+    differentiable w.r.t. its parameters — the cached low-precision copies are detached and only for no-grad paths."""
+    from fgnn_amd.mpnn import PointwiseConv2d
+    torch.manual_seed(0)
+    m = PointwiseConv2d(3, 2).double()
+    x = torch.randn(2, 3, 5, 1, dtype=torch.float64, requires_grad=True)
+    m(x).square().sum().backward()
+    assert m.weight.grad is not None and float(m.weight.grad.abs().sum()) > 0 and m.bias.grad is not None
+    ref = torch.nn.Conv2d(3, 2, 1).double()
+    ref.load_state_dict(m.state_dict())
+    ref(x.detach()).square().sum().backward()
+    assert torch.allclose(m.weight.grad, ref.weight.grad) and torch.allclose(m.bias.grad, ref.bias.grad)
+    with torch.no_grad():                               # no-grad path: cached copy, same values
+        assert torch.allclose(m(x), ref(x))
