@@ -49,6 +49,15 @@ def parse():
     ap.add_argument('--inputs', choices=['channel', 'features'], default='channel',
                     help='channel: encoded codewords through the reference channel (fgnn_amd/datapath.py); '
                          'features: random bits + unit-gain AWGN built with torch ops (ldpc.synthetic_batch)')
+    ap.add_argument('--tables', choices=['shared', 'per_sample'], default='shared',
+                    help="neighbour tables handed to the model: 'shared' = one table expanded over the batch (batch "
+                         "stride 0); 'per_sample' = B materialised copies, the reference's calling convention "
+                         "(train_ldpc.py:209-216) — recognised as one graph by a content check unless --no-dedupe")
+    ap.add_argument('--no-dedupe', action='store_true',
+                    help='with --tables per_sample: switch the content check off, so the kernels take the general '
+                         'per-sample-graph path (a different graph per codeword would run at this speed)')
+    ap.add_argument('--cpu-all-cores', action='store_true',
+                    help='also time the CPU baseline once with every host core (evidence for the --cpu-threads choice)')
     ap.add_argument('--cpu-batch', type=int, default=512)
     ap.add_argument('--cpu-threads', type=int, default=16)
     return ap.parse_args()
@@ -63,7 +72,7 @@ def loss_fn(logits, snr_pred, label, sigma_b):
     return bce + 0.1 * mse
 
 
-def cpu_baseline(batch, mode, threads):
+def cpu_baseline(batch, mode, threads, budget=20.0, max_iters=5):
     """The oracle (reference op order, PyTorch CPU, all host cores) on a bounded sample."""
     sys.path.insert(0, os.path.join(ROOT, 'oracle'))
     import fgnn_oracle as O
@@ -92,9 +101,9 @@ def cpu_baseline(batch, mode, threads):
     t0 = time.time()
     once()
     times = [time.time() - t0]          # kept only if the budget allows nothing else
-    t_end = time.time() + 20.0
+    t_end = time.time() + budget
     fresh = []
-    while len(fresh) < 5 and time.time() + times[0] < t_end:
+    while len(fresh) < max_iters and time.time() + times[0] < t_end:
         t0 = time.time()
         once()
         fresh.append(time.time() - t0)
@@ -156,6 +165,11 @@ def main():
         data = data[:6] + (data[6][:, :48].float().contiguous(), data[7])
     else:
         data = synthetic_batch(args.batch, dev, seed=100 + rank, dtype=dtype)
+    if args.tables == 'per_sample':
+        data = data[:2] + (data[2].contiguous(), data[3].contiguous()) + data[4:]      # B materialised copies
+        assert data[2].stride(0) != 0
+    if args.no_dedupe:
+        ops.DEDUPE_GRAPHS = False
     inputs, label, sigma_b = data[:6], data[6], data[7]
     train = args.mode == 'train'
     model.train(train)
@@ -278,6 +292,10 @@ def main():
     fence()
 
     if rank == 0:
+        tables_note = {'shared': 'graph tables batch-shared (one table, batch stride 0)',
+                       'per_sample': 'graph tables per-sample (B copies, as the reference passes them)%s'
+                                     % (', content check off' if args.no_dedupe else
+                                        ', recognised as one graph by a content check')}[args.tables]
         total_msgs = MESSAGES_PER_CODEWORD * args.batch * world * args.steps
         out = {
             'metric': 'VF+FV messages/sec on 96.3.963 LDPC graph',
@@ -286,9 +304,15 @@ def main():
             'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
             'config': {'workload': 'LDPC 96.3.963 LDPCModel (8 FGNN layers, 32 fused VF/FV operator '
-                                   'calls, 6144 messages/codeword), %s step, batch %d codewords per GPU'
+                                   'calls, 6144 messages/codeword), %s step, batch %d codewords per GPU, %s'
                                    % ('training (fwd+bwd+grad all-reduce+Adam)' if train else
-                                      'inference forward', args.batch),
+                                      'inference forward', args.batch, tables_note),
+                       'tables': args.tables + ('' if args.tables == 'shared' else
+                                                (' (content check off)' if args.no_dedupe else ' (deduplicated by content check)')),
+                       # the 6144 count includes the degree-96 hyper-factor's 2 x 96 edges per layer; parity-check edges
+                       # alone are 8 x (288 + 288) = 4608 per codeword (SURVEY §8d asks for both)
+                       'messages_per_codeword': MESSAGES_PER_CODEWORD, 'parity_messages_per_codeword': 4608,
+                       'parity_only_value': 4608 * args.batch * world * args.steps / elapsed,
                        'global_batch': args.batch * world, 'parallelism': 'dp%d' % world,
                        'inputs': ('random messages -> reference G encode -> AWGN+burst channel, on the GPU'
                                   if args.inputs == 'channel' else 'random bits + AWGN (torch ops)'),
@@ -302,6 +326,9 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args.cpu_batch, args.mode, args.cpu_threads)
+            if args.cpu_all_cores:
+                out['cpu_baseline_all_cores'] = cpu_baseline(args.cpu_batch, args.mode, os.cpu_count() or 1, budget=60.0,
+                                                             max_iters=1)
         else:
             out['cpu_baseline'] = None
         print(json.dumps(out))

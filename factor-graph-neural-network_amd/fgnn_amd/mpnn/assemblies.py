@@ -178,6 +178,10 @@ class FactorNN(torch.nn.Module):
         from .. import ops as _ops
         nft = self.nfactor_types
         nL = len(self.v2f_modules)
+        # the neighbour tables serve all layers: convert once, and recognise B equal copies of one graph (what the
+        # reference's DataLoader collates, train_ldpc.py:209-216) as a table shared by the batch
+        nn_idx_f2v = [_ops.shared_graph_view(t.long()) for t in nn_idx_f2v]
+        nn_idx_v2f = [_ops.shared_graph_view(t.long()) for t in nn_idx_v2f]
         # the edge types feed every layer: one alias per layer, so their gradients meet in one n-way sum
         etype_f2v = [fan_out(e, nL) for e in etype_f2v]
         etype_v2f = [fan_out(e, nL) for e in etype_v2f]
@@ -209,13 +213,13 @@ class FactorNN(torch.nn.Module):
             for j in range(1, nft):
                 with (torch.cuda.stream(side) if two else contextlib.nullcontext()):
                     nf = self.f2f_modules[L][j](fac_c[j][0])
-                    new_fac[j] = _call(self.v2f_modules[L][j], var_c[1 + j], nn_idx_v2f[j].long(), etype_v2f[j][L],
+                    new_fac[j] = _call(self.v2f_modules[L][j], var_c[1 + j], nn_idx_v2f[j], etype_v2f[j][L],
                                        addend=[nf, fac_c[j][-1] if same_width else None, skip[1][j] if skip else None])
-                    h.append(_call(self.f2v_modules[L][j], fac_c[j][1], nn_idx_f2v[j].long(), etype_f2v[j][L]))
+                    h.append(_call(self.f2v_modules[L][j], fac_c[j][1], nn_idx_f2v[j], etype_f2v[j][L]))
             with (torch.cuda.stream(side) if two else contextlib.nullcontext()):
                 new_var = self.v2v_modules[L](var_c[0])        # the variables' node-wise map rides with the side branch
             nf = self.f2f_modules[L][0](fac_c[0][0])
-            new_fac[0] = _call(self.v2f_modules[L][0], var_c[1], nn_idx_v2f[0].long(), etype_v2f[0][L],
+            new_fac[0] = _call(self.v2f_modules[L][0], var_c[1], nn_idx_v2f[0], etype_v2f[0][L],
                                addend=[nf, fac_c[0][-1] if same_width else None, skip[1][0] if skip else None])
             def joined(new_var=new_var, h=h, L=L, same_width=same_width, skip=skip, var_c=var_c):
                 # called by the block right before its closing BatchNorm consumes the addends: only there does the main
@@ -223,7 +227,7 @@ class FactorNN(torch.nn.Module):
                 if two:
                     main.wait_stream(side)
                 return [new_var] + h + [var_c[-1] if same_width else None, skip[0] if skip else None]
-            new_var = _call(self.f2v_modules[L][0], fac_c[0][1], nn_idx_f2v[0].long(), etype_f2v[0][L], addend=joined)
+            new_var = _call(self.f2v_modules[L][0], fac_c[0][1], nn_idx_f2v[0], etype_f2v[0][L], addend=joined)
             var, fac = new_var, new_fac
         out = self.final_classifier(var)
         if self.final_filter is not None:

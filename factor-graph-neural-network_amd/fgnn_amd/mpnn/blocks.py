@@ -179,6 +179,7 @@ class mp_conv_residual(base_mp_nn):
         """``addend`` (optional, the caller's running sum of the same shape as the output — a tensor, a list of tensors,
         or a callable returning either, evaluated right before it is consumed) is added by conv2's fused
         BatchNorm+activation kernel instead of a separate elementwise pass."""
+        nn_idx = ops.shared_graph_view(nn_idx)
         staged = self.training and torch.is_grad_enabled()
         if callable(addend) and not staged:
             addend = addend()                                            # the one-kernel block needs it up front

@@ -137,6 +137,31 @@ def _check_index_range(nn_idx, N):
         raise IndexError('nn_idx holds neighbour ids in [%d, %d] but x has %d nodes' % (memo[1], memo[2], N))
 
 
+DEDUPE_GRAPHS = True     # recognise batch-identical neighbour tables passed as B copies (the reference's calling convention)
+
+
+def shared_graph_view(nn_idx):
+    """The reference's scripts hand the operator one neighbour table PER SAMPLE even though every sample of a batch
+    shares one graph (`.repeat(B,1,1)` in train_syn_*.py:264-293; DataLoader-collated copies of the same alist tables in
+    train_ldpc.py:216).  The kernels have a fast path for a table shared by the batch (batch stride 0: the incidence and
+    its CSR transpose are built once per workgroup instead of once per sample).  This returns a stride-0 view of sample
+    0's table when all B copies are equal — one device comparison + one host read per distinct table, remembered on the
+    tensor that owns the memory (keyed by version and view geometry) — and ``nn_idx`` itself otherwise.  While a hipGraph
+    is being captured no host read is possible: an unseen table is then taken as per-sample (correct, slower)."""
+    B = nn_idx.shape[0]
+    if not DEDUPE_GRAPHS or B <= 1 or nn_idx.stride(0) == 0 or not nn_idx.is_cuda:
+        return nn_idx
+    owner = nn_idx._base if nn_idx._base is not None else nn_idx
+    key = (nn_idx._version, nn_idx.data_ptr(), tuple(nn_idx.shape), tuple(nn_idx.stride()))
+    memo = getattr(owner, '_fgnn_shared_graph', None)
+    if memo is None or memo[0] != key:
+        if torch.cuda.is_current_stream_capturing():
+            return nn_idx
+        memo = (key, bool((nn_idx == nn_idx[:1]).all().item()))
+        owner._fgnn_shared_graph = memo
+    return nn_idx[:1].expand(B, -1, -1) if memo[1] else nn_idx
+
+
 def mpconv_forward_raw(x, nn_idx, etype, filters, bias, nou, net, ext, agg, *,
                        post_scale=None, post_shift=None, relu=False, want_argmax=False, want_stats=False):
     """One launch of fgnn_mpconv_forward.  Returns (y, argmax-or-None).  ``want_stats``: where the shape has a
@@ -144,6 +169,7 @@ def mpconv_forward_raw(x, nn_idx, etype, filters, bias, nou, net, ext, agg, *,
     announces them to the BatchNorm that follows (pointwise.set_pending_stats)."""
     _require_device(x, nn_idx, etype, filters, bias)
     _check_shapes(x, nn_idx, etype, filters, nou, net, ext)
+    nn_idx = shared_graph_view(nn_idx)
     L = _hip.lib()
     M = nn_idx.shape[1]
     y = _alloc_out(x, nou, M)
@@ -245,6 +271,7 @@ class _MPConv(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, nn_idx, etype, filters, bias, nou, net, ext, agg, want_stats=False):
+        nn_idx = shared_graph_view(nn_idx)               # saved in this form: the backward takes the same fast path
         z, amax = mpconv_forward_raw(x, nn_idx, etype, filters, bias, nou, net, ext, agg, want_stats=want_stats,
                                      want_argmax=True)
         ctx.cfg = (nou, net, ext, agg)

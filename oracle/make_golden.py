@@ -69,10 +69,11 @@ def np_sd(sd):
     return {k: v.detach().cpu().numpy() for k, v in sd.items()}
 
 
-def fill_state_dict(sd):
+def fill_state_dict(sd, gain=2.0):
     """Closed-form deterministic parameters: a function of (sorted key rank,
     flat index) only, so the GPU-box tests can regenerate them without the
-    reference.  Mirrored verbatim in tests/helpers.py::fill_state_dict."""
+    reference.  Mirrored verbatim in tests/helpers.py::fill_state_dict.
+    ``gain``: weight matrices are hash values in (-1, 1) times sqrt(gain / fan_in)."""
     out = {}
     for rank, key in enumerate(sorted(sd.keys())):
         t = sd[key]
@@ -92,7 +93,7 @@ def fill_state_dict(sd):
             fan_in = t.shape[1] if key.endswith('weight') else t.shape[0]
             if t.dim() == 4:
                 fan_in = t.shape[1]
-            v = wave * (2.0 / max(fan_in, 1)) ** 0.5
+            v = wave * (gain / max(fan_in, 1)) ** 0.5
         elif key.endswith('bn.weight') or key.endswith('1.weight'):
             v = 1.0 + 0.1 * wave
         else:
@@ -316,7 +317,7 @@ def make_tables():
         ldpc_ef_f2v=ef_f2v.astype(np.float32), ldpc_ef_v2f=ef_v2f.astype(np.float32))
     print('tables.npz written')
     return dict(knn=(knn_idx, knn_ef), pw=(pw_idx, pw_ef), hi=(hi_idx, hi_ef, hi_ff),
-                hop9=(hop9_idx, hop9_ef), gen=gen)
+                hop9=(hop9_idx, hop9_ef), hop8=(hop8_idx, hop8_ef), gen=gen)
 
 
 # --------------------------------------------------------------------------
@@ -400,25 +401,34 @@ def make_ldpc(tabs):
           (e, e2, len(model.state_dict()), blob['eval_cond'], blob['train_cond']))
 
 
+# The 11-layer synthetic-PGM stack alternates message blocks with InstanceNorm layers; with the unit-gain fill used for
+# the other fixtures (gain 2.0, He-style) its EVAL output moves by 3.5e-5 / 5.2e-5 (relative) between the reference's
+# own f32 run and an f64 run of the same maths — too close to the 1e-4 north-star tolerance to assert it flat.  A
+# slightly contracting fill (gain 0.75: per-layer gain just below one) brings that distance to ~2e-6 with outputs and
+# factor features still O(0.2 .. 3), so the eval-mode tests assert 1e-4 with no conditioning allowance.
+CONTRACTING_GAIN = 0.75
+
+
 def make_factor_mpnn(tabs):
-    for tag, hop_dim, (hidx, hef) in (('pw', 1, tabs['hi'][:2]), ('hop', 9, tabs['hop9'])):
-        g = torch.Generator().manual_seed(31 if tag == 'pw' else 32)
+    fill = lambda sd: fill_state_dict(sd, gain=CONTRACTING_GAIN)
+    for tag, hop_dim, (hidx, hef) in (('pw', 1, tabs['hi'][:2]), ('hop', 9, tabs['hop9']), ('hop8', 8, tabs['hop8'])):
+        g = torch.Generator().manual_seed({'pw': 31, 'hop': 32, 'hop8': 33}[tag])
         B = 3
         model = R.factor_mpnn(2, [4, hop_dim], O.SYN_DIMS, [16, 16])
         emodel_pw = torch.nn.Sequential(torch.nn.Conv2d(3, 64, 1), torch.nn.ReLU(inplace=True),
                                         torch.nn.Conv2d(64, 16, 1))
         emodel_hi = torch.nn.Sequential(torch.nn.Conv2d(hef.shape[1], 64, 1),
                                         torch.nn.ReLU(inplace=True), torch.nn.Conv2d(64, 16, 1))
-        model.load_state_dict(fill_state_dict(model.state_dict()))
-        emodel_pw.load_state_dict(fill_state_dict(emodel_pw.state_dict()))
-        emodel_hi.load_state_dict(fill_state_dict(emodel_hi.state_dict()))
+        model.load_state_dict(fill(model.state_dict()))
+        emodel_pw.load_state_dict(fill(emodel_pw.state_dict()))
+        emodel_hi.load_state_dict(fill(emodel_hi.state_dict()))
         pw_idx, pw_ef = tabs['pw']
         nfeature = torch.rand(B, 2, 30, 1, generator=g)
         pws = torch.rand(B, 4, 30, 1, generator=g)
         if tag == 'pw':
             hi_feat = tabs['hi'][2].repeat(B, 1, 1, 1)
         else:
-            hi_feat = torch.rand(B, 9, 30, 1, generator=g)
+            hi_feat = torch.rand(B, hop_dim, 30, 1, generator=g)
         blob = dict(nfeature=nfeature.numpy(), pws=pws.numpy(), hi_feat=hi_feat.numpy())
         for mode in ('eval', 'train'):
             model.train(mode == 'train')
@@ -437,7 +447,7 @@ def make_factor_mpnn(tabs):
             e = maxdiff(pred, po)
             assert e <= 2e-5, (tag, mode, e)
             blob[mode + '_pred'] = pred.detach().numpy()
-            sd_pre = fill_state_dict(model.state_dict())
+            sd_pre = fill(model.state_dict())
             blob[mode + '_cond'] = np.float64(conditioning(
                 pred, lambda: O.factor_mpnn(to64(sd_pre), '', to64(nfeature), to64([pws, hi_feat]),
                                             [[a, to64(b)] for a, b in gs], dims=O.SYN_DIMS,
@@ -503,10 +513,17 @@ if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
     torch.set_num_threads(8)
-    make_operator()
-    make_block()
+    only = set(sys.argv[1:])                  # e.g. `make_golden.py factor_mpnn`: regenerate one family
+    want = lambda name: not only or name in only
+    if want('operator'):
+        make_operator()
+    if want('block'):
+        make_block()
     tabs = make_tables()
-    make_ldpc(tabs)
-    make_factor_mpnn(tabs)
-    make_sequential(tabs)
+    if want('ldpc'):
+        make_ldpc(tabs)
+    if want('factor_mpnn'):
+        make_factor_mpnn(tabs)
+    if want('sequential'):
+        make_sequential(tabs)
     print('done ->', OUT)

@@ -5,6 +5,7 @@ import numpy as np
 import torch
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+CONTRACTING_GAIN = 0.75
 AGGS = ['max', 'softmax', 'mean']
 BNS = ['off', 'train', 'eval']
 
@@ -13,9 +14,10 @@ def load(name):
     return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
 
 
-def fill_state_dict(sd):
+def fill_state_dict(sd, gain=2.0):
     """Closed-form parameters — identical to oracle/make_golden.py::fill_state_dict, which
-    produced the full-size assembly fixtures."""
+    produced the full-size assembly fixtures.  ``gain``: weights are hash values in (-1, 1) times sqrt(gain / fan_in);
+    2.0 (LDPCModel, config 1) or CONTRACTING_GAIN (the factor_mpnn fixtures: see make_golden.py)."""
     out = {}
     for rank, key in enumerate(sorted(sd.keys())):
         t = sd[key]
@@ -34,7 +36,7 @@ def fill_state_dict(sd):
             fan_in = t.shape[1] if key.endswith('weight') else t.shape[0]
             if t.dim() == 4:
                 fan_in = t.shape[1]
-            v = wave * (2.0 / max(fan_in, 1)) ** 0.5
+            v = wave * (gain / max(fan_in, 1)) ** 0.5
         elif key.endswith('bn.weight') or key.endswith('1.weight'):
             v = 1.0 + 0.1 * wave
         else:
@@ -70,3 +72,32 @@ def operator_cases():
 def rel_err(a, b):
     a, b = a.detach().double().cpu(), b.detach().double().cpu()
     return float((a - b).abs().max()) / max(1.0, float(b.abs().max())) if a.numel() else 0.0
+
+
+SYN_TAGS = ['pw', 'hop', 'hop8']          # train_syn_pw_factor.py; train_syn_hop_factor.py at --hop_order 9 and 8
+
+
+def syn_fill(sd):
+    """The factor_mpnn fixtures' parameters: the closed-form fill at the contracting gain (make_golden.py)."""
+    return fill_state_dict(sd, gain=CONTRACTING_GAIN)
+
+
+def syn_setup(tag):
+    """(hop_dim, pw_idx, pw_ef, hi_idx, hi_ef) of one synthetic-PGM configuration, from fgnn_amd.tables."""
+    from fgnn_amd import tables
+    pw_idx, pw_ef = tables.pw_factor_table(30)
+    if tag == 'pw':
+        hi_idx, hi_ef, _ = tables.chain_high_table(30, 9)
+        return 1, pw_idx, pw_ef, hi_idx, hi_ef
+    order = 9 if tag == 'hop' else 8
+    hi_idx, hi_ef = tables.ring_hop_table(30, order)
+    return order, pw_idx, pw_ef, hi_idx, hi_ef
+
+
+def syn_edge_models(hi_ef):
+    C = torch.nn.Conv2d
+    em_pw = torch.nn.Sequential(C(3, 64, 1), torch.nn.ReLU(), C(64, 16, 1))
+    em_hi = torch.nn.Sequential(C(hi_ef.shape[0], 64, 1), torch.nn.ReLU(), C(64, 16, 1))
+    em_pw.load_state_dict(syn_fill(em_pw.state_dict()))
+    em_hi.load_state_dict(syn_fill(em_hi.state_dict()))
+    return em_pw, em_hi

@@ -127,29 +127,23 @@ def test_ldpc_model_inference_at_full_batch(dtype, dev):
         assert H.rel_err(logits[pick], lo_) <= 1e-4 and H.rel_err(snr[pick], so_) <= 1e-4
 
 
-@pytest.mark.parametrize('tag,batch', [('pw', 256), ('hop', 1024)], ids=['pw_factors_b256', 'degree9_hop_factors_b1024'])
+@pytest.mark.parametrize('tag,batch', [('pw', 256), ('hop', 1024), ('hop8', 1024)],
+                         ids=['pw_factors_b256', 'degree9_hop_factors_b1024', 'degree8_hop_factors_b1024'])
 def test_synthetic_pgm_configs_at_baseline_batch(tag, batch, dev):
     """BASELINE.json configs 2 and 5: `factor_mpnn` on the 30-node synthetic PGMs of train_syn_pw_factor.py /
-    train_syn_hop_factor.py (pairwise factors + high-order factors, 16 edge types, softmax and max aggregation, DIFF
-    extension) at batch 256 / 1024, fp32, eval mode: HIP path within 1e-4 (or 4x the reference arithmetic's own f32
-    rounding distance on these inputs, where that is larger) of the CPU oracle on a sample of the batch,
-    and every slice of the batch reproduces the full run."""
+    train_syn_hop_factor.py (pairwise factors + high-order factors of degree 9 — the script's default — and 8 — what
+    BASELINE names; 16 edge types, softmax and max aggregation, DIFF extension) at batch 256 / 1024, fp32, eval mode: HIP
+    path within a flat 1e-4 of the CPU oracle on a sample of the batch, and every slice of the batch reproduces the
+    full run."""
     import fgnn_amd
-    from fgnn_amd import tables
-    hop_dim = 1 if tag == 'pw' else 9
+    hop_dim, pw_idx, pw_ef, hi_idx, hi_ef = H.syn_setup(tag)
     model = fgnn_amd.factor_mpnn(2, [4, hop_dim], O.SYN_DIMS, [16, 16])
-    model.load_state_dict(H.fill_state_dict(model.state_dict()))
-    pw_idx, pw_ef = tables.pw_factor_table(30)
-    hi_idx, hi_ef = (tables.chain_high_table(30, 9)[:2] if tag == 'pw' else tables.ring_hop_table(30, 9))
-    C = torch.nn.Conv2d
-    em_pw = torch.nn.Sequential(C(3, 64, 1), torch.nn.ReLU(), C(64, 16, 1))
-    em_hi = torch.nn.Sequential(C(hi_ef.shape[0], 64, 1), torch.nn.ReLU(), C(64, 16, 1))
-    em_pw.load_state_dict(H.fill_state_dict(em_pw.state_dict()))
-    em_hi.load_state_dict(H.fill_state_dict(em_hi.state_dict()))
+    model.load_state_dict(H.syn_fill(model.state_dict()))
+    em_pw, em_hi = H.syn_edge_models(hi_ef)
     g = torch.Generator().manual_seed(batch)
-    nfeature = torch.randn(batch, 2, 30, 1, generator=g)
-    pws = torch.randn(batch, 4, 30, 1, generator=g)
-    hi_feat = torch.randn(batch, hop_dim, 1 if tag == 'pw' else 30, 1, generator=g)      # pw: one chain factor per graph
+    nfeature = torch.rand(batch, 2, 30, 1, generator=g)          # log-potentials ~ U(0,1) (random_pgm.py:22)
+    pws = torch.rand(batch, 4, 30, 1, generator=g)
+    hi_feat = torch.rand(batch, hop_dim, 1 if tag == 'pw' else 30, 1, generator=g)      # pw: one chain factor per graph
     model.eval()
     with torch.no_grad():
         et_pw_c, et_hi_c = em_pw(torch.from_numpy(pw_ef)[None]), em_hi(torch.from_numpy(hi_ef)[None])
@@ -167,11 +161,8 @@ def test_synthetic_pgm_configs_at_baseline_batch(tag, batch, dev):
                 [torch.from_numpy(hi_idx)[None].repeat(6, 1, 1), et_hi_c.repeat(6, 1, 1, 1)]]
         po, fo = O.factor_mpnn(sd, '', nfeature[pick], [pws[pick], hi_feat[pick]], gs_o, dims=O.SYN_DIMS, netypes=[16, 16],
                                training=False)
-        # how far the reference arithmetic itself (f32) sits from an f64 run of the same maths on these inputs: the
-        # 11-layer stack amplifies rounding (tests/test_oracle_golden.py: *_cond); the HIP path gets 4x that, >= 1e-4
-        d = lambda v: v.double() if torch.is_tensor(v) and v.is_floating_point() else v
-        p64, f64 = O.factor_mpnn({k: d(v) for k, v in sd.items()}, '', d(nfeature[pick]), [d(pws[pick]), d(hi_feat[pick])],
-                                 [[a, d(b)] for a, b in gs_o], dims=O.SYN_DIMS, netypes=[16, 16], training=False)
-    tol = max(1e-4, 4.0 * H.rel_err(po, p64))
-    assert H.rel_err(pred[pick.to(dev)], p64) <= tol
-    assert H.rel_err(ff[1][pick.to(dev)], f64[1]) <= 4 * max(1e-4, 4.0 * H.rel_err(fo[1], f64[1]))
+    e_pred, e_ff = H.rel_err(pred[pick.to(dev)], po), H.rel_err(ff[1][pick.to(dev)], fo[1])
+    print('factor_mpnn %s B=%d vs oracle: pred err %.2e, factor-feature err %.2e' % (tag, batch, e_pred, e_ff))
+    assert float(po.abs().max()) > 0.05 and float(fo[1].abs().max()) > 0.05          # not a vanishing output
+    assert e_pred <= 1e-4
+    assert e_ff <= 1e-4

@@ -72,23 +72,13 @@ def test_ldpc_model_full_size():
     assert np.allclose(rv, z['post_rv_digest'], rtol=1e-3)
 
 
-@pytest.mark.parametrize('tag', ['pw', 'hop'])
+@pytest.mark.parametrize('tag', H.SYN_TAGS)
 def test_factor_mpnn_full_size(tag):
     import fgnn_amd
-    from fgnn_amd import tables
     z = H.load('factor_mpnn_%s.npz' % tag)
-    hop_dim = 1 if tag == 'pw' else 9
+    hop_dim, pw_idx, pw_ef, hi_idx, hi_ef = H.syn_setup(tag)
     model = fgnn_amd.factor_mpnn(2, [4, hop_dim], O.SYN_DIMS, [16, 16])
-    pw_idx, pw_ef = tables.pw_factor_table(30)
-    if tag == 'pw':
-        hi_idx, hi_ef, _ = tables.chain_high_table(30, 9)
-    else:
-        hi_idx, hi_ef = tables.ring_hop_table(30, 9)
-    em_pw = torch.nn.Sequential(torch.nn.Conv2d(3, 64, 1), torch.nn.ReLU(), torch.nn.Conv2d(64, 16, 1))
-    em_hi = torch.nn.Sequential(torch.nn.Conv2d(hi_ef.shape[0], 64, 1), torch.nn.ReLU(),
-                                torch.nn.Conv2d(64, 16, 1))
-    em_pw.load_state_dict(H.fill_state_dict(em_pw.state_dict()))
-    em_hi.load_state_dict(H.fill_state_dict(em_hi.state_dict()))
+    em_pw, em_hi = H.syn_edge_models(hi_ef)
     B = z['nfeature'].shape[0]
     with torch.no_grad():
         et_pw = em_pw(torch.from_numpy(pw_ef)[None]).repeat(B, 1, 1, 1)
@@ -96,13 +86,14 @@ def test_factor_mpnn_full_size(tag):
         gs = [[torch.from_numpy(pw_idx)[None].repeat(B, 1, 1), et_pw],
               [torch.from_numpy(hi_idx)[None].repeat(B, 1, 1), et_hi]]
         for mode in ('eval', 'train'):
-            sd = H.fill_state_dict(model.state_dict())
+            sd = H.syn_fill(model.state_dict())
             pred, ff = O.factor_mpnn(sd, '', torch.from_numpy(z['nfeature']),
                                      [torch.from_numpy(z['pws']), torch.from_numpy(z['hi_feat'])],
                                      gs, dims=O.SYN_DIMS, netypes=[16, 16],
                                      training=(mode == 'train'))
             assert H.rel_err(pred, torch.from_numpy(z[mode + '_pred'])) <= 2e-5
             assert H.rel_err(ff[1], torch.from_numpy(z[mode + '_ff1'])) <= 2e-5
+    assert float(z['eval_cond']) <= 5e-6          # the fixture is well-conditioned: eval parity is asserted at a flat 1e-4
 
 
 def test_sequential_config1():
