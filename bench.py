@@ -17,6 +17,7 @@ Rank 0 prints ONE JSON line: the contract fields plus
                    on a bounded sample of the same workload (rank 0, N=1 only).
 """
 import argparse
+import contextlib
 import json
 import os
 import sys
@@ -82,7 +83,8 @@ def cpu_baseline(batch, mode, threads, budget=20.0, max_iters=5):
     # baseline uses `threads` cores and says so
     cores = max(1, min(threads, os.cpu_count() or 1))
     torch.set_num_threads(cores)
-    model = LDPCModel(2, 6, 4, aggregator='max')
+    with contextlib.redirect_stdout(sys.stderr):
+        model = LDPCModel(2, 6, 4, aggregator='max')
     sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
     data = synthetic_batch(batch, torch.device('cpu'), seed=1, shared_graph=False)
     if mode == 'train':
@@ -154,7 +156,8 @@ def main():
     _trace('process group up')
     torch.manual_seed(0)
     dtype = torch.float32 if args.dtype == 'f32' else torch.bfloat16
-    model = LDPCModel(2, 6, 4, aggregator='max').to(dev)
+    with contextlib.redirect_stdout(sys.stderr):         # the constructors announce their aggregator (as the reference does)
+        model = LDPCModel(2, 6, 4, aggregator='max').to(dev)
     broadcast_parameters(model)
     _trace('parameters broadcast')
     if args.inputs == 'channel':

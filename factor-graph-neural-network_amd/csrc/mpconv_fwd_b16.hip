@@ -473,6 +473,10 @@ static void* b16_pick_agg(int agg, int k, int KSB, int SWP, int NPASS) {
     }
 }
 
+int fgnn_mpconv_forward_sg(const fgnn_mpconv_desc* d, const void* x, const int64_t* nn_idx, const void* etype,
+                           const float* filters, const float* bias, const float* post_scale, const float* post_shift,
+                           void* y, uint8_t* argmax, fgnn_stream_t stream, float* stats, int* plan_grid);
+
 // Returns 1 if launched, 0 if the shape is outside this kernel's family, <0 on error.
 // stats != NULL: also write per-workgroup BatchNorm partials (only one-pass shapes with <= 64 output channels: returns 0
 // otherwise).  plan_grid != NULL: no launch, *plan_grid = the grid (= number of partial rows) the launch would use.
@@ -482,6 +486,11 @@ int fgnn_mpconv_forward_b16(const fgnn_mpconv_desc* d, const void* x, const int6
                             uint8_t* argmax, fgnn_stream_t stream, float* stats, int* plan_grid) {
     if (d->dtype != FGNN_BF16 || d->ext != FGNN_EXT_NONE) return 0;
     if (d->net != 1 && d->net != 4) return 0;
+    {   // batch-shared graph, fixed degree, max aggregation: the second-generation kernel (mpconv_fwd_sg.hip)
+        const int rc = fgnn_mpconv_forward_sg(d, x, nn_idx, etype, filters, bias, post_scale, post_shift, y, argmax, stream,
+                                              stats, plan_grid);
+        if (rc != 0) return rc;
+    }
     const int ncols = d->nou * d->net;
     if (ncols % 16 != 0 || ncols > 512) return 0;
     if (d->nin != 64 && d->nin != 128) return 0;

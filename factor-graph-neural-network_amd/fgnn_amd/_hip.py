@@ -11,7 +11,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libfgnn_hip.so')
+LIB_PATH = os.environ.get('FGNN_HIP_LIB') or os.path.join(_HERE, 'libfgnn_hip.so')      # FGNN_HIP_LIB: a tuning build
 
 EXT_NONE, EXT_NEIGHBOR, EXT_DIFF = 0, 1, 2
 AGG_MAX, AGG_LSE, AGG_MEAN = 0, 1, 2

@@ -1,0 +1,130 @@
+"""GPU parity of the second-generation parity-check kernels (csrc/mpconv_fwd_sg.hip, csrc/mpconv_bwd_sg.hip): the
+calls of the LDPC model with a batch-shared graph, bf16 channel-fastest storage, 4 edge types, max aggregation.
+Forward against the f32 ORACLE on the same bf16-rounded inputs (2^-6 of the output range: P and the output are rounded
+to bf16), the argmax under the near-tie rule, the statistics epilogue against a direct reduction of the stored output;
+backward against torch autograd through the forward's own routing."""
+import pytest
+import torch
+
+import fgnn_oracle as O
+import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+# (nin, nou, N, M, k): the six parity-check call shapes of LDPCModel, then ragged / degenerate ones
+SHAPES = [(64, 64, 96, 48, 6), (64, 64, 48, 96, 3), (64, 128, 96, 48, 6), (64, 128, 48, 96, 3), (128, 64, 96, 48, 6),
+          (128, 64, 48, 96, 3), (64, 64, 91, 47, 6), (64, 64, 37, 95, 3), (64, 64, 96, 1, 6), (64, 64, 40, 20, 3),
+          (64, 128, 33, 7, 6)]
+IDS = ['x'.join(map(str, s)) for s in SHAPES]
+
+
+def _problem(shape, B, dev, seed=0):
+    nin, nou, N, M, k = shape
+    g = torch.Generator().manual_seed(seed + N + 7 * M + nou)
+    x = torch.randn(B, N, 1, nin, generator=g).bfloat16()                   # channel-fastest in memory
+    idx = torch.randint(0, N, (1, M, k), generator=g)
+    et = torch.randn(B, M, k, 4, generator=g).bfloat16()                      # edge-type fastest in memory
+    if k > 2:                                                                  # same neighbour, same edge weights: exact ties
+        idx[0, ::5, k - 1] = idx[0, ::5, 0]
+        et[:, ::5, k - 1, :] = et[:, ::5, 0, :]
+    W = (torch.randn(nin, nou * 4, generator=g) * 0.1).bfloat16().float()
+    bias = torch.randn(nou, generator=g)
+    return x, idx, et, W, bias, g
+
+
+def _dev_views(x, idx, et, dev):
+    B = x.shape[0]
+    return (x.to(dev).permute(0, 3, 1, 2), idx.to(dev).expand(B, -1, -1), et.to(dev).permute(0, 3, 1, 2))
+
+
+@pytest.mark.parametrize('shape', SHAPES, ids=IDS)
+@pytest.mark.parametrize('mode', ['train', 'affine_relu', 'relu_only', 'affine_argmax'])
+def test_sg_forward_vs_oracle(shape, mode, dev):
+    from fgnn_amd import _hip, ops
+    nin, nou, N, M, k = shape
+    B = 37                                                                     # not a multiple of anything
+    x, idx, et, W, bias, g = _problem(shape, B, dev)
+    scale, shift = torch.rand(nou, generator=g) + 0.5, torch.randn(nou, generator=g)
+    pre = O.mp_conv({'filters': W, 'bias': bias}, '', x.permute(0, 3, 1, 2).float(), idx.expand(B, -1, -1).contiguous(),
+                    et.permute(0, 3, 1, 2).float(), nou=nou, net=4, extension=0, aggregator='max', relu=False)
+    kw = dict(want_argmax=mode in ('train', 'affine_argmax'))
+    ref = pre
+    if mode in ('affine_relu', 'affine_argmax'):
+        ref = ref * scale[None, :, None, None] + shift[None, :, None, None]
+        kw.update(post_scale=scale.to(dev), post_shift=shift.to(dev))
+    if mode in ('affine_relu', 'relu_only'):
+        ref = torch.relu(ref)
+        kw.update(relu=True)
+    xd, idxd, etd = _dev_views(x, idx, et, dev)
+    y, am = ops.mpconv_forward_raw(xd, idxd, etd, W.to(dev), bias.to(dev), nou, 4, 0, _hip.AGG_MAX, **kw)
+    assert 'mpconv_fwd_sg' in _hip.lib().fgnn_last_kernel().decode(), _hip.lib().fgnn_last_kernel()
+    assert y.dtype == torch.bfloat16 and y.shape == ref.shape and y.stride(1) == 1
+    err = float((y.float().cpu() - ref).abs().max() / ref.abs().max())
+    assert err <= 2.0 ** -6, err
+    if am is not None:
+        # near-tie rule: the named neighbour's f32 message is the maximum up to the bf16 rounding of P
+        e = O.mp_conv({'filters': W}, '', x.permute(0, 3, 1, 2).float(), idx.expand(B, -1, -1).contiguous(),
+                      et.permute(0, 3, 1, 2).float(), nou=nou, net=4, extension=0, aggregator=None, relu=False)
+        a = am.cpu().long()
+        assert int(a.max()) < k
+        gap = float((e.max(dim=3, keepdim=True)[0] - e.gather(3, a)).max())
+        assert gap <= 2.0 ** -6 * float(e.abs().max()), gap
+        # exact ties (duplicated neighbour in the last slot) resolve to the first occurrence
+        dup = a[:, :, ::5, :]
+        if k > 2:
+            assert int((dup == k - 1).sum()) == 0
+
+
+@pytest.mark.parametrize('shape', SHAPES[:6], ids=IDS[:6])
+def test_sg_forward_matches_first_generation_kernel(shape, dev, monkeypatch):
+    """Same inputs through mpconv_fwd_b16.hip (per-sample copy of the table defeats the shared-graph dispatch): both
+    round P to bf16, so the outputs agree to one bf16 ulp of the output range and the argmax wherever messages differ."""
+    from fgnn_amd import _hip, ops
+    nin, nou, N, M, k = shape
+    B = 64
+    x, idx, et, W, bias, g = _problem(shape, B, dev, seed=3)
+    xd, idxd, etd = _dev_views(x, idx, et, dev)
+    y1, a1 = ops.mpconv_forward_raw(xd, idxd, etd, W.to(dev), bias.to(dev), nou, 4, 0, _hip.AGG_MAX, want_argmax=True)
+    assert 'mpconv_fwd_sg' in _hip.lib().fgnn_last_kernel().decode()
+    monkeypatch.setattr(ops, 'DEDUPE_GRAPHS', False)
+    y2, a2 = ops.mpconv_forward_raw(xd, idxd.contiguous(), etd, W.to(dev), bias.to(dev), nou, 4, 0, _hip.AGG_MAX,
+                                    want_argmax=True)
+    assert 'mpconv_fwd_b16' in _hip.lib().fgnn_last_kernel().decode()
+    assert float((y1.float() - y2.float()).abs().max()) <= 2.0 ** -7 * float(y2.float().abs().max())
+    assert float((a1 != a2).float().mean()) <= 2e-3                       # near-ties only
+
+
+@pytest.mark.parametrize('shape', SHAPES[:6] + SHAPES[6:8], ids=IDS[:6] + IDS[6:8])
+@pytest.mark.parametrize('B', [5, 300, 1100])
+def test_sg_statistics_epilogue(shape, B, dev):
+    """Training-mode mp_conv_v2 on a shared graph: the forward's epilogue leaves (sum, sum of squares) of the STORED
+    output for the BatchNorm behind it; result, running statistics and gradients equal BatchNorm's own reduction pass."""
+    from fgnn_amd import _hip, ops
+    from fgnn_amd.mpnn import mp_conv_type, mp_conv_v2
+    nin, nou, N, M, k = shape
+    x, idx, et, W, bias, g = _problem(shape, B, dev, seed=B)
+    xd, idxd, etd = _dev_views(x, idx, et, dev)
+    gy = torch.randn(B, M, 1, nou, generator=g).bfloat16().to(dev).permute(0, 3, 1, 2)
+
+    def run(epilogue):
+        torch.manual_seed(7)
+        m = mp_conv_v2(nin, nou, 4, extension=mp_conv_type.NO_EXTENSION, aggregtor='max').to(dev).train()
+        xx = xd.detach().clone().requires_grad_(True)
+        ops.STATS_EPILOGUE = epilogue
+        ops.TIMER = ops.KernelTimer()
+        try:
+            y = m(xx, idxd, etd)
+            names = set(ops.TIMER.summary())
+        finally:
+            ops.STATS_EPILOGUE = True
+            ops.TIMER = None
+        y.backward(gy)
+        return (y.detach().float(), m.bn.running_mean.clone(), m.bn.running_var.clone(), xx.grad.float(),
+                m.filters.grad.clone(), names)
+
+    a, b = run(True), run(False)
+    assert any('mpconv_fwd_sg' in n for n in a[5]), a[5]
+    assert not any(n.startswith('bn_stats') for n in a[5]), a[5]           # the epilogue is what ran
+    assert any(n.startswith('bn_stats') for n in b[5]), b[5]
+    assert H.rel_err(a[0], b[0]) <= 2.0 ** -7 and H.rel_err(a[3], b[3]) <= 2.0 ** -6
+    assert H.rel_err(a[1], b[1]) <= 1e-5 and H.rel_err(a[2], b[2]) <= 1e-4 and H.rel_err(a[4], b[4]) <= 2e-3
