@@ -375,6 +375,10 @@ int fgnn_mpconv_backward_b16(const fgnn_mpconv_desc* d, const void* x, const int
                              const float* filters, const void* gz, const uint8_t* argmax, void* gx, void* getype,
                              float* gfilters, float* gbias, void* workspace, int64_t workspace_bytes,
                              fgnn_stream_t stream);
+int fgnn_mpconv_backward_sg(const fgnn_mpconv_desc* d, const void* x, const int64_t* nn_idx, const void* etype,
+                            const float* filters, const void* gz, const uint8_t* argmax, void* gx, void* getype,
+                            float* gfilters, float* gbias, void* workspace, int64_t workspace_bytes,
+                            fgnn_stream_t stream);
 
 static int plan_backward(const fgnn_mpconv_desc* d, BwdParams* p) {
     const int nproj = d->ext == FGNN_EXT_NONE ? 1 : 2;
@@ -453,6 +457,9 @@ extern "C" int fgnn_mpconv_backward(const fgnn_mpconv_desc* d, const void* x, co
         if (!force_generic) {
             rc = fgnn_mpconv_backward_hyper(d, x, nn_idx, etype, filters, gz, argmax, gx, getype, gfilters, gbias,
                                             workspace, workspace_bytes, stream);
+            if (rc != 0) return rc < 0 ? rc : FGNN_OK;
+            rc = fgnn_mpconv_backward_sg(d, x, nn_idx, etype, filters, gz, argmax, gx, getype, gfilters, gbias,
+                                         workspace, workspace_bytes, stream);
             if (rc != 0) return rc < 0 ? rc : FGNN_OK;
             rc = fgnn_mpconv_backward_b16(d, x, nn_idx, etype, filters, gz, argmax, gx, getype, gfilters, gbias,
                                           workspace, workspace_bytes, stream);

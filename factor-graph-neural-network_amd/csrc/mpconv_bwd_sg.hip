@@ -1,0 +1,554 @@
+// mpconv_bwd_sg.hip — second-generation backward of the VF/FV message operator for the LDPC parity-check calls:
+// bf16 channel-fastest x / gz / etype, 64 -> 64 channels, 4 edge types, max aggregation, fixed degree (3 or 6), ONE
+// neighbour table shared by the batch whose transposed incidence is regular enough (in-degree <= 3 or 6).
+// Same maths and rounding points as mpconv_bwd_b16.hip (autograd through /root/reference/lib/model/mpnn/mp_nn.py:115-175):
+//
+//     P[n,o,e]      = sum_c x[n,c] W[c,o*4+e]                                   (recomputed, bf16 in LDS)
+//     detype[e,m,j] = sum_o gz[m,o] [j == argmax[m,o]] P[idx[m,j],o,e]
+//     dP[n,o,e]     = sum_{(m,j): idx[m,j]=n} gz[m,o] [j == argmax[m,o]] etype[m,j,e]     (bf16 in LDS)
+//     dx[n,c]       = sum_col dP[n,col] W[c,col]          dW[c,col] += sum_n x[n,c] dP[n,col]       dbias[o] += sum_m gz[m,o]
+//
+// The first-generation kernel spends ~1 740 VALU instructions per wave and sample (profiles/r01), two thirds of them in
+// the two routing phases (work lists with per-item index arithmetic, byte-wise argmax tests, per-edge LDS traffic).
+// This kernel is organised around what the shared graph makes constant:
+//   * routing by SOURCE node (dP): every wave owns a few nodes; the (destination row, slot) of each of their in-edges
+//     sits in scalar registers for the kernel's lifetime (transposed incidence built once per workgroup in LDS, in
+//     (m, j) order — fixed summation order, no atomics anywhere).  Per in-edge and channel lane: one 4-byte LDS read of
+//     {gz as the high half | one-hot argmax in the low bits}, a bit-field extract, an AND and two packed FMAs;
+//   * routing by DESTINATION (detype): lane = channel reads only the routed P row (v_perm picks the node id out of the
+//     destination's packed neighbour bytes), forms the 4 products, and parks them as bf16 in a wave-private,
+//     zero-initialised [slot j][edge type e][channel] image.  The sum over channels is then an MFMA with an all-ones A
+//     operand (4 instructions per destination) — no cross-lane shuffles;
+//   * the three GEMM-shaped phases run on v_mfma_f32_16x16x32_bf16 as before (dW takes its node-contracted operands by
+//     reading 8 rows x 4 columns per lane and transposing in registers with v_perm_b32).
+// One 1024-thread workgroup (16 waves) per CU: the LDS images of a sample (x double-buffered 2 x 14 KB, P / dP 50 KB —
+// one buffer, used in turn —, gz+argmax 12..25 KB, the per-wave detype images 55 KB) do not leave room for two.
+#include "fgnn_common.h"
+#include <stdlib.h>
+
+#define BS_THREADS 1024
+#define BS_WAVES 16
+#define BS_XSB 144           // x image row stride, bytes (64 bf16 + 16: rows land on distinct 16-byte slots)
+#define BS_PSB 528           // P / dP image row stride, bytes (256 bf16 + 16)
+#define BS_GSB 256           // ga row: 64 dwords {gz bf16 << 16 | argmax << 8 | 1 << argmax}
+#define BS_ZCS 144           // detype image: column (slot j, edge type e) stride in bytes (64 bf16 + 16)
+#define BS_MAXN 96
+
+typedef __bf16 bs_bf16x8 __attribute__((ext_vector_type(8)));
+typedef float bs_f32x2 __attribute__((ext_vector_type(2)));
+
+struct BsParams {
+    const uint16_t* x;
+    const int64_t* idx;
+    const uint16_t* et;
+    const float* W;          // [64][256]
+    const uint16_t* gz;
+    const uint8_t* argmax;
+    uint16_t* gx;
+    uint16_t* get;
+    float* ws;               // per-workgroup slabs [grid][64*256 + 64]
+    int B, N, M, Npad, NPW, DPW;
+    long long x_sb, et_sb, y_sb;     // elements
+    int off_xs, off_pd, off_ga, off_z, off_es, off_tab, off_idx, off_red;      // byte offsets into LDS
+    int zbytes;              // bytes of one wave's detype image
+    long long* prof;         // FGNN_PROF (builds with -DFGNN_ENABLE_PROF only): phase timeline
+};
+
+extern __shared__ __attribute__((aligned(16))) unsigned char bs_lds[];
+
+#ifdef FGNN_ENABLE_PROF
+#define BS_STAMP(slot) do { if (p.prof && blockIdx.x == 0 && lane == 0 && (wave & 3) == 0 && b == b_begin + 3) p.prof[(wave >> 2) * 16 + (slot)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define BS_STAMP(slot) do { } while (0)
+#endif
+
+void fgnn_launch_slab_reduce(const float* ws, int nslab, int64_t slab_len, int64_t nw, float* gW, float* gbias,
+                             hipStream_t st);
+
+// uniform 64-bit base + UNSIGNED 32-bit per-lane byte offset: the form the compiler turns into `global_load v, v_off, s[base]`
+// (a signed or 64-bit per-lane offset becomes a per-lane 64-bit pointer: two VGPRs each, hoisted out of the sample loop)
+template <typename T> __device__ __forceinline__ const T* bs_at(const void* base, unsigned byte_off) {
+    return reinterpret_cast<const T*>(static_cast<const char*>(base) + byte_off);
+}
+template <typename T> __device__ __forceinline__ T* bs_at(void* base, unsigned byte_off) {
+    return reinterpret_cast<T*>(static_cast<char*>(base) + byte_off);
+}
+__device__ __forceinline__ float bs_lo(unsigned u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bs_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
+__device__ __forceinline__ unsigned bs_pack2(float a, float b) {
+    typedef __bf16 v2 __attribute__((ext_vector_type(2)));
+    const v2 h = {(__bf16)a, (__bf16)b};
+    return __builtin_bit_cast(unsigned, h);
+}
+__device__ __forceinline__ bs_bf16x8 bs_frag_f32(const float* p8) {      // 8 consecutive f32 -> one fragment
+    const f32x4 a = *reinterpret_cast<const f32x4*>(p8), b = *reinterpret_cast<const f32x4*>(p8 + 4);
+    return __builtin_bit_cast(bs_bf16x8, make_uint4(bs_pack2(a[0], a[1]), bs_pack2(a[2], a[3]),
+                                                    bs_pack2(b[0], b[1]), bs_pack2(b[2], b[3])));
+}
+// rows r0..r7 each hold columns (c0 c1 | c2 c3) as two dwords: gather column P's eight values
+template <int P>
+__device__ __forceinline__ bs_bf16x8 bs_tr(const uint2 (&r)[8]) {
+    constexpr unsigned sel = (P & 1) ? 0x07060302u : 0x05040100u;
+    unsigned w[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const unsigned a = P < 2 ? r[2 * q].x : r[2 * q].y, b = P < 2 ? r[2 * q + 1].x : r[2 * q + 1].y;
+        w[q] = __builtin_amdgcn_perm(b, a, sel);
+    }
+    return __builtin_bit_cast(bs_bf16x8, make_uint4(w[0], w[1], w[2], w[3]));
+}
+__device__ __forceinline__ bs_bf16x8 bs_tr_dyn(const uint2 (&r)[8], int P) {
+    switch (P) {
+        case 0: return bs_tr<0>(r);
+        case 1: return bs_tr<1>(r);
+        case 2: return bs_tr<2>(r);
+        default: return bs_tr<3>(r);
+    }
+}
+
+// KC = destination degree (neighbour slots per destination), DEG = in-edges per source node the tables are sized for,
+// NPW = source nodes per wave (ceil(N / 16)), DPW = destinations per wave (ceil(M / 16))
+template <int KC, int DEG, int NPW, int DPW, int GSL>
+__global__ __launch_bounds__(BS_THREADS, 4) void mpconv_bwd_sg_kernel(const BsParams p) {
+    constexpr int NIN = 64, NCOLS = 256, NOU = 64;
+    constexpr int NZT = (KC * 4 + 15) / 16;           // 16-column tiles of the detype image: 1 (degree 3) or 2 (degree 6)
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int li = lane & 15, lk = lane >> 4;
+    const int N = p.N, M = p.M, Npad = p.Npad;
+    const int mk = M * KC;
+
+    unsigned char* xs0 = bs_lds + p.off_xs;                              // 2 x [Npad][XSB]  bf16 x (double-buffered)
+    unsigned char* pd = bs_lds + p.off_pd;                               // [Npad][PSB]      bf16 P, then dP
+    unsigned char* ga = bs_lds + p.off_ga;                               // [M][GSB]         {gz | argmax}
+    unsigned char* zb = bs_lds + p.off_z + wave * p.zbytes;              // this wave's detype image [KC*4][ZCS]
+    float* es = reinterpret_cast<float*>(bs_lds + p.off_es) + wave * (NPW * DEG * 4);     // this wave's in-edge weights, f32
+    int* tab = reinterpret_cast<int*>(bs_lds + p.off_tab);               // [N][DEG]  m * 256 + j of every in-edge
+    int* idx_s = reinterpret_cast<int*>(bs_lds + p.off_idx);             // [M * KC]
+    const int xs_bytes = Npad * BS_XSB;
+
+    // ---- zero the LDS images: padding rows are read by the matrix cores, the detype images rely on their zeros ----
+    for (int f = tid; f < (p.off_es - p.off_xs) / 4; f += BS_THREADS) reinterpret_cast<unsigned*>(bs_lds + p.off_xs)[f] = 0u;
+    // ---- neighbour table -> LDS, then the transposed incidence in (m, j) order (deterministic, no atomics) ----
+    for (int r = tid; r < mk; r += BS_THREADS) {
+        long long v = p.idx[r];
+        idx_s[r] = (int)(v < 0 ? 0 : (v >= N ? N - 1 : v));
+    }
+    for (int f = tid; f < N * DEG; f += BS_THREADS) tab[f] = 7;          // padding entry: slot 7 never matches an argmax
+    __syncthreads();
+    for (int r = tid; r < mk; r += BS_THREADS) {
+        const int n = idx_s[r];
+        int pos = 0;
+        for (int q = 0; q < r; ++q) pos += idx_s[q] == n ? 1 : 0;        // rank among the in-edges of n
+        const int m = r / KC, j = r - m * KC;
+        if (pos < DEG) tab[n * DEG + pos] = m * BS_GSB + j;              // (host guarantees in-degree <= DEG)
+    }
+    __syncthreads();
+
+    // ---- per-wave constants ----
+    // in-edges of this wave's source nodes: row offset of the destination in ga (m * 256) + slot j, in SGPRs
+    const int n0 = wave * NPW;
+    int ent2[NPW][DEG / 2 + 1];                       // two 16-bit entries per register
+#pragma unroll
+    for (int i = 0; i < NPW; ++i)
+#pragma unroll
+        for (int q = 0; q < DEG; q += 2) {
+            const int n = n0 + i;
+            const int e0 = n < N ? tab[n * DEG + q] : 7;
+            const int e1 = (n < N && q + 1 < DEG) ? tab[n * DEG + q + 1] : 7;
+            ent2[i][q >> 1] = __builtin_amdgcn_readfirstlane(e0 | (e1 << 16));
+        }
+    // lane l < NPW*DEG fetches the edge-type row of in-edge l of this wave: element offset inside etype[b]
+    int et_goff = 0;
+    {
+        const int i = lane / DEG, q = lane - i * DEG;
+        if (lane < NPW * DEG && n0 + i < N) {
+            const int e = tab[(n0 + i) * DEG + q];
+            const int m = e >> 8, j = e & 0xff;
+            et_goff = j < KC ? (m * KC + j) * 4 : 0;                      // padding entries read row 0 (their gz mask is 0)
+        }
+    }
+    // neighbour ids of this wave's destinations, one byte each (N <= 96), for the routed-row select of the detype phase
+    const int m0 = wave * DPW;
+    unsigned nb[DPW][2];
+#pragma unroll
+    for (int d = 0; d < DPW; ++d) {
+        nb[d][0] = nb[d][1] = 0u;
+        if (m0 + d < M) {
+#pragma unroll
+            for (int j = 0; j < KC; ++j) nb[d][j >> 2] |= (unsigned)idx_s[(m0 + d) * KC + j] << (8 * (j & 3));
+        }
+    }
+    // W fragments.  aP: A of P^T = W^T x (wave = 16-column slab): A[i = col][k = c] = W[c][16 wave + i], 8 consecutive c.
+    //               aT: A of dx^T = W dP^T (wave & 3 = 16-channel tile): A[i = c][k = col] = W[ct*16 + i][col], 8 consecutive cols.
+    //               Resident (32 VGPRs): re-reading it from L2 per sample had every CU of the chip hammering the same 64 KB —
+    //               17 000 cycles per sample in the dx phase (profiles/r02).
+    bs_bf16x8 aP[2], aT[8];
+    const int ct = wave & 3;
+    {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const float* wp = p.W + (int64_t)(32 * ks + 8 * lk) * NCOLS + wave * 16 + li;
+            alignas(16) float w8[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) w8[u] = wp[(int64_t)u * NCOLS];
+            aP[ks] = bs_frag_f32(w8);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) aT[ks] = bs_frag_f32(p.W + (int64_t)(ct * 16 + li) * NCOLS + 32 * ks + 8 * lk);
+    }
+    bs_bf16x8 ones;
+    {
+        const unsigned o2 = 0x3f803f80u;
+        ones = __builtin_bit_cast(bs_bf16x8, make_uint4(o2, o2, o2, o2));
+    }
+
+    f32x4 gw[4];                                      // dW accumulators: A slot pa (channel 4 i + pa) x this wave's column slot
+#pragma unroll
+    for (int t = 0; t < 4; ++t) gw[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float gbacc = 0.f;                                // dbias of channel `lane` over this wave's destinations (detype phase)
+
+    // ---- prefetch registers (raw chunks; decoded at the commit) ----
+    uint4 px;                                         // one 16-byte x chunk (N * 8 <= 768 chunks)
+    uint2 pg[GSL];                                      // gz of items tid, tid + 1024: (m = item >> 4, channels 4 (item & 15) ..+3)
+    unsigned pa[GSL];                                   // argmax of the same items
+    uint2 pe;                                         // edge-type row of in-edge `lane` of this wave
+    const int xchunks = N * 8, gitems = M * 16;
+    auto prefetch = [&](int b, int t) {
+        const unsigned utid = (unsigned)t;
+        const int lane = t & 63;
+        px = make_uint4(0, 0, 0, 0);
+        if (t < xchunks) px = *bs_at<uint4>(p.x + (int64_t)b * p.x_sb, utid * 16u);
+        const uint16_t* gzb = p.gz + (int64_t)b * p.y_sb;
+        const uint8_t* amb = p.argmax + (int64_t)b * p.y_sb;
+#pragma unroll
+        for (int s = 0; s < GSL; ++s) {
+            const unsigned f = utid + (unsigned)s * BS_THREADS;
+            pg[s] = make_uint2(0, 0);
+            pa[s] = 0u;
+            if ((int)f < gitems) {
+                pg[s] = *bs_at<uint2>(gzb, f * 8u);
+                pa[s] = *bs_at<unsigned>(amb, f * 4u);
+            }
+        }
+        pe = make_uint2(0, 0);
+        if (lane < NPW * DEG) pe = *bs_at<uint2>(p.et + (int64_t)b * p.et_sb, (unsigned)et_goff * 2u);
+    };
+    auto commit = [&](unsigned char* xs, int t) {
+        const int lane = t & 63;
+        if (t < xchunks) *reinterpret_cast<uint4*>(xs + (t >> 3) * BS_XSB + (t & 7) * 16) = px;
+#pragma unroll
+        for (int s = 0; s < GSL; ++s) {
+            const int f = t + s * BS_THREADS;
+            if (f < gitems) {
+                const unsigned g01 = pg[s].x, g23 = pg[s].y, a4 = pa[s];
+                unsigned w[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const unsigned a = (a4 >> (8 * u)) & 7u;               // slots 0..5 (a corrupt byte cannot reach the gz bits)
+                    const unsigned g2 = u < 2 ? g01 : g23;
+                    const unsigned hi = (u & 1) ? (g2 & 0xffff0000u) : (g2 << 16);
+                    w[u] = hi | (a << 8) | (1u << a);
+                }
+                *reinterpret_cast<uint4*>(ga + (f >> 4) * BS_GSB + (f & 15) * 16) = make_uint4(w[0], w[1], w[2], w[3]);
+            }
+        }
+        if (lane < NPW * DEG)
+            *reinterpret_cast<f32x4*>(es + lane * 4) = (f32x4){bs_lo(pe.x), bs_hi(pe.x), bs_lo(pe.y), bs_hi(pe.y)};
+    };
+
+    const int ntile = Npad / 16;                      // 16-node tiles: 2..6
+    const int nkst = Npad / 32;                       // 32-node k-steps of dW
+    const int chunk = (p.B + gridDim.x - 1) / gridDim.x;
+    const int b_begin = blockIdx.x * chunk;
+    const int b_end = min(p.B, b_begin + chunk);
+    __syncthreads();                                  // (tables read above; zeros in place)
+    if (b_begin < b_end) {
+        prefetch(b_begin, tid);
+        commit(xs0, tid);
+        if (b_begin + 1 < b_end) prefetch(b_begin + 1, tid);
+    }
+    int cur = 0;
+
+    for (int b = b_begin; b < b_end; ++b) {
+        // per-lane offsets are re-derived every sample from an opaque copy of the thread id: left to itself the compiler
+        // hoists ~20 per-lane 64-bit global pointers out of the loop and spills them (scratch round trips in the hot loop)
+        int t = tid;
+        asm volatile("" : "+v"(t));
+        const int lane = t & 63, li = t & 15, lk = (t >> 4) & 3;
+        unsigned char* xs = xs0 + cur * xs_bytes;
+        BS_STAMP(0);
+        __syncthreads();                              // B_a: x / ga / es of this sample are staged; pd is free
+        BS_STAMP(1);
+
+        // ---- P^T slab (wave = 16-column slab = channels 4 wave .. +3): D[i = col][j = node] ----
+        for (int nt0 = 0; nt0 < ntile; nt0 += 2) {       // two node tiles in flight (ntile is even: Npad is a multiple of 32)
+            f32x4 acc[2];
+            bs_bf16x8 bf[2][2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const unsigned char* bp = xs + ((nt0 + u) * 16 + li) * BS_XSB + lk * 16;
+                bf[u][0] = __builtin_bit_cast(bs_bf16x8, *reinterpret_cast<const uint4*>(bp));
+                bf[u][1] = __builtin_bit_cast(bs_bf16x8, *reinterpret_cast<const uint4*>(bp + 64));
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                acc[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aP[0], bf[u][0], acc[u], 0, 0, 0);
+                acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aP[1], bf[u][1], acc[u], 0, 0, 0);
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+                *reinterpret_cast<uint2*>(pd + ((nt0 + u) * 16 + li) * BS_PSB + (4 * wave + lk) * 8) =
+                    make_uint2(bs_pack2(acc[u][0], acc[u][1]), bs_pack2(acc[u][2], acc[u][3]));
+        }
+        BS_STAMP(2);
+        __syncthreads();                              // B_b: P complete
+        BS_STAMP(3);
+
+        // ---- detype: lane = channel; the routed row's products go to the wave's [slot][edge type][channel] image, the sum
+        //      over channels is an all-ones MFMA ----
+        {
+            uint16_t* gb = p.get + (int64_t)b * 4 * mk;
+#pragma unroll
+            for (int d = 0; d < DPW; ++d) {
+                const int m = m0 + d;
+                if (m < M) {
+                    const unsigned dw = *reinterpret_cast<const unsigned*>(ga + m * BS_GSB + lane * 4);
+                    const unsigned jst = (dw >> 8) & 7u;
+                    const unsigned n = __builtin_amdgcn_perm(nb[d][1], nb[d][0], 0x0c0c0c00u | jst);
+                    const uint2 pk = *reinterpret_cast<const uint2*>(pd + n * BS_PSB + lane * 8);
+                    const float g = __uint_as_float(dw & 0xffff0000u);
+                    gbacc += g;
+                    const unsigned c01 = bs_pack2(g * bs_lo(pk.x), g * bs_hi(pk.x));
+                    const unsigned c23 = bs_pack2(g * bs_lo(pk.y), g * bs_hi(pk.y));
+                    unsigned short* zw = reinterpret_cast<unsigned short*>(zb + jst * (4 * BS_ZCS) + lane * 2);
+                    zw[0] = (unsigned short)c01;
+                    zw[BS_ZCS / 2] = (unsigned short)(c01 >> 16);
+                    zw[2 * (BS_ZCS / 2)] = (unsigned short)c23;
+                    zw[3 * (BS_ZCS / 2)] = (unsigned short)(c23 >> 16);
+                    asm volatile("" ::: "memory");            // the image is re-read below through another type: keep the stores
+                    f32x4 sum[NZT];
+#pragma unroll
+                    for (int t = 0; t < NZT; ++t) {
+                        sum[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                        const unsigned char* zr = zb + (16 * t + li) * BS_ZCS + lk * 16;
+#pragma unroll
+                        for (int ks = 0; ks < 2; ++ks)
+                            sum[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                                ones, __builtin_bit_cast(bs_bf16x8, *reinterpret_cast<const uint4*>(zr + 64 * ks)), sum[t], 0, 0, 0);
+                    }
+                    asm volatile("" ::: "memory");
+                    zw[0] = 0;
+                    zw[BS_ZCS / 2] = 0;
+                    zw[2 * (BS_ZCS / 2)] = 0;
+                    zw[3 * (BS_ZCS / 2)] = 0;
+                    asm volatile("" ::: "memory");
+                    // column c = 16 t + li of the image is (slot j = c >> 2, edge type e = c & 3); every row of D holds its sum
+                    if (lk == 0) {
+#pragma unroll
+                        for (int t = 0; t < NZT; ++t) {
+                            const int c = 16 * t + li;
+                            if (c < KC * 4) {
+                                const __bf16 h = (__bf16)sum[t][0];
+                                *bs_at<uint16_t>(gb, (unsigned)((c & 3) * mk + m * KC + (c >> 2)) * 2u) = __builtin_bit_cast(uint16_t, h);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        BS_STAMP(4);
+        __syncthreads();                              // B_c: every wave is done reading P
+        BS_STAMP(5);
+
+        // ---- dP: wave owns source nodes n0 .. n0 + NPW - 1, lane = channel; in-edges in (m, j) order ----
+#pragma unroll
+        for (int i = 0; i < NPW; ++i) {
+            const int n = n0 + i;
+            if (n < N) {
+                bs_f32x2 a01 = {0.f, 0.f}, a23 = {0.f, 0.f};
+#pragma unroll
+                for (int q = 0; q < DEG; ++q) {
+                    const int e = (ent2[i][q >> 1] >> (16 * (q & 1))) & 0xffff;
+                    const unsigned dw = *reinterpret_cast<const unsigned*>(ga + (e & ~0xff) + lane * 4);
+                    const int msk = __builtin_amdgcn_sbfe((int)dw, e & 0xff, 1);            // -1 where this edge won the max
+                    const float g = __uint_as_float(dw & (unsigned)msk & 0xffff0000u);
+                    const f32x4 w4 = *reinterpret_cast<const f32x4*>(es + (i * DEG + q) * 4);
+                    const bs_f32x2 g2 = {g, g};
+                    a01 = g2 * (bs_f32x2){w4[0], w4[1]} + a01;
+                    a23 = g2 * (bs_f32x2){w4[2], w4[3]} + a23;
+                }
+                *reinterpret_cast<uint2*>(pd + n * BS_PSB + lane * 8) = make_uint2(bs_pack2(a01[0], a01[1]), bs_pack2(a23[0], a23[1]));
+            }
+        }
+        BS_STAMP(6);
+        __syncthreads();                              // B_d: dP complete; ga / es of this sample are no longer read
+        BS_STAMP(7);
+
+        // ---- stage the next sample (its loads were issued a whole sample ago) ----
+        if (b + 1 < b_end) {
+            commit(xs0 + (cur ^ 1) * xs_bytes, t);
+            if (b + 2 < b_end) prefetch(b + 2, t);
+        }
+
+        BS_STAMP(8);
+        // ---- dx^T tiles: D[i = c][j = n] = W[c][:] . dP[n][:], channel tile ct, node tiles (wave >> 2) and (wave >> 2) + 4 ----
+        {
+            uint16_t* gxb = p.gx + (int64_t)b * p.x_sb;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int nt = (wave >> 2) + 4 * t;
+                if (nt < ntile) {
+                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                    const unsigned char* bp = pd + (nt * 16 + li) * BS_PSB + lk * 16;
+#pragma unroll
+                    for (int ks = 0; ks < 8; ++ks)
+                        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                            aT[ks], __builtin_bit_cast(bs_bf16x8, *reinterpret_cast<const uint4*>(bp + 64 * ks)), acc, 0, 0, 0);
+                    const int n = nt * 16 + li;
+                    if (n < N)
+                        *bs_at<uint2>(gxb, (unsigned)(n * NIN + ct * 16 + 4 * lk) * 2u) =
+                            make_uint2(bs_pack2(acc[0], acc[1]), bs_pack2(acc[2], acc[3]));
+                }
+            }
+        }
+        BS_STAMP(9);
+        // ---- dW: contraction over nodes.  A = x^T (four column slots of the 64 channels), B = dP^T column slot
+        //      (group h' = wave >> 2 of 64 columns, slot p' = wave & 3) ----
+        for (int kst = 0; kst < nkst; ++kst) {
+            const int row0 = 32 * kst + 8 * lk;
+            bs_bf16x8 bfr;
+            {
+                uint2 rd[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    rd[j] = *reinterpret_cast<const uint2*>(pd + (row0 + j) * BS_PSB + 128 * (wave >> 2) + 8 * li);
+                bfr = bs_tr_dyn(rd, wave & 3);
+            }
+            uint2 rx[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) rx[j] = *reinterpret_cast<const uint2*>(xs + (row0 + j) * BS_XSB + 8 * li);
+            gw[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bs_tr<0>(rx), bfr, gw[0], 0, 0, 0);
+            gw[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bs_tr<1>(rx), bfr, gw[1], 0, 0, 0);
+            gw[2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bs_tr<2>(rx), bfr, gw[2], 0, 0, 0);
+            gw[3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bs_tr<3>(rx), bfr, gw[3], 0, 0, 0);
+        }
+        BS_STAMP(10);
+        cur ^= 1;
+    }   // samples
+
+    // ---- flush dW tiles and dbias into this workgroup's slab (summed by the slab reduce, fixed order) ----
+    if (b_begin < b_end) {
+        float* slab = p.ws + (int64_t)blockIdx.x * ((int64_t)NIN * NCOLS + NOU);
+        const int col = 64 * (wave >> 2) + 4 * li + (wave & 3);
+#pragma unroll
+        for (int pa_ = 0; pa_ < 4; ++pa_)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) slab[(int64_t)(4 * (4 * lk + r) + pa_) * NCOLS + col] = gw[pa_][r];
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(bs_lds + p.off_red);         // [16 waves][64 channels]
+        red[wave * 64 + lane] = gbacc;
+        __syncthreads();
+        if (tid < NOU) {
+            float s = 0.f;
+            for (int w = 0; w < BS_WAVES; ++w) s += red[w * 64 + tid];
+            slab[(int64_t)NIN * NCOLS + tid] = s;
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------------------
+// host side
+// ----------------------------------------------------------------------------------------
+#define BS_REJECT(code) do { if (getenv("FGNN_TRACE")) fprintf(stderr, "[fgnn] sg backward rejects shape: rule %d\n", code); return 0; } while (0)
+
+// Returns 1 if launched, 0 if the call is outside this kernel's family, <0 on error.  d->reserved carries the largest
+// in-degree of the (batch-shared) neighbour table as the caller measured it (0 = unknown: not this kernel).
+int fgnn_mpconv_backward_sg(const fgnn_mpconv_desc* d, const void* x, const int64_t* nn_idx, const void* etype,
+                            const float* filters, const void* gz, const uint8_t* argmax, void* gx, void* getype,
+                            float* gfilters, float* gbias, void* workspace, int64_t workspace_bytes,
+                            fgnn_stream_t stream) {
+    static const bool off = getenv("FGNN_NO_SG") != nullptr;
+    if (off) BS_REJECT(0);
+    if (d->dtype != FGNN_BF16 || d->ext != FGNN_EXT_NONE || d->agg != FGNN_AGG_MAX || d->net != 4) BS_REJECT(1);
+    if (d->nin != 64 || d->nou != 64) BS_REJECT(2);
+    if (d->k != 3 && d->k != 6) BS_REJECT(3);
+    if (d->idx_sb != 0 && d->B > 1) BS_REJECT(4);
+    if (!(d->idx_sk == 1 && d->idx_sm == d->k)) BS_REJECT(5);
+    if (!getype || !argmax || !gbias) BS_REJECT(6);
+    if (d->N < 1 || d->N > BS_MAXN || d->M < 1 || d->M > 96) BS_REJECT(7);
+    const int indeg = d->reserved;
+    const int KC = d->k, DEG = KC == 6 ? 3 : 6;        // LDPC: degree-6 checks <-> degree-3 variables
+    if (indeg < 1 || indeg > DEG) BS_REJECT(8);
+    if (!(d->x_sc == 1 && d->x_sn == d->nin && d->x_sb % 8 == 0)) BS_REJECT(9);
+    if (!(d->y_sc == 1 && (d->y_sm == d->nou || d->M == 1) && d->y_sb % 8 == 0)) BS_REJECT(10);
+    if (!(d->et_se == 1 && d->et_sk == 4 && (d->et_sm == 4 * d->k || d->M == 1) && d->et_sb % 4 == 0)) BS_REJECT(11);
+    if (((uintptr_t)x & 15) || ((uintptr_t)gz & 7) || ((uintptr_t)etype & 7) || ((uintptr_t)argmax & 3) ||
+        ((uintptr_t)gx & 7)) BS_REJECT(12);
+    const int64_t nw = (int64_t)d->nin * d->nou * 4, slab_len = nw + d->nou;
+    if (!workspace || workspace_bytes < 256 * slab_len * 4) BS_REJECT(13);
+    const int NPW = (d->N + BS_WAVES - 1) / BS_WAVES, DPW = (d->M + BS_WAVES - 1) / BS_WAVES;
+    void* fn = nullptr;
+    const int GSL = (d->M * 16 + BS_THREADS - 1) / BS_THREADS;
+    if (KC == 6 && NPW <= 6 && DPW <= 3 && GSL == 1) fn = (void*)mpconv_bwd_sg_kernel<6, 3, 6, 3, 1>;
+    else if (KC == 3 && NPW <= 3 && DPW <= 6) fn = GSL == 1 ? (void*)mpconv_bwd_sg_kernel<3, 6, 3, 6, 1> : (void*)mpconv_bwd_sg_kernel<3, 6, 3, 6, 2>;
+    if (!fn) BS_REJECT(14);
+
+    BsParams p;
+    p.x = (const uint16_t*)x; p.idx = nn_idx; p.et = (const uint16_t*)etype; p.W = filters;
+    p.gz = (const uint16_t*)gz; p.argmax = argmax; p.gx = (uint16_t*)gx; p.get = (uint16_t*)getype;
+    p.ws = (float*)workspace;
+    p.B = d->B; p.N = d->N; p.M = d->M; p.Npad = fgnn_round_up(d->N, 32);
+    p.NPW = KC == 6 ? 6 : 3; p.DPW = KC == 6 ? 3 : 6;
+    p.x_sb = d->x_sb; p.et_sb = d->et_sb; p.y_sb = d->y_sb;
+    int off_b = 0;
+    auto take = [&](int bytes) { const int o = off_b; off_b = fgnn_round_up(off_b + bytes, 16); return o; };
+    p.off_xs = take(2 * p.Npad * BS_XSB);
+    p.off_pd = take(p.Npad * BS_PSB);
+    p.off_ga = take(d->M * BS_GSB);
+    p.zbytes = KC * 4 * BS_ZCS;
+    p.off_z = take(BS_WAVES * p.zbytes + 16 * BS_ZCS);                  // + slack: the last 16-column tile reads past column 4 KC
+    p.off_es = take(BS_WAVES * p.NPW * DEG * 16);
+    p.off_tab = take(d->N * DEG * 4);
+    p.off_idx = take(d->M * KC * 4);
+    p.off_red = p.off_xs;                                               // dbias partials: after the last sample (16 KB)
+    const int lds = off_b > 16384 ? off_b : 16384;
+    if (lds > 160 * 1024) BS_REJECT(15);
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "hipFuncSetAttribute(%d B LDS): %s", lds, hipGetErrorString(e));
+    int grid = 256;
+    if (grid > d->B) grid = d->B;
+    const int chunk = (d->B + grid - 1) / grid;
+    grid = (d->B + chunk - 1) / chunk;
+    hipStream_t st = (hipStream_t)stream;
+    fgnn_note_kernel("mpconv_bwd_sg_kernel<%d, %d>", KC, DEG);
+    p.prof = nullptr;
+#ifdef FGNN_ENABLE_PROF
+    static long long* prof_buf = nullptr;
+    if (getenv("FGNN_PROF")) {
+        if (!prof_buf) (void)hipMalloc(&prof_buf, 64 * 8);
+        (void)hipMemset(prof_buf, 0, 64 * 8);
+        p.prof = prof_buf;
+    }
+#endif
+    void* args[] = {(void*)&p};
+    e = hipLaunchKernel(fn, dim3(grid), dim3(BS_THREADS), args, lds, st);
+    if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "mpconv sg backward launch: %s", hipGetErrorString(e));
+#ifdef FGNN_ENABLE_PROF
+    if (p.prof) {                                     // tuning aid: phase timeline of one sample, waves 0 / 4 / 8 / 12 (shader clocks)
+        long long h[64];
+        (void)hipDeviceSynchronize();
+        (void)hipMemcpy(h, p.prof, sizeof(h), hipMemcpyDeviceToHost);
+        for (int w = 0; w < 4; ++w) {
+            fprintf(stderr, "[fgnn prof sg bwd] wave %d:", 4 * w);
+            for (int i = 0; i < 11; ++i) fprintf(stderr, " %lld", h[w * 16 + i] - h[0]);
+            fprintf(stderr, "\n");
+        }
+    }
+#endif
+    fgnn_launch_slab_reduce(p.ws, grid, slab_len, nw, gfilters, gbias, st);
+    e = hipGetLastError();
+    if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "mpconv backward helper launch: %s", hipGetErrorString(e));
+    return 1;
+}

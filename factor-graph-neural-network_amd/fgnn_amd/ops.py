@@ -162,6 +162,27 @@ def shared_graph_view(nn_idx):
     return nn_idx[:1].expand(B, -1, -1) if memo[1] else nn_idx
 
 
+def max_in_degree(nn_idx, N):
+    """Largest number of times one source node appears in a batch-SHARED neighbour table (the degree of the transposed
+    incidence), 0 when unknown.  The second-generation backward (csrc/mpconv_bwd_sg.hip) keeps every source node's
+    in-edges in registers and needs this bound up front (LDPC 96.3.963: 3 for the variables, 6 for the checks); it is
+    measured once per table — one bincount + host read, remembered on the tensor that owns the memory — and travels to the
+    C ABI in ``fgnn_mpconv_desc.reserved``.  Unknown (a per-sample table, or a first sight during hipGraph capture) sends
+    the call to the first-generation kernels."""
+    if nn_idx.shape[0] > 1 and nn_idx.stride(0) != 0:
+        return 0
+    owner = nn_idx._base if nn_idx._base is not None else nn_idx
+    key = (nn_idx._version, nn_idx.data_ptr(), tuple(nn_idx.shape), tuple(nn_idx.stride()), N)
+    memo = getattr(owner, '_fgnn_in_degree', None)
+    if memo is None or memo[0] != key:
+        if torch.cuda.is_current_stream_capturing():
+            return 0
+        flat = nn_idx[0].reshape(-1).clamp(0, N - 1)
+        memo = (key, int(torch.bincount(flat, minlength=N).max().item()) if flat.numel() else 0)
+        owner._fgnn_in_degree = memo
+    return memo[1]
+
+
 def mpconv_forward_raw(x, nn_idx, etype, filters, bias, nou, net, ext, agg, *,
                        post_scale=None, post_shift=None, relu=False, want_argmax=False, want_stats=False):
     """One launch of fgnn_mpconv_forward.  Returns (y, argmax-or-None).  ``want_stats``: where the shape has a
@@ -304,6 +325,7 @@ class _MPConv(torch.autograd.Function):
             gb = gb_sink if gb_sink is not None else torch.zeros((nou,), device=x.device, dtype=torch.float32)
         w = filters.detach().float().contiguous()
         d = _hip.make_desc(xx, nn_idx, etype, nou, net, ext, agg, False, gz)
+        d.reserved = max_in_degree(nn_idx, x.shape[2])
         ws = _workspace(x.device, int(L.fgnn_mpconv_backward_workspace_bytes(ctypes.byref(d))))
         nbytes = 0
         if TIMER is not None:

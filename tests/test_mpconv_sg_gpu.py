@@ -128,3 +128,83 @@ def test_sg_statistics_epilogue(shape, B, dev):
     assert any(n.startswith('bn_stats') for n in b[5]), b[5]
     assert H.rel_err(a[0], b[0]) <= 2.0 ** -7 and H.rel_err(a[3], b[3]) <= 2.0 ** -6
     assert H.rel_err(a[1], b[1]) <= 1e-5 and H.rel_err(a[2], b[2]) <= 1e-4 and H.rel_err(a[4], b[4]) <= 2e-3
+
+
+def _regular_table(N, M, k, g):
+    """A random bipartite graph in which every source node appears M k / N times (like the 96.3.963 code: 3 / 6)."""
+    assert (M * k) % N == 0
+    slots = torch.arange(N).repeat_interleave(M * k // N)[torch.randperm(M * k, generator=g)]
+    return slots.reshape(1, M, k)
+
+
+BWD_SHAPES = [(96, 48, 6), (48, 96, 3), (64, 32, 6), (32, 64, 3), (96, 16, 6), (16, 32, 3)]      # (N, M, k), 64 -> 64 channels
+
+
+@pytest.mark.parametrize('shape', BWD_SHAPES, ids=lambda s: 'x'.join(map(str, s)))
+@pytest.mark.parametrize('B', [1, 37, 600])
+def test_sg_backward_vs_routed_reference(shape, B, dev):
+    """Shared regular graph, 64 -> 64 channels: csrc/mpconv_bwd_sg.hip against torch autograd through the forward's own
+    routing (same bf16-rounded x / etype / gz, f32 arithmetic): what remains is the bf16 rounding of P, dP, the routed
+    products and the bf16 outputs -> 2^-6 of each gradient's range.  Ragged batches (B = 37: chunks of different length per
+    workgroup; B = 600: several samples per workgroup) and the real LDPC degrees (3 in / 6 out, 6 in / 3 out)."""
+    from fgnn_amd import _hip, ops
+    N, M, k = shape
+    nin = nou = 64
+    net = 4
+    g = torch.Generator().manual_seed(100 + N + B)
+    x = torch.randn(B, N, 1, nin, generator=g).bfloat16()
+    idx = _regular_table(N, M, k, g)
+    et = torch.randn(B, M, k, net, generator=g).bfloat16()
+    W = torch.randn(nin, nou * net, generator=g) * 0.1
+    bias = torch.randn(nou, generator=g)
+    gz = torch.randn(B, M, 1, nou, generator=g).bfloat16()
+    xd = x.to(dev).permute(0, 3, 1, 2).requires_grad_(True)
+    etd = et.to(dev).permute(0, 3, 1, 2).requires_grad_(True)
+    idxd = idx.to(dev).expand(B, -1, -1)
+    Wd, bd = W.to(dev).requires_grad_(True), bias.to(dev).requires_grad_(True)
+    z = ops.mpconv(xd, idxd, etd, Wd, bd, nou, net, 0, _hip.AGG_MAX)
+    _, am = ops.mpconv_forward_raw(xd.detach(), idxd, etd.detach(), W.to(dev), bias.to(dev), nou, net, 0, _hip.AGG_MAX,
+                                   want_argmax=True)
+    z.backward(gz.to(dev).permute(0, 3, 1, 2))
+    assert 'mpconv_bwd_sg' in _hip.lib().fgnn_last_kernel().decode(), _hip.lib().fgnn_last_kernel()
+    xr = x[:, :, 0, :].float().clone().requires_grad_(True)                                # [B,N,nin]
+    er = et.float().clone().requires_grad_(True)                                           # [B,M,k,net]
+    Wr, br = W.clone().requires_grad_(True), bias.clone().requires_grad_(True)
+    P = torch.einsum('bnc,cq->bnq', xr, Wr).reshape(B, N, nou, net)
+    E = (P[:, idx[0]] * er[:, :, :, None, :]).sum(-1)                                      # [B,M,k,nou]
+    sel = am.cpu().long()[..., 0].permute(0, 2, 1)[:, :, None, :]                          # [B,M,1,nou]
+    zr = E.gather(2, sel)[:, :, 0, :] + br[None, None, :]                                  # [B,M,nou]
+    zr.backward(gz[:, :, 0, :].float())
+    tol = 2.0 ** -6
+    assert H.rel_err(xd.grad.float().permute(0, 2, 3, 1)[:, :, 0, :], xr.grad) <= tol
+    assert H.rel_err(etd.grad.float().permute(0, 2, 3, 1), er.grad) <= tol
+    assert H.rel_err(Wd.grad, Wr.grad) <= tol
+    assert H.rel_err(bd.grad, br.grad) <= tol
+
+
+def test_sg_backward_is_bitwise_reproducible_and_matches_first_generation(dev, monkeypatch):
+    """No atomics, fixed summation orders: two runs give identical bits; and the first-generation kernel (taken when the
+    in-degree is not passed) agrees within bf16 rounding."""
+    from fgnn_amd import _hip, ops
+    N, M, k, B = 96, 48, 6, 300
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(B, N, 1, 64, generator=g).bfloat16().to(dev).permute(0, 3, 1, 2)
+    idx = _regular_table(N, M, k, g).to(dev).expand(B, -1, -1)
+    et = torch.randn(B, M, k, 4, generator=g).bfloat16().to(dev).permute(0, 3, 1, 2)
+    W, bias = (torch.randn(64, 256, generator=g) * 0.1).to(dev), torch.randn(64, generator=g).to(dev)
+    gz = torch.randn(B, M, 1, 64, generator=g).bfloat16().to(dev).permute(0, 3, 1, 2)
+
+    def run():
+        xd, ed = x.detach().requires_grad_(True), et.detach().requires_grad_(True)
+        Wd, bd = W.detach().requires_grad_(True), bias.detach().requires_grad_(True)
+        ops.mpconv(xd, idx, ed, Wd, bd, 64, 4, 0, _hip.AGG_MAX).backward(gz)
+        return xd.grad, ed.grad, Wd.grad, bd.grad, _hip.lib().fgnn_last_kernel().decode()
+
+    a, b = run(), run()
+    assert 'mpconv_bwd_sg' in a[4]
+    assert all(torch.equal(u, v) for u, v in zip(a[:4], b[:4]))
+    monkeypatch.setattr(ops, 'max_in_degree', lambda *_: 0)
+    c = run()
+    assert 'mpconv_bwd_b16' in c[4]
+    for u, v in zip(a[:4], c[:4]):
+        assert H.rel_err(u.float(), v.float()) <= 2.0 ** -6

@@ -40,6 +40,7 @@ def main():
     ap.add_argument('--dtype', default='f32')
     ap.add_argument('--layout', default='cl', choices=['cl', 'nchw'])
     ap.add_argument('--bwd', action='store_true')
+    ap.add_argument('--regular', action='store_true', help='regular random graphs (constant in-degree) for the parity shapes')
     ap.add_argument('--only', default='')
     ap.add_argument('--syn', action='store_true', help='the synthetic-PGM shapes instead of the LDPC ones')
     ap.add_argument('--etgrad', action='store_true', help='hyper shapes: also ask for the edge-weight gradient')
@@ -58,7 +59,12 @@ def main():
         x = torch.randn(B, nin, N, 1, generator=g).to(dev, dt)
         if a.layout == 'cl':
             x = x.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
-        idx = torch.randint(0, N, (1, M, k), generator=g).to(dev).expand(B, -1, -1)
+        if a.regular and (M * k) % N == 0:
+            # a random REGULAR bipartite graph (every source node appears M k / N times), like the 96.3.963 code
+            slots = torch.arange(N).repeat_interleave(M * k // N)[torch.randperm(M * k, generator=g)]
+            idx = slots.reshape(1, M, k).to(dev).expand(B, -1, -1)
+        else:
+            idx = torch.randint(0, N, (1, M, k), generator=g).to(dev).expand(B, -1, -1)
         if net == 1:
             et = torch.ones(1, 1, M, k, device=dev, dtype=dt).expand(B, -1, -1, -1)
         else:
@@ -83,6 +89,7 @@ def main():
             gw = torch.zeros_like(W)
             gb = torch.zeros(nou, device=dev)
             dsc = _hip.make_desc(x, idx, et, nou, net, ext, agg, False, gz)
+            dsc.reserved = ops.max_in_degree(idx, N)
             nbytes = (x.element_size() * (x.numel() + gz.numel()) + et.element_size() * net * M * k *
                       (1 if et.stride(0) == 0 else B) + 8 * M * k + B * nou * M + x.element_size() * (gx.numel() + (get.numel() if get is not None else 0))
                       + 8 * W.numel())
