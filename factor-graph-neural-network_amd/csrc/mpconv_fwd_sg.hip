@@ -406,7 +406,10 @@ int fgnn_mpconv_forward_sg(const fgnn_mpconv_desc* d, const void* x, const int64
     if (off) return 0;
     if (d->dtype != FGNN_BF16 || d->ext != FGNN_EXT_NONE || d->net != 4 || d->agg != FGNN_AGG_MAX) return 0;
     if (d->k != 3 && d->k != 6) return 0;
-    if (!((d->nin == 64 && (d->nou == 64 || d->nou == 128)) || (d->nin == 128 && d->nou == 64))) return 0;
+    // 64 -> 128 (two column passes: 32 more resident fragment registers) spills under the 128-VGPR budget of 2 workgroups per
+    // CU and measured slower than the first-generation kernel (200 vs 150 us): it stays there unless FGNN_SG_WIDE is set
+    static const bool wide = getenv("FGNN_SG_WIDE") != nullptr;
+    if (!((d->nin == 64 && (d->nou == 64 || (wide && d->nou == 128))) || (d->nin == 128 && d->nou == 64))) return 0;
     if (d->N < 1 || d->N > 96 || d->M < 1) return 0;
     const int DPW = (d->M + SG_WAVES - 1) / SG_WAVES;
     const int MAXD = d->k == 6 ? 6 : 12;
