@@ -220,8 +220,8 @@ def main():
         else:
             compute()
         if train:
-            bucket.all_reduce_mean()
-            opt.step()
+            bucket.all_reduce_sum()                 # one RCCL all-reduce of the flat gradient; the mean is folded into Adam
+            opt.step(grad_scale=1.0 / world)
 
     def fence():
         torch.cuda.synchronize()

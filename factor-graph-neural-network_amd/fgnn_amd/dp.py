@@ -70,6 +70,11 @@ class FlatGradBucket:
     def world(self):
         return dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
 
+    def all_reduce_sum(self):
+        """Sum over ranks, nothing else: the division by the world size rides in ``FlatAdam.step(grad_scale=1/world)``."""
+        if self.world > 1:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+
     def all_reduce_mean(self, async_op=False):
         """Sum over ranks then divide by world size (mean gradient of the global batch)."""
         w = self.world
@@ -89,7 +94,7 @@ class FlatGradBucket:
 
 class FlatAdam:
     """Adam (torch.optim.Adam's update, no amsgrad) on the flat parameter / gradient buffers of a
-    ``FlatGradBucket(..., flatten_params=True)``: eight elementwise kernels per step, whatever the number of
+    ``FlatGradBucket(..., flatten_params=True)``: one kernel per step (csrc/flat_adam.hip), whatever the number of
     parameter tensors.  In-place updates of the flat buffer do not bump the per-parameter version counters,
     so the step also invalidates this package's cached low-precision weight copies."""
 
@@ -103,17 +108,30 @@ class FlatAdam:
         self.t = 0
 
     @torch.no_grad()
-    def step(self):
+    def step(self, grad_scale=1.0):
+        """One update.  On a ROCm device: ONE kernel over the four flat buffers (csrc/flat_adam.hip); ``grad_scale`` folds a
+        pending division of the gradient (1 / world after an all-reduce SUM) into it.  On the CPU (tests): the same
+        rule as elementwise torch ops."""
         p, g = self.bucket.flat_param, self.bucket.flat
         b1, b2 = self.betas
         self.t += 1
-        if self.weight_decay:
-            g = g.add(p, alpha=self.weight_decay)
-        self.exp_avg.lerp_(g, 1.0 - b1)
-        self.exp_avg_sq.mul_(b2).addcmul_(g, g, value=1.0 - b2)
-        bc1, bc2 = 1.0 - b1 ** self.t, 1.0 - b2 ** self.t
-        denom = (self.exp_avg_sq.sqrt() / (bc2 ** 0.5)).add_(self.eps)
-        p.addcdiv_(self.exp_avg, denom, value=-self.lr / bc1)
+        if p.is_cuda:
+            from . import _hip
+            P = _hip._ptr
+            _hip.check(_hip.lib().fgnn_flat_adam(P(p), P(g), P(self.exp_avg), P(self.exp_avg_sq), None, p.numel(),
+                                                 float(self.lr), float(b1), float(b2), float(self.eps),
+                                                 float(self.weight_decay), float(grad_scale), int(self.t),
+                                                 _hip.stream_ptr()))
+        else:
+            if grad_scale != 1.0:
+                g = g * grad_scale
+            if self.weight_decay:
+                g = g.add(p, alpha=self.weight_decay)
+            self.exp_avg.lerp_(g, 1.0 - b1)
+            self.exp_avg_sq.mul_(b2).addcmul_(g, g, value=1.0 - b2)
+            bc1, bc2 = 1.0 - b1 ** self.t, 1.0 - b2 ** self.t
+            denom = (self.exp_avg_sq.sqrt() / (bc2 ** 0.5)).add_(self.eps)
+            p.addcdiv_(self.exp_avg, denom, value=-self.lr / bc1)
         from .mpnn import pointwise
         pointwise.invalidate_casts()
         pointwise.note_state_change()

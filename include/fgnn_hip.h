@@ -205,6 +205,17 @@ int fgnn_mpconv_block_forward_fanin(const fgnn_mpconv_desc* d, const void* x, co
 int fgnn_sum_n(const void* const* inputs, int32_t n, int64_t numel, int32_t dtype, void* out, fgnn_stream_t stream);
 
 /*
+ * One Adam step (torch.optim.Adam's rule, no amsgrad — the optimizer of the reference's training scripts, e.g.
+ * train_ldpc.py:160-166) over a flat f32 parameter buffer and its flat gradient in a single pass:
+ *   g' = grad * grad_scale + weight_decay * param;  exp_avg, exp_avg_sq updated in place;  param updated in place.
+ * bf16_mirror (or NULL): a bf16 copy of the parameters refreshed in the same pass (what the bf16 GEMMs read).
+ * grad_scale = 1 / world_size turns the all-reduced SUM of the data-parallel ranks into their mean.  step >= 1.
+ */
+int fgnn_flat_adam(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, void* bf16_mirror, int64_t n,
+                   float lr, float beta1, float beta2, float eps, float weight_decay, float grad_scale, int64_t step,
+                   fgnn_stream_t stream);
+
+/*
  * The edge-type MLP in front of the operator, etype = W2 ReLU(W1 efeature + b1) + b2 with Cin <= 8 -> 64 -> net <= 4
  * (`emodel_f2v / emodel_v2f`, /root/reference/train_ldpc.py:32-38,68-69), without the 64-channel hidden tensor ever
  * reaching memory.  x is bf16 with element (b, c, r) at b*x_sb + c*x_sc + r*x_sr (r one of the E = M*k edge rows of

@@ -1,0 +1,105 @@
+"""GPU, world_size 2 on ONE device over gloo: the data-parallel path bench.py drives with RCCL — the real LDPCModel, the
+flat gradient bucket and its single all-reduce, FlatAdam on the flat parameter buffer, and the hipGraph-captured step
+— exercised end to end without an 8-GPU node (BASELINE config 4 is run by the driver; this is its readiness check).
+
+Every rank takes half of one fixed 128-codeword batch.  With BatchNorm normalising by its running statistics (so that no
+statistic depends on how the batch is split) the mean of the two ranks' gradients IS the full-batch gradient: after 3 steps
+the replicas must be bit-identical to each other and equal — to f32 summation-order rounding — to a single process that
+trained on the whole batch."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+STEPS, PER_RANK = 3, 64
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _setup_paths():
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    for p in (os.path.join(os.path.dirname(here), 'factor-graph-neural-network_amd'), here):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+
+
+def _train(rank, world, graph):
+    """3 steps on this rank's shard; returns the flat parameter buffer (a CPU tensor)."""
+    _setup_paths()
+    import contextlib
+    import io
+    import fgnn_amd
+    from fgnn_amd.datapath import LdpcDataPath
+    from fgnn_amd.dp import FlatAdam, FlatGradBucket, broadcast_parameters, shard_range
+    from fgnn_amd.graph import StepGraph
+    dev = torch.device('cuda', 0)
+    torch.cuda.set_device(dev)
+    torch.manual_seed(11)
+    with contextlib.redirect_stdout(io.StringIO()):
+        model = fgnn_amd.LDPCModel(2, 6, 4, aggregator='max').to(dev)
+    if rank == 1:                                   # replicas start different: the broadcast must fix it
+        with torch.no_grad():
+            for q in model.parameters():
+                if q.requires_grad:
+                    q.add_(0.5)
+    broadcast_parameters(model)
+    model.eval()                                    # BatchNorm by running statistics: shard-independent
+    data = LdpcDataPath(dev).sample(PER_RANK * 2, seed=77, dtype=torch.bfloat16)
+    lo, hi = shard_range(PER_RANK * 2, rank, world)
+    inputs = tuple(t[lo:hi] for t in data[:6])
+    label = data[6][lo:hi, :48].float().contiguous()
+    bucket = FlatGradBucket(model.parameters(), flatten_params=True)
+    opt = FlatAdam(bucket, lr=1e-3)
+    amp = torch.autocast('cuda', dtype=torch.bfloat16)
+
+    def compute():
+        bucket.zero()
+        with amp:
+            logits, _ = model(*inputs)
+        torch.nn.functional.binary_cross_entropy_with_logits(logits.float().reshape(-1), label.reshape(-1)).backward()
+
+    step = StepGraph(compute) if graph else compute
+    for _ in range(STEPS):
+        step()
+        bucket.all_reduce_mean()
+        opt.step()
+    torch.cuda.synchronize()
+    return bucket.flat_param.detach().cpu().clone()
+
+
+def _worker(rank, world, port, out, graph):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    flat = _train(rank, world, graph)
+    torch.save(flat, os.path.join(out, 'rank%d.pt' % rank))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('graph', [False, True], ids=['eager', 'hipgraph'])
+def test_two_ranks_on_one_gpu_equal_single_process(graph, tmp_path, dev):
+    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path), graph), nprocs=2, join=True)
+    a = torch.load(os.path.join(str(tmp_path), 'rank0.pt'))
+    b = torch.load(os.path.join(str(tmp_path), 'rank1.pt'))
+    assert torch.equal(a, b), 'replicas diverged'
+    ref = _train(0, 1, graph)                       # one process, the whole batch
+    assert ref.shape == a.shape and float(ref.abs().max()) > 0
+    moved = float((ref - 0).abs().max())
+    err = float((a - ref).abs().max())
+    print('2-rank vs 1-process parameters after %d steps: max abs diff %.3e (parameter scale %.3g)' % (STEPS, err, moved))
+    # Adam divides by sqrt(v): where a gradient is ~0 its sign is rounding noise and the update +-lr either way — bound the
+    # disagreement by a few learning rates, and demand near-equality in the bulk
+    assert err <= 3 * STEPS * 1e-3
+    assert float(((a - ref).abs() > 1e-5).float().mean()) <= 0.02

@@ -268,3 +268,27 @@ def test_repeated_tables_take_the_shared_graph_path(dev):
         outs.append((z.detach(), xd.grad, ed.grad, Wd.grad))
     for a, b in zip(*outs):
         assert torch.equal(a, b)
+
+
+def test_fused_flat_adam_matches_torch_adam(dev):
+    """dp.FlatAdam's single kernel (csrc/flat_adam.hip) against torch.optim.Adam on the same parameters and gradients,
+    weight decay and the folded gradient scale included, over several steps (bias corrections change every step)."""
+    from fgnn_amd.dp import FlatAdam, FlatGradBucket
+    torch.manual_seed(0)
+    make = lambda: torch.nn.Sequential(torch.nn.Linear(37, 53), torch.nn.Tanh(), torch.nn.Linear(53, 3)).to(dev)
+    a = make()
+    b = make()
+    b.load_state_dict(a.state_dict())
+    ref = torch.optim.Adam(a.parameters(), lr=3e-3, weight_decay=1e-2)
+    bucket = FlatGradBucket(b.parameters(), flatten_params=True)
+    opt = FlatAdam(bucket, lr=3e-3, weight_decay=1e-2)
+    x, y = torch.randn(64, 37, device=dev), torch.randn(64, 3, device=dev)
+    for _ in range(7):
+        ref.zero_grad()
+        torch.nn.functional.mse_loss(a(x), y).backward()
+        ref.step()
+        bucket.zero()
+        (2.0 * torch.nn.functional.mse_loss(b(x), y)).backward()          # twice the gradient ...
+        opt.step(grad_scale=0.5)                                          # ... halved inside the kernel
+    for pa, pb in zip(a.parameters(), b.parameters()):
+        assert torch.allclose(pa, pb, rtol=2e-5, atol=2e-7), float((pa - pb).abs().max())
