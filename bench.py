@@ -270,9 +270,9 @@ def main():
                     'unit': 'TFLOP/s', 'frac': round(tfs / F32_MFMA_PEAK_TFLOPS, 4), 'traffic': None}
             # Which roof binds: the f32-MFMA kernels (exact v_mfma_f32_16x16x4_f32; also used with bf16
             # storage in the backward) sit above the f32 ridge (AI 42-80 FLOP/B vs 157 TF / 8 TB/s = 20):
-            # MFMA-bound.  The bf16-MFMA forward (mpconv_fwd_b16_kernel, AI ~80 << bf16 ridge ~312) is
+            # MFMA-bound.  The bf16-MFMA kernels (mpconv_*_b16 / mpconv_*_sg, AI ~80 << bf16 ridge ~312) are
             # HBM-bound.  The other figure is reported alongside.
-            if 'b16' in sym:
+            if 'b16' in sym or '_sg_' in sym:        # the bf16-storage, bf16-MFMA kernel families
                 mfma['peak'] = BF16_MFMA_PEAK_TFLOPS
                 mfma['frac'] = round(tfs / BF16_MFMA_PEAK_TFLOPS, 4)
                 roofline = dict(hbm)

@@ -3,9 +3,9 @@ flat gradient bucket and its single all-reduce, FlatAdam on the flat parameter b
 — exercised end to end without an 8-GPU node (BASELINE config 4 is run by the driver; this is its readiness check).
 
 Every rank takes half of one fixed 128-codeword batch.  With BatchNorm normalising by its running statistics (so that no
-statistic depends on how the batch is split) the mean of the two ranks' gradients IS the full-batch gradient: after 3 steps
-the replicas must be bit-identical to each other and equal — to f32 summation-order rounding — to a single process that
-trained on the whole batch."""
+statistic depends on how the batch is split) the mean of the two ranks' gradients IS the full-batch gradient: it must equal —
+to f32 summation-order rounding — the gradient of a single process on the whole batch, the first optimizer step must land on the
+same parameters, and after 3 steps the two replicas must still be bit-identical to each other."""
 import os
 import socket
 
@@ -71,20 +71,25 @@ def _train(rank, world, graph):
         torch.nn.functional.binary_cross_entropy_with_logits(logits.float().reshape(-1), label.reshape(-1)).backward()
 
     step = StepGraph(compute) if graph else compute
-    for _ in range(STEPS):
+    first_grad = first_param = None
+    for it in range(STEPS):
         step()
         bucket.all_reduce_mean()
+        if it == 0:
+            first_grad = bucket.flat.detach().cpu().clone()
         opt.step()
+        if it == 0:
+            first_param = bucket.flat_param.detach().cpu().clone()
     torch.cuda.synchronize()
-    return bucket.flat_param.detach().cpu().clone()
+    return bucket.flat_param.detach().cpu().clone(), first_grad, first_param
 
 
 def _worker(rank, world, port, out, graph):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
-    flat = _train(rank, world, graph)
-    torch.save(flat, os.path.join(out, 'rank%d.pt' % rank))
+    flat, grad, p1 = _train(rank, world, graph)
+    torch.save({'param': flat, 'grad': grad, 'param1': p1}, os.path.join(out, 'rank%d.pt' % rank))
     dist.destroy_process_group()
 
 
@@ -93,13 +98,17 @@ def test_two_ranks_on_one_gpu_equal_single_process(graph, tmp_path, dev):
     mp.spawn(_worker, args=(2, _free_port(), str(tmp_path), graph), nprocs=2, join=True)
     a = torch.load(os.path.join(str(tmp_path), 'rank0.pt'))
     b = torch.load(os.path.join(str(tmp_path), 'rank1.pt'))
-    assert torch.equal(a, b), 'replicas diverged'
-    ref = _train(0, 1, graph)                       # one process, the whole batch
-    assert ref.shape == a.shape and float(ref.abs().max()) > 0
-    moved = float((ref - 0).abs().max())
-    err = float((a - ref).abs().max())
-    print('2-rank vs 1-process parameters after %d steps: max abs diff %.3e (parameter scale %.3g)' % (STEPS, err, moved))
-    # Adam divides by sqrt(v): where a gradient is ~0 its sign is rounding noise and the update +-lr either way — bound the
-    # disagreement by a few learning rates, and demand near-equality in the bulk
-    assert err <= 3 * STEPS * 1e-3
-    assert float(((a - ref).abs() > 1e-5).float().mean()) <= 0.02
+    assert torch.equal(a['param'], b['param']) and torch.equal(a['grad'], b['grad']), 'replicas diverged'
+    ref_param, ref_grad, ref_p1 = _train(0, 1, graph)       # one process, the whole batch
+    scale = float(ref_grad.abs().max())
+    assert scale > 0 and torch.isfinite(a['param']).all() and torch.isfinite(ref_param).all()
+    err = float((a['grad'] - ref_grad).abs().max()) / scale
+    print('mean of the 2 ranks\' gradients vs the full-batch gradient: max abs diff %.2e of the gradient range' % err)
+    # same per-sample gradients, summed in a different order / grouping (f32): rounding only
+    assert err <= 1e-4, err
+    # one optimizer step from equal gradients gives equal parameters wherever the gradient is above its own rounding noise
+    # (Adam normalises every coordinate to +-lr: a coordinate that is pure cancellation noise moves by +-lr with a random
+    # sign).  Later steps are NOT compared across the two runs: a bf16 decoder with max-routing amplifies those +-lr
+    # differences chaotically; what data parallelism must guarantee there is that the replicas stay identical (above).
+    firm = ref_grad.abs() > 1e-3 * scale
+    assert float((a['param1'] - ref_p1).abs()[firm].max()) <= 1e-5
