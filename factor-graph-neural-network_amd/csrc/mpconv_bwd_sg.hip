@@ -17,8 +17,8 @@
 //     {gz as the high half | one-hot argmax in the low bits}, a bit-field extract, an AND and two packed FMAs;
 //   * routing by DESTINATION (detype): lane = channel reads only the routed P row (v_perm picks the node id out of the
 //     destination's packed neighbour bytes), forms the 4 products, and parks them as bf16 in a wave-private,
-//     zero-initialised [slot j][edge type e][channel] image.  The sum over channels is then an MFMA with an all-ones A
-//     operand (4 instructions per destination) — no cross-lane shuffles;
+//     zero-initialised [slot j][edge-type pair][channel] image (one dword = two edge types).  The sum over channels is
+//     then an MFMA whose A operand is an even / odd selector (4 instructions per destination) — no cross-lane shuffles;
 //   * the three GEMM-shaped phases run on v_mfma_f32_16x16x32_bf16 as before (dW takes its node-contracted operands by
 //     reading 8 rows x 4 columns per lane and transposing in registers with v_perm_b32).
 // One 1024-thread workgroup (16 waves) per CU: the LDS images of a sample (x double-buffered 2 x 14 KB, P / dP 50 KB —
@@ -31,7 +31,7 @@
 #define BS_XSB 144           // x image row stride, bytes (64 bf16 + 16: rows land on distinct 16-byte slots)
 #define BS_PSB 528           // P / dP image row stride, bytes (256 bf16 + 16)
 #define BS_GSB 256           // ga row: 64 dwords {gz bf16 << 16 | argmax << 8 | 1 << argmax}
-#define BS_ZCS 144           // detype image: column (slot j, edge type e) stride in bytes (64 bf16 + 16)
+#define BS_ZCS 272           // detype image: column (slot j, edge-type pair) stride in bytes (64 dwords {e even | e odd} + 16)
 #define BS_MAXN 96
 
 typedef __bf16 bs_bf16x8 __attribute__((ext_vector_type(8)));
@@ -111,7 +111,6 @@ __device__ __forceinline__ bs_bf16x8 bs_tr_dyn(const uint2 (&r)[8], int P) {
 template <int KC, int DEG, int NPW, int DPW, int GSL>
 __global__ __launch_bounds__(BS_THREADS, 4) void mpconv_bwd_sg_kernel(const BsParams p) {
     constexpr int NIN = 64, NCOLS = 256, NOU = 64;
-    constexpr int NZT = (KC * 4 + 15) / 16;           // 16-column tiles of the detype image: 1 (degree 3) or 2 (degree 6)
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int li = lane & 15, lk = lane >> 4;
@@ -121,8 +120,7 @@ __global__ __launch_bounds__(BS_THREADS, 4) void mpconv_bwd_sg_kernel(const BsPa
     unsigned char* xs0 = bs_lds + p.off_xs;                              // 2 x [Npad][XSB]  bf16 x (double-buffered)
     unsigned char* pd = bs_lds + p.off_pd;                               // [Npad][PSB]      bf16 P, then dP
     unsigned char* ga = bs_lds + p.off_ga;                               // [M][GSB]         {gz | argmax}
-    unsigned char* zb = bs_lds + p.off_z + wave * p.zbytes;              // this wave's detype image [KC*4][ZCS]
-    float* es = reinterpret_cast<float*>(bs_lds + p.off_es) + wave * (NPW * DEG * 4);     // this wave's in-edge weights, f32
+    unsigned char* zb = bs_lds + p.off_z + wave * p.zbytes;              // this wave's detype image [KC*2][ZCS]
     int* tab = reinterpret_cast<int*>(bs_lds + p.off_tab);               // [N][DEG]  m * 256 + j of every in-edge
     int* idx_s = reinterpret_cast<int*>(bs_lds + p.off_idx);             // [M * KC]
     const int xs_bytes = Npad * BS_XSB;
@@ -183,8 +181,7 @@ __global__ __launch_bounds__(BS_THREADS, 4) void mpconv_bwd_sg_kernel(const BsPa
     //               aT: A of dx^T = W dP^T (wave & 3 = 16-channel tile): A[i = c][k = col] = W[ct*16 + i][col], 8 consecutive cols.
     //               Resident (32 VGPRs): re-reading it from L2 per sample had every CU of the chip hammering the same 64 KB —
     //               17 000 cycles per sample in the dx phase (profiles/r02).
-    bs_bf16x8 aP[2], aT[8];
-    const int ct = wave & 3;
+    bs_bf16x8 aP[2];
     {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -194,25 +191,36 @@ __global__ __launch_bounds__(BS_THREADS, 4) void mpconv_bwd_sg_kernel(const BsPa
             for (int u = 0; u < 8; ++u) w8[u] = wp[(int64_t)u * NCOLS];
             aP[ks] = bs_frag_f32(w8);
         }
-#pragma unroll
-        for (int ks = 0; ks < 8; ++ks) aT[ks] = bs_frag_f32(p.W + (int64_t)(ct * 16 + li) * NCOLS + 32 * ks + 8 * lk);
     }
-    bs_bf16x8 ones;
+    // The last two phases of a sample both only READ the dP image, so they run side by side on the two halves of the
+    // workgroup: waves 0-7 accumulate dW (each re-reads x^T and its dP^T columns: halving the waves that do halves that
+    // LDS traffic), waves 8-15 produce dx.  The 32 registers each needs for the whole kernel are ONE array R:
+    //   waves 0-7 : R[2 pa + s] = dW accumulator of A slot pa (channel 4 i + pa) x column slot 2 (wave & 1) + s of group wave >> 1
+    //   waves 8-15: R[ks]       = A fragment of dx^T = W dP^T: W[ct*16 + i][32 ks + 8 lk ..+7] as bf16 (ct = wave & 3)
+    const bool dw_wave = wave < 8;
+    const int ct = wave & 3;
+    f32x4 R[8];
+    if (dw_wave) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) R[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    } else {
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks)
+            R[ks] = __builtin_bit_cast(f32x4, bs_frag_f32(p.W + (int64_t)(ct * 16 + li) * NCOLS + 32 * ks + 8 * lk));
+    }
+    // A operand of the channel sums: row 0 adds the even k (first edge type of a pair), row 1 the odd k, other rows nothing
+    bs_bf16x8 evod;
     {
-        const unsigned o2 = 0x3f803f80u;
-        ones = __builtin_bit_cast(bs_bf16x8, make_uint4(o2, o2, o2, o2));
+        const unsigned w = li == 0 ? 0x00003f80u : (li == 1 ? 0x3f800000u : 0u);
+        evod = __builtin_bit_cast(bs_bf16x8, make_uint4(w, w, w, w));
     }
-
-    f32x4 gw[4];                                      // dW accumulators: A slot pa (channel 4 i + pa) x this wave's column slot
-#pragma unroll
-    for (int t = 0; t < 4; ++t) gw[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float gbacc = 0.f;                                // dbias of channel `lane` over this wave's destinations (detype phase)
 
     // ---- prefetch registers (raw chunks; decoded at the commit) ----
     uint4 px;                                         // one 16-byte x chunk (N * 8 <= 768 chunks)
     uint2 pg[GSL];                                      // gz of items tid, tid + 1024: (m = item >> 4, channels 4 (item & 15) ..+3)
     unsigned pa[GSL];                                   // argmax of the same items
-    uint2 pe;                                         // edge-type row of in-edge `lane` of this wave
+    uint2 pe, pe_cur = make_uint2(0, 0);              // edge-type row of in-edge `lane` of this wave: next sample's / this sample's
     const int xchunks = N * 8, gitems = M * 16;
     auto prefetch = [&](int b, int t) {
         const unsigned utid = (unsigned)t;
@@ -235,7 +243,6 @@ __global__ __launch_bounds__(BS_THREADS, 4) void mpconv_bwd_sg_kernel(const BsPa
         if (lane < NPW * DEG) pe = *bs_at<uint2>(p.et + (int64_t)b * p.et_sb, (unsigned)et_goff * 2u);
     };
     auto commit = [&](unsigned char* xs, int t) {
-        const int lane = t & 63;
         if (t < xchunks) *reinterpret_cast<uint4*>(xs + (t >> 3) * BS_XSB + (t & 7) * 16) = px;
 #pragma unroll
         for (int s = 0; s < GSL; ++s) {
@@ -253,8 +260,7 @@ __global__ __launch_bounds__(BS_THREADS, 4) void mpconv_bwd_sg_kernel(const BsPa
                 *reinterpret_cast<uint4*>(ga + (f >> 4) * BS_GSB + (f & 15) * 16) = make_uint4(w[0], w[1], w[2], w[3]);
             }
         }
-        if (lane < NPW * DEG)
-            *reinterpret_cast<f32x4*>(es + lane * 4) = (f32x4){bs_lo(pe.x), bs_hi(pe.x), bs_lo(pe.y), bs_hi(pe.y)};
+        pe_cur = pe;
     };
 
     const int ntile = Npad / 16;                      // 16-node tiles: 2..6
@@ -322,38 +328,29 @@ __global__ __launch_bounds__(BS_THREADS, 4) void mpconv_bwd_sg_kernel(const BsPa
                     gbacc += g;
                     const unsigned c01 = bs_pack2(g * bs_lo(pk.x), g * bs_hi(pk.x));
                     const unsigned c23 = bs_pack2(g * bs_lo(pk.y), g * bs_hi(pk.y));
-                    unsigned short* zw = reinterpret_cast<unsigned short*>(zb + jst * (4 * BS_ZCS) + lane * 2);
-                    zw[0] = (unsigned short)c01;
-                    zw[BS_ZCS / 2] = (unsigned short)(c01 >> 16);
-                    zw[2 * (BS_ZCS / 2)] = (unsigned short)c23;
-                    zw[3 * (BS_ZCS / 2)] = (unsigned short)(c23 >> 16);
+                    // column (slot jst, pair 0) <- {e0 | e1}, column (slot jst, pair 1) <- {e2 | e3}, dword `lane` of each
+                    unsigned* zw = reinterpret_cast<unsigned*>(zb + jst * (2 * BS_ZCS) + lane * 4);
+                    zw[0] = c01;
+                    zw[BS_ZCS / 4] = c23;
                     asm volatile("" ::: "memory");            // the image is re-read below through another type: keep the stores
-                    f32x4 sum[NZT];
+                    // D[0][col] = sum over channels of the even halves, D[1][col] of the odd halves; K = 64 channels x 2
+                    f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+                    const unsigned char* zr = zb + li * BS_ZCS + lk * 16;
+                    bs_bf16x8 fr[4];
 #pragma unroll
-                    for (int t = 0; t < NZT; ++t) {
-                        sum[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                        const unsigned char* zr = zb + (16 * t + li) * BS_ZCS + lk * 16;
-#pragma unroll
-                        for (int ks = 0; ks < 2; ++ks)
-                            sum[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                                ones, __builtin_bit_cast(bs_bf16x8, *reinterpret_cast<const uint4*>(zr + 64 * ks)), sum[t], 0, 0, 0);
-                    }
+                    for (int ks = 0; ks < 4; ++ks) fr[ks] = __builtin_bit_cast(bs_bf16x8, *reinterpret_cast<const uint4*>(zr + 64 * ks));
                     asm volatile("" ::: "memory");
-                    zw[0] = 0;
-                    zw[BS_ZCS / 2] = 0;
-                    zw[2 * (BS_ZCS / 2)] = 0;
-                    zw[3 * (BS_ZCS / 2)] = 0;
+                    zw[0] = 0u;                               // (issued right behind the reads: LDS runs a wave's operations in order)
+                    zw[BS_ZCS / 4] = 0u;
                     asm volatile("" ::: "memory");
-                    // column c = 16 t + li of the image is (slot j = c >> 2, edge type e = c & 3); every row of D holds its sum
-                    if (lk == 0) {
 #pragma unroll
-                        for (int t = 0; t < NZT; ++t) {
-                            const int c = 16 * t + li;
-                            if (c < KC * 4) {
-                                const __bf16 h = (__bf16)sum[t][0];
-                                *bs_at<uint16_t>(gb, (unsigned)((c & 3) * mk + m * KC + (c >> 2)) * 2u) = __builtin_bit_cast(uint16_t, h);
-                            }
-                        }
+                    for (int ks = 0; ks < 4; ++ks) sum = __builtin_amdgcn_mfma_f32_16x16x32_bf16(evod, fr[ks], sum, 0, 0, 0);
+                    // column li of the image is (slot j = li >> 1, pair li & 1); rows 0 / 1 of D are its two edge types
+                    if (lk == 0 && li < KC * 2) {
+                        const int j = li >> 1, e0 = 2 * (li & 1);
+                        const __bf16 h0 = (__bf16)sum[0], h1 = (__bf16)sum[1];
+                        *bs_at<uint16_t>(gb, (unsigned)(e0 * mk + m * KC + j) * 2u) = __builtin_bit_cast(uint16_t, h0);
+                        *bs_at<uint16_t>(gb, (unsigned)((e0 + 1) * mk + m * KC + j) * 2u) = __builtin_bit_cast(uint16_t, h1);
                     }
                 }
             }
@@ -374,10 +371,11 @@ __global__ __launch_bounds__(BS_THREADS, 4) void mpconv_bwd_sg_kernel(const BsPa
                     const unsigned dw = *reinterpret_cast<const unsigned*>(ga + (e & ~0xff) + lane * 4);
                     const int msk = __builtin_amdgcn_sbfe((int)dw, e & 0xff, 1);            // -1 where this edge won the max
                     const float g = __uint_as_float(dw & (unsigned)msk & 0xffff0000u);
-                    const f32x4 w4 = *reinterpret_cast<const f32x4*>(es + (i * DEG + q) * 4);
+                    // the four edge-type weights of this in-edge are wave-uniform: read them out of lane (i DEG + q) of the staged row
+                    const unsigned w01 = __builtin_amdgcn_readlane(pe_cur.x, i * DEG + q), w23 = __builtin_amdgcn_readlane(pe_cur.y, i * DEG + q);
                     const bs_f32x2 g2 = {g, g};
-                    a01 = g2 * (bs_f32x2){w4[0], w4[1]} + a01;
-                    a23 = g2 * (bs_f32x2){w4[2], w4[3]} + a23;
+                    a01 = g2 * (bs_f32x2){bs_lo(w01), bs_hi(w01)} + a01;
+                    a23 = g2 * (bs_f32x2){bs_lo(w23), bs_hi(w23)} + a23;
                 }
                 *reinterpret_cast<uint2*>(pd + n * BS_PSB + lane * 8) = make_uint2(bs_pack2(a01[0], a01[1]), bs_pack2(a23[0], a23[1]));
             }
@@ -393,46 +391,65 @@ __global__ __launch_bounds__(BS_THREADS, 4) void mpconv_bwd_sg_kernel(const BsPa
         }
 
         BS_STAMP(8);
-        // ---- dx^T tiles: D[i = c][j = n] = W[c][:] . dP[n][:], channel tile ct, node tiles (wave >> 2) and (wave >> 2) + 4 ----
-        {
+        BS_STAMP(9);
+        if (!dw_wave) {
+            // ---- dx^T tiles: D[i = c][j = n] = W[c][:] . dP[n][:], channel tile ct, node tiles ((wave - 8) >> 2) + 2 i ----
             uint16_t* gxb = p.gx + (int64_t)b * p.x_sb;
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const int nt = (wave >> 2) + 4 * t;
+            for (int i = 0; i < 3; ++i) {
+                const int nt = ((wave - 8) >> 2) + 2 * i;
                 if (nt < ntile) {
                     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
                     const unsigned char* bp = pd + (nt * 16 + li) * BS_PSB + lk * 16;
 #pragma unroll
                     for (int ks = 0; ks < 8; ++ks)
                         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                            aT[ks], __builtin_bit_cast(bs_bf16x8, *reinterpret_cast<const uint4*>(bp + 64 * ks)), acc, 0, 0, 0);
+                            __builtin_bit_cast(bs_bf16x8, R[ks]),
+                            __builtin_bit_cast(bs_bf16x8, *reinterpret_cast<const uint4*>(bp + 64 * ks)), acc, 0, 0, 0);
                     const int n = nt * 16 + li;
                     if (n < N)
                         *bs_at<uint2>(gxb, (unsigned)(n * NIN + ct * 16 + 4 * lk) * 2u) =
                             make_uint2(bs_pack2(acc[0], acc[1]), bs_pack2(acc[2], acc[3]));
                 }
             }
-        }
-        BS_STAMP(9);
-        // ---- dW: contraction over nodes.  A = x^T (four column slots of the 64 channels), B = dP^T column slot
-        //      (group h' = wave >> 2 of 64 columns, slot p' = wave & 3) ----
-        for (int kst = 0; kst < nkst; ++kst) {
-            const int row0 = 32 * kst + 8 * lk;
-            bs_bf16x8 bfr;
-            {
-                uint2 rd[8];
+        } else {
+            // ---- dW: contraction over nodes.  A = x^T (four column slots of the 64 channels), B = dP^T column slots
+            //      2 (wave & 1), 2 (wave & 1) + 1 of the 64-column group wave >> 1 ----
+            for (int kst = 0; kst < nkst; ++kst) {
+                const int row0 = 32 * kst + 8 * lk;
+                bs_bf16x8 bfr0, bfr1;
+                {
+                    uint2 rd[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j)
-                    rd[j] = *reinterpret_cast<const uint2*>(pd + (row0 + j) * BS_PSB + 128 * (wave >> 2) + 8 * li);
-                bfr = bs_tr_dyn(rd, wave & 3);
+                    for (int j = 0; j < 8; ++j)
+                        rd[j] = *reinterpret_cast<const uint2*>(pd + (row0 + j) * BS_PSB + 128 * (wave >> 1) + 8 * li);
+                    if (wave & 1) { bfr0 = bs_tr<2>(rd); bfr1 = bs_tr<3>(rd); }
+                    else { bfr0 = bs_tr<0>(rd); bfr1 = bs_tr<1>(rd); }
+                }
+                uint2 rx[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) rx[j] = *reinterpret_cast<const uint2*>(xs + (row0 + j) * BS_XSB + 8 * li);
+                {
+                    const bs_bf16x8 a0 = bs_tr<0>(rx);
+                    R[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, bfr0, R[0], 0, 0, 0);
+                    R[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, bfr1, R[1], 0, 0, 0);
+                }
+                {
+                    const bs_bf16x8 a1 = bs_tr<1>(rx);
+                    R[2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, bfr0, R[2], 0, 0, 0);
+                    R[3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, bfr1, R[3], 0, 0, 0);
+                }
+                {
+                    const bs_bf16x8 a2 = bs_tr<2>(rx);
+                    R[4] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, bfr0, R[4], 0, 0, 0);
+                    R[5] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, bfr1, R[5], 0, 0, 0);
+                }
+                {
+                    const bs_bf16x8 a3 = bs_tr<3>(rx);
+                    R[6] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3, bfr0, R[6], 0, 0, 0);
+                    R[7] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3, bfr1, R[7], 0, 0, 0);
+                }
             }
-            uint2 rx[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) rx[j] = *reinterpret_cast<const uint2*>(xs + (row0 + j) * BS_XSB + 8 * li);
-            gw[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bs_tr<0>(rx), bfr, gw[0], 0, 0, 0);
-            gw[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bs_tr<1>(rx), bfr, gw[1], 0, 0, 0);
-            gw[2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bs_tr<2>(rx), bfr, gw[2], 0, 0, 0);
-            gw[3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bs_tr<3>(rx), bfr, gw[3], 0, 0, 0);
         }
         BS_STAMP(10);
         cur ^= 1;
@@ -441,11 +458,16 @@ __global__ __launch_bounds__(BS_THREADS, 4) void mpconv_bwd_sg_kernel(const BsPa
     // ---- flush dW tiles and dbias into this workgroup's slab (summed by the slab reduce, fixed order) ----
     if (b_begin < b_end) {
         float* slab = p.ws + (int64_t)blockIdx.x * ((int64_t)NIN * NCOLS + NOU);
-        const int col = 64 * (wave >> 2) + 4 * li + (wave & 3);
+        if (dw_wave) {
 #pragma unroll
-        for (int pa_ = 0; pa_ < 4; ++pa_)
+            for (int pa_ = 0; pa_ < 4; ++pa_)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) slab[(int64_t)(4 * (4 * lk + r) + pa_) * NCOLS + col] = gw[pa_][r];
+                for (int sl = 0; sl < 2; ++sl) {
+                    const int col = 64 * (wave >> 1) + 4 * li + 2 * (wave & 1) + sl;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) slab[(int64_t)(4 * (4 * lk + r) + pa_) * NCOLS + col] = R[2 * pa_ + sl][r];
+                }
+        }
         __syncthreads();
         float* red = reinterpret_cast<float*>(bs_lds + p.off_red);         // [16 waves][64 channels]
         red[wave * 64 + lane] = gbacc;
@@ -507,8 +529,8 @@ int fgnn_mpconv_backward_sg(const fgnn_mpconv_desc* d, const void* x, const int6
     p.off_xs = take(2 * p.Npad * BS_XSB);
     p.off_pd = take(p.Npad * BS_PSB);
     p.off_ga = take(d->M * BS_GSB);
-    p.zbytes = KC * 4 * BS_ZCS;
-    p.off_z = take(BS_WAVES * p.zbytes + 16 * BS_ZCS);                  // + slack: the last 16-column tile reads past column 4 KC
+    p.zbytes = KC * 2 * BS_ZCS;
+    p.off_z = take(BS_WAVES * p.zbytes + 16 * BS_ZCS);                  // + slack: the 16-column tile reads past column 2 KC
     p.off_es = take(BS_WAVES * p.NPW * DEG * 16);
     p.off_tab = take(d->N * DEG * 4);
     p.off_idx = take(d->M * KC * 4);
