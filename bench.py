@@ -280,11 +280,15 @@ def main():
             else:
                 roofline = dict(mfma)
                 other = ('hbm', hbm)
-            # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r01/pmc_traffic.json:
+            # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r0N/pmc_traffic.json:
             # FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE), measured at the kernel's LDPC 64->64
             # shape; null when this kernel symbol has no committed PMC pass
             try:
-                pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r01', 'pmc_traffic.json')))['kernels']
+                pmc = {}
+                for rnd in ('r01', 'r02'):            # later rounds' passes override (new kernel families)
+                    pth = os.path.join(ROOT, 'profiles', rnd, 'pmc_traffic.json')
+                    if os.path.exists(pth):
+                        pmc.update(json.load(open(pth))['kernels'])
                 traffic = pmc.get(sym, {}).get('traffic_bytes_per_launch')
             except (OSError, ValueError, KeyError):
                 traffic = None

@@ -544,7 +544,7 @@ int fgnn_mpconv_backward_sg(const fgnn_mpconv_desc* d, const void* x, const int6
     const int chunk = (d->B + grid - 1) / grid;
     grid = (d->B + chunk - 1) / chunk;
     hipStream_t st = (hipStream_t)stream;
-    fgnn_note_kernel("mpconv_bwd_sg_kernel<%d, %d>", KC, DEG);
+    fgnn_note_kernel("mpconv_bwd_sg_kernel<%d, %d, %d, %d, %d>", KC, DEG, p.NPW, p.DPW, GSL);
     p.prof = nullptr;
 #ifdef FGNN_ENABLE_PROF
     static long long* prof_buf = nullptr;

@@ -444,7 +444,7 @@ int fgnn_mpconv_forward_sg(const fgnn_mpconv_desc* d, const void* x, const int64
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "hipFuncSetAttribute(%d B LDS): %s", lds, hipGetErrorString(e));
     }
-    fgnn_note_kernel("mpconv_fwd_sg_kernel<%d, %d, %d, %d>", d->nin, d->nou, d->k, mode);
+    fgnn_note_kernel("mpconv_fwd_sg_kernel<%d, %d, %d, %d, %d>", d->nin, d->nou, d->k, MAXD, mode);
     p.prof = nullptr;
 #ifdef FGNN_ENABLE_PROF
     static long long* prof_buf = nullptr;

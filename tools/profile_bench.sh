@@ -1,13 +1,13 @@
 #!/bin/sh
 # Run on the GPU box (e.g. `gpurun -- sh tools/profile_bench.sh`): rocprofv3 kernel statistics of `bench.py` in both modes,
-# written under gpurun_out/prof4/ (merged back by gpurun); tools/refresh_profiles.py then copies them into profiles/r01/.
+# written under gpurun_out/${FGNN_PROF_OUT:-prof4}/ (merged back by gpurun); tools/refresh_profiles.py then copies them into profiles/r01/.
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-mkdir -p $R/gpurun_out/prof4
+mkdir -p $R/gpurun_out/${FGNN_PROF_OUT:-prof4}
 cd $R
 for mode in train fwd; do
   rm -rf /tmp/prof_$mode
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$mode -o $mode -- python bench.py --steps 10 --warmup 3 --mode $mode --no-cpu-baseline > /tmp/prof_$mode.log 2>&1
-  grep "^{\"metric" /tmp/prof_$mode.log | tail -1 > $R/gpurun_out/prof4/bench_$mode.json
-  find /tmp/prof_$mode -name "*kernel_stats*.csv" -exec cp {} $R/gpurun_out/prof4/ \;
+  grep "^{\"metric" /tmp/prof_$mode.log | tail -1 > $R/gpurun_out/${FGNN_PROF_OUT:-prof4}/bench_$mode.json
+  find /tmp/prof_$mode -name "*kernel_stats*.csv" -exec cp {} $R/gpurun_out/${FGNN_PROF_OUT:-prof4}/ \;
 done

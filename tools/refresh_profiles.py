@@ -1,14 +1,17 @@
 #!/usr/bin/env python3
 """Copies the outputs of tools/profile_bench.sh (rocprofv3 --kernel-trace --stats over `bench.py`, merged back under
-gpurun_out/prof4/) into profiles/r01/final_* and prints the live-vs-rocprof agreement table for its README."""
+gpurun_out/<src>/) into profiles/<round>/final_* and prints the live-vs-rocprof agreement table for its README.
+    python tools/refresh_profiles.py [src dir under gpurun_out = prof4] [round dir under profiles = r01]"""
 import csv
 import json
 import os
 import shutil
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(ROOT, 'gpurun_out', 'prof4')
-DST = os.path.join(ROOT, 'profiles', 'r01')
+import sys
+SRC = os.path.join(ROOT, 'gpurun_out', sys.argv[1] if len(sys.argv) > 1 else 'prof4')
+DST = os.path.join(ROOT, 'profiles', sys.argv[2] if len(sys.argv) > 2 else 'r01')
+os.makedirs(DST, exist_ok=True)
 
 
 def main():
