@@ -441,6 +441,17 @@ static void* pick_net_b(int net, int agg) {
     }
 }
 
+int fgnn_mpconv_backward_ext(const fgnn_mpconv_desc* d, const void* x, const int64_t* nn_idx, const void* etype,
+                             const float* filters, const void* gz, const uint8_t* argmax, void* gx, void* getype,
+                             float* gfilters, float* gbias, void* workspace, int64_t workspace_bytes,
+                             fgnn_stream_t stream);
+int fgnn_mpconv_backward_ext_accepts(const fgnn_mpconv_desc* d);
+
+extern "C" int fgnn_mpconv_backward_reduces_getype(const fgnn_mpconv_desc* d) {
+    if (!d || fgnn_check_desc(d)) return 0;
+    return fgnn_mpconv_backward_ext_accepts(d);
+}
+
 extern "C" int fgnn_mpconv_backward(const fgnn_mpconv_desc* d, const void* x, const int64_t* nn_idx,
                                     const void* etype, const float* filters, const void* gz,
                                     const void* z, const uint8_t* argmax, void* gx, void* getype,
@@ -455,6 +466,9 @@ extern "C" int fgnn_mpconv_backward(const fgnn_mpconv_desc* d, const void* x, co
     {   // LDPC shape family: W-stationary persistent kernel (mpconv_bwd_res.hip)
         static const bool force_generic = getenv("FGNN_FORCE_GENERIC") != nullptr;
         if (!force_generic) {
+            rc = fgnn_mpconv_backward_ext(d, x, nn_idx, etype, filters, gz, argmax, gx, getype, gfilters, gbias,
+                                          workspace, workspace_bytes, stream);
+            if (rc != 0) return rc < 0 ? rc : FGNN_OK;
             rc = fgnn_mpconv_backward_hyper(d, x, nn_idx, etype, filters, gz, argmax, gx, getype, gfilters, gbias,
                                             workspace, workspace_bytes, stream);
             if (rc != 0) return rc < 0 ? rc : FGNN_OK;
@@ -469,6 +483,8 @@ extern "C" int fgnn_mpconv_backward(const fgnn_mpconv_desc* d, const void* x, co
             if (rc != 0) return rc < 0 ? rc : FGNN_OK;
         }
     }
+    if (d->reserved & FGNN_DESC_GETYPE_REDUCED)
+        FGNN_FAIL(FGNN_EUNSUPPORTED, "batch-reduced edge-type gradient asked of a shape without that kernel");
     BwdParams p;
     p.d = *d;
     p.x = x; p.idx = nn_idx; p.et = etype; p.W = filters; p.gz = gz; p.z = z; p.argmax = argmax;

@@ -1,0 +1,469 @@
+// mpconv_bwd_ext.hip — backward of the VF/FV message operator for the synthetic-PGM calls (BASELINE configs 1 / 2 / 5):
+// f32, ORIG_WITH_NEIGHBOR / ORIG_WITH_DIFF, 16 edge types, 64 -> 64 channels, max aggregation, N = M <= 64, graph and
+// edge types shared by the batch.  Counterpart of mpconv_fwd_ext.hip (same node-level split S = x Ws, T = x Wt); the
+// reference trains this operator through autograd (/root/reference/lib/model/mpnn/mp_nn.py:136-175).
+//
+// With z[m,o] = max_j E[m,j,o] + bias, E[m,j,o] = sum_e et[m,j,e] (S[m,o,e] + T[idx[m,j],o,e]) and j* the forward's argmax:
+//     dS[m,o,e]   = gz[m,o] et[m,j*,e]
+//     dT[n,o,e]   = sum over edges (m,j) into n with j == j*(m,o):  gz[m,o] et[m,j,e]
+//     get[m,j*,e] += gz[m,o] (S[m,o,e] + T[n,o,e])                       (summed over the batch: the edge types are shared)
+//     gx  = dS Ws^T + dT Wt^T          gWs = x^T dS        gWt = x^T dT        gbias = sum gz
+// The shape-generic kernel (mpconv_bwd.hip) scatters dT, gW and gx with float atomics (order-dependent bits) and spends
+// 6.6 ms per call at B = 1024; this one has NO atomics anywhere — dT is a gather over a CSR of the shared graph built once
+// per workgroup, gW / gbias / get go through per-workgroup slabs folded in a fixed order — and all three GEMMs
+// (P = x W recomputed, gx, gW: 50 MFLOP per sample) run on the f32 matrix cores (v_mfma_f32_16x16x4_f32, exact f32).
+//
+// Loop order is pass-major like the forward: a pass = 4 output channels = 64 S + 64 T columns of the projection; its
+// filter slice (as B operand of P = x W and of gx = dP W^T) and the gW accumulators of the pass stay in registers while
+// the workgroup runs all of its samples through it; gx of a sample is accumulated across the 16 passes by the same lanes
+// with plain global read-modify-write (L2-resident, deterministic).  f32 MFMAs keep the SIMD's VALU busy (measured:
+// tools/ubench/mfma_f32_partner.hip), so the phases of a stage simply follow each other on all 8 waves:
+//     A  P = x [Ws | Wt]_pass                    (64 MFMAs per wave)     -> LDS P
+//     B1 get += gz (S + T) at the argmax         (VALU, 256 threads)
+//     B2 dS (waves 0-3), dT (waves 4-7)          (VALU)                  -> LDS dP (over P)
+//     C  gx += dP W^T (global RMW), gW += x^T dP (64 + 64 MFMAs per wave)
+// LDS rows: x image stride 68 floats, P / dP stride 132: every access pattern above is bank-conflict-free (the k index of
+// the gW product runs over nodes in the order 4 lk + (kk & 3) + 16 (kk >> 2) for that reason).
+#include "fgnn_common.h"
+#include <stdlib.h>
+
+#define BX_THREADS 512
+#define BX_NIN 64
+#define BX_NOU 64
+#define BX_NET 16
+#define BX_NCOLS 1024
+#define BX_PCH 4
+#define BX_NPASS (BX_NOU / BX_PCH)
+#define BX_XS 68
+#define BX_PS 132
+#define BX_MAX_MK 640
+
+struct BxParams {
+    const float* x;
+    const int64_t* idx;
+    const float* et;
+    const float* W;
+    const float* gz;
+    const uint8_t* am;
+    float* gx;
+    float* ws;               // [grid][nw + nou] gW / gbias slabs
+    float* get_ws;           // [grid][16][N][k] edge-type gradient slabs, or null
+    int B, N, k, ext;
+    long long x_sb, y_sb, idx_sm, idx_sk, et_se, et_sm, et_sk;
+    int off_xs, off_ps, off_et, off_get, off_idx, off_csr, off_gz, off_am;
+    long long slab_len, get_len;
+};
+
+extern __shared__ __attribute__((aligned(16))) unsigned char bx_lds[];
+
+__device__ __forceinline__ int bx_krow(int kk, int lk) { return 4 * lk + (kk & 3) + 16 * (kk >> 2); }
+
+__global__ __launch_bounds__(BX_THREADS, 2) void mpconv_bwd_ext_kernel(const BxParams p) {
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int li = lane & 15, lk = lane >> 4;
+    const int N = p.N, k = p.k, mk = N * k;
+    const int ntile = (N + 15) >> 4;
+    const bool want_get = p.get_ws != nullptr;
+    const bool diff = p.ext == FGNN_EXT_DIFF;
+
+    float* xs = reinterpret_cast<float*>(bx_lds + p.off_xs);          // [64][XS]
+    float* ps = reinterpret_cast<float*>(bx_lds + p.off_ps);          // [64][PS]: P, then dP
+    float* et_s = reinterpret_cast<float*>(bx_lds + p.off_et);        // [mk][16]
+    float* get_s = reinterpret_cast<float*>(bx_lds + p.off_get);      // [mk][16] batch-summed edge-type gradient
+    int* idx_s = reinterpret_cast<int*>(bx_lds + p.off_idx);          // [mk]
+    unsigned short* csr_ent = reinterpret_cast<unsigned short*>(bx_lds + p.off_csr);     // [mk] edge ids by source node
+    int* csr_off = reinterpret_cast<int*>(bx_lds + p.off_csr + ((mk * 2 + 15) & ~15));  // [65]
+    float* gz_s = reinterpret_cast<float*>(bx_lds + p.off_gz);        // [64][4]
+    unsigned* am_s = reinterpret_cast<unsigned*>(bx_lds + p.off_am);  // [64] four argmax bytes
+
+    const int chunk = (p.B + gridDim.x - 1) / gridDim.x;
+    const int b_begin = blockIdx.x * chunk;
+    const int ns = min(p.B, b_begin + chunk) - b_begin;
+    float* slab = p.ws + (int64_t)blockIdx.x * p.slab_len;
+    if (ns <= 0) {                                                    // the fold reads every slab
+        for (int64_t f = tid; f < p.slab_len; f += BX_THREADS) slab[f] = 0.f;
+        if (want_get) for (int64_t f = tid; f < p.get_len; f += BX_THREADS) p.get_ws[(int64_t)blockIdx.x * p.get_len + f] = 0.f;
+        return;
+    }
+
+    // ---------------- one-time setup: graph tables, edge types, CSR by source node ----------------
+    for (int f = tid; f < 64 * BX_XS; f += BX_THREADS) xs[f] = 0.f;
+    for (int r = tid; r < mk; r += BX_THREADS) {
+        const int m = r / k, j = r - m * k;
+        long long v = p.idx[(int64_t)m * p.idx_sm + (int64_t)j * p.idx_sk];
+        idx_s[r] = (int)(v < 0 ? 0 : (v >= N ? N - 1 : v));
+    }
+    for (int f = tid; f < mk * BX_NET; f += BX_THREADS) {
+        const int e = f / mk, r = f - e * mk;
+        const int m = r / k, j = r - m * k;
+        et_s[r * BX_NET + e] = p.et[(int64_t)e * p.et_se + (int64_t)m * p.et_sm + (int64_t)j * p.et_sk];
+        get_s[r * BX_NET + e] = 0.f;
+    }
+    __syncthreads();
+    if (tid < 64) {                                                   // in-degree of node tid
+        int c = 0;
+        if (tid < N) for (int r = 0; r < mk; ++r) c += idx_s[r] == tid;
+        gz_s[tid] = __int_as_float(c);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int a = 0;
+        for (int n = 0; n < 64; ++n) { csr_off[n] = a; a += __float_as_int(gz_s[n]); }
+        csr_off[64] = a;
+    }
+    __syncthreads();
+    if (tid < N) {                                                    // edges into node tid, ascending edge id: a fixed order
+        int o = csr_off[tid];
+        for (int r = 0; r < mk; ++r) if (idx_s[r] == tid) csr_ent[o++] = (unsigned short)r;
+    }
+
+    // ---------------- per-thread roles ----------------
+    // phase A: wave = (half, sl): slab of 16 columns = channel sl of the pass, S (half 0) or T (half 1)
+    const int a_half = wave >> 2, a_sl = wave & 3;
+    // phase B1: 256 threads = (destination m, quad of edge types eq); lanes of a 16-group take m 4 apart (banks)
+    const int b1_eq = lane & 3, b1_m = 16 * wave + 4 * ((lane >> 2) & 3) + (lane >> 4);
+    // phase B2: waves 0-3 thread (m, oc) -> dS; waves 4-7 thread (n, oc) -> dT
+    const int b2_t = tid & 255, b2_row = b2_t >> 2, b2_oc = b2_t & 3;
+    // phase C: gx: wave = (c tile ct, node-tile pair np); gW: wave = (column tile wt of S and of T, c-tile pair cp)
+    const int c_ct = wave & 3, c_np = wave >> 2;
+    const int w_t = wave & 3, w_cp = wave >> 2;
+
+    // prefetch registers: x of the next stage (2 x 16 B per thread), gz / argmax slices (threads < 64)
+    uint4 xr[2];
+    uint4 gzr = make_uint4(0, 0, 0, 0);
+    unsigned amr = 0;
+    auto prefetch = [&](int b, int pass) {
+        const uint4* xb = reinterpret_cast<const uint4*>(p.x + (int64_t)b * p.x_sb);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int f = tid + q * BX_THREADS;
+            xr[q] = (f >> 4) < N ? xb[f] : make_uint4(0, 0, 0, 0);
+        }
+        if (tid < 64) {
+            gzr = make_uint4(0, 0, 0, 0);
+            amr = 0;
+            if (tid < N) {
+                const int64_t o = (int64_t)b * p.y_sb + (int64_t)tid * BX_NOU + BX_PCH * pass;
+                gzr = *reinterpret_cast<const uint4*>(p.gz + o);
+                amr = *reinterpret_cast<const unsigned*>(p.am + o);
+            }
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int f = tid + q * BX_THREADS;
+            if ((f >> 4) < N) *reinterpret_cast<uint4*>(xs + (f >> 4) * BX_XS + (f & 15) * 4) = xr[q];
+        }
+        if (tid < 64) {
+            *reinterpret_cast<uint4*>(gz_s + tid * 4) = gzr;
+            am_s[tid] = amr;
+        }
+    };
+
+    __syncthreads();
+    prefetch(b_begin, blockIdx.x & (BX_NPASS - 1));
+
+    for (int pp = 0; pp < BX_NPASS; ++pp) {
+        const int pass = (pp + blockIdx.x) & (BX_NPASS - 1);          // staggered: the chip does not read one filter slice at once
+        const int pass_next = (pp + 1 + blockIdx.x) & (BX_NPASS - 1);
+        // ---- filter slice of the pass ----
+        float aW[16];                                                 // phase A B-operand: W[c = 16 lk + kk][column of this wave's slab]
+        {
+            const int col = 16 * (BX_PCH * pass + a_sl) + li;
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk) {
+                const int c = 16 * lk + kk;
+                const float wt = p.W[(int64_t)c * BX_NCOLS + col], wb = p.W[(int64_t)(BX_NIN + c) * BX_NCOLS + col];
+                aW[kk] = a_half == 0 ? (diff ? wt + wb : wt) : (diff ? -wb : wb);
+            }
+        }
+        float gB[32];                                                 // gx B-operand: Wc[dP column 32 lk + kk][c = 16 ct + li]
+        {
+            const int c = 16 * c_ct + li;
+            const float* wtop = p.W + (int64_t)c * BX_NCOLS + 64 * pass + 32 * (lk & 1);
+            const float* wbot = wtop + (int64_t)BX_NIN * BX_NCOLS;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const f32x4 t = *reinterpret_cast<const f32x4*>(wtop + 4 * q), b = *reinterpret_cast<const f32x4*>(wbot + 4 * q);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    gB[4 * q + i] = lk < 2 ? (diff ? t[i] + b[i] : t[i]) : (diff ? -b[i] : b[i]);
+            }
+        }
+        f32x4 accW[2][2];                                             // [c tile of the pair][S, T]
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) accW[a][h] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        float gb_acc = 0.f;
+
+        for (int s = 0; s < ns; ++s) {
+            const int b = b_begin + s;
+            __syncthreads();                                          // previous stage is done with xs, P, gz_s
+            commit();
+            if (s + 1 < ns) prefetch(b + 1, pass);
+            else if (pp + 1 < BX_NPASS) prefetch(b_begin, pass_next);
+            __syncthreads();
+
+            // ================= phase A: P = x [Ws | Wt] =================
+            {
+                const int colbase = 64 * a_half + 16 * a_sl + li;
+                for (int np = 0; np < (ntile + 1) >> 1; ++np) {
+                    f32x4 bq[2][4];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const float* bp = xs + ((2 * np + h) * 16 + li) * BX_XS + 16 * lk;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) bq[h][q] = *reinterpret_cast<const f32x4*>(bp + 4 * q);
+                    }
+                    f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+                    for (int kk = 0; kk < 16; ++kk)
+#pragma unroll
+                        for (int h = 0; h < 2; ++h)
+                            acc[h] = __builtin_amdgcn_mfma_f32_16x16x4f32(bq[h][kk >> 2][kk & 3], aW[kk], acc[h], 0, 0, 0);
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) ps[((2 * np + h) * 16 + 4 * lk + r) * BX_PS + colbase] = acc[h][r];
+                }
+            }
+            __syncthreads();
+
+            // ================= phase B1: get[m][j*][e] += gz (S + T) =================
+            if (want_get && tid < 256 && b1_m < N) {
+                const unsigned am4 = am_s[b1_m];
+                const f32x4 g4 = *reinterpret_cast<const f32x4*>(gz_s + b1_m * 4);
+#pragma unroll
+                for (int oc = 0; oc < BX_PCH; ++oc) {
+                    const int j = min((int)((am4 >> (8 * oc)) & 255u), k - 1);
+                    const int r = b1_m * k + j;
+                    const f32x4 sv = *reinterpret_cast<const f32x4*>(ps + b1_m * BX_PS + 16 * oc + 4 * b1_eq);
+                    const f32x4 tv = *reinterpret_cast<const f32x4*>(ps + idx_s[r] * BX_PS + 64 + 16 * oc + 4 * b1_eq);
+                    f32x4* gp = reinterpret_cast<f32x4*>(get_s + r * BX_NET + 4 * b1_eq);
+                    *gp = *gp + g4[oc] * (sv + tv);
+                }
+            }
+            __syncthreads();
+
+            // ================= phase B2: dS (waves 0-3), dT (waves 4-7) over P =================
+            if (tid < 256) {
+                f32x4 row[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) row[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (b2_row < N) {
+                    const float g = gz_s[b2_row * 4 + b2_oc];
+                    const int j = min((int)((am_s[b2_row] >> (8 * b2_oc)) & 255u), k - 1);
+                    const float* er = et_s + (b2_row * k + j) * BX_NET;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) row[q] = g * *reinterpret_cast<const f32x4*>(er + 4 * q);
+                    gb_acc += g;
+                }
+                float* dr = ps + b2_row * BX_PS + 16 * b2_oc;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(dr + 4 * q) = row[q];
+            } else {
+                f32x4 row[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) row[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (b2_row < N) {
+                    const int e1 = csr_off[b2_row + 1];
+                    for (int i = csr_off[b2_row]; i < e1; ++i) {
+                        const int r = csr_ent[i];
+                        const int m = r / k, j = r - m * k;
+                        if ((int)((am_s[m] >> (8 * b2_oc)) & 255u) == j) {
+                            const float g = gz_s[m * 4 + b2_oc];
+                            const float* er = et_s + r * BX_NET;
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) row[q] = g * *reinterpret_cast<const f32x4*>(er + 4 * q) + row[q];
+                        }
+                    }
+                }
+                float* dr = ps + b2_row * BX_PS + 64 + 16 * b2_oc;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(dr + 4 * q) = row[q];
+            }
+            __syncthreads();
+
+            // ================= phase C: gx += dP Wc (global RMW), gW += x^T dP =================
+            {
+                float* gxb = p.gx + (int64_t)b * p.x_sb + 16 * c_ct + li;
+                f32x4 old[2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    old[h] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    if (pp > 0) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int node = (2 * c_np + h) * 16 + 4 * lk + r;
+                            if (node < N) old[h][r] = gxb[(int64_t)node * BX_NIN];
+                        }
+                    }
+                }
+                // gW first (the gx read-modify-write loads fly meanwhile)
+                float xa[2][16];
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int kk = 0; kk < 16; ++kk) xa[a][kk] = xs[bx_krow(kk, lk) * BX_XS + 16 * (2 * w_cp + a) + li];
+                float db[2][16];
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int kk = 0; kk < 16; ++kk) db[h][kk] = ps[bx_krow(kk, lk) * BX_PS + 64 * h + 16 * w_t + li];
+#pragma unroll
+                for (int kk = 0; kk < 16; ++kk)
+#pragma unroll
+                    for (int a = 0; a < 2; ++a)
+#pragma unroll
+                        for (int h = 0; h < 2; ++h)
+                            accW[a][h] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[a][kk], db[h][kk], accW[a][h], 0, 0, 0);
+                // gx tiles: nodes (2 np, 2 np + 1) x c tile ct, K = 128 dP columns in the order 32 lk + kk
+                f32x4 accx[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {               // 16 k-steps at a time: 2 x 4 b128 of operands in flight
+                    f32x4 dq[2][4];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const float* dp = ps + ((2 * c_np + h) * 16 + li) * BX_PS + 32 * lk + 16 * half;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) dq[h][q] = *reinterpret_cast<const f32x4*>(dp + 4 * q);
+                    }
+#pragma unroll
+                    for (int kk = 0; kk < 16; ++kk)
+#pragma unroll
+                        for (int h = 0; h < 2; ++h)
+                            accx[h] = __builtin_amdgcn_mfma_f32_16x16x4f32(dq[h][kk >> 2][kk & 3], gB[16 * half + kk], accx[h], 0, 0, 0);
+                }
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int node = (2 * c_np + h) * 16 + 4 * lk + r;
+                        if (node < N) gxb[(int64_t)node * BX_NIN] = old[h][r] + accx[h][r];
+                    }
+            }
+        }
+
+        // ---- end of pass: filter-gradient tiles and the bias gradient of the pass -> this workgroup's slab ----
+        {
+            // D[i = c = 16 (2 cp + a) + 4 lk + r][j = column 16 t + li]; filters row c (top) and 64 + c (bottom)
+            const int col = 64 * pass + 16 * w_t + li;
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int c = 16 * (2 * w_cp + a) + 4 * lk + r;
+                    const float gs = accW[a][0][r], gt = accW[a][1][r];
+                    slab[(int64_t)c * BX_NCOLS + col] = gs;
+                    slab[(int64_t)(BX_NIN + c) * BX_NCOLS + col] = diff ? gs - gt : gt;
+                }
+            __syncthreads();                                          // phase C is done with P: scratch for the bias reduction
+            if (tid < 256) ps[tid] = gb_acc;                          // [m][oc]
+            __syncthreads();
+            if (tid < BX_PCH) {
+                float sum = 0.f;
+                for (int m = 0; m < 64; ++m) sum += ps[m * 4 + tid];
+                slab[(int64_t)2 * BX_NIN * BX_NCOLS + BX_PCH * pass + tid] = sum;
+            }
+        }
+    }
+    if (want_get) {
+        __syncthreads();
+        float* go = p.get_ws + (int64_t)blockIdx.x * p.get_len;       // [16][N][k]
+        for (int f = tid; f < mk * BX_NET; f += BX_THREADS) {
+            const int e = f / mk, r = f - e * mk;
+            go[f] = get_s[r * BX_NET + e];
+        }
+    }
+}
+
+void fgnn_launch_slab_reduce(const float* ws, int nslab, int64_t slab_len, int64_t nw, float* gW, float* gbias,
+                             hipStream_t st);
+
+// bytes of workspace this kernel wants on top of the gW / gbias slabs: the edge-type gradient slabs
+int64_t fgnn_mpconv_backward_ext_extra_bytes(const fgnn_mpconv_desc* d) {
+    if (d->ext == FGNN_EXT_NONE || d->dtype != FGNN_F32 || d->net != BX_NET) return 0;
+    return (int64_t)256 * BX_NET * d->M * d->k * 4;
+}
+
+// 1 when this descriptor's backward sums the edge-type gradient over the batch itself (getype = [net, M, k]); the caller
+// asks for that form with FGNN_DESC_GETYPE_REDUCED in d->reserved.
+int fgnn_mpconv_backward_ext_accepts(const fgnn_mpconv_desc* d) {
+    static const bool off = getenv("FGNN_NO_EXT") != nullptr;
+    if (off) return 0;
+    if (d->dtype != FGNN_F32 || (d->ext != FGNN_EXT_NEIGHBOR && d->ext != FGNN_EXT_DIFF) || d->agg != FGNN_AGG_MAX) return 0;
+    if (d->net != BX_NET || d->nin != BX_NIN || d->nou != BX_NOU) return 0;
+    if (d->N != d->M || d->N < 1 || d->N > 64 || d->k < 1 || d->k > 16 || d->N * d->k > BX_MAX_MK) return 0;
+    if ((d->idx_sb != 0 || d->et_sb != 0) && d->B != 1) return 0;
+    if (!(d->x_sc == 1 && d->x_sn == BX_NIN && d->x_sb % 4 == 0)) return 0;
+    if (!(d->y_sc == 1 && d->y_sm == BX_NOU && d->y_sb % 4 == 0)) return 0;
+    return 1;
+}
+
+// Returns 1 if launched, 0 if the call is outside this kernel's family, < 0 on error.
+int fgnn_mpconv_backward_ext(const fgnn_mpconv_desc* d, const void* x, const int64_t* nn_idx, const void* etype,
+                             const float* filters, const void* gz, const uint8_t* argmax, void* gx, void* getype,
+                             float* gfilters, float* gbias, void* workspace, int64_t workspace_bytes,
+                             fgnn_stream_t stream) {
+    const bool reduced = (d->reserved & FGNN_DESC_GETYPE_REDUCED) != 0;
+    if (!fgnn_mpconv_backward_ext_accepts(d)) {
+        if (reduced) FGNN_FAIL(FGNN_EUNSUPPORTED, "batch-reduced edge-type gradient asked of a shape without that kernel");
+        return 0;
+    }
+    if (getype && !reduced && d->B != 1) return 0;                   // per-sample edge-type gradient: the generic kernel
+    if (((uintptr_t)x & 15) || ((uintptr_t)gz & 15) || ((uintptr_t)argmax & 3) || ((uintptr_t)filters & 15)) {
+        if (reduced) FGNN_FAIL(FGNN_EINVAL, "mpconv ext backward needs 16-byte aligned x / gz / filters");
+        return 0;
+    }
+    const int mk = d->N * d->k;
+    const int64_t nw = (int64_t)2 * BX_NIN * BX_NCOLS, slab_len = nw + BX_NOU, get_len = (int64_t)BX_NET * mk;
+    int grid = 256;
+    if (grid > d->B) grid = d->B;
+    const int chunk = (d->B + grid - 1) / grid;
+    grid = (d->B + chunk - 1) / chunk;
+    const int64_t need = (grid * slab_len + (getype ? grid * get_len : 0)) * 4;
+    if (!workspace || workspace_bytes < need)
+        FGNN_FAIL(FGNN_EINVAL, "mpconv ext backward needs %lld bytes of workspace (fgnn_mpconv_backward_workspace_bytes)", (long long)need);
+    BxParams p;
+    p.x = (const float*)x; p.idx = nn_idx; p.et = (const float*)etype; p.W = filters; p.gz = (const float*)gz;
+    p.am = argmax; p.gx = (float*)gx; p.ws = (float*)workspace;
+    p.get_ws = getype ? (float*)workspace + grid * slab_len : nullptr;
+    p.B = d->B; p.N = d->N; p.k = d->k; p.ext = d->ext;
+    p.x_sb = d->x_sb; p.y_sb = d->y_sb; p.idx_sm = d->idx_sm; p.idx_sk = d->idx_sk;
+    p.et_se = d->et_se; p.et_sm = d->et_sm; p.et_sk = d->et_sk;
+    p.slab_len = slab_len; p.get_len = get_len;
+    int off_b = 0;
+    auto take = [&](int bytes) { const int o = off_b; off_b = fgnn_round_up(off_b + bytes, 16); return o; };
+    p.off_xs = take(64 * BX_XS * 4);
+    p.off_ps = take(64 * BX_PS * 4);
+    p.off_et = take(mk * BX_NET * 4);
+    p.off_get = take(mk * BX_NET * 4);
+    p.off_idx = take(mk * 4);
+    p.off_csr = take(((mk * 2 + 15) & ~15) + 65 * 4);
+    p.off_gz = take(64 * 4 * 4);
+    p.off_am = take(64 * 4);
+    const int lds = off_b;
+    if (lds > 160 * 1024) {
+        if (reduced) FGNN_FAIL(FGNN_EUNSUPPORTED, "mpconv ext backward: %d bytes of LDS", lds);
+        return 0;
+    }
+    void* fn = (void*)mpconv_bwd_ext_kernel;
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "hipFuncSetAttribute(%d B LDS): %s", lds, hipGetErrorString(e));
+    fgnn_note_kernel("mpconv_bwd_ext_kernel");
+    void* args[] = {(void*)&p};
+    e = hipLaunchKernel(fn, dim3(grid), dim3(BX_THREADS), args, lds, (hipStream_t)stream);
+    if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "mpconv ext backward launch: %s", hipGetErrorString(e));
+    fgnn_launch_slab_reduce(p.ws, grid, slab_len, nw, gfilters, gbias, (hipStream_t)stream);
+    if (getype) {
+        e = hipMemsetAsync(getype, 0, get_len * 4, (hipStream_t)stream);
+        if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "memset: %s", hipGetErrorString(e));
+        fgnn_launch_slab_reduce(p.get_ws, grid, get_len, get_len, (float*)getype, nullptr, (hipStream_t)stream);
+    }
+    e = hipGetLastError();
+    if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "mpconv ext backward helper launch: %s", hipGetErrorString(e));
+    return 1;
+}

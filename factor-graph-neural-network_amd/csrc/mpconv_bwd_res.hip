@@ -614,11 +614,12 @@ static void* bres_pick(int KS, int NPASS) {
     return nullptr;
 }
 
+int64_t fgnn_mpconv_backward_ext_extra_bytes(const fgnn_mpconv_desc* d);
 extern "C" int64_t fgnn_mpconv_backward_workspace_bytes(const fgnn_mpconv_desc* d) {
     if (!d) return 0;
     const int64_t R = d->ext == FGNN_EXT_NONE ? d->nin : 2 * d->nin;
     const int64_t nw = R * d->nou * d->net;
-    return (256 * (nw + d->nou) + nw) * 4;            // 256 slabs + the transposed filter copy
+    return (256 * (nw + d->nou) + nw) * 4 + fgnn_mpconv_backward_ext_extra_bytes(d);   // 256 slabs + the transposed filter copy (+ edge-type slabs)
 }
 
 #define BR_REJECT(code) do { if (getenv("FGNN_TRACE")) fprintf(stderr, "[fgnn] resident backward rejects shape: rule %d (line %d)\n", code, __LINE__); return 0; } while (0)

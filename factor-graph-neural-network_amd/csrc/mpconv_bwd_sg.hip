@@ -500,7 +500,7 @@ int fgnn_mpconv_backward_sg(const fgnn_mpconv_desc* d, const void* x, const int6
     if (!(d->idx_sk == 1 && d->idx_sm == d->k)) BS_REJECT(5);
     if (!getype || !argmax || !gbias) BS_REJECT(6);
     if (d->N < 1 || d->N > BS_MAXN || d->M < 1 || d->M > 96) BS_REJECT(7);
-    const int indeg = d->reserved;
+    const int indeg = d->reserved & 0xffff;
     const int KC = d->k, DEG = KC == 6 ? 3 : 6;        // LDPC: degree-6 checks <-> degree-3 variables
     if (indeg < 1 || indeg > DEG) BS_REJECT(8);
     if (!(d->x_sc == 1 && d->x_sn == d->nin && d->x_sb % 8 == 0)) BS_REJECT(9);

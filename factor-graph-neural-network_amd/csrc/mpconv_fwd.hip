@@ -317,6 +317,10 @@ int fgnn_mpconv_forward_b16(const fgnn_mpconv_desc* d, const void* x, const int6
                             const float* post_scale, const float* post_shift, void* y,
                             uint8_t* argmax, fgnn_stream_t stream, float* stats, int* plan_grid);
 
+int fgnn_mpconv_forward_ext(const fgnn_mpconv_desc* d, const void* x, const int64_t* nn_idx, const void* etype,
+                            const float* filters, const float* bias, const float* post_scale, const float* post_shift,
+                            void* y, uint8_t* argmax, fgnn_stream_t stream);
+
 int fgnn_check_desc(const fgnn_mpconv_desc* d) {
     if (!d) FGNN_FAIL(FGNN_EINVAL, "null descriptor");
     if (d->B < 0 || d->nin < 1 || d->nou < 1 || d->net < 1 || d->N < 1 || d->M < 1 || d->k < 1)
@@ -373,6 +377,8 @@ extern "C" int fgnn_mpconv_forward(const fgnn_mpconv_desc* d, const void* x, con
             if (rc != 0) return rc < 0 ? rc : FGNN_OK;
             rc = fgnn_mpconv_forward_b16(d, x, nn_idx, etype, filters, bias, post_scale, post_shift, y, argmax,
                                          stream, nullptr, nullptr);
+            if (rc != 0) return rc < 0 ? rc : FGNN_OK;
+            rc = fgnn_mpconv_forward_ext(d, x, nn_idx, etype, filters, bias, post_scale, post_shift, y, argmax, stream);
             if (rc != 0) return rc < 0 ? rc : FGNN_OK;
             rc = fgnn_mpconv_forward_resident(d, x, nn_idx, etype, filters, bias, post_scale, post_shift, y,
                                               argmax, stream);

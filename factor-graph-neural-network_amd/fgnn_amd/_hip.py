@@ -14,6 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('FGNN_HIP_LIB') or os.path.join(_HERE, 'libfgnn_hip.so')      # FGNN_HIP_LIB: a tuning build
 
 EXT_NONE, EXT_NEIGHBOR, EXT_DIFF = 0, 1, 2
+DESC_GETYPE_REDUCED = 0x10000
 AGG_MAX, AGG_LSE, AGG_MEAN = 0, 1, 2
 F32, BF16 = 0, 1
 EUNSUPPORTED = -3            # FGNN_EUNSUPPORTED: shape outside a kernel's family (callers fall back)
@@ -21,7 +22,7 @@ EUNSUPPORTED = -3            # FGNN_EUNSUPPORTED: shape outside a kernel's famil
 AGG_CODES = {'max': AGG_MAX, 'softmax': AGG_LSE, 'mean': AGG_MEAN}
 
 EXPORTS = ('fgnn_mpconv_forward', 'fgnn_mpconv_backward', 'fgnn_mpconv_forward_lds_bytes',
-           'fgnn_mpconv_backward_workspace_bytes', 'fgnn_linear_wgrad', 'fgnn_linear_wgrad_workspace_bytes',
+           'fgnn_mpconv_backward_workspace_bytes', 'fgnn_mpconv_backward_reduces_getype', 'fgnn_linear_wgrad', 'fgnn_linear_wgrad_workspace_bytes',
            'fgnn_instnorm_forward', 'fgnn_instnorm_backward', 'fgnn_bn_supported', 'fgnn_bn_workspace_bytes',
            'fgnn_bn_stats', 'fgnn_bn_finalize', 'fgnn_bn_apply', 'fgnn_bn_backward',
            'fgnn_linear_forward', 'fgnn_linear_forward_partials', 'fgnn_sum_n', 'fgnn_flat_adam', 'fgnn_edge_mlp_forward', 'fgnn_edge_mlp_workspace_bytes', 'fgnn_edge_mlp_backward', 'fgnn_ldpc_encode', 'fgnn_ldpc_channel_features', 'fgnn_ldpc_decode', 'fgnn_mpconv_block_forward', 'fgnn_mpconv_block_forward_fanout', 'fgnn_mpconv_block_forward_fanin', 'fgnn_mpconv_forward_stats', 'fgnn_mpconv_forward_stats_partials',
@@ -63,6 +64,8 @@ def lib():
     L.fgnn_mpconv_forward_stats_partials.argtypes = [dp]
     L.fgnn_mpconv_backward.restype = ctypes.c_int
     L.fgnn_mpconv_backward.argtypes = [dp] + [vp] * 12 + [ctypes.c_int64, vp]
+    L.fgnn_mpconv_backward_reduces_getype.restype = ctypes.c_int
+    L.fgnn_mpconv_backward_reduces_getype.argtypes = [dp]
     L.fgnn_mpconv_backward_workspace_bytes.restype = ctypes.c_int64
     L.fgnn_mpconv_backward_workspace_bytes.argtypes = [dp]
     L.fgnn_mpconv_forward_lds_bytes.restype = ctypes.c_int64

@@ -293,6 +293,10 @@ class _MPConv(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, nn_idx, etype, filters, bias, nou, net, ext, agg, want_stats=False):
         nn_idx = shared_graph_view(nn_idx)               # saved in this form: the backward takes the same fast path
+        # edge weights shared by the batch arrive un-expanded ([1, net, M, k], see mpconv()): their gradient is the batch SUM
+        ctx.shared_et = etype.shape[0] == 1 and x.shape[0] > 1
+        if ctx.shared_et:
+            etype = etype.expand(x.shape[0], -1, -1, -1)
         z, amax = mpconv_forward_raw(x, nn_idx, etype, filters, bias, nou, net, ext, agg, want_stats=want_stats,
                                      want_argmax=True)
         ctx.cfg = (nou, net, ext, agg)
@@ -326,6 +330,11 @@ class _MPConv(torch.autograd.Function):
         w = filters.detach().float().contiguous()
         d = _hip.make_desc(xx, nn_idx, etype, nou, net, ext, agg, False, gz)
         d.reserved = max_in_degree(nn_idx, x.shape[2])
+        # shared edge weights: where the kernel sums their gradient over the batch itself, ask for that form
+        reduced = bool(want_get and ctx.shared_et and L.fgnn_mpconv_backward_reduces_getype(ctypes.byref(d)))
+        if reduced:
+            d.reserved |= _hip.DESC_GETYPE_REDUCED
+            get = torch.empty((1, net, M, k), device=x.device, dtype=torch.float32)
         ws = _workspace(x.device, int(L.fgnn_mpconv_backward_workspace_bytes(ctypes.byref(d))))
         nbytes = 0
         if TIMER is not None:
@@ -342,12 +351,34 @@ class _MPConv(torch.autograd.Function):
             ctypes.byref(d), _hip._ptr(xx), _hip._ptr(nn_idx), _hip._ptr(etype), _hip._ptr(w),
             _hip._ptr(gz), None, _hip._ptr(amax), _hip._ptr(gx), _hip._ptr(get),
             _hip._ptr(gw), _hip._ptr(gb), _hip._ptr(ws), ws.numel() * 4, _hip.stream_ptr())))
+        if want_get and ctx.shared_et and not reduced:
+            get = get.sum(dim=0, keepdim=True)
+        if want_get and get.dtype != etype.dtype:
+            get = get.to(etype.dtype)
         return (gx, None, get, None if gw_sink is not None else gw.to(filters.dtype),
                 None if gb_sink is not None else gb, None, None, None, None, None)
 
 
+def _unexpanded(etype):
+    """[1, net, M, k] tensor that ``etype`` is a batch-``expand`` of (same storage, same autograd history up to views), or
+    None.  The reference scripts build one edge-weight table and repeat it over the batch
+    (train_syn_hop_factor.py:284-295); given the un-expanded tensor the operator returns its gradient already summed."""
+    if etype.dim() != 4 or etype.shape[0] < 2 or etype.stride(0) != 0:
+        return None
+    base = etype._base
+    if (base is not None and base.dim() == 4 and base.shape[0] == 1 and base.shape[1:] == etype.shape[1:]
+            and base.data_ptr() == etype.data_ptr() and base.stride()[1:] == etype.stride()[1:]
+            and base.requires_grad == etype.requires_grad):
+        return base
+    return None
+
+
 def mpconv(x, nn_idx, etype, filters, bias, nou, net, ext, agg, want_stats=False):
     """Differentiable pre-BatchNorm operator output z [B, nou, M, 1]."""
+    if ext != _hip.EXT_NONE:
+        base = _unexpanded(etype)
+        if base is not None:
+            etype = base
     return _MPConv.apply(x, nn_idx, etype, filters, bias, nou, net, ext, agg, want_stats)
 
 

@@ -45,7 +45,8 @@ typedef struct fgnn_mpconv_desc {
     int32_t agg;    /* FGNN_AGG_*  */
     int32_t dtype;  /* FGNN_F32 / FGNN_BF16: storage type of x, etype, y (accumulation is f32) */
     int32_t relu;   /* apply max(.,0) last (forward only) */
-    int32_t reserved;
+    int32_t reserved; /* backward only: bits 0-15 = largest in-degree of the shared neighbour table (0 = unknown),
+                         FGNN_DESC_GETYPE_REDUCED = getype is the batch-summed [net, M, k] gradient (see below) */
     int64_t x_sb, x_sc, x_sn;
     int64_t idx_sb, idx_sm, idx_sk;
     int64_t et_sb, et_se, et_sm, et_sk;
@@ -88,6 +89,16 @@ int fgnn_mpconv_backward(const fgnn_mpconv_desc* d, const void* x, const int64_t
                          fgnn_stream_t stream);
 
 int64_t fgnn_mpconv_backward_workspace_bytes(const fgnn_mpconv_desc* d);
+
+/*
+ * Edge weights shared by the batch (et_sb == 0; every reference script builds them from one [1, ., M, k] feature table,
+ * train_syn_hop_factor.py:284-295): what autograd needs is the gradient SUMMED over the batch.  Where
+ * fgnn_mpconv_backward_reduces_getype(d) returns 1, setting FGNN_DESC_GETYPE_REDUCED in d->reserved makes
+ * fgnn_mpconv_backward write getype as [net, M, k] (float32, contiguous, fully written, summed over the batch in a fixed
+ * order) instead of [B, net, M, k]; with the flag set on any other descriptor the call fails with FGNN_EUNSUPPORTED.
+ */
+#define FGNN_DESC_GETYPE_REDUCED 0x10000
+int fgnn_mpconv_backward_reduces_getype(const fgnn_mpconv_desc* d);
 
 /* Bytes of dynamic LDS the forward will request for this descriptor (diagnostics / tests). */
 /*

@@ -43,6 +43,7 @@ def main():
     ap.add_argument('--regular', action='store_true', help='regular random graphs (constant in-degree) for the parity shapes')
     ap.add_argument('--only', default='')
     ap.add_argument('--syn', action='store_true', help='the synthetic-PGM shapes instead of the LDPC ones')
+    ap.add_argument('--shared-et', action='store_true', help='edge types shared by the batch ([1, net, M, k] expanded), as in the synthetic-PGM scripts')
     ap.add_argument('--etgrad', action='store_true', help='hyper shapes: also ask for the edge-weight gradient')
     a = ap.parse_args()
     dev = torch.device('cuda:0')
@@ -67,12 +68,14 @@ def main():
             idx = torch.randint(0, N, (1, M, k), generator=g).to(dev).expand(B, -1, -1)
         if net == 1:
             et = torch.ones(1, 1, M, k, device=dev, dtype=dt).expand(B, -1, -1, -1)
+        elif a.shared_et:
+            et = torch.randn(1, net, M, k, generator=g).to(dev, dt).expand(B, -1, -1, -1)
         else:
             et = torch.randn(B, M, k, net, generator=g).to(dev, dt).permute(0, 3, 1, 2)
         W = (torch.randn(nin * (1 if ext == 0 else 2), nou * net, generator=g) * 0.1).to(dev)
         bias = torch.randn(nou, generator=g).to(dev)
         nbytes = ops.algorithmic_bytes(x, idx, et, nou, net, ext, agg)
-        flops = 2.0 * B * N * nin * nou * net + 2.0 * B * M * k * nou * net
+        flops = 2.0 * B * N * nin * (1 if ext == 0 else 2) * nou * net + 2.0 * B * M * k * nou * net * (1 if ext == 0 else 2)
 
         def fwd():
             return ops.mpconv_forward_raw(x, idx, et, W, bias, nou, net, ext, agg, want_argmax=a.bwd)
@@ -90,6 +93,9 @@ def main():
             gb = torch.zeros(nou, device=dev)
             dsc = _hip.make_desc(x, idx, et, nou, net, ext, agg, False, gz)
             dsc.reserved = ops.max_in_degree(idx, N)
+            if get is not None and et.stride(0) == 0 and L.fgnn_mpconv_backward_reduces_getype(ctypes.byref(dsc)):
+                dsc.reserved |= _hip.DESC_GETYPE_REDUCED              # shared edge weights: batch-summed gradient
+                get = torch.empty((1, net, M, k), device=dev, dtype=torch.float32)
             nbytes = (x.element_size() * (x.numel() + gz.numel()) + et.element_size() * net * M * k *
                       (1 if et.stride(0) == 0 else B) + 8 * M * k + B * nou * M + x.element_size() * (gx.numel() + (get.numel() if get is not None else 0))
                       + 8 * W.numel())
