@@ -39,7 +39,10 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--batch', type=int, default=4096, help='codewords per GPU (weak scaling)')
+    ap.add_argument('--workload', choices=['ldpc', 'syn_pw', 'syn_hop'], default='ldpc',
+                    help='ldpc: BASELINE configs 3/4 (the metric); syn_pw / syn_hop: factor_mpnn on 30-node synthetic PGMs '
+                         '(configs 2 / 5: train_syn_pw_factor.py at batch 256, train_syn_hop_factor.py at batch 1024), f32')
+    ap.add_argument('--batch', type=int, default=None, help='samples per GPU (weak scaling); default 4096 / 256 / 1024 by workload')
     ap.add_argument('--mode', choices=['train', 'fwd'], default='train')
     ap.add_argument('--dtype', choices=['f32', 'bf16'], default='bf16',
                     help='bf16 (BASELINE config 3): bf16 activations/messages + bf16 matrix cores in the forward, '
@@ -61,7 +64,11 @@ def parse():
                     help='also time the CPU baseline once with every host core (evidence for the --cpu-threads choice)')
     ap.add_argument('--cpu-batch', type=int, default=512)
     ap.add_argument('--cpu-threads', type=int, default=16)
-    return ap.parse_args()
+    ap.add_argument('--hop-order', type=int, default=9, help='syn_hop: order of the high-order factors (train_syn_hop_factor.py --hop_order)')
+    a = ap.parse_args()
+    if a.batch is None:
+        a.batch = {'ldpc': 4096, 'syn_pw': 256, 'syn_hop': 1024}[a.workload]
+    return a
 
 
 def loss_fn(logits, snr_pred, label, sigma_b):
@@ -120,6 +127,249 @@ def cpu_baseline(batch, mode, threads, budget=20.0, max_iters=5):
                                         torch.__version__)}
 
 
+# ----------------------------------------------------------------------------------------------------------------------
+# synthetic-PGM workloads (BASELINE configs 2 / 5): factor_mpnn as train_syn_pw_factor.py / train_syn_hop_factor.py build it
+# ----------------------------------------------------------------------------------------------------------------------
+SYN_DIMS = [64, 64, 128, 128, 256, 256, 128, 128, 64, 64, 2]
+
+
+def syn_tables(workload, hop_order):
+    """(hop feature dim, nodes of the high-order factor axis, pw table, pw edge features, high table, high edge features)."""
+    from fgnn_amd import tables
+    pw_idx, pw_ef = tables.pw_factor_table(30)
+    if workload == 'syn_pw':                              # train_syn_pw_factor.py: one chain factor per graph besides the pairwise ones
+        hi_idx, hi_ef, _ = tables.chain_high_table(30, 9)
+        return 1, 1, pw_idx, pw_ef, hi_idx, hi_ef
+    hi_idx, hi_ef = tables.ring_hop_table(30, hop_order)  # train_syn_hop_factor.py: 30 order-k factors on a ring
+    return hop_order, 30, pw_idx, pw_ef, hi_idx, hi_ef
+
+
+def syn_messages_per_graph(model, tabs):
+    """VF+FV messages of one forward: edges (M x k) of every message-operator call."""
+    from fgnn_amd.mpnn import mp_conv_residual, mp_conv_v2
+    edges = [t.shape[0] * t.shape[1] for t in tabs]
+    total = 0
+    for row in model.mp_nn_modules:
+        for j, m in enumerate(row):
+            if isinstance(m, (mp_conv_v2, mp_conv_residual)):
+                total += edges[j]
+    return total
+
+
+def syn_cpu_baseline(workload, hop_order, batch, mode, threads, budget=20.0, max_iters=5):
+    """The oracle's factor_mpnn (reference op order, PyTorch CPU) on a bounded sample of the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    import fgnn_oracle as O
+    import fgnn_amd
+    cores = max(1, min(threads, os.cpu_count() or 1))
+    torch.set_num_threads(cores)
+    hop_dim, hi_nodes, pw_idx, pw_ef, hi_idx, hi_ef = syn_tables(workload, hop_order)
+    with contextlib.redirect_stdout(sys.stderr):
+        model = fgnn_amd.factor_mpnn(2, [4, hop_dim], SYN_DIMS, [16, 16])
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    g = torch.Generator().manual_seed(1)
+    nf, pws = torch.rand(batch, 2, 30, 1, generator=g), torch.rand(batch, 4, 30, 1, generator=g)
+    hi = torch.rand(batch, hop_dim, hi_nodes, 1, generator=g)
+    label = torch.randint(0, 2, (batch, 30), generator=g)
+    et_pw, et_hi = torch.randn(1, 16, *pw_idx.shape, generator=g), torch.randn(1, 16, *hi_idx.shape, generator=g)
+    gs = [[torch.from_numpy(pw_idx)[None].repeat(batch, 1, 1), et_pw.repeat(batch, 1, 1, 1)],
+          [torch.from_numpy(hi_idx)[None].repeat(batch, 1, 1), et_hi.repeat(batch, 1, 1, 1)]]
+    if mode == 'train':
+        for k, v in sd.items():
+            if v.is_floating_point() and 'running_' not in k:
+                v.requires_grad_(True)
+
+    def once():
+        if mode == 'train':
+            pred, _ = O.factor_mpnn(sd, '', nf, [pws, hi], gs, dims=SYN_DIMS, netypes=[16, 16], training=True)
+            torch.nn.functional.cross_entropy(pred.squeeze(-1).permute(0, 2, 1).reshape(-1, 2), label.reshape(-1)).backward()
+        else:
+            with torch.no_grad():
+                O.factor_mpnn(sd, '', nf, [pws, hi], gs, dims=SYN_DIMS, netypes=[16, 16], training=False)
+
+    t0 = time.time()
+    once()
+    times = [time.time() - t0]
+    t_end = time.time() + budget
+    fresh = []
+    while len(fresh) < max_iters and time.time() + times[0] < t_end:
+        t0 = time.time()
+        once()
+        fresh.append(time.time() - t0)
+    times = sorted(fresh or times)
+    med = times[len(times) // 2]
+    msgs = syn_messages_per_graph(model, [pw_idx, hi_idx])
+    return {'value': msgs * batch / med, 'unit': 'messages/s', 'cores': cores, 'kind': 'port',
+            'sample': 'oracle factor_mpnn (%s) %s, batch %d graphs, median of %d iterations (%.2f s each), %d of %d host cores, '
+                      'torch %s CPU' % (workload, 'train fwd+bwd' if mode == 'train' else 'eval fwd', batch, len(times), med,
+                                        cores, os.cpu_count() or 1, torch.__version__)}
+
+
+def main_syn(args):
+    """factor_mpnn training (or inference) step on synthetic 30-node PGMs, f32: edge models -> factor_mpnn (12 fused message
+    operator calls through csrc/mpconv_fwd_ext.hip / mpconv_bwd_ext.hip) -> cross entropy -> backward -> gradient-norm clip
+    -> Adam (train_syn_hop_factor.py:283-303).  Same JSON contract as the LDPC workload; `value` counts VF+FV messages."""
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world != args.gpus and world > 1:
+        raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a ROCm device: the FGNN hot path has no CPU fallback')
+    dev_index = int(os.environ.get('FGNN_BENCH_DEVICE', local_rank))
+    torch.cuda.set_device(dev_index)
+    dev = torch.device('cuda', dev_index)
+    if world > 1:
+        backend = os.environ.get('FGNN_DIST_BACKEND', 'nccl')
+        if backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    torch.backends.cudnn.enabled = bool(args.miopen_bn)
+    import fgnn_amd
+    from fgnn_amd import ops
+    from fgnn_amd.dp import FlatAdam, FlatGradBucket, broadcast_parameters
+
+    torch.manual_seed(0)
+    hop_dim, hi_nodes, pw_idx, pw_ef, hi_idx, hi_ef = syn_tables(args.workload, args.hop_order)
+    C = torch.nn.Conv2d
+    with contextlib.redirect_stdout(sys.stderr):
+        model = fgnn_amd.factor_mpnn(2, [4, hop_dim], SYN_DIMS, [16, 16]).to(dev)
+    em_pw = torch.nn.Sequential(C(3, 64, 1), torch.nn.ReLU(inplace=True), C(64, 16, 1)).to(dev)
+    em_hi = torch.nn.Sequential(C(hi_ef.shape[0], 64, 1), torch.nn.ReLU(inplace=True), C(64, 16, 1)).to(dev)
+    everything = torch.nn.ModuleList([model, em_pw, em_hi])
+    broadcast_parameters(everything)
+    B = args.batch
+    g = torch.Generator().manual_seed(100 + rank)
+    nf = torch.rand(B, 2, 30, 1, generator=g).to(dev)                  # log-potentials ~ U(0, 1) (lib/data/random_pgm.py)
+    pws = torch.rand(B, 4, 30, 1, generator=g).to(dev)
+    hi = torch.rand(B, hop_dim, hi_nodes, 1, generator=g).to(dev)
+    label = torch.randint(0, 2, (B, 30), generator=g).to(dev)
+    idx_pw, idx_hi = torch.from_numpy(pw_idx).to(dev)[None], torch.from_numpy(hi_idx).to(dev)[None]
+    ef_pw, ef_hi = torch.from_numpy(pw_ef).to(dev)[None], torch.from_numpy(hi_ef).to(dev)[None]
+    if args.tables == 'per_sample':                                    # B materialised copies, as the reference's .repeat passes them
+        rep_i, rep_e = (lambda t: t.repeat(B, 1, 1)), (lambda t: t.repeat(B, 1, 1, 1))
+    else:
+        rep_i, rep_e = (lambda t: t.expand(B, -1, -1)), (lambda t: t.expand(B, -1, -1, -1))
+    if args.no_dedupe:
+        ops.DEDUPE_GRAPHS = False
+    train = args.mode == 'train'
+    everything.train(train)
+    if train:
+        bucket = FlatGradBucket(everything.parameters(), flatten_params=True)
+        opt = FlatAdam(bucket, lr=3e-3)
+
+    def forward():
+        et_pw, et_hi = em_pw(ef_pw), em_hi(ef_hi)
+        pred, _ = model(nf, [pws, hi], [[rep_i(idx_pw), rep_e(et_pw)], [rep_i(idx_hi), rep_e(et_hi)]])
+        return pred
+
+    def compute():
+        if train:
+            bucket.zero()
+            pred = forward()
+            torch.nn.functional.cross_entropy(pred.squeeze(-1).permute(0, 2, 1).reshape(-1, 2), label.reshape(-1)).backward()
+        else:
+            with torch.no_grad():
+                forward()
+
+    graphed = None
+    if not args.no_graph:
+        try:
+            from fgnn_amd.graph import StepGraph
+            graphed = StepGraph(compute)
+        except Exception as e:           # noqa: BLE001 — report and fall back to eager launches
+            print('bench.py: hipGraph capture failed (%s: %s); running eagerly' % (type(e).__name__, e), file=sys.stderr)
+            graphed = None
+
+    def step():
+        if graphed is not None:
+            graphed.replay()
+        else:
+            compute()
+        if train:
+            bucket.all_reduce_sum()
+            # torch.nn.utils.clip_grad_norm(parameters, 1.0) on the flat gradient, without a host round trip
+            gflat = bucket.flat
+            norm = torch.linalg.vector_norm(gflat) / world
+            gflat.mul_(torch.clamp(1.0 / (norm + 1e-6), max=1.0))
+            opt.step(grad_scale=1.0 / world)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    roofline, kernels = None, {}
+    if rank == 0:
+        ops.SIDE_STREAM = False
+        compute()
+        torch.cuda.synchronize()
+        ops.TIMER = ops.KernelTimer()
+        compute()
+        ops.SIDE_STREAM = True
+        kernels = ops.TIMER.summary()
+        ops.TIMER = None
+        mp = [(k, v) for k, v in kernels.items() if k.startswith('mpconv_')]
+        if mp:
+            sym, r = max(mp, key=lambda kv: kv[1]['ms'])
+            avg_ms = r['ms'] / r['launches']
+            tfs = (r['flops'] / r['launches']) / (avg_ms * 1e-3) / 1e12
+            gbs = (r['bytes'] / r['launches']) / (avg_ms * 1e-3) / 1e9
+            roofline = {'bound': 'mfma', 'achieved': round(tfs, 2), 'peak': F32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                        'frac': round(tfs / F32_MFMA_PEAK_TFLOPS, 4), 'traffic': None, 'kernel': sym,
+                        'launches_per_step': r['launches'], 'avg_launch_us': round(avg_ms * 1e3, 2),
+                        'algorithmic_bytes_per_launch': r['bytes'] // r['launches'],
+                        'algorithmic_flops_per_launch': r['flops'] // r['launches'],
+                        'hbm': {'bound': 'hbm', 'achieved': round(gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                                'frac': round(gbs / HBM_PEAK_GBS, 4), 'traffic': None}}
+    fence()
+    if rank == 0:
+        msgs = syn_messages_per_graph(model, [pw_idx, hi_idx])
+        out = {
+            'metric': 'VF+FV messages/sec on 30-node synthetic PGMs (%s)' % args.workload,
+            'value': msgs * B * world * args.steps / elapsed, 'unit': 'messages/s', 'n_gpus': world,
+            'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': '%s: factor_mpnn(2, [4, %d], %s, [16, 16]) + two edge models, %s step, batch %d graphs per GPU '
+                                   '(30 variables, 30 pairwise factors k=2, %s), graph tables %s'
+                                   % (args.workload, hop_dim, SYN_DIMS,
+                                      'training (fwd + bwd + grad all-reduce + norm clip + Adam)' if train else 'inference forward', B,
+                                      'one chain factor' if args.workload == 'syn_pw' else '30 order-%d factors' % args.hop_order,
+                                      'batch-shared (expand)' if args.tables == 'shared' else 'per-sample copies (repeat)'),
+                       'messages_per_graph': msgs, 'graphs_per_s': B * world * args.steps / elapsed,
+                       'global_batch': B * world, 'parallelism': 'dp%d' % world, 'mode': args.mode,
+                       'hip_graph': graphed is not None,
+                       'peak_hbm_GB': round(torch.cuda.max_memory_allocated(dev) / 1e9, 2)},
+            'roofline': roofline,
+            'kernels': {k: {'launches': v['launches'], 'avg_us': round(v['ms'] / v['launches'] * 1e3, 2),
+                            'total_ms': round(v['ms'], 3),
+                            'algorithmic_GBs': round(v['bytes'] / max(v['ms'], 1e-9) / 1e6, 1)}
+                        for k, v in sorted(kernels.items(), key=lambda kv: -kv[1]['ms'])},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = syn_cpu_baseline(args.workload, args.hop_order, min(args.cpu_batch, 64), args.mode, args.cpu_threads)
+        else:
+            out['cpu_baseline'] = None
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def _trace(msg):
     if os.environ.get('FGNN_BENCH_TRACE'):
         print('[bench rank %s] %s' % (os.environ.get('RANK', '0'), msg), file=sys.stderr, flush=True)
@@ -127,6 +377,8 @@ def _trace(msg):
 
 def main():
     args = parse()
+    if args.workload != 'ldpc':
+        return main_syn(args)
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))

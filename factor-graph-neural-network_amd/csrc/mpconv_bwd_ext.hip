@@ -48,9 +48,9 @@ struct BxParams {
     float* gx;
     float* ws;               // [grid][nw + nou] gW / gbias slabs
     float* get_ws;           // [grid][16][N][k] edge-type gradient slabs, or null
-    int B, N, k, ext;
+    int B, N, k, ext, nou, ncols, npass, wvec;      // wvec: filter rows are 16-byte aligned (float4 loads)
     long long x_sb, y_sb, idx_sm, idx_sk, et_se, et_sm, et_sk;
-    int off_xs, off_ps, off_et, off_get, off_idx, off_csr, off_gz, off_am;
+    int off_xs, off_ps, off_et, off_get, off_idx, off_csr, off_gz, off_am, off_w;
     long long slab_len, get_len;
 };
 
@@ -58,6 +58,7 @@ extern __shared__ __attribute__((aligned(16))) unsigned char bx_lds[];
 
 __device__ __forceinline__ int bx_krow(int kk, int lk) { return 4 * lk + (kk & 3) + 16 * (kk >> 2); }
 
+template <int AGG>
 __global__ __launch_bounds__(BX_THREADS, 2) void mpconv_bwd_ext_kernel(const BxParams p) {
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
@@ -76,6 +77,8 @@ __global__ __launch_bounds__(BX_THREADS, 2) void mpconv_bwd_ext_kernel(const BxP
     int* csr_off = reinterpret_cast<int*>(bx_lds + p.off_csr + ((mk * 2 + 15) & ~15));  // [65]
     float* gz_s = reinterpret_cast<float*>(bx_lds + p.off_gz);        // [64][4]
     unsigned* am_s = reinterpret_cast<unsigned*>(bx_lds + p.off_am);  // [64] four argmax bytes
+    float* w_s = reinterpret_cast<float*>(bx_lds + p.off_w);          // LSE: [mk][4] softmax weight of edge (m, j) per channel of the pass
+    const int nou = p.nou, ncols = p.ncols, npass = p.npass;
 
     const int chunk = (p.B + gridDim.x - 1) / gridDim.x;
     const int b_begin = blockIdx.x * chunk;
@@ -144,9 +147,20 @@ __global__ __launch_bounds__(BX_THREADS, 2) void mpconv_bwd_ext_kernel(const BxP
             gzr = make_uint4(0, 0, 0, 0);
             amr = 0;
             if (tid < N) {
-                const int64_t o = (int64_t)b * p.y_sb + (int64_t)tid * BX_NOU + BX_PCH * pass;
-                gzr = *reinterpret_cast<const uint4*>(p.gz + o);
-                amr = *reinterpret_cast<const unsigned*>(p.am + o);
+                const int64_t o = (int64_t)b * p.y_sb + (int64_t)tid * nou + BX_PCH * pass;
+                if ((nou & 3) == 0) {
+                    gzr = *reinterpret_cast<const uint4*>(p.gz + o);
+                    if (AGG == FGNN_AGG_MAX) amr = *reinterpret_cast<const unsigned*>(p.am + o);
+                } else {                                              // narrow outputs (64 -> 2 closes factor_mpnn): guarded scalars
+                    float gq[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (BX_PCH * pass + i < nou) {
+                            gq[i] = p.gz[o + i];
+                            if (AGG == FGNN_AGG_MAX) amr |= (unsigned)p.am[o + i] << (8 * i);
+                        }
+                    gzr = make_uint4(__float_as_uint(gq[0]), __float_as_uint(gq[1]), __float_as_uint(gq[2]), __float_as_uint(gq[3]));
+                }
             }
         }
     };
@@ -163,30 +177,40 @@ __global__ __launch_bounds__(BX_THREADS, 2) void mpconv_bwd_ext_kernel(const BxP
     };
 
     __syncthreads();
-    prefetch(b_begin, blockIdx.x & (BX_NPASS - 1));
+    prefetch(b_begin, blockIdx.x % npass);
 
-    for (int pp = 0; pp < BX_NPASS; ++pp) {
-        const int pass = (pp + blockIdx.x) & (BX_NPASS - 1);          // staggered: the chip does not read one filter slice at once
-        const int pass_next = (pp + 1 + blockIdx.x) & (BX_NPASS - 1);
+    for (int pp = 0; pp < npass; ++pp) {
+        const int pass = (pp + blockIdx.x) % npass;                   // staggered: the chip does not read one filter slice at once
+        const int pass_next = (pp + 1 + blockIdx.x) % npass;
         // ---- filter slice of the pass ----
         float aW[16];                                                 // phase A B-operand: W[c = 16 lk + kk][column of this wave's slab]
         {
             const int col = 16 * (BX_PCH * pass + a_sl) + li;
+            const bool live = BX_PCH * pass + a_sl < nou;
 #pragma unroll
             for (int kk = 0; kk < 16; ++kk) {
                 const int c = 16 * lk + kk;
-                const float wt = p.W[(int64_t)c * BX_NCOLS + col], wb = p.W[(int64_t)(BX_NIN + c) * BX_NCOLS + col];
+                const float wt = live ? p.W[(int64_t)c * ncols + col] : 0.f, wb = live ? p.W[(int64_t)(BX_NIN + c) * ncols + col] : 0.f;
                 aW[kk] = a_half == 0 ? (diff ? wt + wb : wt) : (diff ? -wb : wb);
             }
         }
         float gB[32];                                                 // gx B-operand: Wc[dP column 32 lk + kk][c = 16 ct + li]
         {
             const int c = 16 * c_ct + li;
-            const float* wtop = p.W + (int64_t)c * BX_NCOLS + 64 * pass + 32 * (lk & 1);
-            const float* wbot = wtop + (int64_t)BX_NIN * BX_NCOLS;
+            const float* wtop = p.W + (int64_t)c * ncols + 64 * pass + 32 * (lk & 1);
+            const float* wbot = wtop + (int64_t)BX_NIN * ncols;
+            const bool live = 64 * pass + 32 * (lk & 1) < ncols;     // ncols is a multiple of 32 (nou even)
+            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
-                const f32x4 t = *reinterpret_cast<const f32x4*>(wtop + 4 * q), b = *reinterpret_cast<const f32x4*>(wbot + 4 * q);
+                f32x4 t = zero, b = zero;
+                if (live && p.wvec) {
+                    t = *reinterpret_cast<const f32x4*>(wtop + 4 * q);
+                    b = *reinterpret_cast<const f32x4*>(wbot + 4 * q);
+                } else if (live) {                                    // parameters living at odd offsets of a flat buffer
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { t[i] = wtop[4 * q + i]; b[i] = wbot[4 * q + i]; }
+                }
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
                     gB[4 * q + i] = lk < 2 ? (diff ? t[i] + b[i] : t[i]) : (diff ? -b[i] : b[i]);
@@ -204,7 +228,7 @@ __global__ __launch_bounds__(BX_THREADS, 2) void mpconv_bwd_ext_kernel(const BxP
             __syncthreads();                                          // previous stage is done with xs, P, gz_s
             commit();
             if (s + 1 < ns) prefetch(b + 1, pass);
-            else if (pp + 1 < BX_NPASS) prefetch(b_begin, pass_next);
+            else if (pp + 1 < npass) prefetch(b_begin, pass_next);
             __syncthreads();
 
             // ================= phase A: P = x [Ws | Wt] =================
@@ -232,18 +256,60 @@ __global__ __launch_bounds__(BX_THREADS, 2) void mpconv_bwd_ext_kernel(const BxP
             }
             __syncthreads();
 
-            // ================= phase B1: get[m][j*][e] += gz (S + T) =================
+            if (AGG == FGNN_AGG_LSE) {
+                // ================= phase B0 (softmax aggregator): w[m][j][oc] = exp(3 E_j - 3 agg) =================
+                if (tid < 256 && b2_row < N) {
+                    const float* srow = ps + b2_row * BX_PS + 16 * b2_oc;
+                    f32x4 sv[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) sv[q] = *reinterpret_cast<const f32x4*>(srow + 4 * q);
+                    float mx = -INFINITY, ssum = 0.f;
+                    for (int j = 0; j < k; ++j) {
+                        const int r = b2_row * k + j;
+                        const float* trow = ps + idx_s[r] * BX_PS + 64 + 16 * b2_oc;
+                        const float* er = et_s + r * BX_NET;
+                        float v = 0.f;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const f32x4 tv = *reinterpret_cast<const f32x4*>(trow + 4 * q), ev = *reinterpret_cast<const f32x4*>(er + 4 * q);
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) v = fmaf(ev[i], sv[q][i] + tv[i], v);
+                        }
+                        v *= 3.0f;
+                        w_s[r * 4 + b2_oc] = v;
+                        if (v > mx) { ssum = ssum * expf(mx - v) + 1.0f; mx = v; }
+                        else ssum += expf(v - mx);
+                    }
+                    const float zagg = mx + logf(ssum);
+                    for (int j = 0; j < k; ++j) {
+                        const int r = b2_row * k + j;
+                        w_s[r * 4 + b2_oc] = expf(w_s[r * 4 + b2_oc] - zagg);
+                    }
+                }
+                __syncthreads();
+            }
+
+            // ================= phase B1: get[m][j][e] += gz w_j (S + T)   (max: w = 1 at the argmax only) =================
             if (want_get && tid < 256 && b1_m < N) {
                 const unsigned am4 = am_s[b1_m];
                 const f32x4 g4 = *reinterpret_cast<const f32x4*>(gz_s + b1_m * 4);
 #pragma unroll
                 for (int oc = 0; oc < BX_PCH; ++oc) {
-                    const int j = min((int)((am4 >> (8 * oc)) & 255u), k - 1);
-                    const int r = b1_m * k + j;
                     const f32x4 sv = *reinterpret_cast<const f32x4*>(ps + b1_m * BX_PS + 16 * oc + 4 * b1_eq);
-                    const f32x4 tv = *reinterpret_cast<const f32x4*>(ps + idx_s[r] * BX_PS + 64 + 16 * oc + 4 * b1_eq);
-                    f32x4* gp = reinterpret_cast<f32x4*>(get_s + r * BX_NET + 4 * b1_eq);
-                    *gp = *gp + g4[oc] * (sv + tv);
+                    if (AGG == FGNN_AGG_MAX) {
+                        const int j = min((int)((am4 >> (8 * oc)) & 255u), k - 1);
+                        const int r = b1_m * k + j;
+                        const f32x4 tv = *reinterpret_cast<const f32x4*>(ps + idx_s[r] * BX_PS + 64 + 16 * oc + 4 * b1_eq);
+                        f32x4* gp = reinterpret_cast<f32x4*>(get_s + r * BX_NET + 4 * b1_eq);
+                        *gp = *gp + g4[oc] * (sv + tv);
+                    } else {
+                        for (int j = 0; j < k; ++j) {
+                            const int r = b1_m * k + j;
+                            const f32x4 tv = *reinterpret_cast<const f32x4*>(ps + idx_s[r] * BX_PS + 64 + 16 * oc + 4 * b1_eq);
+                            f32x4* gp = reinterpret_cast<f32x4*>(get_s + r * BX_NET + 4 * b1_eq);
+                            *gp = *gp + (g4[oc] * w_s[r * 4 + oc]) * (sv + tv);
+                        }
+                    }
                 }
             }
             __syncthreads();
@@ -255,10 +321,20 @@ __global__ __launch_bounds__(BX_THREADS, 2) void mpconv_bwd_ext_kernel(const BxP
                 for (int q = 0; q < 4; ++q) row[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 if (b2_row < N) {
                     const float g = gz_s[b2_row * 4 + b2_oc];
-                    const int j = min((int)((am_s[b2_row] >> (8 * b2_oc)) & 255u), k - 1);
-                    const float* er = et_s + (b2_row * k + j) * BX_NET;
+                    if (AGG == FGNN_AGG_MAX) {
+                        const int j = min((int)((am_s[b2_row] >> (8 * b2_oc)) & 255u), k - 1);
+                        const float* er = et_s + (b2_row * k + j) * BX_NET;
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) row[q] = g * *reinterpret_cast<const f32x4*>(er + 4 * q);
+                        for (int q = 0; q < 4; ++q) row[q] = g * *reinterpret_cast<const f32x4*>(er + 4 * q);
+                    } else {
+                        for (int j = 0; j < k; ++j) {
+                            const int r = b2_row * k + j;
+                            const float gw = g * w_s[r * 4 + b2_oc];
+                            const float* er = et_s + r * BX_NET;
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) row[q] = gw * *reinterpret_cast<const f32x4*>(er + 4 * q) + row[q];
+                        }
+                    }
                     gb_acc += g;
                 }
                 float* dr = ps + b2_row * BX_PS + 16 * b2_oc;
@@ -273,8 +349,9 @@ __global__ __launch_bounds__(BX_THREADS, 2) void mpconv_bwd_ext_kernel(const BxP
                     for (int i = csr_off[b2_row]; i < e1; ++i) {
                         const int r = csr_ent[i];
                         const int m = r / k, j = r - m * k;
-                        if ((int)((am_s[m] >> (8 * b2_oc)) & 255u) == j) {
-                            const float g = gz_s[m * 4 + b2_oc];
+                        if (AGG != FGNN_AGG_MAX || (int)((am_s[m] >> (8 * b2_oc)) & 255u) == j) {
+                            float g = gz_s[m * 4 + b2_oc];
+                            if (AGG != FGNN_AGG_MAX) g *= w_s[r * 4 + b2_oc];
                             const float* er = et_s + r * BX_NET;
 #pragma unroll
                             for (int q = 0; q < 4; ++q) row[q] = g * *reinterpret_cast<const f32x4*>(er + 4 * q) + row[q];
@@ -351,22 +428,24 @@ __global__ __launch_bounds__(BX_THREADS, 2) void mpconv_bwd_ext_kernel(const BxP
         {
             // D[i = c = 16 (2 cp + a) + 4 lk + r][j = column 16 t + li]; filters row c (top) and 64 + c (bottom)
             const int col = 64 * pass + 16 * w_t + li;
+            if (col < ncols) {
 #pragma unroll
-            for (int a = 0; a < 2; ++a)
+                for (int a = 0; a < 2; ++a)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int c = 16 * (2 * w_cp + a) + 4 * lk + r;
-                    const float gs = accW[a][0][r], gt = accW[a][1][r];
-                    slab[(int64_t)c * BX_NCOLS + col] = gs;
-                    slab[(int64_t)(BX_NIN + c) * BX_NCOLS + col] = diff ? gs - gt : gt;
-                }
+                    for (int r = 0; r < 4; ++r) {
+                        const int c = 16 * (2 * w_cp + a) + 4 * lk + r;
+                        const float gs = accW[a][0][r], gt = accW[a][1][r];
+                        slab[(int64_t)c * ncols + col] = gs;
+                        slab[(int64_t)(BX_NIN + c) * ncols + col] = diff ? gs - gt : gt;
+                    }
+            }
             __syncthreads();                                          // phase C is done with P: scratch for the bias reduction
             if (tid < 256) ps[tid] = gb_acc;                          // [m][oc]
             __syncthreads();
-            if (tid < BX_PCH) {
+            if (tid < BX_PCH && BX_PCH * pass + tid < nou) {
                 float sum = 0.f;
                 for (int m = 0; m < 64; ++m) sum += ps[m * 4 + tid];
-                slab[(int64_t)2 * BX_NIN * BX_NCOLS + BX_PCH * pass + tid] = sum;
+                slab[(int64_t)2 * BX_NIN * ncols + BX_PCH * pass + tid] = sum;
             }
         }
     }
@@ -394,12 +473,14 @@ int64_t fgnn_mpconv_backward_ext_extra_bytes(const fgnn_mpconv_desc* d) {
 int fgnn_mpconv_backward_ext_accepts(const fgnn_mpconv_desc* d) {
     static const bool off = getenv("FGNN_NO_EXT") != nullptr;
     if (off) return 0;
-    if (d->dtype != FGNN_F32 || (d->ext != FGNN_EXT_NEIGHBOR && d->ext != FGNN_EXT_DIFF) || d->agg != FGNN_AGG_MAX) return 0;
-    if (d->net != BX_NET || d->nin != BX_NIN || d->nou != BX_NOU) return 0;
+    if (d->dtype != FGNN_F32 || (d->ext != FGNN_EXT_NEIGHBOR && d->ext != FGNN_EXT_DIFF)) return 0;
+    if (d->agg != FGNN_AGG_MAX && d->agg != FGNN_AGG_LSE) return 0;
+    if (d->net != BX_NET || d->nin != BX_NIN || d->nou < 2 || d->nou > BX_NOU || (d->nou & 1)) return 0;
     if (d->N != d->M || d->N < 1 || d->N > 64 || d->k < 1 || d->k > 16 || d->N * d->k > BX_MAX_MK) return 0;
     if ((d->idx_sb != 0 || d->et_sb != 0) && d->B != 1) return 0;
     if (!(d->x_sc == 1 && d->x_sn == BX_NIN && d->x_sb % 4 == 0)) return 0;
-    if (!(d->y_sc == 1 && d->y_sm == BX_NOU && d->y_sb % 4 == 0)) return 0;
+    if (!(d->y_sc == 1 && d->y_sm == d->nou)) return 0;
+    if ((d->nou & 3) == 0 && d->y_sb % 4 != 0) return 0;
     return 1;
 }
 
@@ -414,12 +495,13 @@ int fgnn_mpconv_backward_ext(const fgnn_mpconv_desc* d, const void* x, const int
         return 0;
     }
     if (getype && !reduced && d->B != 1) return 0;                   // per-sample edge-type gradient: the generic kernel
-    if (((uintptr_t)x & 15) || ((uintptr_t)gz & 15) || ((uintptr_t)argmax & 3) || ((uintptr_t)filters & 15)) {
-        if (reduced) FGNN_FAIL(FGNN_EINVAL, "mpconv ext backward needs 16-byte aligned x / gz / filters");
+    if (((uintptr_t)x & 15) || ((d->nou & 3) == 0 && (((uintptr_t)gz & 15) || ((uintptr_t)argmax & 3)))) {
+        if (reduced) FGNN_FAIL(FGNN_EINVAL, "mpconv ext backward needs 16-byte aligned x / gz");
         return 0;
     }
     const int mk = d->N * d->k;
-    const int64_t nw = (int64_t)2 * BX_NIN * BX_NCOLS, slab_len = nw + BX_NOU, get_len = (int64_t)BX_NET * mk;
+    const int ncols = d->nou * BX_NET;
+    const int64_t nw = (int64_t)2 * BX_NIN * ncols, slab_len = nw + d->nou, get_len = (int64_t)BX_NET * mk;
     int grid = 256;
     if (grid > d->B) grid = d->B;
     const int chunk = (d->B + grid - 1) / grid;
@@ -431,7 +513,7 @@ int fgnn_mpconv_backward_ext(const fgnn_mpconv_desc* d, const void* x, const int
     p.x = (const float*)x; p.idx = nn_idx; p.et = (const float*)etype; p.W = filters; p.gz = (const float*)gz;
     p.am = argmax; p.gx = (float*)gx; p.ws = (float*)workspace;
     p.get_ws = getype ? (float*)workspace + grid * slab_len : nullptr;
-    p.B = d->B; p.N = d->N; p.k = d->k; p.ext = d->ext;
+    p.B = d->B; p.N = d->N; p.k = d->k; p.ext = d->ext; p.nou = d->nou; p.ncols = ncols; p.wvec = ((uintptr_t)filters & 15) == 0; p.npass = (d->nou + BX_PCH - 1) / BX_PCH;
     p.x_sb = d->x_sb; p.y_sb = d->y_sb; p.idx_sm = d->idx_sm; p.idx_sk = d->idx_sk;
     p.et_se = d->et_se; p.et_sm = d->et_sm; p.et_sk = d->et_sk;
     p.slab_len = slab_len; p.get_len = get_len;
@@ -445,15 +527,16 @@ int fgnn_mpconv_backward_ext(const fgnn_mpconv_desc* d, const void* x, const int
     p.off_csr = take(((mk * 2 + 15) & ~15) + 65 * 4);
     p.off_gz = take(64 * 4 * 4);
     p.off_am = take(64 * 4);
+    p.off_w = take(d->agg == FGNN_AGG_LSE ? mk * 4 * 4 : 16);
     const int lds = off_b;
     if (lds > 160 * 1024) {
         if (reduced) FGNN_FAIL(FGNN_EUNSUPPORTED, "mpconv ext backward: %d bytes of LDS", lds);
         return 0;
     }
-    void* fn = (void*)mpconv_bwd_ext_kernel;
+    void* fn = d->agg == FGNN_AGG_MAX ? (void*)mpconv_bwd_ext_kernel<FGNN_AGG_MAX> : (void*)mpconv_bwd_ext_kernel<FGNN_AGG_LSE>;
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "hipFuncSetAttribute(%d B LDS): %s", lds, hipGetErrorString(e));
-    fgnn_note_kernel("mpconv_bwd_ext_kernel");
+    fgnn_note_kernel("mpconv_bwd_ext_kernel<%d>", d->agg);
     void* args[] = {(void*)&p};
     e = hipLaunchKernel(fn, dim3(grid), dim3(BX_THREADS), args, lds, (hipStream_t)stream);
     if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "mpconv ext backward launch: %s", hipGetErrorString(e));

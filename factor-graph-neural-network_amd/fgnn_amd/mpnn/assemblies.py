@@ -97,7 +97,8 @@ class factor_mpnn(torch.nn.Module):
         for L, row in enumerate(self.mp_nn_modules):
             to_nodes, to_factors = [], []
             for j, m in enumerate(row):
-                both = torch.cat([nfeat, ffeat[j]], dim=2).contiguous()
+                # channel-fastest, like every activation on this path (the operator kernels read node rows of channels)
+                both = torch.cat([nfeat, ffeat[j]], dim=2).contiguous(memory_format=torch.channels_last)
                 nn_idx, etype = graph_structures[j]
                 both = _call(m, both, nn_idx, etype)
                 to_nodes.append(both[:, :, :nnode, :])

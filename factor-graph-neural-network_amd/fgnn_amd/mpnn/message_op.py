@@ -88,6 +88,9 @@ class mp_conv_v2(base_mp_nn):
         if not isinstance(self.aggregtor, str):
             return self._forward_custom_aggregator(x, nn_idx, etype, addend)
         ext, agg = _EXT_CODE[self.extension], _hip.AGG_CODES[self.aggregtor]
+        if ext != _hip.EXT_NONE and x.dim() == 4 and x.shape[1] > 1 and x.stride(1) != 1 and x.is_cuda:
+            # the synthetic-PGM kernels (csrc/mpconv_*_ext.hip) read node rows of channels: one transposing copy of x
+            x = x.contiguous(memory_format=torch.channels_last)
         needs_grad = torch.is_grad_enabled() and (
             x.requires_grad or etype.requires_grad or self.filters.requires_grad)
         bn_batch_stats = self.bn is not None and (self.bn.training or self.bn.running_mean is None)
@@ -97,6 +100,8 @@ class mp_conv_v2(base_mp_nn):
             scale = shift = None
             if self.bn is not None:
                 scale, shift = fold_batchnorm(self.bn)
+            if etype.shape[0] == 1 and x.shape[0] > 1:      # shared edge weights handed over un-expanded
+                etype = etype.expand(x.shape[0], -1, -1, -1)
             y, _ = ops.mpconv_forward_raw(x, nn_idx, etype, self.filters, self.bias, self.nou,
                                           self.nedge_types, ext, agg, post_scale=scale,
                                           post_shift=shift, relu=plain_relu)

@@ -360,9 +360,11 @@ class _MPConv(torch.autograd.Function):
 
 
 def _unexpanded(etype):
-    """[1, net, M, k] tensor that ``etype`` is a batch-``expand`` of (same storage, same autograd history up to views), or
-    None.  The reference scripts build one edge-weight table and repeat it over the batch
-    (train_syn_hop_factor.py:284-295); given the un-expanded tensor the operator returns its gradient already summed."""
+    """[1, net, M, k] tensor that ``etype`` is a batch-``expand`` of, or None.  The reference scripts build one edge-weight
+    table and repeat it over the batch (train_syn_hop_factor.py:284-295); given the un-expanded tensor the operator returns
+    its gradient already summed over the batch.  The tensor the caller expanded when autograd can name it (same storage and
+    strides), else the first row of the expanded view (autograd then pads that row's gradient with zeros before its own sum:
+    still far cheaper than a per-sample gradient)."""
     if etype.dim() != 4 or etype.shape[0] < 2 or etype.stride(0) != 0:
         return None
     base = etype._base
@@ -370,15 +372,17 @@ def _unexpanded(etype):
             and base.data_ptr() == etype.data_ptr() and base.stride()[1:] == etype.stride()[1:]
             and base.requires_grad == etype.requires_grad):
         return base
-    return None
+    return etype[:1]
 
 
 def mpconv(x, nn_idx, etype, filters, bias, nou, net, ext, agg, want_stats=False):
     """Differentiable pre-BatchNorm operator output z [B, nou, M, 1]."""
-    if ext != _hip.EXT_NONE:
+    if ext != _hip.EXT_NONE:                             # a [1, net, M, k] etype (shared edge weights, not expanded) is taken as is
         base = _unexpanded(etype)
         if base is not None:
             etype = base
+    elif etype.shape[0] == 1 and x.shape[0] > 1:
+        etype = etype.expand(x.shape[0], -1, -1, -1)
     return _MPConv.apply(x, nn_idx, etype, filters, bias, nou, net, ext, agg, want_stats)
 
 

@@ -656,3 +656,54 @@ def test_inference_after_training_sees_the_trained_state(dev):
     y3 = infer(m)
     fresh.load_state_dict(m.state_dict())
     assert torch.equal(infer(fresh), y3) and not torch.equal(y3, y2)
+
+
+@pytest.mark.parametrize('tag', ['pw', 'hop'])
+def test_factor_mpnn_training_steps_are_bitwise_reproducible(tag, dev):
+    """BASELINE configs 2 / 5: two runs of the same three f32 training steps of factor_mpnn + its two edge models (same seed,
+    same data; train_syn_hop_factor.py:283-303) end in bit-identical parameters and losses: the message operator's kernels
+    (csrc/mpconv_fwd_ext.hip, csrc/mpconv_bwd_ext.hip) and everything around them have no order-dependent accumulation."""
+    import fgnn_amd
+    from fgnn_amd import _hip
+    from fgnn_amd.dp import FlatAdam, FlatGradBucket
+
+    hop_dim, pw_idx, pw_ef, hi_idx, hi_ef = H.syn_setup(tag)
+    B = 96
+
+    def run():
+        torch.manual_seed(77)
+        model = fgnn_amd.factor_mpnn(2, [4, hop_dim], O.SYN_DIMS, [16, 16]).to(dev).train()
+        # the edge models are 1x1 convolutions: this package's Conv2d subclass (same state_dict; torch / MIOpen's own
+        # weight-gradient kernel for a [1, 1, 31, 9] input is not run-to-run reproducible, with or without
+        # torch.backends.cudnn.deterministic)
+        C = fgnn_amd.mpnn.pointwise.PointwiseConv2d
+        em_pw = torch.nn.Sequential(C(3, 64, 1), torch.nn.ReLU(), C(64, 16, 1)).to(dev)
+        em_hi = torch.nn.Sequential(C(hi_ef.shape[0], 64, 1), torch.nn.ReLU(), C(64, 16, 1)).to(dev)
+        everything = torch.nn.ModuleList([model, em_pw, em_hi])
+        bucket = FlatGradBucket(everything.parameters(), flatten_params=True)
+        opt = FlatAdam(bucket, lr=3e-3)
+        g = torch.Generator().manual_seed(5)
+        nf, pws = torch.rand(B, 2, 30, 1, generator=g).to(dev), torch.rand(B, 4, 30, 1, generator=g).to(dev)
+        hi = torch.rand(B, hop_dim, 1 if tag == 'pw' else 30, 1, generator=g).to(dev)
+        label = torch.randint(0, 2, (B, 30), generator=g).to(dev)
+        t = lambda a: torch.from_numpy(a).to(dev)[None]
+        losses = []
+        for _ in range(3):
+            bucket.zero()
+            et_pw, et_hi = em_pw(t(pw_ef)), em_hi(t(hi_ef))
+            pred, _ = model(nf, [pws, hi], [[t(pw_idx).expand(B, -1, -1), et_pw.expand(B, -1, -1, -1)],
+                                           [t(hi_idx).expand(B, -1, -1), et_hi.expand(B, -1, -1, -1)]])
+            loss = torch.nn.functional.cross_entropy(pred.squeeze(-1).permute(0, 2, 1).reshape(-1, 2), label.reshape(-1))
+            loss.backward()
+            opt.step()
+            losses.append(float(loss.detach()))
+        torch.cuda.synchronize()
+        return bucket.flat_param.detach().clone(), losses, bucket.flat.detach().clone()
+
+    pa, la, ga = run()
+    pb, lb, gb = run()
+    assert la == lb, (la, lb)
+    assert torch.equal(ga, gb)
+    assert torch.equal(pa, pb)
+    assert all(l == l and abs(l) < 1e3 for l in la)               # finite
+    assert float((ga != 0).float().mean()) > 0.5                   # the gradients reach (nearly) every parameter

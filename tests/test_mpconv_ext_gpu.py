@@ -99,29 +99,35 @@ def test_ext_forward_matches_generic_kernel(dev, monkeypatch):
 BWD_SHAPES = [(60, 2), (60, 9), (59, 3), (64, 10), (17, 16), (1, 1)]
 
 
-def _grads_vs_oracle(N, k, B, ext, dev, seed=0):
+def _grads_vs_oracle(N, k, B, ext, dev, seed=0, nou=64, agg='max'):
     from fgnn_amd import _hip, ops
     x, idx, et, W, bias, g = _problem(N, k, B, seed=seed)
-    gy = torch.randn(B, N, 1, 64, generator=g)
+    W, bias = W[:, :nou * 16].contiguous(), bias[:nou].contiguous()
+    gy = torch.randn(B, N, 1, nou, generator=g)
+    code = {'max': _hip.AGG_MAX, 'softmax': _hip.AGG_LSE}[agg]
     # device: the autograd Function around the C-ABI calls
     xd = x.to(dev).permute(0, 3, 1, 2).requires_grad_(True)
     ed = et.to(dev).requires_grad_(True)
     Wd, bd = W.to(dev).requires_grad_(True), bias.to(dev).requires_grad_(True)
-    z = ops.mpconv(xd, idx.to(dev).expand(B, -1, -1), ed.expand(B, -1, -1, -1), Wd, bd, 64, 16, ext, _hip.AGG_MAX)
-    assert 'mpconv_fwd_ext' in _hip.lib().fgnn_last_kernel().decode()
+    z = ops.mpconv(xd, idx.to(dev).expand(B, -1, -1), ed.expand(B, -1, -1, -1), Wd, bd, nou, 16, ext, code)
+    assert ('mpconv_fwd_ext' in _hip.lib().fgnn_last_kernel().decode()) == (nou == 64)
     (z * gy.to(dev).permute(0, 3, 1, 2)).sum().backward()
     assert 'mpconv_bwd_ext' in _hip.lib().fgnn_last_kernel().decode(), _hip.lib().fgnn_last_kernel()
-    # oracle: autograd through the reference's op order on the CPU, routed through the forward's own argmax (near-ties
-    # between the per-edge and the node-level summation order may pick another maximiser; test_ext_forward_vs_oracle
-    # bounds that gap)
-    _, am = ops.mpconv_forward_raw(xd.detach(), idx.to(dev).expand(B, -1, -1), ed.detach().expand(B, -1, -1, -1), Wd.detach(),
-                                   bd.detach(), 64, 16, ext, _hip.AGG_MAX, want_argmax=True)
     xo = x.permute(0, 3, 1, 2).clone().requires_grad_(True)
     eo = et.clone().requires_grad_(True)
     Wo, bo = W.clone().requires_grad_(True), bias.clone().requires_grad_(True)
-    e_all = O.mp_conv({'filters': Wo}, '', xo, idx.expand(B, -1, -1).contiguous(), eo.expand(B, -1, -1, -1),
-                      nou=64, net=16, extension=ext, aggregator=None, relu=False)
-    ref = e_all.gather(3, am.cpu().long()) + bo.reshape(1, 64, 1, 1)
+    if agg == 'max':
+        # oracle: autograd through the reference's op order on the CPU, routed through the forward's own argmax (near-ties
+        # between the per-edge and the node-level summation order may pick another maximiser; test_ext_forward_vs_oracle
+        # bounds that gap)
+        _, am = ops.mpconv_forward_raw(xd.detach(), idx.to(dev).expand(B, -1, -1), ed.detach().expand(B, -1, -1, -1), Wd.detach(),
+                                       bd.detach(), nou, 16, ext, code, want_argmax=True)
+        e_all = O.mp_conv({'filters': Wo}, '', xo, idx.expand(B, -1, -1).contiguous(), eo.expand(B, -1, -1, -1),
+                          nou=nou, net=16, extension=ext, aggregator=None, relu=False)
+        ref = e_all.gather(3, am.cpu().long()) + bo.reshape(1, nou, 1, 1)
+    else:
+        ref = O.mp_conv({'filters': Wo, 'bias': bo}, '', xo, idx.expand(B, -1, -1).contiguous(), eo.expand(B, -1, -1, -1),
+                        nou=nou, net=16, extension=ext, aggregator=agg, relu=False)
     (ref * gy.permute(0, 3, 1, 2)).sum().backward()
     return (xo.grad, eo.grad, Wo.grad, bo.grad), (xd.grad.cpu(), ed.grad.cpu(), Wd.grad.cpu(), bd.grad.cpu())
 
@@ -165,4 +171,21 @@ def test_ext_backward_without_edge_type_gradient(dev):
         assert 'mpconv_bwd_ext' in _hip.lib().fgnn_last_kernel().decode()
         res.append((xd.grad, Wd.grad, bd.grad))
     for a, b in zip(*res):
+        assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize('nou,agg', [(2, 'softmax'), (64, 'softmax'), (6, 'max'), (8, 'max'), (2, 'max')])
+@pytest.mark.parametrize('shape', [(60, 9), (31, 9), (60, 2)], ids=['60x9', '31x9', '60x2'])
+def test_ext_backward_narrow_and_softmax(nou, agg, shape, dev):
+    """The operator that closes factor_mpnn (64 -> 2 channels, softmax aggregator, factor_mpnn.py:57-61) and other narrow /
+    log-sum-exp calls take the same atomic-free kernel: gradients against autograd through the oracle, and the same bits
+    on a second run."""
+    N, k = shape
+    ref, got = _grads_vs_oracle(N, k, 50, 2, dev, seed=nou, nou=nou, agg=agg)
+    for name, r, g in zip(('gx', 'getype', 'gfilters', 'gbias'), ref, got):
+        assert r.shape == g.shape, (name, r.shape, g.shape)
+        err = float((r - g).abs().max() / r.abs().max().clamp_min(1e-20))
+        assert err <= 2e-4, (name, err)
+    _, again = _grads_vs_oracle(N, k, 50, 2, dev, seed=nou, nou=nou, agg=agg)
+    for a, b in zip(got, again):
         assert torch.equal(a, b)
