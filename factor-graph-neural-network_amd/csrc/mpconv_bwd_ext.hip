@@ -50,15 +50,24 @@ struct BxParams {
     float* get_ws;           // [grid][16][N][k] edge-type gradient slabs, or null
     int B, N, k, ext, nou, ncols, npass, wvec;      // wvec: filter rows are 16-byte aligned (float4 loads)
     long long x_sb, y_sb, idx_sm, idx_sk, et_se, et_sm, et_sk;
-    int off_xs, off_ps, off_et, off_get, off_idx, off_csr, off_gz, off_am, off_w;
+    int off_xs, off_ps, off_dp, off_et, off_get, off_idx, off_csr, off_e16, off_gz, off_am, off_w;      // off_dp == off_ps: dP overwrites P
     long long slab_len, get_len;
+    long long* prof;         // FGNN_PROF (builds with -DFGNN_ENABLE_PROF only): phase timeline of one stage
+    int dbg;                 // prof builds: FGNN_EXT_DBG bits switch parts of phase B off (timing experiments)
 };
 
 extern __shared__ __attribute__((aligned(16))) unsigned char bx_lds[];
 
+#ifdef FGNN_ENABLE_PROF
+#define BX_STAMP(slot) do { if (p.prof && blockIdx.x == 0 && lane == 0 && pp == 1 && s == (ns > 1 ? 1 : 0)) p.prof[wave * 8 + (slot)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define BX_STAMP(slot) do { } while (0)
+#endif
+
 __device__ __forceinline__ int bx_krow(int kk, int lk) { return 4 * lk + (kk & 3) + 16 * (kk >> 2); }
 
-template <int AGG>
+// NARROW: fewer than 64 output channels (runtime column counts, guarded loads); WVEC: filter rows 16-byte aligned.
+template <int AGG, bool NARROW, bool WVEC>
 __global__ __launch_bounds__(BX_THREADS, 2) void mpconv_bwd_ext_kernel(const BxParams p) {
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
@@ -69,7 +78,10 @@ __global__ __launch_bounds__(BX_THREADS, 2) void mpconv_bwd_ext_kernel(const BxP
     const bool diff = p.ext == FGNN_EXT_DIFF;
 
     float* xs = reinterpret_cast<float*>(bx_lds + p.off_xs);          // [64][XS]
-    float* ps = reinterpret_cast<float*>(bx_lds + p.off_ps);          // [64][PS]: P, then dP
+    float* ps = reinterpret_cast<float*>(bx_lds + p.off_ps);          // [64][PS]: P
+    float* dps = reinterpret_cast<float*>(bx_lds + p.off_dp);         // [64][PS]: dP (its own image when LDS allows: B1 / dS / dT then run side by side)
+    const bool sep = p.off_dp != p.off_ps;
+    unsigned short* e16 = reinterpret_cast<unsigned short*>(bx_lds + p.off_e16);         // [64][16] first 16 in-edges (m << 4 | j) of a node, 0xffff = none
     float* et_s = reinterpret_cast<float*>(bx_lds + p.off_et);        // [mk][16]
     float* get_s = reinterpret_cast<float*>(bx_lds + p.off_get);      // [mk][16] batch-summed edge-type gradient
     int* idx_s = reinterpret_cast<int*>(bx_lds + p.off_idx);          // [mk]
@@ -78,7 +90,7 @@ __global__ __launch_bounds__(BX_THREADS, 2) void mpconv_bwd_ext_kernel(const BxP
     float* gz_s = reinterpret_cast<float*>(bx_lds + p.off_gz);        // [64][4]
     unsigned* am_s = reinterpret_cast<unsigned*>(bx_lds + p.off_am);  // [64] four argmax bytes
     float* w_s = reinterpret_cast<float*>(bx_lds + p.off_w);          // LSE: [mk][4] softmax weight of edge (m, j) per channel of the pass
-    const int nou = p.nou, ncols = p.ncols, npass = p.npass;
+    const int nou = NARROW ? p.nou : BX_NOU, ncols = NARROW ? p.ncols : BX_NCOLS, npass = NARROW ? p.npass : BX_NPASS;
 
     const int chunk = (p.B + gridDim.x - 1) / gridDim.x;
     const int b_begin = blockIdx.x * chunk;
@@ -118,7 +130,12 @@ __global__ __launch_bounds__(BX_THREADS, 2) void mpconv_bwd_ext_kernel(const BxP
     __syncthreads();
     if (tid < N) {                                                    // edges into node tid, ascending edge id: a fixed order
         int o = csr_off[tid];
-        for (int r = 0; r < mk; ++r) if (idx_s[r] == tid) csr_ent[o++] = (unsigned short)r;
+        for (int r = 0; r < mk; ++r) if (idx_s[r] == tid) csr_ent[o++] = (unsigned short)(((r / k) << 4) | (r % k));      // (m, j)
+    }
+    __syncthreads();
+    for (int f = tid; f < 64 * 16; f += BX_THREADS) {                 // padded copy: one 32-byte read gives a thread all of a node's in-edges
+        const int n = f >> 4, i = csr_off[n] + (f & 15);
+        e16[f] = (n < N && i < csr_off[n + 1]) ? csr_ent[i] : (unsigned short)0xffff;
     }
 
     // ---------------- per-thread roles ----------------
@@ -148,7 +165,7 @@ __global__ __launch_bounds__(BX_THREADS, 2) void mpconv_bwd_ext_kernel(const BxP
             amr = 0;
             if (tid < N) {
                 const int64_t o = (int64_t)b * p.y_sb + (int64_t)tid * nou + BX_PCH * pass;
-                if ((nou & 3) == 0) {
+                if (!NARROW) {
                     gzr = *reinterpret_cast<const uint4*>(p.gz + o);
                     if (AGG == FGNN_AGG_MAX) amr = *reinterpret_cast<const unsigned*>(p.am + o);
                 } else {                                              // narrow outputs (64 -> 2 closes factor_mpnn): guarded scalars
@@ -186,7 +203,7 @@ __global__ __launch_bounds__(BX_THREADS, 2) void mpconv_bwd_ext_kernel(const BxP
         float aW[16];                                                 // phase A B-operand: W[c = 16 lk + kk][column of this wave's slab]
         {
             const int col = 16 * (BX_PCH * pass + a_sl) + li;
-            const bool live = BX_PCH * pass + a_sl < nou;
+            const bool live = !NARROW || BX_PCH * pass + a_sl < nou;
 #pragma unroll
             for (int kk = 0; kk < 16; ++kk) {
                 const int c = 16 * lk + kk;
@@ -199,12 +216,12 @@ __global__ __launch_bounds__(BX_THREADS, 2) void mpconv_bwd_ext_kernel(const BxP
             const int c = 16 * c_ct + li;
             const float* wtop = p.W + (int64_t)c * ncols + 64 * pass + 32 * (lk & 1);
             const float* wbot = wtop + (int64_t)BX_NIN * ncols;
-            const bool live = 64 * pass + 32 * (lk & 1) < ncols;     // ncols is a multiple of 32 (nou even)
+            const bool live = !NARROW || 64 * pass + 32 * (lk & 1) < ncols;     // ncols is a multiple of 32 (nou even)
             const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 f32x4 t = zero, b = zero;
-                if (live && p.wvec) {
+                if (live && WVEC) {
                     t = *reinterpret_cast<const f32x4*>(wtop + 4 * q);
                     b = *reinterpret_cast<const f32x4*>(wbot + 4 * q);
                 } else if (live) {                                    // parameters living at odd offsets of a flat buffer
@@ -230,6 +247,7 @@ __global__ __launch_bounds__(BX_THREADS, 2) void mpconv_bwd_ext_kernel(const BxP
             if (s + 1 < ns) prefetch(b + 1, pass);
             else if (pp + 1 < npass) prefetch(b_begin, pass_next);
             __syncthreads();
+            BX_STAMP(0);
 
             // ================= phase A: P = x [Ws | Wt] =================
             {
@@ -254,7 +272,9 @@ __global__ __launch_bounds__(BX_THREADS, 2) void mpconv_bwd_ext_kernel(const BxP
                         for (int r = 0; r < 4; ++r) ps[((2 * np + h) * 16 + 4 * lk + r) * BX_PS + colbase] = acc[h][r];
                 }
             }
+            BX_STAMP(1);
             __syncthreads();
+            BX_STAMP(2);
 
             if (AGG == FGNN_AGG_LSE) {
                 // ================= phase B0 (softmax aggregator): w[m][j][oc] = exp(3 E_j - 3 agg) =================
@@ -289,33 +309,32 @@ __global__ __launch_bounds__(BX_THREADS, 2) void mpconv_bwd_ext_kernel(const BxP
                 __syncthreads();
             }
 
-            // ================= phase B1: get[m][j][e] += gz w_j (S + T)   (max: w = 1 at the argmax only) =================
-            if (want_get && tid < 256 && b1_m < N) {
-                const unsigned am4 = am_s[b1_m];
-                const f32x4 g4 = *reinterpret_cast<const f32x4*>(gz_s + b1_m * 4);
+            // ================= phase B: B1 get += gz w (S + T) and dS on waves 0-3, dT on waves 4-7 =================
+            auto phase_b1 = [&]() {                                   // get[m][j][e] += gz w_j (S + T)   (max: w = 1 at the argmax only)
+                if (want_get && b1_m < N) {
+                    const unsigned am4 = am_s[b1_m];
+                    const f32x4 g4 = *reinterpret_cast<const f32x4*>(gz_s + b1_m * 4);
 #pragma unroll
-                for (int oc = 0; oc < BX_PCH; ++oc) {
-                    const f32x4 sv = *reinterpret_cast<const f32x4*>(ps + b1_m * BX_PS + 16 * oc + 4 * b1_eq);
-                    if (AGG == FGNN_AGG_MAX) {
-                        const int j = min((int)((am4 >> (8 * oc)) & 255u), k - 1);
-                        const int r = b1_m * k + j;
-                        const f32x4 tv = *reinterpret_cast<const f32x4*>(ps + idx_s[r] * BX_PS + 64 + 16 * oc + 4 * b1_eq);
-                        f32x4* gp = reinterpret_cast<f32x4*>(get_s + r * BX_NET + 4 * b1_eq);
-                        *gp = *gp + g4[oc] * (sv + tv);
-                    } else {
-                        for (int j = 0; j < k; ++j) {
+                    for (int oc = 0; oc < BX_PCH; ++oc) {
+                        const f32x4 sv = *reinterpret_cast<const f32x4*>(ps + b1_m * BX_PS + 16 * oc + 4 * b1_eq);
+                        if (AGG == FGNN_AGG_MAX) {
+                            const int j = min((int)((am4 >> (8 * oc)) & 255u), k - 1);
                             const int r = b1_m * k + j;
                             const f32x4 tv = *reinterpret_cast<const f32x4*>(ps + idx_s[r] * BX_PS + 64 + 16 * oc + 4 * b1_eq);
                             f32x4* gp = reinterpret_cast<f32x4*>(get_s + r * BX_NET + 4 * b1_eq);
-                            *gp = *gp + (g4[oc] * w_s[r * 4 + oc]) * (sv + tv);
+                            *gp = *gp + g4[oc] * (sv + tv);
+                        } else {
+                            for (int j = 0; j < k; ++j) {
+                                const int r = b1_m * k + j;
+                                const f32x4 tv = *reinterpret_cast<const f32x4*>(ps + idx_s[r] * BX_PS + 64 + 16 * oc + 4 * b1_eq);
+                                f32x4* gp = reinterpret_cast<f32x4*>(get_s + r * BX_NET + 4 * b1_eq);
+                                *gp = *gp + (g4[oc] * w_s[r * 4 + oc]) * (sv + tv);
+                            }
                         }
                     }
                 }
-            }
-            __syncthreads();
-
-            // ================= phase B2: dS (waves 0-3), dT (waves 4-7) over P =================
-            if (tid < 256) {
+            };
+            auto phase_ds = [&]() {                                   // thread (m, oc): dS[m][oc][:] = gz sum_j w_j et[m][j][:]
                 f32x4 row[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) row[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -337,32 +356,63 @@ __global__ __launch_bounds__(BX_THREADS, 2) void mpconv_bwd_ext_kernel(const BxP
                     }
                     gb_acc += g;
                 }
-                float* dr = ps + b2_row * BX_PS + 16 * b2_oc;
+                float* dr = dps + b2_row * BX_PS + 16 * b2_oc;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(dr + 4 * q) = row[q];
-            } else {
+            };
+            auto phase_dt = [&]() {                                   // thread (n, oc): dT[n][oc][:] = sum over in-edges gz w et
                 f32x4 row[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) row[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 if (b2_row < N) {
-                    const int e1 = csr_off[b2_row + 1];
-                    for (int i = csr_off[b2_row]; i < e1; ++i) {
-                        const int r = csr_ent[i];
-                        const int m = r / k, j = r - m * k;
-                        if (AGG != FGNN_AGG_MAX || (int)((am_s[m] >> (8 * b2_oc)) & 255u) == j) {
+                    // all in-edge ids in two 16-byte reads, then every edge's loads at once: no branch on the argmax test
+                    // (a losing edge gets weight zero), no load waits for an earlier edge
+                    const uint4 ea = *reinterpret_cast<const uint4*>(e16 + b2_row * 16), eb = *reinterpret_cast<const uint4*>(e16 + b2_row * 16 + 8);
+                    const unsigned ew[8] = {ea.x, ea.y, ea.z, ea.w, eb.x, eb.y, eb.z, eb.w};
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const int ent = (ew[i >> 1] >> (16 * (i & 1))) & 0xffff;
+                        if (ent != 0xffff) {
+                            const int m = ent >> 4, j = ent & 15;
+                            const int r = m * k + j;
                             float g = gz_s[m * 4 + b2_oc];
-                            if (AGG != FGNN_AGG_MAX) g *= w_s[r * 4 + b2_oc];
+                            if (AGG == FGNN_AGG_MAX) g = (int)((am_s[m] >> (8 * b2_oc)) & 255u) == j ? g : 0.f;
+                            else g *= w_s[r * 4 + b2_oc];
                             const float* er = et_s + r * BX_NET;
 #pragma unroll
                             for (int q = 0; q < 4; ++q) row[q] = g * *reinterpret_cast<const f32x4*>(er + 4 * q) + row[q];
                         }
                     }
+                    const int e1 = csr_off[b2_row + 1];
+                    for (int i = csr_off[b2_row] + 16; i < e1; ++i) {  // in-degree above 16: the tail of the list
+                        const int ent = csr_ent[i];
+                        const int m = ent >> 4, j = ent & 15;
+                        const int r = m * k + j;
+                        float g = gz_s[m * 4 + b2_oc];
+                        if (AGG == FGNN_AGG_MAX) g = (int)((am_s[m] >> (8 * b2_oc)) & 255u) == j ? g : 0.f;
+                        else g *= w_s[r * 4 + b2_oc];
+                        const float* er = et_s + r * BX_NET;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) row[q] = g * *reinterpret_cast<const f32x4*>(er + 4 * q) + row[q];
+                    }
                 }
-                float* dr = ps + b2_row * BX_PS + 64 + 16 * b2_oc;
+                float* dr = dps + b2_row * BX_PS + 64 + 16 * b2_oc;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(dr + 4 * q) = row[q];
+            };
+            if (sep) {
+                if (tid < 256) { phase_b1(); phase_ds(); }
+                else phase_dt();
+            } else {                                                  // dP overwrites P: get must have read P first
+                if (tid < 256) phase_b1();
+                BX_STAMP(3);
+                __syncthreads();
+                if (tid < 256) phase_ds();
+                else phase_dt();
             }
+            BX_STAMP(4);
             __syncthreads();
+            BX_STAMP(5);
 
             // ================= phase C: gx += dP Wc (global RMW), gW += x^T dP =================
             {
@@ -389,7 +439,7 @@ __global__ __launch_bounds__(BX_THREADS, 2) void mpconv_bwd_ext_kernel(const BxP
 #pragma unroll
                 for (int h = 0; h < 2; ++h)
 #pragma unroll
-                    for (int kk = 0; kk < 16; ++kk) db[h][kk] = ps[bx_krow(kk, lk) * BX_PS + 64 * h + 16 * w_t + li];
+                    for (int kk = 0; kk < 16; ++kk) db[h][kk] = dps[bx_krow(kk, lk) * BX_PS + 64 * h + 16 * w_t + li];
 #pragma unroll
                 for (int kk = 0; kk < 16; ++kk)
 #pragma unroll
@@ -404,7 +454,7 @@ __global__ __launch_bounds__(BX_THREADS, 2) void mpconv_bwd_ext_kernel(const BxP
                     f32x4 dq[2][4];
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
-                        const float* dp = ps + ((2 * c_np + h) * 16 + li) * BX_PS + 32 * lk + 16 * half;
+                        const float* dp = dps + ((2 * c_np + h) * 16 + li) * BX_PS + 32 * lk + 16 * half;
 #pragma unroll
                         for (int q = 0; q < 4; ++q) dq[h][q] = *reinterpret_cast<const f32x4*>(dp + 4 * q);
                     }
@@ -421,6 +471,7 @@ __global__ __launch_bounds__(BX_THREADS, 2) void mpconv_bwd_ext_kernel(const BxP
                         const int node = (2 * c_np + h) * 16 + 4 * lk + r;
                         if (node < N) gxb[(int64_t)node * BX_NIN] = old[h][r] + accx[h][r];
                     }
+                BX_STAMP(6);
             }
         }
 
@@ -428,7 +479,7 @@ __global__ __launch_bounds__(BX_THREADS, 2) void mpconv_bwd_ext_kernel(const BxP
         {
             // D[i = c = 16 (2 cp + a) + 4 lk + r][j = column 16 t + li]; filters row c (top) and 64 + c (bottom)
             const int col = 64 * pass + 16 * w_t + li;
-            if (col < ncols) {
+            if (!NARROW || col < ncols) {
 #pragma unroll
                 for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -442,7 +493,7 @@ __global__ __launch_bounds__(BX_THREADS, 2) void mpconv_bwd_ext_kernel(const BxP
             __syncthreads();                                          // phase C is done with P: scratch for the bias reduction
             if (tid < 256) ps[tid] = gb_acc;                          // [m][oc]
             __syncthreads();
-            if (tid < BX_PCH && BX_PCH * pass + tid < nou) {
+            if (tid < BX_PCH && (!NARROW || BX_PCH * pass + tid < nou)) {
                 float sum = 0.f;
                 for (int m = 0; m < 64; ++m) sum += ps[m * 4 + tid];
                 slab[(int64_t)2 * BX_NIN * ncols + BX_PCH * pass + tid] = sum;
@@ -521,25 +572,56 @@ int fgnn_mpconv_backward_ext(const fgnn_mpconv_desc* d, const void* x, const int
     auto take = [&](int bytes) { const int o = off_b; off_b = fgnn_round_up(off_b + bytes, 16); return o; };
     p.off_xs = take(64 * BX_XS * 4);
     p.off_ps = take(64 * BX_PS * 4);
+    p.off_dp = p.off_ps;
     p.off_et = take(mk * BX_NET * 4);
     p.off_get = take(mk * BX_NET * 4);
     p.off_idx = take(mk * 4);
     p.off_csr = take(((mk * 2 + 15) & ~15) + 65 * 4);
+    p.off_e16 = take(64 * 16 * 2);
     p.off_gz = take(64 * 4 * 4);
     p.off_am = take(64 * 4);
     p.off_w = take(d->agg == FGNN_AGG_LSE ? mk * 4 * 4 : 16);
+    if (off_b + 64 * BX_PS * 4 <= 160 * 1024) p.off_dp = take(64 * BX_PS * 4);      // room for dP's own image
     const int lds = off_b;
     if (lds > 160 * 1024) {
         if (reduced) FGNN_FAIL(FGNN_EUNSUPPORTED, "mpconv ext backward: %d bytes of LDS", lds);
         return 0;
     }
-    void* fn = d->agg == FGNN_AGG_MAX ? (void*)mpconv_bwd_ext_kernel<FGNN_AGG_MAX> : (void*)mpconv_bwd_ext_kernel<FGNN_AGG_LSE>;
+    const bool narrow = d->nou != BX_NOU, wvec = p.wvec != 0;
+    void* fn;
+#define BX_PICK(A) (narrow ? (wvec ? (void*)mpconv_bwd_ext_kernel<A, true, true> : (void*)mpconv_bwd_ext_kernel<A, true, false>) \
+                           : (wvec ? (void*)mpconv_bwd_ext_kernel<A, false, true> : (void*)mpconv_bwd_ext_kernel<A, false, false>))
+    fn = d->agg == FGNN_AGG_MAX ? BX_PICK(FGNN_AGG_MAX) : BX_PICK(FGNN_AGG_LSE);
+#undef BX_PICK
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "hipFuncSetAttribute(%d B LDS): %s", lds, hipGetErrorString(e));
-    fgnn_note_kernel("mpconv_bwd_ext_kernel<%d>", d->agg);
+    fgnn_note_kernel("mpconv_bwd_ext_kernel<%d, %s, %s>", d->agg, narrow ? "true" : "false", wvec ? "true" : "false");
+    p.prof = nullptr;
+    p.dbg = 0;
+#ifdef FGNN_ENABLE_PROF
+    if (getenv("FGNN_EXT_DBG")) p.dbg = atoi(getenv("FGNN_EXT_DBG"));
+    static long long* prof_buf = nullptr;
+    if (getenv("FGNN_PROF")) {
+        if (!prof_buf) (void)hipMalloc(&prof_buf, 64 * 8);
+        (void)hipMemset(prof_buf, 0, 64 * 8);
+        p.prof = prof_buf;
+    }
+#endif
     void* args[] = {(void*)&p};
     e = hipLaunchKernel(fn, dim3(grid), dim3(BX_THREADS), args, lds, (hipStream_t)stream);
     if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "mpconv ext backward launch: %s", hipGetErrorString(e));
+#ifdef FGNN_ENABLE_PROF
+    if (p.prof) {              // tuning aid: one stage of workgroup 0 (shader clocks): A start, A end, B1 start, B1 end, B2 end, C start, C end
+        long long h[64];
+        (void)hipDeviceSynchronize();
+        (void)hipMemcpy(h, p.prof, sizeof(h), hipMemcpyDeviceToHost);
+        for (int w = 0; w < 8; ++w) {
+            fprintf(stderr, "[fgnn prof ext bwd] wave %d:", w);
+            for (int i = 0; i < 8; ++i) fprintf(stderr, " %lld", h[w * 8 + i] - h[0]);
+            fprintf(stderr, "\n");
+        }
+    }
+#endif
     fgnn_launch_slab_reduce(p.ws, grid, slab_len, nw, gfilters, gbias, (hipStream_t)stream);
     if (getype) {
         e = hipMemsetAsync(getype, 0, get_len * 4, (hipStream_t)stream);

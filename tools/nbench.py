@@ -28,3 +28,12 @@ for dt in (torch.bfloat16, torch.float32):
         def f_in(): y = inn(x); y.backward(gy)
         mb = x.numel() * x.element_size() / 1e6
         print('%s C=%3d N=%2d (%.0f MB): BN+act fwd+bwd mine %7.1f us  torch %7.1f us | IN+relu fwd+bwd %7.1f us' % (str(dt)[6:], C, N, mb, timeit(f_mine), timeit(f_ref), timeit(f_in)))
+
+# reference points for the streaming kernels above: a plain device copy and an elementwise op of the same tensors
+for C, N in [(64, 96), (128, 96)]:
+    x = torch.randn(4096, N, 1, C, device=dev).bfloat16()
+    y = torch.empty_like(x)
+    mb = x.numel() * 2 / 1e6
+    t_copy = timeit(lambda: y.copy_(x), 20)
+    t_relu = timeit(lambda: torch.relu(x), 20)
+    print('bf16 C=%3d N=%2d (%.0f MB): copy %6.1f us = %.2f TB/s | relu (new tensor) %6.1f us = %.2f TB/s' % (C, N, mb, t_copy, 2 * mb / t_copy, t_relu, 2 * mb / t_relu))
