@@ -330,8 +330,13 @@ def main_syn(args):
             avg_ms = r['ms'] / r['launches']
             tfs = (r['flops'] / r['launches']) / (avg_ms * 1e-3) / 1e12
             gbs = (r['bytes'] / r['launches']) / (avg_ms * 1e-3) / 1e9
+            try:       # HBM-side bytes per launch from the committed PMC passes (order-9 shape, batch 1024: profiles/r02/README.md)
+                traffic = json.load(open(os.path.join(ROOT, 'profiles', 'r02', 'pmc_traffic_syn.json')))['kernels'].get(sym, {}).get(
+                    'traffic_bytes_per_launch') if (args.workload == 'syn_hop' and B == 1024) else None
+            except (OSError, ValueError, KeyError):
+                traffic = None
             roofline = {'bound': 'mfma', 'achieved': round(tfs, 2), 'peak': F32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                        'frac': round(tfs / F32_MFMA_PEAK_TFLOPS, 4), 'traffic': None, 'kernel': sym,
+                        'frac': round(tfs / F32_MFMA_PEAK_TFLOPS, 4), 'traffic': traffic, 'kernel': sym,
                         'launches_per_step': r['launches'], 'avg_launch_us': round(avg_ms * 1e3, 2),
                         'algorithmic_bytes_per_launch': r['bytes'] // r['launches'],
                         'algorithmic_flops_per_launch': r['flops'] // r['launches'],
