@@ -365,8 +365,16 @@ def _unexpanded(etype):
     its gradient already summed over the batch.  The tensor the caller expanded when autograd can name it (same storage and
     strides), else the first row of the expanded view (autograd then pads that row's gradient with zeros before its own sum:
     still far cheaper than a per-sample gradient)."""
-    if etype.dim() != 4 or etype.shape[0] < 2 or etype.stride(0) != 0:
+    if etype.dim() != 4 or etype.shape[0] < 2:
         return None
+    if etype.stride(0) != 0:
+        # B materialised copies (`etype.repeat(bsize, 1, 1, 1)`, train_syn_hop_factor.py:291): one device comparison + host
+        # read per call (the tensor is new every iteration, so nothing can be remembered) — a few tens of microseconds against
+        # a backward that is 7x faster on shared edge weights.  Not during hipGraph capture (no host read possible).
+        if (not DEDUPE_GRAPHS or not etype.is_cuda or torch.cuda.is_current_stream_capturing()
+                or not bool((etype.detach() == etype.detach()[:1]).all().item())):
+            return None
+        return etype[:1]
     base = etype._base
     if (base is not None and base.dim() == 4 and base.shape[0] == 1 and base.shape[1:] == etype.shape[1:]
             and base.data_ptr() == etype.data_ptr() and base.stride()[1:] == etype.stride()[1:]

@@ -189,3 +189,32 @@ def test_ext_backward_narrow_and_softmax(nou, agg, shape, dev):
     _, again = _grads_vs_oracle(N, k, 50, 2, dev, seed=nou, nou=nou, agg=agg)
     for a, b in zip(got, again):
         assert torch.equal(a, b)
+
+
+def test_repeated_edge_weights_take_the_shared_kernels(dev):
+    """`etype.repeat(bsize, 1, 1, 1)` as the reference scripts pass it (train_syn_hop_factor.py:291): recognised as one table by
+    a content check, same kernels and the same gradient on the un-repeated tensor as with `expand`; genuinely different
+    per-sample edge weights keep the per-sample path."""
+    from fgnn_amd import _hip, ops
+    N, k, B = 60, 9, 48
+    x, idx, et, W, bias, g = _problem(N, k, B, seed=21)
+    gy = torch.randn(B, N, 1, 64, generator=g).to(dev).permute(0, 3, 1, 2)
+    grads = []
+    for how in ('expand', 'repeat'):
+        xd = x.to(dev).permute(0, 3, 1, 2).requires_grad_(True)
+        ed = et.to(dev).requires_grad_(True)
+        Wd, bd = W.to(dev).requires_grad_(True), bias.to(dev).requires_grad_(True)
+        e_in = ed.expand(B, -1, -1, -1) if how == 'expand' else ed.repeat(B, 1, 1, 1)
+        i_in = idx.to(dev).expand(B, -1, -1) if how == 'expand' else idx.to(dev).repeat(B, 1, 1)
+        z = ops.mpconv(xd, i_in, e_in, Wd, bd, 64, 16, 2, _hip.AGG_MAX)
+        assert 'mpconv_fwd_extp' in _hip.lib().fgnn_last_kernel().decode(), (how, _hip.lib().fgnn_last_kernel())
+        (z * gy).sum().backward()
+        assert 'mpconv_bwd_ext' in _hip.lib().fgnn_last_kernel().decode(), (how, _hip.lib().fgnn_last_kernel())
+        grads.append((xd.grad, ed.grad, Wd.grad, bd.grad))
+    for a, b in zip(*grads):
+        assert torch.equal(a, b)
+    et_b = torch.randn(B, 16, N, k, generator=g).to(dev).requires_grad_(True)          # per-sample edge weights
+    z = ops.mpconv(x.to(dev).permute(0, 3, 1, 2), idx.to(dev).expand(B, -1, -1), et_b, W.to(dev), bias.to(dev), 64, 16, 2, _hip.AGG_MAX)
+    assert 'mpconv_fwd_ext_kernel' in _hip.lib().fgnn_last_kernel().decode()
+    (z * gy).sum().backward()
+    assert et_b.grad.shape == et_b.shape and 'mpconv_bwd_ext' not in _hip.lib().fgnn_last_kernel().decode()
