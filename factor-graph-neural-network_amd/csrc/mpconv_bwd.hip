@@ -17,6 +17,13 @@
 //       dW    += MFMA(x^T, dP)          -> f32 accumulators in registers across the chunk
 //     flush dW tile with one atomicAdd per element per chunk
 // so no gradient tensor the size of the edge set is ever written to HBM.
+//
+// SCOPE (round 2): this file is the fallback for shapes no specialised kernel takes — odd channel counts, per-sample graphs
+// with an extension, per-sample edge-type gradients, the `mean` aggregator.  Every call of the reference's models goes
+// elsewhere: the LDPC family to mpconv_bwd_sg / _b16 / _res / _hyper.hip, the synthetic-PGM family (16 edge types,
+// DIFF / NEIGHBOR, max and softmax, 2..64 output channels) to mpconv_bwd_ext.hip — all of them free of atomics.  The float
+// atomics below (LDS scatter of dP, global flush of dW / dbias) make THIS kernel's gradients order-dependent in the last
+// bits; the reproducibility tests cover the specialised kernels only.
 #include "fgnn_common.h"
 #include <stdlib.h>
 

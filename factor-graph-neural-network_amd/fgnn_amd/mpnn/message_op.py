@@ -42,10 +42,18 @@ _EXT_CODE = {mp_conv_type.NO_EXTENSION: _hip.EXT_NONE,
 
 
 def fold_batchnorm(bn):
-    """Eval-mode BatchNorm as a per-channel affine (scale, shift)."""
-    scale = bn.weight.detach() * torch.rsqrt(bn.running_var + bn.eps)
-    shift = bn.bias.detach() - bn.running_mean * scale
-    return scale, shift
+    """Eval-mode BatchNorm as a per-channel affine (scale, shift); recomputed only when a parameter / buffer changed (the
+    same key and storage-preserving refresh as BatchNormAct2d._folded: an inference hipGraph keeps its addresses)."""
+    from .pointwise import refresh_in_place, state_epoch
+    key = (bn.weight._version, bn.bias._version, bn.running_mean._version, bn.running_var._version, bn.weight.device,
+           bn.weight.dtype, state_epoch())
+    if getattr(bn, '_fgnn_fold_key', None) != key:
+        with torch.no_grad():
+            scale = bn.weight.detach() * torch.rsqrt(bn.running_var + bn.eps)
+            shift = bn.bias.detach() - bn.running_mean * scale
+        bn._fgnn_fold = refresh_in_place(getattr(bn, '_fgnn_fold', None), (scale, shift))
+        bn._fgnn_fold_key = key
+    return bn._fgnn_fold
 
 
 class mp_conv_v2(base_mp_nn):

@@ -14,8 +14,23 @@ names = [e[2] for e in ev]
 adam = [i for i, nm in enumerate(names) if 'flat_adam' in nm]
 if len(adam) >= steps + 1:
     lo, hi = adam[-steps - 1] + 1, adam[-1] + 1
-else:
+else:                                       # inference: find the periodic stretch (the graph replays) by its period
     lo, hi = 0, n
+    found = False
+    for e in range(n, max(n - 6000, 0), -1):
+        for per in range(40, 4000):
+            if e - 3 * per < 0:
+                break
+            if names[e - per:e] == names[e - 2 * per:e - per] == names[e - 3 * per:e - 2 * per]:
+                k = 3
+                while e - (k + 1) * per >= 0 and names[e - (k + 1) * per:e - k * per] == names[e - per:e]:
+                    k += 1
+                steps = min(steps, k)
+                lo, hi = e - steps * per, e
+                found = True
+                break
+        if found:
+            break
 seg = ev[lo:hi]
 t0, t1 = seg[0][0], max(e[1] for e in seg)
 span = t1 - t0
@@ -53,3 +68,10 @@ for g, at in gaps[:12]:
     before = ends.get(at, '?')
     after = starts.get(at + g, '?')
     print('  %7.1f us after %-60s before %s' % (g / 1e3, before[:60], after[:60]))
+if len(sys.argv) > 3:                       # per-step launch counts by kernel name
+    cnt = {}
+    for s, e, nm in seg:
+        c = cnt.setdefault(nm, [0, 0]); c[0] += 1; c[1] += e - s
+    print('launches per step by kernel:')
+    for nm, (c, d) in sorted(cnt.items(), key=lambda kv: -kv[1][1]):
+        print('  %6.1f x %8.1f us  %s' % (c / steps, d / c / 1e3, nm[:110]))
