@@ -18,7 +18,7 @@
 
 #define LF_THREADS 512
 #define LF_WAVES 8
-#define LF_MAXGRID 512   // <= BN_MAXPART of bnact.hip: the statistics partials reuse its workspace layout (256 / 1024 measured level / slower)
+#define LF_MAXGRID 256   // one workgroup per CU (cold tensors, 393 k rows 64->64: 23.9 us; 512: 25.4; 768: 28.3; 1024: 25.6); <= BN_MAXPART of bnact.hip: the statistics partials reuse its workspace layout
 
 typedef __bf16 lf_bf16x8 __attribute__((ext_vector_type(8)));
 
@@ -70,48 +70,69 @@ __global__ __launch_bounds__(LF_THREADS) void linear_fwd_b16_kernel(const LfPara
     __syncthreads();
 
     const int o_base = cg * OTW * 16;                     // this wave's first output channel
+    // Operand permutations that make every lane's global traffic contiguous (OTW == 4):
+    //  * output tile ot, MFMA row i  <->  channel 16 (i >> 2) + 4 ot + (i & 3): the D fragments of the four tiles then give lane
+    //    (row li, lk) the 16 CONSECUTIVE channels 16 lk .. 16 lk + 15 of its row: two 16-byte stores instead of four 8-byte ones;
+    //  * k-step ks, k-group lk  <->  input channels 8 KS lk + 8 ks .. + 7: a lane's KS loads are one contiguous 16 KS-byte run.
+    static_assert(OTW == 4, "the channel permutation assumes 64 output channels per wave");
+    auto orow = [&](int ot) { return 16 * (li >> 2) + 4 * ot + (li & 3); };
+    auto kcol = [&](int ks) { return 8 * KS * lk + 8 * ks; };
     lf_bf16x8 aW[WREG ? OTW : 1][WREG ? KS : 1];
     if constexpr (WREG) {
 #pragma unroll
         for (int ot = 0; ot < OTW; ++ot)
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks)
-                aW[ot][ks] = __builtin_bit_cast(lf_bf16x8, *reinterpret_cast<const uint4*>(Wl + (o_base + ot * 16 + li) * WS + 32 * ks + 8 * lk));
+                aW[ot][ks] = __builtin_bit_cast(lf_bf16x8, *reinterpret_cast<const uint4*>(Wl + (o_base + orow(ot)) * WS + kcol(ks)));
     }
     f32x4 bv[OTW];
 #pragma unroll
-    for (int ot = 0; ot < OTW; ++ot) bv[ot] = *reinterpret_cast<const f32x4*>(bl + o_base + ot * 16 + 4 * lk);
+    for (int ot = 0; ot < OTW; ++ot) bv[ot] = *reinterpret_cast<const f32x4*>(bl + o_base + 16 * lk + 4 * ot);
     f32x4 s0[OTW], s1[OTW];
 #pragma unroll
     for (int ot = 0; ot < OTW; ++ot) { s0[ot] = (f32x4){0.f, 0.f, 0.f, 0.f}; s1[ot] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
 
     const int ntile = (R + 15) / 16;
     const int stride = gridDim.x * nrg;
+    auto load_tile = [&](int tile, uint4 (&bx)[KS]) {
+        const int row = tile * 16 + li;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+            bx[ks] = (tile < ntile && row < R) ? *reinterpret_cast<const uint4*>(p.x + (int64_t)row * CIN + kcol(ks)) : make_uint4(0, 0, 0, 0);
+    };
+    uint4 nx[KS];
+    load_tile(blockIdx.x * nrg + rg, nx);
     for (int tile = blockIdx.x * nrg + rg; tile < ntile; tile += stride) {
         const int row = tile * 16 + li;
         const bool ok = row < R;
         uint4 bx[KS];
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks)
-            bx[ks] = ok ? *reinterpret_cast<const uint4*>(p.x + (int64_t)row * CIN + 32 * ks + 8 * lk) : make_uint4(0, 0, 0, 0);
+        for (int ks = 0; ks < KS; ++ks) bx[ks] = nx[ks];
+        load_tile(tile + stride, nx);                     // the next tile's rows are in flight while this one is multiplied and stored
+        f32x4 acc[OTW];
 #pragma unroll
         for (int ot = 0; ot < OTW; ++ot) {
-            f32x4 acc = bv[ot];
+            acc[ot] = bv[ot];
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 lf_bf16x8 a;
                 if constexpr (WREG) a = aW[ot][ks];
-                else a = __builtin_bit_cast(lf_bf16x8, *reinterpret_cast<const uint4*>(Wl + (o_base + ot * 16 + li) * WS + 32 * ks + 8 * lk));
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, __builtin_bit_cast(lf_bf16x8, bx[ks]), acc, 0, 0, 0);
+                else a = __builtin_bit_cast(lf_bf16x8, *reinterpret_cast<const uint4*>(Wl + (o_base + orow(ot)) * WS + kcol(ks)));
+                acc[ot] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, __builtin_bit_cast(lf_bf16x8, bx[ks]), acc[ot], 0, 0, 0);
             }
-            // D[i = o 4lk+r][j = row]: four consecutive output channels of this lane's row
-            if (ok) {
-                *reinterpret_cast<uint2*>(p.y + (int64_t)row * Cout + o_base + ot * 16 + 4 * lk) =
-                    make_uint2(lf_pack2(acc[0], acc[1]), lf_pack2(acc[2], acc[3]));
-                if (p.part) {
+        }
+        // D[i = 4 lk + r][j = row] of tile ot = channel o_base + 16 lk + 4 ot + r of this lane's row
+        if (ok) {
+            uint16_t* yp = p.y + (int64_t)row * Cout + o_base + 16 * lk;
+            *reinterpret_cast<uint4*>(yp) = make_uint4(lf_pack2(acc[0][0], acc[0][1]), lf_pack2(acc[0][2], acc[0][3]),
+                                                       lf_pack2(acc[1][0], acc[1][1]), lf_pack2(acc[1][2], acc[1][3]));
+            *reinterpret_cast<uint4*>(yp + 8) = make_uint4(lf_pack2(acc[2][0], acc[2][1]), lf_pack2(acc[2][2], acc[2][3]),
+                                                           lf_pack2(acc[3][0], acc[3][1]), lf_pack2(acc[3][2], acc[3][3]));
+            if (p.part) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) { s0[ot][r] += acc[r]; s1[ot][r] = fmaf(acc[r], acc[r], s1[ot][r]); }
-                }
+                for (int ot = 0; ot < OTW; ++ot)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { s0[ot][r] += acc[ot][r]; s1[ot][r] = fmaf(acc[ot][r], acc[ot][r], s1[ot][r]); }
             }
         }
     }
@@ -124,7 +145,7 @@ __global__ __launch_bounds__(LF_THREADS) void linear_fwd_b16_kernel(const LfPara
 #pragma unroll
                 for (int m = 1; m < 16; m <<= 1) { a += __shfl_xor(a, m); b += __shfl_xor(b, m); }   // the 16 rows of a tile
                 if (li == 0) {
-                    const int o = o_base + ot * 16 + 4 * lk + r;
+                    const int o = o_base + 16 * lk + 4 * ot + r;
                     red[(rg * 2) * Cout + o] = a;
                     red[(rg * 2 + 1) * Cout + o] = b;
                 }
@@ -166,7 +187,7 @@ extern "C" int fgnn_linear_forward(const void* x, const float* W, const float* b
                                    int Cout, float* stats_partials, int w_transposed, fgnn_stream_t stream) {
     if (!x || !W || !y) FGNN_FAIL(FGNN_EINVAL, "linear_forward: null pointer");
     int CG, grid;
-    if (lf_plan(R, Cin, Cout, &CG, &grid) || ((uintptr_t)x & 15) || ((uintptr_t)y & 7) || ((uintptr_t)W & 7))
+    if (lf_plan(R, Cin, Cout, &CG, &grid) || ((uintptr_t)x & 15) || ((uintptr_t)y & 15) || ((uintptr_t)W & 7))
         FGNN_FAIL(FGNN_EUNSUPPORTED, "linear_forward: Cin=%d Cout=%d outside the bf16 streaming kernel's family", Cin, Cout);
     LfParams p;
     p.x = (const uint16_t*)x; p.W = W; p.bias = bias; p.y = (uint16_t*)y; p.part = stats_partials;

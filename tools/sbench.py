@@ -98,3 +98,38 @@ for C, N in [(64, 96), (128, 96)]:
     t_copy, t_app, t_bwd = graph_time(f_copy, 48), graph_time(f_app, 48), graph_time(f_bwd, 48)
     print('bf16 R=%d C=%3d (%.0f MB): copy %5.1f us (%.2f TB/s) | bn_apply %5.1f us (%.2f TB/s) | bn_backward %5.1f us (%.2f TB/s of 5T)'
           % (R, C, mb, t_copy, 2 * mb / t_copy, t_app, 2 * mb / t_app, t_bwd, 5 * mb / t_bwd))
+
+# node-wise maps (1x1 convolutions) and their weight gradients, cold: the other two streaming families of the step
+print('node-wise maps, cold (24 rotating tensor pairs):')
+for Cin, Cout, N in [(64, 64, 96), (64, 64, 48), (128, 64, 96), (64, 128, 96)]:
+    R = 4096 * N
+    K = 24
+    xs = [torch.randn(R, Cin, device=dev).bfloat16() for _ in range(K)]
+    ys = [torch.empty(R, Cout, device=dev, dtype=torch.bfloat16) for _ in range(K)]
+    W = torch.randn(Cout, Cin, device=dev) * 0.1
+    bias = torch.randn(Cout, device=dev)
+    npart = int(L.fgnn_linear_forward_partials(R, Cin, Cout))
+    parts = torch.empty(max(npart, 1) * 2 * Cout, device=dev)
+    gW, gb = torch.zeros(Cout, Cin, device=dev), torch.zeros(Cout, device=dev)
+    wsb = int(L.fgnn_linear_wgrad_workspace_bytes(R, Cin, Cout))
+    ws = torch.empty(max(wsb, 4) // 4, device=dev)
+    state = {'i': 0}
+
+    def nxt():
+        state['i'] = (state['i'] + 1) % K
+        return state['i']
+
+    def f_fwd(stats):
+        i = nxt()
+        _hip.check(L.fgnn_linear_forward(_hip._ptr(xs[i]), _hip._ptr(W), _hip._ptr(bias), _hip._ptr(ys[i]), R, Cin, Cout,
+                                         _hip._ptr(parts) if stats else None, 0, _hip.stream_ptr()))
+
+    def f_wg():
+        i = nxt()
+        _hip.check(L.fgnn_linear_wgrad(_hip._ptr(xs[i]), _hip._ptr(ys[(i + 5) % K]), R, Cin, Cout, 1, _hip._ptr(gW), _hip._ptr(gb),
+                                       _hip._ptr(ws), wsb, _hip.stream_ptr()))
+
+    mb_in, mb_out = R * Cin * 2 / 1e6, R * Cout * 2 / 1e6
+    t0, t1, t2 = graph_time(lambda: f_fwd(False), 48), graph_time(lambda: f_fwd(True), 48), graph_time(f_wg, 48)
+    print('bf16 R=%d %3d->%3d: forward %5.1f us (%.2f TB/s) | with statistics epilogue %5.1f us (%.2f TB/s) | weight gradient %5.1f us '
+          '(%.2f TB/s)' % (R, Cin, Cout, t0, (mb_in + mb_out) / t0, t1, (mb_in + mb_out) / t1, t2, (mb_in + mb_out) / t2))
