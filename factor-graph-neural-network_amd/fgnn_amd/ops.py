@@ -95,7 +95,9 @@ def _alloc_out(x, nou, M, dtype=None):
     B = x.shape[0]
     dtype = x.dtype if dtype is None else dtype
     if _channels_last_like(x):
-        return torch.empty((B, M, 1, nou), device=x.device, dtype=dtype).permute(0, 3, 1, 2)
+        # channel-fastest storage as a tensor of its OWN (not a permuted view: an in-place activation on the operator's output
+        # would otherwise be an in-place write to a view made inside the autograd Function, which autograd refuses)
+        return torch.empty_strided((B, nou, M, 1), (M * nou, 1, nou, nou), device=x.device, dtype=dtype)
     return torch.empty((B, nou, M, 1), device=x.device, dtype=dtype)
 
 
