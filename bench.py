@@ -342,6 +342,13 @@ def main_syn(args):
                         'algorithmic_flops_per_launch': r['flops'] // r['launches'],
                         'hbm': {'bound': 'hbm', 'achieved': round(gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                                 'frac': round(gbs / HBM_PEAK_GBS, 4), 'traffic': None}}
+            if 'fwd_extp_kernel' in sym and 'true>' in sym:
+                # this kernel runs its projections as a three-term bf16 split on the bf16 matrix cores (6 MFMAs per f32 product
+                # term set, f32-level accuracy: csrc/mpconv_fwd_ext.hip): `achieved` counts the ALGORITHMIC f32 FLOPs against the
+                # f32 matrix-core peak, the executed bf16 FLOPs (6x the projection) against the bf16 peak are given beside it
+                roofline['arithmetic'] = 'f32 result from a 3-term bf16 operand split, 6 bf16 MFMAs per product, f32 accumulation'
+                roofline['executed_bf16'] = {'achieved': round(6.0 * tfs, 1), 'peak': BF16_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                                             'frac': round(6.0 * tfs / BF16_MFMA_PEAK_TFLOPS, 4)}
     fence()
     if rank == 0:
         msgs = syn_messages_per_graph(model, [pw_idx, hi_idx])

@@ -225,15 +225,44 @@ __global__ __launch_bounds__(FX_THREADS, 2) void mpconv_fwd_ext_kernel(const FxP
 
 __device__ __forceinline__ int fp_sw(int row) { return (row ^ (row >> 2)) & 3; }
 
-template <int AGG>
+// single f32 VALU ops the compiler's SLP vectoriser cannot pair into v_pk_* instructions
+__device__ __forceinline__ float fx_add(float a, float b) { float r; asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float fx_fma(float a, float b, float c) { float r; asm("v_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+
+// ---- three-term bf16 split of f32 operands (SPLIT variant) ----
+// x = h + m + l exactly (three 8-bit mantissa pieces, same exponent range as f32).  A product x w is then the six bf16 MFMA
+// terms  h h' + (h m' + m h') + (h l' + l h' + m m')  accumulated in f32: what is dropped (m l', l m', l l') is below 2^-24
+// of |x w|, the size of one f32 rounding.  On the bf16 matrix cores six MFMAs cost 6 / 16 of one f32 MFMA, and — unlike the
+// f32 MFMA — they leave the SIMD's VALU to the gather running beside them (tools/ubench/mfma_f32_partner.hip).
+#define FQ_XS 72             // split x image row stride in bf16 elements (64 + 8: rows 144 bytes apart, conflict-free 16-byte reads)
+typedef __bf16 fq_bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ unsigned fq_pack2(float a, float b) {
+    typedef __bf16 v2 __attribute__((ext_vector_type(2)));
+    const v2 h = {(__bf16)a, (__bf16)b};
+    return __builtin_bit_cast(unsigned, h);
+}
+// (a, b) -> packed bf16 pairs of the three terms
+__device__ __forceinline__ float fx_sub(float a, float b) { float r; asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ void fq_split2(float a, float b, unsigned& h, unsigned& m, unsigned& l) {
+    // single (not packed) subtractions: v_pk_add_f32 does not issue beside the producers' bf16 MFMA stream
+    h = fq_pack2(a, b);
+    const float ra = fx_sub(a, __uint_as_float(h << 16)), rb = fx_sub(b, __uint_as_float(h & 0xffff0000u));
+    m = fq_pack2(ra, rb);
+    l = fq_pack2(fx_sub(ra, __uint_as_float(m << 16)), fx_sub(rb, __uint_as_float(m & 0xffff0000u)));
+}
+
+template <int AGG, bool SPLIT>
 __global__ __launch_bounds__(FX_THREADS, 2) void mpconv_fwd_extp_kernel(const FxParams p) {
+    constexpr int NTHR = FX_THREADS, NCT = NTHR - 256, XQN = 1024 / NCT;      // consumer threads, x chunks per consumer thread
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int li = lane & 15, lk = lane >> 4;
     const int N = p.N, k = p.k, mk = N * k;
     const int ntile = (N + 15) >> 4;
 
-    float* xs = reinterpret_cast<float*>(fx_lds + p.off_xs);      // [2][64][XS]
+    float* xs = reinterpret_cast<float*>(fx_lds + p.off_xs);      // [2][64][XS] f32 x image (exact-f32 variant)
+    uint16_t* xq = reinterpret_cast<uint16_t*>(fx_lds + p.off_xs);   // SPLIT: [2][3 terms][64][FQ_XS] bf16
+    constexpr int XQ_TERM = 64 * FQ_XS, XQ_BUF = 3 * XQ_TERM;
     float* ps = reinterpret_cast<float*>(fx_lds + p.off_ps);      // [2][64][128], block-swizzled rows
     float* et_s = reinterpret_cast<float*>(fx_lds + p.off_et);    // [mk][16]
     int* idx_s = reinterpret_cast<int*>(fx_lds + p.off_idx);      // [mk]: (row * 128 + 64) | swizzle of the neighbour's row
@@ -251,29 +280,44 @@ __global__ __launch_bounds__(FX_THREADS, 2) void mpconv_fwd_extp_kernel(const Fx
         par_s[64 + tid] = p.pscale ? p.pscale[tid] : 1.f;
         par_s[128 + tid] = p.pscale ? p.pshift[tid] : 0.f;
     }
-    for (int f = tid; f < 2 * 64 * FX_XS; f += FX_THREADS) xs[f] = 0.f;
-    for (int r = tid; r < mk; r += FX_THREADS) {
+    if (SPLIT) { for (int f = tid; f < 2 * XQ_BUF / 2; f += NTHR) reinterpret_cast<unsigned*>(xq)[f] = 0u; }
+    else { for (int f = tid; f < 2 * 64 * FX_XS; f += NTHR) xs[f] = 0.f; }
+    for (int r = tid; r < mk; r += NTHR) {
         const int m = r / k, j = r - m * k;
         long long v = p.idx[(int64_t)m * p.idx_sm + (int64_t)j * p.idx_sk];
         const int n = (int)(v < 0 ? 0 : (v >= N ? N - 1 : v));
         idx_s[r] = (n * FP_PROW + 64) | fp_sw(n);
     }
-    for (int f = tid; f < mk * FX_NET; f += FX_THREADS) {
+    for (int f = tid; f < mk * FX_NET; f += NTHR) {
         const int e = f / mk, r = f - e * mk;
         const int m = r / k, j = r - m * k;
         et_s[r * FX_NET + e] = p.et[(int64_t)e * p.et_se + (int64_t)m * p.et_sm + (int64_t)j * p.et_sk];
     }
     __syncthreads();
+    // chunk f of a sample's x (row f >> 4, four channels from 4 (f & 15)) into x image `buf`
+    auto put_x = [&](int buf, int f, const uint4& v) {
+        if (SPLIT) {
+            unsigned h0, m0, l0, h1, m1, l1;
+            fq_split2(__uint_as_float(v.x), __uint_as_float(v.y), h0, m0, l0);
+            fq_split2(__uint_as_float(v.z), __uint_as_float(v.w), h1, m1, l1);
+            uint16_t* q = xq + buf * XQ_BUF + (f >> 4) * FQ_XS + (f & 15) * 4;
+            *reinterpret_cast<uint2*>(q) = make_uint2(h0, h1);
+            *reinterpret_cast<uint2*>(q + XQ_TERM) = make_uint2(m0, m1);
+            *reinterpret_cast<uint2*>(q + 2 * XQ_TERM) = make_uint2(l0, l1);
+        } else {
+            *reinterpret_cast<uint4*>(xs + buf * 64 * FX_XS + (f >> 4) * FX_XS + (f & 15) * 4) = v;
+        }
+    };
     // x of the first stage (all threads: 1024 chunks of 16 B)
     {
         const uint4* xb = reinterpret_cast<const uint4*>(p.x + (int64_t)b_begin * p.x_sb);
-        for (int f = tid; f < N * 16; f += FX_THREADS)
-            *reinterpret_cast<uint4*>(xs + (f >> 4) * FX_XS + (f & 15) * 4) = xb[f];
+        for (int f = tid; f < N * 16; f += NTHR) put_x(0, f, xb[f]);
     }
     __syncthreads();
 
     if (wave < 4) {
         // =========================== producers ===========================
+      if constexpr (!SPLIT) {
         // Filter rows of the NEXT pass travel as raw loads (rT = W_top, rB = W_bot columns) while this pass computes; they
         // are combined into the S / T operands only when the pass starts, so no stage waits on the L2 round trip.
         float aS[16], aT[16], rT[16], rB[16];
@@ -351,6 +395,83 @@ __global__ __launch_bounds__(FX_THREADS, 2) void mpconv_fwd_extp_kernel(const Fx
             FP_STAMP(1);
             __syncthreads();
         }
+      } else {
+        // ---- SPLIT: three-term bf16 operands on v_mfma_f32_16x16x32_bf16.  k-step ks, k-group lk <-> channels 32 ks + 8 lk .. + 7 ----
+        float rT[16], rB[16];                                              // raw filter rows of the next pass (c = 32 (kk >> 3) + 8 lk + (kk & 7))
+        fq_bf16x8 wS[3][2], wT[3][2];                                      // [term][k-step] B operands of this wave's S and T slab
+        auto load_w = [&](int pass) {
+            const int col = 16 * (FP_PCH * pass + wave) + li;
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk) {
+                const int c = 32 * (kk >> 3) + 8 * lk + (kk & 7);
+                rT[kk] = p.W[(int64_t)c * FX_NCOLS + col];
+                rB[kk] = p.W[(int64_t)(FX_NIN + c) * FX_NCOLS + col];
+            }
+        };
+        auto split_w = [&]() {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                unsigned hs[4], ms[4], ls[4], ht[4], mt[4], lt[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int k0 = 8 * ks + 2 * q;
+                    const float s0 = p.ext == FGNN_EXT_DIFF ? rT[k0] + rB[k0] : rT[k0], s1 = p.ext == FGNN_EXT_DIFF ? rT[k0 + 1] + rB[k0 + 1] : rT[k0 + 1];
+                    const float t0 = p.ext == FGNN_EXT_DIFF ? -rB[k0] : rB[k0], t1 = p.ext == FGNN_EXT_DIFF ? -rB[k0 + 1] : rB[k0 + 1];
+                    fq_split2(s0, s1, hs[q], ms[q], ls[q]);
+                    fq_split2(t0, t1, ht[q], mt[q], lt[q]);
+                }
+                wS[0][ks] = __builtin_bit_cast(fq_bf16x8, make_uint4(hs[0], hs[1], hs[2], hs[3]));
+                wS[1][ks] = __builtin_bit_cast(fq_bf16x8, make_uint4(ms[0], ms[1], ms[2], ms[3]));
+                wS[2][ks] = __builtin_bit_cast(fq_bf16x8, make_uint4(ls[0], ls[1], ls[2], ls[3]));
+                wT[0][ks] = __builtin_bit_cast(fq_bf16x8, make_uint4(ht[0], ht[1], ht[2], ht[3]));
+                wT[1][ks] = __builtin_bit_cast(fq_bf16x8, make_uint4(mt[0], mt[1], mt[2], mt[3]));
+                wT[2][ks] = __builtin_bit_cast(fq_bf16x8, make_uint4(lt[0], lt[1], lt[2], lt[3]));
+            }
+        };
+        int si = 0, pi = 0;
+        load_w(blockIdx.x & (FP_NPASS - 1));
+        for (int t = 0; t <= nstage; ++t) {
+            FP_STAMP(0);
+            if (t < nstage) {
+                if (si == 0) {
+                    split_w();
+                    if (pi + 1 < FP_NPASS) load_w((pi + 1 + blockIdx.x) & (FP_NPASS - 1));
+                }
+                const uint16_t* xi = xq + (t & 1) * XQ_BUF;
+                float* pb = ps + (t & 1) * 64 * FP_PROW;
+                for (int nt = 0; nt < ((p.dbg & 1) ? 0 : ntile); ++nt) {
+                    fq_bf16x8 xa[3][2];                                    // [term][k-step] A operand: 8 consecutive channels of node row li
+#pragma unroll
+                    for (int tm = 0; tm < 3; ++tm)
+#pragma unroll
+                        for (int ks = 0; ks < 2; ++ks)
+                            xa[tm][ks] = __builtin_bit_cast(fq_bf16x8, *reinterpret_cast<const uint4*>(xi + tm * XQ_TERM + (nt * 16 + li) * FQ_XS + 32 * ks + 8 * lk));
+                    // four independent accumulator chains (S / T x the two k-steps), smallest terms first in each:
+                    // l h' + h l' + m m', then m h' + h m', then h h'
+                    f32x4 aS[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, aT[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+                    constexpr int TA[6] = {2, 0, 1, 1, 0, 0}, TB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+                    for (int pr = 0; pr < 6; ++pr)
+#pragma unroll
+                        for (int ks = 0; ks < 2; ++ks) {
+                            aS[ks] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa[TA[pr]][ks], wS[TB[pr]][ks], aS[ks], 0, 0, 0);
+                            aT[ks] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa[TA[pr]][ks], wT[TB[pr]][ks], aT[ks], 0, 0, 0);
+                        }
+                    const f32x4 accS = aS[0] + aS[1], accT = aT[0] + aT[1];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = nt * 16 + 4 * lk + r;
+                        float* pr = pb + row * FP_PROW + ((wave ^ fp_sw(row)) << 4) + li;
+                        pr[0] = accS[r];
+                        pr[64] = accT[r];
+                    }
+                }
+                if (++si == ns) { si = 0; ++pi; }
+            }
+            FP_STAMP(1);
+            __syncthreads();
+        }
+      }
     } else {
         // =========================== consumers ===========================
         if (!(p.dbg & 4)) __builtin_amdgcn_s_setprio(3);      // VALU issue is arbitrated by priority, then age: without it the gather starves beside the producers' MFMA stream
@@ -361,12 +482,12 @@ __global__ __launch_bounds__(FX_THREADS, 2) void mpconv_fwd_extp_kernel(const Fx
         int si = 0, pi = 0;                       // of stage t - 1
         // x travels two stages ahead: loaded during stage t - 1, written to the idle x image during stage t, read by the
         // producers in stage t + 1 (the load's latency never sits between two barriers)
-        uint4 xr[4];
+        uint4 xr[XQN];
         auto load_x = [&](int stage) {
             const uint4* xb = reinterpret_cast<const uint4*>(p.x + (int64_t)(b_begin + stage % ns) * p.x_sb);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int f = ct + q * 256;
+            for (int q = 0; q < XQN; ++q) {
+                const int f = ct + q * NCT;
                 xr[q] = (f >> 4) < N ? xb[f] : make_uint4(0, 0, 0, 0);
             }
         };
@@ -374,11 +495,10 @@ __global__ __launch_bounds__(FX_THREADS, 2) void mpconv_fwd_extp_kernel(const Fx
         for (int t = 0; t <= nstage; ++t) {
             FP_STAMP(0);
             if (t + 1 < nstage) {
-                float* xo = xs + ((t + 1) & 1) * 64 * FX_XS;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int f = ct + q * 256;
-                    if ((f >> 4) < N) *reinterpret_cast<uint4*>(xo + (f >> 4) * FX_XS + (f & 15) * 4) = xr[q];
+                for (int q = 0; q < XQN; ++q) {
+                    const int f = ct + q * NCT;
+                    if ((f >> 4) < N) put_x((t + 1) & 1, f, xr[q]);
                 }
             }
             FP_STAMP(2);
@@ -395,21 +515,7 @@ __global__ __launch_bounds__(FX_THREADS, 2) void mpconv_fwd_extp_kernel(const Fx
                     }
                     float best = 0.f, mx = -INFINITY, ssum = 0.f;
                     int arg = 0;
-                    for (int j = 0; j < k; ++j) {
-                        const int r = gm * k + j;
-                        const int iv = idx_s[r];
-                        const float* trow = pb + (iv & ~3) + ((goc ^ (iv & 3)) << 4);
-                        const float* erow = et_s + r * FX_NET;
-                        fx_f32x2 acc = {0.f, 0.f};
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const int c4 = 4 * ((q + mg) & 3);
-                            const f32x4 tv = *reinterpret_cast<const f32x4*>(trow + c4);
-                            const f32x4 ev = *reinterpret_cast<const f32x4*>(erow + c4);
-                            acc = (fx_f32x2){ev[0], ev[1]} * (s2[2 * q] + (fx_f32x2){tv[0], tv[1]}) + acc;
-                            acc = (fx_f32x2){ev[2], ev[3]} * (s2[2 * q + 1] + (fx_f32x2){tv[2], tv[3]}) + acc;
-                        }
-                        const float v = acc[0] + acc[1];
+                    auto fold = [&](float v, int j) {
                         if (AGG == FGNN_AGG_MAX) {
                             if (j == 0 || v > best) { best = v; arg = j; }
                         } else if (AGG == FGNN_AGG_LSE) {
@@ -418,6 +524,46 @@ __global__ __launch_bounds__(FX_THREADS, 2) void mpconv_fwd_extp_kernel(const Fx
                             else ssum += expf(v3 - mx);
                         } else {
                             ssum += v;
+                        }
+                    };
+                    if (SPLIT) {
+                        // plain f32 VALU: packed f32 ops do not issue beside a bf16 MFMA stream (tools/ubench/mfma_f32_partner.hip).
+                        // (Requesting neighbour j + 1's rows before neighbour j's products, or pairing lanes over the edge types on 8
+                        // consumer waves, measured slower: the order-9 gather is bound by LDS throughput, not by its round trips.)
+                        for (int j = 0; j < k; ++j) {
+                            const int r = gm * k + j;
+                            const int iv = idx_s[r];
+                            const float* trow = pb + (iv & ~3) + ((goc ^ (iv & 3)) << 4);
+                            const float* erow = et_s + r * FX_NET;
+                            float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const int c4 = 4 * ((q + mg) & 3);
+                                const f32x4 tv = *reinterpret_cast<const f32x4*>(trow + c4);
+                                const f32x4 ev = *reinterpret_cast<const f32x4*>(erow + c4);
+                                a0 = fx_fma(ev[0], fx_add(s2[2 * q][0], tv[0]), a0);
+                                a1 = fx_fma(ev[1], fx_add(s2[2 * q][1], tv[1]), a1);
+                                a0 = fx_fma(ev[2], fx_add(s2[2 * q + 1][0], tv[2]), a0);
+                                a1 = fx_fma(ev[3], fx_add(s2[2 * q + 1][1], tv[3]), a1);
+                            }
+                            fold(a0 + a1, j);
+                        }
+                    } else {
+                        for (int j = 0; j < k; ++j) {
+                            const int r = gm * k + j;
+                            const int iv = idx_s[r];
+                            const float* trow = pb + (iv & ~3) + ((goc ^ (iv & 3)) << 4);
+                            const float* erow = et_s + r * FX_NET;
+                            fx_f32x2 acc = {0.f, 0.f};
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const int c4 = 4 * ((q + mg) & 3);
+                                const f32x4 tv = *reinterpret_cast<const f32x4*>(trow + c4);
+                                const f32x4 ev = *reinterpret_cast<const f32x4*>(erow + c4);
+                                acc = (fx_f32x2){ev[0], ev[1]} * (s2[2 * q] + (fx_f32x2){tv[0], tv[1]}) + acc;
+                                acc = (fx_f32x2){ev[2], ev[3]} * (s2[2 * q + 1] + (fx_f32x2){tv[2], tv[3]}) + acc;
+                            }
+                            fold(acc[0] + acc[1], j);
                         }
                     }
                     float res;
@@ -461,7 +607,10 @@ int fgnn_mpconv_forward_ext(const fgnn_mpconv_desc* d, const void* x, const int6
     int off_b = 0;
     auto take = [&](int bytes) { const int o = off_b; off_b = fgnn_round_up(off_b + bytes, 16); return o; };
     const bool piped = (d->idx_sb == 0 && d->et_sb == 0) || d->B == 1;
-    p.off_xs = take((piped ? 2 : 1) * 64 * FX_XS * 4);
+    static const bool exact = getenv("FGNN_EXT_F32MFMA") != nullptr;      // projections on the f32 matrix cores (bitwise an fmaf chain)
+    // default: three-term bf16 split on the bf16 matrix cores, when its larger x images still fit next to the edge types
+    const bool split = piped && !exact && (2 * 3 * 64 * FQ_XS * 2 + 2 * 64 * FP_PROW * 4 + d->N * d->k * (FX_NET * 4 + 4) + 3 * 64 * 4 + 64 <= 160 * 1024);
+    p.off_xs = take(split ? 2 * 3 * 64 * FQ_XS * 2 : (piped ? 2 : 1) * 64 * FX_XS * 4);
     p.off_ps = take(piped ? 2 * 64 * FP_PROW * 4 : 64 * FX_PS * 4);
     p.off_et = take(d->N * d->k * FX_NET * 4);
     p.off_idx = take(d->N * d->k * 4);
@@ -470,16 +619,19 @@ int fgnn_mpconv_forward_ext(const fgnn_mpconv_desc* d, const void* x, const int6
     if (lds > 160 * 1024) return 0;
     void* fn = d->agg == FGNN_AGG_MAX ? (void*)mpconv_fwd_ext_kernel<FGNN_AGG_MAX>
              : d->agg == FGNN_AGG_LSE ? (void*)mpconv_fwd_ext_kernel<FGNN_AGG_LSE> : (void*)mpconv_fwd_ext_kernel<FGNN_AGG_MEAN>;
-    if (piped)
-        fn = d->agg == FGNN_AGG_MAX ? (void*)mpconv_fwd_extp_kernel<FGNN_AGG_MAX>
-           : d->agg == FGNN_AGG_LSE ? (void*)mpconv_fwd_extp_kernel<FGNN_AGG_LSE> : (void*)mpconv_fwd_extp_kernel<FGNN_AGG_MEAN>;
+    if (piped && split)
+        fn = d->agg == FGNN_AGG_MAX ? (void*)mpconv_fwd_extp_kernel<FGNN_AGG_MAX, true>
+           : d->agg == FGNN_AGG_LSE ? (void*)mpconv_fwd_extp_kernel<FGNN_AGG_LSE, true> : (void*)mpconv_fwd_extp_kernel<FGNN_AGG_MEAN, true>;
+    else if (piped)
+        fn = d->agg == FGNN_AGG_MAX ? (void*)mpconv_fwd_extp_kernel<FGNN_AGG_MAX, false>
+           : d->agg == FGNN_AGG_LSE ? (void*)mpconv_fwd_extp_kernel<FGNN_AGG_LSE, false> : (void*)mpconv_fwd_extp_kernel<FGNN_AGG_MEAN, false>;
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "hipFuncSetAttribute(%d B LDS): %s", lds, hipGetErrorString(e));
     int grid = 256;
     if (grid > d->B) grid = d->B;
     const int chunk = (d->B + grid - 1) / grid;
     grid = (d->B + chunk - 1) / chunk;
-    fgnn_note_kernel(piped ? "mpconv_fwd_extp_kernel<%d>" : "mpconv_fwd_ext_kernel<%d>", d->agg);
+    fgnn_note_kernel(piped ? (split ? "mpconv_fwd_extp_kernel<%d, true>" : "mpconv_fwd_extp_kernel<%d, false>") : "mpconv_fwd_ext_kernel<%d>", d->agg);
     p.prof = nullptr;
     p.dbg = 0;
 #ifdef FGNN_ENABLE_PROF

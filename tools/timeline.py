@@ -14,23 +14,15 @@ names = [e[2] for e in ev]
 adam = [i for i, nm in enumerate(names) if 'flat_adam' in nm]
 if len(adam) >= steps + 1:
     lo, hi = adam[-steps - 1] + 1, adam[-1] + 1
-else:                                       # inference: find the periodic stretch (the graph replays) by its period
-    lo, hi = 0, n
-    found = False
-    for e in range(n, max(n - 6000, 0), -1):
-        for per in range(40, 4000):
-            if e - 3 * per < 0:
-                break
-            if names[e - per:e] == names[e - 2 * per:e - per] == names[e - 3 * per:e - 2 * per]:
-                k = 3
-                while e - (k + 1) * per >= 0 and names[e - (k + 1) * per:e - k * per] == names[e - per:e]:
-                    k += 1
-                steps = min(steps, k)
-                lo, hi = e - steps * per, e
-                found = True
-                break
-        if found:
-            break
+else:                                       # inference: the timed replays are the longest gap-free stretch of the trace
+    cuts = [0]
+    run_end = ev[0][1]
+    for i in range(1, n):
+        if ev[i][0] - run_end > 150000:     # 150 us of idle GPU: a host synchronisation
+            cuts.append(i)
+        run_end = max(run_end, ev[i][1])
+    cuts.append(n)
+    lo, hi = max(((cuts[i], cuts[i + 1]) for i in range(len(cuts) - 1)), key=lambda ab: ab[1] - ab[0])
 seg = ev[lo:hi]
 t0, t1 = seg[0][0], max(e[1] for e in seg)
 span = t1 - t0
