@@ -399,23 +399,36 @@ __global__ __launch_bounds__(512) void mpconv_block_fanout_kernel(const KfParams
                 for (int u = 0; u < 4; ++u) { v[u] = fmaxf(fmaf(e, p0[u], t0[u]), 0.f); v[4 + u] = fmaxf(fmaf(e, p1[u], t1[u]), 0.f); }
                 bf[ks] = __builtin_bit_cast(kb_bf16x8, make_uint4(kb_pack2(v[0], v[1]), kb_pack2(v[2], v[3]), kb_pack2(v[4], v[5]), kb_pack2(v[6], v[7])));
             }
-            for (int q = 0; q < qtile; ++q) {
-                const uint16_t* wr = W2l + (q * 16 + li) * KB_XSB + 8 * lk;
-                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(kb_bf16x8, *reinterpret_cast<const uint4*>(wr)), bf[0], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(kb_bf16x8, *reinterpret_cast<const uint4*>(wr + 32)), bf[1], acc, 0, 0, 0);
-                if (m < M) {
-                    const f32x4 s3 = *reinterpret_cast<const f32x4*>(p.s3 + q * 16 + 4 * lk), t3 = *reinterpret_cast<const f32x4*>(p.t3 + q * 16 + 4 * lk);
-                    float v[4];
+            // Output channels in groups of 64 = four MFMA tiles whose rows are permuted (tile qt, row i <-> channel 16 (i >> 2) + 4 qt
+            // + (i & 3)): lane (row li, lk) then holds the 16 CONSECUTIVE channels 16 lk .. + 15 of its row and moves them (and the
+            // addend) as two 16-byte accesses instead of four 8-byte ones.
+            for (int g = 0; g < qtile / 4; ++g) {
+                f32x4 acc[4];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) { const float u = fmaf(acc[r], s3[r], t3[r]); v[r] = u > 0.f ? u : u * p.slope; }
-                    const int64_t off = (int64_t)m * nout + q * 16 + 4 * lk;
-                    if (adb) {
-                        const uint2 a = *reinterpret_cast<const uint2*>(adb + off);
-                        v[0] += __uint_as_float(a.x << 16); v[1] += __uint_as_float(a.x & 0xffff0000u);
-                        v[2] += __uint_as_float(a.y << 16); v[3] += __uint_as_float(a.y & 0xffff0000u);
+                for (int qt = 0; qt < 4; ++qt) {
+                    const uint16_t* wr = W2l + (64 * g + 16 * (li >> 2) + 4 * qt + (li & 3)) * KB_XSB + 8 * lk;
+                    acc[qt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    acc[qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(kb_bf16x8, *reinterpret_cast<const uint4*>(wr)), bf[0], acc[qt], 0, 0, 0);
+                    acc[qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(kb_bf16x8, *reinterpret_cast<const uint4*>(wr + 32)), bf[1], acc[qt], 0, 0, 0);
+                }
+                if (m < M) {
+                    const int ch = 64 * g + 16 * lk;                       // D[i = 4 lk + r] of tile qt = channel ch + 4 qt + r
+                    float v[16];
+#pragma unroll
+                    for (int qt = 0; qt < 4; ++qt) {
+                        const f32x4 s3 = *reinterpret_cast<const f32x4*>(p.s3 + ch + 4 * qt), t3 = *reinterpret_cast<const f32x4*>(p.t3 + ch + 4 * qt);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { const float u = fmaf(acc[qt][r], s3[r], t3[r]); v[4 * qt + r] = u > 0.f ? u : u * p.slope; }
                     }
-                    *reinterpret_cast<uint2*>(yb + off) = make_uint2(kb_pack2(v[0], v[1]), kb_pack2(v[2], v[3]));
+                    const int64_t off = (int64_t)m * nout + ch;
+                    if (adb) {
+                        const uint4 a0 = *reinterpret_cast<const uint4*>(adb + off), a1 = *reinterpret_cast<const uint4*>(adb + off + 8);
+                        const unsigned aw[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) { v[2 * u] += __uint_as_float(aw[u] << 16); v[2 * u + 1] += __uint_as_float(aw[u] & 0xffff0000u); }
+                    }
+                    *reinterpret_cast<uint4*>(yb + off) = make_uint4(kb_pack2(v[0], v[1]), kb_pack2(v[2], v[3]), kb_pack2(v[4], v[5]), kb_pack2(v[6], v[7]));
+                    *reinterpret_cast<uint4*>(yb + off + 8) = make_uint4(kb_pack2(v[8], v[9]), kb_pack2(v[10], v[11]), kb_pack2(v[12], v[13]), kb_pack2(v[14], v[15]));
                 }
             }
         }
@@ -578,7 +591,7 @@ extern "C" int fgnn_mpconv_block_forward_fanout(const fgnn_mpconv_desc* d, const
                     d->N == 1 && d->k == 1 && d->M >= 1 && d->M <= 256 &&
                     (nin == 64 || nin == 128 || nin == 256) && (nout == 64 || nout == 128 || nout == 256) &&
                     d->x_sc == 1 && d->y_sc == 1 && d->y_sm == nout && d->y_sb == (int64_t)d->M * nout &&
-                    !((uintptr_t)y & 7) && !((uintptr_t)addend & 7);
+                    !((uintptr_t)y & 15) && !((uintptr_t)addend & 15);
     if (!ok) FGNN_FAIL(FGNN_EUNSUPPORTED, "mpconv_block_forward_fanout: outside the fused block's family");
     if (d->B == 0) return FGNN_OK;
     KfParams p;
