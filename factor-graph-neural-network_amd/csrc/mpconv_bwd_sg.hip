@@ -49,7 +49,7 @@ struct BsParams {
     float* ws;               // per-workgroup slabs [grid][64*256 + 64]
     int B, N, M, Npad, NPW, DPW;
     long long x_sb, et_sb, y_sb;     // elements
-    int off_xs, off_pd, off_ga, off_z, off_es, off_tab, off_idx, off_red;      // byte offsets into LDS
+    int off_xs, off_pd, off_ga, off_z, off_es, off_tab, off_idx, off_red, off_gst;      // byte offsets into LDS
     int zbytes;              // bytes of one wave's detype image
     long long* prof;         // FGNN_PROF (builds with -DFGNN_ENABLE_PROF only): phase timeline
 };
@@ -218,10 +218,13 @@ __global__ __launch_bounds__(BS_THREADS, 4) void mpconv_bwd_sg_kernel(const BsPa
 
     // ---- prefetch registers (raw chunks; decoded at the commit) ----
     uint4 px;                                         // one 16-byte x chunk (N * 8 <= 768 chunks)
-    uint2 pg[GSL];                                      // gz of items tid, tid + 1024: (m = item >> 4, channels 4 (item & 15) ..+3)
-    unsigned pa[GSL];                                   // argmax of the same items
+    // gz / argmax of item tid = eight consecutive channels (m = item >> 3, channels 8 (item & 7) .. + 7): one 16-byte and one
+    // 8-byte load per lane of the first M * 8 threads (<= 768).  The vector-memory path issues a wave's load in ~16 cycles
+    // whatever its width: uint2 + dword loads on all 16 waves cost ~0.8 k cycles more per sample than these.
+    uint4 pg = make_uint4(0, 0, 0, 0);
+    uint2 pa = make_uint2(0, 0);
     uint2 pe, pe_cur = make_uint2(0, 0);              // edge-type row of in-edge `lane` of this wave: next sample's / this sample's
-    const int xchunks = N * 8, gitems = M * 16;
+    const int xchunks = N * 8, gitems = M * 8;
     auto prefetch = [&](int b, int t) {
         const unsigned utid = (unsigned)t;
         const int lane = t & 63;
@@ -229,36 +232,30 @@ __global__ __launch_bounds__(BS_THREADS, 4) void mpconv_bwd_sg_kernel(const BsPa
         if (t < xchunks) px = *bs_at<uint4>(p.x + (int64_t)b * p.x_sb, utid * 16u);
         const uint16_t* gzb = p.gz + (int64_t)b * p.y_sb;
         const uint8_t* amb = p.argmax + (int64_t)b * p.y_sb;
-#pragma unroll
-        for (int s = 0; s < GSL; ++s) {
-            const unsigned f = utid + (unsigned)s * BS_THREADS;
-            pg[s] = make_uint2(0, 0);
-            pa[s] = 0u;
-            if ((int)f < gitems) {
-                pg[s] = *bs_at<uint2>(gzb, f * 8u);
-                pa[s] = *bs_at<unsigned>(amb, f * 4u);
-            }
+        pg = make_uint4(0, 0, 0, 0);
+        pa = make_uint2(0, 0);
+        if (t < gitems) {
+            pg = *bs_at<uint4>(gzb, utid * 16u);
+            pa = *bs_at<uint2>(amb, utid * 8u);
         }
         pe = make_uint2(0, 0);
         if (lane < NPW * DEG) pe = *bs_at<uint2>(p.et + (int64_t)b * p.et_sb, (unsigned)et_goff * 2u);
     };
     auto commit = [&](unsigned char* xs, int t) {
         if (t < xchunks) *reinterpret_cast<uint4*>(xs + (t >> 3) * BS_XSB + (t & 7) * 16) = px;
+        if (t < gitems) {
+            const unsigned gq[4] = {pg.x, pg.y, pg.z, pg.w};
+            unsigned w[8];
 #pragma unroll
-        for (int s = 0; s < GSL; ++s) {
-            const int f = t + s * BS_THREADS;
-            if (f < gitems) {
-                const unsigned g01 = pg[s].x, g23 = pg[s].y, a4 = pa[s];
-                unsigned w[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const unsigned a = (a4 >> (8 * u)) & 7u;               // slots 0..5 (a corrupt byte cannot reach the gz bits)
-                    const unsigned g2 = u < 2 ? g01 : g23;
-                    const unsigned hi = (u & 1) ? (g2 & 0xffff0000u) : (g2 << 16);
-                    w[u] = hi | (a << 8) | (1u << a);
-                }
-                *reinterpret_cast<uint4*>(ga + (f >> 4) * BS_GSB + (f & 15) * 16) = make_uint4(w[0], w[1], w[2], w[3]);
+            for (int u = 0; u < 8; ++u) {
+                const unsigned a = ((u < 4 ? pa.x : pa.y) >> (8 * (u & 3))) & 7u;      // slots 0..5 (a corrupt byte cannot reach the gz bits)
+                const unsigned g2 = gq[u >> 1];
+                const unsigned hi = (u & 1) ? (g2 & 0xffff0000u) : (g2 << 16);
+                w[u] = hi | (a << 8) | (1u << a);
             }
+            unsigned char* gp = ga + (t >> 3) * BS_GSB + (t & 7) * 32;
+            *reinterpret_cast<uint4*>(gp) = make_uint4(w[0], w[1], w[2], w[3]);
+            *reinterpret_cast<uint4*>(gp + 16) = make_uint4(w[4], w[5], w[6], w[7]);
         }
         pe_cur = pe;
     };
@@ -272,7 +269,6 @@ __global__ __launch_bounds__(BS_THREADS, 4) void mpconv_bwd_sg_kernel(const BsPa
     if (b_begin < b_end) {
         prefetch(b_begin, tid);
         commit(xs0, tid);
-        if (b_begin + 1 < b_end) prefetch(b_begin + 1, tid);
     }
     int cur = 0;
 
@@ -286,6 +282,10 @@ __global__ __launch_bounds__(BS_THREADS, 4) void mpconv_bwd_sg_kernel(const BsPa
         BS_STAMP(0);
         __syncthreads();                              // B_a: x / ga / es of this sample are staged; pd is free
         BS_STAMP(1);
+        // the next sample's loads go out here, under the projection's MFMAs, while the vector-memory path is idle (issued
+        // after the dP phase, behind this sample's stores, the same five loads took 1 300-1 900 cycles to issue); they are
+        // consumed after B_d, ~10 000 cycles from now
+        if (b + 1 < b_end) prefetch(b + 1, t);
 
         // ---- P^T slab (wave = 16-column slab = channels 4 wave .. +3): D[i = col][j = node] ----
         for (int nt0 = 0; nt0 < ntile; nt0 += 2) {       // two node tiles in flight (ntile is even: Npad is a multiple of 32)
@@ -315,7 +315,10 @@ __global__ __launch_bounds__(BS_THREADS, 4) void mpconv_bwd_sg_kernel(const BsPa
         // ---- detype: lane = channel; the routed row's products go to the wave's [slot][edge type][channel] image, the sum
         //      over channels is an all-ones MFMA ----
         {
-            uint16_t* gb = p.get + (int64_t)b * 4 * mk;
+            // the sample's edge-type gradient (4 x mk bf16, contiguous in memory) is collected in LDS and leaves as 16-byte
+            // stores after the barrier: two-byte stores scattered over it kept the vector-memory queue busy for ~1 500 cycles
+            // (the next sample's staging below waits on that queue)
+            uint16_t* gb = reinterpret_cast<uint16_t*>(bs_lds + p.off_gst);
 #pragma unroll
             for (int d = 0; d < DPW; ++d) {
                 const int m = m0 + d;
@@ -349,8 +352,8 @@ __global__ __launch_bounds__(BS_THREADS, 4) void mpconv_bwd_sg_kernel(const BsPa
                     if (lk == 0 && li < KC * 2) {
                         const int j = li >> 1, e0 = 2 * (li & 1);
                         const __bf16 h0 = (__bf16)sum[0], h1 = (__bf16)sum[1];
-                        *bs_at<uint16_t>(gb, (unsigned)(e0 * mk + m * KC + j) * 2u) = __builtin_bit_cast(uint16_t, h0);
-                        *bs_at<uint16_t>(gb, (unsigned)((e0 + 1) * mk + m * KC + j) * 2u) = __builtin_bit_cast(uint16_t, h1);
+                        gb[e0 * mk + m * KC + j] = __builtin_bit_cast(uint16_t, h0);
+                        gb[(e0 + 1) * mk + m * KC + j] = __builtin_bit_cast(uint16_t, h1);
                     }
                 }
             }
@@ -358,6 +361,13 @@ __global__ __launch_bounds__(BS_THREADS, 4) void mpconv_bwd_sg_kernel(const BsPa
         BS_STAMP(4);
         __syncthreads();                              // B_c: every wave is done reading P
         BS_STAMP(5);
+        {   // edge-type gradient of this sample: LDS -> memory, 16 bytes per lane (8 mk bytes in all; a 2-byte tail loop for odd sizes)
+            const unsigned char* gsrc = bs_lds + p.off_gst;
+            unsigned char* gdst = reinterpret_cast<unsigned char*>(p.get + (int64_t)b * 4 * mk);
+            const int nbytes = 8 * mk, nvec = ((uintptr_t)gdst & 15) ? 0 : nbytes >> 4;
+            if (t < nvec) *bs_at<uint4>(gdst, (unsigned)t * 16u) = *reinterpret_cast<const uint4*>(gsrc + t * 16);
+            for (int f = nvec * 8 + t; f < 4 * mk; f += BS_THREADS) *bs_at<uint16_t>(gdst, (unsigned)f * 2u) = *reinterpret_cast<const uint16_t*>(gsrc + f * 2);
+        }
 
         // ---- dP: wave owns source nodes n0 .. n0 + NPW - 1, lane = channel; in-edges in (m, j) order ----
 #pragma unroll
@@ -387,10 +397,8 @@ __global__ __launch_bounds__(BS_THREADS, 4) void mpconv_bwd_sg_kernel(const BsPa
         // ---- stage the next sample (its loads were issued a whole sample ago) ----
         if (b + 1 < b_end) {
             commit(xs0 + (cur ^ 1) * xs_bytes, t);
-            if (b + 2 < b_end) prefetch(b + 2, t);
+            BS_STAMP(8);
         }
-
-        BS_STAMP(8);
         BS_STAMP(9);
         if (!dw_wave) {
             // ---- dx^T tiles: D[i = c][j = n] = W[c][:] . dP[n][:], channel tile ct, node tiles ((wave - 8) >> 2) + 2 i ----
@@ -506,7 +514,7 @@ int fgnn_mpconv_backward_sg(const fgnn_mpconv_desc* d, const void* x, const int6
     if (!(d->x_sc == 1 && d->x_sn == d->nin && d->x_sb % 8 == 0)) BS_REJECT(9);
     if (!(d->y_sc == 1 && (d->y_sm == d->nou || d->M == 1) && d->y_sb % 8 == 0)) BS_REJECT(10);
     if (!(d->et_se == 1 && d->et_sk == 4 && (d->et_sm == 4 * d->k || d->M == 1) && d->et_sb % 4 == 0)) BS_REJECT(11);
-    if (((uintptr_t)x & 15) || ((uintptr_t)gz & 7) || ((uintptr_t)etype & 7) || ((uintptr_t)argmax & 3) ||
+    if (((uintptr_t)x & 15) || ((uintptr_t)gz & 15) || ((uintptr_t)etype & 7) || ((uintptr_t)argmax & 7) ||
         ((uintptr_t)gx & 7)) BS_REJECT(12);
     const int64_t nw = (int64_t)d->nin * d->nou * 4, slab_len = nw + d->nou;
     if (!workspace || workspace_bytes < 256 * slab_len * 4) BS_REJECT(13);
@@ -534,6 +542,7 @@ int fgnn_mpconv_backward_sg(const fgnn_mpconv_desc* d, const void* x, const int6
     p.off_es = take(BS_WAVES * p.NPW * DEG * 16);
     p.off_tab = take(d->N * DEG * 4);
     p.off_idx = take(d->M * KC * 4);
+    p.off_gst = take(8 * d->M * KC);
     p.off_red = p.off_xs;                                               // dbias partials: after the last sample (16 KB)
     const int lds = off_b > 16384 ? off_b : 16384;
     if (lds > 160 * 1024) BS_REJECT(15);

@@ -44,6 +44,7 @@ def main():
     ap.add_argument('--only', default='')
     ap.add_argument('--syn', action='store_true', help='the synthetic-PGM shapes instead of the LDPC ones')
     ap.add_argument('--shared-et', action='store_true', help='edge types shared by the batch ([1, net, M, k] expanded), as in the synthetic-PGM scripts')
+    ap.add_argument('--no-etgrad', action='store_true', help='backward without the edge-weight gradient (getype = NULL)')
     ap.add_argument('--etgrad', action='store_true', help='hyper shapes: also ask for the edge-weight gradient')
     a = ap.parse_args()
     dev = torch.device('cuda:0')
@@ -88,7 +89,7 @@ def main():
             y, amax = ops.mpconv_forward_raw(x, idx, et, W, bias, nou, net, ext, agg, want_argmax=True)
             gz = torch.randn_like(y)
             gx = torch.empty_like(x)
-            get = None if (net == 1 and not a.etgrad) else torch.empty((B, net, M, k), device=dev, dtype=dt)
+            get = None if ((net == 1 and not a.etgrad) or a.no_etgrad) else torch.empty((B, net, M, k), device=dev, dtype=dt)
             gw = torch.zeros_like(W)
             gb = torch.zeros(nou, device=dev)
             dsc = _hip.make_desc(x, idx, et, nou, net, ext, agg, False, gz)
