@@ -10,8 +10,8 @@
 // The reference does this per codeword on the host (a pybind11 call per item, numpy takes, a DataLoader); at
 // B = 4096 codewords per step per GPU that is the input bottleneck.  Here a batch is two launches of byte / gather
 // work, written once, coalesced, in the storage dtype the model kernels read.  The random draws (z1, u, z2) are
-// inputs: the transform is deterministic and is checked bit-for-bit (encode) / to f32 rounding (channel) against
-// the oracle.
+// inputs (the transform is deterministic and is checked bit-for-bit (encode) / to f32 rounding (channel) against
+// the oracle) or come from a counter-based generator inside the kernel (fgnn_ldpc_channel_features_rng).
 #include "fgnn_common.h"
 #include <stdint.h>
 
@@ -56,10 +56,31 @@ struct LdFeatParams {
     void *node, *hop, *ef_f2v, *ef_v2f;
     float rho;
     int nvar, nchk, dv, dc;
+    unsigned long long seed, offset;     // RNG variant: Philox key and stream offset (z1 / u / z2 are not read)
 };
 
+// Philox4x32-10 (Salmon et al., "Parallel random numbers: as easy as 1, 2, 3", SC'11): counter-based, so the draws of
+// codeword bit i of the batch depend on (seed, offset, i) only — not on the grid, the launch order or earlier calls.
+// oracle/fgnn_oracle.py::philox4x32 restates it in numpy; tests compare the two streams through the channel output.
+__device__ __forceinline__ void ld_philox(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1, unsigned (&r)[4]) {
+#pragma unroll
+    for (int round = 0; round < 10; ++round) {
+        const unsigned long long p0 = 0xD2511F53ull * c0, p1 = 0xCD9E8D57ull * c2;
+        const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1, n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    r[0] = c0; r[1] = c1; r[2] = c2; r[3] = c3;
+}
+// standard normal from two 32-bit words (Box-Muller, cosine branch): u1 in (0, 1], u2 in [0, 1)
+__device__ __forceinline__ float ld_normal(unsigned a, unsigned b) {
+    const float u1 = ((float)(a >> 8) + 1.0f) * 5.9604644775390625e-08f, u2 = (float)(b >> 8) * 5.9604644775390625e-08f;
+    return sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u2);
+}
+
+
 // One workgroup per codeword: y into LDS, then every output array is written by flat index (coalesced).
-template <typename T>
+template <typename T, bool RNG>
 __global__ __launch_bounds__(LD_THREADS) void ldpc_features_kernel(const LdFeatParams p) {
     __shared__ float ys[1024];
     const int64_t b = blockIdx.x;
@@ -68,8 +89,20 @@ __global__ __launch_bounds__(LD_THREADS) void ldpc_features_kernel(const LdFeatP
     const float gcx = exp2f(snr * 0.16609640474436813f);          // 10^(snr/20) = 2^(snr log2(10)/20)
     for (int n = tid; n < nvar; n += LD_THREADS) {
         const int64_t i = b * nvar + n;
-        float v = 2.f * gcx * ((float)p.cw[i] - 0.5f) + p.z1[i];
-        if (sb >= 1e-20f && p.u[i] < p.rho) v += gcx * sb * p.z2[i];
+        float z1, u, z2;
+        if (RNG) {          // the channel's draws (MNC_py.cpp:89,94-97) from the counter (i, offset): no noise tensors in HBM
+            unsigned ra[4], rb[4];
+            const unsigned long long ctr = (unsigned long long)i;
+            ld_philox((unsigned)ctr, (unsigned)(ctr >> 32), (unsigned)p.offset, (unsigned)(p.offset >> 32), (unsigned)p.seed, (unsigned)(p.seed >> 32), ra);
+            ld_philox((unsigned)ctr, (unsigned)(ctr >> 32), (unsigned)p.offset, (unsigned)(p.offset >> 32) ^ 0x80000000u, (unsigned)p.seed, (unsigned)(p.seed >> 32), rb);
+            z1 = ld_normal(ra[0], ra[1]);
+            u = (float)(ra[2] >> 8) * 5.9604644775390625e-08f;
+            z2 = ld_normal(rb[0], rb[1]);
+        } else {
+            z1 = p.z1[i]; u = p.u[i]; z2 = p.z2[i];
+        }
+        float v = 2.f * gcx * ((float)p.cw[i] - 0.5f) + z1;
+        if (sb >= 1e-20f && u < p.rho) v += gcx * sb * z2;
         ys[n] = v;
         p.y[i] = v;
     }
@@ -112,24 +145,51 @@ extern "C" int fgnn_ldpc_encode(const uint8_t* s, const uint64_t* gmask, int64_t
 // Received words and the model's inputs for B codewords of a (nvar, nchk) code with dv checks per variable and dc
 // variables per check: y [B][nvar] f32; node [B][2][nvar], hop [B][dc][nchk], ef_f2v [B][dc+1][nvar][dv],
 // ef_v2f [B][dc+1][nchk][dc] in `dtype` (FGNN_F32 / FGNN_BF16).
+static int ld_channel_launch(bool rng, const uint8_t* cw, const float* snr_db, const float* sigma_b, float rho, const float* z1,
+                             const float* u, const float* z2, uint64_t seed, uint64_t offset, const int32_t* var_to_factors,
+                             const int32_t* factor_to_vars, int64_t B, int nvar, int nchk, int dv, int dc, int dtype, float* y,
+                             void* node, void* hop, void* ef_f2v, void* ef_v2f, fgnn_stream_t stream) {
+    if (B < 0 || nvar < 1 || nvar > 1024 || nchk < 1 || dv < 1 || dc < 1 || (dtype != FGNN_F32 && dtype != FGNN_BF16))
+        FGNN_FAIL(FGNN_EUNSUPPORTED, "ldpc_channel_features: nvar=%d (<= 1024) nchk=%d dv=%d dc=%d dtype=%d", nvar, nchk, dv,
+                  dc, dtype);
+    if (B == 0) return FGNN_OK;
+    if (!cw || !snr_db || !sigma_b || (!rng && (!z1 || !u || !z2)) || !var_to_factors || !factor_to_vars || !y || !node || !hop ||
+        !ef_f2v || !ef_v2f)
+        FGNN_FAIL(FGNN_EINVAL, "ldpc_channel_features: null pointer");
+    LdFeatParams p = {cw, snr_db, sigma_b, z1, u, z2, var_to_factors, factor_to_vars, y, node, hop, ef_f2v, ef_v2f,
+                      rho, nvar, nchk, dv, dc, seed, offset};
+    fgnn_note_kernel(rng ? "ldpc_features_kernel<rng>" : "ldpc_features_kernel");
+    const dim3 grid((unsigned)B), block(LD_THREADS);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == FGNN_F32) {
+        if (rng) hipLaunchKernelGGL((ldpc_features_kernel<float, true>), grid, block, 0, st, p);
+        else hipLaunchKernelGGL((ldpc_features_kernel<float, false>), grid, block, 0, st, p);
+    } else {
+        if (rng) hipLaunchKernelGGL((ldpc_features_kernel<bf16_t, true>), grid, block, 0, st, p);
+        else hipLaunchKernelGGL((ldpc_features_kernel<bf16_t, false>), grid, block, 0, st, p);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "ldpc_channel_features launch: %s", hipGetErrorString(e));
+    return FGNN_OK;
+}
+
 extern "C" int fgnn_ldpc_channel_features(const uint8_t* cw, const float* snr_db, const float* sigma_b, float rho,
                                           const float* z1, const float* u, const float* z2,
                                           const int32_t* var_to_factors, const int32_t* factor_to_vars, int64_t B,
                                           int nvar, int nchk, int dv, int dc, int dtype, float* y, void* node,
                                           void* hop, void* ef_f2v, void* ef_v2f, fgnn_stream_t stream) {
-    if (B < 0 || nvar < 1 || nvar > 1024 || nchk < 1 || dv < 1 || dc < 1 || (dtype != FGNN_F32 && dtype != FGNN_BF16))
-        FGNN_FAIL(FGNN_EUNSUPPORTED, "ldpc_channel_features: nvar=%d (<= 1024) nchk=%d dv=%d dc=%d dtype=%d", nvar, nchk, dv,
-                  dc, dtype);
-    if (B == 0) return FGNN_OK;
-    if (!cw || !snr_db || !sigma_b || !z1 || !u || !z2 || !var_to_factors || !factor_to_vars || !y || !node || !hop ||
-        !ef_f2v || !ef_v2f)
-        FGNN_FAIL(FGNN_EINVAL, "ldpc_channel_features: null pointer");
-    LdFeatParams p = {cw, snr_db, sigma_b, z1, u, z2, var_to_factors, factor_to_vars, y, node, hop, ef_f2v, ef_v2f,
-                      rho, nvar, nchk, dv, dc};
-    fgnn_note_kernel("ldpc_features_kernel");
-    if (dtype == FGNN_F32) hipLaunchKernelGGL(ldpc_features_kernel<float>, dim3((unsigned)B), dim3(LD_THREADS), 0, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL(ldpc_features_kernel<bf16_t>, dim3((unsigned)B), dim3(LD_THREADS), 0, (hipStream_t)stream, p);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "ldpc_channel_features launch: %s", hipGetErrorString(e));
-    return FGNN_OK;
+    return ld_channel_launch(false, cw, snr_db, sigma_b, rho, z1, u, z2, 0, 0, var_to_factors, factor_to_vars, B, nvar, nchk, dv,
+                             dc, dtype, y, node, hop, ef_f2v, ef_v2f, stream);
+}
+
+// The same with the channel's random draws made in the kernel: Philox4x32-10 keyed by `seed`, counter = (index of the
+// codeword bit in the batch, `offset`): z1 = Box-Muller of words 0, 1, u = word 2 / 2^32 (24 bits), z2 = Box-Muller of words
+// 0, 1 of the block with the counter's top bit flipped.  A training loop passes its step number as `offset`.
+extern "C" int fgnn_ldpc_channel_features_rng(const uint8_t* cw, const float* snr_db, const float* sigma_b, float rho,
+                                              uint64_t seed, uint64_t offset, const int32_t* var_to_factors,
+                                              const int32_t* factor_to_vars, int64_t B, int nvar, int nchk, int dv, int dc,
+                                              int dtype, float* y, void* node, void* hop, void* ef_f2v, void* ef_v2f,
+                                              fgnn_stream_t stream) {
+    return ld_channel_launch(true, cw, snr_db, sigma_b, rho, nullptr, nullptr, nullptr, seed, offset, var_to_factors,
+                             factor_to_vars, B, nvar, nchk, dv, dc, dtype, y, node, hop, ef_f2v, ef_v2f, stream);
 }

@@ -50,9 +50,11 @@ class LdpcDataPath:
         return cw
 
     def channel_features(self, cw, snr_db, sigma_b, burst_prob=0.05, noise=None, generator=None,
-                         dtype=torch.float32):
+                         dtype=torch.float32, kernel_rng=None):
         """Received words + model inputs for codewords cw [B,96].  ``noise`` = (z1, u, z2) [B,96] f32 draws
-        (standard normal, uniform [0,1), standard normal); drawn from ``generator`` when None.
+        (standard normal, uniform [0,1), standard normal); drawn from ``generator`` when None.  ``kernel_rng`` = (seed,
+        offset): no noise tensors at all — the kernel draws them itself (Philox4x32-10 keyed by seed, counter = (bit index,
+        offset); csrc/ldpc_datapath.hip, restated in oracle/fgnn_oracle.py::philox_channel_draws).
         Returns (y [B,96] f32, node_feature [B,2,96,1], hop_feature [B,6,48,1], efeature_f2v [B,7,96,3],
         efeature_v2f [B,7,48,6])."""
         if dtype not in (torch.float32, torch.bfloat16):
@@ -62,7 +64,9 @@ class LdpcDataPath:
         cw = cw.to(dev, torch.uint8).contiguous()
         snr_db = snr_db.to(dev, torch.float32).contiguous()
         sigma_b = sigma_b.to(dev, torch.float32).contiguous()
-        if noise is None:
+        if kernel_rng is not None:
+            z1 = u = z2 = None
+        elif noise is None:
             z1 = torch.randn((B, N), device=dev, generator=generator)
             u = torch.rand((B, N), device=dev, generator=generator)
             z2 = torch.randn((B, N), device=dev, generator=generator)
@@ -74,6 +78,12 @@ class LdpcDataPath:
         ef_f2v = torch.empty((B, 7, 96, 3), device=dev, dtype=dtype)
         ef_v2f = torch.empty((B, 7, 48, 6), device=dev, dtype=dtype)
         P = _hip._ptr
+        if kernel_rng is not None:
+            seed, offset = (int(v) & 0xFFFFFFFFFFFFFFFF for v in kernel_rng)
+            _hip.check(_hip.lib().fgnn_ldpc_channel_features_rng(
+                P(cw), P(snr_db), P(sigma_b), float(burst_prob), seed, offset, P(self.var_to_factors), P(self.factor_to_vars),
+                B, 96, 48, 3, 6, _hip.dtype_code(node), P(y), P(node), P(hop), P(ef_f2v), P(ef_v2f), _hip.stream_ptr()))
+            return y, node, hop, ef_f2v, ef_v2f
         _hip.check(_hip.lib().fgnn_ldpc_channel_features(
             P(cw), P(snr_db), P(sigma_b), float(burst_prob), P(z1), P(u), P(z2), P(self.var_to_factors),
             P(self.factor_to_vars), B, 96, 48, 3, 6, _hip.dtype_code(node), P(y), P(node), P(hop), P(ef_f2v), P(ef_v2f),
@@ -120,7 +130,7 @@ class LdpcDataPath:
                                                int(loops), P(x), P(q1), P(viol), P(iters), _hip.stream_ptr()))
         return (x, viol, iters, q1) if want_posteriors else (x, viol, iters)
 
-    def sample(self, B, seed=0, dtype=torch.float32, snr_db=None, burst_prob=0.05):
+    def sample(self, B, seed=0, dtype=torch.float32, snr_db=None, burst_prob=0.05, kernel_rng=False, step=0):
         """A batch of B training items (ldpc_dataset.py:222-236): random messages, encoded, sent through the
         channel at a per-item SNR drawn from ``snr_db_choices`` (or the fixed ``snr_db``) and burst level from
         ``sigma_b_choices``.  Returns (node_feature, hop_feature, nn_idx_f2v [B,96,3], nn_idx_v2f [B,48,6],
@@ -132,6 +142,8 @@ class LdpcDataPath:
             torch.randint(0, len(choices), (B,), device=self.device, generator=gen)]
         snr = pick(self.snr_db_choices) if snr_db is None else torch.full((B,), float(snr_db), device=self.device)
         sigma_b = pick(self.sigma_b_choices)
-        _, node, hop, ef_f2v, ef_v2f = self.channel_features(cw, snr, sigma_b, burst_prob, generator=gen, dtype=dtype)
+        # kernel_rng: the channel's draws are made inside the feature kernel from (seed, step) instead of three noise tensors
+        _, node, hop, ef_f2v, ef_v2f = self.channel_features(cw, snr, sigma_b, burst_prob, generator=gen, dtype=dtype,
+                                                             kernel_rng=(seed, step) if kernel_rng else None)
         return (node, hop, self.nn_idx_f2v.unsqueeze(0).expand(B, -1, -1), self.nn_idx_v2f.unsqueeze(0).expand(B, -1, -1),
                 ef_f2v, ef_v2f, cw.long(), sigma_b)

@@ -263,6 +263,13 @@ int fgnn_ldpc_channel_features(const uint8_t* cw, const float* snr_db, const flo
                                const int32_t* factor_to_vars, int64_t B, int32_t nvar, int32_t nchk, int32_t dv,
                                int32_t dc, int32_t dtype, float* y, void* node, void* hop, void* ef_f2v, void* ef_v2f,
                                fgnn_stream_t stream);
+/* fgnn_ldpc_channel_features with t2y's draws (`xt::random::randn` / `rand`, MNC_py.cpp:89,94-97) made inside the kernel by a
+ * counter-based generator — Philox4x32-10, key = seed, counter = (index of the codeword bit in the batch, offset) — so no noise
+ * tensor exists in HBM and a batch is reproducible from (seed, offset) whatever the launch geometry. */
+int fgnn_ldpc_channel_features_rng(const uint8_t* cw, const float* snr_db, const float* sigma_b, float rho, uint64_t seed,
+                                   uint64_t offset, const int32_t* var_to_factors, const int32_t* factor_to_vars, int64_t B,
+                                   int32_t nvar, int32_t nchk, int32_t dv, int32_t dc, int32_t dtype, float* y, void* node,
+                                   void* hop, void* ef_f2v, void* ef_v2f, fgnn_stream_t stream);
 
 /*
  * The reference's classical baseline: MacKay's sum-product decoder `zb2x(z, k, n, Afile, 1, loops)` ->

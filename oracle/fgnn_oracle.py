@@ -360,6 +360,46 @@ def ldpc_channel(t, snr_db, sigma_b, rho, z1, u, z2):
     return y + np.where(burst, gcx * sb * np.asarray(z2), 0.0)
 
 
+def philox4x32(counter, key, rounds=10):
+    """Philox4x32-10 (Salmon, Moraes, Dror, Shaw: "Parallel random numbers: as easy as 1, 2, 3", SC'11) on arrays:
+    counter [..., 4] uint32, key [2] uint32 -> [..., 4] uint32.  The generator csrc/ldpc_datapath.hip runs per codeword bit."""
+    import numpy as np
+    c = np.array(counter, dtype=np.uint64)
+    k0, k1 = np.uint64(key[0]), np.uint64(key[1])
+    M0, M1, mask = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57), np.uint64(0xFFFFFFFF)
+    for _ in range(rounds):
+        p0, p1 = M0 * c[..., 0], M1 * c[..., 2]
+        n = np.stack([(p1 >> np.uint64(32)) ^ c[..., 1] ^ k0, p1 & mask, (p0 >> np.uint64(32)) ^ c[..., 3] ^ k1, p0 & mask], axis=-1)
+        c = n & mask
+        k0 = (k0 + np.uint64(0x9E3779B9)) & mask
+        k1 = (k1 + np.uint64(0xBB67AE85)) & mask
+    return c.astype(np.uint32)
+
+
+def philox_channel_draws(nbits, seed, offset):
+    """(z1, u, z2) float32 [nbits] as `fgnn_ldpc_channel_features_rng` draws them for the codeword bits 0 .. nbits-1 of a batch:
+    block A = philox(counter (i lo, i hi, offset lo, offset hi), key seed), block B = the same with the counter's top bit flipped;
+    z1 = Box-Muller(A0, A1), u = (A2 >> 8) 2^-24, z2 = Box-Muller(B0, B1), Box-Muller on the top 24 bits of each word in float32:
+    sqrt(-2 ln((a >> 8) + 1) 2^-24) cos(2 pi (b >> 8) 2^-24)."""
+    import numpy as np
+    i = np.arange(nbits, dtype=np.uint64)
+    lo, hi = (i & np.uint64(0xFFFFFFFF)), (i >> np.uint64(32))
+    off_lo, off_hi = np.uint64(offset & 0xFFFFFFFF), np.uint64((offset >> 32) & 0xFFFFFFFF)
+    key = (seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
+    ca = np.stack([lo, hi, np.full_like(lo, off_lo), np.full_like(lo, off_hi)], axis=-1)
+    cb = ca.copy()
+    cb[..., 3] ^= np.uint64(0x80000000)
+    A, Bk = philox4x32(ca, key), philox4x32(cb, key)
+    s = np.float32(5.9604644775390625e-08)
+
+    def normal(a, b):
+        u1 = ((a >> np.uint32(8)).astype(np.float32) + np.float32(1.0)) * s
+        u2 = (b >> np.uint32(8)).astype(np.float32) * s
+        return (np.sqrt(np.float32(-2.0) * np.log(u1)) * np.cos(np.float32(6.283185307179586) * u2)).astype(np.float32)
+
+    return normal(A[:, 0], A[:, 1]), (A[:, 2] >> np.uint32(8)).astype(np.float32) * s, normal(Bk[:, 0], Bk[:, 1])
+
+
 def ldpc_sum_product(nlist, nchk, bias, loops=100, tinydiv=1e-40, clip=0.9999999999):
     """MacKay's probability-domain sum-product decoder as the reference runs it for its classical baseline
     (`zb2x(z, 48, 48, A2, 1, 100)`, /root/reference/lib/data/ldpc.py:20-24 -> `bndecode`,

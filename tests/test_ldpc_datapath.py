@@ -95,3 +95,18 @@ def test_oracle_decoder_matches_compiled_reference_vectors():
     easy = np.arange(64, 96)[ok[64:]]
     assert len(easy) >= 24 and np.array_equal(z['dec_x'][easy], z['codewords'][easy - 64])
     assert np.allclose(O.ldpc_bit_prior(z['y'], z['snr_db']), z['dec_bias'][:64], rtol=0, atol=0)
+
+
+def test_philox_restatement_known_answers():
+    """Random123's published known-answer vectors for Philox4x32-10 (the generator of fgnn_ldpc_channel_features_rng)."""
+    import numpy as np
+    kat = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+           ((0xffffffff,) * 4, (0xffffffff, 0xffffffff), (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+           ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0), (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for ctr, key, want in kat:
+        got = O.philox4x32(np.array([ctr], dtype=np.uint32), key)[0]
+        assert tuple(int(v) for v in got) == want
+    z1, u, z2 = O.philox_channel_draws(100000, 99, 3)
+    assert abs(float(z1.mean())) < 0.01 and abs(float(z1.std()) - 1.0) < 0.01 and abs(float(z2.std()) - 1.0) < 0.01
+    assert 0.0 <= float(u.min()) and float(u.max()) < 1.0 and abs(float(u.mean()) - 0.5) < 0.005
+    assert abs(float(np.corrcoef(z1, z2)[0, 1])) < 0.01

@@ -136,3 +136,48 @@ def test_decode_from_received_words(path):
     x, viol, iters = path.decode(bias)
     ok = (viol == 0)
     assert ok.float().mean().item() > 0.3 and (x[ok].long() == label[ok]).float().mean().item() > 0.98
+
+
+def test_kernel_rng_channel_matches_the_philox_restatement(path):
+    """fgnn_ldpc_channel_features_rng: the channel's draws come from Philox4x32-10 inside the kernel.  The oracle restates the
+    generator (pinned by the Random123 known-answer vectors in the CPU suite) and the Box-Muller map; the received words must
+    agree to f32 rounding of the transcendental functions, the burst decisions (u < rho) exactly."""
+    z = H.load('ldpc_datapath.npz')
+    B, seed, step, rho = 64, 0x1234567887654321, 5, 0.05
+    cw, snr, sb = z['codewords'], z['snr_db'], z['sigma_b']
+    y = path.channel_features(torch.from_numpy(cw), torch.from_numpy(snr), torch.from_numpy(sb), rho, kernel_rng=(seed, step))[0]
+    z1, u, z2 = (a.reshape(B, 96) for a in O.philox_channel_draws(B * 96, seed, step))
+    ref = O.ldpc_channel(cw, snr, sb, rho, z1.astype(np.float64), u, z2.astype(np.float64))
+    err = np.abs(y.cpu().numpy() - ref)
+    assert err.max() <= 2e-5 * np.abs(ref).max(), err.max()
+    # reproducible from (seed, step) whatever the batch is cut into: the first 16 codewords alone give the same words
+    y16 = path.channel_features(torch.from_numpy(cw[:16]), torch.from_numpy(snr[:16]), torch.from_numpy(sb[:16]), rho,
+                                kernel_rng=(seed, step))[0]
+    assert torch.equal(y16, y[:16])
+    # another step, another stream
+    y2 = path.channel_features(torch.from_numpy(cw), torch.from_numpy(snr), torch.from_numpy(sb), rho, kernel_rng=(seed, step + 1))[0]
+    assert float((y2 - y).abs().min()) > 0.0 or float((y2 != y).float().mean()) > 0.99
+
+
+def test_kernel_rng_statistics(path, dev):
+    """40 000 codewords: unit-variance Gaussian noise around the BPSK points, bursts on a fraction rho of the bits."""
+    B, rho = 40000, 0.05
+    cw = torch.zeros(B, 96, dtype=torch.uint8)
+    snr = torch.zeros(B)                                   # gcx = 1
+    y0 = path.channel_features(cw, snr, torch.zeros(B), rho, kernel_rng=(7, 0))[0]        # no bursts: y = -1 + z1
+    n = (y0 + 1.0).double()
+    assert abs(float(n.mean())) < 2e-3 and abs(float(n.var()) - 1.0) < 5e-3
+    assert abs(float((n ** 4).mean()) - 3.0) < 5e-2                                      # kurtosis of a normal
+    yb = path.channel_features(cw, snr, torch.full((B,), 10.0), rho, kernel_rng=(7, 0))[0]   # bursts of sigma 10 where u < rho
+    hit = (yb != y0).double().mean()
+    assert abs(float(hit) - rho) < 1e-3
+    extra = (yb - y0)[yb != y0].double()
+    assert abs(float(extra.mean())) < 0.1 and abs(float(extra.std()) - 10.0) < 0.1
+
+
+def test_sample_with_kernel_rng_is_a_training_batch(path, dev):
+    a = path.sample(32, seed=3, dtype=torch.bfloat16, kernel_rng=True, step=0)
+    b = path.sample(32, seed=3, dtype=torch.bfloat16, kernel_rng=True, step=0)
+    c = path.sample(32, seed=3, dtype=torch.bfloat16, kernel_rng=True, step=1)
+    assert all(torch.equal(x, y) for x, y in zip(a, b))
+    assert not torch.equal(a[0], c[0]) and torch.equal(a[6], c[6])       # new noise, same codewords
