@@ -44,6 +44,8 @@ def main():
     ap.add_argument('--only', default='')
     ap.add_argument('--syn', action='store_true', help='the synthetic-PGM shapes instead of the LDPC ones')
     ap.add_argument('--shared-et', action='store_true', help='edge types shared by the batch ([1, net, M, k] expanded), as in the synthetic-PGM scripts')
+    ap.add_argument('--argmax', action='store_true', help='forward that also stores the argmax (what training needs)')
+    ap.add_argument('--stats', action='store_true', help='forward with the BatchNorm statistics epilogue (training form)')
     ap.add_argument('--no-etgrad', action='store_true', help='backward without the edge-weight gradient (getype = NULL)')
     ap.add_argument('--etgrad', action='store_true', help='hyper shapes: also ask for the edge-weight gradient')
     a = ap.parse_args()
@@ -79,7 +81,7 @@ def main():
         flops = 2.0 * B * N * nin * (1 if ext == 0 else 2) * nou * net + 2.0 * B * M * k * nou * net * (1 if ext == 0 else 2)
 
         def fwd():
-            return ops.mpconv_forward_raw(x, idx, et, W, bias, nou, net, ext, agg, want_argmax=a.bwd)
+            return ops.mpconv_forward_raw(x, idx, et, W, bias, nou, net, ext, agg, want_argmax=a.bwd or a.stats or a.argmax, want_stats=a.stats)
 
         if not a.bwd:
             run = fwd
