@@ -707,3 +707,40 @@ def test_factor_mpnn_training_steps_are_bitwise_reproducible(tag, dev):
     assert torch.equal(pa, pb)
     assert all(l == l and abs(l) < 1e3 for l in la)               # finite
     assert float((ga != 0).float().mean()) > 0.5                   # the gradients reach (nearly) every parameter
+
+
+@pytest.mark.parametrize('tag', ['pw', 'hop'])
+def test_factor_mpnn_training_reduces_loss(tag, dev):
+    """The synthetic-PGM training step as train_syn_hop_factor.py:283-303 runs it — edge models, factor_mpnn, cross entropy,
+    gradient-norm clip, Adam — on one fixed batch whose labels are a function of the node potentials: the loss must come down,
+    i.e. every gradient of csrc/mpconv_bwd_ext.hip (inputs, filters, bias, shared edge weights) points the right way."""
+    import fgnn_amd
+    hop_dim, pw_idx, pw_ef, hi_idx, hi_ef = H.syn_setup(tag)
+    B = 64
+    torch.manual_seed(3)
+    model = fgnn_amd.factor_mpnn(2, [4, hop_dim], O.SYN_DIMS, [16, 16]).to(dev).train()
+    C = torch.nn.Conv2d
+    em_pw = torch.nn.Sequential(C(3, 64, 1), torch.nn.ReLU(), C(64, 16, 1)).to(dev)
+    em_hi = torch.nn.Sequential(C(hi_ef.shape[0], 64, 1), torch.nn.ReLU(), C(64, 16, 1)).to(dev)
+    params = list(model.parameters()) + list(em_pw.parameters()) + list(em_hi.parameters())
+    opt = torch.optim.Adam(params, lr=3e-3)
+    g = torch.Generator().manual_seed(11)
+    nf = torch.rand(B, 2, 30, 1, generator=g)
+    label = (nf[:, 1, :, 0] > nf[:, 0, :, 0]).long().to(dev)             # the better unary potential: learnable from the inputs
+    nf, pws = nf.to(dev), torch.rand(B, 4, 30, 1, generator=g).to(dev)
+    hi = torch.rand(B, hop_dim, 1 if tag == 'pw' else 30, 1, generator=g).to(dev)
+    t = lambda a: torch.from_numpy(a).to(dev)[None]
+    losses = []
+    for _ in range(25):
+        opt.zero_grad()
+        et_pw, et_hi = em_pw(t(pw_ef)), em_hi(t(hi_ef))
+        pred, _ = model(nf, [pws, hi], [[t(pw_idx).repeat(B, 1, 1), et_pw.repeat(B, 1, 1, 1)],       # the scripts' .repeat form
+                                       [t(hi_idx).repeat(B, 1, 1), et_hi.repeat(B, 1, 1, 1)]])
+        loss = torch.nn.functional.cross_entropy(pred.squeeze(-1).permute(0, 2, 1).reshape(-1, 2), label.reshape(-1))
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(params, 1.0)
+        opt.step()
+        losses.append(float(loss.detach()))
+    assert all(l == l for l in losses), losses
+    assert losses[-1] < 0.7 * losses[0], losses
+    assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in params)
