@@ -126,9 +126,10 @@ def hip_linear(rows, weight, bias, want_stats=False, transposed=False):
         return None
     R, cin = rows.shape
     cout = weight.shape[1] if transposed else weight.shape[0]      # transposed: weight is [cin, cout] (y = rows @ weight)
-    # measured on MI355X (scratch lbench, R = 393 k rows): the streaming kernel beats rocBLAS up to 64x128 maps
-    # (21 vs 32 us at 64x64); with the statistics epilogue it also wins at 64x256 / 256x64 because it saves the
-    # BatchNorm's own pass over the output; wider maps stay with rocBLAS (4 TB/s there)
+    # measured on MI355X (tools/lbench.py, cold tensors, R = 393 k rows): the streaming kernel beats hipBLASLt up to 128x128 maps
+    # (23.7 vs 34.4 us at 64x64, 37.7 vs 45.9 at 64x128, 52.7 vs 57.6 at 128x128: the step time does not move with that last
+    # one); at 64x256 / 256x64 it loses 10 us (72 vs 61) but with the statistics epilogue saves the BatchNorm's own 25 us pass
+    # over the output; wider maps stay with hipBLASLt (4 TB/s there)
     if cin * cout > (16384 if want_stats else 8192):
         return None
     L = _hip.lib()
