@@ -44,6 +44,31 @@ class mp_sequential(base_mp_nn):
         return (node_feature, extras) if extras else node_feature
 
 
+class _SplitNodes(torch.autograd.Function):
+    """``both[:, :, :n]``, ``both[:, :, n:]`` as two views whose gradients come back in ONE concatenation.  Autograd's own
+    backward of the two slices (factor_mpnn.py:108-112) is two zero-filled tensors of ``both``'s size, two strided copies and
+    an add: five activation-sized kernels per block instead of one."""
+
+    @staticmethod
+    def forward(ctx, both, n):
+        ctx.n, ctx.shape, ctx.cl = n, both.shape, both.stride(1) == 1
+        ctx.set_materialize_grads(False)
+        return both[:, :, :n, :], both[:, :, n:, :]
+
+    @staticmethod
+    def backward(ctx, g_nodes, g_factors):
+        if g_nodes is None and g_factors is None:
+            return None, None
+        B, C, N, W = ctx.shape
+        ref = g_nodes if g_nodes is not None else g_factors
+        if g_nodes is None:
+            g_nodes = ref.new_zeros((B, C, ctx.n, W))
+        if g_factors is None:
+            g_factors = ref.new_zeros((B, C, N - ctx.n, W))
+        g = torch.cat([g_nodes, g_factors], dim=2)
+        return (g.contiguous(memory_format=torch.channels_last) if ctx.cl else g), None
+
+
 class factor_mpnn(torch.nn.Module):
     """Synthetic-PGM body.  Per layer and factor type the variables and that type's factors are
     concatenated along the node axis and pushed through one mp block (rows < nnode gather from
@@ -94,15 +119,24 @@ class factor_mpnn(torch.nn.Module):
         nfeat = self.mapping_modules[0](node_features)
         ffeat = [m(f) for f, m in zip(factor_features, self.mapping_modules[1:])]
         history = []
+        from ..ops import fan_out
+        track = torch.is_grad_enabled() and nfeat.requires_grad
         for L, row in enumerate(self.mp_nn_modules):
             to_nodes, to_factors = [], []
+            # the variables' state feeds every factor type's block: one alias per consumer, so that their gradients meet in a
+            # single n-way sum (ops.fan_out) instead of autograd's pairwise adds
+            nf_c = fan_out(nfeat, len(row)) if (track and len(row) > 1 and L not in self.skip_link.values()) else [nfeat] * len(row)
             for j, m in enumerate(row):
                 # channel-fastest, like every activation on this path (the operator kernels read node rows of channels)
-                both = torch.cat([nfeat, ffeat[j]], dim=2).contiguous(memory_format=torch.channels_last)
+                both = torch.cat([nf_c[j], ffeat[j]], dim=2).contiguous(memory_format=torch.channels_last)
                 nn_idx, etype = graph_structures[j]
                 both = _call(m, both, nn_idx, etype)
-                to_nodes.append(both[:, :, :nnode, :])
-                to_factors.append(both[:, :, nnode:, :])
+                if track:
+                    nd, fc = _SplitNodes.apply(both, nnode)
+                else:
+                    nd, fc = both[:, :, :nnode, :], both[:, :, nnode:, :]
+                to_nodes.append(nd)
+                to_factors.append(fc)
             nfeat = self.mp_merge_modules[L](torch.cat(to_nodes, dim=1))
             ffeat = to_factors
             if L in self.skip_link:

@@ -8,7 +8,10 @@ from fgnn_amd import _hip, ops
 dev = torch.device('cuda:0')
 L = _hip.lib()
 R = 4096 * 96
-for dt in (torch.bfloat16,) if '--bf16' in sys.argv else (torch.bfloat16, torch.float32):
+for a in sys.argv[1:]:
+    if a.startswith('--rows='):
+        R = int(a.split('=')[1])          # e.g. --rows=61440: the synthetic-PGM maps (1024 graphs x 60 nodes)
+for dt in (torch.bfloat16,) if '--bf16' in sys.argv else (torch.float32,) if '--f32' in sys.argv else (torch.bfloat16, torch.float32):
     for cin, cout in [(64, 64), (64, 128), (128, 64), (64, 256), (256, 64), (128, 256), (256, 128), (256, 256), (96, 64), (7, 64), (2, 64), (64, 4)]:
         x = torch.randn(R, cin, device=dev).to(dt); gy = torch.randn(R, cout, device=dev).to(dt)
         gw = torch.zeros(cout, cin, device=dev); gb = torch.zeros(cout, device=dev)
