@@ -318,13 +318,22 @@ int64_t fgnn_linear_wgrad_b16_workspace_bytes(int64_t R, int Cin, int Cout);
 int fgnn_linear_wgrad_b16(const void* x, const void* gy, int64_t R, int Cin, int Cout, float* gW, float* gb,
                           void* workspace, int64_t workspace_bytes, fgnn_stream_t stream);
 
+// f32, rows >= 2048, channel counts in multiples of 4: the output-blocked kernel of linear_wgrad_f32.hip
+int64_t fgnn_linear_wgrad_f32_workspace_bytes(int64_t R, int Cin, int Cout);
+int fgnn_linear_wgrad_f32(const void* x, const void* gy, int64_t R, int Cin, int Cout, float* gW, float* gb, void* workspace,
+                          int64_t workspace_bytes, fgnn_stream_t stream);
+
 extern "C" int64_t fgnn_linear_wgrad_workspace_bytes(int64_t R, int Cin, int Cout) {
     WgradParams p;
     int gx, gy;
-    if (R <= 0 || Cin <= 0 || Cout <= 0 || wgrad_plan((int)R, Cin, Cout, &p, &gx, &gy)) return -1;
-    const int64_t a = (int64_t)gx * gy * ((int64_t)p.Cop * p.Cip + p.Cop) * 4;
+    if (R <= 0 || Cin <= 0 || Cout <= 0) return -1;
+    const bool general = wgrad_plan((int)R, Cin, Cout, &p, &gx, &gy) == 0;
+    if (!general && fgnn_linear_wgrad_f32_workspace_bytes(R, Cin, Cout) == 0) return -1;
+    const int64_t a = general ? (int64_t)gx * gy * ((int64_t)p.Cop * p.Cip + p.Cop) * 4 : 0;
     const int64_t b = fgnn_linear_wgrad_b16_workspace_bytes(R, Cin, Cout);
-    return a > b ? a : b;
+    const int64_t c = fgnn_linear_wgrad_f32_workspace_bytes(R, Cin, Cout);
+    const int64_t m = a > b ? a : b;
+    return m > c ? m : c;
 }
 
 // gW [Cout][Cin] f32 and gb [Cout] f32 (or NULL) are ACCUMULATED into.  x [R][Cin], gy [R][Cout] dense
@@ -337,6 +346,10 @@ extern "C" int fgnn_linear_wgrad(const void* x, const void* gy, int64_t R, int C
     if (dtype != FGNN_F32 && dtype != FGNN_BF16) FGNN_FAIL(FGNN_EINVAL, "linear_wgrad: unknown dtype %d", dtype);
     if (dtype == FGNN_BF16) {
         const int rc = fgnn_linear_wgrad_b16(x, gy, R, Cin, Cout, gW, gb, workspace, workspace_bytes, stream);
+        if (rc != 0) return rc < 0 ? rc : FGNN_OK;
+    }
+    if (dtype == FGNN_F32) {
+        const int rc = fgnn_linear_wgrad_f32(x, gy, R, Cin, Cout, gW, gb, workspace, workspace_bytes, stream);
         if (rc != 0) return rc < 0 ? rc : FGNN_OK;
     }
     WgradParams p;

@@ -202,8 +202,11 @@ class _RowLinear(torch.autograd.Function):
                 grows = gy @ cast_cached(weight._base if weight._base is not None else weight, gy.dtype).view(weight.shape)
         R, cin = rows.shape
         cout = weight.shape[0]
+        # wide maps: bf16 multiples of 64 up to 256 and f32 multiples of 4 (csrc/linear_wgrad_f32.hip) have their own kernels;
+        # what is left (odd widths) goes to the library
         if cin * cout >= 256 * 256 and not (rows.dtype == torch.bfloat16 and cin % 64 == 0 and cout % 64 == 0
-                                            and cin <= 256 and cout <= 256):
+                                            and cin <= 256 and cout <= 256) and not (
+                rows.dtype == torch.float32 and cin % 4 == 0 and cout % 4 == 0 and cin <= 1024 and cout <= 1024 and R >= 2048):
             gw = (gy.t() @ rows).float()                # f32 square 256-wide maps: rocBLAS is ahead there
             gb = gy.float().sum(0) if ctx.has_bias else None
             return grows, gw.to(weight.dtype), (gb.to(weight.dtype) if gb is not None else None), None

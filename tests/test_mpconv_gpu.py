@@ -507,3 +507,29 @@ def test_bf16_forward_statistics_epilogue_feeds_batchnorm(shape, B, dev):
     finally:
         ops.TIMER = None
     assert not any(n.startswith('bn_stats') for n in names), names
+
+
+@pytest.mark.parametrize('R,cin,cout', [(61440, 128, 64), (61440, 256, 256), (5001, 512, 256), (2048, 64, 128), (30720, 132, 68), (4096, 1024, 16)])
+def test_f32_blocked_weight_gradient_vs_torch(R, cin, cout, dev):
+    """csrc/linear_wgrad_f32.hip (f32 node-wise maps of the synthetic-PGM models) through fgnn_linear_wgrad: against a float64
+    torch product, accumulating into gW / gb, and bit-identical on a second run (slab fold in a fixed order)."""
+    import ctypes
+    from fgnn_amd import _hip, ops
+    L = _hip.lib()
+    g = torch.Generator().manual_seed(R + cin)
+    x = torch.randn(R, cin, generator=g).to(dev)
+    gy = torch.randn(R, cout, generator=g).to(dev)
+    ref_w = (gy.double().t() @ x.double())
+    ref_b = gy.double().sum(0)
+    outs = []
+    for _ in range(2):
+        gw = torch.ones(cout, cin, device=dev)
+        gb = torch.full((cout,), 2.0, device=dev)
+        ws = ops._workspace(dev, int(L.fgnn_linear_wgrad_workspace_bytes(R, cin, cout)))
+        _hip.check(L.fgnn_linear_wgrad(_hip._ptr(x), _hip._ptr(gy), R, cin, cout, _hip.dtype_code(x), _hip._ptr(gw), _hip._ptr(gb),
+                                       _hip._ptr(ws), ws.numel() * 4, _hip.stream_ptr()))
+        outs.append((gw.clone(), gb.clone()))
+    gw, gb = outs[0]
+    assert float(((gw.double() - 1.0) - ref_w).abs().max()) <= 2e-5 * float(ref_w.abs().max())
+    assert float(((gb.double() - 2.0) - ref_b).abs().max()) <= 2e-5 * float(ref_b.abs().max())
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
