@@ -111,30 +111,15 @@ __global__ __launch_bounds__(WF_THREADS, 2) void linear_wgrad_f32_kernel(const W
     if (bias_role && o0 + tid < Cout) slab[(int64_t)Cout * Cin + o0 + tid] = bsum;
 }
 
-// out[i] += sum over the nrc slabs, in slab order (fixed: bit-reproducible); i < nw -> gW, else gb
-__global__ __launch_bounds__(256) void linear_wgrad_f32_fold_kernel(const float* __restrict__ ws, int nrc, int64_t nw, int64_t slab_len,
-                                                                    float* __restrict__ gW, float* __restrict__ gb) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= slab_len || (i >= nw && !gb)) return;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int w = 0;
-    for (; w + 3 < nrc; w += 4) {
-        s0 += ws[(int64_t)w * slab_len + i];
-        s1 += ws[(int64_t)(w + 1) * slab_len + i];
-        s2 += ws[(int64_t)(w + 2) * slab_len + i];
-        s3 += ws[(int64_t)(w + 3) * slab_len + i];
-    }
-    for (; w < nrc; ++w) s0 += ws[(int64_t)w * slab_len + i];
-    const float s = (s0 + s1) + (s2 + s3);
-    if (i < nw) gW[i] += s;
-    else gb[i - nw] += s;
-}
+// fold of the per-chunk slabs: the fixed-order, LDS-staged slab reduction shared with the operator backward kernels
+// (mpconv_bwd_res.hip: 16 elements x 16 slab groups per workgroup, every group walks its slabs in order)
+void fgnn_launch_slab_reduce(const float* ws, int nslab, int64_t slab_len, int64_t nw, float* gW, float* gbias, hipStream_t st);
 
 static void wf_plan(int64_t R, int Cin, int Cout, int* nrc, int* rows_per, int* nblk_o, int* nblk_c) {
     *nblk_o = (Cout + WF_BLK - 1) / WF_BLK;
     *nblk_c = (Cin + WF_BLK - 1) / WF_BLK;
     const int nblk = *nblk_o * *nblk_c;
-    int target = (nblk >= 4 ? 256 : 512) / nblk;          // enough workgroups for the chip; wide maps keep the slab traffic down
+    int target = 256 / nblk;                              // one workgroup per CU: enough for the chip, and the slab traffic stays down
     if (target < 1) target = 1;
     int64_t rows = (R + target - 1) / target;
     if (rows < 2 * WF_TR) rows = 2 * WF_TR;
@@ -146,9 +131,9 @@ static void wf_plan(int64_t R, int Cin, int Cout, int* nrc, int* rows_per, int* 
 // 1 if the f32 blocked kernel takes this call
 int fgnn_linear_wgrad_f32_accepts(int64_t R, int Cin, int Cout) {
     static const bool off = getenv("FGNN_NO_WGRAD_F32") != nullptr;
-    // narrower maps than 64 x 128 stay with the general kernel (64 x 64 at 61 440 rows: 38 us there, 58 us here)
+    // maps narrower than 64 x 64 stay with the general kernel (one block would be mostly padding)
     return !off && R >= 2048 && R <= 0x7fffffff && Cin % 4 == 0 && Cout % 4 == 0 && Cin >= 16 && Cout >= 16 && Cin <= 1024 && Cout <= 1024 &&
-           (int64_t)Cin * Cout >= 8192;
+           (int64_t)Cin * Cout >= 4096;
 }
 
 int64_t fgnn_linear_wgrad_f32_workspace_bytes(int64_t R, int Cin, int Cout) {
@@ -170,8 +155,7 @@ int fgnn_linear_wgrad_f32(const void* x, const void* gy, int64_t R, int Cin, int
     p.x = (const float*)x; p.gy = (const float*)gy; p.ws = (float*)workspace; p.R = (int)R; p.Cin = Cin; p.Cout = Cout;
     p.rows_per_chunk = rows; p.nblk_c = nbc; p.want_bias = gb != nullptr;
     hipLaunchKernelGGL(linear_wgrad_f32_kernel, dim3(nrc, nbo * nbc), dim3(WF_THREADS), 0, (hipStream_t)stream, p);
-    hipLaunchKernelGGL(linear_wgrad_f32_fold_kernel, dim3((unsigned)((slab_len + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       p.ws, nrc, nw, slab_len, gW, gb);
+    fgnn_launch_slab_reduce(p.ws, nrc, slab_len, nw, gW, gb, (hipStream_t)stream);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "linear_wgrad f32 launch: %s", hipGetErrorString(e));
     return 1;
