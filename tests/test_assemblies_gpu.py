@@ -723,7 +723,9 @@ def test_factor_mpnn_training_reduces_loss(tag, dev):
     em_pw = torch.nn.Sequential(C(3, 64, 1), torch.nn.ReLU(), C(64, 16, 1)).to(dev)
     em_hi = torch.nn.Sequential(C(hi_ef.shape[0], 64, 1), torch.nn.ReLU(), C(64, 16, 1)).to(dev)
     params = list(model.parameters()) + list(em_pw.parameters()) + list(em_hi.parameters())
-    opt = torch.optim.Adam(params, lr=3e-3)
+    # lr 1e-3: at the scripts' 3e-3 this batch sits on a plateau for 15-35 steps before it drops, and WHEN depends on the last
+    # bits of the gradients (tools/diag_loss.py); at 1e-3 every kernel variant is under 0.2 by step 20
+    opt = torch.optim.Adam(params, lr=1e-3)
     g = torch.Generator().manual_seed(11)
     nf = torch.rand(B, 2, 30, 1, generator=g)
     label = (nf[:, 1, :, 0] > nf[:, 0, :, 0]).long().to(dev)             # the better unary potential: learnable from the inputs
@@ -731,7 +733,7 @@ def test_factor_mpnn_training_reduces_loss(tag, dev):
     hi = torch.rand(B, hop_dim, 1 if tag == 'pw' else 30, 1, generator=g).to(dev)
     t = lambda a: torch.from_numpy(a).to(dev)[None]
     losses = []
-    for _ in range(25):
+    for _ in range(30):
         opt.zero_grad()
         et_pw, et_hi = em_pw(t(pw_ef)), em_hi(t(hi_ef))
         pred, _ = model(nf, [pws, hi], [[t(pw_idx).repeat(B, 1, 1), et_pw.repeat(B, 1, 1, 1)],       # the scripts' .repeat form
@@ -742,5 +744,5 @@ def test_factor_mpnn_training_reduces_loss(tag, dev):
         opt.step()
         losses.append(float(loss.detach()))
     assert all(l == l for l in losses), losses
-    assert losses[-1] < 0.7 * losses[0], losses
+    assert min(losses[-5:]) < 0.5 * losses[0], losses
     assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in params)

@@ -509,7 +509,8 @@ def test_bf16_forward_statistics_epilogue_feeds_batchnorm(shape, B, dev):
     assert not any(n.startswith('bn_stats') for n in names), names
 
 
-@pytest.mark.parametrize('R,cin,cout', [(61440, 128, 64), (61440, 256, 256), (5001, 512, 256), (2048, 64, 128), (30720, 132, 68), (4096, 1024, 16)])
+@pytest.mark.parametrize('R,cin,cout', [(61440, 128, 64), (61440, 256, 256), (5001, 512, 256), (2048, 64, 128), (30720, 132, 68), (4096, 1024, 16),
+                                         (3840, 64, 64), (3900, 64, 64), (3840, 256, 64), (2050, 64, 256), (15360, 64, 64)])
 def test_f32_blocked_weight_gradient_vs_torch(R, cin, cout, dev):
     """csrc/linear_wgrad_f32.hip (f32 node-wise maps of the synthetic-PGM models) through fgnn_linear_wgrad: against a float64
     torch product, accumulating into gW / gb, and bit-identical on a second run (slab fold in a fixed order)."""
