@@ -133,3 +133,25 @@ for Cin, Cout, N in [(64, 64, 96), (64, 64, 48), (128, 64, 96), (64, 128, 96)]:
     t0, t1, t2 = graph_time(lambda: f_fwd(False), 48), graph_time(lambda: f_fwd(True), 48), graph_time(f_wg, 48)
     print('bf16 R=%d %3d->%3d: forward %5.1f us (%.2f TB/s) | with statistics epilogue %5.1f us (%.2f TB/s) | weight gradient %5.1f us '
           '(%.2f TB/s)' % (R, Cin, Cout, t0, (mb_in + mb_out) / t0, t1, (mb_in + mb_out) / t1, t2, (mb_in + mb_out) / t2))
+
+# InstanceNorm (+ReLU) over the node axis, cold
+print('InstanceNorm, cold:')
+for C, N in [(64, 96), (128, 96), (256, 96), (64, 48), (256, 48)]:
+    Bn = 4096
+    K = max(3, int(2.4e9 // (Bn * N * C * 2 * 2)))
+    xs = [torch.randn(Bn, N, C, device=dev).bfloat16() for _ in range(K)]
+    ys = [torch.empty_like(xs[0]) for _ in range(K)]
+    gs = [torch.randn(Bn, N, C, device=dev).bfloat16() for _ in range(K)]
+    state = {'i': 0}
+    def nxt():
+        state['i'] = (state['i'] + 1) % K
+        return state['i']
+    def f_fwd():
+        i = nxt()
+        _hip.check(L.fgnn_instnorm_forward(_hip._ptr(xs[i]), _hip._ptr(ys[i]), Bn, N, C, 1, 1, _hip.stream_ptr()))
+    def f_bwd():
+        i = nxt()
+        _hip.check(L.fgnn_instnorm_backward(_hip._ptr(xs[i]), _hip._ptr(gs[i]), _hip._ptr(ys[i]), Bn, N, C, 1, 1, _hip.stream_ptr()))
+    mb = Bn * N * C * 2 / 1e6
+    t0, t1 = graph_time(f_fwd, 48), graph_time(f_bwd, 48)
+    print('bf16 [4096, %d, %3d] (%.0f MB): forward %6.1f us (%.2f TB/s of 2T) | backward %6.1f us (%.2f TB/s of 3T)' % (N, C, mb, t0, 2 * mb / t0, t1, 3 * mb / t1))
