@@ -288,7 +288,17 @@ def main_syn(args):
         else:
             compute()
         if train:
-            bucket.all_reduce_sum()
+            if os.environ.get('FGNN_BENCH_STEP_TIMES') is not None:
+                torch.cuda.synchronize()
+                ta = time.perf_counter()
+                bucket.all_reduce_sum()
+                torch.cuda.synchronize()
+                gf = bucket.flat
+                print('rank %d all-reduce %.3f ms; finite %s, |g| %.3e, denormal %d' % (
+                    rank, (time.perf_counter() - ta) * 1e3, bool(torch.isfinite(gf).all()), float(gf.abs().max()),
+                    int(((gf != 0) & (gf.abs() < 1.2e-38)).sum())), file=sys.stderr)
+            else:
+                bucket.all_reduce_sum()
             # torch.nn.utils.clip_grad_norm(parameters, 1.0) on the flat gradient, without a host round trip
             gflat = bucket.flat
             norm = torch.linalg.vector_norm(gflat) / world
@@ -304,9 +314,14 @@ def main_syn(args):
     for _ in range(args.warmup):
         step()
     fence()
+    trace_steps = os.environ.get('FGNN_BENCH_STEP_TIMES') is not None   # diagnosis: per-step wall times (adds a device sync per step)
     t0 = time.perf_counter()
     for _ in range(args.steps):
+        t1 = time.perf_counter()
         step()
+        if trace_steps:
+            torch.cuda.synchronize()
+            print('rank %d step %.3f ms' % (rank, (time.perf_counter() - t1) * 1e3), file=sys.stderr)
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -498,9 +513,14 @@ def main():
     _trace('warmup enqueued')
     fence()
     _trace('warmup done')
+    trace_steps = os.environ.get('FGNN_BENCH_STEP_TIMES') is not None   # diagnosis: per-step wall times (adds a device sync per step)
     t0 = time.perf_counter()
     for _ in range(args.steps):
+        t1 = time.perf_counter()
         step()
+        if trace_steps:
+            torch.cuda.synchronize()
+            print('rank %d step %.3f ms' % (rank, (time.perf_counter() - t1) * 1e3), file=sys.stderr)
     fence()
     elapsed = time.perf_counter() - t0
     _trace('timed steps done')

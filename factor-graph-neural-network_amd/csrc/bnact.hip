@@ -137,6 +137,12 @@ __global__ __launch_bounds__(BN_THREADS) void bn_reduce_kernel(const BnParams p)
     }
 }
 
+// K = row 0 of x (f32 path)
+__global__ void bn_ref_kernel(const float* x, float* ref, int C) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c < C) ref[c] = x[c];
+}
+
 // Sum of the workgroup partials of one channel: 16 channels x 16 partial groups per block, folded in LDS.
 // 4 channels x 64 partial groups per block (grid = C/4 blocks: enough workgroups in flight to cover the
 // cross-die latency of partials written on all 8 XCDs); folded in f64 through LDS in a fixed order.
@@ -317,7 +323,8 @@ extern "C" int fgnn_bn_stats(const void* x, int64_t R, int C, int dtype, const f
     float* ref = ws + (int64_t)BN_MAXPART * 2 * C;          // per-channel shift K = x[0][:]
     hipStream_t st = (hipStream_t)stream;
     // K: copy row 0 as f32 (tiny) — reuse the apply kernel's chunk loader through a 1-row reduce is overkill
-    if (dtype == FGNN_F32) (void)hipMemcpyAsync(ref, x, (size_t)C * 4, hipMemcpyDeviceToDevice, st);
+    // (a kernel, not hipMemcpyAsync: copy / memset NODES of a captured hipGraph have been seen to run out of order on replay)
+    if (dtype == FGNN_F32) hipLaunchKernelGGL(bn_ref_kernel, dim3((C + 255) / 256), dim3(256), 0, st, (const float*)x, ref, C);
     else ref = nullptr;      // bf16: accumulate against K = 0 (values are O(1) after the preceding map; f32 sums, f64 finaliser)
     p.x = x; p.ws = ws; p.ref = ref;
     if (dtype == FGNN_F32) hipLaunchKernelGGL((bn_reduce_kernel<float, 0>), dim3(grid), dim3(BN_THREADS), 0, st, p);

@@ -510,6 +510,7 @@ __global__ __launch_bounds__(BX_THREADS, 2) void mpconv_bwd_ext_kernel(const BxP
     }
 }
 
+void fgnn_launch_slab_store(const float* ws, int nslab, int64_t slab_len, float* out, hipStream_t st);
 void fgnn_launch_slab_reduce(const float* ws, int nslab, int64_t slab_len, int64_t nw, float* gW, float* gbias,
                              hipStream_t st);
 
@@ -624,9 +625,7 @@ int fgnn_mpconv_backward_ext(const fgnn_mpconv_desc* d, const void* x, const int
 #endif
     fgnn_launch_slab_reduce(p.ws, grid, slab_len, nw, gfilters, gbias, (hipStream_t)stream);
     if (getype) {
-        e = hipMemsetAsync(getype, 0, get_len * 4, (hipStream_t)stream);
-        if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "memset: %s", hipGetErrorString(e));
-        fgnn_launch_slab_reduce(p.get_ws, grid, get_len, get_len, (float*)getype, nullptr, (hipStream_t)stream);
+        fgnn_launch_slab_store(p.get_ws, grid, get_len, (float*)getype, (hipStream_t)stream);
     }
     e = hipGetLastError();
     if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "mpconv ext backward helper launch: %s", hipGetErrorString(e));

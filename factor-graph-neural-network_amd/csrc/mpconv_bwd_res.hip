@@ -563,7 +563,7 @@ __global__ __launch_bounds__(BR_THREADS) void mpconv_bwd_res_kernel(const BresPa
 // the 16 partials of an element are folded in a fixed order through LDS (bit-reproducible).
 __global__ __launch_bounds__(256) void bres_reduce_kernel(const float* __restrict__ ws, int nslab, int64_t slab_len,
                                                           int64_t nw, float* __restrict__ gW,
-                                                          float* __restrict__ gbias) {
+                                                          float* __restrict__ gbias, int overwrite) {
     __shared__ float part[16][17];
     const int e = threadIdx.x & 15, g = threadIdx.x >> 4;
     const int64_t i = (int64_t)blockIdx.x * 16 + e;
@@ -585,8 +585,8 @@ __global__ __launch_bounds__(256) void bres_reduce_kernel(const float* __restric
         float s = 0.f;
 #pragma unroll
         for (int q = 0; q < 16; ++q) s += part[q][e];
-        if (i < nw) gW[i] += s;
-        else if (gbias) gbias[i - nw] += s;
+        if (i < nw) gW[i] = overwrite ? s : gW[i] + s;
+        else if (gbias) gbias[i - nw] = overwrite ? s : gbias[i - nw] + s;
     }
 }
 
@@ -594,7 +594,13 @@ __global__ __launch_bounds__(256) void bres_reduce_kernel(const float* __restric
 void fgnn_launch_slab_reduce(const float* ws, int nslab, int64_t slab_len, int64_t nw, float* gW, float* gbias,
                              hipStream_t st) {
     hipLaunchKernelGGL(bres_reduce_kernel, dim3((unsigned)((slab_len + 15) / 16)), dim3(256), 0, st, ws, nslab,
-                       slab_len, nw, gW, gbias);
+                       slab_len, nw, gW, gbias, 0);
+}
+
+// The same fold, STORED (out[i] = sum_w ws[w][i]): for outputs that are not accumulators (the batch-summed edge-type gradient).
+void fgnn_launch_slab_store(const float* ws, int nslab, int64_t slab_len, float* out, hipStream_t st) {
+    hipLaunchKernelGGL(bres_reduce_kernel, dim3((unsigned)((slab_len + 15) / 16)), dim3(256), 0, st, ws, nslab,
+                       slab_len, slab_len, out, (float*)nullptr, 1);
 }
 
 void fgnn_launch_w_transpose(const float* W, float* Wt, int nin, int ncols, hipStream_t st) {

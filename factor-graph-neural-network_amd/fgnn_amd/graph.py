@@ -12,21 +12,25 @@ import torch
 
 class StepGraph:
     def __init__(self, fn, warmup=2):
-        """``fn()`` is run ``warmup`` times on a side stream (allocator / workspace / autotune warm-up),
-        then captured."""
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
+        """``fn()`` is run ``warmup`` times (allocator / workspace / autotune warm-up), then captured — both on ONE side
+        stream.  Autograd runs a leaf's gradient accumulation on the stream the leaf was first used on; if the warm-up ran
+        on another stream than the capture, parameters whose gradients come through autograd (plain torch modules such as
+        the edge models of train_syn_*.py, not this package's gradient-sink kernels) would be accumulated on a branch of
+        the graph while the allocator, which only knows the capture stream, hands the incoming gradient's memory to the
+        next kernel: replayed steps then add garbage into those gradients (tools/diag_graph.py)."""
+        self.stream = torch.cuda.Stream()
+        self.stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.stream):
             for _ in range(warmup):
                 fn()
-        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.current_stream().wait_stream(self.stream)
         torch.cuda.synchronize()
         # cached low-precision weight copies are refreshed in place where they are stale: make them stale now, so the
         # refresh kernels are captured and every replay casts the parameters as they are at that moment
         from .mpnn import pointwise
         pointwise.invalidate_casts()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        with torch.cuda.graph(self.graph, stream=self.stream):
             fn()
 
     def replay(self):

@@ -746,3 +746,59 @@ def test_factor_mpnn_training_reduces_loss(tag, dev):
     assert all(l == l for l in losses), losses
     assert min(losses[-5:]) < 0.5 * losses[0], losses
     assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in params)
+
+
+@pytest.mark.parametrize('tag', ['pw', 'hop'])
+def test_factor_mpnn_graph_replays_equal_eager_steps(tag, dev):
+    """`bench.py --workload syn_*` times hipGraph replays of the training step: each replay must leave the gradients the eager
+    step leaves, bit for bit, over several optimizer steps — for the package's own parameters (gradient-sink kernels) AND for
+    the plain torch edge models, whose gradients come through the batch-summed edge-type gradient of csrc/mpconv_bwd_ext.hip.
+    (A captured hipMemsetAsync in front of that sum ran out of order on replay: finite garbage in exactly those gradients from
+    the second replay on, depending on the allocator's layout — nothing of the step is kept alive here, as in bench.py.)"""
+    import fgnn_amd
+    from fgnn_amd.dp import FlatAdam, FlatGradBucket
+    from fgnn_amd.graph import StepGraph
+
+    hop_dim, pw_idx, pw_ef, hi_idx, hi_ef = H.syn_setup(tag)
+    B = 256
+    torch.manual_seed(21)
+    model = fgnn_amd.factor_mpnn(2, [4, hop_dim], O.SYN_DIMS, [16, 16]).to(dev).train()
+    C = torch.nn.Conv2d
+    em_pw = torch.nn.Sequential(C(3, 64, 1), torch.nn.ReLU(inplace=True), C(64, 16, 1)).to(dev)
+    em_hi = torch.nn.Sequential(C(hi_ef.shape[0], 64, 1), torch.nn.ReLU(inplace=True), C(64, 16, 1)).to(dev)
+    everything = torch.nn.ModuleList([model, em_pw, em_hi])
+    bucket = FlatGradBucket(everything.parameters(), flatten_params=True)
+    opt = FlatAdam(bucket, lr=3e-3)
+    g = torch.Generator().manual_seed(9)
+    nf, pws = torch.rand(B, 2, 30, 1, generator=g).to(dev), torch.rand(B, 4, 30, 1, generator=g).to(dev)
+    hi = torch.rand(B, hop_dim, 1 if tag == 'pw' else 30, 1, generator=g).to(dev)
+    label = torch.randint(0, 2, (B, 30), generator=g).to(dev)
+    t = lambda a: torch.from_numpy(a).to(dev)[None]
+    idx_pw, idx_hi, ef_pw, ef_hi = t(pw_idx), t(hi_idx), t(pw_ef), t(hi_ef)
+
+    def compute():
+        bucket.zero()
+        et_pw, et_hi = em_pw(ef_pw), em_hi(ef_hi)
+        pred, _ = model(nf, [pws, hi], [[idx_pw.expand(B, -1, -1), et_pw.expand(B, -1, -1, -1)],
+                                       [idx_hi.expand(B, -1, -1), et_hi.expand(B, -1, -1, -1)]])
+        torch.nn.functional.cross_entropy(pred.squeeze(-1).permute(0, 2, 1).reshape(-1, 2), label.reshape(-1)).backward()
+
+    prev_cudnn = torch.backends.cudnn.enabled
+    torch.backends.cudnn.enabled = False          # as bench.py: no MIOpen find-mode inside the capture
+    try:
+        graph = StepGraph(compute)
+        for step in range(4):
+            buffers = [b.clone() for b in everything.buffers()]
+            graph.replay()
+            torch.cuda.synchronize()
+            g_graph = bucket.flat.clone()
+            for b, s in zip(everything.buffers(), buffers):      # the eager step starts from the same running statistics
+                b.copy_(s)
+            compute()
+            torch.cuda.synchronize()
+            assert bool(torch.isfinite(g_graph).all())
+            assert torch.equal(g_graph, bucket.flat), 'step %d: max |graph - eager| %.3e of %.3e' % (
+                step, float((g_graph - bucket.flat).abs().max()), float(bucket.flat.abs().max()))
+            opt.step()
+    finally:
+        torch.backends.cudnn.enabled = prev_cudnn
