@@ -16,6 +16,9 @@ from .pointwise import NodeInstanceNorm, PointwiseConv2d as _Conv, add_all
 from .message_op import base_mp_nn, mp_conv_type, mp_conv_v2
 
 
+FUSE_EVAL_LAYERS = True      # inference: a 64 -> 64 bf16 FactorNN layer of the LDPC shape runs as ONE kernel (csrc/factor_layer_fwd.hip)
+
+
 def _call(module, x, nn_idx, etype, addend=None):
     """The reference's dispatch contract: graph-aware modules get (x, nn_idx, etype).  ``addend`` is this
     build's extra: blocks that end in a fused BatchNorm+activation kernel add it there (``acc + block(x)``
@@ -203,6 +206,83 @@ class FactorNN(torch.nn.Module):
             _Conv(dim_mapping_list[-1], 128, 1), NodeInstanceNorm(relu=True),
             torch.nn.Identity(), _Conv(128, final_dim, 1, bias=True))
 
+    def _fused_layer(self, L, var, fac, skip, nn_idx_f2v, nn_idx_v2f, etype_f2v, etype_v2f):
+        """Inference: layer ``L`` as one kernel (csrc/factor_layer_fwd.hip) when it is a 64 -> 64 layer of the
+        LDPC shape — bf16 channel-fastest states of 96 variables / 48 degree-6 checks / one hyper-factor, neighbour tables
+        shared by the batch, four foldable blocks.  Returns (new_var, new_fac) or None (the staged path then runs)."""
+        import ctypes
+        from .. import _hip
+        from .blocks import _is_identity_list
+        from .pointwise import refresh_in_place, state_epoch
+        dims = self.dim_mapping_list
+        if (not FUSE_EVAL_LAYERS or self.training or torch.is_grad_enabled() or self.nfactor_types != 2
+                or dims[L] != 64 or dims[L + 1] != 64 or not var.is_cuda or var.dtype != torch.bfloat16):
+            return None
+        B = var.shape[0]
+        blocks = [self.v2f_modules[L][0], self.f2v_modules[L][0], self.v2f_modules[L][1], self.f2v_modules[L][1]]
+        nets = [4, 4, 1, 1]
+        maps = [self.v2v_modules[L], self.f2f_modules[L][0]]
+        if not all(isinstance(m, mp_conv_residual) and m.fusable_for_inference() and m.mp_conv.nedge_types == n
+                   and m.conv1[0].in_channels == 64 and m.conv2[0].out_channels == 64 for m, n in zip(blocks, nets)):
+            return None
+        if len({float(m.conv1[1].slope) for m in blocks}) != 1:
+            return None
+        if not all(isinstance(m, iid_mapping_in) and isinstance(m.main[0], _Conv) and m.main[0].in_channels == 64
+                   and m.main[0].out_channels == 64 and isinstance(m.main[1], NodeInstanceNorm) and m.main[1].relu for m in maps):
+            return None
+        cl = lambda t, n: tuple(t.shape) == (B, 64, n, 1) and t.dtype == var.dtype and t.permute(0, 2, 3, 1).is_contiguous()
+        if not (cl(var, 96) and cl(fac[0], 48) and tuple(fac[1].shape) == (B, 64, 1, 1) and fac[1].dtype == var.dtype):
+            return None
+        if skip is not None and not (cl(skip[0], 96) and cl(skip[1][0], 48) and tuple(skip[1][1].shape) == (B, 64, 1, 1)):
+            return None
+        iv, if_ = nn_idx_v2f[0], nn_idx_f2v[0]
+        if not (tuple(iv.shape) == (B, 48, 6) and tuple(if_.shape) == (B, 96, 3) and (B == 1 or (iv.stride(0) == 0 and if_.stride(0) == 0))
+                and iv.dtype == torch.int64 and if_.dtype == torch.int64):
+            return None
+        hv2f, hf2v = nn_idx_v2f[1], nn_idx_f2v[1]
+        if not (tuple(hv2f.shape) == (B, 1, 96) and tuple(hf2v.shape) == (B, 96, 1) and _is_identity_list(hv2f)):
+            return None
+        ev, ef, hev, hef = etype_v2f[0][L], etype_f2v[0][L], etype_v2f[1][L], etype_f2v[1][L]
+
+        def et_ok(e, M, k):
+            q = e.permute(0, 2, 3, 1)
+            return (tuple(e.shape) == (B, 4, M, k) and e.dtype == var.dtype
+                    and (q.is_contiguous() or (e.stride(0) == 0 and q[0].is_contiguous())) and e.stride(0) % 4 == 0)
+        if not (et_ok(ev, 48, 6) and et_ok(ef, 96, 3)):
+            return None
+        if not (tuple(hev.shape) == (B, 1, 1, 96) and tuple(hef.shape) == (B, 1, 96, 1) and hev.dtype == var.dtype and hef.dtype == var.dtype
+                and (B == 1 or (hev.stride(0) == 0 and hef.stride(0) == 0)) and hev.stride(3) == 1 and hef.stride(2) == 1):
+            return None
+        # packed parameters: maps, then per block W1, s1, t1, filters, s2, t2, W2, s3, t3 (refreshed in place when anything moved)
+        folded = [m.folded_for_inference(var.device) for m in blocks]
+        key = tuple(m._fuse_key for m in blocks) + tuple(m.main[0].weight._version for m in maps) + (state_epoch(),)
+        cache = self.__dict__.setdefault('_layer_pack', {})
+        ent = cache.get(L)
+        if ent is None or ent[0] != key:
+            flat = torch.cat([m.main[0].weight.detach().float().reshape(-1) for m in maps] +
+                             [t.reshape(-1) for f in folded for t in f])
+            assert flat.numel() == int(_hip.lib().fgnn_factor_layer_param_count()), flat.numel()
+            ent = cache[L] = (key, refresh_in_place(ent[1] if ent is not None else None, (flat,)))
+        params = ent[1][0]
+        new_var = torch.empty((B, 96, 1, 64), device=var.device, dtype=var.dtype).permute(0, 3, 1, 2)
+        new_f0 = torch.empty((B, 48, 1, 64), device=var.device, dtype=var.dtype).permute(0, 3, 1, 2)
+        new_f1 = torch.empty((B, 1, 1, 64), device=var.device, dtype=var.dtype).permute(0, 3, 1, 2)
+        f1 = fac[1].reshape(B, 64)
+        s1 = skip[1][1].reshape(B, 64) if skip is not None else None
+        if not f1.is_contiguous():
+            f1 = f1.contiguous()
+        if s1 is not None and not s1.is_contiguous():
+            s1 = s1.contiguous()
+        P = _hip._ptr
+        rc = _hip.lib().fgnn_factor_layer_forward(
+            B, P(var), P(fac[0]), P(f1), P(skip[0]) if skip is not None else None, P(skip[1][0]) if skip is not None else None,
+            P(s1), P(iv), iv.stride(1), iv.stride(2), P(if_), if_.stride(1), if_.stride(2), P(ev), ev.stride(0), P(ef), ef.stride(0),
+            P(hev), P(hef), P(params), 1, float(blocks[0].conv1[1].slope), P(new_var), P(new_f0), P(new_f1), _hip.stream_ptr())
+        if rc == _hip.EUNSUPPORTED:
+            return None
+        _hip.check(rc)
+        return new_var, [new_f0, new_f1]
+
     def mpnn_forward(self, mpnn, node_feature, nn_idx, efeature):
         return _call(mpnn, node_feature, nn_idx, efeature)
 
@@ -226,6 +306,14 @@ class FactorNN(torch.nn.Module):
             same_width = self.dim_mapping_list[L] == self.dim_mapping_list[L + 1]
             res = 1 if same_width else 0
             keep = 1 if (L - 1) in skip_src else 0       # the incoming state is also a later layer's skip input
+            if not torch.is_grad_enabled() and not self.training:
+                if keep:
+                    history[L - 1] = [var, list(fac)]
+                fused = self._fused_layer(L, var, fac, history[self.skip_link[L]] if L in self.skip_link else None,
+                                          nn_idx_f2v, nn_idx_v2f, etype_f2v, etype_v2f)
+                if fused is not None:
+                    var, fac = fused
+                    continue
             # every state feeds several consumers (v2v / f2f map, the message blocks, the residual, a skip link):
             # hand each its own alias so that the backward sums their gradients in one kernel (ops.fan_out)
             var_c = fan_out(var, 1 + nft + res + keep)

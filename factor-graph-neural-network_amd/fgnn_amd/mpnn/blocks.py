@@ -98,6 +98,43 @@ class mp_conv_residual(base_mp_nn):
         self.with_residual = with_residual
         self.with_hop = with_hop
 
+    def folded_for_inference(self, device):
+        """(W1 [64][nin], s1, t1, filters, s2, t2, W2 [nout][64], s3, t3) as f32: conv weights, operator filters and the three
+        eval-mode BatchNorms (with the conv / operator biases) folded into per-channel affines — what the one-kernel block
+        and the one-kernel layer (csrc/factor_layer_fwd.hip) take.  Cached; refreshed IN PLACE when a parameter, a buffer or
+        the package's state epoch moved (a captured inference graph holds these addresses)."""
+        mp = self.mp_conv
+        bn1, bn2, bn3 = self.conv1[1], mp.bn, self.conv2[1]
+        nin, nout = self.conv1[0].in_channels, self.conv2[0].out_channels
+        key = tuple(t._version for t in (self.conv1[0].weight, self.conv1[0].bias, bn1.weight, bn1.bias, bn1.running_mean,
+                                         bn1.running_var, mp.filters, mp.bias, bn2.weight, bn2.bias, bn2.running_mean,
+                                         bn2.running_var, self.conv2[0].weight, self.conv2[0].bias, bn3.weight, bn3.bias,
+                                         bn3.running_mean, bn3.running_var)) + (device, pointwise_state_epoch())
+        if getattr(self, '_fuse_key', None) != key:
+            def fold(bn, bias):
+                s = bn.weight.float() * torch.rsqrt(bn.running_var.float() + bn.eps)
+                t = bn.bias.float() - bn.running_mean.float() * s
+                return s.contiguous(), (t + (bias.float() * s if bias is not None else 0)).contiguous()
+            s1, t1 = fold(bn1, self.conv1[0].bias)
+            s2, t2 = fold(bn2, mp.bias)
+            s3, t3 = fold(bn3, self.conv2[0].bias)
+            self._fuse = refresh_in_place(getattr(self, '_fuse', None), (
+                self.conv1[0].weight.detach().float().reshape(64, nin), s1, t1,
+                mp.filters.detach().float(), s2, t2,
+                self.conv2[0].weight.detach().float().reshape(nout, 64), s3, t3))
+            self._fuse_key = key
+        return self._fuse
+
+    def fusable_for_inference(self):
+        """The block is of the family the one-kernel inference paths fold: nmed 64, max aggregation, no extension, operator
+        bias + BatchNorm + ReLU, BatchNorm + LeakyReLU (one slope) behind both 1x1 maps, no residual of its own."""
+        mp = self.mp_conv
+        bn1, bn2, bn3 = self.conv1[1], mp.bn, self.conv2[1]
+        return (not self.with_residual and mp.nin == 64 and mp.nou == 64 and mp.nedge_types in (1, 4) and mp.aggregtor == 'max'
+                and mp.extension == mp_conv_type.NO_EXTENSION and bn2 is not None and mp.bias is not None
+                and isinstance(mp.activation_fn, torch.nn.ReLU) and isinstance(bn1, BatchNormAct2d)
+                and isinstance(bn3, BatchNormAct2d) and bn1.slope == bn3.slope)
+
     def _fused_eval(self, x, nn_idx, etype, addend):
         """Inference: the whole block as ONE kernel (csrc/mpconv_block_fwd.hip) when it is the 64-wide bf16
         parity-check shape; None otherwise."""
@@ -128,24 +165,7 @@ class mp_conv_residual(base_mp_nn):
             ar = addend.permute(0, 2, 3, 1)
             if addend.dtype != x.dtype or not ar.is_contiguous():
                 return None
-        key = tuple(t._version for t in (self.conv1[0].weight, self.conv1[0].bias, bn1.weight, bn1.bias, bn1.running_mean,
-                                         bn1.running_var, mp.filters, mp.bias, bn2.weight, bn2.bias, bn2.running_mean,
-                                         bn2.running_var, self.conv2[0].weight, self.conv2[0].bias, bn3.weight, bn3.bias,
-                                         bn3.running_mean, bn3.running_var)) + (x.device, pointwise_state_epoch())
-        if getattr(self, '_fuse_key', None) != key:
-            def fold(bn, bias):
-                s = bn.weight.float() * torch.rsqrt(bn.running_var.float() + bn.eps)
-                t = bn.bias.float() - bn.running_mean.float() * s
-                return s.contiguous(), (t + (bias.float() * s if bias is not None else 0)).contiguous()
-            s1, t1 = fold(bn1, self.conv1[0].bias)
-            s2, t2 = fold(bn2, mp.bias)
-            s3, t3 = fold(bn3, self.conv2[0].bias)
-            self._fuse = refresh_in_place(getattr(self, '_fuse', None), (
-                self.conv1[0].weight.detach().float().reshape(64, nin), s1, t1,
-                mp.filters.detach().float(), s2, t2,
-                self.conv2[0].weight.detach().float().reshape(nout, 64), s3, t3))
-            self._fuse_key = key
-        W1, s1, t1, F, s2, t2, W2, s3, t3 = self._fuse
+        W1, s1, t1, F, s2, t2, W2, s3, t3 = self.folded_for_inference(x.device)
         y = torch.empty((B, M, 1, nout), device=x.device, dtype=x.dtype).permute(0, 3, 1, 2)
         d = _hip.make_desc(x, nn_idx, etype, 64, mp.nedge_types, _hip.EXT_NONE, _hip.AGG_MAX, True, y)
         d.nin = 64                      # the inner operator's width; x / y strides stay the block's

@@ -210,6 +210,30 @@ int fgnn_mpconv_block_forward_fanin(const fgnn_mpconv_desc* d, const void* x, co
                                      int32_t nin, int32_t nout, const void* addend, void* y, fgnn_stream_t stream);
 
 /*
+ * §8f-3 — ONE WHOLE 64 -> 64 `FactorNN` layer of the LDPC model in one kernel, inference
+ * (/root/reference/lib/model/mpnn/factor_mpnn_sp.py:136-168: v2v / f2f `iid_mapping_in` maps, the F->V and V->F
+ * `mp_conv_residual` blocks of the parity checks and of the hyper-factor, residual and skip-link sums):
+ *     var'  = ReLU(IN(Wvv var))  + f2v_parity(fac0) + f2v_hyper(fac1) + [residual] var  + skip_var
+ *     fac0' = ReLU(IN(Wff fac0)) + v2f_parity(var)                    + [residual] fac0 + skip_fac0
+ *     fac1' =                      v2f_hyper(var)                     + [residual] fac1 + skip_fac1
+ * States are bf16 channel-fastest: var [B][96][64], fac0 [B][48][64], fac1 [B][64]; skip_* (NULL = none) and out_* have the
+ * same layouts.  idx_v2f [48][6] / idx_f2v [96][3]: the neighbour tables, SHARED by the batch (strides in elements);
+ * et_* the parity edge types [B][M][k][4] (edge-type-fastest) with batch strides in elements; het_* the hyper-factor's
+ * per-edge weights ([96] bf16, shared by the batch; NULL = ones, what train_ldpc.py:60-75 passes).
+ * params: fgnn_factor_layer_param_count() float32 values — Wvv [64][64], Wff [64][64] ([out][in]), then for the blocks
+ * V->F parity, F->V parity, V->F hyper, F->V hyper: W1 [64][64], s1 [64], t1 [64], filters [64][64 * net], s2, t2, W2
+ * [64][64], s3, t3, with conv / operator biases and the eval-mode BatchNorms folded into the (s, t) affines as for
+ * fgnn_mpconv_block_forward.  slope: the blocks' LeakyReLU slope.
+ */
+int64_t fgnn_factor_layer_param_count(void);
+int fgnn_factor_layer_forward(int32_t B, const void* var, const void* fac0, const void* fac1, const void* skip_var,
+                              const void* skip_fac0, const void* skip_fac1, const int64_t* idx_v2f, int32_t idx_v2f_sm,
+                              int32_t idx_v2f_sk, const int64_t* idx_f2v, int32_t idx_f2v_sm, int32_t idx_f2v_sk,
+                              const void* et_v2f, int64_t et_v2f_sb, const void* et_f2v, int64_t et_f2v_sb,
+                              const void* het_v2f, const void* het_f2v, const float* params, int32_t residual, float slope,
+                              void* out_var, void* out_fac0, void* out_fac1, fgnn_stream_t stream);
+
+/*
  * out = inputs[0] + ... + inputs[n-1] (n <= 8) over dense arrays of `numel` elements in one pass — the gradient of
  * a state that fans out into several consumers (factor_mpnn_sp.py:139-170) instead of autograd's pairwise adds.
  */

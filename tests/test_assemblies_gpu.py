@@ -802,3 +802,80 @@ def test_factor_mpnn_graph_replays_equal_eager_steps(tag, dev):
             opt.step()
     finally:
         torch.backends.cudnn.enabled = prev_cudnn
+
+
+@pytest.mark.parametrize('B', [3, 70, 300])
+@pytest.mark.parametrize('hyper_weights', ['ones', 'random'])
+def test_one_kernel_factor_layer_vs_per_block_path_and_oracle(B, hyper_weights, dev):
+    """a 64 -> 64 `FactorNN` layer as ONE kernel (csrc/factor_layer_fwd.hip) — v2v / f2f maps with their
+    InstanceNorms, the four mp_conv_residual blocks, residual and skip-link sums — against (a) the per-block inference path
+    of the same model and (b) the f32 ORACLE's FactorNN (factor_mpnn_sp.py:136-168 in the reference's op order).  Three
+    64-wide layers, the last with a skip link from the first's output; batches below, around and above the grid size;
+    the hyper-factor's edge weights as train_ldpc.py passes them (ones) and arbitrary."""
+    import fgnn_amd
+    from fgnn_amd import _hip
+    from fgnn_amd.ldpc import synthetic_batch
+    from fgnn_amd.mpnn import assemblies
+    torch.manual_seed(17)
+    net = fgnn_amd.mpnn.FactorNN(2, [6, 96], [64, 64, 64, 64], [4, 1], 2, skip_link={2: 0}, ret_high=True, aggregator='max').to(dev)
+    with torch.no_grad():                                # BatchNorm affines / statistics that are not the identity
+        for mod in net.modules():
+            if isinstance(mod, torch.nn.modules.batchnorm._BatchNorm):
+                mod.running_mean.normal_(0, 0.2)
+                mod.running_var.uniform_(0.5, 1.5)
+                mod.weight.uniform_(0.7, 1.3)
+                mod.bias.normal_(0, 0.2)
+    net.eval()
+    node, hop, idx_f2v, idx_v2f = synthetic_batch(B, dev, seed=4, dtype=torch.bfloat16)[:4]
+    g = torch.Generator().manual_seed(8)
+    et_f2v = torch.randn(B, 96, 3, 4, generator=g).to(dev, torch.bfloat16).permute(0, 3, 1, 2)
+    et_v2f = torch.randn(B, 48, 6, 4, generator=g).to(dev, torch.bfloat16).permute(0, 3, 1, 2)
+    hyper_in = node[:, 0, :, :].reshape(B, 96, 1, 1)
+    hidx_v2f = torch.arange(96, device=dev).reshape(1, 1, 96).expand(B, -1, -1)
+    hidx_f2v = torch.zeros(1, 96, 1, dtype=torch.int64, device=dev).expand(B, -1, -1)
+    if hyper_weights == 'ones':
+        het_v2f, het_f2v = torch.ones(1, 1, 1, 96, device=dev), torch.ones(1, 1, 96, 1, device=dev)
+    else:
+        het_v2f, het_f2v = torch.randn(1, 1, 1, 96, generator=g).to(dev), torch.randn(1, 1, 96, 1, generator=g).to(dev)
+    het_v2f, het_f2v = het_v2f.to(torch.bfloat16).expand(B, -1, -1, -1), het_f2v.to(torch.bfloat16).expand(B, -1, -1, -1)
+    args = (node, [hop, hyper_in], [idx_f2v, hidx_f2v], [idx_v2f, hidx_v2f], [et_f2v, het_f2v], [et_v2f, het_v2f])
+
+    def run(fused):
+        assemblies.FUSE_EVAL_LAYERS = fused
+        try:
+            with torch.no_grad(), torch.autocast(device_type='cuda', dtype=torch.bfloat16):
+                out, facs = net(*args)
+            torch.cuda.synchronize()
+            return out.float(), [f.float() for f in facs]
+        finally:
+            assemblies.FUSE_EVAL_LAYERS = True
+
+    calls = []
+    real = assemblies.FactorNN._fused_layer
+
+    def spy(self, L, *a, **k):
+        r = real(self, L, *a, **k)
+        calls.append((L, r is not None))
+        return r
+    assemblies.FactorNN._fused_layer = spy
+    try:
+        y1, f1 = run(True)
+    finally:
+        assemblies.FactorNN._fused_layer = real
+    assert calls == [(0, True), (1, True), (2, True)], calls          # every layer took the one-kernel path
+    y0, f0 = run(False)
+    for a, b in [(y1, y0), (f1[0], f0[0]), (f1[1], f0[1])]:
+        assert torch.isfinite(a).all()
+        assert H.rel_err(a, b) <= 2.0 ** -5, H.rel_err(a, b)           # two bf16 pipelines that round at different points
+    # the f32 oracle on the same (bf16-rounded) inputs and parameters
+    sd = {'main.' + k: v.detach().float().cpu() for k, v in net.state_dict().items()}
+    cpu = lambda t: t.detach().cpu().float() if t.is_floating_point() else t.detach().cpu()
+    with torch.no_grad():
+        yo, fo = O.factor_nn(sd, 'main.', cpu(node), [cpu(hop), cpu(hyper_in)], [cpu(idx_f2v), cpu(hidx_f2v)],
+                             [cpu(idx_v2f), cpu(hidx_v2f)], [cpu(et_f2v), cpu(het_f2v)], [cpu(et_v2f), cpu(het_v2f)],
+                             dims=[64, 64, 64, 64], netypes=[4, 1], skip_link={2: 0})
+    e1, e0 = H.rel_err(y1.cpu(), yo), H.rel_err(y0.cpu(), yo)
+    print('one-kernel layers vs oracle %.3e, per-block path vs oracle %.3e (B = %d)' % (e1, e0, B))
+    assert e1 <= 2.0 ** -5, e1
+    assert H.rel_err(f1[0].cpu(), fo[0]) <= 2.0 ** -5
+    assert H.rel_err(f1[1].cpu(), fo[1]) <= 2.0 ** -5

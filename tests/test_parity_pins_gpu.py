@@ -40,15 +40,20 @@ def _decision_agreement(a, b, margin):
     return float(((a > 0) == (b > 0))[firm].float().mean()), float(firm.float().mean())
 
 
-@pytest.mark.parametrize('mode', ['eval', 'train'])
+@pytest.mark.parametrize('mode', ['eval', 'eval_per_block_kernels', 'train'])
 def test_benched_bf16_model_vs_f32_oracle(mode, dev):
     """The configuration bench.py measures — bf16 activations / messages / matrix cores, f32 parameters — against the
     f32 ORACLE (reference op order) on the same inputs and parameters.
-    eval: the full 4096-codeword data-path batch runs on the GPU (one-kernel inference blocks and all); 96 codewords
-    picked from it are decoded by the oracle.  train: BatchNorm uses batch statistics, so the same 128 picked codewords
+    eval: the full 4096-codeword data-path batch runs on the GPU (one-kernel 64-wide layers, one-kernel inference blocks
+    and all; `eval_per_block_kernels`: the same with the one-kernel layers switched off); 96 codewords picked from it are
+    decoded by the oracle.  train: BatchNorm uses batch statistics, so the same 128 picked codewords
     form the batch on both sides (and the oracle's updated running statistics are compared as well).
     Criterion: max |logit error| <= 2e-2 of the logit range; hard decisions agree on >= 99.9 % of
     the bits the oracle decides firmly (|logit| >= 2e-2 of the range)."""
+    from fgnn_amd.mpnn import assemblies
+    per_block = mode == 'eval_per_block_kernels'
+    if per_block:
+        mode = 'eval'
     m, dp = _trained_like_ldpc(dev)
     B = 4096
     data = dp.sample(B, seed=12, dtype=torch.bfloat16)[:6]
@@ -61,8 +66,12 @@ def test_benched_bf16_model_vs_f32_oracle(mode, dev):
     sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
     if mode == 'eval':
         m.eval()
-        with torch.no_grad(), amp:
-            logits, snr = m(*data)
+        assemblies.FUSE_EVAL_LAYERS = not per_block
+        try:
+            with torch.no_grad(), amp:
+                logits, snr = m(*data)
+        finally:
+            assemblies.FUSE_EVAL_LAYERS = True
         logits, snr = logits[pick], snr[pick]
     else:
         m.train()
