@@ -274,10 +274,17 @@ class FactorNN(torch.nn.Module):
         if s1 is not None and not s1.is_contiguous():
             s1 = s1.contiguous()
         P = _hip._ptr
-        rc = _hip.lib().fgnn_factor_layer_forward(
+        rcs = []
+        # algorithmic bytes: the state read and written once (+ the skip terms), the parity edge types, the parameters
+        nstate = B * (96 + 48 + 1) * 64 * 2
+        nbytes = nstate * (3 if skip is not None else 2) + 2 * 288 * 4 * 2 * (B if ev.stride(0) else 1) + params.numel() * 4
+        from .. import ops as _ops
+        _ops.timed('factor_layer_fwd_kernel', nbytes, lambda: rcs.append(_hip.lib().fgnn_factor_layer_forward(
             B, P(var), P(fac[0]), P(f1), P(skip[0]) if skip is not None else None, P(skip[1][0]) if skip is not None else None,
             P(s1), P(iv), iv.stride(1), iv.stride(2), P(if_), if_.stride(1), if_.stride(2), P(ev), ev.stride(0), P(ef), ef.stride(0),
-            P(hev), P(hef), P(params), 1, float(blocks[0].conv1[1].slope), P(new_var), P(new_f0), P(new_f1), _hip.stream_ptr())
+            P(hev), P(hef), P(params), 1, float(blocks[0].conv1[1].slope), P(new_var), P(new_f0), P(new_f1), _hip.stream_ptr())),
+            nflops=B * 2 * 64 * (64 * (96 * 5 + 48 * 3 + 3) + 256 * (96 + 48) + 64 * 96))
+        rc = rcs[0]
         if rc == _hip.EUNSUPPORTED:
             return None
         _hip.check(rc)
