@@ -219,8 +219,9 @@ __global__ __launch_bounds__(FL_THREADS) void factor_layer_fwd_kernel(const FlPa
     float* het_out = het_in + FL_NV;                                       // [96]
     float* red = het_out + FL_NV;                                          // [2 maps][2 stats][2 halves][64]
     float* zpart = red + 512;                                              // [2 halves][64] fan-in maxima
-    float* hv = zpart + 128;                                               // [64] hyper-factor state, [64] s2 * P, [64] t2, [64] fan-out a1
-    float* aff = hv + 256;                                                 // [4 blocks][s1, t1, s2, t2, s3, t3][64] folded affines
+    float* hv = zpart + 128;                                               // [64] hyper-factor state, [64] s2 * P, [64] t2, [64] spare
+    float* mvp = hv + 256;                                                 // [8 waves][64] partial matrix-vector products
+    float* aff = mvp + 512;                                                 // [4 blocks][s1, t1, s2, t2, s3, t3][64] folded affines
     uint4* wmap = reinterpret_cast<uint4*>(aff + 24 * 64);                 // [2 maps][2 k-steps][4 tiles][64 lanes] fragments of Wvv / Wff
     uint16_t* W2c = reinterpret_cast<uint16_t*>(wmap + 2 * 2 * 4 * 64);    // [o][c] bf16: conv2 of the fan-in block, transposed
     uint16_t* W1d = W2c + 64 * 64;                                         // [c][o] bf16: conv1 of the fan-out block, transposed
@@ -331,9 +332,23 @@ __global__ __launch_bounds__(FL_THREADS) void factor_layer_fwd_kernel(const FlPa
 
     int b = blockIdx.x;
     if (b < p.B) prefetch(b);
+    auto close_hyper = [&](int bp) {                   // wave 0: new state of sample bp's hyper-factor (hv still holds its old state)
+        float acc = 0.f;
+#pragma unroll
+        for (int w8 = 0; w8 < 8; ++w8) acc += mvp[w8 * 64 + lane];
+        float u = fmaf(acc, aff[(2 * 6 + 4) * 64 + lane], aff[(2 * 6 + 5) * 64 + lane]);
+        u = u > 0.f ? u : u * slope;
+        if (p.residual) u += hv[lane];
+        if (p.skip_fac1) u += fl_lo(p.skip_fac1[(int64_t)bp * 64 + lane]);
+        const __bf16 h = (__bf16)u;
+        p.out_fac1[(int64_t)bp * 64 + lane] = __builtin_bit_cast(uint16_t, h);
+    };
+    int b_prev = -1;
     for (; b < p.B; b += gridDim.x) {
         __syncthreads();                               // the previous sample's last readers of the images are done (and the tables are in)
         FL_STAMP(0);
+        if (wave == 0 && b_prev >= 0) close_hyper(b_prev);     // before this wave's commit() overwrites hv[0..63]
+        b_prev = b;
         commit();
         __syncthreads();
         FL_STAMP(1);
@@ -440,14 +455,12 @@ __global__ __launch_bounds__(FL_THREADS) void factor_layer_fwd_kernel(const FlPa
                     red[(6 + 0 * 2 + hf) * 64 + ch4 + r] = qf[r];
                 }
             }
-            if (wave == 7) {                           // the fan-out block opens on the hyper-factor's own state: conv1 as a matrix-vector product
-                const float x = hv[lane];
-                float a1 = 0.f;
-#pragma unroll 8
-                for (int c = 0; c < 64; ++c)
-                    a1 = fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), c)), fl_lo(W1d[c * 64 + lane]), a1);
-                a1 = fmaf(a1, aff[(3 * 6 + 0) * 64 + lane], aff[(3 * 6 + 1) * 64 + lane]);
-                hv[192 + lane] = fl_round(a1 > 0.f ? a1 : a1 * slope);
+            {   // the fan-out block opens on the hyper-factor's own state: conv1 is a matrix-vector product, split over the
+                // waves by input channel (lane <-> output channel); the partials meet after the barrier
+                float part = 0.f;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) part = fmaf(hv[8 * wave + i], fl_lo(W1d[(8 * wave + i) * 64 + lane]), part);
+                mvp[wave * 64 + lane] = part;
             }
             __syncthreads();
             FL_STAMP(2);
@@ -466,22 +479,35 @@ __global__ __launch_bounds__(FL_THREADS) void factor_layer_fwd_kernel(const FlPa
                 for (int i = 0; i < 2; ++i) oF[i][r] = fmaxf((yf[i][r] - mf) * rf, 0.f);
             }
         }
+        float fo_a1;                                   // the fan-out block's a1 (lane <-> channel), every wave its own copy
+        {
+            float a1 = 0.f;
+#pragma unroll
+            for (int w8 = 0; w8 < 8; ++w8) a1 += mvp[w8 * 64 + lane];
+            a1 = fmaf(a1, aff[(3 * 6 + 0) * 64 + lane], aff[(3 * 6 + 1) * 64 + lane]);
+            fo_a1 = fl_round(a1 > 0.f ? a1 : a1 * slope);
+        }
 
         conv1(wide_img, aW1a, vs, 0);
         __syncthreads();
         project(aFa, 6);
-        if (wave == 7) {
-            const float a1 = hv[192 + lane];
+        {   // its projection, again split over the waves by input channel
+            float part = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                part = fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(fo_a1), 8 * wave + i)), fl_lo(Fd[(8 * wave + i) * 64 + lane]), part);
+            mvp[wave * 64 + lane] = part;
+        }
+        __syncthreads();
+        FL_STAMP(3);
+        if (wave == 0) {
             float P = 0.f;
-#pragma unroll 8
-            for (int o = 0; o < 64; ++o)
-                P = fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(a1), o)), fl_lo(Fd[o * 64 + lane]), P);
+#pragma unroll
+            for (int w8 = 0; w8 < 8; ++w8) P += mvp[w8 * 64 + lane];
             P = fl_round(P);
             hv[64 + lane] = aff[(3 * 6 + 2) * 64 + lane] * P;     // a2[m][o] = ReLU(et[m] * (s2 P)[o] + t2[o])
             hv[128 + lane] = aff[(3 * 6 + 3) * 64 + lane];
         }
-        __syncthreads();
-        FL_STAMP(3);
         fl_gather<FL_KF, 3>(ps, idx_vf, et_vf, bs, FL_NF, wave, lane, aff[(0 * 6 + 2) * 64 + lane], aff[(0 * 6 + 3) * 64 + lane]);
         __syncthreads();
         FL_STAMP(4);
@@ -569,19 +595,15 @@ __global__ __launch_bounds__(FL_THREADS) void factor_layer_fwd_kernel(const FlPa
         }
         // ---- phase 10: the fan-out block's conv2 onto the variables; residual, skip link, store; wave 0 first closes the
         //      fan-in block (the hyper-factor's new state: a matrix-vector product) ----
-        if (wave == 0) {
+        {   // the fan-in block closes with a matrix-vector product on the hyper-factor: partials by input channel here, summed by
+            // wave 0 behind the next barrier (the top of the next sample, or the one after the loop)
             float z = fmaxf(zpart[lane], zpart[64 + lane]);
             z = fl_round(fmaxf(fmaf(z, aff[(2 * 6 + 2) * 64 + lane], aff[(2 * 6 + 3) * 64 + lane]), 0.f));
-            float acc = 0.f;
-#pragma unroll 8
-            for (int o = 0; o < 64; ++o)
-                acc = fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(z), o)), fl_lo(W2c[o * 64 + lane]), acc);
-            float u = fmaf(acc, aff[(2 * 6 + 4) * 64 + lane], aff[(2 * 6 + 5) * 64 + lane]);
-            u = u > 0.f ? u : u * slope;
-            if (p.residual) u += hv[lane];
-            if (p.skip_fac1) u += fl_lo(p.skip_fac1[(int64_t)b * 64 + lane]);
-            const __bf16 h = (__bf16)u;
-            p.out_fac1[(int64_t)b * 64 + lane] = __builtin_bit_cast(uint16_t, h);
+            float part = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                part = fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(z), 8 * wave + i)), fl_lo(W2c[(8 * wave + i) * 64 + lane]), part);
+            mvp[wave * 64 + lane] = part;
         }
         {
             f32x4 acc[3], s4, t4;
@@ -617,6 +639,8 @@ __global__ __launch_bounds__(FL_THREADS) void factor_layer_fwd_kernel(const FlPa
         }
         FL_STAMP(10);
     }
+    __syncthreads();
+    if (wave == 0 && b_prev >= 0) close_hyper(b_prev);
 }
 
 // ----------------------------------------------------------------------------------------
@@ -653,7 +677,7 @@ extern "C" int fgnn_factor_layer_forward(int32_t B, const void* var, const void*
     p.et_v2f_sb = et_v2f_sb; p.et_f2v_sb = et_f2v_sb; p.B = B; p.residual = residual; p.slope = slope;
     p.idx_v2f_sm = idx_v2f_sm; p.idx_v2f_sk = idx_v2f_sk; p.idx_f2v_sm = idx_f2v_sm; p.idx_f2v_sk = idx_f2v_sk;
     const int lds = (FL_NV + FL_NF + 2 * FL_NV) * FL_XS * 2 + FL_NV * FL_PS * 2 + (FL_NF * FL_KF + FL_NV * FL_KV) * (4 + 8) +
-                    2 * FL_NV * 4 + (512 + 128 + 256 + 24 * 64) * 4 + 2 * 2 * 4 * 64 * 16 + 3 * 64 * 64 * 2;
+                    2 * FL_NV * 4 + (512 + 128 + 256 + 512 + 24 * 64) * 4 + 2 * 2 * 4 * 64 * 16 + 3 * 64 * 64 * 2;
     hipError_t e = hipFuncSetAttribute((const void*)factor_layer_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "hipFuncSetAttribute(%d B LDS): %s", lds, hipGetErrorString(e));
     int grid = 256;
