@@ -26,13 +26,13 @@
 // eleven barriers over the images {var, fac0, A (conv1 output), B (operator output), P (projection)}:
 //   maps + InstanceNorm statistics | conv1 V->F | projection | gather | conv2 + conv1 F->V | projection | gather |
 //   conv2 + conv1 fan-in | fan-in projection + max, fan-out operator output | conv2 fan-out, residual + skip, store
-// (the fan-out block's two matrix-vector products ride on one wave of the first two phases, the fan-in block's closing one
-// on one wave of the last).  The new state accumulates in registers — every node-wise product has the same tile -> lane
+// (the hyper-factor's three matrix-vector products are split over the eight waves by input channel, partials through LDS; the
+// fan-in block's closing sum is taken by wave 0 behind the next sample's first barrier).  The new state accumulates in registers — every node-wise product has the same tile -> lane
 // mapping, so an element is owned by one lane throughout.  Rounding points are those of the per-block kernels (a1, P, a2
 // rounded to bf16; everything summed in f32 and rounded once).
-// Measured (profiles/r02/README.md): 255 us per layer at 4 096 codewords (16 samples per workgroup, ~37 000 shader clocks per
+// Measured (profiles/r02/README.md): ~245 us per layer at 4 096 codewords (16 samples per workgroup, ~37 000 shader clocks per
 // sample: the phases are short dependent chains with two waves per SIMD to hide them) against ~300 us for the dozen kernels
-// it replaces — the inference forward goes from 4.92 to 4.80 ms, and from 0.99 to 0.85 ms at 64 codewords where launches
+// it replaces — the inference forward goes from 4.92 to 4.78 ms, and from 0.98 to 0.83 ms at 64 codewords where launches
 // dominate.  HBM would allow 21 us: the next step is a software pipeline over samples (projection of sample s + 1 under
 // the gather of sample s, as csrc/mpconv_fwd_sg.hip does for the bare operator).
 #include "fgnn_common.h"
