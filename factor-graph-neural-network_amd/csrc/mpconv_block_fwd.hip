@@ -86,12 +86,17 @@ __global__ __launch_bounds__(KB_THREADS) void mpconv_block_fwd_kernel(const KbPa
     c1s = *reinterpret_cast<const f32x4*>(p.s1 + ot * 16 + 4 * lk0);
     c1t = *reinterpret_cast<const f32x4*>(p.t1 + ot * 16 + 4 * lk0);
 #pragma unroll
-    for (int q = 0; q < NO; ++q) {                     // conv2 output tiles ot + 4q of the 4*NO
+    // conv2: the wave's NO output tiles are tiles u = ot * NO + q of the 4 * NO, with PERMUTED rows: tile (g = u >> 2, qt = u & 3), row i
+    // <-> channel 64 g + 16 (i >> 2) + 4 qt + (i & 3).  Lane (row li, lk) then holds the 4 * NO CONSECUTIVE channels
+    // 64 g + 16 lk + 4 qt0 .. of its node: addend and output move as 16-byte pieces, not 8-byte ones
+    for (int q = 0; q < NO; ++q) {
+        const int u = ot * NO + q, g = u >> 2, qt = u & 3;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) aW2[q][ks] = kb_frag8(p.W2 + ((ot + 4 * q) * 16 + li0) * 64 + 32 * ks + 8 * lk0);
-        c3s[q] = *reinterpret_cast<const f32x4*>(p.s3 + (ot + 4 * q) * 16 + 4 * lk0);
-        c3t[q] = *reinterpret_cast<const f32x4*>(p.t3 + (ot + 4 * q) * 16 + 4 * lk0);
+        for (int ks = 0; ks < 2; ++ks) aW2[q][ks] = kb_frag8(p.W2 + (64 * g + 16 * (li0 >> 2) + 4 * qt + (li0 & 3)) * 64 + 32 * ks + 8 * lk0);
+        c3s[q] = *reinterpret_cast<const f32x4*>(p.s3 + 64 * g + 16 * lk0 + 4 * qt);
+        c3t[q] = *reinterpret_cast<const f32x4*>(p.t3 + 64 * g + 16 * lk0 + 4 * qt);
     }
+    const int cbase = 64 * ((ot * NO) >> 2) + 16 * lk0 + 4 * ((ot * NO) & 3);     // first of this lane's 4 * NO output channels
     // operator filters: A[i = col][k = c] = F[c][col]; slabs wave and wave + 8 of the 16 column slabs
 #pragma unroll
     for (int q = 0; q < 2; ++q)
@@ -182,6 +187,16 @@ __global__ __launch_bounds__(KB_THREADS) void mpconv_block_fwd_kernel(const KbPa
         }
         __syncthreads();                               // P complete; the x image is dead: it becomes a2
 
+        // the addend of this wave's first conv2 node tile: asked for here, it lands under the gather
+        const uint16_t* adb = p.addend ? p.addend + (int64_t)b * M * NOUT : nullptr;
+        uint2 adr[NO];
+#pragma unroll
+        for (int q = 0; q < NO; ++q) adr[q] = make_uint2(0, 0);
+        if (adb && (wave >> 2) * 16 + li < M) {
+            const uint2* ap = reinterpret_cast<const uint2*>(adb + (int64_t)((wave >> 2) * 16 + li) * NOUT + cbase);
+#pragma unroll
+            for (int q = 0; q < NO; ++q) adr[q] = ap[q];
+        }
         // ---- gather + edge-type contraction + max, two destinations in flight per wave; a2 = ReLU(BN2(z)) -> LDS ----
         {
             const unsigned* et_w = reinterpret_cast<const unsigned*>(et_s);
@@ -223,31 +238,47 @@ __global__ __launch_bounds__(KB_THREADS) void mpconv_block_fwd_kernel(const KbPa
         }
         __syncthreads();
 
-        // ---- conv2 + BN3 + LeakyReLU (+ addend) on the destinations: tile (ot, mt), mt = wave/4 + 2 i ----
+        // ---- conv2 + BN3 + LeakyReLU (+ addend) on the destinations: node tiles mt = wave/4 + 2 i, the wave's NO channel tiles ----
         {
             uint16_t* yb = p.y + (int64_t)b * M * NOUT;
-            const uint16_t* adb = p.addend ? p.addend + (int64_t)b * M * NOUT : nullptr;
-            for (int mt = wave >> 2; mt < mtile; mt += 2) {
+            int mt = wave >> 2;
+            for (; mt < mtile; mt += 2) {
                 const uint16_t* bp = xs + (mt * 16 + li) * KB_XSB + 8 * lk;
                 const kb_bf16x8 b0 = __builtin_bit_cast(kb_bf16x8, *reinterpret_cast<const uint4*>(bp));
                 const kb_bf16x8 b1 = __builtin_bit_cast(kb_bf16x8, *reinterpret_cast<const uint4*>(bp + 32));
                 const int m = mt * 16 + li;
+                uint2 acur[NO];
 #pragma unroll
-                for (int q = 0; q < NO; ++q) {
-                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aW2[q][0], b0, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aW2[q][1], b1, acc, 0, 0, 0);
-                    if (m < M) {
+                for (int q = 0; q < NO; ++q) acur[q] = adr[q];
+                if (adb && mt + 2 < mtile && m + 32 < M) {                // the next node tile's addend travels under this one's products
+                    const uint2* ap = reinterpret_cast<const uint2*>(adb + (int64_t)(m + 32) * NOUT + cbase);
+#pragma unroll
+                    for (int q = 0; q < NO; ++q) adr[q] = ap[q];
+                }
+                f32x4 acc[NO];
+#pragma unroll
+                for (int q = 0; q < NO; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aW2[q][0], b0, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+                for (int q = 0; q < NO; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aW2[q][1], b1, acc[q], 0, 0, 0);
+                if (m < M) {
+                    unsigned ow[2 * NO];
+#pragma unroll
+                    for (int q = 0; q < NO; ++q) {
                         float v[4];
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) { const float u = fmaf(acc[r], c3s[q][r], c3t[q][r]); v[r] = u > 0.f ? u : u * p.slope; }
-                        const int64_t off = (int64_t)m * NOUT + (ot + 4 * q) * 16 + 4 * lk;
+                        for (int r = 0; r < 4; ++r) { const float u = fmaf(acc[q][r], c3s[q][r], c3t[q][r]); v[r] = u > 0.f ? u : u * p.slope; }
                         if (adb) {
-                            const uint2 a = *reinterpret_cast<const uint2*>(adb + off);
-                            v[0] += __uint_as_float(a.x << 16); v[1] += __uint_as_float(a.x & 0xffff0000u);
-                            v[2] += __uint_as_float(a.y << 16); v[3] += __uint_as_float(a.y & 0xffff0000u);
+                            v[0] += __uint_as_float(acur[q].x << 16); v[1] += __uint_as_float(acur[q].x & 0xffff0000u);
+                            v[2] += __uint_as_float(acur[q].y << 16); v[3] += __uint_as_float(acur[q].y & 0xffff0000u);
                         }
-                        *reinterpret_cast<uint2*>(yb + off) = make_uint2(kb_pack2(v[0], v[1]), kb_pack2(v[2], v[3]));
+                        ow[2 * q] = kb_pack2(v[0], v[1]);
+                        ow[2 * q + 1] = kb_pack2(v[2], v[3]);
+                    }
+                    uint16_t* yp = yb + (int64_t)m * NOUT + cbase;
+                    if (NO == 1) *reinterpret_cast<uint2*>(yp) = make_uint2(ow[0], ow[1]);
+                    else {
+#pragma unroll
+                        for (int h = 0; h < NO / 2; ++h) *reinterpret_cast<uint4*>(yp + 8 * h) = make_uint4(ow[4 * h], ow[4 * h + 1], ow[4 * h + 2], ow[4 * h + 3]);
                     }
                 }
             }
@@ -276,7 +307,7 @@ extern "C" int fgnn_mpconv_block_forward(const fgnn_mpconv_desc* d, const void* 
                     d->x_sc == 1 && d->x_sn == nin && d->x_sb % 8 == 0 &&
                     d->y_sc == 1 && d->y_sm == nout && d->y_sb == (int64_t)d->M * nout &&
                     d->et_se == 1 && d->et_sk == 4 && d->et_sm == 4 * d->k && d->et_sb % 4 == 0 &&
-                    !((uintptr_t)x & 15) && !((uintptr_t)etype & 7) && !((uintptr_t)y & 7) && !((uintptr_t)addend & 7);
+                    !((uintptr_t)x & 15) && !((uintptr_t)etype & 7) && !((uintptr_t)y & 15) && !((uintptr_t)addend & 7);
     if (!ok) FGNN_FAIL(FGNN_EUNSUPPORTED, "mpconv_block_forward: outside the fused block's family");
     if (d->B == 0) return FGNN_OK;
     KbParams p;
