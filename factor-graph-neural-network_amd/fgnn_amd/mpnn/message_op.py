@@ -115,7 +115,9 @@ class mp_conv_v2(base_mp_nn):
                                           post_shift=shift, relu=plain_relu)
             if self.activation_fn is not None and not plain_relu:
                 y = self.activation_fn(y)
-            return add_all(y, addend() if callable(addend) else addend)
+            from .pointwise import as_addends
+            # the caller's running sums join in ONE n-input pass (csrc/sum_n.hip) rather than one elementwise add each
+            return ops.add_n([y] + as_addends(addend() if callable(addend) else addend))
         # a training-mode BatchNorm right behind the operator takes its batch statistics from the kernel's epilogue
         z = ops.mpconv(x, nn_idx, etype, self.filters, self.bias, self.nou,
                        self.nedge_types, ext, agg, want_stats=bn_batch_stats and self.bn is not None and self.bn.training)
