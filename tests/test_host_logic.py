@@ -126,6 +126,16 @@ def test_side_entry_points_validate_their_arguments_without_a_gpu():
     assert L.fgnn_bn_supported(393216, 64, 1) == 1 and L.fgnn_bn_supported(393216, 60, 1) == 0
     assert L.fgnn_linear_forward_partials(393216, 64, 64) > 0 and L.fgnn_linear_forward_partials(393216, 96, 64) <= 0
     assert L.fgnn_abi_version() == 3
+    # the one-kernel FactorNN layer: packed-parameter count = two 64 x 64 maps + two parity blocks (64 x 256
+    # filters) + two hyper-factor blocks (64 x 64 filters); NULL buffers / misaligned operands / empty batches before any launch
+    blk = lambda ncol: 64 * 64 + 2 * 64 + 64 * ncol + 2 * 64 + 64 * 64 + 2 * 64
+    assert L.fgnn_factor_layer_param_count() == 2 * 64 * 64 + 2 * blk(256) + 2 * blk(64)
+    big = ctypes.c_void_p(4096)
+    layer = lambda var, B=4: L.fgnn_factor_layer_forward(B, var, big, big, None, None, None, big, 6, 1, big, 3, 1, big, 1152, big, 1152,
+                                                         None, None, big, 1, 0.01, big, big, big, None)
+    assert layer(None) == -1 and b'null pointer' in L.fgnn_last_error()
+    assert layer(ctypes.c_void_p(4100)) == _hip.EUNSUPPORTED and b'misaligned' in L.fgnn_last_error()
+    assert layer(big, B=0) == 0
 
 
 def test_flat_adam_matches_torch_adam():
