@@ -6,9 +6,10 @@ TRAINING step of LDPCModel (8 FGNN layers, 32 fused message-operator calls = 614
 per codeword; forward + backward + gradient all-reduce + Adam), per-GPU batch 4096, inputs
 resident in HBM.  `--mode fwd` times the inference forward instead.
 
-  python bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W          (N > 1 without a launcher: bench.py itself starts N ranks,
+                                                          one per GPU, RCCL — see `self_launch`)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-         --master-port P bench.py --gpus N --steps K --warmup W          (N > 1, one rank per GPU)
+         --master-port P bench.py --gpus N --steps K --warmup W          (the driver's form; RANK / WORLD_SIZE from the env)
 
 Rank 0 prints ONE JSON line: the contract fields plus
   "roofline"     — dominant hand-written kernel: algorithmic bytes (SURVEY §8d formula) / average
@@ -127,6 +128,102 @@ def cpu_baseline(batch, mode, threads, budget=20.0, max_iters=5):
                                         torch.__version__)}
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it (no WORLD_SIZE in the environment): start the N
+    ranks here — one process per GPU, rendezvous on 127.0.0.1, backend RCCL ("nccl") — wait for them and return the exit
+    code.  Rank 0 inherits stdout (the ONE JSON line), every rank's stderr is passed through.  Fails loudly when the node
+    has fewer than N devices (FGNN_BENCH_DEVICE, the tests' hook for several ranks on one device over gloo, lifts that)."""
+    import socket
+    import subprocess
+    n = args.gpus
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if os.environ.get('FGNN_BENCH_DEVICE') is None and have < n:
+        raise SystemExit('bench.py --gpus %d: this node exposes %d ROCm device(s); one rank per GPU needs %d '
+                         '(no oversubscription, no silent 1-rank run)' % (n, have, n))
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), FGNN_BENCH_SELF_LAUNCHED='1')
+        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')       # dmabuf IPC: what RCCL needs on this driver
+        env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or 8) // n)))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    try:
+        pending = dict(enumerate(procs))
+        while pending:
+            for r, pr in list(pending.items()):
+                code = pr.poll()
+                if code is None:
+                    continue
+                del pending[r]
+                if code != 0 and rc == 0:
+                    rc = code
+                    print('bench.py: rank %d exited with code %d; stopping the other ranks' % (r, code), file=sys.stderr)
+                    for q in pending.values():
+                        q.terminate()
+            time.sleep(0.05)
+    finally:
+        for pr in procs:
+            if pr.poll() is None:
+                pr.kill()
+    return rc
+
+
+def dist_setup(args):
+    """(rank, world, device) of this process.  world comes from WORLD_SIZE (a launcher's, or self_launch's) and must equal
+    --gpus; with N > 1 the process group is RCCL on this rank's own device.  FGNN_BENCH_DEVICE / FGNN_DIST_BACKEND are the
+    tests' hooks (several ranks sharing one GPU over gloo)."""
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world != args.gpus:
+        raise SystemExit('--gpus %d but WORLD_SIZE=%d: the launcher must start exactly --gpus ranks' % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a ROCm device: the FGNN hot path has no CPU fallback')
+    forced = os.environ.get('FGNN_BENCH_DEVICE')
+    dev_index = int(forced) if forced is not None else local_rank
+    if dev_index >= torch.cuda.device_count():
+        raise SystemExit('rank %d wants device %d but only %d are visible' % (rank, dev_index, torch.cuda.device_count()))
+    torch.cuda.set_device(dev_index)
+    dev = torch.device('cuda', dev_index)
+    if world > 1:
+        backend = os.environ.get('FGNN_DIST_BACKEND', 'nccl')
+        if backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit('process group has %d ranks, --gpus says %d' % (dist.get_world_size(), args.gpus))
+    return rank, world, dev
+
+
+def dist_report(world, dev, elapsed_local, steps):
+    """What a reader needs to trust an N > 1 line: the backend, the RCCL version, every rank's own step time and device."""
+    if world == 1:
+        return None
+    backend = dist.get_backend()
+    t = torch.tensor([elapsed_local / steps * 1e3, float(dev.index)], device=dev if backend == 'nccl' else 'cpu',
+                     dtype=torch.float64)
+    every = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(every, t)
+    ver = None
+    if backend == 'nccl':
+        try:
+            ver = '.'.join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:       # noqa: BLE001
+            ver = None
+    return {'backend': backend + (' (RCCL)' if backend == 'nccl' else ''), 'rccl_version': ver,
+            'devices_visible': torch.cuda.device_count(),
+            'per_rank_ms_per_step': [round(float(e[0]), 4) for e in every],
+            'per_rank_device': [int(e[1]) for e in every],
+            'launched_by': 'bench.py self_launch' if os.environ.get('FGNN_BENCH_SELF_LAUNCHED') else 'external launcher'}
+
+
 # ----------------------------------------------------------------------------------------------------------------------
 # synthetic-PGM workloads (BASELINE configs 2 / 5): factor_mpnn as train_syn_pw_factor.py / train_syn_hop_factor.py build it
 # ----------------------------------------------------------------------------------------------------------------------
@@ -209,22 +306,7 @@ def main_syn(args):
     """factor_mpnn training (or inference) step on synthetic 30-node PGMs, f32: edge models -> factor_mpnn (12 fused message
     operator calls through csrc/mpconv_fwd_ext.hip / mpconv_bwd_ext.hip) -> cross entropy -> backward -> gradient-norm clip
     -> Adam (train_syn_hop_factor.py:283-303).  Same JSON contract as the LDPC workload; `value` counts VF+FV messages."""
-    rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    if world != args.gpus and world > 1:
-        raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
-    if not torch.cuda.is_available():
-        raise SystemExit('bench.py needs a ROCm device: the FGNN hot path has no CPU fallback')
-    dev_index = int(os.environ.get('FGNN_BENCH_DEVICE', local_rank))
-    torch.cuda.set_device(dev_index)
-    dev = torch.device('cuda', dev_index)
-    if world > 1:
-        backend = os.environ.get('FGNN_DIST_BACKEND', 'nccl')
-        if backend == 'nccl':
-            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+    rank, world, dev = dist_setup(args)
     torch.backends.cudnn.enabled = bool(args.miopen_bn)
     import fgnn_amd
     from fgnn_amd import ops
@@ -324,6 +406,7 @@ def main_syn(args):
             print('rank %d step %.3f ms' % (rank, (time.perf_counter() - t1) * 1e3), file=sys.stderr)
     fence()
     elapsed = time.perf_counter() - t0
+    dist_info = dist_report(world, dev, elapsed, args.steps)
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -380,7 +463,7 @@ def main_syn(args):
                                       'batch-shared (expand)' if args.tables == 'shared' else 'per-sample copies (repeat)'),
                        'messages_per_graph': msgs, 'graphs_per_s': B * world * args.steps / elapsed,
                        'global_batch': B * world, 'parallelism': 'dp%d' % world, 'mode': args.mode,
-                       'hip_graph': graphed is not None,
+                       'hip_graph': graphed is not None, 'distributed': dist_info,
                        'peak_hbm_GB': round(torch.cuda.max_memory_allocated(dev) / 1e9, 2)},
             'roofline': roofline,
             'kernels': {k: {'launches': v['launches'], 'avg_us': round(v['ms'] / v['launches'] * 1e3, 2),
@@ -404,26 +487,11 @@ def _trace(msg):
 
 def main():
     args = parse()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(self_launch(args))                  # N ranks of this same command, one per GPU
     if args.workload != 'ldpc':
         return main_syn(args)
-    rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    if world != args.gpus and world > 1:
-        raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
-    if not torch.cuda.is_available():
-        raise SystemExit('bench.py needs a ROCm device: the FGNN hot path has no CPU fallback')
-    # FGNN_BENCH_DEVICE / FGNN_DIST_BACKEND: test hooks (e.g. 2 ranks sharing one GPU over gloo); the driver
-    # launches one rank per GPU over RCCL (backend "nccl")
-    dev_index = int(os.environ.get('FGNN_BENCH_DEVICE', local_rank))
-    torch.cuda.set_device(dev_index)
-    dev = torch.device('cuda', dev_index)
-    if world > 1:
-        backend = os.environ.get('FGNN_DIST_BACKEND', 'nccl')
-        if backend == 'nccl':
-            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+    rank, world, dev = dist_setup(args)
 
     # torch's own channels-last BatchNorm kernels beat MIOpen's spatial BN on these [B,C,N,1]
     # activations (profiles/r01), so MIOpen is bypassed for the plumbing ops by default
@@ -524,6 +592,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     _trace('timed steps done')
+    dist_info = dist_report(world, dev, elapsed, args.steps)
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -610,7 +679,7 @@ def main():
                        'inputs': ('random messages -> reference G encode -> AWGN+burst channel, on the GPU'
                                   if args.inputs == 'channel' else 'random bits + AWGN (torch ops)'),
                        'peak_hbm_GB': round(torch.cuda.max_memory_allocated(dev) / 1e9, 2),
-                       'mode': args.mode, 'hip_graph': graphed is not None},
+                       'mode': args.mode, 'hip_graph': graphed is not None, 'distributed': dist_info},
             'roofline': roofline,
             'kernels': {k: {'launches': v['launches'], 'avg_us': round(v['ms'] / v['launches'] * 1e3, 2),
                             'total_ms': round(v['ms'], 3),

@@ -22,7 +22,7 @@ void fgnn_note_kernel(const char* fmt, ...) {
 
 extern "C" const char* fgnn_last_error(void) { return g_err; }
 extern "C" const char* fgnn_last_kernel(void) { return g_kernel; }
-extern "C" int fgnn_abi_version(void) { return 3; }
+extern "C" int fgnn_abi_version(void) { return FGNN_ABI_VERSION; }
 
 // x read once, etype read once, indices read once (int64 as passed; a batch-shared
 // graph is read once), y written once, filters + bias/BN vectors once.

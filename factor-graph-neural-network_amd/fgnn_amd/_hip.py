@@ -17,6 +17,7 @@ EXT_NONE, EXT_NEIGHBOR, EXT_DIFF = 0, 1, 2
 DESC_GETYPE_REDUCED = 0x10000
 AGG_MAX, AGG_LSE, AGG_MEAN = 0, 1, 2
 F32, BF16 = 0, 1
+ABI_VERSION = 4              # include/fgnn_hip.h: FGNN_ABI_VERSION (checked before any symbol is bound)
 EUNSUPPORTED = -3            # FGNN_EUNSUPPORTED: shape outside a kernel's family (callers fall back)
 
 AGG_CODES = {'max': AGG_MAX, 'softmax': AGG_LSE, 'mean': AGG_MEAN}
@@ -55,6 +56,14 @@ def lib():
             'fallback; build it with `python __graft_entry__.py` (hipcc --offload-arch=gfx950).'
             % LIB_PATH)
     L = ctypes.CDLL(LIB_PATH)
+    try:
+        L.fgnn_abi_version.restype = ctypes.c_int
+        have = int(L.fgnn_abi_version())
+    except AttributeError:
+        have = None
+    if have != ABI_VERSION:
+        raise FgnnHipError('%s speaks C-ABI version %s, this package binds version %d (include/fgnn_hip.h): rebuild it '
+                           'with `python __graft_entry__.py`' % (LIB_PATH, have, ABI_VERSION))
     vp, dp = ctypes.c_void_p, ctypes.POINTER(MPConvDesc)
     L.fgnn_mpconv_forward.restype = ctypes.c_int
     L.fgnn_mpconv_forward.argtypes = [dp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]

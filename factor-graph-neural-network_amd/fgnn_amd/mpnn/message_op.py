@@ -70,7 +70,7 @@ class mp_conv_v2(base_mp_nn):
             torch.empty(rows, nou * nedge_types, dtype=torch.float32).uniform_(-0.01, 0.01))
         self.bias = torch.nn.Parameter(torch.empty(nou).uniform_(0, 0.05)) if bias else None
         from .pointwise import BatchNormAct2d
-        # slope 1.0 = plain BatchNorm2d; forward() switches the fused ReLU on when the activation is ReLU
+        # slope 1.0 = plain BatchNorm2d; forward() asks for the fused ReLU per call when the activation is ReLU
         self.bn = BatchNormAct2d(nou, slope=1.0) if bn else None
         if isinstance(activation_fn, torch.nn.Module):
             self.activation_fn = activation_fn
@@ -125,10 +125,7 @@ class mp_conv_v2(base_mp_nn):
             addend = addend()
         if self.bn is not None:
             if plain_relu:                      # BatchNorm + ReLU (+ addend) in one fused kernel pair
-                self.bn.slope = 0.0
-                z = self.bn(z, addend=addend)
-                self.bn.slope = 1.0
-                return z
+                return self.bn(z, addend=addend, slope=0.0)
             z = self.bn(z)
         if self.activation_fn is not None:
             z = self.activation_fn(z)

@@ -413,17 +413,20 @@ class BatchNormAct2d(torch.nn.BatchNorm2d):
         super().__init__(num_features)
         self.slope = float(slope)
 
-    def _activate(self, y):
-        if self.slope == 0.0:
+    @staticmethod
+    def _activate(y, slope):
+        if slope == 0.0:
             return torch.relu(y)
-        if self.slope == 1.0:
+        if slope == 1.0:
             return y
-        return torch.nn.functional.leaky_relu(y, self.slope)
+        return torch.nn.functional.leaky_relu(y, slope)
 
-    def forward(self, x, addend=None):
+    def forward(self, x, addend=None, slope=None):
         """``addend`` (a tensor of the output's shape, or a list of up to three) is added AFTER the activation — the
         ``acc + block(x) (+ residual + skip)`` that follows every block in FactorNN rides in the apply kernel
-        instead of being separate passes."""
+        instead of being separate passes.  ``slope`` overrides the module's activation for this call (mp_conv_v2 asks its
+        plain BatchNorm for the fused ReLU this way: an argument, not a toggled attribute)."""
+        slope = self.slope if slope is None else float(slope)
         B, C, H, W = x.shape
         addends = as_addends(addend)
         if len(addends) > 3:
@@ -436,7 +439,7 @@ class BatchNormAct2d(torch.nn.BatchNorm2d):
         wants_grad = torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad or
                                                   any(a.requires_grad for a in addends))
         if not ok or (not self.training and wants_grad):
-            return add_all(self._activate(super().forward(x)), addends)
+            return add_all(self._activate(super().forward(x), slope), addends)
         rows = x.permute(0, 2, 3, 1)
         if not rows.is_contiguous():
             rows = rows.contiguous()
@@ -449,13 +452,13 @@ class BatchNormAct2d(torch.nn.BatchNorm2d):
             arows[i] = ar.view(B * H * W, C)
         if self.training:                               # num_batches_tracked += 1 rides in the statistics finaliser
             y = _BatchNormAct.apply(rows, self.weight, self.bias, self.running_mean, self.running_var,
-                                    self.momentum, self.eps, self.slope, arows[0], self.num_batches_tracked,
+                                    self.momentum, self.eps, slope, arows[0], self.num_batches_tracked,
                                     arows[1], arows[2])
         else:                                           # eval: folded affine + activation in one pass
             scale, shift = self._folded()
             y = torch.empty_like(rows)
             _hip.check(_hip.lib().fgnn_bn_apply(_hip._ptr(rows), _hip._ptr(y), B * H * W, C, _hip.dtype_code(rows),
-                                                _hip._ptr(scale), _hip._ptr(shift), self.slope, _hip._ptr(arows[0]),
+                                                _hip._ptr(scale), _hip._ptr(shift), slope, _hip._ptr(arows[0]),
                                                 _hip._ptr(arows[1]), _hip._ptr(arows[2]), _hip.stream_ptr()))
         return y.view(B, H, W, C).permute(0, 3, 1, 2)
 

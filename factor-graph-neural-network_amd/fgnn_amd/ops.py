@@ -364,17 +364,29 @@ class _MPConv(torch.autograd.Function):
 def _unexpanded(etype):
     """[1, net, M, k] tensor that ``etype`` is a batch-``expand`` of, or None.  The reference scripts build one edge-weight
     table and repeat it over the batch (train_syn_hop_factor.py:284-295); given the un-expanded tensor the operator returns
-    its gradient already summed over the batch.  The tensor the caller expanded when autograd can name it (same storage and
-    strides), else the first row of the expanded view (autograd then pads that row's gradient with zeros before its own sum:
-    still far cheaper than a per-sample gradient)."""
+    its gradient already summed over the batch.  Sharing is taken from PROVENANCE only when a gradient flows: a stride-0
+    batch axis (the tensor the caller expanded when autograd can name it, else the first row of the view — autograd pads
+    that row's gradient with zeros before its own sum) or a `repeat` node over the batch axis.  B materialised rows that
+    merely hold equal VALUES are collapsed only when ``etype`` needs no gradient: with a gradient, row b's upstream (a leaf,
+    an edge model whose rows coincide by accident — zero-initialised last layer, saturated ReLU) must receive its own g_b,
+    not the batch sum in row 0."""
     if etype.dim() != 4 or etype.shape[0] < 2:
         return None
     if etype.stride(0) != 0:
-        # B materialised copies (`etype.repeat(bsize, 1, 1, 1)`, train_syn_hop_factor.py:291): one device comparison + host
-        # read per call (the tensor is new every iteration, so nothing can be remembered) — a few tens of microseconds against
-        # a backward that is 7x faster on shared edge weights.  Not during hipGraph capture (no host read possible).
+        # B materialised copies (`etype.repeat(bsize, 1, 1, 1)`, train_syn_hop_factor.py:291).  With a gradient: shared only
+        # if autograd itself says so — the tensor IS the output of `repeat` over the batch axis of a one-row tensor (row 0's
+        # zero-padded gradient then reaches the un-repeated tensor through RepeatBackward's own sum; no host read, works under
+        # hipGraph capture).  Without a gradient: one device comparison + host read (not while capturing).
+        if etype.requires_grad:
+            fn = etype.grad_fn
+            reps = getattr(fn, '_saved_repeats', None) if fn is not None and fn.name() == 'RepeatBackward0' else None
+            src = getattr(fn, '_saved_self_sym_sizes', None) if reps is not None else None
+            if (not DEDUPE_GRAPHS or reps is None or src is None or tuple(reps) != (etype.shape[0], 1, 1, 1)
+                    or tuple(src) != (1,) + tuple(etype.shape[1:])):
+                return None
+            return etype[:1]
         if (not DEDUPE_GRAPHS or not etype.is_cuda or torch.cuda.is_current_stream_capturing()
-                or not bool((etype.detach() == etype.detach()[:1]).all().item())):
+                or not bool((etype == etype[:1]).all().item())):
             return None
         return etype[:1]
     base = etype._base

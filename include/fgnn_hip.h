@@ -311,6 +311,11 @@ int fgnn_ldpc_decode(const double* bias, const int32_t* col_ptr, const int32_t* 
 const char* fgnn_last_error(void);
 /* Name (as rocprofv3 prints it) of the kernel the calling thread's last forward/backward dispatched to. */
 const char* fgnn_last_kernel(void);
+/* Bumped whenever an entry point is added or an argument / descriptor field changes meaning.  The host binding
+ * (fgnn_amd/_hip.py: ABI_VERSION) checks it BEFORE binding symbols, so a stale library is reported as a version
+ * mismatch and not as a missing symbol or a misread field.  4: round-2 additions (flat_adam, factor_layer_*,
+ * ldpc_channel_features_rng, backward_reduces_getype, desc.reserved = in-degree | GETYPE_REDUCED). */
+#define FGNN_ABI_VERSION 4
 int fgnn_abi_version(void);
 
 #ifdef __cplusplus

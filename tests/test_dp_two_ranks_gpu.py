@@ -112,3 +112,25 @@ def test_two_ranks_on_one_gpu_equal_single_process(graph, tmp_path, dev):
     # differences chaotically; what data parallelism must guarantee there is that the replicas stay identical (above).
     firm = ref_grad.abs() > 1e-3 * scale
     assert float((a['param1'] - ref_p1).abs()[firm].max()) <= 1e-5
+
+
+def test_bench_self_launches_its_ranks(dev):
+    """`python bench.py --gpus 2` with NO launcher around it: bench.py starts the two ranks itself (here both on device 0 over
+    gloo — the hooks FGNN_BENCH_DEVICE / FGNN_DIST_BACKEND; the driver's node gives each rank its own GPU over RCCL) and rank 0
+    prints one line that says n_gpus 2, with both ranks' step times and the global batch of two shards."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT')}
+    env.update(FGNN_BENCH_DEVICE='0', FGNN_DIST_BACKEND='gloo')
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--batch', '256', '--steps', '2',
+                        '--warmup', '1', '--no-cpu-baseline'], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['config']['global_batch'] == 512 and out['config']['parallelism'] == 'dp2'
+    d = out['config']['distributed']
+    assert len(d['per_rank_ms_per_step']) == 2 and d['launched_by'] == 'bench.py self_launch' and d['backend'] == 'gloo'
+    assert out['value'] > 0 and out['scaling'] == 'weak'

@@ -125,7 +125,7 @@ def test_side_entry_points_validate_their_arguments_without_a_gpu():
                                         one, one, None) == _hip.EUNSUPPORTED
     assert L.fgnn_bn_supported(393216, 64, 1) == 1 and L.fgnn_bn_supported(393216, 60, 1) == 0
     assert L.fgnn_linear_forward_partials(393216, 64, 64) > 0 and L.fgnn_linear_forward_partials(393216, 96, 64) <= 0
-    assert L.fgnn_abi_version() == 3
+    assert L.fgnn_abi_version() == _hip.ABI_VERSION
     # the one-kernel FactorNN layer: packed-parameter count = two 64 x 64 maps + two parity blocks (64 x 256
     # filters) + two hyper-factor blocks (64 x 64 filters); NULL buffers / misaligned operands / empty batches before any launch
     blk = lambda ncol: 64 * 64 + 2 * 64 + 64 * ncol + 2 * 64 + 64 * 64 + 2 * 64
@@ -301,3 +301,20 @@ def test_pointwise_map_outside_the_hip_path_keeps_weight_gradients():
     assert torch.allclose(m.weight.grad, ref.weight.grad) and torch.allclose(m.bias.grad, ref.bias.grad)
     with torch.no_grad():                               # no-grad path: cached copy, same values
         assert torch.allclose(m(x), ref(x))
+
+
+def test_bench_gpus_n_never_degrades_to_one_rank():
+    """`bench.py --gpus N` without a launcher starts its own N ranks; with fewer than N devices it must refuse (this box
+    has none) rather than print a 1-rank line, and under a launcher WORLD_SIZE must equal --gpus."""
+    import subprocess
+    import sys
+    bench = os.path.join(ROOT, 'bench.py')
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'FGNN_BENCH_DEVICE')}
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        pytest.skip('a multi-GPU node: the refusal cannot be provoked')
+    r = subprocess.run([sys.executable, bench, '--gpus', '2', '--steps', '1', '--warmup', '0'], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and 'one rank per GPU needs 2' in r.stderr and r.stdout.strip() == ''
+    r = subprocess.run([sys.executable, bench, '--gpus', '1', '--steps', '1', '--warmup', '0'],
+                       env=dict(env, WORLD_SIZE='2', RANK='0', LOCAL_RANK='0'), capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and 'WORLD_SIZE=2' in r.stderr and r.stdout.strip() == ''

@@ -218,3 +218,15 @@ def test_repeated_edge_weights_take_the_shared_kernels(dev):
     assert 'mpconv_fwd_ext_kernel' in _hip.lib().fgnn_last_kernel().decode()
     (z * gy).sum().backward()
     assert et_b.grad.shape == et_b.shape and 'mpconv_bwd_ext' not in _hip.lib().fgnn_last_kernel().decode()
+    # B materialised rows with EQUAL VALUES but no shared provenance (a leaf): every row must get its own gradient — the
+    # batch sum in row 0 and zeros elsewhere would be wrong for whatever produced the rows independently
+    leaf = et.to(dev).repeat(B, 1, 1, 1).detach().requires_grad_(True)
+    shared = et.to(dev).requires_grad_(True)
+    xs = x.to(dev).permute(0, 3, 1, 2)
+    z = ops.mpconv(xs, idx.to(dev).expand(B, -1, -1), leaf, W.to(dev), bias.to(dev), 64, 16, 2, _hip.AGG_MAX)
+    (z * gy).sum().backward()
+    z = ops.mpconv(xs, idx.to(dev).expand(B, -1, -1), shared.expand(B, -1, -1, -1), W.to(dev), bias.to(dev), 64, 16, 2, _hip.AGG_MAX)
+    (z * gy).sum().backward()
+    assert leaf.grad.shape == leaf.shape and bool((leaf.grad[1:].abs().amax(dim=(1, 2, 3)) > 0).all())
+    rel = float((leaf.grad.sum(0, keepdim=True) - shared.grad).abs().max() / shared.grad.abs().max())
+    assert rel <= 1e-4, rel
