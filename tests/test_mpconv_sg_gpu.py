@@ -184,6 +184,59 @@ def test_sg_backward_vs_routed_reference(shape, B, dev):
     assert H.rel_err(bd.grad, br.grad) <= tol
 
 
+# (nin, nou, N, M, k): the second-generation backward (64 -> 64) and the wide shapes of LDPCModel's layers 2 / 6
+ORACLE_BWD_SHAPES = [(64, 64, 96, 48, 6), (64, 64, 48, 96, 3), (64, 128, 96, 48, 6), (64, 128, 48, 96, 3), (128, 64, 96, 48, 6),
+                     (128, 64, 48, 96, 3)]
+
+
+@pytest.mark.parametrize('shape', ORACLE_BWD_SHAPES, ids=lambda s: 'x'.join(map(str, s)))
+@pytest.mark.parametrize('B', [37, 600])
+def test_bf16_backward_vs_oracle_autograd(shape, B, dev):
+    """The bf16 backward kernels of the parity calls against the ORACLE's autograd directly — `O.mp_conv` in f32 on the same
+    bf16-rounded inputs, routing by the oracle's OWN maxima (not by the kernel's argmax).  The upstream gradient is zero on
+    the outputs whose best two messages lie closer than the bf16 rounding of P can resolve (a coin flip for any finite
+    precision: there the two sides may legitimately route differently); everywhere else the routes must agree, and every
+    gradient must match to 2^-6 of its range.  Reference: mp_nn.py:115-175."""
+    from fgnn_amd import _hip, ops
+    nin, nou, N, M, k = shape
+    net = 4
+    g = torch.Generator().manual_seed(300 + N + nou + B)
+    x = torch.randn(B, N, 1, nin, generator=g).bfloat16()
+    idx = _regular_table(N, M, k, g)
+    et = torch.randn(B, M, k, net, generator=g).bfloat16()
+    W = (torch.randn(nin, nou * net, generator=g) * 0.1).bfloat16().float()     # what the bf16 matrix cores multiply by
+    bias = torch.randn(nou, generator=g)
+    gz = torch.randn(B, M, 1, nou, generator=g).bfloat16()
+    # messages in f32 (reference order), gap between the best two per output
+    P = torch.einsum('bnc,cq->bnq', x[:, :, 0, :].float(), W).reshape(B, N, nou, net)
+    E = (P[:, idx[0]] * et.float()[:, :, :, None, :]).sum(-1)                              # [B,M,k,nou]
+    top2 = E.topk(2, dim=2)[0]
+    # what bf16 cannot resolve: P is rounded to bf16 (2^-9 relative per term) before the 4-term edge-type contraction
+    mag = (P[:, idx[0]].abs() * et.float().abs()[:, :, :, None, :]).sum(-1).amax(dim=2)    # [B,M,nou]
+    firm = (top2[:, :, 0] - top2[:, :, 1]) > 2.0 ** -7 * mag
+    assert float(firm.float().mean()) > 0.9, float(firm.float().mean())
+    gz = (gz[:, :, 0, :].float() * firm).bfloat16()[:, :, None, :]
+    xo = x.permute(0, 3, 1, 2).float().contiguous().requires_grad_(True)                   # [B,nin,N,1]
+    eo = et.permute(0, 3, 1, 2).float().contiguous().requires_grad_(True)                  # [B,net,M,k]
+    sd = {'filters': W.clone().requires_grad_(True), 'bias': bias.clone().requires_grad_(True)}
+    zo = O.mp_conv(sd, '', xo, idx.expand(B, -1, -1).contiguous(), eo, nou=nou, net=net, extension=0, aggregator='max',
+                   relu=False)
+    zo.backward(gz.permute(0, 3, 1, 2).float())
+    xd = x.to(dev).permute(0, 3, 1, 2).requires_grad_(True)
+    etd = et.to(dev).permute(0, 3, 1, 2).requires_grad_(True)
+    Wd, bd = W.to(dev).requires_grad_(True), bias.to(dev).requires_grad_(True)
+    z = ops.mpconv(xd, idx.to(dev).expand(B, -1, -1), etd, Wd, bd, nou, net, 0, _hip.AGG_MAX)
+    z.backward(gz.to(dev).permute(0, 3, 1, 2))
+    kern = _hip.lib().fgnn_last_kernel().decode()
+    assert 'mpconv_bwd_sg' in kern or 'mpconv_bwd_b16' in kern or 'mpconv_bwd_wide' in kern, kern
+    assert H.rel_err(z.float(), zo) <= 2.0 ** -6
+    tol = 2.0 ** -6
+    assert H.rel_err(xd.grad.float(), xo.grad) <= tol, kern
+    assert H.rel_err(etd.grad.float(), eo.grad) <= tol, kern
+    assert H.rel_err(Wd.grad, sd['filters'].grad) <= tol, kern
+    assert H.rel_err(bd.grad, sd['bias'].grad) <= tol, kern
+
+
 def test_sg_backward_is_bitwise_reproducible_and_matches_first_generation(dev, monkeypatch):
     """No atomics, fixed summation orders: two runs give identical bits; and the first-generation kernel (taken when the
     in-degree is not passed) agrees within bf16 rounding."""
