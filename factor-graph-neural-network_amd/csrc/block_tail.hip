@@ -1,0 +1,567 @@
+// block_tail.hip — TRAINING-mode fusion of the tail of `mp_conv_residual`: everything behind the message
+// operator,
+//
+//     a2 = act2(BN2(e))            e [R][64] = the operator's aggregate + bias, R = B * M destination rows (bf16)
+//     z3 = W2 a2 + b2              the block's second 1x1 map, 64 -> Cout in {64, 128, 256}
+//     out = act3(BN3(z3)) + addends
+//
+// (/root/reference/lib/model/mpnn/mp_nn.py:165-175 epilogue, mp_nn_residual.py:31-35,49-51 conv2 + BatchNorm + LeakyReLU),
+// WITHOUT ever writing the Cout-wide pre-BatchNorm tensor z3 (or, in the backward, reading it back): batch-statistics
+// BatchNorm needs a grid-wide reduction between producing z3 and normalising it, so the staged path stores z3 (bf16),
+// re-reads it to normalise, and in the backward re-reads it twice more and writes / re-reads its gradient three times —
+// 10 passes over the widest tensor of the block.  The K = 64 product is cheap on the matrix cores (13 GFLOP for the widest
+// call, ~6 us at a third of the bf16 peak), so every pass that needs z3 RECOMPUTES it from the 64-channel e instead:
+//
+//   MODE 0 "stats"   : e -> a2 -> z3 -> per-workgroup (sum z3, sum z3^2) partials          (reads 128 bytes per row, writes nothing)
+//   MODE 1 "apply"   : e -> a2 -> z3 -> out = act3(z3 s3 + t3) + addends                    (z3 never stored; optionally stores
+//                                                                                            a2 for the weight-gradient kernel)
+//   MODE 2 "reduce"  : e, gout -> z3 -> g' = gout act3'(.) -> partials (sum g', sum g' z3)  (BatchNorm3's backward sums)
+//   MODE 3 "grad"    : e, gout -> z3 -> gz3 = s3 g' + A z3 + B (BatchNorm3's input gradient, closed form per channel)
+//                      -> stores gz3 (bf16, read once by the weight-gradient kernel) and ga2 = gz3 W2 (64 channels)
+//
+// Layout trick shared by all modes (as csrc/linear_fwd_b16.hip): the product is computed TRANSPOSED, D[i = out channel]
+// [j = row] = W2 a2^T, with the MFMA row <-> channel permutation that hands lane (row, lk) the 16 CONSECUTIVE channels
+// 16 lk .. 16 lk + 15 of its row and 64-channel slab: the e operand is one contiguous 32-byte run of the row per lane,
+// gout / addends / out are contiguous 32-byte runs, and the D fragment is — after the per-element BatchNorm algebra and a
+// bf16 pack — directly the B operand of the next product (ga2^T = W2^T gz3^T), no cross-lane movement anywhere.
+// A wave owns 16-row tiles and walks all Cout / 64 slabs of its tile (W2 / W2^T fragments and the per-channel constants
+// come from LDS, stored in fragment order: conflict-free 16-byte reads; the stream stays HBM-bound).
+#include "fgnn_common.h"
+#include <stdlib.h>
+
+#define BT_THREADS 256
+#define BT_WAVES 4
+#define BT_MAXGRID 1024      // = BN_MAXPART of bnact.hip: the statistics partials use its workspace layout and finalisers
+
+typedef __bf16 bt_bf16x8 __attribute__((ext_vector_type(8)));
+
+struct BtParams {
+    const uint16_t* e;       // [R][64] bf16
+    const float* s2;         // [64] BatchNorm2 scale  (gamma * invstd)
+    const float* t2;         // [64] BatchNorm2 shift  (beta - mean * scale)
+    const float* W2;         // [Cout][64] f32
+    const float* b2;         // [Cout] or NULL
+    const float* s3;         // [Cout] BatchNorm3 scale                         (modes 1, 2, 3)
+    const float* t3;         // [Cout] BatchNorm3 shift                         (modes 1, 2, 3)
+    const float* ga;         // [Cout] A  = -s3 k2 invstd3                      (mode 3)
+    const float* gb;         // [Cout] Bc = -s3 k1 + s3 k2 invstd3 mean3        (mode 3)
+    const uint16_t* gout;    // [R][Cout] bf16 upstream gradient                (modes 2, 3)
+    const uint16_t* add0;    // [R][Cout] addends of the output or NULL         (mode 1)
+    const uint16_t* add1;
+    const uint16_t* add2;
+    uint16_t* out;           // mode 1: out [R][Cout];  mode 3: gz3 [R][Cout]
+    uint16_t* out2;          // mode 1: a2 [R][64] or NULL;  mode 3: ga2 [R][64]
+    float* part;             // [grid][2][Cout] partial sums                    (modes 0, 2)
+    float* part2;            // [grid][2][64] BatchNorm2's backward sums (sum g2', sum g2' e), or NULL      (mode 3)
+    int R, Cout;
+    float slope2, slope3;
+};
+
+extern __shared__ __attribute__((aligned(16))) unsigned char bt_lds[];
+
+__device__ __forceinline__ unsigned bt_pack2(float a, float b) {
+    typedef __bf16 v2 __attribute__((ext_vector_type(2)));
+    const v2 h = {(__bf16)a, (__bf16)b};
+    return __builtin_bit_cast(unsigned, h);
+}
+__device__ __forceinline__ float bt_lo(unsigned u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bt_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
+__device__ __forceinline__ void bt_unpack8(const uint4 q, float (&v)[8]) {
+    v[0] = bt_lo(q.x); v[1] = bt_hi(q.x); v[2] = bt_lo(q.y); v[3] = bt_hi(q.y);
+    v[4] = bt_lo(q.z); v[5] = bt_hi(q.z); v[6] = bt_lo(q.w); v[7] = bt_hi(q.w);
+}
+__device__ __forceinline__ float bt_act(float v, float slope) { return v > 0.f ? v : v * slope; }
+// Scalar f32 VALU only in this file (and -fno-slp-vectorize in the Makefile): beside a bf16 MFMA stream a packed-f32 op
+// (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32) costs ~22 extra cycles (MI355X_MICROARCH.md, per-instruction constants) — the
+// first version of the statistics pass, written with packed pairs, ran at 1 000 cycles per tile and slab instead of ~250.
+// Leaky ReLU for 0 <= slope <= 1 as max(v, slope v) (no compare / select); Z = the slope is 0: plain ReLU, one instruction.
+template <bool Z> __device__ __forceinline__ float bt_act2(float v, float slope) { return Z ? fmaxf(v, 0.f) : fmaxf(v, v * slope); }
+
+// CG = Cout / 64 slabs, NA = addends (mode 1), SL2Z = the first activation is a plain ReLU (slope2 == 0)
+template <int MODE, int CG, int NA, bool SL2Z>
+__global__ __launch_bounds__(BT_THREADS, MODE == 1 ? 3 : 2) void block_tail_kernel(const BtParams p) {
+    constexpr int COUT = 64 * CG;
+    constexpr int NCST = MODE == 0 ? 1 : (MODE == 3 ? 4 : 2);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lk = lane >> 4;
+    const int R = p.R;
+    // W2 / W2^T live in LDS in FRAGMENT order — one 16-byte slot per (slab, tile, k-step, lane) — so that a wave's operand
+    // read is 64 consecutive slots: conflict-free whatever the row permutation (a [row][k] image puts rows 16 apart, which
+    // the permutation hands to one ds_read_b128 lane group, on the same banks)
+    uint4* Wf = reinterpret_cast<uint4*>(bt_lds);                                        // [CG][4 ot][2 ks][64]   z3^T = W2 a2^T
+    uint4* Tf = Wf + CG * 8 * 64;                                                        // [CG][4 t][2 s][64]     ga2^T = W2^T gz3^T (mode 3)
+    float* cst = reinterpret_cast<float*>(Tf + (MODE == 3 ? CG * 8 * 64 : 0));           // [NCST][COUT]
+    float* red = cst + NCST * COUT;                                                      // [BT_WAVES][2][COUT] (modes 0, 2)
+    for (int f = tid; f < CG * 8 * 64; f += BT_THREADS) {
+        const int fl = f & 63, fs = (f >> 6) & 1, ft = (f >> 7) & 3, sl = f >> 9;
+        const int fi = fl & 15, fk = fl >> 4;
+        const int pr = 16 * (fi >> 2) + (fi & 3) + 4 * ft;
+        {   // A[i = out channel 64 sl + pr][k = input channels 16 fk + 8 fs .. + 7]
+            const float* wp = p.W2 + (int64_t)(64 * sl + pr) * 64 + 16 * fk + 8 * fs;
+            const f32x4 a = *reinterpret_cast<const f32x4*>(wp), b = *reinterpret_cast<const f32x4*>(wp + 4);
+            Wf[f] = make_uint4(bt_pack2(a[0], a[1]), bt_pack2(a[2], a[3]), bt_pack2(b[0], b[1]), bt_pack2(b[2], b[3]));
+        }
+        if (MODE == 3) {   // A[i = input channel pr][k = out channels 64 sl + 16 fk + 8 fs .. + 7]
+            const float* wp = p.W2 + (int64_t)(64 * sl + 16 * fk + 8 * fs) * 64 + pr;
+            float w[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) w[u] = wp[u * 64];
+            Tf[f] = make_uint4(bt_pack2(w[0], w[1]), bt_pack2(w[2], w[3]), bt_pack2(w[4], w[5]), bt_pack2(w[6], w[7]));
+        }
+    }
+    for (int o = tid; o < COUT; o += BT_THREADS) {
+        const float b = p.b2 ? p.b2[o] : 0.f;
+        if (MODE == 0) cst[o] = b;
+        else {
+            const float s = p.s3[o];
+            cst[o] = s;
+            cst[COUT + o] = fmaf(b, s, p.t3[o]);                 // pre3 = (acc + b) s3 + t3 = acc s3 + (b s3 + t3)
+            if (MODE == 3) {
+                const float a = p.ga[o];
+                cst[2 * COUT + o] = a;
+                cst[3 * COUT + o] = fmaf(a, b, p.gb[o]);         // gz3 = s3 g' + A (acc + b) + Bc
+            }
+        }
+    }
+    // BatchNorm2 affine of this lane's 16 input channels (16 lk .. 16 lk + 15)
+    // (mode 3 is short of registers: there the affine is re-read from LDS every tile — 8 broadcast reads)
+    constexpr bool S2REG = MODE != 3;
+    float* s2l = red + ((MODE == 0 || MODE == 2) ? BT_WAVES * 2 * COUT : 0);             // [2][64] (mode 3)
+    float s2[S2REG ? 16 : 1], t2[S2REG ? 16 : 1];
+    if (S2REG) {
+#pragma unroll
+        for (int c = 0; c < 16; ++c) { s2[c] = p.s2[16 * lk + c]; t2[c] = p.t2[16 * lk + c]; }
+    } else if (tid < 64) { s2l[tid] = p.s2[tid]; s2l[64 + tid] = p.t2[tid]; }
+    __syncthreads();
+
+    // MFMA row i of output tile ot  <->  channel 16 (i >> 2) + 4 ot + (i & 3) of the slab: D then gives lane (row li, lk)
+    // the channels 16 lk + 4 ot + r; k-step ks, k-group lk  <->  input channels 16 lk + 8 ks .. + 7.
+    // Modes 0 / 1 / 2 have no dependency across slabs: a wave is BOUND to one slab (its W2 fragments and per-channel
+    // constants stay in registers, the CG waves of a row group share the e rows through L1); mode 3 sums ga2 over the
+    // slabs, so there a wave walks all of them with the fragments coming from LDS.
+    constexpr bool BOUND = MODE != 3;                       // (mode 0 walking all slabs — one a2 prologue per tile instead of one per
+                                                            // tile and slab — measured SLOWER: 60 vs 46 us at Cout 256, 393 k rows: fewer,
+                                                            // fatter waves expose the MFMA -> statistics dependency)
+    const int cg = BOUND ? wave % CG : 0, rg = BOUND ? wave / CG : wave;
+    constexpr int NRG = BOUND ? BT_WAVES / CG : BT_WAVES;
+    uint4 aW[BOUND ? 4 : 1][2];
+    f32x4 c0[BOUND ? 4 : 1], c1[BOUND ? 4 : 1];
+    if (BOUND) {
+#pragma unroll
+        for (int ot = 0; ot < 4; ++ot) {
+            aW[ot][0] = Wf[((cg * 4 + ot) * 2 + 0) * 64 + lane];
+            aW[ot][1] = Wf[((cg * 4 + ot) * 2 + 1) * 64 + lane];
+            c0[ot] = *reinterpret_cast<const f32x4*>(cst + 64 * cg + 16 * lk + 4 * ot);
+            c1[ot] = MODE == 0 ? c0[ot] : *reinterpret_cast<const f32x4*>(cst + COUT + 64 * cg + 16 * lk + 4 * ot);
+        }
+    }
+    f32x4 s0[4], s1[4];
+#pragma unroll
+    for (int ot = 0; ot < 4; ++ot) { s0[ot] = (f32x4){0.f, 0.f, 0.f, 0.f}; s1[ot] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+
+    const int ntile = (R + 15) / 16;
+    const int stride = gridDim.x * NRG;
+    // Every tile's global loads are asked for DEPTH tiles ahead (a ring of register slots): a wave that only ever has the
+    // next tile in flight runs at one memory latency per tile (the statistics pass, 2 KB per tile, measured 36 us for 50 MB).
+    // The loop body is STRAIGHT-LINE code — loads are unconditional (rows past the end are clamped to the last row and masked
+    // where they are used, a wave's tile count is rounded up to a multiple of DEPTH): with loads under exec-masked branches
+    // the compiler's s_waitcnt placement falls back to vmcnt(0) at every merge and the ring buys nothing.
+    constexpr int DEPTH = MODE == 0 ? 4 : (MODE == 2 ? 2 : 1);
+    const int first = blockIdx.x * NRG + rg;
+    const int mine = first < ntile ? (ntile - first + stride - 1) / stride : 0;           // tiles of this wave
+    auto load_e = [&](int it, uint4 (&q)[2]) {
+        const int row = min((first + it * stride) * 16 + li, R - 1);
+        const uint16_t* ep = p.e + (int64_t)row * 64 + 16 * lk;
+        q[0] = *reinterpret_cast<const uint4*>(ep);
+        q[1] = *reinterpret_cast<const uint4*>(ep + 8);
+    };
+    auto load_g = [&](int it, uint4 (&gp)[2]) {           // a slab-bound wave knows its slab: the upstream gradient rides along (mode 2)
+        const int row = min((first + it * stride) * 16 + li, R - 1);
+        const uint16_t* gpp = p.gout + (int64_t)row * COUT + 64 * cg + 16 * lk;
+        gp[0] = *reinterpret_cast<const uint4*>(gpp);
+        gp[1] = *reinterpret_cast<const uint4*>(gpp + 8);
+    };
+    // A slot is refilled right AFTER its last use, into the same registers: a refill issued while the old value is still
+    // live gets registers of its own and a copy at the loop's back edge — a copy that has to wait for the load.
+    uint4 ring_e[DEPTH][2], ring_g[MODE == 2 ? DEPTH : 1][2];
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) {                     // (issued in slot order, like the refills: the loop header's wait is the
+        load_e(d, ring_e[d]);                             //  worst case over both ways into the loop)
+        if (MODE == 2) load_g(d, ring_g[d]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    for (int base = 0; base < mine; base += DEPTH) {
+#pragma unroll
+      for (int d = 0; d < DEPTH; ++d) {
+        const int it = base + d;
+        const int tile = first + it * stride;
+        const int row = tile * 16 + li;
+        const bool ok = it < mine && row < R;
+        const bool partial = it >= mine || tile * 16 + 15 >= R;     // wave-uniform
+        if (MODE == 3) asm volatile("" ::: "memory");       // LDS operands are re-read per tile, not hoisted into (spilled) registers
+        uint4 (&eq)[2] = ring_e[d];
+        const uint4 zq4 = make_uint4(0, 0, 0, 0);
+        const int crow = min(row, R - 1);                   // (address arithmetic of masked rows stays inside the tensors)
+        // ---- a2 = act2(e s2 + t2), packed to bf16: the B operand of z3^T = W2 a2^T (and the tensor the staged path stores) ----
+        bt_bf16x8 a2f[2];
+        unsigned pos2 = 0u;                                // bit c: pre2 > 0 for channel 16 lk + c of this row (mode 3)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const unsigned w[4] = {eq[ks].x, eq[ks].y, eq[ks].z, eq[ks].w};
+            unsigned o[4];
+            f32x4 sl4[2], tl4[2];
+            if (!S2REG) {
+                sl4[0] = *reinterpret_cast<const f32x4*>(s2l + 16 * lk + 8 * ks); sl4[1] = *reinterpret_cast<const f32x4*>(s2l + 16 * lk + 8 * ks + 4);
+                tl4[0] = *reinterpret_cast<const f32x4*>(s2l + 64 + 16 * lk + 8 * ks); tl4[1] = *reinterpret_cast<const f32x4*>(s2l + 64 + 16 * lk + 8 * ks + 4);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int c = 8 * ks + 2 * u;
+                const float sc0 = S2REG ? s2[S2REG ? c : 0] : sl4[u >> 1][2 * (u & 1)], sc1 = S2REG ? s2[S2REG ? c + 1 : 0] : sl4[u >> 1][2 * (u & 1) + 1];
+                const float sh0 = S2REG ? t2[S2REG ? c : 0] : tl4[u >> 1][2 * (u & 1)], sh1 = S2REG ? t2[S2REG ? c + 1 : 0] : tl4[u >> 1][2 * (u & 1) + 1];
+                const float v0 = bt_act2<SL2Z>(fmaf(bt_lo(w[u]), sc0, sh0), p.slope2), v1 = bt_act2<SL2Z>(fmaf(bt_hi(w[u]), sc1, sh1), p.slope2);
+                o[u] = bt_pack2(v0, v1);
+                if (MODE == 3) pos2 |= (v0 > 0.f ? 1u : 0u) << c | (v1 > 0.f ? 1u : 0u) << (c + 1);
+            }
+            uint4 q = make_uint4(o[0], o[1], o[2], o[3]);
+            if (partial && !ok) q = make_uint4(0, 0, 0, 0);      // rows past the end contribute nothing to any sum (last tile only)
+            a2f[ks] = __builtin_bit_cast(bt_bf16x8, q);
+            if (MODE == 1 && p.out2 && ok && cg == 0) *reinterpret_cast<uint4*>(p.out2 + (int64_t)row * 64 + 16 * lk + 8 * ks) = q;
+        }
+        if (MODE != 3) {                                    // e of this slot is consumed: ask for the tile DEPTH ahead (pinned here)
+            load_e(it + DEPTH, ring_e[d]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        f32x4 g2acc[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) g2acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (MODE == 0) {           // sums of z3 - b2 (the finaliser adds the bias back: K = b2); rows past the end are zero columns
+            f32x4 acc[4];
+#pragma unroll
+            for (int ot = 0; ot < 4; ++ot) {
+                acc[ot] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+                    acc[ot] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bt_bf16x8, aW[BOUND ? ot : 0][ks]), a2f[ks], acc[ot], 0, 0, 0);
+            }
+#pragma unroll
+            for (int ot = 0; ot < 4; ++ot)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    s0[ot][r] += acc[ot][r];
+                    s1[ot][r] = fmaf(acc[ot][r], acc[ot][r], s1[ot][r]);
+                }
+        }
+#pragma unroll 1
+        for (int sl = BOUND ? cg : 0; sl < (MODE == 0 ? 0 : (BOUND ? cg + 1 : CG)); ++sl) {
+            const int o_base = 64 * sl;
+            // the slab's upstream gradient / addends: 32 contiguous bytes of this lane's row each, asked for before the product
+            uint4 gq[2] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
+            uint4 aq[3][2];
+            const int64_t eoff = (int64_t)crow * COUT + o_base + 16 * lk;
+            if (MODE == 2) { gq[0] = ok ? ring_g[d][0] : zq4; gq[1] = ok ? ring_g[d][1] : zq4; }
+            if (MODE == 3) {
+                const uint4 g0 = *reinterpret_cast<const uint4*>(p.gout + eoff), g1 = *reinterpret_cast<const uint4*>(p.gout + eoff + 8);
+                gq[0] = ok ? g0 : zq4;
+                gq[1] = ok ? g1 : zq4;
+            }
+            if (MODE == 1) {
+                const uint16_t* const ads[3] = {p.add0, p.add1, p.add2};
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    aq[a][0] = aq[a][1] = zq4;
+                    if (a < NA) { aq[a][0] = *reinterpret_cast<const uint4*>(ads[a] + eoff); aq[a][1] = *reinterpret_cast<const uint4*>(ads[a] + eoff + 8); }
+                }
+            }
+            f32x4 acc[4];
+#pragma unroll
+            for (int ot = 0; ot < 4; ++ot) {
+                acc[ot] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const uint4 a = BOUND ? aW[BOUND ? ot : 0][ks] : Wf[((sl * 4 + ot) * 2 + ks) * 64 + lane];
+                    acc[ot] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bt_bf16x8, a), a2f[ks], acc[ot], 0, 0, 0);
+                }
+            }
+            // acc[ot][r] = z3 - b2 of channel o_base + 16 lk + 4 ot + r, row li
+            const float* cp = cst + o_base + 16 * lk;
+            if (MODE == 0) {
+            } else if (MODE == 1) {
+                float y[16];
+#pragma unroll
+                for (int ot = 0; ot < 4; ++ot)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) y[4 * ot + r] = bt_act2<false>(fmaf(acc[ot][r], c0[ot][r], c1[ot][r]), p.slope3);
+#pragma unroll
+                for (int a = 0; a < NA; ++a) {
+                    float v[8];
+                    bt_unpack8(aq[a][0], v);
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) y[u] += v[u];
+                    bt_unpack8(aq[a][1], v);
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) y[8 + u] += v[u];
+                }
+                if (ok) {
+                    uint16_t* op = p.out + eoff;
+                    *reinterpret_cast<uint4*>(op) = make_uint4(bt_pack2(y[0], y[1]), bt_pack2(y[2], y[3]), bt_pack2(y[4], y[5]), bt_pack2(y[6], y[7]));
+                    *reinterpret_cast<uint4*>(op + 8) = make_uint4(bt_pack2(y[8], y[9]), bt_pack2(y[10], y[11]), bt_pack2(y[12], y[13]), bt_pack2(y[14], y[15]));
+                }
+            } else {
+                float g[16];
+                {
+                    float v[8];
+                    bt_unpack8(gq[0], v);
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) g[u] = v[u];
+                    bt_unpack8(gq[1], v);
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) g[8 + u] = v[u];
+                }
+                if (MODE == 2) {
+                    load_g(it + DEPTH, ring_g[d]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                float gz[16];
+#pragma unroll
+                for (int ot = 0; ot < 4; ++ot) {
+                    f32x4 s, t, ca = {0.f, 0.f, 0.f, 0.f}, cb = {0.f, 0.f, 0.f, 0.f};
+                    if (MODE == 2) { s = c0[ot]; t = c1[ot]; }
+                    else {
+                        s = *reinterpret_cast<const f32x4*>(cp + 4 * ot);
+                        t = *reinterpret_cast<const f32x4*>(cp + COUT + 4 * ot);
+                        ca = *reinterpret_cast<const f32x4*>(cp + 2 * COUT + 4 * ot);
+                        cb = *reinterpret_cast<const f32x4*>(cp + 3 * COUT + 4 * ot);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float pre = fmaf(acc[ot][r], s[r], t[r]);
+                        const float ge = pre > 0.f ? g[4 * ot + r] : g[4 * ot + r] * p.slope3;
+                        if (MODE == 2) {
+                            s0[ot][r] += ge;                                       // rows >= R carry g = 0
+                            s1[ot][r] = fmaf(ge, acc[ot][r], s1[ot][r]);
+                        } else gz[4 * ot + r] = fmaf(s[r], ge, fmaf(ca[r], acc[ot][r], cb[r]));
+                    }
+                }
+                if (MODE == 3) {
+                    const uint4 q0 = make_uint4(bt_pack2(gz[0], gz[1]), bt_pack2(gz[2], gz[3]), bt_pack2(gz[4], gz[5]), bt_pack2(gz[6], gz[7]));
+                    const uint4 q1 = make_uint4(bt_pack2(gz[8], gz[9]), bt_pack2(gz[10], gz[11]), bt_pack2(gz[12], gz[13]), bt_pack2(gz[14], gz[15]));
+                    if (ok) {
+                        *reinterpret_cast<uint4*>(p.out + eoff) = q0;
+                        *reinterpret_cast<uint4*>(p.out + eoff + 8) = q1;
+                    }
+                    // ga2^T += W2^T[:, slab] gz3^T[slab]: k-step s, k-group lk <-> out channels o_base + 16 lk + 8 s .. + 7 = q_s as it stands
+                    const uint4 zq = make_uint4(0, 0, 0, 0);
+                    const bt_bf16x8 b0 = __builtin_bit_cast(bt_bf16x8, ok ? q0 : zq), b1 = __builtin_bit_cast(bt_bf16x8, ok ? q1 : zq);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const uint4* wp = Tf + ((sl * 4 + t) * 2) * 64 + lane;
+                        g2acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bt_bf16x8, wp[0]), b0, g2acc[t], 0, 0, 0);
+                        g2acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bt_bf16x8, wp[64]), b1, g2acc[t], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        if (MODE == 3 && p.part2 && ok) {     // BatchNorm2's backward sums over this row: g2' = ga2 act2'(pre2), against the raw e
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const unsigned w0 = t < 2 ? (t == 0 ? eq[0].x : eq[0].z) : (t == 2 ? eq[1].x : eq[1].z);
+                const unsigned w1 = t < 2 ? (t == 0 ? eq[0].y : eq[0].w) : (t == 2 ? eq[1].y : eq[1].w);
+                const float ev[4] = {bt_lo(w0), bt_hi(w0), bt_lo(w1), bt_hi(w1)};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float gg = (pos2 >> (4 * t + r)) & 1u ? g2acc[t][r] : g2acc[t][r] * p.slope2;
+                    s0[t][r] += gg;
+                    s1[t][r] = fmaf(gg, ev[r], s1[t][r]);
+                }
+            }
+        }
+        if (MODE == 3 && ok) {       // g2acc[t][r] = ga2 of channel 16 lk + 4 t + r of row li
+            uint16_t* gp = p.out2 + (int64_t)row * 64 + 16 * lk;
+            *reinterpret_cast<uint4*>(gp) = make_uint4(bt_pack2(g2acc[0][0], g2acc[0][1]), bt_pack2(g2acc[0][2], g2acc[0][3]),
+                                                       bt_pack2(g2acc[1][0], g2acc[1][1]), bt_pack2(g2acc[1][2], g2acc[1][3]));
+            *reinterpret_cast<uint4*>(gp + 8) = make_uint4(bt_pack2(g2acc[2][0], g2acc[2][1]), bt_pack2(g2acc[2][2], g2acc[2][3]),
+                                                           bt_pack2(g2acc[3][0], g2acc[3][1]), bt_pack2(g2acc[3][2], g2acc[3][3]));
+        }
+        if (MODE == 3) load_e(it + DEPTH, ring_e[d]);
+      }
+    }
+    if (MODE == 0 || MODE == 2 || (MODE == 3 && p.part2)) {
+        // per-workgroup partial sums of every channel: fold the 16 rows of the tiles, then the row groups (mode 3: BatchNorm2's
+        // sums over the 64 input channels, 16 lk + 4 t + r)
+        constexpr int CF = MODE == 3 ? 64 : COUT;
+        float* redf = MODE == 3 ? reinterpret_cast<float*>(bt_lds) : red;     // mode 3: the fragments are no longer needed
+        if (MODE == 3) __syncthreads();
+#pragma unroll
+        for (int ot = 0; ot < 4; ++ot)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float a = s0[ot][r], b = s1[ot][r];
+#pragma unroll
+                for (int m = 1; m < 16; m <<= 1) { a += __shfl_xor(a, m); b += __shfl_xor(b, m); }
+                if (li == 0) {
+                    const int o = 64 * cg + 16 * lk + 4 * ot + r;
+                    redf[(rg * 2) * CF + o] = a;
+                    redf[(rg * 2 + 1) * CF + o] = b;
+                }
+            }
+        __syncthreads();
+        float* dst = MODE == 3 ? p.part2 : p.part;
+        for (int f = tid; f < 2 * CF; f += BT_THREADS) {
+            float s = 0.f;
+#pragma unroll
+            for (int w = 0; w < NRG; ++w) s += redf[w * 2 * CF + f];
+            dst[(int64_t)blockIdx.x * 2 * CF + f] = s;
+        }
+    }
+}
+
+// BatchNorm3's backward sums from the "reduce" partials, and the per-channel constants of the closed-form input gradient:
+//   S0 = sum g', S1 = sum g' (z3 - b2)   ->   dbeta = S0,  dgamma = invstd (S1 + (b2 - mean) S0)
+//   gz3 = s3 (g' - dbeta / R - zhat dgamma / R) = s3 g' + A z3 + Bc,   A = -s3 invstd dgamma / R,   Bc = -s3 dbeta / R - A mean
+// 4 channels x 64 partial groups per block, folded in f64 in a fixed order.
+__global__ __launch_bounds__(256) void block_tail_bwd_final_kernel(const float* ws, int nwg, int C, int64_t R, const float* b2,
+                                                                   const float* mean, const float* invstd, const float* gamma,
+                                                                   float* A, float* Bc, float* gweight, float* gbias) {
+    __shared__ double r0[256], r1[256];
+    const int cc = threadIdx.x & 3, pg = threadIdx.x >> 2;
+    const int c = blockIdx.x * 4 + cc;
+    double a = 0.0, b = 0.0;
+    if (c < C)
+        for (int w = pg; w < nwg; w += 64) { a += (double)ws[(int64_t)w * 2 * C + c]; b += (double)ws[(int64_t)w * 2 * C + C + c]; }
+    r0[threadIdx.x] = a;
+    r1[threadIdx.x] = b;
+    __syncthreads();
+    if (pg != 0 || c >= C) return;
+    double S0 = 0.0, S1 = 0.0;
+    for (int q = 0; q < 64; ++q) { S0 += r0[q * 4 + cc]; S1 += r1[q * 4 + cc]; }
+    const double mu = (double)mean[c], is = (double)invstd[c], bb = b2 ? (double)b2[c] : 0.0;
+    const double dbeta = S0, dgamma = is * (S1 + (bb - mu) * S0);
+    const double s3 = (double)gamma[c] * is, n = (double)R;
+    const double Ac = -s3 * is * dgamma / n;
+    A[c] = (float)Ac;
+    Bc[c] = (float)(-s3 * dbeta / n - Ac * mu);
+    if (gbias) gbias[c] += (float)dbeta;
+    if (gweight) gweight[c] += (float)dgamma;
+}
+
+// ----------------------------------------------------------------------------------------
+// host side
+// ----------------------------------------------------------------------------------------
+static int bt_plan(int64_t R, int Cout, int* grid, bool bound = true) {
+    if (R <= 0 || R > 0x7fffffff || (Cout != 64 && Cout != 128 && Cout != 256)) return -1;
+    const int64_t ntile = (R + 15) / 16;
+    const int nrg = bound ? BT_WAVES / (Cout / 64) : BT_WAVES;       // row groups per workgroup (modes 0-2: a wave is bound to a slab)
+    int64_t g = (ntile + 2 * nrg - 1) / (2 * nrg);                    // >= 2 tiles per wave
+    static const int maxg = getenv("FGNN_BT_GRID") ? atoi(getenv("FGNN_BT_GRID")) : 768;
+    if (g > maxg) g = maxg;
+    if (g > BT_MAXGRID) g = BT_MAXGRID;
+    if (g < 1) g = 1;
+    *grid = (int)g;
+    return 0;
+}
+
+extern "C" int fgnn_block_tail_partials(int64_t R, int Cout) {
+    int grid;
+    return bt_plan(R, Cout, &grid) ? 0 : grid;
+}
+
+// rows of [2][64] BatchNorm2 partials fgnn_block_tail_backward writes when asked to (0 = shape not supported)
+extern "C" int fgnn_block_tail_backward_partials(int64_t R, int Cout) {
+    int grid;
+    return bt_plan(R, Cout, &grid, false) ? 0 : grid;
+}
+
+template <int MODE, int NA = 0>
+static int bt_launch(const BtParams& p, int grid, hipStream_t st) {
+    const int CG = p.Cout / 64;
+    void* fn;
+    if (p.slope2 == 0.f) fn = CG == 1 ? (void*)block_tail_kernel<MODE, 1, NA, true> : (CG == 2 ? (void*)block_tail_kernel<MODE, 2, NA, true> : (void*)block_tail_kernel<MODE, 4, NA, true>);
+    else fn = CG == 1 ? (void*)block_tail_kernel<MODE, 1, NA, false> : (CG == 2 ? (void*)block_tail_kernel<MODE, 2, NA, false> : (void*)block_tail_kernel<MODE, 4, NA, false>);
+    const int ncst = MODE == 0 ? 1 : (MODE == 3 ? 4 : 2);
+    const int lds = CG * 8 * 64 * 16 * (MODE == 3 ? 2 : 1) + ncst * p.Cout * 4 + ((MODE == 0 || MODE == 2) ? BT_WAVES * 2 * p.Cout * 4 : 128 * 4);
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "hipFuncSetAttribute(%d B LDS): %s", lds, hipGetErrorString(e));
+    }
+    void* args[] = {(void*)&p};
+    hipError_t e = hipLaunchKernel(fn, dim3(grid), dim3(BT_THREADS), args, lds, st);
+    if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "block_tail launch (mode %d): %s", MODE, hipGetErrorString(e));
+    return FGNN_OK;
+}
+
+static int bt_check(const char* who, const void* e, const float* s2, const float* t2, const float* W2, int64_t R, int Cout, int* grid) {
+    if (!e || !s2 || !t2 || !W2) FGNN_FAIL(FGNN_EINVAL, "%s: null pointer", who);
+    if (bt_plan(R, Cout, grid) || ((uintptr_t)e & 15) || ((uintptr_t)W2 & 7))
+        FGNN_FAIL(FGNN_EUNSUPPORTED, "%s: Cout=%d / alignment outside the fused block tail's family", who, Cout);
+    return FGNN_OK;
+}
+
+extern "C" int fgnn_block_tail_stats(const void* e, const float* scale2, const float* shift2, float slope2, const float* W2,
+                                     const float* b2, int64_t R, int Cout, float* partials, fgnn_stream_t stream) {
+    int grid, rc;
+    if ((rc = bt_check("block_tail_stats", e, scale2, shift2, W2, R, Cout, &grid))) return rc;
+    if (!partials) FGNN_FAIL(FGNN_EINVAL, "block_tail_stats: null partials");
+    BtParams p = {};
+    p.e = (const uint16_t*)e; p.s2 = scale2; p.t2 = shift2; p.W2 = W2; p.b2 = b2; p.part = partials;
+    p.R = (int)R; p.Cout = Cout; p.slope2 = slope2;
+    return bt_launch<0>(p, grid, (hipStream_t)stream);
+}
+
+extern "C" int fgnn_block_tail_apply(const void* e, const float* scale2, const float* shift2, float slope2, const float* W2,
+                                     const float* b2, const float* scale3, const float* shift3, float slope3,
+                                     const void* addend0, const void* addend1, const void* addend2, void* out, void* a2_out,
+                                     int64_t R, int Cout, fgnn_stream_t stream) {
+    int grid, rc;
+    if ((rc = bt_check("block_tail_apply", e, scale2, shift2, W2, R, Cout, &grid))) return rc;
+    if (!scale3 || !shift3 || !out) FGNN_FAIL(FGNN_EINVAL, "block_tail_apply: null pointer");
+    if (((uintptr_t)out | (uintptr_t)a2_out | (uintptr_t)addend0 | (uintptr_t)addend1 | (uintptr_t)addend2) & 15)
+        FGNN_FAIL(FGNN_EUNSUPPORTED, "block_tail_apply: misaligned operand");
+    BtParams p = {};
+    p.e = (const uint16_t*)e; p.s2 = scale2; p.t2 = shift2; p.W2 = W2; p.b2 = b2; p.s3 = scale3; p.t3 = shift3;
+    const void* ads[3] = {addend0, addend1, addend2};      // packed to the front: the kernel is specialised on their number
+    int na = 0;
+    for (int a = 0; a < 3; ++a) if (ads[a]) ads[na++] = ads[a];
+    p.add0 = (const uint16_t*)(na > 0 ? ads[0] : nullptr); p.add1 = (const uint16_t*)(na > 1 ? ads[1] : nullptr);
+    p.add2 = (const uint16_t*)(na > 2 ? ads[2] : nullptr);
+    p.out = (uint16_t*)out; p.out2 = (uint16_t*)a2_out; p.R = (int)R; p.Cout = Cout; p.slope2 = slope2; p.slope3 = slope3;
+    hipStream_t st = (hipStream_t)stream;
+    switch (na) {
+        case 0: return bt_launch<1, 0>(p, grid, st);
+        case 1: return bt_launch<1, 1>(p, grid, st);
+        case 2: return bt_launch<1, 2>(p, grid, st);
+        default: return bt_launch<1, 3>(p, grid, st);
+    }
+}
+
+extern "C" int fgnn_block_tail_backward(const void* e, const float* scale2, const float* shift2, float slope2,
+                                        const float* W2, const float* b2, const float* mean3, const float* invstd3,
+                                        const float* gamma3, const float* scale3, const float* shift3, float slope3,
+                                        const void* gout, void* gz3, void* ga2, float* gweight3, float* gbias3,
+                                        float* bn2_partials, int64_t R, int Cout, void* workspace, int64_t workspace_bytes,
+                                        fgnn_stream_t stream) {
+    int grid, rc;
+    if ((rc = bt_check("block_tail_backward", e, scale2, shift2, W2, R, Cout, &grid))) return rc;
+    if (!mean3 || !invstd3 || !gamma3 || !scale3 || !shift3 || !gout || !gz3 || !ga2 || !workspace)
+        FGNN_FAIL(FGNN_EINVAL, "block_tail_backward: null pointer");
+    if (((uintptr_t)gout | (uintptr_t)gz3 | (uintptr_t)ga2) & 15) FGNN_FAIL(FGNN_EUNSUPPORTED, "block_tail_backward: misaligned operand");
+    if (workspace_bytes < ((int64_t)BT_MAXGRID * 2 * Cout + 2 * Cout) * 4) FGNN_FAIL(FGNN_EINVAL, "block_tail_backward: workspace too small");
+    float* ws = (float*)workspace;
+    float* A = ws + (int64_t)BT_MAXGRID * 2 * Cout;
+    float* Bc = A + Cout;
+    hipStream_t st = (hipStream_t)stream;
+    BtParams p = {};
+    p.e = (const uint16_t*)e; p.s2 = scale2; p.t2 = shift2; p.W2 = W2; p.b2 = b2; p.s3 = scale3; p.t3 = shift3;
+    p.gout = (const uint16_t*)gout; p.part = ws; p.R = (int)R; p.Cout = Cout; p.slope2 = slope2; p.slope3 = slope3;
+    if ((rc = bt_launch<2>(p, grid, st))) return rc;
+    int grid3;
+    (void)bt_plan(R, Cout, &grid3, false);
+    hipLaunchKernelGGL(block_tail_bwd_final_kernel, dim3((Cout + 3) / 4), dim3(256), 0, st, ws, grid, Cout, R, b2, mean3,
+                       invstd3, gamma3, A, Bc, gweight3, gbias3);
+    p.ga = A; p.gb = Bc; p.out = (uint16_t*)gz3; p.out2 = (uint16_t*)ga2; p.part = nullptr; p.part2 = bn2_partials;
+    if ((rc = bt_launch<3>(p, grid3, st))) return rc;
+    hipError_t e2 = hipGetLastError();
+    if (e2 != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "block_tail_backward launch: %s", hipGetErrorString(e2));
+    return FGNN_OK;
+}

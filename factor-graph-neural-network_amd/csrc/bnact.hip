@@ -353,6 +353,21 @@ extern "C" int fgnn_bn_finalize(const float* partials, int npartials, int64_t R,
     return FGNN_OK;
 }
 
+// The same with partials of (y - K[c]): the producer summed its values before adding a per-channel constant K (a bias).
+extern "C" int fgnn_bn_finalize_shifted(const float* partials, int npartials, int64_t R, int C, const float* K, const float* gamma,
+                                        const float* beta, float* running_mean, float* running_var, float momentum,
+                                        float eps, float* mean, float* invstd, float* scale, float* shift,
+                                        int64_t* num_batches_tracked, fgnn_stream_t stream) {
+    if (!partials || !mean || !invstd || !scale || !shift) FGNN_FAIL(FGNN_EINVAL, "bn_finalize_shifted: null pointer");
+    if (npartials < 1 || npartials > BN_MAXPART || R < 1 || C < 1) FGNN_FAIL(FGNN_EINVAL, "bn_finalize_shifted: bad sizes");
+    hipLaunchKernelGGL(bn_stats_final_kernel, dim3((C + BN_FC - 1) / BN_FC), dim3(256), 0, (hipStream_t)stream, partials,
+                       npartials, C, R, K, gamma, beta, running_mean, running_var, momentum, eps,
+                       mean, invstd, scale, shift, (long long*)num_batches_tracked);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "bn_finalize_shifted launch: %s", hipGetErrorString(e));
+    return FGNN_OK;
+}
+
 // y = act(x * scale + shift) [+ addend + addend2 + addend3], act = LeakyReLU(slope) (slope 0: ReLU, slope 1: identity)
 extern "C" int fgnn_bn_apply(const void* x, void* y, int64_t R, int C, int dtype, const float* scale,
                              const float* shift, float slope, const void* addend, const void* addend2,
@@ -396,5 +411,44 @@ extern "C" int fgnn_bn_backward(const void* x, const void* gy, void* gx, int64_t
     else hipLaunchKernelGGL((bn_apply_kernel<bf16_t, 1>), dim3(agrid), dim3(BN_THREADS), 0, st, pa);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "bn_backward launch: %s", hipGetErrorString(e));
+    return FGNN_OK;
+}
+
+// backward finaliser for partials of (sum g, sum g * x) with the RAW x: dbeta = S0, dgamma = invstd (S1 - mean S0)
+__global__ __launch_bounds__(256) void bn_bwd_final_raw_kernel(const float* ws, int nwg, int C, const float* mean,
+                                                               const float* invstd, float* dsum, float* gweight, float* gbias) {
+    const int c = blockIdx.x * BN_FC + (threadIdx.x & (BN_FC - 1)), pg = threadIdx.x / BN_FC;
+    double s0, s1;
+    bn_fold(ws, nwg, C, c, pg, c < C, s0, s1);
+    if (pg != 0 || c >= C) return;
+    const double dg = (double)invstd[c] * (s1 - (double)mean[c] * s0);
+    dsum[c] = (float)s0;
+    dsum[C + c] = (float)dg;
+    if (gbias) gbias[c] += (float)s0;
+    if (gweight) gweight[c] += (float)dg;
+}
+
+// fgnn_bn_backward without its reduction pass: somebody else (csrc/block_tail.hip's grad kernel) already left per-workgroup
+// partials [npartials][2][C] of (sum g, sum g * x), g = gy * act'(pre), x raw.  workspace: >= 2 * C floats.
+extern "C" int fgnn_bn_backward_partials(const void* x, const void* gy, void* gx, int64_t R, int C, int dtype,
+                                         const float* mean, const float* invstd, const float* gamma, const float* beta,
+                                         float slope, float* gweight, float* gbias, const float* partials, int npartials,
+                                         void* workspace, fgnn_stream_t stream) {
+    BnParams p = {};
+    int grid;
+    if (!x || !gy || !gx || !mean || !invstd || !gamma || !beta || !partials || !workspace)
+        FGNN_FAIL(FGNN_EINVAL, "bn_backward_partials: null pointer");
+    if (npartials < 1 || npartials > BN_MAXPART) FGNN_FAIL(FGNN_EINVAL, "bn_backward_partials: bad partial count");
+    if (bn_plan(R, C, dtype, &p, &grid, bn_apply_grid())) FGNN_FAIL(FGNN_EUNSUPPORTED, "bn: C=%d not a supported channel count", C);
+    float* dsum = (float*)workspace;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(bn_bwd_final_raw_kernel, dim3((C + BN_FC - 1) / BN_FC), dim3(256), 0, st, partials, npartials, C, mean,
+                       invstd, dsum, gweight, gbias);
+    p.x = x; p.gy = gy; p.out = gx; p.a = mean; p.b = invstd; p.gamma = gamma; p.beta = beta;
+    p.slope = slope; p.dsum_scale = 1.0f / (float)R; p.dbeta = dsum; p.dgamma = dsum + C;
+    if (dtype == FGNN_F32) hipLaunchKernelGGL((bn_apply_kernel<float, 1>), dim3(grid), dim3(BN_THREADS), 0, st, p);
+    else hipLaunchKernelGGL((bn_apply_kernel<bf16_t, 1>), dim3(grid), dim3(BN_THREADS), 0, st, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "bn_backward_partials launch: %s", hipGetErrorString(e));
     return FGNN_OK;
 }

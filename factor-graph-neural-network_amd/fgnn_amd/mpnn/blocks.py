@@ -83,6 +83,113 @@ def _is_identity_list(nn_idx):
     return memo[1]
 
 
+FUSE_TRAIN_TAIL = True       # training: BatchNorm2 + ReLU -> conv2 -> BatchNorm3 + LeakyReLU (+ addends) without storing conv2's output
+
+
+class _BlockTail(torch.autograd.Function):
+    """Everything behind the message operator in a training-mode ``mp_conv_residual`` (mp_nn.py:165-175 BatchNorm + ReLU,
+    mp_nn_residual.py:31-35,49-51 conv2 + BatchNorm + LeakyReLU, + the caller's addends) through csrc/block_tail.hip: the
+    Cout-wide pre-BatchNorm tensor of conv2 is recomputed from the operator's 64-channel output wherever it is needed
+    (statistics, normalisation, BatchNorm3's backward sums and input gradient) instead of being stored and re-read."""
+
+    @staticmethod
+    def forward(ctx, e, w2, b2, slope2, slope3, momentum2, eps2, momentum3, eps3, W2, bias2, w3, b3, rm2, rv2, nbt2, rm3, rv3,
+                nbt3, add0=None, add1=None, add2=None):
+        import ctypes
+        from .. import _hip
+        from . import pointwise
+        L = _hip.lib()
+        P = _hip._ptr
+        R, Cout = e.shape[0], W2.shape[0]
+        dev = e.device
+        st2 = torch.empty((4, 64), device=dev, dtype=torch.float32)         # mean, invstd, scale, shift
+        st3 = torch.empty((4, Cout), device=dev, dtype=torch.float32)
+        ws = ops._workspace(dev, int(L.fgnn_bn_workspace_bytes(R, Cout)))
+        npart = pointwise.take_pending_stats(e)
+        if npart:           # the operator's epilogue left (sum, sum of squares) partials of e
+            _hip.check(L.fgnn_bn_finalize(P(ws), npart, R, 64, P(w2), P(b2), P(rm2), P(rv2), momentum2, eps2, P(st2[0]), P(st2[1]),
+                                          P(st2[2]), P(st2[3]), P(nbt2), _hip.stream_ptr()))
+        else:
+            ops.timed('bn_stats (reduce + finalise)', e.numel() * 2, lambda: _hip.check(L.fgnn_bn_stats(
+                P(e), R, 64, _hip.BF16, P(w2), P(b2), P(rm2), P(rv2), momentum2, eps2, P(st2[0]), P(st2[1]), P(st2[2]), P(st2[3]),
+                P(nbt2), P(ws), ws.numel() * 4, _hip.stream_ptr())))
+        a2 = torch.empty_like(e)
+        W2c = W2.detach()
+        bias2c = None if bias2 is None else bias2.detach()
+        flops = 2 * R * 64 * Cout
+        ops.timed('block_tail_stats_kernel', 2 * R * 64, lambda: _hip.check(L.fgnn_block_tail_stats(
+            P(e), P(st2[2]), P(st2[3]), slope2, P(W2c), P(bias2c), R, Cout, P(ws), _hip.stream_ptr())), nflops=flops)
+        _hip.check(L.fgnn_bn_finalize_shifted(P(ws), int(L.fgnn_block_tail_partials(R, Cout)), R, Cout, P(bias2c), P(w3), P(b3), P(rm3),
+                                              P(rv3), momentum3, eps3, P(st3[0]), P(st3[1]), P(st3[2]), P(st3[3]), P(nbt3),
+                                              _hip.stream_ptr()))
+        out = torch.empty((R, Cout), device=dev, dtype=e.dtype)
+        adds = (add0, add1, add2)
+        nadd = sum(a is not None for a in adds)
+        ops.timed('block_tail_apply_kernel', 2 * R * (2 * 64 + (1 + nadd) * Cout), lambda: _hip.check(L.fgnn_block_tail_apply(
+            P(e), P(st2[2]), P(st2[3]), slope2, P(W2c), P(bias2c), P(st3[2]), P(st3[3]), slope3, P(add0), P(add1), P(add2), P(out), P(a2),
+            R, Cout, _hip.stream_ptr())), nflops=flops)
+        pointwise.note_state_change()                   # running statistics / num_batches_tracked were just updated in place
+        ctx.save_for_backward(e, a2, st2, st3, w2, b2, W2, w3)
+        ctx.slopes = (slope2, slope3)
+        ctx.has_add = tuple(a is not None for a in adds)
+        ctx.has_bias2 = bias2 is not None
+        ctx.params = (w2, b2, W2, bias2, w3, b3)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        from .. import _hip
+        L = _hip.lib()
+        P = _hip._ptr
+        e, a2, st2, st3, w2, b2, W2, w3 = ctx.saved_tensors
+        slope2, slope3 = ctx.slopes
+        pw2, pb2, pW2, pbias2, pw3, pb3 = ctx.params
+        R, Cout = e.shape[0], W2.shape[0]
+        dev = e.device
+        gout = gout.contiguous()
+        if gout.dtype != e.dtype:
+            gout = gout.to(e.dtype)
+
+        def sink(param, shape):
+            g = ops.grad_sink(param)
+            return (g, True) if g is not None else (torch.zeros(shape, device=dev, dtype=torch.float32), False)
+        gw3, s_w3 = sink(pw3, (Cout,))
+        gb3, s_b3 = sink(pb3, (Cout,))
+        gw2, s_w2 = sink(pw2, (64,))
+        gb2, s_b2 = sink(pb2, (64,))
+        Wbase = pW2._base if pW2._base is not None and pW2._base.numel() == pW2.numel() else pW2
+        gW2, s_W2 = sink(Wbase, (Cout, 64))
+        gbias2, s_bias2 = sink(pbias2, (Cout,)) if ctx.has_bias2 else (None, True)
+        gz3 = torch.empty((R, Cout), device=dev, dtype=e.dtype)
+        ga2 = torch.empty_like(e)
+        nb3 = int(L.fgnn_bn_workspace_bytes(R, Cout))
+        np2 = int(L.fgnn_block_tail_backward_partials(R, Cout))
+        ws = ops._workspace(dev, max(nb3 + (np2 * 128 + 128) * 4, int(L.fgnn_linear_wgrad_workspace_bytes(R, 64, Cout))))
+        part2 = ws[nb3 // 4: nb3 // 4 + np2 * 128]          # BatchNorm2's backward sums, left by the grad kernel
+        dsum2 = ws[nb3 // 4 + np2 * 128:]
+        bias2c = None if pbias2 is None else pbias2.detach()
+        # BatchNorm3 backward (sums, parameter gradients, input gradient gz3) + ga2 = gz3 W2 + BatchNorm2's backward sums
+        ops.timed('block_tail_backward (reduce + finalise + grad)', 2 * R * (2 * 64 + 2 * Cout + 64 + Cout),
+                  lambda: _hip.check(L.fgnn_block_tail_backward(
+                      P(e), P(st2[2]), P(st2[3]), slope2, P(W2.detach()), P(bias2c), P(st3[0]), P(st3[1]), P(w3.detach()), P(st3[2]),
+                      P(st3[3]), slope3, P(gout), P(gz3), P(ga2), P(gw3), P(gb3), P(part2), R, Cout, P(ws), nb3, _hip.stream_ptr())),
+                  nflops=6 * R * 64 * Cout)
+        # BatchNorm2 + activation backward on the 64-channel tensor: finaliser + one element-wise pass (no reduction pass)
+        ge = torch.empty_like(e)
+        ops.timed('bn_backward (finalise + apply)', 3 * e.numel() * 2, lambda: _hip.check(L.fgnn_bn_backward_partials(
+            P(e), P(ga2), P(ge), R, 64, _hip.BF16, P(st2[0]), P(st2[1]), P(w2.detach()), P(b2.detach()), slope2, P(gw2), P(gb2),
+            P(part2), np2, P(dsum2), _hip.stream_ptr())))
+        # conv2's weight / bias gradient: gz3^T a2 over the R rows (csrc/linear_wgrad_b16.hip)
+        ops.timed('linear_wgrad_b16_kernel', 2 * R * (64 + Cout), lambda: _hip.check(L.fgnn_linear_wgrad(
+            P(a2), P(gz3), R, 64, Cout, _hip.BF16, P(gW2.view(Cout, 64)), P(gbias2), P(ws), ws.numel() * 4, _hip.stream_ptr())),
+            nflops=2 * R * 64 * Cout)
+        ha = ctx.has_add
+        return (ge, None if s_w2 else gw2, None if s_b2 else gb2, None, None, None, None, None, None,
+                None if s_W2 else gW2.view(pW2.shape).to(pW2.dtype), None if (s_bias2 or gbias2 is None) else gbias2,
+                None if s_w3 else gw3, None if s_b3 else gb3, None, None, None, None, None, None,
+                gout if ha[0] else None, gout if ha[1] else None, gout if ha[2] else None)
+
+
 class mp_conv_residual(base_mp_nn):
     """Bottleneck: 1x1 conv+BN+LeakyReLU on the sources -> message operator ->
     1x1 conv+BN+LeakyReLU on the destinations (+ input when ``with_residual``)."""
@@ -213,9 +320,58 @@ class mp_conv_residual(base_mp_nn):
                 return y
         fuse = self.training            # BatchNorm statistics ride in the 1x1 map's epilogue when training
         h = self.conv1[1](self.conv1[0](node_feature, want_stats=fuse))
+        y = self._fused_train_tail(h, nn_idx, etype, addend)
+        if y is not None:
+            return y + node_feature if self.with_residual else y
         h = self.mp_conv(h, nn_idx, etype)
         h = self.conv2[0](h, want_stats=fuse)
         if callable(addend):            # produced on another stream: asked for (and waited on) only where it is consumed
             addend = addend()
         h = self.conv2[1](h, addend=addend)
         return h + node_feature if self.with_residual else h
+
+    def _fused_train_tail(self, h, nn_idx, etype, addend):
+        """Training, bf16: the operator's pre-BatchNorm output goes straight into csrc/block_tail.hip (``_BlockTail``) —
+        BatchNorm + ReLU, conv2, BatchNorm + LeakyReLU and the addends without conv2's Cout-wide output ever being stored.
+        None = not this family (the staged path runs)."""
+        from .. import _hip
+        from .message_op import _EXT_CODE
+        mp = self.mp_conv
+        bn2, conv2, bn3 = mp.bn, self.conv2[0], self.conv2[1]
+        if not (FUSE_TRAIN_TAIL and self.training and torch.is_grad_enabled() and h.is_cuda and h.dtype == torch.bfloat16
+                and mp.nou == 64 and isinstance(mp.aggregtor, str) and isinstance(mp.activation_fn, torch.nn.ReLU)
+                and isinstance(bn2, BatchNormAct2d) and bn2.training and isinstance(bn3, BatchNormAct2d) and bn3.training
+                and isinstance(conv2, PointwiseConv2d) and conv2.in_channels == 64 and conv2.out_channels in (64, 128, 256)
+                and all(b.track_running_stats and b.affine and b.momentum is not None for b in (bn2, bn3))
+                and conv2.weight.dtype == torch.float32 and bn2.weight.dtype == torch.float32):
+            return None
+        B, M = h.shape[0], nn_idx.shape[1]
+        if B * M < 2 or not _hip.lib().fgnn_block_tail_partials(B * M, conv2.out_channels):
+            return None
+        # the operator's epilogue leaves BatchNorm2's statistics partials in the stream's workspace: size it for the whole
+        # tail FIRST (a later, larger request would move the buffer and orphan them)
+        ops._workspace(h.device, int(_hip.lib().fgnn_bn_workspace_bytes(B * M, conv2.out_channels)))
+        z = ops.mpconv(h, nn_idx, etype, mp.filters, mp.bias, mp.nou, mp.nedge_types, _EXT_CODE[mp.extension],
+                       _hip.AGG_CODES[mp.aggregtor], want_stats=True)
+        rows = z.permute(0, 2, 3, 1)
+        if not rows.is_contiguous():
+            from .pointwise import take_pending_stats
+            take_pending_stats(rows)                        # (drop them: they describe another buffer)
+            rows = rows.contiguous()
+        rows = rows.view(B * M, 64)
+        if callable(addend):            # produced on another stream: asked for (and waited on) only where it is consumed
+            addend = addend()
+        addends = as_addends(addend)
+        if len(addends) > 3:
+            addends = addends[:2] + [ops.add_n(addends[2:])]
+        Cout = conv2.out_channels
+        arows = [None, None, None]
+        for i, a in enumerate(addends):
+            ar = a.permute(0, 2, 3, 1)
+            if ar.dtype != rows.dtype or not ar.is_contiguous():
+                ar = ar.to(rows.dtype).contiguous()
+            arows[i] = ar.view(B * M, Cout)
+        y = _BlockTail.apply(rows, bn2.weight, bn2.bias, 0.0, float(bn3.slope), bn2.momentum, bn2.eps, bn3.momentum, bn3.eps,
+                             conv2.weight.view(Cout, 64), conv2.bias, bn3.weight, bn3.bias, bn2.running_mean, bn2.running_var,
+                             bn2.num_batches_tracked, bn3.running_mean, bn3.running_var, bn3.num_batches_tracked, *arows)
+        return y.view(B, M, 1, Cout).permute(0, 3, 1, 2)

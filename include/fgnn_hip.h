@@ -152,6 +152,41 @@ int fgnn_instnorm_backward(const void* x, const void* gy, void* gx, int32_t B, i
                            int32_t dtype, int32_t relu, fgnn_stream_t stream);
 
 /*
+ * TRAINING-mode fusion of the tail of `mp_conv_residual` (reference mp_nn.py:165-175 = the operator's
+ * BatchNorm + ReLU, mp_nn_residual.py:31-35,49-51 = conv2 + BatchNorm + LeakyReLU): behind the message operator's
+ * 64-channel output e [R][64] (bf16, R = B * M destination rows)
+ *     a2 = act2(e * scale2 + shift2);   z3 = a2 W2^T + b2  (W2 [Cout][64] f32, Cout in {64, 128, 256});
+ *     out = act3(z3 * scale3 + shift3) + addend0 + addend1 + addend2
+ * with batch-statistics BatchNorms, WITHOUT storing the Cout-wide z3: every pass recomputes it from e on the matrix cores.
+ *   fgnn_block_tail_stats   : per-workgroup (sum z3, sum z3^2) partials [fgnn_block_tail_partials(R, Cout)][2][Cout] for
+ *                             fgnn_bn_finalize_shifted (BatchNorm3's batch statistics).
+ *   fgnn_block_tail_apply   : out [R][Cout] bf16 (addends: bf16 [R][Cout] or NULL); a2_out (or NULL) receives a2 [R][64]
+ *                             bf16 for the weight-gradient kernel of the backward.
+ *   fgnn_block_tail_backward: from gout [R][Cout]: BatchNorm3's parameter gradients (ACCUMULATED into gweight3 / gbias3, may
+ *                             be NULL), gz3 [R][Cout] = the gradient of z3 (bf16; what fgnn_linear_wgrad contracts with a2)
+ *                             and ga2 [R][64] = gz3 W2 (the gradient of a2, before act2' / BatchNorm2).  Three launches
+ *                             (reduce, finalise, grad).  workspace: >= (2048 * Cout + 2 * Cout) * 4 bytes.  bn2_partials (or
+ *                             NULL): fgnn_block_tail_backward_partials(R, Cout) rows of [2][64] floats receiving BatchNorm2's
+ *                             backward sums (sum g2', sum g2' e; g2' = ga2 act2'(.)) for fgnn_bn_backward_partials — the
+ *                             64-channel BatchNorm then needs no reduction pass of its own.
+ *   The statistics partials of fgnn_block_tail_stats are sums of z3 - b2: finalise them with fgnn_bn_finalize_shifted(K = b2).
+ * slope: LeakyReLU slope of the activation (0 = ReLU, 1 = none).  FGNN_EUNSUPPORTED outside this family.
+ */
+int fgnn_block_tail_partials(int64_t R, int32_t Cout);
+int fgnn_block_tail_stats(const void* e, const float* scale2, const float* shift2, float slope2, const float* W2,
+                          const float* b2, int64_t R, int32_t Cout, float* partials, fgnn_stream_t stream);
+int fgnn_block_tail_apply(const void* e, const float* scale2, const float* shift2, float slope2, const float* W2,
+                          const float* b2, const float* scale3, const float* shift3, float slope3, const void* addend0,
+                          const void* addend1, const void* addend2, void* out, void* a2_out, int64_t R, int32_t Cout,
+                          fgnn_stream_t stream);
+int fgnn_block_tail_backward(const void* e, const float* scale2, const float* shift2, float slope2, const float* W2,
+                             const float* b2, const float* mean3, const float* invstd3, const float* gamma3,
+                             const float* scale3, const float* shift3, float slope3, const void* gout, void* gz3, void* ga2,
+                             float* gweight3, float* gbias3, float* bn2_partials, int64_t R, int32_t Cout, void* workspace,
+                             int64_t workspace_bytes, fgnn_stream_t stream);
+int fgnn_block_tail_backward_partials(int64_t R, int32_t Cout);
+
+/*
  * Train-mode BatchNorm fused with the LeakyReLU(slope) behind it (slope 0 = ReLU, 1 = none) on dense
  * channel-fastest x[R][C] (conv1/conv2 blocks mp_nn_residual.py:25-35, mp_conv_v2.bn mp_nn.py:57-58,170-173,
  * iid_mapping_bn base_model.py:62-79).  torch.nn.BatchNorm2d semantics: biased variance normalises, running
@@ -171,6 +206,16 @@ int fgnn_bn_finalize(const float* partials, int32_t npartials, int64_t R, int32_
                      fgnn_stream_t stream);
 /* y = act(x*scale + shift) + addend + addend2 + addend3: up to three tensors of y's layout (NULL = absent) ride in
  * the apply pass — the `acc + block(x) + residual + skip` sums of factor_mpnn_sp.py:139-170. */
+/* fgnn_bn_finalize for partials of (y - K[c]) (the producer summed before adding a per-channel constant K, e.g. a bias). */
+int fgnn_bn_finalize_shifted(const float* partials, int32_t npartials, int64_t R, int32_t C, const float* K, const float* gamma,
+                             const float* beta, float* running_mean, float* running_var, float momentum, float eps,
+                             float* mean, float* invstd, float* scale, float* shift, int64_t* num_batches_tracked,
+                             fgnn_stream_t stream);
+/* fgnn_bn_backward without its reduction pass: partials [npartials][2][C] of (sum g, sum g * x) (g = gy * act'(pre), x raw)
+ * were left by the producer of gy (fgnn_block_tail_backward).  workspace: >= 2 * C floats. */
+int fgnn_bn_backward_partials(const void* x, const void* gy, void* gx, int64_t R, int32_t C, int32_t dtype, const float* mean,
+                              const float* invstd, const float* gamma, const float* beta, float slope, float* gweight,
+                              float* gbias, const float* partials, int32_t npartials, void* workspace, fgnn_stream_t stream);
 int fgnn_bn_apply(const void* x, void* y, int64_t R, int32_t C, int32_t dtype, const float* scale,
                   const float* shift, float slope, const void* addend, const void* addend2, const void* addend3,
                   fgnn_stream_t stream);
@@ -314,8 +359,8 @@ const char* fgnn_last_kernel(void);
 /* Bumped whenever an entry point is added or an argument / descriptor field changes meaning.  The host binding
  * (fgnn_amd/_hip.py: ABI_VERSION) checks it BEFORE binding symbols, so a stale library is reported as a version
  * mismatch and not as a missing symbol or a misread field.  4: round-2 additions (flat_adam, factor_layer_*,
- * ldpc_channel_features_rng, backward_reduces_getype, desc.reserved = in-degree | GETYPE_REDUCED). */
-#define FGNN_ABI_VERSION 4
+ * ldpc_channel_features_rng, backward_reduces_getype, desc.reserved = in-degree | GETYPE_REDUCED); 5: fgnn_block_tail_*. */
+#define FGNN_ABI_VERSION 5
 int fgnn_abi_version(void);
 
 #ifdef __cplusplus

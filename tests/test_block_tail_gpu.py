@@ -1,0 +1,185 @@
+"""GPU: the training-mode fused tail of `mp_conv_residual` (csrc/block_tail.hip) — BatchNorm2 + ReLU ->
+conv2 -> BatchNorm3 + LeakyReLU (+ addends) with conv2's wide output recomputed instead of stored.
+  * every kernel mode through the C ABI against a plain f32 torch restatement of the same op chain (bf16 rounding points as
+    documented: a2 and the matrix-core operand of W2 are bf16, everything else f32);
+  * the whole block, forward + backward, against the staged path (FUSE_TRAIN_TAIL off) and against the f32 oracle."""
+import ctypes
+
+import pytest
+import torch
+
+import fgnn_oracle as O
+import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref_chain(e, s2, t2, slope2, W2, b2):
+    a2 = torch.nn.functional.leaky_relu(e.float() * s2 + t2, slope2).bfloat16()
+    z3 = a2.float() @ W2.bfloat16().float().t() + b2
+    return a2, z3
+
+
+@pytest.mark.parametrize('Cout', [64, 128, 256])
+@pytest.mark.parametrize('R', [1, 37, 4096 + 5, 48 * 300])
+def test_block_tail_kernels_vs_torch(R, Cout, dev):
+    from fgnn_amd import _hip
+    L = _hip.lib()
+    P = _hip._ptr
+    g = torch.Generator().manual_seed(R + Cout)
+    e = torch.randn(R, 64, generator=g).bfloat16().to(dev)
+    s2, t2 = (torch.rand(64, generator=g) + 0.5).to(dev), (torch.randn(64, generator=g) * 0.3).to(dev)
+    W2, b2 = (torch.randn(Cout, 64, generator=g) * 0.2).to(dev), torch.randn(Cout, generator=g).to(dev)
+    slope2, slope3 = 0.0, 0.01
+    a2_ref, z3 = _ref_chain(e, s2, t2, slope2, W2, b2)
+    npart = int(L.fgnn_block_tail_partials(R, Cout))
+    assert 1 <= npart <= 1024
+    ws = torch.zeros(int(L.fgnn_bn_workspace_bytes(R, Cout)) // 4, device=dev)
+    a2 = torch.empty_like(e)
+    st = _hip.stream_ptr()
+    # ---- mode 0: statistics partials ----
+    _hip.check(L.fgnn_block_tail_stats(P(e), P(s2), P(t2), slope2, P(W2), P(b2), R, Cout, P(ws), st))
+    part = ws[:npart * 2 * Cout].reshape(npart, 2, Cout).double().sum(0)      # sums of z3 - b2
+    zz = z3.double()
+    z0 = zz - b2.double()
+    assert H.rel_err(part[0], z0.sum(0)) <= 1e-4 and H.rel_err(part[1], (z0 * z0).sum(0)) <= 1e-4
+    # BatchNorm3 through the library's finaliser on those partials
+    gamma3, beta3 = (torch.rand(Cout, generator=g) + 0.5).to(dev), torch.randn(Cout, generator=g).to(dev)
+    rm, rv = torch.zeros(Cout, device=dev), torch.ones(Cout, device=dev)
+    st3 = torch.empty(4, Cout, device=dev)
+    _hip.check(L.fgnn_bn_finalize_shifted(P(ws), npart, R, Cout, P(b2), P(gamma3), P(beta3), P(rm), P(rv), 0.1, 1e-5, P(st3[0]),
+                                          P(st3[1]), P(st3[2]), P(st3[3]), None, st))
+    mean, var = zz.mean(0), zz.var(0, unbiased=False)
+    assert H.rel_err(st3[0], mean) <= 1e-4
+    if R > 1:               # (a single row: variance 0 on one side, rounding noise on the other — invstd ~ eps^-1/2 either way)
+        assert H.rel_err(st3[1], 1.0 / torch.sqrt(var + 1e-5)) <= 1e-3
+    # ---- mode 1: apply with 0 .. 3 addends ----
+    adds = [torch.randn(R, Cout, generator=g).bfloat16().to(dev) for _ in range(3)]
+    for nadd in range(4):
+        out = torch.empty(R, Cout, device=dev, dtype=torch.bfloat16)
+        ap = [P(a) for a in adds[:nadd]] + [None] * (3 - nadd)
+        a2.zero_()
+        _hip.check(L.fgnn_block_tail_apply(P(e), P(s2), P(t2), slope2, P(W2), P(b2), P(st3[2]), P(st3[3]), slope3, ap[0], ap[1],
+                                           ap[2], P(out), P(a2) if nadd != 1 else None, R, Cout, st))
+        if nadd != 1:
+            assert H.rel_err(a2.float(), a2_ref.float()) <= 2.0 ** -8        # (the kernel's affine is one fused multiply-add)
+        ref = torch.nn.functional.leaky_relu(z3 * st3[2] + st3[3], slope3)
+        for a in adds[:nadd]:
+            ref = ref + a.float()
+        assert H.rel_err(out.float(), ref) <= 2.0 ** -7, nadd
+    # ---- modes 2 + 3: BatchNorm3 backward sums, gz3 and ga2 ----
+    gout = torch.randn(R, Cout, generator=g).bfloat16().to(dev)
+    gz3, ga2 = torch.empty(R, Cout, device=dev, dtype=torch.bfloat16), torch.empty(R, 64, device=dev, dtype=torch.bfloat16)
+    gw3, gb3 = torch.zeros(Cout, device=dev), torch.zeros(Cout, device=dev)
+    np2 = int(L.fgnn_block_tail_backward_partials(R, Cout))
+    part2 = torch.zeros(np2, 2, 64, device=dev)
+    _hip.check(L.fgnn_block_tail_backward(P(e), P(s2), P(t2), slope2, P(W2), P(b2), P(st3[0]), P(st3[1]), P(gamma3), P(st3[2]),
+                                          P(st3[3]), slope3, P(gout), P(gz3), P(ga2), P(gw3), P(gb3), P(part2), R, Cout, P(ws),
+                                          ws.numel() * 4, st))
+    zl = z3.detach().clone().requires_grad_(True)
+    gam, bet = gamma3.clone().requires_grad_(True), beta3.clone().requires_grad_(True)
+    zh = (zl - zl.mean(0)) * torch.rsqrt(zl.var(0, unbiased=False) + 1e-5)
+    torch.nn.functional.leaky_relu(zh * gam + bet, slope3).backward(gout.float())
+    scale = max(1.0, float(zl.grad.abs().max()))
+    if R > 1:
+        assert float((gz3.float() - zl.grad).abs().max()) <= 2.0 ** -6 * scale
+        assert H.rel_err(gw3, gam.grad) <= 2e-3 and H.rel_err(gb3, bet.grad) <= 2e-3
+    ga_ref = gz3.float() @ W2.bfloat16().float()
+    assert H.rel_err(ga2.float(), ga_ref) <= 2.0 ** -7
+    # BatchNorm2's backward sums ride along: sum g2', sum g2' e with g2' = ga2 act2'(pre2) (from the f32 accumulators)
+    pos = (e.float() * s2 + t2) > 0
+    g2 = torch.where(pos, ga_ref, ga_ref * slope2).double()
+    p2 = part2.double().sum(0)
+    assert H.rel_err(p2[0], g2.sum(0)) <= 2e-3 and H.rel_err(p2[1], (g2 * e.double()).sum(0)) <= 2e-3
+
+
+CASES = [  # nin, nout, N, M, k, net
+    (64, 64, 96, 48, 6, 4), (64, 64, 48, 96, 3, 4), (128, 256, 96, 48, 6, 4), (256, 256, 48, 96, 3, 4), (256, 128, 96, 48, 6, 4),
+    (64, 64, 96, 1, 96, 1), (256, 256, 1, 96, 1, 1)]
+
+
+@pytest.mark.parametrize('case', CASES, ids=lambda c: 'x'.join(map(str, c)))
+@pytest.mark.parametrize('nadd', [0, 2, 4])
+def test_fused_training_tail_matches_staged_path_and_oracle(case, nadd, dev):
+    """`mp_conv_residual` in training mode, bf16, fused tail on / off.  Forward: same output (2^-6) and running statistics, and
+    within 2^-5 of the f32 oracle's block.  Backward: both paths share the operator kernels and their routing; what differs is
+    where bf16 rounding enters the BatchNorm backward sums, which batch-statistics BatchNorm amplifies — so every gradient is
+    held against the ORACLE's autograd: the fused path's distance may not exceed 1.5 x the staged path's
+    (+ 2^-5: max-norm of quantities that are themselves 8 - 30 % off the f32 result in either path); gradients that are pure cancellation noise (biases in front of a batch-statistics BatchNorm) are skipped."""
+    from fgnn_amd import ops
+    from fgnn_amd.mpnn import blocks, mp_conv_residual, mp_conv_type
+    nin, nout, N, M, k, net = case
+    B = 40
+    g = torch.Generator().manual_seed(nin + nout + M + nadd)
+    torch.manual_seed(5)
+    m = mp_conv_residual(nin, 64, net, extension=mp_conv_type.NO_EXTENSION, with_residual=False, aggregator='max',
+                         nout=None if nout == nin else nout).to(dev).train()
+    with torch.no_grad():
+        m.mp_conv.filters.mul_(10.0)                         # the constructor's U(-.01, .01) would leave every message tiny
+    x = torch.randn(B, N, 1, nin, generator=g).bfloat16().to(dev).permute(0, 3, 1, 2)
+    if M == 1:
+        idx = torch.arange(N).reshape(1, 1, N)
+    else:
+        idx = torch.randint(0, N, (1, M, k), generator=g)
+    idx = idx.to(dev).expand(B, -1, -1)
+    et = torch.randn(B, M, k, net, generator=g).bfloat16().to(dev).permute(0, 3, 1, 2)
+    adds = [torch.randn(B, M, 1, nout, generator=g).bfloat16().to(dev).permute(0, 3, 1, 2) for _ in range(nadd)]
+    gy = torch.randn(B, M, 1, nout, generator=g).bfloat16().to(dev).permute(0, 3, 1, 2)
+    sd0 = {k_: v.clone() for k_, v in m.state_dict().items()}
+
+    def run(fused):
+        m.load_state_dict(sd0)
+        for q in m.parameters():
+            q.grad = None
+        ops._WS.clear()                                      # (a cold workspace: the tail must size it before the operator runs)
+        blocks.FUSE_TRAIN_TAIL = fused
+        try:
+            xd, ed = x.detach().requires_grad_(True), et.detach().requires_grad_(True)
+            ad = [a.detach().requires_grad_(True) for a in adds]
+            with torch.autocast('cuda', dtype=torch.bfloat16):
+                y = m(xd, idx, ed, addend=list(ad) if ad else None)
+            y.backward(gy)
+        finally:
+            blocks.FUSE_TRAIN_TAIL = True
+        out = {'y': y.detach().float().cpu(), 'gx': xd.grad.float().cpu(), 'get': ed.grad.float().cpu()}
+        out.update({n: q.grad.detach().float().cpu() for n, q in m.named_parameters()})
+        stats = {n: v.detach().float().clone() for n, v in m.state_dict().items() if 'running' in n}
+        return out, [a.grad.float() for a in ad], stats
+
+    rec = []
+    ops.TIMER = type('T', (), {'run': staticmethod(lambda sym, nb, nf, launch, use_note=True: (rec.append(sym), launch()))})()
+    try:
+        f, fa, fs = run(True)
+    finally:
+        ops.TIMER = None
+    assert any('block_tail_apply' in r for r in rec) and any('block_tail_backward' in r for r in rec), rec
+    s, sa, ss = run(False)
+    assert H.rel_err(f['y'], s['y']) <= 2.0 ** -6
+    for a, b in zip(fa, sa):
+        assert torch.equal(a, b)                             # an addend's gradient is the upstream gradient itself
+    for n in fs:
+        assert H.rel_err(fs[n], ss[n]) <= 1e-3, n
+    # the f32 oracle's block, forward and autograd, on the same (bf16-rounded) inputs
+    sd = {k_: v.detach().cpu().float().clone() for k_, v in sd0.items()}
+    names = [n for n, _ in m.named_parameters()]
+    for n in names:
+        sd[n].requires_grad_(True)
+    xo, eo = x.float().cpu().contiguous().requires_grad_(True), et.float().cpu().contiguous().requires_grad_(True)
+    ref = O.residual_block(sd, '', xo, idx.cpu().contiguous(), eo, net=net, extension=0, aggregator='max', with_residual=False,
+                           training=True)
+    ref.backward(gy.float().cpu())
+    with torch.no_grad():
+        for a in adds:
+            ref = ref + a.float().cpu()
+    assert H.rel_err(f['y'], ref) <= 2.0 ** -5
+    r = {'gx': xo.grad, 'get': eo.grad}
+    r.update({n: sd[n].grad for n in names})
+    gmax = max(float(v.abs().max()) for v in r.values() if v is not None)
+    checked = 0
+    for n, rv in r.items():
+        if rv is None or float(rv.abs().max()) < 1e-4 * gmax:        # no gradient / cancellation noise
+            continue
+        ef, es = H.rel_err(f[n], rv), H.rel_err(s[n], rv)
+        assert ef <= 1.5 * es + 2.0 ** -5, (n, ef, es)
+        checked += 1
+    assert checked >= 8
