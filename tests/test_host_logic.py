@@ -136,6 +136,25 @@ def test_side_entry_points_validate_their_arguments_without_a_gpu():
     assert layer(None) == -1 and b'null pointer' in L.fgnn_last_error()
     assert layer(ctypes.c_void_p(4100)) == _hip.EUNSUPPORTED and b'misaligned' in L.fgnn_last_error()
     assert layer(big, B=0) == 0
+    # the training-mode fused block tail (csrc/block_tail.hip): family = Cout in {64, 128, 256}, 16-byte aligned
+    # operands; partial rows fit the BatchNorm workspace the finalisers fold (<= 1024)
+    assert 1 <= L.fgnn_block_tail_partials(393216, 256) <= 1024 and 1 <= L.fgnn_block_tail_backward_partials(393216, 64) <= 1024
+    assert L.fgnn_block_tail_partials(393216, 96) == 0 and L.fgnn_block_tail_partials(0, 64) == 0
+    assert L.fgnn_block_tail_partials(5, 64) == 1
+    stats = lambda e, part, Cout=64: L.fgnn_block_tail_stats(e, big, big, 0.0, big, None, 4096, Cout, part, None)
+    assert stats(None, big) == -1 and b'null pointer' in L.fgnn_last_error()
+    assert stats(big, None) == -1
+    assert stats(big, big, Cout=96) == _hip.EUNSUPPORTED and stats(ctypes.c_void_p(4100), big) == _hip.EUNSUPPORTED
+    apply = lambda out, add0=None: L.fgnn_block_tail_apply(big, big, big, 0.0, big, None, big, big, 0.01, add0, None, None, out, None,
+                                                           4096, 128, None)
+    assert apply(None) == -1 and apply(ctypes.c_void_p(4104)) == _hip.EUNSUPPORTED
+    assert apply(big, add0=ctypes.c_void_p(4104)) == _hip.EUNSUPPORTED and b'misaligned' in L.fgnn_last_error()
+    bwd = lambda gout, ws, nbytes: L.fgnn_block_tail_backward(big, big, big, 0.0, big, None, big, big, big, big, big, 0.01, gout, big, big,
+                                                              None, None, None, 4096, 256, ws, nbytes, None)
+    assert bwd(None, big, 1 << 30) == -1
+    assert bwd(big, big, 1024) == -1 and b'workspace too small' in L.fgnn_last_error()
+    assert L.fgnn_bn_backward_partials(big, big, big, 4096, 64, 1, big, big, big, big, 0.0, None, None, big, 0, big, None) == -1
+    assert L.fgnn_bn_finalize_shifted(big, 2000, 4096, 64, None, None, None, None, None, 0.1, 1e-5, big, big, big, big, None, None) == -1
 
 
 def test_flat_adam_matches_torch_adam():
