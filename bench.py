@@ -226,14 +226,15 @@ def dist_report(world, dev, elapsed_local, steps):
 
 
 def cpu_baseline_suite(args):
-    """The default line's CPU legs (rank 0, N = 1): the reported baseline — `--cpu-threads` (16) threads at batch `--cpu-batch`
-    (512), the fastest setting measured on the GPU box's host — and, as evidence for that choice, BASELINE.md §3's own setting:
-    batch 256 with the same threads and with EVERY host core (`torch.set_num_threads(os.cpu_count())`).  The all-cores leg runs in
-    a child process with a hard time limit: oversubscribed intra-op threading on a 256-core host has been seen to take minutes
-    per iteration, and the default run must finish within minutes.  All legs are bounded samples of the benched workload."""
+    """The default line's CPU legs (rank 0, N = 1), all bounded samples of the benched workload (the oracle's LDPCModel, reference
+    op order).  `cpu_baseline` = BASELINE.md §3's setting for the batch (256 codewords) on `--cpu-threads` (16) threads — the
+    FASTEST CPU configuration measured on the GPU box's host (r03: 3.96 M messages/s; batch 512 on the same threads: 1.17 M,
+    reported as `cpu_baseline_b512`; PyTorch's CPU backend loses to contention beyond ~16 intra-op threads on these small
+    tensors).  `cpu_baseline_all_cores` is §3's `torch.set_num_threads(os.cpu_count())` taken literally, run in a child process
+    with a hard time limit: on the 256-core host one iteration does not finish within a minute."""
     import subprocess
-    out = {'cpu_baseline': cpu_baseline(args.cpu_batch, args.mode, args.cpu_threads)}
-    out['cpu_baseline_b256'] = cpu_baseline(256, args.mode, args.cpu_threads, budget=10.0, max_iters=3)
+    out = {'cpu_baseline': cpu_baseline(256, args.mode, args.cpu_threads, budget=12.0, max_iters=5)}
+    out['cpu_baseline_b512'] = cpu_baseline(args.cpu_batch, args.mode, args.cpu_threads, budget=12.0, max_iters=3)
     ncores = os.cpu_count() or 1
     limit = 60
     cmd = [sys.executable, os.path.abspath(__file__), '--cpu-baseline-only', '--cpu-batch', '256', '--cpu-threads', str(ncores),
