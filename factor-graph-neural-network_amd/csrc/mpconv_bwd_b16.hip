@@ -25,7 +25,12 @@
 #define BB_WAVES 8
 #define BB_MAXN 128
 #define BB_GS 40         // gz_s / am_s row stride (32 channels of a pass + 8: rows stay 8-byte aligned)
+#ifndef BB_PSB
 #define BB_PSB 136       // P / dP row stride in bf16 elements (128 columns of a pass + 8)
+#endif
+#ifndef BB_XPAD
+#define BB_XPAD 8
+#endif
 
 typedef __bf16 bb_bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bb_bf16x4 __attribute__((ext_vector_type(4)));
@@ -107,7 +112,7 @@ __global__ __launch_bounds__(BB_THREADS) void mpconv_bwd_b16_kernel(const Bb16Pa
     constexpr int NIN = 32 * KS2;
     constexpr int NCOLS = 128 * NPASS;
     constexpr int NOU = 32 * NPASS;
-    constexpr int XSB = NIN + 8;                      // x row stride (bf16 elements)
+    constexpr int XSB = NIN + BB_XPAD;                // x row stride (bf16 elements)
     constexpr int NCT = NIN / 16;                     // 16-channel tiles of dx: 4 or 8
     constexpr int DXT = (NCT == 4) ? 3 : 6;           // dx tiles per wave (Npad16 <= 96)
     constexpr int HX = NIN / 64;                      // 64-channel groups of x for the dW transposes
@@ -566,7 +571,7 @@ int fgnn_mpconv_backward_b16(const fgnn_mpconv_desc* d, const void* x, const int
     if (d->k == 1) BB_REJECT(10);
     int off_b = 0;
     auto take = [&](int bytes) { const int o = off_b; off_b = fgnn_round_up(off_b + bytes, 16); return o; };
-    p.off_xb = take(p.Npad32 * (d->nin + 8) * 2);
+    p.off_xb = take(p.Npad32 * (d->nin + BB_XPAD) * 2);
     p.off_pb = take(p.Npad32 * BB_PSB * 2);
     p.off_db = take(p.Npad32 * BB_PSB * 2);
     p.off_gz = take((d->M * BB_GS > BB_THREADS ? d->M * BB_GS : BB_THREADS) * 4);

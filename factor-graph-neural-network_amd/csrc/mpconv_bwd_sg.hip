@@ -28,10 +28,18 @@
 
 #define BS_THREADS 1024
 #define BS_WAVES 16
-#define BS_XSB 144           // x image row stride, bytes (64 bf16 + 16: rows land on distinct 16-byte slots)
+#ifndef BS_XSB
+#define BS_XSB 160           // x image row stride, bytes: 64 bf16 + 32 = 10 slots (2 mod 4, see BS_ZCS): the projection's operand reads are
+                             // conflict-free; the dW phase's transposed reads (rows 8 apart) become 2-way — net 132.1 -> 128.5 us (V->F)
+#endif
+#ifndef BS_PSB
 #define BS_PSB 528           // P / dP image row stride, bytes (256 bf16 + 16)
+#endif
 #define BS_GSB 256           // ga row: 64 dwords {gz bf16 << 16 | argmax << 8 | 1 << argmax}
-#define BS_ZCS 272           // detype image: column (slot j, edge-type pair) stride in bytes (64 dwords {e even | e odd} + 16)
+#define BS_ZCS 288           // detype image: column (slot j, edge-type pair) stride in bytes: 64 dwords {e even | e odd} + 32 = 18 16-byte
+                             // slots.  ds_read_b128 is serviced in the lane groups {0-3, 12-15, 20-27}, ... (two k-groups mixed): the
+                             // 16 rows of an operand tile are conflict-free only at a stride of 2 mod 4 slots (tools/lds_swizzle.py);
+                             // at 17 slots (272 B) every read cost 2x: 140.7 -> 132.8 us (V->F), 148.6 -> 136.4 us (F->V)
 #define BS_MAXN 96
 
 typedef __bf16 bs_bf16x8 __attribute__((ext_vector_type(8)));

@@ -15,6 +15,12 @@
 //     per (edge, channel), lanes = channels, destinations walk across the 4 waves;
 //   * next sample's x / etype / nn_idx are prefetched into registers during the current sample.
 #include "fgnn_common.h"
+#ifndef B16_XPAD
+#define B16_XPAD 16
+#endif
+#ifndef B16_PPAD
+#define B16_PPAD 16
+#endif
 #include <stdlib.h>
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
@@ -527,8 +533,8 @@ int fgnn_mpconv_forward_b16(const fgnn_mpconv_desc* d, const void* x, const int6
     const int slabs_per_pass = p.pass_cols / 16;
     const int SWP = (slabs_per_pass + B16_WAVES - 1) / B16_WAVES;
     const int KSB = d->nin / 32;
-    p.XSB = d->nin * 2 + 16;                             // +16 B: rows land on distinct 16-byte bank groups
-    p.PSB = p.pass_cols * 2 + 16;
+    p.XSB = d->nin * 2 + B16_XPAD;                       // + padding: rows land on distinct 16-byte bank groups
+    p.PSB = p.pass_cols * 2 + B16_PPAD;
     p.c8shift = d->nin == 64 ? 3 : 4;
     p.et_mode = et_mode;
     { const char* e = getenv("FGNN_DBG"); p.dbg = e ? atoi(e) : 0; }
