@@ -44,8 +44,12 @@
 #define FL_NF 48             // parity checks
 #define FL_KF 6              // check degree   (V -> F gathers 6 variables)
 #define FL_KV 3              // variable degree (F -> V gathers 3 checks)
+#ifndef FL_XS
 #define FL_XS 72             // row stride (bf16) of the 64-channel images
+#endif
+#ifndef FL_PS
 #define FL_PS 264            // row stride (bf16) of the projection image: 256 columns + 8
+#endif
 #define FL_EPS 1e-5f
 
 typedef __bf16 fl_bf16x8 __attribute__((ext_vector_type(8)));

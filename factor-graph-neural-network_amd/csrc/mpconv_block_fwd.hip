@@ -21,8 +21,12 @@
 
 #define KB_THREADS 512
 #define KB_WAVES 8
+#ifndef KB_XSB
 #define KB_XSB 72        // row stride (bf16 elements) of the a1 / a2 images: 64 channels + 8 (x image: nin + 8)
+#endif
+#ifndef KB_PSB
 #define KB_PSB 264       // row stride of the P image: 256 columns + 8
+#endif
 
 typedef __bf16 kb_bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 kb_bf16x2 __attribute__((ext_vector_type(2)));

@@ -10,20 +10,23 @@
 //     for each sample of the chunk:
 //       stage x, nn_idx, etype, gz tile            -> LDS
 //       P tile = MFMA(W^T, x)                       -> LDS               (forward recompute)
-//       per (m, o): dE_j = gz * dagg/dE_j  (argmax one-hot | softmax weights | 1/k)
-//            dP[idx[m,j], o, :] += dE_j * etype[:, m, j]     (LDS float atomics, per sample)
-//            detype[:, m, j]    += dE_j * (P[idx[m,j], o, :] + Q[m, o, :])
+//       routing weights w[m,o,j] = gz[m,o] * dagg/dE_j  (argmax one-hot | softmax weights | 1/k), then — NO atomics, every
+//       output element has one owner thread and a fixed summation order (round 3; was LDS / global float atomicAdd):
+//            detype[:, m, j]  = sum_o w[m,o,j] * (P[idx[m,j], o, :] + Q[m, o, :])        owner: the edge (m, j)
+//            dP[n, o, :]      = sum over the in-edges (m, j) of n, in (m, j) order, of w[m,o,j] * etype[:, m, j]
+//                               owner: (n, o); the in-edge lists = a CSR transpose of nn_idx[b] built in LDS per sample
+//            dQ[m, o, :]      = sum_j w[m,o,j] * etype[:, m, j]                            owner: (m, o)
 //       dx^T  += MFMA(W_tile, dP^T)     -> read-modify-write of this sample's gx (owner = this WG)
 //       dW    += MFMA(x^T, dP)          -> f32 accumulators in registers across the chunk
-//     flush dW tile with one atomicAdd per element per chunk
-// so no gradient tensor the size of the edge set is ever written to HBM.
+//     dW tile / dbias of the chunk -> this workgroup's SLAB (filters' own [R][nou*net] layout); fgnn_launch_slab_reduce sums
+//     the slabs in a fixed order into gfilters / gbias
+// so no gradient tensor the size of the edge set is ever written to HBM, and two runs give identical bits.
 //
 // SCOPE (round 2): this file is the fallback for shapes no specialised kernel takes — odd channel counts, per-sample graphs
 // with an extension, per-sample edge-type gradients, the `mean` aggregator.  Every call of the reference's models goes
 // elsewhere: the LDPC family to mpconv_bwd_sg / _b16 / _res / _hyper.hip, the synthetic-PGM family (16 edge types,
-// DIFF / NEIGHBOR, max and softmax, 2..64 output channels) to mpconv_bwd_ext.hip — all of them free of atomics.  The float
-// atomics below (LDS scatter of dP, global flush of dW / dbias) make THIS kernel's gradients order-dependent in the last
-// bits; the reproducibility tests cover the specialised kernels only.
+// DIFF / NEIGHBOR, max and softmax, 2..64 output channels) to mpconv_bwd_ext.hip.  Like those, this kernel is free of
+// atomics (tests/test_mpconv_gpu.py::test_generic_backward_is_bitwise_reproducible).
 #include "fgnn_common.h"
 #include <stdlib.h>
 
@@ -40,12 +43,12 @@ struct BwdParams {
     const uint8_t* argmax;
     void* gx;            // dtype T, x's element strides
     void* get;           // dtype T, [net][M][k] contiguous per sample, or NULL
-    float* gW;
-    float* gbias;
+    float* slab;         // per-workgroup slabs [grid][R * nou * net + nou] (filters' layout + dbias), folded by fgnn_launch_slab_reduce
+    int has_gbias;
     const float* bias;   // unused (z - bias is recovered from gz-side data only for LSE via zagg)
     int chunk;           // samples per workgroup
     int OT, CT, nproj, Npad, Kpad, XS, WS, PS;
-    int off_xs, off_ws, off_ps, off_dps, off_idx, off_et, off_det, off_gz, off_aux, off_gb;
+    int off_xs, off_ws, off_ps, off_dps, off_idx, off_et, off_det, off_gz, off_aux, off_gb, off_cs, off_cl;
 };
 
 extern __shared__ __attribute__((aligned(16))) float fgnn_lds_b[];
@@ -85,6 +88,10 @@ __global__ __launch_bounds__(FGNN_THREADS) void mpconv_bwd_kernel(const BwdParam
     float* gz_s = fgnn_lds_b + p.off_gz;     // [OT][M]
     float* aux_s = fgnn_lds_b + p.off_aux;   // [OT][M]: argmax (as int)
     float* gb_s = fgnn_lds_b + p.off_gb;     // [OT]
+    int* cs_start = reinterpret_cast<int*>(fgnn_lds_b + p.off_cs);     // [N + 1] CSR transpose of nn_idx[b]: in-edges of node n are
+    int* cs_list = reinterpret_cast<int*>(fgnn_lds_b + p.off_cl);      // [M k]   cs_list[cs_start[n] .. cs_start[n + 1]) = r = m k + j, ascending
+    const int64_t R_rows = d.ext == FGNN_EXT_NONE ? nin : 2 * nin;
+    float* slab = p.slab + (int64_t)blockIdx.x * (R_rows * ncols + nou);
 
     const T* xg = static_cast<const T*>(p.x);
     const T* etg = static_cast<const T*>(p.et);
@@ -178,6 +185,26 @@ __global__ __launch_bounds__(FGNN_THREADS) void mpconv_bwd_kernel(const BwdParam
                 for (int f = tid; f < p.Npad * p.PS; f += FGNN_THREADS) dps[f] = 0.f;
             }
             __syncthreads();
+            // ---- CSR transpose of this sample's neighbour table: who reads node n?  Thread n counts, one thread scans, thread n
+            //      fills its list in ascending r = m k + j: a fixed order, no atomics ----
+            for (int n = tid; n < N; n += FGNN_THREADS) {
+                int c = 0;
+                for (int r = 0; r < mk; ++r) c += idx_s[r] == n ? 1 : 0;
+                cs_start[n + 1] = c;
+            }
+            __syncthreads();
+            if (tid == 0) {
+                int run = 0;
+                for (int n = 0; n < N; ++n) { const int c = cs_start[n + 1]; cs_start[n] = run; run += c; }
+                cs_start[N] = run;
+            }
+            __syncthreads();
+            for (int n = tid; n < N; n += FGNN_THREADS) {
+                int pos = cs_start[n];
+                for (int r = 0; r < mk; ++r)
+                    if (idx_s[r] == n) cs_list[pos++] = r;
+            }
+            // (the barrier behind the projection below orders these lists before their readers)
 
             // ---- forward recompute: P^T tile = W^T . x ----
             {
@@ -203,69 +230,93 @@ __global__ __launch_bounds__(FGNN_THREADS) void mpconv_bwd_kernel(const BwdParam
             }
             __syncthreads();
 
-            // ---- per (m, o): route gz through the aggregator, scatter into dP / detype ----
-            for (int it = tid; it < M * otc; it += FGNN_THREADS) {
-                const int m = it / otc, ol = it - m * otc;
+            // ---- routing weight of edge r = (m, j) for output channel ol: dz/dE_j ----
+            auto edge_w = [&](int m, int j, int ol, int r, int n) -> float {
                 const float g = gz_s[ol * M + m];
-                atomicAdd(&gb_s[ol], g);
+                if (AGG == FGNN_AGG_MAX) return reinterpret_cast<const int*>(aux_s)[ol * M + m] == j ? g : 0.f;
+                if (AGG == FGNN_AGG_MEAN) return g / (float)k;
                 const float* pself = self ? ps + m * p.PS + CT + ol * net : nullptr;
-                float* dself = dps + m * p.PS + CT + ol * net;
-                const int* ip = idx_s + m * k;
-                int j_lo = 0, j_hi = k;
-                float zagg = 0.f;
-                if (AGG == FGNN_AGG_MAX) {
-                    j_lo = reinterpret_cast<const int*>(aux_s)[ol * M + m];
-                    j_hi = j_lo + 1;
-                } else if (AGG == FGNN_AGG_LSE) {
-                    // softmax weight_j = exp(3 E_j - 3 agg): agg is recomputed by the same online
-                    // log-sum-exp as the forward (the saved z may have been clobbered by an
-                    // in-place ReLU, and is not needed).
-                    float mx = -INFINITY, s = 0.f;
+                return g * expf(3.0f * bwd_edge_dot<NET>(et_s + r * net, ps + n * p.PS + ol * net, pself, net) - aux_s[ol * M + m]);
+            };
+            // ---- (m, o) owners: softmax normaliser (3 * agg, by the forward's online log-sum-exp: the saved z may have been
+            //      clobbered by an in-place ReLU) and the self-projection gradient dQ[m, o, :] ----
+            if (AGG == FGNN_AGG_LSE) {
+                for (int it = tid; it < M * otc; it += FGNN_THREADS) {
+                    const int m = it / otc, ol = it - m * otc;
+                    const float* pself = self ? ps + m * p.PS + CT + ol * net : nullptr;
+                    const int* ip = idx_s + m * k;
+                    float mx = -INFINITY, sm = 0.f;
                     for (int j = 0; j < k; ++j) {
-                        const float v = 3.0f * bwd_edge_dot<NET>(et_s + (m * k + j) * net,
-                                                                  ps + ip[j] * p.PS + ol * net, pself, net);
-                        if (v > mx) { s = s * expf(mx - v) + 1.0f; mx = v; }
-                        else s += expf(v - mx);
+                        const float v = 3.0f * bwd_edge_dot<NET>(et_s + (m * k + j) * net, ps + ip[j] * p.PS + ol * net, pself, net);
+                        if (v > mx) { sm = sm * expf(mx - v) + 1.0f; mx = v; }
+                        else sm += expf(v - mx);
                     }
-                    zagg = mx + logf(s);      // = 3 * agg
+                    aux_s[ol * M + m] = mx + logf(sm);
                 }
-                float dq[NET > 0 ? NET : 1];
-                if constexpr (NET > 0) {
-#pragma unroll
-                    for (int e = 0; e < NET; ++e) dq[e] = 0.f;
-                }
-                for (int j = j_lo; j < j_hi; ++j) {
-                    const float* etp = et_s + (m * k + j) * net;
-                    const float* pn = ps + ip[j] * p.PS + ol * net;
-                    float w = g;
-                    if (AGG == FGNN_AGG_LSE)
-                        w = g * expf(3.0f * bwd_edge_dot<NET>(etp, pn, pself, net) - zagg);
-                    else if (AGG == FGNN_AGG_MEAN)
-                        w = g / (float)k;
-                    float* dpn = dps + ip[j] * p.PS + ol * net;
-                    float* detp = det_s + (m * k + j) * net;
-                    if constexpr (NET > 0) {
-#pragma unroll
-                        for (int e = 0; e < NET; ++e) {
-                            const float we = w * etp[e];
-                            atomicAdd(&dpn[e], we);
-                            dq[e] += we;
-                            atomicAdd(&detp[e], w * (pn[e] + (pself ? pself[e] : 0.f)));
-                        }
-                    } else {
-                        for (int e = 0; e < net; ++e) {
-                            const float we = w * etp[e];
-                            atomicAdd(&dpn[e], we);
-                            if (self) atomicAdd(&dself[e], we);
-                            atomicAdd(&detp[e], w * (pn[e] + (pself ? pself[e] : 0.f)));
-                        }
+                __syncthreads();
+            }
+            if (tid < otc) {                                  // dbias of this tile: one owner per channel, m ascending
+                float sgz = gb_s[tid];
+                for (int m = 0; m < M; ++m) sgz += gz_s[tid * M + m];
+                gb_s[tid] = sgz;
+            }
+            if (self) {
+                for (int it = tid; it < M * otc; it += FGNN_THREADS) {
+                    const int m = it / otc, ol = it - m * otc;
+                    float* dself = dps + m * p.PS + CT + ol * net;
+                    for (int e = 0; e < net; ++e) dself[e] = 0.f;
+                    int j_lo = 0, j_hi = k;
+                    if (AGG == FGNN_AGG_MAX) { j_lo = reinterpret_cast<const int*>(aux_s)[ol * M + m]; j_hi = j_lo + 1; }
+                    for (int j = j_lo; j < j_hi; ++j) {
+                        const int r = m * k + j;
+                        const float w = edge_w(m, j, ol, r, idx_s[r]);
+                        for (int e = 0; e < net; ++e) dself[e] = fmaf(w, et_s[r * net + e], dself[e]);
                     }
                 }
-                if constexpr (NET > 0) {
-                    if (self) {
-#pragma unroll
-                        for (int e = 0; e < NET; ++e) dself[e] = dq[e];   // (m, ol) has one owner
+            }
+            // ---- edge owners: detype[r, :] = sum over ol of w * (P[n, ol, :] + Q[m, ol, :]) ----
+            for (int r = tid; r < mk; r += FGNN_THREADS) {
+                const int m = r / k, j = r - m * k, n = idx_s[r];
+                for (int e0 = 0; e0 < net; e0 += 4) {         // four edge types at a time (weights recomputed per group)
+                    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+                    for (int ol = 0; ol < otc; ++ol) {
+                        const float w = edge_w(m, j, ol, r, n);
+                        if (AGG == FGNN_AGG_MAX && w == 0.f) continue;
+                        const float* pn = ps + n * p.PS + ol * net + e0;
+                        const float* pq = ps + m * p.PS + CT + ol * net + e0;
+                        a0 = fmaf(w, pn[0] + (self ? pq[0] : 0.f), a0);
+                        if (e0 + 1 < net) a1 = fmaf(w, pn[1] + (self ? pq[1] : 0.f), a1);
+                        if (e0 + 2 < net) a2 = fmaf(w, pn[2] + (self ? pq[2] : 0.f), a2);
+                        if (e0 + 3 < net) a3 = fmaf(w, pn[3] + (self ? pq[3] : 0.f), a3);
                     }
+                    det_s[r * net + e0] = a0;
+                    if (e0 + 1 < net) det_s[r * net + e0 + 1] = a1;
+                    if (e0 + 2 < net) det_s[r * net + e0 + 2] = a2;
+                    if (e0 + 3 < net) det_s[r * net + e0 + 3] = a3;
+                }
+            }
+            // ---- (n, ol) owners: dP[n, ol, :] = sum over the in-edges of n (ascending r) of w * etype[r, :] ----
+            for (int it = tid; it < N * otc; it += FGNN_THREADS) {
+                const int n = it / otc, ol = it - n * otc;
+                float* dpn = dps + n * p.PS + ol * net;
+                const int q0 = cs_start[n], q1 = cs_start[n + 1];
+                for (int e0 = 0; e0 < net; e0 += 4) {
+                    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+                    for (int q = q0; q < q1; ++q) {
+                        const int r = cs_list[q];
+                        const int m = r / k, j = r - m * k;
+                        const float w = edge_w(m, j, ol, r, n);
+                        if (AGG == FGNN_AGG_MAX && w == 0.f) continue;
+                        const float* etp = et_s + r * net + e0;
+                        a0 = fmaf(w, etp[0], a0);
+                        if (e0 + 1 < net) a1 = fmaf(w, etp[1], a1);
+                        if (e0 + 2 < net) a2 = fmaf(w, etp[2], a2);
+                        if (e0 + 3 < net) a3 = fmaf(w, etp[3], a3);
+                    }
+                    dpn[e0] = a0;
+                    if (e0 + 1 < net) dpn[e0 + 1] = a1;
+                    if (e0 + 2 < net) dpn[e0 + 2] = a2;
+                    if (e0 + 3 < net) dpn[e0 + 3] = a3;
                 }
             }
             __syncthreads();
@@ -325,41 +376,40 @@ __global__ __launch_bounds__(FGNN_THREADS) void mpconv_bwd_kernel(const BwdParam
             }
         }   // samples
 
-        // ---- flush dW tile and dbias for this chunk ----
+        // ---- dW tile and dbias of this chunk -> this workgroup's slab, in the filters' own layout.  ORIG_WITH_DIFF sends the
+        //      neighbour projection's gradient to -W_bot and the self projection's to W_top AND W_bot: the self tiles store first,
+        //      the neighbour tiles subtract after a barrier (every element has one writer per step) ----
+        for (int step = 0; step < (d.ext == FGNN_EXT_DIFF ? 2 : 1); ++step) {
 #pragma unroll
-        for (int t = 0; t < BWD_MAXT; ++t) {
-            const int u = wave + FGNN_WAVES * t;
-            if (u < tpt) {
-                const int ctile = u % nct, colt = u / nct;
-                const int tc = colt * 16 + li;            // column inside the staged tile
-                const int proj = tc / CT, q = tc - proj * CT;
-                if (q < vcols) {
-                    const int g = o0 * net + q;
+            for (int t = 0; t < BWD_MAXT; ++t) {
+                const int u = wave + FGNN_WAVES * t;
+                if (u < tpt) {
+                    const int ctile = u % nct, colt = u / nct;
+                    const int tc = colt * 16 + li;            // column inside the staged tile
+                    const int proj = tc / CT, q = tc - proj * CT;
+                    if (q < vcols) {
+                        const int g = o0 * net + q;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int c = ctile * 16 + 4 * lk + r;
-                        if (c >= nin) continue;
-                        const float v = gw[t][r];
-                        if (d.ext == FGNN_EXT_NONE) {
-                            atomicAdd(&p.gW[(int64_t)c * ncols + g], v);
-                        } else if (d.ext == FGNN_EXT_NEIGHBOR) {
-                            // W_nb = W_bot, W_self = W_top
-                            atomicAdd(&p.gW[(int64_t)(proj == 0 ? nin + c : c) * ncols + g], v);
-                        } else {
-                            // W_nb = -W_bot, W_self = W_top + W_bot
-                            if (proj == 0) {
-                                atomicAdd(&p.gW[(int64_t)(nin + c) * ncols + g], -v);
-                            } else {
-                                atomicAdd(&p.gW[(int64_t)c * ncols + g], v);
-                                atomicAdd(&p.gW[(int64_t)(nin + c) * ncols + g], v);
+                        for (int r = 0; r < 4; ++r) {
+                            const int c = ctile * 16 + 4 * lk + r;
+                            if (c >= nin) continue;
+                            const float v = gw[t][r];
+                            if (d.ext == FGNN_EXT_NONE) {
+                                slab[(int64_t)c * ncols + g] = v;
+                            } else if (d.ext == FGNN_EXT_NEIGHBOR) {          // W_nb = W_bot, W_self = W_top
+                                slab[(int64_t)(proj == 0 ? nin + c : c) * ncols + g] = v;
+                            } else if (step == 0) {                           // W_nb = -W_bot, W_self = W_top + W_bot
+                                if (proj == 1) { slab[(int64_t)c * ncols + g] = v; slab[(int64_t)(nin + c) * ncols + g] = v; }
+                            } else if (proj == 0) {
+                                slab[(int64_t)(nin + c) * ncols + g] -= v;
                             }
                         }
                     }
                 }
             }
+            __syncthreads();
         }
-        __syncthreads();
-        if (p.gbias && tid < otc) atomicAdd(&p.gbias[o0 + tid], gb_s[tid]);
+        if (tid < otc) slab[R_rows * ncols + o0 + tid] = gb_s[tid];
     }   // channel tiles
 }
 
@@ -367,6 +417,7 @@ __global__ __launch_bounds__(FGNN_THREADS) void mpconv_bwd_kernel(const BwdParam
 // host side
 // ----------------------------------------------------------------------------------------
 int fgnn_check_desc(const fgnn_mpconv_desc* d);
+void fgnn_launch_slab_reduce(const float* ws, int nslab, int64_t slab_len, int64_t nw, float* gW, float* gbias, hipStream_t st);
 int fgnn_mpconv_backward_resident(const fgnn_mpconv_desc* d, const void* x, const int64_t* nn_idx,
                                   const void* etype, const float* filters, const void* gz,
                                   const uint8_t* argmax, void* gx, void* getype, float* gfilters,
@@ -406,7 +457,8 @@ static int plan_backward(const fgnn_mpconv_desc* d, BwdParams* p) {
             const int PS = CTT + 4;
             int64_t fl = (int64_t)p->Npad * p->XS + (int64_t)p->Kpad * WS + 2 * (int64_t)p->Npad * PS +
                          fgnn_round_up(mk, 4) + 2 * (int64_t)fgnn_round_up(mk * d->net, 4) +
-                         2 * (int64_t)fgnn_round_up(ot * d->M, 4) + fgnn_round_up(ot, 4);
+                         2 * (int64_t)fgnn_round_up(ot * d->M, 4) + fgnn_round_up(ot, 4) +
+                         fgnn_round_up(d->N + 1, 4) + fgnn_round_up(mk, 4);               // + the CSR transpose
             if (fl * 4 <= budget) { best = ot; break; }
         }
     }
@@ -427,6 +479,8 @@ static int plan_backward(const fgnn_mpconv_desc* d, BwdParams* p) {
     p->off_gz = off;  off += fgnn_round_up(best * d->M, 4);
     p->off_aux = off; off += fgnn_round_up(best * d->M, 4);
     p->off_gb = off;  off += fgnn_round_up(best, 4);
+    p->off_cs = off;  off += fgnn_round_up(d->N + 1, 4);
+    p->off_cl = off;  off += fgnn_round_up(mk, 4);
     return off * 4;
 }
 
@@ -495,12 +549,16 @@ extern "C" int fgnn_mpconv_backward(const fgnn_mpconv_desc* d, const void* x, co
     BwdParams p;
     p.d = *d;
     p.x = x; p.idx = nn_idx; p.et = etype; p.W = filters; p.gz = gz; p.z = z; p.argmax = argmax;
-    p.gx = gx; p.get = getype; p.gW = gfilters; p.gbias = gbias; p.bias = nullptr;
+    p.gx = gx; p.get = getype; p.bias = nullptr; p.has_gbias = gbias != nullptr;
     const int lds = plan_backward(d, &p);
     if (lds < 0) return lds;
-    // chunk: enough workgroups to fill 256 CUs twice over, few enough that the dW flush
-    // (one atomicAdd per element per chunk) stays small
-    int chunk = (d->B + 511) / 512;
+    // one slab per workgroup (<= 256: the workspace every backward kernel of this library sizes), folded in a fixed order
+    const int64_t R_rows = d->ext == FGNN_EXT_NONE ? d->nin : 2 * d->nin;
+    const int64_t nw = R_rows * d->nou * d->net, slab_len = nw + d->nou;
+    if (!workspace || workspace_bytes < 256 * slab_len * 4)
+        FGNN_FAIL(FGNN_EINVAL, "mpconv backward: workspace of fgnn_mpconv_backward_workspace_bytes(d) bytes needed");
+    p.slab = (float*)workspace;
+    int chunk = (d->B + 255) / 256;
     if (chunk < 1) chunk = 1;
     p.chunk = chunk;
     const int grid = (d->B + chunk - 1) / chunk;
@@ -514,5 +572,8 @@ extern "C" int fgnn_mpconv_backward(const fgnn_mpconv_desc* d, const void* x, co
     void* args[] = {(void*)&p};
     hipError_t e = hipLaunchKernel(fn, dim3(grid), dim3(FGNN_THREADS), args, lds, (hipStream_t)stream);
     if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "mpconv backward launch: %s", hipGetErrorString(e));
+    fgnn_launch_slab_reduce(p.slab, grid, slab_len, nw, gfilters, gbias, (hipStream_t)stream);
+    e = hipGetLastError();
+    if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "mpconv backward fold launch: %s", hipGetErrorString(e));
     return FGNN_OK;
 }

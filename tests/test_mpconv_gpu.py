@@ -101,6 +101,44 @@ def test_layouts_and_shared_graph_vs_oracle(ext, agg, layout, dev):
         assert y.stride(1) == 1          # output keeps the input's layout
 
 
+@pytest.mark.parametrize('ext,agg,net', [(0, 'mean', 4), (1, 'mean', 16), (2, 'softmax', 5), (2, 'max', 3), (0, 'max', 7), (1, 'softmax', 1)])
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16], ids=['f32', 'bf16'])
+def test_generic_backward_is_bitwise_reproducible(ext, agg, net, dtype, dev):
+    """The shape-generic backward (csrc/mpconv_bwd.hip: odd channel counts / edge-type counts, per-sample graphs, the `mean`
+    aggregator, ...) used LDS and global float atomics until round 3.  Now every gradient element has one owner and a fixed
+    summation order (CSR transpose of the sample's table in LDS, per-workgroup slabs folded in order): two runs give identical
+    bits, and the values match the oracle's autograd (mp_nn.py:115-175)."""
+    from fgnn_amd import _hip, ops
+    B, nin, nou, N, k = 37, 12, 10, 23, 5
+    M = N if ext else 17
+    x, idx, et, g = _random_problem(31 + ext + net, B, nin, nou, net, N, M, k, dev)
+    idx[:, 3, :] = idx[:, 3, :1]                       # a destination listening to one node k times (duplicates are legal)
+    R = nin if ext == 0 else 2 * nin
+    W, bias = torch.randn(R, nou * net, generator=g) * 0.3, torch.randn(nou, generator=g)
+    gz = torch.randn(B, nou, M, 1, generator=g)
+    xr, er = x.to(dtype).float(), et.to(dtype).float()
+
+    def run():
+        xd = xr.to(dev).to(dtype).requires_grad_(True)
+        ed = er.to(dev).to(dtype).requires_grad_(True)
+        Wd, bd = W.to(dev).requires_grad_(True), bias.to(dev).requires_grad_(True)
+        z = ops.mpconv(xd, idx.to(dev), ed, Wd, bd, nou, net, ext, _hip.AGG_CODES[agg])
+        z.backward(gz.to(dev).to(z.dtype))
+        return xd.grad, ed.grad, Wd.grad, bd.grad, _hip.lib().fgnn_last_kernel().decode()
+
+    a, b = run(), run()
+    assert a[4].startswith('mpconv_bwd_kernel<'), a[4]
+    for u, v in zip(a[:4], b[:4]):
+        assert torch.equal(u, v)
+    xo, eo = xr.clone().requires_grad_(True), er.clone().requires_grad_(True)
+    sd = {'filters': W.clone().requires_grad_(True), 'bias': bias.clone().requires_grad_(True)}
+    zo = O.mp_conv(sd, '', xo, idx, eo, nou=nou, net=net, extension=ext, aggregator=agg, relu=False)
+    zo.backward(gz.to(dtype).float() if dtype == torch.bfloat16 else gz)
+    tol = 1e-4 if dtype == torch.float32 else 2.0 ** -6
+    assert H.rel_err(a[0].float(), xo.grad) <= tol and H.rel_err(a[1].float(), eo.grad) <= tol
+    assert H.rel_err(a[2], sd['filters'].grad) <= tol and H.rel_err(a[3], sd['bias'].grad) <= tol
+
+
 def test_bf16_storage_vs_oracle(dev):
     """bf16 x / etype / y with f32 accumulation: compare with the oracle run on the SAME
     bf16-rounded inputs; only the output rounding (2^-9 relative) differs."""

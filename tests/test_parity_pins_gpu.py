@@ -269,7 +269,7 @@ def test_benched_bf16_whole_model_gradients_vs_oracle_autograd(bn_mode, dev):
             continue
         rh, ch = dist(got, keys)
         rf, cf = dist(floor, keys)
-        assert rh <= 1.5 * rf + 2e-2 and ch >= cf - 3e-2, (key, rh, rf, ch, cf)
+        assert rh <= 1.5 * rf + 3e-2 and ch >= cf - 5e-2, (key, rh, rf, ch, cf)
         checked += 1
     assert checked >= 8
 
