@@ -542,13 +542,21 @@ __global__ __launch_bounds__(BR_THREADS) void mpconv_bwd_res_kernel(const BresPa
         }
         __syncthreads();
         float* red = pb;                              // P / dP are dead now
+        float* parts = pb + nou;                      // [BR_THREADS] per-thread partials of one pass
         for (int f = tid; f < nou; f += BR_THREADS) red[f] = 0.f;
         __syncthreads();
 #pragma unroll
         for (int pass = 0; pass < NPASS; ++pass) {
-            if (p.fast_bias) {                        // 512/otcP threads hold partials of channel tid % otcP
-                const int o = pass * p.otcP + tid % p.otcP;
-                if (o < nou) atomicAdd(&red[o], gbacc[pass]);
+            if (p.fast_bias) {                        // 512/otcP threads hold partials of channel tid % otcP: folded by the
+                parts[tid] = gbacc[pass];             // channel's first thread in thread order (no float atomics: same bits every run)
+                __syncthreads();
+                const int o = pass * p.otcP + tid;
+                if (tid < p.otcP && o < nou) {
+                    float sgb = 0.f;
+                    for (int q = tid; q < BR_THREADS; q += p.otcP) sgb += parts[q];
+                    red[o] = sgb;
+                }
+                __syncthreads();
             } else if (tid < p.otcP && pass * p.otcP + tid < nou) {
                 red[pass * p.otcP + tid] = gbacc[pass];
             }
