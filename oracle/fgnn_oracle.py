@@ -472,3 +472,80 @@ def ldpc_bit_prior(y, snr_db):
     import numpy as np
     gcx = np.power(10.0, np.asarray(snr_db, np.float64) / 20.0)
     return 1.0 / (1.0 + np.exp(-2.0 * gcx[..., None] * np.asarray(y, np.float64)))
+
+
+class XtensorStream:
+    """The random stream `t2y` draws from, restated: xtensor's default engine is ONE process-wide `std::mt19937`
+    (3rdparty/xtensor/include/xtensor/xrandom.hpp:300-313; `init_seed(s)` = `engine.seed(s)`, MNC_py.cpp:185-187), and each
+    `xt::random::rand` / `randn` call builds a FRESH `std::uniform_real_distribution<double>` / `std::normal_distribution<double>`
+    over it (xrandom.hpp:329-372).  With libstdc++ (the reference's toolchain):
+      * a double in [0,1) = `generate_canonical<double,53>` = two 32-bit engine outputs, (lo + hi 2^32) 2^-64;
+      * a normal = Marsaglia's polar method on x, y = 2 U - 1: the call returns y m and keeps x m for the NEXT call on the
+        same distribution object (m = sqrt(-2 ln r2 / r2)); the kept value dies with the object, so `randn({1})` costs one
+        accepted pair per call and `randn({n})` n/2 pairs.
+    Pinned bit-for-bit against the reference's compiled MNC module by oracle/make_t2y_golden.py
+    (tests/golden/ldpc_t2y_stream.npz)."""
+
+    def __init__(self, seed):
+        import numpy as np
+        self._bg = np.random.MT19937()
+        self._bg._legacy_seeding(int(seed) & 0xFFFFFFFF)       # init_genrand: what std::mt19937::seed(value) runs
+        self._buf, self._pos = [], 0
+
+    def _u32(self):
+        if self._pos == len(self._buf):
+            self._buf, self._pos = self._bg.random_raw(4096).tolist(), 0
+        self._pos += 1
+        return self._buf[self._pos - 1]
+
+    def canonical(self):
+        lo, hi = self._u32(), self._u32()
+        r = (float(lo) + float(hi) * 4294967296.0) / 18446744073709551616.0
+        return r if r < 1.0 else 1.0 - 2.0 ** -53              # libstdc++ clamps the round-to-1.0 case to nextafter(1, 0)
+
+    def rand1(self):
+        """`xt::random::rand<double>({1})[0]`."""
+        return self.canonical()
+
+    def randn(self, n, std_dev=1.0):
+        """`xt::random::randn<double>({n}, 0, std_dev)` evaluated in storage order."""
+        import math
+        out, saved = [], None
+        for _ in range(n):
+            if saved is not None:
+                v, saved = saved, None
+            else:
+                while True:
+                    x = 2.0 * self.canonical() - 1.0
+                    y = 2.0 * self.canonical() - 1.0
+                    r2 = x * x + y * y
+                    if not (r2 > 1.0 or r2 == 0.0):
+                        break
+                m = math.sqrt(-2.0 * math.log(r2) / r2)
+                saved, v = x * m, y * m
+            out.append(v * std_dev + 0.0)
+        return out
+
+
+def ldpc_channel_stream(t, snr_db, sigma_b, rho, stream, return_draws=False):
+    """One `t2y(t, snr_db, sigma_b, rho)` call (/root/reference/lib/data/MNC/MNC_py.cpp:86-102) INCLUDING its draws from
+    `stream` (an XtensorStream, advanced in place): N normals for the AWGN term first, then — only if sigma_b >= 1e-20 — per
+    bit one uniform and, where it is below rho, one N(0, gcx sigma_b) from a fresh distribution object.  t [N] bits -> y [N]
+    float64, bit-for-bit what the reference returns after `init_seed`.  With return_draws also (z1, u, z2) as `ldpc_channel`
+    takes them: the unit normals and uniforms this call consumed (u = 1 and z2 = 0 where the reference drew none)."""
+    import math
+    import numpy as np
+    t = np.asarray(t, np.float64)
+    n = t.shape[0]
+    gcx = math.pow(10.0, float(snr_db) / 20.0)
+    z1 = np.asarray(stream.randn(n), np.float64)
+    y = 2 * gcx * (t - 0.5) + z1
+    sigma = gcx * float(sigma_b)
+    u, z2 = np.ones(n), np.zeros(n)
+    if sigma_b >= 1e-20:
+        for i in range(n):
+            u[i] = stream.rand1()
+            if u[i] < rho:
+                z2[i] = stream.randn(1)[0]
+                y[i] += z2[i] * sigma + 0.0                    # normal_distribution(0, sigma): unit draw * sigma + mean
+    return (y, z1, u, z2) if return_draws else y

@@ -110,3 +110,65 @@ def test_philox_restatement_known_answers():
     assert abs(float(z1.mean())) < 0.01 and abs(float(z1.std()) - 1.0) < 0.01 and abs(float(z2.std()) - 1.0) < 0.01
     assert 0.0 <= float(u.min()) and float(u.max()) < 1.0 and abs(float(u.mean()) - 0.5) < 0.005
     assert abs(float(np.corrcoef(z1, z2)[0, 1])) < 0.01
+
+
+def _t2y_streams():
+    z = H.load('ldpc_t2y_stream.npz')
+    start = 0
+    for sd in dict.fromkeys(int(s) for s in z['seed']):                     # the calls of a seed continue one stream
+        rows = [i for i in range(len(z['seed'])) if int(z['seed'][i]) == sd]
+        assert rows == list(range(start, start + len(rows)))
+        start += len(rows)
+        yield z, sd, rows
+
+
+def test_oracle_replays_the_reference_t2y_stream_bit_for_bit():
+    """`init_seed(s)` + successive `t2y` calls of the reference's own compiled module (oracle/make_t2y_golden.py): the restated
+    generator (mt19937 -> libstdc++ canonical doubles -> polar normals, a fresh distribution per xtensor call) reproduces every
+    received word exactly, across calls, with and without burst draws, for even and odd lengths."""
+    seen = set()
+    for z, sd, rows in _t2y_streams():
+        stream = O.XtensorStream(sd)
+        for i in rows:
+            n = int(z['length'][i])
+            y = O.ldpc_channel_stream(z['t'][i, :n], z['snr_db'][i], z['sigma_b'][i], z['rho'][i], stream)
+            assert np.array_equal(y, z['y'][i, :n]), (sd, i)
+            assert np.abs(O.ldpc_bit_prior(y[None], z['snr_db'][i:i + 1])[0] - z['prior'][i, :n]).max() <= 2.0 ** -52
+            seen.add((n % 2, bool(z['sigma_b'][i] >= 1e-20), float(z['rho'][i])))
+    assert {(0, False), (0, True), (1, True)} <= {(a, b) for a, b, _ in seen} and {0.0, 0.05, 0.5, 1.0} <= {r for _, _, r in seen}
+
+
+def test_stream_draws_fed_to_the_explicit_channel_give_the_reference_words():
+    """The product's channel takes its draws as inputs (`ldpc_channel` = fgnn_ldpc_channel_features' arithmetic): with the
+    draws the reference's stream made, it returns the reference's words."""
+    for z, sd, rows in _t2y_streams():
+        stream = O.XtensorStream(sd)
+        for i in rows:
+            n = int(z['length'][i])
+            y, z1, u, z2 = O.ldpc_channel_stream(z['t'][i, :n], z['snr_db'][i], z['sigma_b'][i], z['rho'][i], stream, return_draws=True)
+            again = O.ldpc_channel(z['t'][i:i + 1, :n], z['snr_db'][i:i + 1], z['sigma_b'][i:i + 1], z['rho'][i], z1[None], u[None], z2[None])[0]
+            assert np.abs(again - y).max() <= 2.0 ** -50 * np.abs(y).max()       # numpy's vector pow vs libm's: 1 ulp of gcx
+
+
+def test_whole_items_chain_like_gen_data_item():
+    """s -> s2t -> t2y -> y2b -> zb2x of the reference module, item after item on one stream (lib/data/ldpc.py:7-30)."""
+    z, fix = H.load('ldpc_t2y_stream.npz'), H.load('ldpc_datapath.npz')
+    stream = O.XtensorStream(int(z['item_seed']))
+    wrong = 0
+    for i in range(len(z['item_s'])):
+        t = O.ldpc_encode(fix['G'], z['item_s'][i])
+        assert np.array_equal(t, z['item_t'][i])
+        y = O.ldpc_channel_stream(t, z['item_snr_db'][i], z['item_sigma_b'][i], 0.05, stream)
+        assert np.array_equal(y, z['item_y'][i])
+        if i % 4 == 0:
+            x, _, viol, _ = O.ldpc_sum_product(fix['A2_nlist'], 48, z['item_prior'][i])
+            assert np.array_equal(x[:48], z['item_x'][i])
+            wrong += int(viol > 0)
+    assert 0 < (z['item_x'] != z['item_s']).mean() < 0.2
+
+
+def test_xtensor_stream_statistics():
+    st = O.XtensorStream(5)
+    zs = np.array(st.randn(20001))
+    us = np.array([st.rand1() for _ in range(20000)])
+    assert abs(zs.mean()) < 0.03 and abs(zs.std() - 1.0) < 0.03 and 0.0 <= us.min() and us.max() < 1.0 and abs(us.mean() - 0.5) < 0.01

@@ -181,3 +181,28 @@ def test_sample_with_kernel_rng_is_a_training_batch(path, dev):
     c = path.sample(32, seed=3, dtype=torch.bfloat16, kernel_rng=True, step=1)
     assert all(torch.equal(x, y) for x, y in zip(a, b))
     assert not torch.equal(a[0], c[0]) and torch.equal(a[6], c[6])       # new noise, same codewords
+
+
+def test_channel_fed_the_reference_stream_draws_gives_the_reference_words(path):
+    """tests/golden/ldpc_t2y_stream.npz holds words the reference's own `t2y` returned after `init_seed` (draws included).  The
+    draws its generator made, replayed by the oracle's XtensorStream, go into fgnn_ldpc_channel_features as its noise inputs:
+    the device's f32 channel lands on the reference's float64 words."""
+    z = H.load('ldpc_t2y_stream.npz')
+    rows, draws, stream, seed = [], [], None, None
+    for i in range(len(z['seed'])):
+        if int(z['seed'][i]) != seed:
+            seed = int(z['seed'][i])
+            stream = O.XtensorStream(seed)
+        n = int(z['length'][i])
+        y, z1, u, z2 = O.ldpc_channel_stream(z['t'][i, :n], z['snr_db'][i], z['sigma_b'][i], z['rho'][i], stream, return_draws=True)
+        assert np.array_equal(y, z['y'][i, :n])
+        if n == 96:
+            rows.append(i), draws.append((z1, u, z2))
+    assert len(rows) >= 30
+    for rho in sorted(set(z['rho'][rows])):
+        sel = [k for k, i in enumerate(rows) if z['rho'][i] == rho]
+        idx = [rows[k] for k in sel]
+        noise = tuple(torch.from_numpy(np.stack([draws[k][j] for k in sel])) for j in range(3))
+        y = path.channel_features(torch.from_numpy(z['t'][idx]), torch.from_numpy(z['snr_db'][idx]), torch.from_numpy(z['sigma_b'][idx]),
+                                  float(rho), noise=noise)[0].cpu().numpy()
+        assert np.abs(y - z['y'][idx]).max() <= 4e-6 * np.abs(z['y'][idx]).max()
