@@ -349,8 +349,8 @@ def ldpc_channel(t, snr_db, sigma_b, rho, z1, u, z2):
     """`t2y` (/root/reference/lib/data/MNC/MNC_py.cpp:86-102) with the random draws made explicit:
     gcx = 10^(snr_db/20);  y = 2 gcx (t - 0.5) + z1;  where sigma_b >= 1e-20 and u < rho: y += gcx sigma_b z2.
     t [B,N] bits, snr_db / sigma_b [B], z1 / z2 ~ N(0,1), u ~ U[0,1) of t's shape.  float64 like the reference
-    (`T` = double when called from Python).  PARITY UNPINNED for the RNG stream itself (xtensor's generator is
-    not reproducible here) — the arithmetic above is what is checked."""
+    (`T` = double when called from Python).  The draws themselves, as the reference's generator makes them, are
+    `ldpc_channel_stream` / `XtensorStream` below (pinned against the reference's compiled module)."""
     import numpy as np
     t = np.asarray(t, np.float64)
     gcx = np.power(10.0, np.asarray(snr_db, np.float64) / 20.0)[:, None]

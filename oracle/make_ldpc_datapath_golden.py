@@ -12,8 +12,9 @@ factor-graph-neural-network_amd/fgnn_amd/data/ldpc_96_3_963_G.npz from the REFER
     its own sources into oracle/_ref/libbnd_ref.so and run on 96 received words: hard decisions, pseudo-posteriors
     (float64, bit-for-bit), violated checks and iteration counts are stored, and the pure-Python restatement
     `ldpc_sum_product` is asserted IDENTICAL to it on all of them;
-  * the channel `t2y` (MNC_py.cpp:86-102) draws from xtensor's RNG, which cannot be replayed here; its ARITHMETIC
-    is stored for fixed seeded noise draws via the float64 restatement in oracle/fgnn_oracle.py (`ldpc_channel`).
+  * the channel `t2y` (MNC_py.cpp:86-102): its ARITHMETIC is stored here for fixed seeded noise draws via the float64
+    restatement in oracle/fgnn_oracle.py (`ldpc_channel`); its random stream is pinned separately, against the reference's own
+    module, by oracle/make_t2y_golden.py.
 
 Run here (needs /root/reference and `sh oracle/build_ref.sh`); the outputs are data and are committed.
 """
