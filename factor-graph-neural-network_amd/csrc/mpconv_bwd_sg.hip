@@ -129,12 +129,15 @@ __global__ __launch_bounds__(BS_THREADS, 4) void mpconv_bwd_sg_kernel(const BsPa
     unsigned char* pd = bs_lds + p.off_pd;                               // [Npad][PSB]      bf16 P, then dP
     unsigned char* ga = bs_lds + p.off_ga;                               // [M][GSB]         {gz | argmax}
     unsigned char* zb = bs_lds + p.off_z + wave * p.zbytes;              // this wave's detype image [KC*2][ZCS]
+    // this wave's edge-type image [4 e][NPW nodes][QS in-edge slots] bf16: the A operands of the dP products (slots >= DEG stay 0)
+    constexpr int QS = DEG > 4 ? 8 : 4;
+    unsigned char* etw = bs_lds + p.off_es + wave * (4 * NPW * QS * 2);
     int* tab = reinterpret_cast<int*>(bs_lds + p.off_tab);               // [N][DEG]  m * 256 + j of every in-edge
     int* idx_s = reinterpret_cast<int*>(bs_lds + p.off_idx);             // [M * KC]
     const int xs_bytes = Npad * BS_XSB;
 
     // ---- zero the LDS images: padding rows are read by the matrix cores, the detype images rely on their zeros ----
-    for (int f = tid; f < (p.off_es - p.off_xs) / 4; f += BS_THREADS) reinterpret_cast<unsigned*>(bs_lds + p.off_xs)[f] = 0u;
+    for (int f = tid; f < (p.off_tab - p.off_xs) / 4; f += BS_THREADS) reinterpret_cast<unsigned*>(bs_lds + p.off_xs)[f] = 0u;
     // ---- neighbour table -> LDS, then the transposed incidence in (m, j) order (deterministic, no atomics) ----
     for (int r = tid; r < mk; r += BS_THREADS) {
         long long v = p.idx[r];
@@ -231,7 +234,7 @@ __global__ __launch_bounds__(BS_THREADS, 4) void mpconv_bwd_sg_kernel(const BsPa
     // whatever its width: uint2 + dword loads on all 16 waves cost ~0.8 k cycles more per sample than these.
     uint4 pg = make_uint4(0, 0, 0, 0);
     uint2 pa = make_uint2(0, 0);
-    uint2 pe, pe_cur = make_uint2(0, 0);              // edge-type row of in-edge `lane` of this wave: next sample's / this sample's
+    uint2 pe;                                         // edge-type row (4 bf16) of in-edge `lane` of this wave, next sample's
     const int xchunks = N * 8, gitems = M * 8;
     auto prefetch = [&](int b, int t) {
         const unsigned utid = (unsigned)t;
@@ -265,7 +268,15 @@ __global__ __launch_bounds__(BS_THREADS, 4) void mpconv_bwd_sg_kernel(const BsPa
             *reinterpret_cast<uint4*>(gp) = make_uint4(w[0], w[1], w[2], w[3]);
             *reinterpret_cast<uint4*>(gp + 16) = make_uint4(w[4], w[5], w[6], w[7]);
         }
-        pe_cur = pe;
+        {   // in-edge (node i, slot q) of this wave -> etw[e][i][q]: wave-private, read by this wave's dP phase only (program order)
+            const int l = t & 63;
+            if (l < NPW * DEG) {
+                const int i = l / DEG, q = l - i * DEG;
+                uint16_t* ew = reinterpret_cast<uint16_t*>(etw) + i * QS + q;
+                ew[0] = (uint16_t)pe.x; ew[NPW * QS] = (uint16_t)(pe.x >> 16);
+                ew[2 * NPW * QS] = (uint16_t)pe.y; ew[3 * NPW * QS] = (uint16_t)(pe.y >> 16);
+            }
+        }
     };
 
     const int ntile = Npad / 16;                      // 16-node tiles: 2..6
@@ -380,25 +391,38 @@ __global__ __launch_bounds__(BS_THREADS, 4) void mpconv_bwd_sg_kernel(const BsPa
             for (int f = nvec * 8 + t; f < 4 * mk; f += BS_THREADS) *bs_at<uint16_t>(gdst, (unsigned)f * 2u) = *reinterpret_cast<const uint16_t*>(gsrc + f * 2);
         }
 
-        // ---- dP: wave owns source nodes n0 .. n0 + NPW - 1, lane = channel; in-edges in (m, j) order ----
+        // ---- dP: wave owns source nodes n0 .. n0 + NPW - 1, lane = channel.  For one node dP[n][o][e] = sum_q et_q[e] gzm_q[o] over its
+        //      in-edges q is a [4 e x DEG] x [DEG x 64 o] product: ONE v_mfma_f32_4x4x4_16b_bf16 per four in-edges (16 independent
+        //      4x4x4 blocks = 16 groups of 4 channels; A = the node's edge types, the same in every block; B = the masked gz of
+        //      lane = channel, four in-edges in the lane; D = the 4 edge types of channel `lane`, i.e. the lane's 8 bytes of the dP
+        //      row).  Per in-edge and lane: one LDS read, a bit-field extract, an AND (the FMA form took 10 VALU instructions per
+        //      in-edge: 3 300 cycles of the sample on the vector ALUs) ----
+        {
+            typedef short bs_s16x4 __attribute__((ext_vector_type(4)));
 #pragma unroll
-        for (int i = 0; i < NPW; ++i) {
-            const int n = n0 + i;
-            if (n < N) {
-                bs_f32x2 a01 = {0.f, 0.f}, a23 = {0.f, 0.f};
+            for (int i = 0; i < NPW; ++i) {
+                const int n = n0 + i;
+                if (n < N) {
+                    unsigned gm[8];
 #pragma unroll
-                for (int q = 0; q < DEG; ++q) {
-                    const int e = (ent2[i][q >> 1] >> (16 * (q & 1))) & 0xffff;
-                    const unsigned dw = *reinterpret_cast<const unsigned*>(ga + (e & ~0xff) + lane * 4);
-                    const int msk = __builtin_amdgcn_sbfe((int)dw, e & 0xff, 1);            // -1 where this edge won the max
-                    const float g = __uint_as_float(dw & (unsigned)msk & 0xffff0000u);
-                    // the four edge-type weights of this in-edge are wave-uniform: read them out of lane (i DEG + q) of the staged row
-                    const unsigned w01 = __builtin_amdgcn_readlane(pe_cur.x, i * DEG + q), w23 = __builtin_amdgcn_readlane(pe_cur.y, i * DEG + q);
-                    const bs_f32x2 g2 = {g, g};
-                    a01 = g2 * (bs_f32x2){bs_lo(w01), bs_hi(w01)} + a01;
-                    a23 = g2 * (bs_f32x2){bs_lo(w23), bs_hi(w23)} + a23;
+                    for (int q = 0; q < 8; ++q) gm[q] = 0u;
+#pragma unroll
+                    for (int q = 0; q < DEG; ++q) {
+                        const int e = (ent2[i][q >> 1] >> (16 * (q & 1))) & 0xffff;
+                        const unsigned dw = *reinterpret_cast<const unsigned*>(ga + (e & ~0xff) + lane * 4);
+                        gm[q] = dw & (unsigned)__builtin_amdgcn_sbfe((int)dw, e & 0xff, 1);         // gz in the high half where this edge won the max
+                    }
+                    const unsigned char* ap = etw + ((lane & 3) * NPW + i) * (QS * 2);
+                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int g4 = 0; g4 < (DEG + 3) / 4; ++g4) {
+                        const uint2 av = *reinterpret_cast<const uint2*>(ap + 8 * g4);
+                        const uint2 bv = make_uint2(__builtin_amdgcn_perm(gm[4 * g4 + 1], gm[4 * g4], 0x07060302u),
+                                                    __builtin_amdgcn_perm(gm[4 * g4 + 3], gm[4 * g4 + 2], 0x07060302u));
+                        acc = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(__builtin_bit_cast(bs_s16x4, av), __builtin_bit_cast(bs_s16x4, bv), acc, 0, 0, 0);
+                    }
+                    *reinterpret_cast<uint2*>(pd + n * BS_PSB + lane * 8) = make_uint2(bs_pack2(acc[0], acc[1]), bs_pack2(acc[2], acc[3]));
                 }
-                *reinterpret_cast<uint2*>(pd + n * BS_PSB + lane * 8) = make_uint2(bs_pack2(a01[0], a01[1]), bs_pack2(a23[0], a23[1]));
             }
         }
         BS_STAMP(6);
@@ -550,7 +574,7 @@ int fgnn_mpconv_backward_sg(const fgnn_mpconv_desc* d, const void* x, const int6
     p.off_ga = take(d->M * BS_GSB);
     p.zbytes = KC * 2 * BS_ZCS;
     p.off_z = take(BS_WAVES * p.zbytes + 16 * BS_ZCS);                  // + slack: the 16-column tile reads past column 2 KC
-    p.off_es = take(BS_WAVES * p.NPW * DEG * 16);
+    p.off_es = take(BS_WAVES * 4 * p.NPW * (DEG > 4 ? 16 : 8));         // per-wave [4 e][NPW][8 | 4 slots] bf16 edge-type images
     p.off_tab = take(d->N * DEG * 4);
     p.off_idx = take(d->M * KC * 4);
     p.off_gst = take(8 * d->M * KC);

@@ -1,0 +1,16 @@
+#!/bin/sh
+# Run on the GPU box: kernel trace (start / end per launch) of a few training steps, attributed to wall time by tools/timeline.py.
+#   gpurun --timeout 900 -- sh tools/profile_timeline.sh [outdir under gpurun_out] [extra bench.py flags]
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/${1:-timeline}
+shift
+mkdir -p $O
+cd $R
+rm -rf /tmp/tl
+timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/tl -o tl -- python bench.py --steps 4 --warmup 2 --mode train --no-cpu-baseline "$@" > $O/bench.log 2>&1
+T=$(find /tmp/tl -name "*kernel_trace.csv" | head -1)
+python tools/timeline.py $T --json $O/timeline.json > $O/timeline.txt 2>&1
+tail -n 2000 $T > $O/trace_tail.csv
+head -1 $T > $O/trace_head.csv
+cat $O/timeline.txt | head -60

@@ -1,69 +1,86 @@
-#!/usr/bin/env python3
-"""GPU occupancy of one replayed step from a rocprofv3 --kernel-trace CSV: how much of the step some kernel is running,
-how much two run at once, where the idle gaps are and which kernels border the longest ones.
-  python tools/timeline.py <kernel_trace.csv> [steps=10]   (the trace of `bench.py --steps N`: the last N graph replays are used)"""
-import csv, sys
-rows = list(csv.DictReader(open(sys.argv[1])))
-steps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
-ev = sorted(((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name']) for r in rows), key=lambda e: e[0])
-# the timed region: the last `steps` repetitions; find it by the largest idle gaps (fences) near the end
-n = len(ev)
-per = None
-names = [e[2] for e in ev]
-# period detection: number of kernels per step = distance between successive occurrences of the flat Adam kernel
-adam = [i for i, nm in enumerate(names) if 'flat_adam' in nm]
-if len(adam) >= steps + 1:
-    lo, hi = adam[-steps - 1] + 1, adam[-1] + 1
-else:                                       # inference: the timed replays are the longest gap-free stretch of the trace
-    cuts = [0]
-    run_end = ev[0][1]
-    for i in range(1, n):
-        if ev[i][0] - run_end > 150000:     # 150 us of idle GPU: a host synchronisation
-            cuts.append(i)
-        run_end = max(run_end, ev[i][1])
-    cuts.append(n)
-    lo, hi = max(((cuts[i], cuts[i + 1]) for i in range(len(cuts) - 1)), key=lambda ab: ab[1] - ab[0])
-seg = ev[lo:hi]
-t0, t1 = seg[0][0], max(e[1] for e in seg)
-span = t1 - t0
-# sweep
-pts = []
-for s, e, _ in seg:
-    pts.append((s, 1)); pts.append((e, -1))
-pts.sort()
-busy1 = busy2 = 0
-depth = 0
-last = t0
-gaps = []
-for t, d in pts:
-    if depth >= 1: busy1 += t - last
-    if depth >= 2: busy2 += t - last
-    if depth == 0 and t > last: gaps.append((t - last, last))
-    depth += d
-    last = t
-print('kernels in window: %d (%.1f per step), window %.3f ms per step' % (len(seg), len(seg) / steps, span / steps / 1e6))
-print('some kernel running: %.1f %%   two or more: %.1f %%   idle: %.1f %% (%.3f ms per step)' % (
-    100.0 * busy1 / span, 100.0 * busy2 / span, 100.0 * (span - busy1) / span, (span - busy1) / steps / 1e6))
-ksum = sum(e[1] - e[0] for e in seg)
-print('sum of kernel durations: %.3f ms per step' % (ksum / steps / 1e6))
-gaps.sort(reverse=True)
-hist = {}
-for g, _ in gaps:
-    b = 1 if g < 2000 else 2 if g < 5000 else 5 if g < 10000 else 10 if g < 50000 else 50
-    hist[b] = hist.get(b, [0, 0]); hist[b][0] += 1; hist[b][1] += g
-for b in sorted(hist):
-    print('  gaps %s us: %5d per step, %.3f ms per step' % ({1: '<2', 2: '2-5', 5: '5-10', 10: '10-50', 50: '>50'}[b], hist[b][0] / steps, hist[b][1] / steps / 1e6))
-ends = {e[1]: e[2] for e in seg}
-starts = {e[0]: e[2] for e in seg}
-print('longest gaps:')
-for g, at in gaps[:12]:
-    before = ends.get(at, '?')
-    after = starts.get(at + g, '?')
-    print('  %7.1f us after %-60s before %s' % (g / 1e3, before[:60], after[:60]))
-if len(sys.argv) > 3:                       # per-step launch counts by kernel name
-    cnt = {}
-    for s, e, nm in seg:
-        c = cnt.setdefault(nm, [0, 0]); c[0] += 1; c[1] += e - s
-    print('launches per step by kernel:')
-    for nm, (c, d) in sorted(cnt.items(), key=lambda kv: -kv[1][1]):
-        print('  %6.1f x %8.1f us  %s' % (c / steps, d / c / 1e3, nm[:110]))
+"""Wall-time attribution of one replayed training step from a rocprofv3 kernel trace (`--kernel-trace --output-format csv`).
+
+    python tools/timeline.py <kernel_trace.csv> [--marker flat_adam] [--top 40]
+
+The step is the window between the ends of the last two launches of the marker kernel (one per step).  Inside it every
+instant is attributed to the kernels running then, 1/k each when k run concurrently (two streams), and idle instants to the
+kernel that starts next ("gap before").  Sum of the attributed times = the wall time of the step."""
+import argparse
+import collections
+import csv
+import json
+import re
+
+
+def short(name):
+    name = re.sub(r'^void ', '', name)
+    name = re.sub(r'\(.*$', '', name)
+    return name[:70]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('csv')
+    ap.add_argument('--marker', default='flat_adam')
+    ap.add_argument('--top', type=int, default=40)
+    ap.add_argument('--json', default=None)
+    a = ap.parse_args()
+    rows = []
+    with open(a.csv) as f:
+        for r in csv.DictReader(f):
+            rows.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name'], r.get('Queue_Id', '0'), r.get('Stream_Id', '0')))
+    rows.sort()
+    marks = [r for r in rows if a.marker in r[2]]
+    assert len(marks) >= 2, 'marker kernel not found twice'
+    t0, t1 = marks[-2][1], marks[-1][1]
+    win = [r for r in rows if r[0] >= t0 and r[1] <= t1]
+    ev = []
+    for i, (s, e, _, _, _) in enumerate(win):
+        ev.append((s, 1, i)), ev.append((e, 0, i))
+    ev.sort()
+    live, last = set(), t0
+    attr = collections.Counter()
+    gap_before = collections.Counter()
+    conc = collections.Counter()
+    idle_from = None
+    for t, kind, i in ev:
+        dt = t - last
+        if dt > 0:
+            conc[min(len(live), 3)] += dt
+            if live:
+                for j in live:
+                    attr[short(win[j][2])] += dt / len(live)
+            else:
+                idle_from = (idle_from or 0) + dt
+        if kind == 1:
+            if not live and idle_from:
+                gap_before[short(win[i][2])] += idle_from
+                idle_from = None
+            live.add(i)
+        else:
+            live.discard(i)
+        last = t
+    wall = t1 - t0
+    dur = collections.Counter()
+    cnt = collections.Counter()
+    for s, e, n, _, _ in win:
+        dur[short(n)] += e - s
+        cnt[short(n)] += 1
+    queues = collections.Counter()
+    for s, e, n, q, st in win:
+        queues[(q, st)] += e - s
+    out = {'wall_ms': wall / 1e6, 'launches': len(win), 'sum_kernel_ms': sum(dur.values()) / 1e6,
+           'idle_ms': conc[0] / 1e6, 'one_kernel_ms': conc[1] / 1e6, 'two_kernels_ms': conc[2] / 1e6, 'three_plus_ms': conc[3] / 1e6,
+           'queues_busy_ms': {'%s/%s' % k: v / 1e6 for k, v in queues.items()}}
+    print(json.dumps(out))
+    print('%-72s %5s %9s %9s %9s' % ('kernel', 'n', 'attr_ms', 'sum_ms', 'gap_ms'))
+    for n, v in attr.most_common(a.top):
+        print('%-72s %5d %9.3f %9.3f %9.3f' % (n, cnt[n], v / 1e6, dur[n] / 1e6, gap_before[n] / 1e6))
+    print('total attributed %.3f ms + idle %.3f ms = wall %.3f ms' % (sum(attr.values()) / 1e6, conc[0] / 1e6, wall / 1e6))
+    if a.json:
+        out['kernels'] = {n: {'n': cnt[n], 'attr_ms': attr[n] / 1e6, 'sum_ms': dur[n] / 1e6, 'gap_before_ms': gap_before[n] / 1e6} for n in dur}
+        json.dump(out, open(a.json, 'w'), indent=1)
+
+
+if __name__ == '__main__':
+    main()
