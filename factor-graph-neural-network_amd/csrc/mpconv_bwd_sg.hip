@@ -187,6 +187,9 @@ __global__ __launch_bounds__(BS_THREADS, 4) void mpconv_bwd_sg_kernel(const BsPa
 #pragma unroll
             for (int j = 0; j < KC; ++j) nb[d][j >> 2] |= (unsigned)idx_s[(m0 + d) * KC + j] << (8 * (j & 3));
         }
+        // kept in vector registers: as wave-uniform values they are spilled to VGPR lanes with ~60 other scalars and come back
+        // through v_readlane + s_nop in front of every use
+        asm volatile("" : "+v"(nb[d][0]), "+v"(nb[d][1]));
     }
     // W fragments.  aP: A of P^T = W^T x (wave = 16-column slab): A[i = col][k = c] = W[c][16 wave + i], 8 consecutive c.
     //               aT: A of dx^T = W dP^T (wave & 3 = 16-channel tile): A[i = c][k = col] = W[ct*16 + i][col], 8 consecutive cols.
@@ -341,42 +344,69 @@ __global__ __launch_bounds__(BS_THREADS, 4) void mpconv_bwd_sg_kernel(const BsPa
             // stores after the barrier: two-byte stores scattered over it kept the vector-memory queue busy for ~1 500 cycles
             // (the next sample's staging below waits on that queue)
             uint16_t* gb = reinterpret_cast<uint16_t*>(bs_lds + p.off_gst);
+            // stage 1, all destinations of the wave: {gz | argmax} of channel `lane`, then the routed P row (two dependent LDS
+            // reads per destination, all in flight together).  Destinations past M (small graphs) read row M - 1 with gz forced
+            // to 0 and store nothing.
+            unsigned dwv[DPW];
+            uint2 pkv[DPW];
 #pragma unroll
             for (int d = 0; d < DPW; ++d) {
-                const int m = m0 + d;
-                if (m < M) {
-                    const unsigned dw = *reinterpret_cast<const unsigned*>(ga + m * BS_GSB + lane * 4);
-                    const unsigned jst = (dw >> 8) & 7u;
-                    const unsigned n = __builtin_amdgcn_perm(nb[d][1], nb[d][0], 0x0c0c0c00u | jst);
-                    const uint2 pk = *reinterpret_cast<const uint2*>(pd + n * BS_PSB + lane * 8);
-                    const float g = __uint_as_float(dw & 0xffff0000u);
+                const int mm = min(m0 + d, M - 1);
+                dwv[d] = *reinterpret_cast<const unsigned*>(ga + mm * BS_GSB + lane * 4);
+            }
+#pragma unroll
+            for (int d = 0; d < DPW; ++d) {
+                const unsigned jst = (dwv[d] >> 8) & 7u;
+                const unsigned n = __builtin_amdgcn_perm(nb[d][1], nb[d][0], 0x0c0c0c00u | jst);
+                pkv[d] = *reinterpret_cast<const uint2*>(pd + n * BS_PSB + lane * 8);
+            }
+            // stage 2: the phase is bound by LDS cycles, most of them the 16-column operand reads of the image (4 x 8 cycles per
+            // pass for 2 KC real columns).  With 3 slots TWO destinations share a pass: columns 0-5 and 6-11.
+            constexpr int DPP = KC == 3 ? 2 : 1;          // destinations per pass
+#pragma unroll
+            for (int d0 = 0; d0 < DPW; d0 += DPP) {
+                unsigned* zw[DPP];
+#pragma unroll
+                for (int u = 0; u < DPP; ++u) {
+                    const int d = d0 + u;
+                    const bool live = m0 + d < M;
+                    const unsigned jst = (dwv[d] >> 8) & 7u;
+                    const uint2 pk = pkv[d];
+                    const float g = live ? __uint_as_float(dwv[d] & 0xffff0000u) : 0.f;
                     gbacc += g;
                     const unsigned c01 = bs_pack2(g * bs_lo(pk.x), g * bs_hi(pk.x));
                     const unsigned c23 = bs_pack2(g * bs_lo(pk.y), g * bs_hi(pk.y));
-                    // column (slot jst, pair 0) <- {e0 | e1}, column (slot jst, pair 1) <- {e2 | e3}, dword `lane` of each
-                    unsigned* zw = reinterpret_cast<unsigned*>(zb + jst * (2 * BS_ZCS) + lane * 4);
-                    zw[0] = c01;
-                    zw[BS_ZCS / 4] = c23;
-                    asm volatile("" ::: "memory");            // the image is re-read below through another type: keep the stores
-                    // D[0][col] = sum over channels of the even halves, D[1][col] of the odd halves; K = 64 channels x 2
-                    f32x4 sum = {0.f, 0.f, 0.f, 0.f};
-                    const unsigned char* zr = zb + li * BS_ZCS + lk * 16;
-                    bs_bf16x8 fr[4];
+                    // column (destination u, slot jst, pair 0) <- {e0 | e1}, (.., pair 1) <- {e2 | e3}, dword `lane` of each
+                    zw[u] = reinterpret_cast<unsigned*>(zb + (u * KC + jst) * (2 * BS_ZCS) + lane * 4);
+                    zw[u][0] = c01;
+                    zw[u][BS_ZCS / 4] = c23;
+                }
+                asm volatile("" ::: "memory");            // the image is re-read below through another type: keep the stores
+                // D[0][col] = sum over channels of the even halves, D[1][col] of the odd halves; K = 64 channels x 2
+                const unsigned char* zr = zb + li * BS_ZCS + lk * 16;
+                bs_bf16x8 fr[4];
 #pragma unroll
-                    for (int ks = 0; ks < 4; ++ks) fr[ks] = __builtin_bit_cast(bs_bf16x8, *reinterpret_cast<const uint4*>(zr + 64 * ks));
-                    asm volatile("" ::: "memory");
-                    zw[0] = 0u;                               // (issued right behind the reads: LDS runs a wave's operations in order)
-                    zw[BS_ZCS / 4] = 0u;
-                    asm volatile("" ::: "memory");
+                for (int ks = 0; ks < 4; ++ks) fr[ks] = __builtin_bit_cast(bs_bf16x8, *reinterpret_cast<const uint4*>(zr + 64 * ks));
+                asm volatile("" ::: "memory");
 #pragma unroll
-                    for (int ks = 0; ks < 4; ++ks) sum = __builtin_amdgcn_mfma_f32_16x16x32_bf16(evod, fr[ks], sum, 0, 0, 0);
-                    // column li of the image is (slot j = li >> 1, pair li & 1); rows 0 / 1 of D are its two edge types
-                    if (lk == 0 && li < KC * 2) {
-                        const int j = li >> 1, e0 = 2 * (li & 1);
-                        const __bf16 h0 = (__bf16)sum[0], h1 = (__bf16)sum[1];
-                        gb[e0 * mk + m * KC + j] = __builtin_bit_cast(uint16_t, h0);
-                        gb[(e0 + 1) * mk + m * KC + j] = __builtin_bit_cast(uint16_t, h1);
-                    }
+                for (int u = 0; u < DPP; ++u) {           // (issued right behind the reads: LDS runs a wave's operations in order)
+                    zw[u][0] = 0u;
+                    zw[u][BS_ZCS / 4] = 0u;
+                }
+                asm volatile("" ::: "memory");
+                f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};      // two chains of two instead of one of four
+                s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(evod, fr[0], s0, 0, 0, 0);
+                s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(evod, fr[2], s1, 0, 0, 0);
+                s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(evod, fr[1], s0, 0, 0, 0);
+                s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(evod, fr[3], s1, 0, 0, 0);
+                // column li of the image is (destination u = li / 2 KC, slot j, pair li & 1); rows 0 / 1 of D are its two edge types
+                const int u = li >= 2 * KC ? 1 : 0, lc = li - 2 * KC * u;
+                const int m = m0 + d0 + u;
+                if (lk == 0 && li < 2 * KC * DPP && m < M) {
+                    const int j = lc >> 1, e0 = 2 * (lc & 1);
+                    const __bf16 h0 = (__bf16)(s0[0] + s1[0]), h1 = (__bf16)(s0[1] + s1[1]);
+                    gb[e0 * mk + m * KC + j] = __builtin_bit_cast(uint16_t, h0);
+                    gb[(e0 + 1) * mk + m * KC + j] = __builtin_bit_cast(uint16_t, h1);
                 }
             }
         }
@@ -572,7 +602,7 @@ int fgnn_mpconv_backward_sg(const fgnn_mpconv_desc* d, const void* x, const int6
     p.off_xs = take(2 * p.Npad * BS_XSB);
     p.off_pd = take(p.Npad * BS_PSB);
     p.off_ga = take(d->M * BS_GSB);
-    p.zbytes = KC * 2 * BS_ZCS;
+    p.zbytes = (KC == 3 ? 2 : 1) * KC * 2 * BS_ZCS;                      // 3 slots: two destinations per image
     p.off_z = take(BS_WAVES * p.zbytes + 16 * BS_ZCS);                  // + slack: the 16-column tile reads past column 2 KC
     p.off_es = take(BS_WAVES * 4 * p.NPW * (DEG > 4 ? 16 : 8));         // per-wave [4 e][NPW][8 | 4 slots] bf16 edge-type images
     p.off_tab = take(d->N * DEG * 4);
