@@ -60,6 +60,9 @@ struct SgParams {
     uint8_t* argmax;
     float* stats;
     int B, N, M, Npad, DPW, relu;
+    int y_ld, w_ld, st_ld;                        // row strides (elements) of y / argmax, of W, of a statistics partial row: NOU,
+                                                  // 4 NOU, NOU for a whole call; the 64 -> 128 calls run as TWO 64-channel launches
+                                                  // over the halves of a 128-wide output (y_ld = st_ld = 128, w_ld = 512)
     long long x_sb, et_sb, y_sb;                  // elements
     long long* prof;                              // FGNN_PROF (builds with -DFGNN_ENABLE_PROF only): phase timeline
 };
@@ -137,7 +140,7 @@ __global__ __launch_bounds__(SG_THREADS, 4) void mpconv_fwd_sg_kernel(const SgPa
     // ---- W^T A-fragments: areg[pass][kk] = W[c = 16kk + 8lh + 0..7][col = 256 pass + 32 wave + l31] ----
     sg_bf16x8 areg[NPASS][KS];
     {
-        constexpr int ncols = NOU * 4;
+        const int ncols = p.w_ld;
 #pragma unroll
         for (int ps_i = 0; ps_i < NPASS; ++ps_i) {
             const float* wc = p.W + ps_i * 256 + 32 * wave + l31;
@@ -243,8 +246,8 @@ __global__ __launch_bounds__(SG_THREADS, 4) void mpconv_fwd_sg_kernel(const SgPa
             if (b + (int)gridDim.x < p.B) prefetch(b + gridDim.x);
         }
 #endif
-        unsigned short* yb = p.y + (int64_t)b * p.y_sb + (int64_t)m0 * NOU;
-        uint8_t* ab = (WANT_ARG && p.argmax) ? p.argmax + (int64_t)b * p.y_sb + (int64_t)m0 * NOU : nullptr;
+        unsigned short* yb = p.y + (int64_t)b * p.y_sb + (int64_t)m0 * p.y_ld;
+        uint8_t* ab = (WANT_ARG && p.argmax) ? p.argmax + (int64_t)b * p.y_sb + (int64_t)m0 * p.y_ld : nullptr;
         SG_STAMP(1);
         __syncthreads();                                          // x image complete; every wave is done with P
         SG_STAMP(2);
@@ -342,7 +345,7 @@ __global__ __launch_bounds__(SG_THREADS, 4) void mpconv_fwd_sg_kernel(const SgPa
                     if (MODE >= SG_MODE_AFFINE_RELU) res = fmaf(res, c_scale[pass], c_shift[pass]);
                     if (MODE == SG_MODE_AFFINE_RELU || (MODE == SG_MODE_GENERIC && p.relu)) res = fmaxf(res, 0.f);
                     const unsigned packed = sg_pack(res, 0.f);
-                    const int off = d * NOU + pass * 64 + lane;
+                    const int off = d * p.y_ld + pass * 64 + lane;
                     yb[off] = (unsigned short)packed;
                     if (MODE == SG_MODE_TRAIN_STATS) {
                         const float zr = __uint_as_float(packed << 16);            // of the value as stored
@@ -373,7 +376,7 @@ __global__ __launch_bounds__(SG_THREADS, 4) void mpconv_fwd_sg_kernel(const SgPa
             float sum = 0.f;
 #pragma unroll
             for (int w = 0; w < SG_WAVES; ++w) sum += red[((w * 2 + which) * NPASS + (c >> 6)) * 64 + (c & 63)];
-            p.stats[((int64_t)blockIdx.x * 2 + which) * NOU + c] = sum;
+            p.stats[((int64_t)blockIdx.x * 2 + which) * p.st_ld + c] = sum;
         }
     }
 }
@@ -406,10 +409,14 @@ int fgnn_mpconv_forward_sg(const fgnn_mpconv_desc* d, const void* x, const int64
     if (off) return 0;
     if (d->dtype != FGNN_BF16 || d->ext != FGNN_EXT_NONE || d->net != 4 || d->agg != FGNN_AGG_MAX) return 0;
     if (d->k != 3 && d->k != 6) return 0;
-    // 64 -> 128 (two column passes: 32 more resident fragment registers) spills under the 128-VGPR budget of 2 workgroups per
-    // CU and measured slower than the first-generation kernel (200 vs 150 us): it stays there unless FGNN_SG_WIDE is set
+    // 64 -> 128 as ONE launch (two column passes: 32 more resident fragment registers) spills under the 128-VGPR budget of 2
+    // workgroups per CU and measured slower than the first-generation kernel (200 vs 150 us; FGNN_SG_WIDE=1 selects it).  The
+    // output channels are independent, so the call runs as TWO launches of the 64 -> 64 kernel over the halves of W's columns
+    // and of the 128-wide y / argmax / statistics rows (x and etype are read twice: +60 MB at 4 096 codewords).
     static const bool wide = getenv("FGNN_SG_WIDE") != nullptr;
-    if (!((d->nin == 64 && (d->nou == 64 || (wide && d->nou == 128))) || (d->nin == 128 && d->nou == 64))) return 0;
+    static const bool no_split = getenv("FGNN_SG_NOSPLIT") != nullptr;
+    const bool split = d->nin == 64 && d->nou == 128 && !wide && !no_split;
+    if (!((d->nin == 64 && (d->nou == 64 || d->nou == 128) && !(d->nou == 128 && no_split && !wide)) || (d->nin == 128 && d->nou == 64))) return 0;
     if (d->N < 1 || d->N > 96 || d->M < 1) return 0;
     const int DPW = (d->M + SG_WAVES - 1) / SG_WAVES;
     const int MAXD = d->k == 6 ? 6 : 12;
@@ -427,7 +434,8 @@ int fgnn_mpconv_forward_sg(const fgnn_mpconv_desc* d, const void* x, const int64
     else if (post_scale && d->relu && !argmax && bias) mode = SG_MODE_AFFINE_RELU;
     else mode = SG_MODE_GENERIC;
     if (d->idx_sb != 0 && d->B > 1) return 0;                     // per-sample graphs: first-generation kernel
-    void* fn = d->k == 6 ? sg_pick_width<6, 6>(d->nin, d->nou, mode) : sg_pick_width<3, 12>(d->nin, d->nou, mode);
+    const int knou = split ? 64 : d->nou;                         // output channels of one launch
+    void* fn = d->k == 6 ? sg_pick_width<6, 6>(d->nin, knou, mode) : sg_pick_width<3, 12>(d->nin, knou, mode);
     if (!fn) return 0;
     const int Npad = fgnn_round_up(d->N, 32);
     const int lds = Npad * (d->nin * 2 + 16) + Npad * SG_PSB + SG_WAVES * 2 * SG_ESLOT;
@@ -440,11 +448,12 @@ int fgnn_mpconv_forward_sg(const fgnn_mpconv_desc* d, const void* x, const int64
     p.y = static_cast<unsigned short*>(y); p.argmax = argmax; p.stats = stats;
     p.B = d->B; p.N = d->N; p.M = d->M; p.Npad = Npad; p.DPW = DPW; p.relu = d->relu;
     p.x_sb = d->x_sb; p.et_sb = d->et_sb; p.y_sb = d->y_sb;
+    p.y_ld = d->nou; p.w_ld = d->nou * 4; p.st_ld = d->nou;
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "hipFuncSetAttribute(%d B LDS): %s", lds, hipGetErrorString(e));
     }
-    fgnn_note_kernel("mpconv_fwd_sg_kernel<%d, %d, %d, %d, %d>", d->nin, d->nou, d->k, MAXD, mode);
+    fgnn_note_kernel(split ? "mpconv_fwd_sg_kernel<%d, %d, %d, %d, %d> x2" : "mpconv_fwd_sg_kernel<%d, %d, %d, %d, %d>", d->nin, knou, d->k, MAXD, mode);
     p.prof = nullptr;
 #ifdef FGNN_ENABLE_PROF
     static long long* prof_buf = nullptr;
@@ -457,6 +466,15 @@ int fgnn_mpconv_forward_sg(const fgnn_mpconv_desc* d, const void* x, const int64
     void* args[] = {(void*)&p};
     hipError_t e = hipLaunchKernel(fn, dim3(grid), dim3(SG_THREADS), args, lds, (hipStream_t)stream);
     if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "mpconv sg forward launch: %s", hipGetErrorString(e));
+    if (split) {                                                  // the upper 64 output channels
+        p.W += 256; p.y += 64;
+        if (p.bias) p.bias += 64;
+        if (p.pscale) { p.pscale += 64; p.pshift += 64; }
+        if (p.argmax) p.argmax += 64;
+        if (p.stats) p.stats += 64;
+        e = hipLaunchKernel(fn, dim3(grid), dim3(SG_THREADS), args, lds, (hipStream_t)stream);
+        if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "mpconv sg forward launch (upper half): %s", hipGetErrorString(e));
+    }
 #ifdef FGNN_ENABLE_PROF
     if (p.prof) {                                     // tuning aid: per-wave phase timeline of one sample (shader clocks)
         long long h[64];

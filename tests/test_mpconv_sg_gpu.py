@@ -57,9 +57,9 @@ def test_sg_forward_vs_oracle(shape, mode, dev):
         kw.update(relu=True)
     xd, idxd, etd = _dev_views(x, idx, et, dev)
     y, am = ops.mpconv_forward_raw(xd, idxd, etd, W.to(dev), bias.to(dev), nou, 4, 0, _hip.AGG_MAX, **kw)
-    # 64 -> 128 stays with the first-generation kernel (the two-pass variant of the new one does not fit its register budget)
-    want = 'mpconv_fwd_sg' if nou == 64 else 'mpconv_fwd_b16'
-    assert want in _hip.lib().fgnn_last_kernel().decode(), _hip.lib().fgnn_last_kernel()
+    # 64 -> 128 runs as two launches of the 64 -> 64 kernel over the halves of the output channels
+    kern = _hip.lib().fgnn_last_kernel().decode()
+    assert 'mpconv_fwd_sg' in kern and kern.endswith(' x2') == (nou == 128), kern
     assert y.dtype == torch.bfloat16 and y.shape == ref.shape and y.stride(1) == 1
     err = float((y.float().cpu() - ref).abs().max() / ref.abs().max())
     assert err <= 2.0 ** -6, err
@@ -77,7 +77,7 @@ def test_sg_forward_vs_oracle(shape, mode, dev):
             assert int((dup == k - 1).sum()) == 0
 
 
-@pytest.mark.parametrize('shape', SHAPES[:2] + SHAPES[4:6], ids=IDS[:2] + IDS[4:6])
+@pytest.mark.parametrize('shape', SHAPES[:6], ids=IDS[:6])
 def test_sg_forward_matches_first_generation_kernel(shape, dev, monkeypatch):
     """Same inputs through mpconv_fwd_b16.hip (per-sample copy of the table defeats the shared-graph dispatch): both
     round P to bf16, so the outputs agree to one bf16 ulp of the output range and the argmax wherever messages differ."""
