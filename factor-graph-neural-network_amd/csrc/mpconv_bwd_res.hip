@@ -571,7 +571,7 @@ __global__ __launch_bounds__(BR_THREADS) void mpconv_bwd_res_kernel(const BresPa
 // the 16 partials of an element are folded in a fixed order through LDS (bit-reproducible).
 __global__ __launch_bounds__(256) void bres_reduce_kernel(const float* __restrict__ ws, int nslab, int64_t slab_len,
                                                           int64_t nw, float* __restrict__ gW,
-                                                          float* __restrict__ gbias, int overwrite) {
+                                                          float* __restrict__ gbias, int overwrite, int ncols, int ld) {
     __shared__ float part[16][17];
     const int e = threadIdx.x & 15, g = threadIdx.x >> 4;
     const int64_t i = (int64_t)blockIdx.x * 16 + e;
@@ -593,7 +593,9 @@ __global__ __launch_bounds__(256) void bres_reduce_kernel(const float* __restric
         float s = 0.f;
 #pragma unroll
         for (int q = 0; q < 16; ++q) s += part[q][e];
-        if (i < nw) gW[i] = overwrite ? s : gW[i] + s;
+        // the slab's weight part is [rows][ncols]; its rows land ld apart in gW (ld == ncols: dense, the usual case)
+        const int64_t o = ncols == ld ? i : (i / ncols) * ld + i % ncols;
+        if (i < nw) gW[o] = overwrite ? s : gW[o] + s;
         else if (gbias) gbias[i - nw] = overwrite ? s : gbias[i - nw] + s;
     }
 }
@@ -602,13 +604,20 @@ __global__ __launch_bounds__(256) void bres_reduce_kernel(const float* __restric
 void fgnn_launch_slab_reduce(const float* ws, int nslab, int64_t slab_len, int64_t nw, float* gW, float* gbias,
                              hipStream_t st) {
     hipLaunchKernelGGL(bres_reduce_kernel, dim3((unsigned)((slab_len + 15) / 16)), dim3(256), 0, st, ws, nslab,
-                       slab_len, nw, gW, gbias, 0);
+                       slab_len, nw, gW, gbias, 0, 1, 1);
+}
+
+// The same with the slab's [nw / ncols][ncols] weight block landing in rows `ld` apart (a column block of a wider gfilters).
+void fgnn_launch_slab_reduce_ld(const float* ws, int nslab, int64_t slab_len, int64_t nw, int ncols, int ld, float* gW,
+                                float* gbias, hipStream_t st) {
+    hipLaunchKernelGGL(bres_reduce_kernel, dim3((unsigned)((slab_len + 15) / 16)), dim3(256), 0, st, ws, nslab,
+                       slab_len, nw, gW, gbias, 0, ncols, ld);
 }
 
 // The same fold, STORED (out[i] = sum_w ws[w][i]): for outputs that are not accumulators (the batch-summed edge-type gradient).
 void fgnn_launch_slab_store(const float* ws, int nslab, int64_t slab_len, float* out, hipStream_t st) {
     hipLaunchKernelGGL(bres_reduce_kernel, dim3((unsigned)((slab_len + 15) / 16)), dim3(256), 0, st, ws, nslab,
-                       slab_len, slab_len, out, (float*)nullptr, 1);
+                       slab_len, slab_len, out, (float*)nullptr, 1, 1, 1);
 }
 
 void fgnn_launch_w_transpose(const float* W, float* Wt, int nin, int ncols, hipStream_t st) {

@@ -56,6 +56,8 @@ struct BsParams {
     uint16_t* get;
     float* ws;               // per-workgroup slabs [grid][64*256 + 64]
     int B, N, M, Npad, NPW, DPW;
+    int y_ld, w_ld, accum;           // row strides (elements) of gz / argmax and of W; accum: gx and getype are ADDED to (the 64 -> 128
+                                     // calls run as two launches over the halves of the output channels: y_ld = 128, w_ld = 512)
     long long x_sb, et_sb, y_sb;     // elements
     int off_xs, off_pd, off_ga, off_z, off_es, off_tab, off_idx, off_red, off_gst;      // byte offsets into LDS
     int zbytes;              // bytes of one wave's detype image
@@ -72,6 +74,8 @@ extern __shared__ __attribute__((aligned(16))) unsigned char bs_lds[];
 
 void fgnn_launch_slab_reduce(const float* ws, int nslab, int64_t slab_len, int64_t nw, float* gW, float* gbias,
                              hipStream_t st);
+void fgnn_launch_slab_reduce_ld(const float* ws, int nslab, int64_t slab_len, int64_t nw, int ncols, int ld, float* gW,
+                                float* gbias, hipStream_t st);
 
 // uniform 64-bit base + UNSIGNED 32-bit per-lane byte offset: the form the compiler turns into `global_load v, v_off, s[base]`
 // (a signed or 64-bit per-lane offset becomes a per-lane 64-bit pointer: two VGPRs each, hoisted out of the sample loop)
@@ -199,10 +203,10 @@ __global__ __launch_bounds__(BS_THREADS, 4) void mpconv_bwd_sg_kernel(const BsPa
     {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            const float* wp = p.W + (int64_t)(32 * ks + 8 * lk) * NCOLS + wave * 16 + li;
+            const float* wp = p.W + (int64_t)(32 * ks + 8 * lk) * p.w_ld + wave * 16 + li;
             alignas(16) float w8[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) w8[u] = wp[(int64_t)u * NCOLS];
+            for (int u = 0; u < 8; ++u) w8[u] = wp[(int64_t)u * p.w_ld];
             aP[ks] = bs_frag_f32(w8);
         }
     }
@@ -220,7 +224,7 @@ __global__ __launch_bounds__(BS_THREADS, 4) void mpconv_bwd_sg_kernel(const BsPa
     } else {
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks)
-            R[ks] = __builtin_bit_cast(f32x4, bs_frag_f32(p.W + (int64_t)(ct * 16 + li) * NCOLS + 32 * ks + 8 * lk));
+            R[ks] = __builtin_bit_cast(f32x4, bs_frag_f32(p.W + (int64_t)(ct * 16 + li) * p.w_ld + 32 * ks + 8 * lk));
     }
     // A operand of the channel sums: row 0 adds the even k (first edge type of a pair), row 1 the odd k, other rows nothing
     bs_bf16x8 evod;
@@ -249,8 +253,9 @@ __global__ __launch_bounds__(BS_THREADS, 4) void mpconv_bwd_sg_kernel(const BsPa
         pg = make_uint4(0, 0, 0, 0);
         pa = make_uint2(0, 0);
         if (t < gitems) {
-            pg = *bs_at<uint4>(gzb, utid * 16u);
-            pa = *bs_at<uint2>(amb, utid * 8u);
+            const unsigned el = (utid >> 3) * (unsigned)p.y_ld + (utid & 7u) * 8u;      // row m = item >> 3, channels 8 (item & 7) ..
+            pg = *bs_at<uint4>(gzb, el * 2u);
+            pa = *bs_at<uint2>(amb, el);
         }
         pe = make_uint2(0, 0);
         if (lane < NPW * DEG) pe = *bs_at<uint2>(p.et + (int64_t)b * p.et_sb, (unsigned)et_goff * 2u);
@@ -417,8 +422,20 @@ __global__ __launch_bounds__(BS_THREADS, 4) void mpconv_bwd_sg_kernel(const BsPa
             const unsigned char* gsrc = bs_lds + p.off_gst;
             unsigned char* gdst = reinterpret_cast<unsigned char*>(p.get + (int64_t)b * 4 * mk);
             const int nbytes = 8 * mk, nvec = ((uintptr_t)gdst & 15) ? 0 : nbytes >> 4;
-            if (t < nvec) *bs_at<uint4>(gdst, (unsigned)t * 16u) = *reinterpret_cast<const uint4*>(gsrc + t * 16);
-            for (int f = nvec * 8 + t; f < 4 * mk; f += BS_THREADS) *bs_at<uint16_t>(gdst, (unsigned)f * 2u) = *reinterpret_cast<const uint16_t*>(gsrc + f * 2);
+            if (t < nvec) {
+                uint4 v = *reinterpret_cast<const uint4*>(gsrc + t * 16);
+                if (p.accum) {                         // second launch of a split call: add to what the first one stored
+                    const uint4 o = *bs_at<uint4>(gdst, (unsigned)t * 16u);
+                    v = make_uint4(bs_pack2(bs_lo(v.x) + bs_lo(o.x), bs_hi(v.x) + bs_hi(o.x)), bs_pack2(bs_lo(v.y) + bs_lo(o.y), bs_hi(v.y) + bs_hi(o.y)),
+                                   bs_pack2(bs_lo(v.z) + bs_lo(o.z), bs_hi(v.z) + bs_hi(o.z)), bs_pack2(bs_lo(v.w) + bs_lo(o.w), bs_hi(v.w) + bs_hi(o.w)));
+                }
+                *bs_at<uint4>(gdst, (unsigned)t * 16u) = v;
+            }
+            for (int f = nvec * 8 + t; f < 4 * mk; f += BS_THREADS) {
+                uint16_t v = *reinterpret_cast<const uint16_t*>(gsrc + f * 2);
+                if (p.accum) v = (uint16_t)(bs_pack2(bs_lo(v) + bs_lo(*bs_at<uint16_t>(gdst, (unsigned)f * 2u)), 0.f) & 0xffffu);
+                *bs_at<uint16_t>(gdst, (unsigned)f * 2u) = v;
+            }
         }
 
         // ---- dP: wave owns source nodes n0 .. n0 + NPW - 1, lane = channel.  For one node dP[n][o][e] = sum_q et_q[e] gzm_q[o] over its
@@ -468,6 +485,13 @@ __global__ __launch_bounds__(BS_THREADS, 4) void mpconv_bwd_sg_kernel(const BsPa
         if (!dw_wave) {
             // ---- dx^T tiles: D[i = c][j = n] = W[c][:] . dP[n][:], channel tile ct, node tiles ((wave - 8) >> 2) + 2 i ----
             uint16_t* gxb = p.gx + (int64_t)b * p.x_sb;
+            uint2 old[3];                             // second launch of a split call: what the first one stored, fetched ahead of the products
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const int n = (((wave - 8) >> 2) + 2 * i) * 16 + li;
+                old[i] = make_uint2(0u, 0u);
+                if (p.accum && n < N) old[i] = *bs_at<uint2>(gxb, (unsigned)(n * NIN + ct * 16 + 4 * lk) * 2u);
+            }
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
                 const int nt = ((wave - 8) >> 2) + 2 * i;
@@ -482,7 +506,8 @@ __global__ __launch_bounds__(BS_THREADS, 4) void mpconv_bwd_sg_kernel(const BsPa
                     const int n = nt * 16 + li;
                     if (n < N)
                         *bs_at<uint2>(gxb, (unsigned)(n * NIN + ct * 16 + 4 * lk) * 2u) =
-                            make_uint2(bs_pack2(acc[0], acc[1]), bs_pack2(acc[2], acc[3]));
+                            make_uint2(bs_pack2(acc[0] + bs_lo(old[i].x), acc[1] + bs_hi(old[i].x)),
+                                       bs_pack2(acc[2] + bs_lo(old[i].y), acc[3] + bs_hi(old[i].y)));
                 }
             }
         } else {
@@ -567,7 +592,12 @@ int fgnn_mpconv_backward_sg(const fgnn_mpconv_desc* d, const void* x, const int6
     static const bool off = getenv("FGNN_NO_SG") != nullptr;
     if (off) BS_REJECT(0);
     if (d->dtype != FGNN_BF16 || d->ext != FGNN_EXT_NONE || d->agg != FGNN_AGG_MAX || d->net != 4) BS_REJECT(1);
-    if (d->nin != 64 || d->nou != 64) BS_REJECT(2);
+    // 64 -> 128: the output channels are independent and every gradient is a sum over them, so the call runs as TWO launches
+    // of this 64 -> 64 kernel over the halves of gz / argmax / W's columns; the second one ADDS to gx and getype (one more bf16
+    // rounding of those two) and its dW / dbias land in the upper halves of gfilters' columns / gbias.
+    static const bool no_split = getenv("FGNN_SG_NOSPLIT") != nullptr;
+    const bool split = d->nin == 64 && d->nou == 128 && !no_split;
+    if (d->nin != 64 || (d->nou != 64 && !split)) BS_REJECT(2);
     if (d->k != 3 && d->k != 6) BS_REJECT(3);
     if (d->idx_sb != 0 && d->B > 1) BS_REJECT(4);
     if (!(d->idx_sk == 1 && d->idx_sm == d->k)) BS_REJECT(5);
@@ -581,7 +611,7 @@ int fgnn_mpconv_backward_sg(const fgnn_mpconv_desc* d, const void* x, const int6
     if (!(d->et_se == 1 && d->et_sk == 4 && (d->et_sm == 4 * d->k || d->M == 1) && d->et_sb % 4 == 0)) BS_REJECT(11);
     if (((uintptr_t)x & 15) || ((uintptr_t)gz & 15) || ((uintptr_t)etype & 7) || ((uintptr_t)argmax & 7) ||
         ((uintptr_t)gx & 7)) BS_REJECT(12);
-    const int64_t nw = (int64_t)d->nin * d->nou * 4, slab_len = nw + d->nou;
+    const int64_t nw = (int64_t)d->nin * 64 * 4, slab_len = nw + 64;                  // of ONE launch (64 output channels)
     if (!workspace || workspace_bytes < 256 * slab_len * 4) BS_REJECT(13);
     const int NPW = (d->N + BS_WAVES - 1) / BS_WAVES, DPW = (d->M + BS_WAVES - 1) / BS_WAVES;
     void* fn = nullptr;
@@ -597,6 +627,7 @@ int fgnn_mpconv_backward_sg(const fgnn_mpconv_desc* d, const void* x, const int6
     p.B = d->B; p.N = d->N; p.M = d->M; p.Npad = fgnn_round_up(d->N, 32);
     p.NPW = KC == 6 ? 6 : 3; p.DPW = KC == 6 ? 3 : 6;
     p.x_sb = d->x_sb; p.et_sb = d->et_sb; p.y_sb = d->y_sb;
+    p.y_ld = d->nou; p.w_ld = d->nou * 4; p.accum = 0;
     int off_b = 0;
     auto take = [&](int bytes) { const int o = off_b; off_b = fgnn_round_up(off_b + bytes, 16); return o; };
     p.off_xs = take(2 * p.Npad * BS_XSB);
@@ -618,7 +649,7 @@ int fgnn_mpconv_backward_sg(const fgnn_mpconv_desc* d, const void* x, const int6
     const int chunk = (d->B + grid - 1) / grid;
     grid = (d->B + chunk - 1) / chunk;
     hipStream_t st = (hipStream_t)stream;
-    fgnn_note_kernel("mpconv_bwd_sg_kernel<%d, %d, %d, %d, %d>", KC, DEG, p.NPW, p.DPW, GSL);
+    fgnn_note_kernel(split ? "mpconv_bwd_sg_kernel<%d, %d, %d, %d, %d> x2" : "mpconv_bwd_sg_kernel<%d, %d, %d, %d, %d>", KC, DEG, p.NPW, p.DPW, GSL);
     p.prof = nullptr;
 #ifdef FGNN_ENABLE_PROF
     static long long* prof_buf = nullptr;
@@ -643,7 +674,15 @@ int fgnn_mpconv_backward_sg(const fgnn_mpconv_desc* d, const void* x, const int6
         }
     }
 #endif
-    fgnn_launch_slab_reduce(p.ws, grid, slab_len, nw, gfilters, gbias, st);
+    if (!split) fgnn_launch_slab_reduce(p.ws, grid, slab_len, nw, gfilters, gbias, st);
+    else {
+        // slab rows are 256 columns of gfilters' 512: lower half, then the second launch on the upper 64 output channels
+        fgnn_launch_slab_reduce_ld(p.ws, grid, slab_len, nw, 256, 512, gfilters, gbias, st);
+        p.W += 256; p.gz += 64; p.argmax += 64; p.accum = 1;
+        e = hipLaunchKernel(fn, dim3(grid), dim3(BS_THREADS), args, lds, st);
+        if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "mpconv sg backward launch (upper half): %s", hipGetErrorString(e));
+        fgnn_launch_slab_reduce_ld(p.ws, grid, slab_len, nw, 256, 512, gfilters + 256, gbias + 64, st);
+    }
     e = hipGetLastError();
     if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "mpconv backward helper launch: %s", hipGetErrorString(e));
     return 1;
