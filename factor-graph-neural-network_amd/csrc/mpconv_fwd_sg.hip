@@ -427,7 +427,12 @@ int fgnn_mpconv_forward_sg(const fgnn_mpconv_desc* d, const void* x, const int64
     // nn_idx: dense [M][k] per sample (or shared); etype: edge-type fastest [M][k][4], per sample, 4-byte aligned rows
     if (!(d->idx_sk == 1 && d->idx_sm == d->k)) return 0;
     if (!(d->et_se == 1 && d->et_sk == 4 && d->et_sm == 4 * d->k) || (d->et_sb % 2) != 0) return 0;
-    if (x && ((((uintptr_t)x) & 15) || (((uintptr_t)etype) & 3))) return 0;
+    if (x && ((((uintptr_t)x) & 15) || (((uintptr_t)etype) & 3))) {
+        // The plan call (x == NULL) announced THIS kernel's grid, and the caller sized / will finalise that many statistics rows:
+        // falling through to the first-generation kernel (another grid) would leave rows unwritten or overrun them, silently.
+        if (stats) FGNN_FAIL(FGNN_EINVAL, "mpconv forward with statistics: x must be 16-byte and etype 4-byte aligned (the partial rows were planned for the shared-graph kernel)");
+        return 0;
+    }
     int mode;
     if (stats || plan_grid) mode = SG_MODE_TRAIN_STATS;
     else if (!post_scale && !d->relu) mode = SG_MODE_TRAIN;

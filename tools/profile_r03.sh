@@ -24,4 +24,10 @@ python bench.py > $O/bench_default.json 2> $O/bench_default.err
 python bench.py --dtype f32 --no-cpu-baseline > $O/bench_f32.json 2> /dev/null
 python bench.py --tables per_sample --no-cpu-baseline > $O/bench_per_sample.json 2> /dev/null
 python bench.py --mode fwd --no-cpu-baseline > $O/bench_fwd.json 2> /dev/null
+# 5. wall-time attribution of one replayed training step (kernel trace -> tools/timeline.py) and the wide parity shapes
+sh tools/profile_timeline.sh r03/timeline > /dev/null 2>&1
+python tools/kbench.py --dtype bf16 --regular --stats --argmax --only "64->128" > $O/kbench_fwd_wide.log 2>&1
+FGNN_SG_NOSPLIT=1 python tools/kbench.py --dtype bf16 --regular --stats --argmax --only "64->128" >> $O/kbench_fwd_wide.log 2>&1
+FGNN_SG_NOSPLIT=1 python tools/kbench.py --dtype bf16 --regular --bwd --only "64->128" > $O/kbench_bwd_wide_first_generation.log 2>&1
+python tools/wbench.py --bf16 > $O/wbench.log 2>&1
 ls -la $O

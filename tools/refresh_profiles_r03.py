@@ -101,9 +101,13 @@ def main():
                                                .replace(', ', '_')), 'w'), indent=1)
                 traffic['kernels'][sym] = {k: s[k] for k in ('traffic_bytes_per_launch', 'mfma_busy') if k in s}
     json.dump(traffic, open(os.path.join(DST, 'pmc_traffic.json'), 'w'), indent=1)
-    for f in ('bench_default.json', 'bench_f32.json', 'bench_per_sample.json', 'bench_fwd.json', 'tbench.log', 'kbench_fwd.log', 'kbench_bwd.log'):
+    for f in ('bench_default.json', 'bench_f32.json', 'bench_per_sample.json', 'bench_fwd.json', 'tbench.log', 'kbench_fwd.log', 'kbench_bwd.log', 'kbench_fwd_wide.log',
+              'kbench_bwd_wide_first_generation.log', 'wbench.log'):
         if os.path.exists(os.path.join(SRC, f)):
             shutil.copy(os.path.join(SRC, f), os.path.join(DST, f))
+    for f in ('timeline.txt', 'timeline.json'):
+        if os.path.exists(os.path.join(SRC, 'timeline', f)):
+            shutil.copy(os.path.join(SRC, 'timeline', f), os.path.join(DST, 'train_step_' + f))
     print(json.dumps(traffic['kernels'], indent=1))
 
 
