@@ -38,6 +38,7 @@ class _EdgeMLPFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy):
         from . import ops
+        ops.backward_node_begins()
         x, w1, b1, w2 = ctx.saved_tensors
         B, cin, M, k = x.shape
         net = w2.shape[0]

@@ -86,6 +86,27 @@ def _is_identity_list(nn_idx):
 FUSE_TRAIN_TAIL = True       # training: BatchNorm2 + ReLU -> conv2 -> BatchNorm3 + LeakyReLU (+ addends) without storing conv2's output
 
 
+ROUTE_ADDEND_GRADS = True    # the addends' gradient leaves through its own autograd node, ahead of the tail's backward kernels
+
+
+class _AddendRoute(torch.autograd.Function):
+    """`out` already holds `+ addends` (the tail's apply kernel added them); this node only gives the sum its autograd
+    edges.  The addends' gradient is the output's gradient unchanged, so it should not wait for the tail's backward KERNELS:
+    as outputs of `_BlockTail.backward` the producers of the addends — FactorNN's side-stream branch: the variables' node-wise
+    map and the hyper-factor's messages — could start their backward only after the main stream's tail backward (~0.2 ms
+    per layer, which the main stream then spent waiting for that branch at the layer's gradient sum: 1.6 ms of a step,
+    profiles/r03/README.md).  No kernel runs here."""
+
+    @staticmethod
+    def forward(ctx, out, *adds):
+        ctx.n = len(adds)
+        return out.view_as(out)
+
+    @staticmethod
+    def backward(ctx, g):
+        return (g,) + (g,) * ctx.n
+
+
 class _BlockTail(torch.autograd.Function):
     """Everything behind the message operator in a training-mode ``mp_conv_residual`` (mp_nn.py:165-175 BatchNorm + ReLU,
     mp_nn_residual.py:31-35,49-51 conv2 + BatchNorm + LeakyReLU, + the caller's addends) through csrc/block_tail.hip: the
@@ -131,7 +152,7 @@ class _BlockTail(torch.autograd.Function):
         pointwise.note_state_change()                   # running statistics / num_batches_tracked were just updated in place
         ctx.save_for_backward(e, a2, st2, st3, w2, b2, W2, w3)
         ctx.slopes = (slope2, slope3)
-        ctx.has_add = tuple(a is not None for a in adds)
+        ctx.has_add = tuple(a is not None and a.requires_grad for a in adds)
         ctx.has_bias2 = bias2 is not None
         ctx.params = (w2, b2, W2, bias2, w3, b3)
         return out
@@ -139,6 +160,7 @@ class _BlockTail(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gout):
         from .. import _hip
+        ops.backward_node_begins()
         L = _hip.lib()
         P = _hip._ptr
         e, a2, st2, st3, w2, b2, W2, w3 = ctx.saved_tensors
@@ -179,10 +201,17 @@ class _BlockTail(torch.autograd.Function):
         ops.timed('bn_backward (finalise + apply)', 3 * e.numel() * 2, lambda: _hip.check(L.fgnn_bn_backward_partials(
             P(e), P(ga2), P(ge), R, 64, _hip.BF16, P(st2[0]), P(st2[1]), P(w2.detach()), P(b2.detach()), slope2, P(gw2), P(gb2),
             P(part2), np2, P(dsum2), _hip.stream_ptr())))
-        # conv2's weight / bias gradient: gz3^T a2 over the R rows (csrc/linear_wgrad_b16.hip)
-        ops.timed('linear_wgrad_b16_kernel', 2 * R * (64 + Cout), lambda: _hip.check(L.fgnn_linear_wgrad(
-            P(a2), P(gz3), R, 64, Cout, _hip.BF16, P(gW2.view(Cout, 64)), P(gbias2), P(ws), ws.numel() * 4, _hip.stream_ptr())),
-            nflops=2 * R * 64 * Cout)
+        # conv2's weight / bias gradient: gz3^T a2 over the R rows (csrc/linear_wgrad_b16.hip); parked when it goes to the flat
+        # bucket (ops.defer_wgrad: nothing in the backward reads it)
+        def launch(a2=a2, gz3=gz3, gW2=gW2, gbias2=gbias2):
+            wsw = ops._workspace(dev, int(L.fgnn_linear_wgrad_workspace_bytes(R, 64, Cout)))
+            ops.timed('linear_wgrad_b16_kernel', 2 * R * (64 + Cout), lambda: _hip.check(L.fgnn_linear_wgrad(
+                P(a2), P(gz3), R, 64, Cout, _hip.BF16, P(gW2.view(Cout, 64)), P(gbias2), P(wsw), wsw.numel() * 4, _hip.stream_ptr())),
+                nflops=2 * R * 64 * Cout)
+        if s_W2 and s_bias2:
+            ops.defer_wgrad(launch, (a2, gz3))
+        else:
+            launch()
         ha = ctx.has_add
         return (ge, None if s_w2 else gw2, None if s_b2 else gb2, None, None, None, None, None, None,
                 None if s_W2 else gW2.view(pW2.shape).to(pW2.dtype), None if (s_bias2 or gbias2 is None) else gbias2,
@@ -371,7 +400,11 @@ class mp_conv_residual(base_mp_nn):
             if ar.dtype != rows.dtype or not ar.is_contiguous():
                 ar = ar.to(rows.dtype).contiguous()
             arows[i] = ar.view(B * M, Cout)
+        route = ROUTE_ADDEND_GRADS and torch.is_grad_enabled() and any(a is not None and a.requires_grad for a in arows)
         y = _BlockTail.apply(rows, bn2.weight, bn2.bias, 0.0, float(bn3.slope), bn2.momentum, bn2.eps, bn3.momentum, bn3.eps,
                              conv2.weight.view(Cout, 64), conv2.bias, bn3.weight, bn3.bias, bn2.running_mean, bn2.running_var,
-                             bn2.num_batches_tracked, bn3.running_mean, bn3.running_var, bn3.num_batches_tracked, *arows)
+                             bn2.num_batches_tracked, bn3.running_mean, bn3.running_var, bn3.num_batches_tracked,
+                             *[(a.detach() if (route and a is not None) else a) for a in arows])
+        if route:
+            y = _AddendRoute.apply(y, *[a for a in arows if a is not None])
         return y.view(B, M, 1, Cout).permute(0, 3, 1, 2)

@@ -192,6 +192,7 @@ class _RowLinear(torch.autograd.Function):
     def backward(ctx, gy):
         rows, weight = ctx.saved_tensors
         from .. import ops
+        ops.backward_node_begins()
         gy = gy.contiguous()
         if gy.dtype != rows.dtype:
             gy = gy.to(rows.dtype)
@@ -219,13 +220,20 @@ class _RowLinear(torch.autograd.Function):
         gb = None
         if ctx.has_bias:
             gb = gb_sink if gb_sink is not None else torch.zeros((cout,), device=rows.device, dtype=torch.float32)
-        ws = ops._workspace(rows.device, int(L.fgnn_linear_wgrad_workspace_bytes(R, cin, cout)))
-        ops.timed('linear_wgrad_b16_kernel' if rows.dtype == torch.bfloat16 else 'linear_wgrad_kernel',
-                  rows.element_size() * R * (cin + cout),
-                  lambda: _hip.check(L.fgnn_linear_wgrad(_hip._ptr(rows), _hip._ptr(gy), R, cin, cout,
-                                                         _hip.dtype_code(rows), _hip._ptr(gw), _hip._ptr(gb),
-                                                         _hip._ptr(ws), ws.numel() * 4, _hip.stream_ptr())),
-                  nflops=2 * R * cin * cout)
+        def launch(rows=rows, gy=gy, gw=gw, gb=gb):      # (the closure keeps rows / gy alive until the kernel is issued)
+            ws = ops._workspace(rows.device, int(L.fgnn_linear_wgrad_workspace_bytes(R, cin, cout)))
+            ops.timed('linear_wgrad_b16_kernel' if rows.dtype == torch.bfloat16 else 'linear_wgrad_kernel',
+                      rows.element_size() * R * (cin + cout),
+                      lambda: _hip.check(L.fgnn_linear_wgrad(_hip._ptr(rows), _hip._ptr(gy), R, cin, cout,
+                                                             _hip.dtype_code(rows), _hip._ptr(gw), _hip._ptr(gb),
+                                                             _hip._ptr(ws), ws.numel() * 4, _hip.stream_ptr())),
+                      nflops=2 * R * cin * cout)
+        # nothing in the backward reads a weight gradient: with both gradients going to the flat bucket the kernel is parked
+        # and issued where its stream would otherwise wait for the other one (ops.defer_wgrad)
+        if gw_sink is not None and (gb is None or gb_sink is not None):
+            ops.defer_wgrad(launch, (rows, gy))
+        else:
+            launch()
         return (grows, None if gw_sink is not None else gw.to(weight.dtype),
                 None if (gb is None or gb_sink is not None) else gb.to(weight.dtype), None)
 
@@ -287,6 +295,8 @@ class _InstNormAct(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy):
         (rows,) = ctx.saved_tensors
+        from .. import ops
+        ops.backward_node_begins()
         B, N, _, C = rows.shape
         g = gy.permute(0, 2, 3, 1)
         if not g.is_contiguous() or g.dtype != rows.dtype:
@@ -382,6 +392,7 @@ class _BatchNormAct(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy):
         from .. import ops
+        ops.backward_node_begins()
         rows, weight, bias, stats = ctx.saved_tensors
         L = _hip.lib()
         R, C = rows.shape

@@ -78,6 +78,68 @@ def timed(symbol, nbytes, fn, nflops=0):
         TIMER.run(symbol, nbytes, nflops, fn, use_note=False)
 
 
+# ---- deferred weight-gradient kernels -------------------------------------------------------------------------------------
+# Nothing in a backward pass READS a weight gradient: the kernels that produce them (2.6 ms of a 18.8 ms LDPC step) only have to be
+# done before the optimizer.  FactorNN's two streams spend the backward waiting for each other at every layer's joins (the
+# main stream 3.5 ms, the side stream 7 ms of a step: profiles/r03/train_step_timeline.txt), so a weight-gradient kernel that sits
+# in stream order IN FRONT of a kernel the other stream waits for is on the critical path for nothing.  With DEFER_WGRAD the
+# launches are parked per stream and issued when the autograd engine moves on to a node of ANOTHER stream — i.e. right behind the
+# stream's last critical kernel, into the slot where it would otherwise idle until the join — and at the latest when the
+# backward pass ends (an engine callback, which also joins every such stream into the caller's).  Only gradients that go to
+# a sink (ops.grad_sink: the flat bucket) are deferred: a gradient tensor handed back to autograd must be complete in stream order.
+DEFER_WGRAD = os.environ.get('FGNN_NO_DEFER_WGRAD') is None       # (the variable: an A/B switch for tools / bench runs)
+_DEFERRED = {}              # stream -> [(launch closure, operands)]
+_DEFER_CALLBACK = [False]
+_DEFER_ISSUED = set()       # streams that got parked launches issued during the current backward pass
+
+
+def defer_wgrad(launch, operands=()):
+    """Park `launch` (a closure that enqueues one weight-gradient kernel on the CURRENT stream).  `operands`: the tensors the
+    kernel reads.  They are kept alive until the kernel is issued and then marked as in use by its stream: an activation the
+    OTHER stream allocated is otherwise handed back to that stream's allocator the moment the last reference drops — the
+    engine's join with this stream happened before the parked kernel went out, so nothing else orders the reuse behind it
+    (found as three weight gradients of hyper-factor maps reading overwritten rows on hipGraph replay)."""
+    if not DEFER_WGRAD:
+        launch()
+        return
+    st = torch.cuda.current_stream()
+    _DEFERRED.setdefault(st, []).append((launch, tuple(operands)))
+    if not _DEFER_CALLBACK[0]:
+        _DEFER_CALLBACK[0] = True
+        torch.autograd.Variable._execution_engine.queue_callback(_flush_at_end_of_backward)
+
+
+def flush_deferred(except_stream=None):
+    """Issue the parked launches of every stream but `except_stream`, each on its own stream."""
+    for st, lst in _DEFERRED.items():
+        if not lst or st == except_stream:
+            continue
+        with torch.cuda.stream(st):
+            for fn, operands in lst:
+                fn()
+                for t in operands:
+                    t.record_stream(st)
+        lst.clear()
+        _DEFER_ISSUED.add(st)
+
+
+def _flush_at_end_of_backward():
+    _DEFER_CALLBACK[0] = False
+    flush_deferred()
+    cur = torch.cuda.current_stream()
+    for st in _DEFER_ISSUED:    # the engine joined its streams BEFORE this callback: what was issued since needs its own join
+        if st != cur:
+            cur.wait_stream(st)
+    _DEFER_ISSUED.clear()
+
+
+def backward_node_begins():
+    """Called at the top of every hand-written backward: the engine has moved to a node on the current stream, so the other
+    streams' parked weight-gradient launches go out now (behind their last critical kernel)."""
+    if _DEFER_CALLBACK[0]:
+        flush_deferred(except_stream=torch.cuda.current_stream())
+
+
 def _require_device(*tensors):
     for t in tensors:
         if t is not None and not t.is_cuda:
@@ -309,6 +371,7 @@ class _MPConv(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gz):
+        backward_node_begins()
         x, nn_idx, etype, filters, amax = ctx.saved_tensors
         nou, net, ext, agg = ctx.cfg
         L = _hip.lib()
@@ -449,6 +512,7 @@ class _FanOut(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *grads):
+        backward_node_begins()
         grads = [g for g in grads if g is not None]
         return (sum_tensors(grads) if grads else None), None
 

@@ -77,6 +77,31 @@ def main():
     for n, v in attr.most_common(a.top):
         print('%-72s %5d %9.3f %9.3f %9.3f' % (n, cnt[n], v / 1e6, dur[n] / 1e6, gap_before[n] / 1e6))
     print('total attributed %.3f ms + idle %.3f ms = wall %.3f ms' % (sum(attr.values()) / 1e6, conc[0] / 1e6, wall / 1e6))
+    # cross-stream waits: for every queue, the time it sits idle while ANOTHER queue runs a kernel, charged to the kernel it starts
+    # next (the consumer of the join)
+    waits = {}
+    for q in sorted(set((r[3], r[4]) for r in win)):
+        mine = [r for r in win if (r[3], r[4]) == q]
+        other = sorted((r[0], r[1]) for r in win if (r[3], r[4]) != q)
+        by, tot, last, oi = collections.Counter(), 0, t0, 0
+        for s_, e_, n_, _, _ in mine:
+            if s_ > last:
+                busy = 0
+                for os_, oe_ in other:
+                    if oe_ <= last:
+                        continue
+                    if os_ >= s_:
+                        break
+                    busy += min(oe_, s_) - max(os_, last)
+                by[short(n_)] += busy
+                tot += busy
+            last = max(last, e_)
+        waits['%s/%s' % q] = {'kernels': len(mine), 'waiting_while_other_busy_ms': tot / 1e6,
+                              'resumes_with': {n: v / 1e6 for n, v in by.most_common(10)}}
+        print('queue %s/%s: %d kernels, idle while the other queue is busy %.3f ms; it resumes with:' % (q[0], q[1], len(mine), tot / 1e6))
+        for n, v in by.most_common(10):
+            print('    %-70s %.3f ms' % (n, v / 1e6))
+    out['cross_stream_waits'] = waits
     if a.json:
         out['kernels'] = {n: {'n': cnt[n], 'attr_ms': attr[n] / 1e6, 'sum_ms': dur[n] / 1e6, 'gap_before_ms': gap_before[n] / 1e6} for n in dur}
         json.dump(out, open(a.json, 'w'), indent=1)
