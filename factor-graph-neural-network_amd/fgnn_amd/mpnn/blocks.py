@@ -5,6 +5,8 @@ Mirrors (names, constructor signatures, state_dict keys) of
   iid_mapping / _bn / _in            /root/reference/lib/model/mpnn/base_model.py:43-90
   max_pool_layer, flatten            /root/reference/lib/model/mpnn/base_model.py:19-40
 """
+import os
+
 import torch
 
 from .message_op import base_mp_nn, mp_conv_type, mp_conv_v2
@@ -86,6 +88,7 @@ def _is_identity_list(nn_idx):
 FUSE_TRAIN_TAIL = True       # training: BatchNorm2 + ReLU -> conv2 -> BatchNorm3 + LeakyReLU (+ addends) without storing conv2's output
 
 
+LATE_JOIN = os.environ.get('FGNN_EARLY_JOIN') is None     # the tail asks for addends of another stream behind its statistics pass
 ROUTE_ADDEND_GRADS = True    # the addends' gradient leaves through its own autograd node, ahead of the tail's backward kernels
 
 
@@ -144,6 +147,8 @@ class _BlockTail(torch.autograd.Function):
                                               P(rv3), momentum3, eps3, P(st3[0]), P(st3[1]), P(st3[2]), P(st3[3]), P(nbt3),
                                               _hip.stream_ptr()))
         out = torch.empty((R, Cout), device=dev, dtype=e.dtype)
+        if callable(add0):          # the addends come from another stream: asked for (and waited on) only HERE, behind the statistics
+            add0, add1, add2 = add0()   # pass, which does not read them (the join used to sit in front of it)
         adds = (add0, add1, add2)
         nadd = sum(a is not None for a in adds)
         ops.timed('block_tail_apply_kernel', 2 * R * (2 * 64 + (1 + nadd) * Cout), lambda: _hip.check(L.fgnn_block_tail_apply(
@@ -388,23 +393,36 @@ class mp_conv_residual(base_mp_nn):
             take_pending_stats(rows)                        # (drop them: they describe another buffer)
             rows = rows.contiguous()
         rows = rows.view(B * M, 64)
-        if callable(addend):            # produced on another stream: asked for (and waited on) only where it is consumed
-            addend = addend()
-        addends = as_addends(addend)
-        if len(addends) > 3:
-            addends = addends[:2] + [ops.add_n(addends[2:])]
         Cout = conv2.out_channels
-        arows = [None, None, None]
-        for i, a in enumerate(addends):
-            ar = a.permute(0, 2, 3, 1)
-            if ar.dtype != rows.dtype or not ar.is_contiguous():
-                ar = ar.to(rows.dtype).contiguous()
-            arows[i] = ar.view(B * M, Cout)
-        route = ROUTE_ADDEND_GRADS and torch.is_grad_enabled() and any(a is not None and a.requires_grad for a in arows)
+        got = {}
+
+        def addend_rows():
+            """Evaluates the caller's addend (a callable joins the stream that produced it) and returns the three row views the
+            apply kernel reads; the differentiable tensors stay in `got` for the gradient route."""
+            with torch.enable_grad():
+                a = addend() if callable(addend) else addend
+                addends = as_addends(a)
+                if len(addends) > 3:
+                    addends = addends[:2] + [ops.add_n(addends[2:])]
+                arows = [None, None, None]
+                for i, t in enumerate(addends):
+                    ar = t.permute(0, 2, 3, 1)
+                    if ar.dtype != rows.dtype or not ar.is_contiguous():
+                        ar = ar.to(rows.dtype).contiguous()
+                    arows[i] = ar.view(B * M, Cout)
+            got['arows'] = arows
+            return arows
+
+        late = ROUTE_ADDEND_GRADS and LATE_JOIN and callable(addend) and torch.is_grad_enabled()
+        arows = None if late else addend_rows()
+        route = late or (ROUTE_ADDEND_GRADS and torch.is_grad_enabled() and any(a is not None and a.requires_grad for a in arows))
+        if late:
+            tail_adds = [lambda: [None if a is None else a.detach() for a in addend_rows()], None, None]
+        else:
+            tail_adds = [(a.detach() if (route and a is not None) else a) for a in arows]
         y = _BlockTail.apply(rows, bn2.weight, bn2.bias, 0.0, float(bn3.slope), bn2.momentum, bn2.eps, bn3.momentum, bn3.eps,
                              conv2.weight.view(Cout, 64), conv2.bias, bn3.weight, bn3.bias, bn2.running_mean, bn2.running_var,
-                             bn2.num_batches_tracked, bn3.running_mean, bn3.running_var, bn3.num_batches_tracked,
-                             *[(a.detach() if (route and a is not None) else a) for a in arows])
+                             bn2.num_batches_tracked, bn3.running_mean, bn3.running_var, bn3.num_batches_tracked, *tail_adds)
         if route:
-            y = _AddendRoute.apply(y, *[a for a in arows if a is not None])
+            y = _AddendRoute.apply(y, *[a for a in got['arows'] if a is not None])
         return y.view(B, M, 1, Cout).permute(0, 3, 1, 2)
