@@ -879,3 +879,41 @@ def test_one_kernel_factor_layer_vs_per_block_path_and_oracle(B, hyper_weights, 
     assert e1 <= 2.0 ** -5, e1
     assert H.rel_err(f1[0].cpu(), fo[0]) <= 2.0 ** -5
     assert H.rel_err(f1[1].cpu(), fo[1]) <= 2.0 ** -5
+
+
+def test_parked_weight_gradients_equal_inline_ones_bitwise(dev, monkeypatch):
+    """ops.defer_wgrad parks the weight-gradient kernels of a backward pass and issues them where their stream would wait for
+    the other one (at the latest from an engine callback when the pass ends).  Same kernels, same operands, another place in
+    stream order: the flat gradient must come out bit-identical to the inline schedule — eagerly, twice, and with the addends'
+    gradient routed through its own node or through the fused tail's backward."""
+    import fgnn_amd
+    from fgnn_amd import ops
+    from fgnn_amd.dp import FlatGradBucket
+    from fgnn_amd.ldpc import synthetic_batch
+    from fgnn_amd.mpnn import blocks
+    torch.manual_seed(7)
+    m = fgnn_amd.LDPCModel(2, 6, 4).to(dev).train()
+    bucket = FlatGradBucket(m.parameters(), flatten_params=True)
+    data = synthetic_batch(200, dev, seed=5, dtype=torch.bfloat16)
+    state = {k: v.clone() for k, v in m.state_dict().items()}
+
+    def grads():
+        m.load_state_dict(state)
+        bucket.zero()
+        with torch.autocast('cuda', dtype=torch.bfloat16):
+            logits, snr = m(*data[:6])
+        (torch.nn.functional.binary_cross_entropy_with_logits(logits.float(), data[6]) + 0.1 * snr.float().pow(2).mean()).backward()
+        torch.cuda.synchronize()
+        assert not any(lst for lst in ops._DEFERRED.values())                  # nothing is left parked after a backward pass
+        return bucket.flat.clone()
+
+    monkeypatch.setattr(ops, 'DEFER_WGRAD', False)
+    inline = grads()
+    assert float(inline.abs().max()) > 0
+    monkeypatch.setattr(ops, 'DEFER_WGRAD', True)
+    assert torch.equal(grads(), inline) and torch.equal(grads(), inline)
+    monkeypatch.setattr(blocks, 'ROUTE_ADDEND_GRADS', False)
+    assert torch.equal(grads(), inline)
+    monkeypatch.setattr(blocks, 'ROUTE_ADDEND_GRADS', True)
+    monkeypatch.setattr(blocks, 'LATE_JOIN', False)
+    assert torch.equal(grads(), inline)
