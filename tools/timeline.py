@@ -23,7 +23,11 @@ def main():
     ap.add_argument('csv')
     ap.add_argument('--marker', default='flat_adam')
     ap.add_argument('--top', type=int, default=40)
+    ap.add_argument('--marker-stride', type=int, default=1, help='launches of the marker kernel per step')
     ap.add_argument('--json', default=None)
+    ap.add_argument('--dump', default=None, help='kernel-name substring: list, per queue, what runs between consecutive launches of it')
+    ap.add_argument('--dump-from', type=int, default=0)
+    ap.add_argument('--dump-count', type=int, default=2)
     a = ap.parse_args()
     rows = []
     with open(a.csv) as f:
@@ -32,7 +36,8 @@ def main():
     rows.sort()
     marks = [r for r in rows if a.marker in r[2]]
     assert len(marks) >= 2, 'marker kernel not found twice'
-    t0, t1 = marks[-2][1], marks[-1][1]
+    assert len(marks) > a.marker_stride
+    t0, t1 = marks[-1 - a.marker_stride][1], marks[-1][1]
     win = [r for r in rows if r[0] >= t0 and r[1] <= t1]
     ev = []
     for i, (s, e, _, _, _) in enumerate(win):
@@ -102,6 +107,19 @@ def main():
         for n, v in by.most_common(10):
             print('    %-70s %.3f ms' % (n, v / 1e6))
     out['cross_stream_waits'] = waits
+    if a.dump:
+        hits = [r for r in win if a.dump in r[2]]
+        for k in range(a.dump_from, min(a.dump_from + a.dump_count, len(hits) - 1)):
+            w0, w1 = hits[k][0], hits[k + 1][1]
+            print('--- window %d: %.1f us, from %s to the next one' % (k, (w1 - w0) / 1e3, short(hits[k][2])))
+            for q in sorted(set((r[3], r[4]) for r in win)):
+                print('  queue %s/%s' % q)
+                last = w0
+                for s_, e_, n_, q3, q4 in win:
+                    if (q3, q4) != q or e_ < w0 or s_ > w1:
+                        continue
+                    print('    +%7.1f  %6.1f us  %s%s' % ((s_ - w0) / 1e3, (e_ - s_) / 1e3, short(n_), ('   [gap %.1f]' % ((s_ - last) / 1e3)) if s_ - last > 4000 else ''))
+                    last = e_
     if a.json:
         out['kernels'] = {n: {'n': cnt[n], 'attr_ms': attr[n] / 1e6, 'sum_ms': dur[n] / 1e6, 'gap_before_ms': gap_before[n] / 1e6} for n in dur}
         json.dump(out, open(a.json, 'w'), indent=1)
