@@ -9,5 +9,5 @@ cd $R
 rm -rf /tmp/tlf
 timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/tlf -o tl -- python bench.py --steps 6 --warmup 2 --mode fwd --no-cpu-baseline > $O/bench.log 2>&1
 T=$(find /tmp/tlf -name "*kernel_trace.csv" | head -1)
-python tools/timeline.py $T --marker edge_mlp_fwd --marker-stride 2 --json $O/timeline.json > $O/timeline.txt 2>&1
+python tools/timeline.py $T --marker edge_mlp_fwd --marker-stride 2 --marker-skip ${2:-4} --json $O/timeline.json > $O/timeline.txt 2>&1
 cat $O/timeline.txt | head -70

@@ -24,6 +24,7 @@ def main():
     ap.add_argument('--marker', default='flat_adam')
     ap.add_argument('--top', type=int, default=40)
     ap.add_argument('--marker-stride', type=int, default=1, help='launches of the marker kernel per step')
+    ap.add_argument('--marker-skip', type=int, default=0, help='ignore the last N launches of the marker kernel (e.g. eager steps behind the replayed ones)')
     ap.add_argument('--json', default=None)
     ap.add_argument('--dump', default=None, help='kernel-name substring: list, per queue, what runs between consecutive launches of it')
     ap.add_argument('--dump-from', type=int, default=0)
@@ -36,6 +37,8 @@ def main():
     rows.sort()
     marks = [r for r in rows if a.marker in r[2]]
     assert len(marks) >= 2, 'marker kernel not found twice'
+    if a.marker_skip:
+        marks = marks[:-a.marker_skip]
     assert len(marks) > a.marker_stride
     t0, t1 = marks[-1 - a.marker_stride][1], marks[-1][1]
     win = [r for r in rows if r[0] >= t0 and r[1] <= t1]
