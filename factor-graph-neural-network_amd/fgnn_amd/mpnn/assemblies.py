@@ -8,6 +8,7 @@ so the reference's train_*.py scripts construct and call them unchanged; every V
 message inside runs through the fused HIP operator.
 """
 import contextlib
+import os
 
 import torch
 
@@ -150,6 +151,9 @@ class factor_mpnn(torch.nn.Module):
         if self.final_filter is not None:
             nfeat = self.final_filter(nfeat, node_features)
         return nfeat, ffeat
+
+
+_V2V_MAIN = set(int(v) for v in os.environ.get('FGNN_V2V_MAIN', '').split(',') if v)      # (tuning: layers whose v2v map stays on the main stream)
 
 
 class FactorNN(torch.nn.Module):
@@ -346,7 +350,7 @@ class FactorNN(torch.nn.Module):
                     new_fac[j] = _call(self.v2f_modules[L][j], var_c[1 + j], nn_idx_v2f[j], etype_v2f[j][L],
                                        addend=[nf, fac_c[j][-1] if same_width else None, skip[1][j] if skip else None])
                     h.append(_call(self.f2v_modules[L][j], fac_c[j][1], nn_idx_f2v[j], etype_f2v[j][L]))
-            with (torch.cuda.stream(side) if two else contextlib.nullcontext()):
+            with (torch.cuda.stream(side) if (two and L not in _V2V_MAIN) else contextlib.nullcontext()):
                 new_var = self.v2v_modules[L](var_c[0])        # the variables' node-wise map rides with the side branch
             nf = self.f2f_modules[L][0](fac_c[0][0])
             new_fac[0] = _call(self.v2f_modules[L][0], var_c[1], nn_idx_v2f[0], etype_v2f[0][L],
