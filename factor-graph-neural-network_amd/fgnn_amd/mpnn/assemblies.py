@@ -153,7 +153,8 @@ class factor_mpnn(torch.nn.Module):
         return nfeat, ffeat
 
 
-_V2V_MAIN = set(int(v) for v in os.environ.get('FGNN_V2V_MAIN', '').split(',') if v)      # (tuning: layers whose v2v map stays on the main stream)
+_V2V_MAIN = set(int(v) for v in os.environ.get('FGNN_V2V_MAIN', '').split(',') if v)      # tuning knob: layers whose v2v map stays on the main
+# stream.  Measured on one box (18.25 ms with none): layers 0,1,7: 18.27; 2-6: 18.47; 3-5: 18.54; all: 18.48 — the map belongs on the side stream.
 
 
 class FactorNN(torch.nn.Module):
