@@ -41,12 +41,15 @@ def flatten_parameters(params):
 class FlatGradBucket:
     """Owns one contiguous gradient buffer; ``param.grad`` are views into it."""
 
-    def __init__(self, params, process_group=None, flatten_params=False):
+    def __init__(self, params, process_group=None, flatten_params=False, reduce_single_rank=False):
         """``flatten_params=True`` also moves the parameters themselves into one flat f32 buffer
         (``flat_param``; every ``p.data`` becomes a view of it) so that the optimizer is a handful of
         kernels over 5.5 MB instead of a multi-tensor sweep over ~330 tensors — see ``FlatAdam``."""
         self.params = [p for p in params if p.requires_grad]
         self.group = process_group
+        # a group of one rank skips the collective (the sum over one rank is the identity); reduce_single_rank issues it
+        # anyway — how a one-GPU box exercises the RCCL call itself (tests/test_dp_two_ranks_gpu.py)
+        self.reduce_single_rank = bool(reduce_single_rank)
         if not self.params:
             raise ValueError('no trainable parameters')
         dev, dt = self.params[0].device, torch.float32
@@ -72,13 +75,13 @@ class FlatGradBucket:
 
     def all_reduce_sum(self):
         """Sum over ranks, nothing else: the division by the world size rides in ``FlatAdam.step(grad_scale=1/world)``."""
-        if self.world > 1:
+        if self.world > 1 or (self.reduce_single_rank and dist.is_initialized()):
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
 
     def all_reduce_mean(self, async_op=False):
         """Sum over ranks then divide by world size (mean gradient of the global batch)."""
         w = self.world
-        if w == 1:
+        if w == 1 and not (self.reduce_single_rank and dist.is_initialized()):
             return None
         work = dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
         if async_op:

@@ -35,7 +35,7 @@ def _setup_paths():
             sys.path.insert(0, p)
 
 
-def _train(rank, world, graph):
+def _train(rank, world, graph, reduce_single_rank=False):
     """3 steps on this rank's shard; returns the flat parameter buffer (a CPU tensor)."""
     _setup_paths()
     import contextlib
@@ -60,7 +60,7 @@ def _train(rank, world, graph):
     lo, hi = shard_range(PER_RANK * 2, rank, world)
     inputs = tuple(t[lo:hi] for t in data[:6])
     label = data[6][lo:hi, :48].float().contiguous()
-    bucket = FlatGradBucket(model.parameters(), flatten_params=True)
+    bucket = FlatGradBucket(model.parameters(), flatten_params=True, reduce_single_rank=reduce_single_rank)
     opt = FlatAdam(bucket, lr=1e-3)
     amp = torch.autocast('cuda', dtype=torch.bfloat16)
 
@@ -134,3 +134,29 @@ def test_bench_self_launches_its_ranks(dev):
     d = out['config']['distributed']
     assert len(d['per_rank_ms_per_step']) == 2 and d['launched_by'] == 'bench.py self_launch' and d['backend'] == 'gloo'
     assert out['value'] > 0 and out['scaling'] == 'weak'
+
+
+def _worker_rccl(rank, world, port, out, graph):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    torch.cuda.set_device(0)
+    dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', 0))
+    assert dist.get_backend() == 'nccl'
+    flat, grad, p1 = _train(rank, world, graph, reduce_single_rank=True)      # the all-reduce IS issued, through RCCL
+    torch.save({'param': flat, 'grad': grad, 'param1': p1, 'rccl': list(torch.cuda.nccl.version())},
+               os.path.join(out, 'rccl_rank%d.pt' % rank))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('graph', [False, True], ids=['eager', 'hipgraph'])
+def test_rccl_backend_runs_the_flat_bucket_all_reduce(graph, tmp_path, dev):
+    """The collective of the data-parallel step through RCCL itself (backend "nccl"), as bench.py's ranks issue it — here a
+    group of ONE rank, which is what a one-GPU box can form (RCCL refuses two ranks on one device): communicator set-up on the
+    rank's device, the all-reduce of the 5.5 MB flat gradient next to hipGraph replays of the step, FlatAdam behind it.  With one
+    rank the reduction is the identity, so three steps must end on exactly the parameters of the plain single-process run."""
+    mp.spawn(_worker_rccl, args=(1, _free_port(), str(tmp_path), graph), nprocs=1, join=True)
+    a = torch.load(os.path.join(str(tmp_path), 'rccl_rank0.pt'))
+    assert len(a['rccl']) >= 2
+    ref_param, ref_grad, ref_p1 = _train(0, 1, graph)       # no process group at all
+    assert torch.equal(a['grad'], ref_grad) and torch.equal(a['param1'], ref_p1) and torch.equal(a['param'], ref_param)
