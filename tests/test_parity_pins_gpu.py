@@ -40,27 +40,32 @@ def _decision_agreement(a, b, margin):
     return float(((a > 0) == (b > 0))[firm].float().mean()), float(firm.float().mean())
 
 
-@pytest.mark.parametrize('mode', ['eval', 'eval_per_block_kernels', 'train'])
+@pytest.mark.parametrize('mode', ['eval', 'eval_per_block_kernels', 'train', 'train_benched_batch'])
 def test_benched_bf16_model_vs_f32_oracle(mode, dev):
     """The configuration bench.py measures — bf16 activations / messages / matrix cores, f32 parameters — against the
     f32 ORACLE (reference op order) on the same inputs and parameters.
     eval: the full 4096-codeword data-path batch runs on the GPU (one-kernel 64-wide layers, one-kernel inference blocks
     and all; `eval_per_block_kernels`: the same with the one-kernel layers switched off); 96 codewords picked from it are
     decoded by the oracle.  train: BatchNorm uses batch statistics, so the same 128 picked codewords
-    form the batch on both sides (and the oracle's updated running statistics are compared as well).
+    form the batch on both sides (and the oracle's updated running statistics are compared as well); `train_benched_batch`: the
+    same with ALL 4096 codewords as the batch on both sides — the batch bench.py times (the oracle's forward takes ~10 s of host
+    time there).
     Criterion: max |logit error| <= 2e-2 of the logit range; hard decisions agree on >= 99.9 % of
     the bits the oracle decides firmly (|logit| >= 2e-2 of the range)."""
     from fgnn_amd.mpnn import assemblies
     per_block = mode == 'eval_per_block_kernels'
     if per_block:
         mode = 'eval'
+    full = mode == 'train_benched_batch'
+    if full:
+        mode = 'train'
     m, dp = _trained_like_ldpc(dev)
     B = 4096
     data = dp.sample(B, seed=12, dtype=torch.bfloat16)[:6]
     data32 = dp.sample(B, seed=12, dtype=torch.float32)[:6]
     # the bf16 feature tensors are the f32 ones rounded once (same draws)
     assert H.rel_err(data[0].float(), data32[0]) <= 2.0 ** -8
-    npick = 96 if mode == 'eval' else 128
+    npick = 96 if mode == 'eval' else (B if full else 128)
     pick = torch.randperm(B, generator=torch.Generator().manual_seed(5))[:npick].to(dev)
     amp = torch.autocast('cuda', dtype=torch.bfloat16)
     sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
