@@ -89,7 +89,7 @@ def timed(symbol, nbytes, fn, nflops=0):
 # a sink (ops.grad_sink: the flat bucket) are deferred: a gradient tensor handed back to autograd must be complete in stream order.
 DEFER_WGRAD = os.environ.get('FGNN_NO_DEFER_WGRAD') is None       # (the variable: an A/B switch for tools / bench runs)
 _DEFERRED = {}              # stream -> [(launch closure, operands)]
-_DEFER_CALLBACK = [False]
+_DEFER_CALLBACK = [None]     # id of the backward pass (autograd graph task) whose end-of-pass callback is queued
 _DEFER_ISSUED = set()       # streams that got parked launches issued during the current backward pass
 
 
@@ -103,10 +103,17 @@ def defer_wgrad(launch, operands=()):
         launch()
         return
     st = torch.cuda.current_stream()
-    _DEFERRED.setdefault(st, []).append((launch, tuple(operands)))
-    if not _DEFER_CALLBACK[0]:
-        _DEFER_CALLBACK[0] = True
+    task = torch._C._current_graph_task_id()           # (-1 outside a backward pass: then nothing would ever issue the launch)
+    if task < 0:
+        launch()
+        return
+    if _DEFER_CALLBACK[0] != task:
+        for lst in _DEFERRED.values():      # a backward pass that died half-way left its launches parked: they belong to no pass
+            lst.clear()
+        _DEFER_ISSUED.clear()
+        _DEFER_CALLBACK[0] = task
         torch.autograd.Variable._execution_engine.queue_callback(_flush_at_end_of_backward)
+    _DEFERRED.setdefault(st, []).append((launch, tuple(operands)))
 
 
 def flush_deferred(except_stream=None):
@@ -124,7 +131,7 @@ def flush_deferred(except_stream=None):
 
 
 def _flush_at_end_of_backward():
-    _DEFER_CALLBACK[0] = False
+    _DEFER_CALLBACK[0] = None
     flush_deferred()
     cur = torch.cuda.current_stream()
     for st in _DEFER_ISSUED:    # the engine joined its streams BEFORE this callback: what was issued since needs its own join
@@ -136,7 +143,7 @@ def _flush_at_end_of_backward():
 def backward_node_begins():
     """Called at the top of every hand-written backward: the engine has moved to a node on the current stream, so the other
     streams' parked weight-gradient launches go out now (behind their last critical kernel)."""
-    if _DEFER_CALLBACK[0]:
+    if _DEFER_CALLBACK[0] is not None and _DEFER_CALLBACK[0] == torch._C._current_graph_task_id():
         flush_deferred(except_stream=torch.cuda.current_stream())
 
 

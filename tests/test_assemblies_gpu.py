@@ -917,3 +917,45 @@ def test_parked_weight_gradients_equal_inline_ones_bitwise(dev, monkeypatch):
     monkeypatch.setattr(blocks, 'ROUTE_ADDEND_GRADS', True)
     monkeypatch.setattr(blocks, 'LATE_JOIN', False)
     assert torch.equal(grads(), inline)
+
+
+def test_parked_launches_of_a_failed_backward_pass_are_dropped(dev):
+    """A backward pass that raises half-way never reaches the end-of-pass callback: what it parked must neither be issued by the
+    next pass nor keep that pass from queueing its own callback."""
+    import fgnn_amd
+    from fgnn_amd import ops
+    from fgnn_amd.dp import FlatGradBucket
+    from fgnn_amd.mpnn.pointwise import PointwiseConv2d
+
+    class Boom(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x):
+            return x.view_as(x)
+
+        @staticmethod
+        def backward(ctx, g):
+            raise RuntimeError('boom')
+
+    torch.manual_seed(3)
+    a, b = PointwiseConv2d(64, 64).to(dev), PointwiseConv2d(64, 64).to(dev)
+    bucket = FlatGradBucket(list(a.parameters()) + list(b.parameters()))
+    x = torch.randn(8, 64, 96, 1, device=dev).bfloat16().contiguous(memory_format=torch.channels_last)
+
+    def run(fail):
+        bucket.zero()
+        with torch.autocast('cuda', dtype=torch.bfloat16):
+            h = a(x)
+            if fail:
+                h = Boom.apply(h)
+            y = b(h)
+        y.float().sum().backward()
+        torch.cuda.synchronize()
+        return bucket.flat.clone()
+
+    good = run(False)
+    with pytest.raises(RuntimeError, match='boom'):
+        run(True)                                       # b's weight gradient was parked, then the pass died
+    assert any(lst for lst in ops._DEFERRED.values())
+    again = run(False)
+    assert torch.equal(again, good)                     # not doubled by the stale launch, and a's / b's own gradients are there
+    assert not any(lst for lst in ops._DEFERRED.values())
