@@ -565,3 +565,178 @@ extern "C" int fgnn_block_tail_backward(const void* e, const float* scale2, cons
     if (e2 != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "block_tail_backward launch: %s", hipGetErrorString(e2));
     return FGNN_OK;
 }
+
+// ----------------------------------------------------------------------------------------
+// HEAD of the block, backward (round 3): conv1 -> BatchNorm1 -> LeakyReLU in front of the operator
+// (/root/reference/lib/model/mpnn/mp_nn_residual.py:25-29,42-44).  Given z1 = conv1's output [R][64] and ga1 = the operator's
+// input gradient [R][64]:
+//     gz1 = kc g' + A z1 + B      BatchNorm1's input gradient in closed form per channel (kc = gamma invstd, g' = ga1 act'(pre),
+//                                 A = -kc invstd dgamma / R, B = kc (invstd mean dgamma - dbeta) / R)
+//     gx  = gz1 W1                conv1's input gradient, [R][Cin], Cin in {64, 128, 256}
+// in ONE pass: the staged path wrote gz1 (bn_apply_kernel<1>) and read it back in the input-gradient GEMM.  gz1 is still stored once
+// (the weight-gradient kernel reads it); the sums dbeta / dgamma come from the BatchNorm reduction pass in front of this kernel.
+// Same transposed product and lane <-> 16-consecutive-channels layout as above: the computed gz1 fragment IS the B operand.
+// ----------------------------------------------------------------------------------------
+struct BhParams {
+    const uint16_t* z;       // [R][64] bf16 conv1 output (BatchNorm1's input)
+    const uint16_t* g;       // [R][64] bf16 gradient of BatchNorm1's activated output
+    const float* mean; const float* invstd; const float* gamma; const float* beta;    // [64]
+    const float* dsum;       // [2][64] dbeta, dgamma
+    const float* W;          // [64][Cin] f32 conv1 weight
+    uint16_t* gz;            // [R][64] out
+    uint16_t* gx;            // [R][Cin] out
+    int R, Cin;
+    float slope, inv_r;
+};
+
+template <int CG>
+__global__ __launch_bounds__(BT_THREADS, 3) void block_head_bwd_kernel(const BhParams p) {
+    constexpr int CIN = 64 * CG;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lk = lane >> 4;
+    const int R = p.R;
+    uint4* Wf = reinterpret_cast<uint4*>(bt_lds);                                        // [CG][4 ot][2 ks][64]   gx^T = W1^T gz1^T
+    float* cst = reinterpret_cast<float*>(Wf + CG * 8 * 64);                             // [5][64]  s1, t1, kc, A, B
+    for (int f = tid; f < CG * 8 * 64; f += BT_THREADS) {
+        const int fl = f & 63, fs = (f >> 6) & 1, ft = (f >> 7) & 3, sl = f >> 9;
+        const int fi = fl & 15, fk = fl >> 4;
+        const int pr = 16 * (fi >> 2) + (fi & 3) + 4 * ft;
+        // A[i = input channel 64 sl + pr][k = BatchNorm channels 16 fk + 8 fs .. + 7] = W1[k][i]
+        const float* wp = p.W + (int64_t)(16 * fk + 8 * fs) * CIN + 64 * sl + pr;
+        float w[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) w[u] = wp[(int64_t)u * CIN];
+        Wf[f] = make_uint4(bt_pack2(w[0], w[1]), bt_pack2(w[2], w[3]), bt_pack2(w[4], w[5]), bt_pack2(w[6], w[7]));
+    }
+    if (tid < 64) {
+        const float m = p.mean[tid], is = p.invstd[tid], kc = p.gamma[tid] * is;
+        const float ke = p.dsum[tid] * p.inv_r, kf = p.dsum[64 + tid] * p.inv_r;
+        cst[tid] = kc;                                    // pre = z kc + (beta - mean kc)
+        cst[64 + tid] = p.beta[tid] - m * kc;
+        cst[128 + tid] = kc;
+        cst[192 + tid] = -kc * kf * is;                   // gz = kc (g' - ke - (z - m) is kf) = kc g' + A z + B
+        cst[256 + tid] = kc * (kf * is * m - ke);
+    }
+    __syncthreads();
+    const int cg = wave % CG, rg = wave / CG;
+    constexpr int NRG = BT_WAVES / CG;
+    uint4 aW[4][2];
+#pragma unroll
+    for (int ot = 0; ot < 4; ++ot) {
+        aW[ot][0] = Wf[((cg * 4 + ot) * 2 + 0) * 64 + lane];
+        aW[ot][1] = Wf[((cg * 4 + ot) * 2 + 1) * 64 + lane];
+    }
+    float s1[16], t1[16], ka[16], kb[16];                // (kc == s1)
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        s1[c] = cst[16 * lk + c]; t1[c] = cst[64 + 16 * lk + c]; ka[c] = cst[192 + 16 * lk + c]; kb[c] = cst[256 + 16 * lk + c];
+    }
+    const int ntile = (R + 15) / 16;
+    const int stride = gridDim.x * NRG;
+    const int first = blockIdx.x * NRG + rg;
+    const int mine = first < ntile ? (ntile - first + stride - 1) / stride : 0;
+    auto load2 = [&](int it, uint4 (&zq)[2], uint4 (&gq)[2]) {
+        const int row = min((first + it * stride) * 16 + li, R - 1);
+        const uint16_t* zp = p.z + (int64_t)row * 64 + 16 * lk;
+        const uint16_t* gp = p.g + (int64_t)row * 64 + 16 * lk;
+        zq[0] = *reinterpret_cast<const uint4*>(zp); zq[1] = *reinterpret_cast<const uint4*>(zp + 8);
+        gq[0] = *reinterpret_cast<const uint4*>(gp); gq[1] = *reinterpret_cast<const uint4*>(gp + 8);
+    };
+    // two tiles in flight per wave (a ring of two register slots, refilled right behind their last use; rows past the end are
+    // clamped, so the loads are unconditional and the loop body stays straight-line code)
+    constexpr int HD = 2;
+    uint4 rz[HD][2], rgq[HD][2];
+#pragma unroll
+    for (int d = 0; d < HD; ++d) { load2(d, rz[d], rgq[d]); __builtin_amdgcn_sched_barrier(0); }
+    for (int base = 0; base < mine; base += HD) {
+#pragma unroll
+      for (int d = 0; d < HD; ++d) {
+        const int it = base + d;
+        uint4 (&zq)[2] = rz[d];
+        uint4 (&gq)[2] = rgq[d];
+        const int row = (first + it * stride) * 16 + li;
+        const bool ok = it < mine && row < R;
+        bt_bf16x8 gzf[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            float z[8], g[8];
+            bt_unpack8(zq[ks], z);
+            bt_unpack8(gq[ks], g);
+            unsigned o[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                float v[2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int c = 8 * ks + 2 * u + h;
+                    const float pre = fmaf(z[2 * u + h], s1[c], t1[c]);
+                    const float ge = pre > 0.f ? g[2 * u + h] : g[2 * u + h] * p.slope;
+                    v[h] = fmaf(s1[c], ge, fmaf(ka[c], z[2 * u + h], kb[c]));
+                }
+                o[u] = bt_pack2(v[0], v[1]);
+            }
+            uint4 q = make_uint4(o[0], o[1], o[2], o[3]);
+            if (!ok) q = make_uint4(0, 0, 0, 0);
+            gzf[ks] = __builtin_bit_cast(bt_bf16x8, q);
+            if (ok && cg == 0) *reinterpret_cast<uint4*>(p.gz + (int64_t)row * 64 + 16 * lk + 8 * ks) = q;
+        }
+        load2(it + HD, rz[d], rgq[d]);
+        __builtin_amdgcn_sched_barrier(0);
+        f32x4 acc[4];
+#pragma unroll
+        for (int ot = 0; ot < 4; ++ot) {
+            acc[ot] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+                acc[ot] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bt_bf16x8, aW[ot][ks]), gzf[ks], acc[ot], 0, 0, 0);
+        }
+        if (ok) {     // acc[ot][r] = gx of input channel 64 cg + 16 lk + 4 ot + r, row li
+            uint16_t* op = p.gx + (int64_t)row * CIN + 64 * cg + 16 * lk;
+            *reinterpret_cast<uint4*>(op) = make_uint4(bt_pack2(acc[0][0], acc[0][1]), bt_pack2(acc[0][2], acc[0][3]),
+                                                      bt_pack2(acc[1][0], acc[1][1]), bt_pack2(acc[1][2], acc[1][3]));
+            *reinterpret_cast<uint4*>(op + 8) = make_uint4(bt_pack2(acc[2][0], acc[2][1]), bt_pack2(acc[2][2], acc[2][3]),
+                                                          bt_pack2(acc[3][0], acc[3][1]), bt_pack2(acc[3][2], acc[3][3]));
+        }
+      }
+    }
+}
+
+int fgnn_bn_backward_sums_bf16(const void* x, const void* gy, int64_t R, int C, const float* mean, const float* invstd,
+                               const float* gamma, const float* beta, float slope, float* gweight, float* gbias,
+                               void* workspace, hipStream_t st, const float** dsum_out);
+
+// BatchNorm1 + activation backward and conv1's input gradient (see above).  z1 / ga1 [R][64] bf16, W1 [64][Cin] f32 (Cin in
+// {64, 128, 256}), gz1 [R][64] and gx [R][Cin] bf16 out, gweight / gbias [64] ACCUMULATED into (BatchNorm1's parameter gradients).
+// workspace: fgnn_bn_workspace_bytes(R, 64).
+extern "C" int fgnn_block_head_backward(const void* z1, const void* ga1, const float* mean, const float* invstd,
+                                        const float* gamma, const float* beta, float slope, const float* W1, void* gz1,
+                                        void* gx, float* gweight, float* gbias, int64_t R, int Cin, void* workspace,
+                                        int64_t workspace_bytes, fgnn_stream_t stream) {
+    if (!z1 || !ga1 || !mean || !invstd || !gamma || !beta || !W1 || !gz1 || !gx || !workspace)
+        FGNN_FAIL(FGNN_EINVAL, "block_head_backward: null pointer");
+    int grid;
+    if (bt_plan(R, Cin, &grid) || (((uintptr_t)z1 | (uintptr_t)ga1 | (uintptr_t)gz1 | (uintptr_t)gx) & 15))
+        FGNN_FAIL(FGNN_EUNSUPPORTED, "block_head_backward: Cin=%d / alignment outside the fused block head's family", Cin);
+    if (workspace_bytes < (int64_t)BT_MAXGRID * 2 * 64 * 4 + 2 * 64 * 4) FGNN_FAIL(FGNN_EINVAL, "block_head_backward: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    const float* dsum = nullptr;
+    if (fgnn_bn_backward_sums_bf16(z1, ga1, R, 64, mean, invstd, gamma, beta, slope, gweight, gbias, workspace, st, &dsum))
+        FGNN_FAIL(FGNN_EUNSUPPORTED, "block_head_backward: BatchNorm reduction plan failed");
+    BhParams p = {};
+    p.z = (const uint16_t*)z1; p.g = (const uint16_t*)ga1; p.mean = mean; p.invstd = invstd; p.gamma = gamma; p.beta = beta;
+    p.dsum = dsum; p.W = W1; p.gz = (uint16_t*)gz1; p.gx = (uint16_t*)gx; p.R = (int)R; p.Cin = Cin; p.slope = slope;
+    p.inv_r = 1.0f / (float)R;
+    const int CG = Cin / 64;
+    void* fn = CG == 1 ? (void*)block_head_bwd_kernel<1> : (CG == 2 ? (void*)block_head_bwd_kernel<2> : (void*)block_head_bwd_kernel<4>);
+    const int lds = CG * 8 * 64 * 16 + 5 * 64 * 4;
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "hipFuncSetAttribute(%d B LDS): %s", lds, hipGetErrorString(e));
+    }
+    fgnn_note_kernel("block_head_bwd_kernel<%d>", CG);
+    void* args[] = {(void*)&p};
+    hipError_t e = hipLaunchKernel(fn, dim3(grid), dim3(BT_THREADS), args, lds, st);
+    if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "block_head_backward launch: %s", hipGetErrorString(e));
+    return FGNN_OK;
+}

@@ -414,6 +414,25 @@ extern "C" int fgnn_bn_backward(const void* x, const void* gy, void* gx, int64_t
     return FGNN_OK;
 }
 
+// The reduction half of fgnn_bn_backward (bf16): per-channel dbeta / dgamma into workspace (returned through `dsum`:
+// [2][C] floats) and ACCUMULATED into gweight / gbias.  For callers that fuse the element-wise half with something else
+// (csrc/block_tail.hip: BatchNorm1's input gradient + conv1's input gradient in one pass).  Host-side helper, not C ABI.
+int fgnn_bn_backward_sums_bf16(const void* x, const void* gy, int64_t R, int C, const float* mean, const float* invstd,
+                               const float* gamma, const float* beta, float slope, float* gweight, float* gbias,
+                               void* workspace, hipStream_t st, const float** dsum_out) {
+    BnParams p = {};
+    int grid;
+    if (bn_plan(R, C, FGNN_BF16, &p, &grid)) return -1;
+    float* ws = (float*)workspace;
+    float* dsum = ws + (int64_t)BN_MAXPART * 2 * C;
+    p.x = x; p.gy = gy; p.out = nullptr; p.ws = ws; p.a = mean; p.b = invstd; p.gamma = gamma; p.beta = beta;
+    p.slope = slope; p.dsum_scale = 1.0f / (float)R; p.dbeta = dsum; p.dgamma = dsum + C;
+    hipLaunchKernelGGL((bn_reduce_kernel<bf16_t, 1>), dim3(grid), dim3(BN_THREADS), 0, st, p);
+    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((C + BN_FC - 1) / BN_FC), dim3(256), 0, st, ws, grid, C, dsum, gweight, gbias);
+    *dsum_out = dsum;
+    return 0;
+}
+
 // backward finaliser for partials of (sum g, sum g * x) with the RAW x: dbeta = S0, dgamma = invstd (S1 - mean S0)
 __global__ __launch_bounds__(256) void bn_bwd_final_raw_kernel(const float* ws, int nwg, int C, const float* mean,
                                                                const float* invstd, float* dsum, float* gweight, float* gbias) {

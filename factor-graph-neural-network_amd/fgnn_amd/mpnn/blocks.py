@@ -88,6 +88,95 @@ def _is_identity_list(nn_idx):
 FUSE_TRAIN_TAIL = True       # training: BatchNorm2 + ReLU -> conv2 -> BatchNorm3 + LeakyReLU (+ addends) without storing conv2's output
 
 
+FUSE_TRAIN_HEAD = os.environ.get('FGNN_STAGED_HEAD') is None    # training: BatchNorm1's input gradient and conv1's input gradient in one pass
+
+
+# Input widths the fused head backward takes.  Measured alone (R = 393 216 rows): 73 vs 76 us staged at 64 channels in, 90 vs 88 at
+# 128, 127 vs 119 at 256 (R = 196 608: 40 / 46 / 65 vs 45 / 50 / 67) — the tensor it avoids re-reading (gz1, 25-50 MB) is read back
+# from the 256 MB infinity cache in the staged path, so the fusion only saves the launch and a cached pass; in the step 64 and 128
+# are worth ~0.05 ms together, 256 nothing.
+_HEAD_WIDTHS = tuple(int(v) for v in os.environ.get('FGNN_HEAD_WIDTHS', '64,128').split(',') if v)
+
+
+class _BlockHead(torch.autograd.Function):
+    """conv1 -> BatchNorm -> LeakyReLU in front of the operator of a training-mode ``mp_conv_residual`` (mp_nn_residual.py:25-29,
+    42-44), 64 output channels.  The forward is the staged one (the 1x1 map with the statistics epilogue, the finaliser, the apply
+    pass); the BACKWARD runs BatchNorm's reduction pass and then ONE kernel (csrc/block_tail.hip::block_head_bwd_kernel) that forms
+    BatchNorm's input gradient gz1 and multiplies it by conv1's weight on the way out — the staged path wrote gz1 and read it back
+    in the input-gradient GEMM.  gz1 is still stored once for conv1's weight-gradient kernel, which is parked like every other."""
+
+    @staticmethod
+    def forward(ctx, rows, weight, bias, bn_w, bn_b, rm, rv, nbt, momentum, eps, slope):
+        from .. import _hip
+        from . import pointwise
+        L = _hip.lib()
+        P = _hip._ptr
+        z1 = pointwise.hip_linear(rows, weight, bias, want_stats=True)
+        if z1 is None:
+            raise _hip.FgnnHipError('fused block head: the 1x1 map is outside csrc/linear_fwd_b16.hip (checked by the caller)')
+        R, dev = rows.shape[0], rows.device
+        stats = torch.empty((4, 64), device=dev, dtype=torch.float32)       # mean, invstd, scale, shift
+        ws = ops._workspace(dev, int(L.fgnn_bn_workspace_bytes(R, 64)))
+        npart = pointwise.take_pending_stats(z1)
+        if npart:
+            _hip.check(L.fgnn_bn_finalize(P(ws), npart, R, 64, P(bn_w), P(bn_b), P(rm), P(rv), momentum, eps, P(stats[0]), P(stats[1]),
+                                          P(stats[2]), P(stats[3]), P(nbt), _hip.stream_ptr()))
+        else:
+            ops.timed('bn_stats (reduce + finalise)', z1.numel() * 2, lambda: _hip.check(L.fgnn_bn_stats(
+                P(z1), R, 64, _hip.BF16, P(bn_w), P(bn_b), P(rm), P(rv), momentum, eps, P(stats[0]), P(stats[1]), P(stats[2]),
+                P(stats[3]), P(nbt), P(ws), ws.numel() * 4, _hip.stream_ptr())))
+        a1 = torch.empty_like(z1)
+        pointwise.note_state_change()
+        ops.timed('bn_apply (forward)', 2 * z1.numel() * 2, lambda: _hip.check(L.fgnn_bn_apply(
+            P(z1), P(a1), R, 64, _hip.BF16, P(stats[2]), P(stats[3]), slope, None, None, None, _hip.stream_ptr())))
+        ctx.save_for_backward(rows, z1, stats, weight, bn_w, bn_b)
+        ctx.slope = slope
+        ctx.params = (weight, bias, bn_w, bn_b)
+        return a1
+
+    @staticmethod
+    def backward(ctx, ga1):
+        from .. import _hip
+        ops.backward_node_begins()
+        L = _hip.lib()
+        P = _hip._ptr
+        rows, z1, stats, weight, bn_w, bn_b = ctx.saved_tensors
+        pW, pbias, pw, pb = ctx.params
+        R, cin = rows.shape
+        dev = rows.device
+        ga1 = ga1.contiguous()
+        if ga1.dtype != z1.dtype:
+            ga1 = ga1.to(z1.dtype)
+
+        def sink(param, shape):
+            g = ops.grad_sink(param)
+            return (g, True) if g is not None else (torch.zeros(shape, device=dev, dtype=torch.float32), False)
+        gw1, s_w1 = sink(pw, (64,))
+        gb1, s_b1 = sink(pb, (64,))
+        Wbase = pW._base if pW._base is not None and pW._base.numel() == pW.numel() else pW
+        gW, s_W = sink(Wbase, (64, cin))
+        gbias, s_bias = sink(pbias, (64,)) if pbias is not None else (None, True)
+        gz1 = torch.empty_like(z1)
+        gx = torch.empty((R, cin), device=dev, dtype=z1.dtype)
+        ws = ops._workspace(dev, int(L.fgnn_bn_workspace_bytes(R, 64)))
+        ops.timed('block_head_backward (reduce + finalise + grad)', 2 * R * (5 * 64 + cin), lambda: _hip.check(L.fgnn_block_head_backward(
+            P(z1), P(ga1), P(stats[0]), P(stats[1]), P(bn_w.detach()), P(bn_b.detach()), ctx.slope, P(weight.detach()), P(gz1), P(gx),
+            P(gw1), P(gb1), R, cin, P(ws), ws.numel() * 4, _hip.stream_ptr())), nflops=2 * R * 64 * cin)
+
+        def launch(rows=rows, gz1=gz1, gW=gW, gbias=gbias):
+            wsw = ops._workspace(dev, int(L.fgnn_linear_wgrad_workspace_bytes(R, cin, 64)))
+            ops.timed('linear_wgrad_b16_kernel', 2 * R * (cin + 64), lambda: _hip.check(L.fgnn_linear_wgrad(
+                P(rows), P(gz1), R, cin, 64, _hip.BF16, P(gW.view(64, cin)), P(gbias), P(wsw), wsw.numel() * 4, _hip.stream_ptr())),
+                nflops=2 * R * cin * 64)
+        if s_W and s_bias:
+            ops.defer_wgrad(launch, (rows, gz1))
+        else:
+            launch()
+        return (gx if ctx.needs_input_grad[0] else None, None if s_W else gW.view(pW.shape).to(pW.dtype),
+                None if (s_bias or gbias is None) else gbias, None if s_w1 else gw1, None if s_b1 else gb1,
+                None, None, None, None, None, None)
+
+
 LATE_JOIN = os.environ.get('FGNN_EARLY_JOIN') is None     # the tail asks for addends of another stream behind its statistics pass
 ROUTE_ADDEND_GRADS = True    # the addends' gradient leaves through its own autograd node, ahead of the tail's backward kernels
 
@@ -353,7 +442,9 @@ class mp_conv_residual(base_mp_nn):
             if y is not None:
                 return y
         fuse = self.training            # BatchNorm statistics ride in the 1x1 map's epilogue when training
-        h = self.conv1[1](self.conv1[0](node_feature, want_stats=fuse))
+        h = self._fused_train_head(node_feature)
+        if h is None:
+            h = self.conv1[1](self.conv1[0](node_feature, want_stats=fuse))
         y = self._fused_train_tail(h, nn_idx, etype, addend)
         if y is not None:
             return y + node_feature if self.with_residual else y
@@ -363,6 +454,31 @@ class mp_conv_residual(base_mp_nn):
             addend = addend()
         h = self.conv2[1](h, addend=addend)
         return h + node_feature if self.with_residual else h
+
+    def _fused_train_head(self, x):
+        """Training, bf16, 64 channels in the middle: conv1 + BatchNorm + LeakyReLU as ``_BlockHead`` (same forward kernels, fused
+        backward).  None = not this family."""
+        from .. import _hip
+        conv, bn = self.conv1[0], self.conv1[1]
+        if not (FUSE_TRAIN_HEAD and self.training and torch.is_grad_enabled() and x.is_cuda and isinstance(conv, PointwiseConv2d)
+                and isinstance(bn, BatchNormAct2d) and bn.training and conv.out_channels == 64 and conv.in_channels in _HEAD_WIDTHS
+                and bn.track_running_stats and bn.affine and bn.momentum is not None and conv.weight.dtype == torch.float32
+                and bn.weight.dtype == torch.float32 and (x.requires_grad or conv.weight.requires_grad)):
+            return None
+        B, C, H, W = x.shape
+        rows = x.permute(0, 2, 3, 1)
+        if not rows.is_contiguous():
+            rows = rows.contiguous()
+        rows = rows.view(B * H * W, C)
+        if torch.is_autocast_enabled():
+            rows = rows.to(torch.get_autocast_dtype('cuda'))
+        L = _hip.lib()
+        R = B * H * W
+        if rows.dtype != torch.bfloat16 or R < 2 or not L.fgnn_block_tail_partials(R, C) or not L.fgnn_linear_forward_partials(R, C, 64):
+            return None
+        a1 = _BlockHead.apply(rows, conv.weight.view(64, C), conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                              bn.num_batches_tracked, bn.momentum, bn.eps, float(bn.slope))
+        return a1.view(B, H, W, 64).permute(0, 3, 1, 2)
 
     def _fused_train_tail(self, h, nn_idx, etype, addend):
         """Training, bf16: the operator's pre-BatchNorm output goes straight into csrc/block_tail.hip (``_BlockTail``) —

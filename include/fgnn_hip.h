@@ -187,6 +187,20 @@ int fgnn_block_tail_backward(const void* e, const float* scale2, const float* sh
 int fgnn_block_tail_backward_partials(int64_t R, int32_t Cout);
 
 /*
+ * HEAD of a training-mode `mp_conv_residual`, backward: autograd through `self.conv1` = Conv2d(nin, nmed, 1) -> BatchNorm2d ->
+ * LeakyReLU (/root/reference/lib/model/mpnn/mp_nn_residual.py:25-29,42-44) for nmed = 64, bf16 channel-fastest rows.
+ *   z1 [R][64]   conv1's output (BatchNorm1's input), ga1 [R][64] the gradient of the activated output (what the operator's
+ *   backward returns for its x), mean / invstd / gamma / beta [64] BatchNorm1's batch statistics and parameters, W1 [64][Cin] f32.
+ *   Writes gz1 [R][64] (BatchNorm1's input gradient: conv1's weight-gradient kernel reads it) and gx [R][Cin] = gz1 W1 (conv1's
+ *   input gradient) in ONE element pass — gz1 is not read back — after BatchNorm1's reduction pass; gweight / gbias [64]
+ *   (BatchNorm1's parameter gradients) are ACCUMULATED into.  Cin in {64, 128, 256}; workspace: fgnn_bn_workspace_bytes(R, 64).
+ */
+int fgnn_block_head_backward(const void* z1, const void* ga1, const float* mean, const float* invstd, const float* gamma,
+                             const float* beta, float slope, const float* W1, void* gz1, void* gx, float* gweight,
+                             float* gbias, int64_t R, int32_t Cin, void* workspace, int64_t workspace_bytes,
+                             fgnn_stream_t stream);
+
+/*
  * Train-mode BatchNorm fused with the LeakyReLU(slope) behind it (slope 0 = ReLU, 1 = none) on dense
  * channel-fastest x[R][C] (conv1/conv2 blocks mp_nn_residual.py:25-35, mp_conv_v2.bn mp_nn.py:57-58,170-173,
  * iid_mapping_bn base_model.py:62-79).  torch.nn.BatchNorm2d semantics: biased variance normalises, running
@@ -359,8 +373,9 @@ const char* fgnn_last_kernel(void);
 /* Bumped whenever an entry point is added or an argument / descriptor field changes meaning.  The host binding
  * (fgnn_amd/_hip.py: ABI_VERSION) checks it BEFORE binding symbols, so a stale library is reported as a version
  * mismatch and not as a missing symbol or a misread field.  4: round-2 additions (flat_adam, factor_layer_*,
- * ldpc_channel_features_rng, backward_reduces_getype, desc.reserved = in-degree | GETYPE_REDUCED); 5: fgnn_block_tail_*. */
-#define FGNN_ABI_VERSION 5
+ * ldpc_channel_features_rng, backward_reduces_getype, desc.reserved = in-degree | GETYPE_REDUCED); 5: fgnn_block_tail_*;
+ * 6: fgnn_block_head_backward. */
+#define FGNN_ABI_VERSION 6
 int fgnn_abi_version(void);
 
 #ifdef __cplusplus

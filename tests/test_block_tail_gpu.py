@@ -183,3 +183,93 @@ def test_fused_training_tail_matches_staged_path_and_oracle(case, nadd, dev):
         assert ef <= 1.5 * es + 2.0 ** -5, (n, ef, es)
         checked += 1
     assert checked >= 8
+
+
+@pytest.mark.parametrize('Cin', [64, 128, 256])
+@pytest.mark.parametrize('R', [2, 37, 4096 + 5, 96 * 300])
+def test_block_head_backward_kernel_vs_torch(R, Cin, dev):
+    """fgnn_block_head_backward through the C ABI: BatchNorm1 + LeakyReLU backward (batch statistics) and conv1's input gradient
+    against autograd through the same chain in f32 torch (the kernel rounds gz1 to bf16 before the product, as the staged path
+    does): gz1 and gx to 2^-7 of their range, the BatchNorm parameter gradients to 1e-3."""
+    from fgnn_amd import _hip, ops
+    L, P = _hip.lib(), _hip._ptr
+    g = torch.Generator().manual_seed(R + Cin)
+    z1 = (torch.randn(R, 64, generator=g) * 1.5 + 0.3).bfloat16()
+    ga1 = torch.randn(R, 64, generator=g).bfloat16()
+    gamma, beta = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.3
+    W1 = torch.randn(64, Cin, generator=g) * 0.1
+    slope, eps = 0.01, 1e-5
+    zf = z1.float().requires_grad_(True)
+    mean, var = zf.mean(0), zf.var(0, unbiased=False)
+    invstd = torch.rsqrt(var + eps)
+    gam, bet = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    a1 = torch.nn.functional.leaky_relu((zf - mean) * invstd * gam + bet, slope)
+    a1.backward(ga1.float())
+    gz_ref = zf.grad
+    gx_ref = gz_ref.bfloat16().float() @ W1.bfloat16().float()
+    d = lambda t: t.to(dev).contiguous()
+    gz, gx = torch.empty(R, 64, device=dev, dtype=torch.bfloat16), torch.empty(R, Cin, device=dev, dtype=torch.bfloat16)
+    gw, gb = torch.zeros(64, device=dev), torch.zeros(64, device=dev)
+    ws = ops._workspace(dev, int(L.fgnn_bn_workspace_bytes(R, 64)))
+    z1d, gad, md, isd, gd, bd, Wd = d(z1), d(ga1), d(mean.detach()), d(invstd.detach()), d(gamma), d(beta), d(W1)
+    _hip.check(L.fgnn_block_head_backward(P(z1d), P(gad), P(md), P(isd), P(gd), P(bd), slope, P(Wd), P(gz), P(gx), P(gw), P(gb), R, Cin,
+                                          P(ws), ws.numel() * 4, _hip.stream_ptr()))
+    assert _hip.lib().fgnn_last_kernel().decode() == 'block_head_bwd_kernel<%d>' % (Cin // 64)
+    assert H.rel_err(gz.float().cpu(), gz_ref) <= 2.0 ** -7
+    assert H.rel_err(gx.float().cpu(), gx_ref) <= 2.0 ** -7
+    assert H.rel_err(gw.cpu(), gam.grad) <= 1e-3 and H.rel_err(gb.cpu(), bet.grad) <= 1e-3
+    with pytest.raises(_hip.FgnnHipError):
+        _hip.check(L.fgnn_block_head_backward(P(z1d), P(gad), P(md), P(isd), P(gd), P(bd), slope, P(Wd), P(gz), P(gx), P(gw), P(gb), R, 96,
+                                              P(ws), ws.numel() * 4, _hip.stream_ptr()))
+
+
+@pytest.mark.parametrize('case', CASES[:5], ids=lambda c: 'x'.join(map(str, c)))
+def test_fused_training_head_matches_staged_head(case, dev, monkeypatch):
+    """`mp_conv_residual` in training mode with the head's backward fused (blocks._BlockHead) and staged: the forward runs the
+    same kernels (bit-identical output and running statistics); in the backward only the rounding of BatchNorm1's input gradient
+    and the summation order of conv1's input-gradient product differ."""
+    from fgnn_amd import ops
+    from fgnn_amd.mpnn import blocks, mp_conv_residual, mp_conv_type
+    nin, nout, N, M, k, net = case
+    B = 40
+    g = torch.Generator().manual_seed(nin + nout + M)
+    torch.manual_seed(6)
+    m = mp_conv_residual(nin, 64, net, extension=mp_conv_type.NO_EXTENSION, with_residual=False, aggregator='max',
+                         nout=None if nout == nin else nout).to(dev).train()
+    with torch.no_grad():
+        m.mp_conv.filters.mul_(10.0)
+    x = torch.randn(B, N, 1, nin, generator=g).bfloat16().to(dev).permute(0, 3, 1, 2)
+    idx = torch.randint(0, N, (1, M, k), generator=g).to(dev).expand(B, -1, -1)
+    et = torch.randn(B, M, k, net, generator=g).bfloat16().to(dev).permute(0, 3, 1, 2)
+    gy = torch.randn(B, M, 1, nout, generator=g).bfloat16().to(dev).permute(0, 3, 1, 2)
+    sd0 = {k_: v.clone() for k_, v in m.state_dict().items()}
+
+    def run(fused):
+        m.load_state_dict(sd0)
+        for q in m.parameters():
+            q.grad = None
+        monkeypatch.setattr(blocks, "FUSE_TRAIN_HEAD", fused)
+        monkeypatch.setattr(blocks, "_HEAD_WIDTHS", (64, 128, 256))
+        rec = []
+        ops.TIMER = type('T', (), {'run': staticmethod(lambda sym, nb, nf, launch, use_note=True: (rec.append(sym), launch()))})()
+        try:
+            xd, ed = x.detach().requires_grad_(True), et.detach().requires_grad_(True)
+            with torch.autocast('cuda', dtype=torch.bfloat16):
+                y = m(xd, idx, ed)
+            y.backward(gy)
+        finally:
+            ops.TIMER = None
+        out = {'y': y.detach().float(), 'gx': xd.grad.float(), 'get': ed.grad.float()}
+        out.update({n: q.grad.detach().float().clone() for n, q in m.named_parameters()})
+        out.update({n: v.detach().float().clone() for n, v in m.state_dict().items() if 'running' in n})
+        return out, rec
+
+    f, frec = run(True)
+    s, srec = run(False)
+    assert any('block_head_backward' in r for r in frec) and not any('block_head_backward' in r for r in srec), (frec, srec)
+    assert torch.equal(f['y'], s['y'])
+    for n in f:
+        if 'running' in n or n == 'get' or not n.startswith('conv1') and n not in ('gx',):
+            assert torch.equal(f[n], s[n]), n                 # everything behind the head sees the same tensors
+    for n in ('gx', 'conv1.0.weight', 'conv1.1.weight', 'conv1.1.bias'):
+        assert H.rel_err(f[n], s[n]) <= 2.0 ** -7, (n, H.rel_err(f[n], s[n]))
