@@ -347,7 +347,7 @@ _WS_CAPTURED = []       # workspaces whose addresses live in captured graphs
 
 
 _SIDE = {}
-SIDE_STREAM = True      # FactorNN: factor types beyond the first run on a second stream (captured as parallel graph branches)
+SIDE_STREAM = os.environ.get('FGNN_NO_SIDE_STREAM') is None      # FactorNN: factor types beyond the first run on a second stream (captured as parallel graph branches)
 
 
 def side_stream(device):
