@@ -400,6 +400,10 @@ static void* sg_pick_width(int nin, int nou, int mode) {
     return nullptr;
 }
 
+int fgnn_mpconv_forward_ws(const fgnn_mpconv_desc* d, const void* x, const int64_t* nn_idx, const void* etype,
+                           const float* filters, const float* bias, const float* post_scale, const float* post_shift,
+                           void* y, uint8_t* argmax, fgnn_stream_t stream, float* stats, int* plan_grid, int mode, int split);
+
 // Same contract as fgnn_mpconv_forward_b16 (mpconv_fwd_b16.hip): 1 = launched, 0 = shape outside this kernel's family,
 // < 0 = error; stats / plan_grid as there.
 int fgnn_mpconv_forward_sg(const fgnn_mpconv_desc* d, const void* x, const int64_t* nn_idx, const void* etype,
@@ -440,6 +444,11 @@ int fgnn_mpconv_forward_sg(const fgnn_mpconv_desc* d, const void* x, const int64
     else mode = SG_MODE_GENERIC;
     if (d->idx_sb != 0 && d->B > 1) return 0;                     // per-sample graphs: first-generation kernel
     const int knou = split ? 64 : d->nou;                         // output channels of one launch
+    if (knou == 64) {                                             // third generation first (mpconv_fwd_ws.hip); 0 = not its shape
+        const int r = fgnn_mpconv_forward_ws(d, x, nn_idx, etype, filters, bias, post_scale, post_shift, y, argmax, stream, stats,
+                                             plan_grid, mode, split ? 1 : 0);
+        if (r != 0) return r;
+    }
     void* fn = d->k == 6 ? sg_pick_width<6, 6>(d->nin, knou, mode) : sg_pick_width<3, 12>(d->nin, knou, mode);
     if (!fn) return 0;
     const int Npad = fgnn_round_up(d->N, 32);
