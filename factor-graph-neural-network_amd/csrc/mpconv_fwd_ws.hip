@@ -57,7 +57,15 @@ struct WsParams {
     int B, N, M, Npad, relu;
     int y_ld, w_ld, st_ld;                        // row strides (elements) of y / argmax, of W, of a statistics partial row
     long long x_sb, et_sb, y_sb;                  // elements
+    long long* prof;                              // FGNN_PROF (builds with -DFGNN_ENABLE_PROF only): stage timeline
 };
+
+// stage-timeline stamps (tuning aid): workgroup 0, waves 0 (producer) and 4 (consumer), one stamp per barrier
+#ifdef FGNN_ENABLE_PROF
+#define WS_STAMP(slot) do { const int sl_ = (slot) - 28; if (p.prof && blockIdx.x == 0 && lane == 0 && sl_ >= 0 && sl_ < 8) p.prof[wave * 8 + sl_] = __builtin_readcyclecounter(); } while (0)
+#else
+#define WS_STAMP(slot) do { } while (0)
+#endif
 
 extern __shared__ __attribute__((aligned(16))) unsigned char ws_lds[];
 
@@ -70,6 +78,25 @@ __device__ __forceinline__ unsigned ws_pack(float a, float b) {
 __device__ __forceinline__ float ws_dot2(unsigned p, unsigned e, float acc) {
     return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(ws_bf16x2, p), __builtin_bit_cast(ws_bf16x2, e), acc, false);
 }
+#ifndef WS_OPT_ASMDOT
+#define WS_OPT_ASMDOT 0       // 1: seed each message with the three-address v_dot2_f32_bf16 (no v_mov of the bias per message)
+#endif
+#ifndef WS_OPT_MASKARG
+#define WS_OPT_MASKARG 0      // argmax through lane masks in SGPRs (first-occurrence logic on the scalar unit) instead of a v_cmp -> s_nop -> v_cndmask chain
+#endif
+__device__ __forceinline__ float ws_dot2_seed(unsigned p, unsigned e, float c) {
+#if WS_OPT_ASMDOT
+    float r;
+    asm("v_dot2_f32_bf16 %0, %1, %2, %3" : "=v"(r) : "v"(p), "v"(e), "v"(c));
+    return r;
+#else
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(ws_bf16x2, p), __builtin_bit_cast(ws_bf16x2, e), c, false);
+#endif
+}
+__device__ __forceinline__ float ws_max3(float a, float b, float c) {
+    // (not inline asm: a VALU read of a v_dot2c result needs wait states the compiler only inserts for instructions it can see)
+    return fmaxf(fmaxf(a, b), c);
+}
 // one LDS-DMA piece: 64 lanes x 16 bytes, lane l's bytes land at lds_dst + 16 l (tools/ubench/lds_dma_tr.hip).  M0 is
 // compiler-reserved: saved and restored inside the statement (cdna_hip_programming.md §5.7).  Not counted by the compiler's
 // s_waitcnt bookkeeping: the producers wait with ws_wait_dma<>.
@@ -79,9 +106,29 @@ __device__ __forceinline__ void ws_dma16(const void* gsrc, unsigned lds_dst) {
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
 template <int N> __device__ __forceinline__ void ws_wait_dma() { asm volatile("s_waitcnt vmcnt(%0)" :: "i"(N) : "memory"); }
-// the stage barrier: LDS operations of this wave done, then s_barrier.  NOT __syncthreads(): that also drains vmcnt, i.e.
-// every consumer would sit out its y / argmax stores once per sample.
-__device__ __forceinline__ void ws_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// Dataflow flags in LDS (monotonic counters, one ds_add per wave and sample) instead of a workgroup barrier per sample: a
+// barrier makes every wave wait for the slowest of all 16 once per sample (measured: the three consumer waves of a SIMD
+// finish ~1 900 / 2 900 / 3 500 cycles into a 3 660-cycle stage, the producers at 2 500); with flags a wave only waits
+// for the data it needs.  LDS executes one wave's operations in order, so a ds_add issued after a wave's ds_write /
+// ds_read of an image is ordered behind them without a wait.
+// (ds instructions through inline asm: a volatile access to a computed LDS address compiles to flat_load + s_waitcnt vmcnt(0),
+// i.e. every poll would drain the wave's stores.  The compiler does not count these two in its lgkmcnt bookkeeping; LDS
+// returns in order, so an uncounted extra operation only makes its own waits conservative.)
+__device__ __forceinline__ void ws_signal(unsigned flag, int lane) {
+    if (lane == 0) {
+        const unsigned one = 1u;
+        asm volatile("ds_add_u32 %0, %1" :: "v"(flag), "v"(one) : "memory");
+    }
+}
+__device__ __forceinline__ void ws_wait_ge(unsigned flag, int need) {
+    for (;;) {
+        int v;
+        asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(flag) : "memory");
+        if (__builtin_amdgcn_readfirstlane(v) >= need) break;
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
 
 // lane <-> (destination slot s, 16-byte column q) such that the 16 lanes of one ds_read_b128 service group share s
 __device__ __forceinline__ void ws_lane_sq(int lane, int& s, int& q) {
@@ -117,9 +164,14 @@ __global__ __launch_bounds__(WS_THREADS) void mpconv_fwd_ws_kernel(const WsParam
     const int N = p.N, M = p.M, Npad = p.Npad;
     const int PBYTES = Npad * WS_PROW;
     const int OFF_E = XBUF * XBYTES, OFF_P = OFF_E + EBUF * WS_ESZ;      // DMA targets first: all below 64 KB
+    // flags: [0] x / edge types of a sample landed (4 per sample), [1] P image written (4 per sample), [2] P image consumed (12 per sample)
     const unsigned lds0 = (unsigned)(uintptr_t)ws_lds;
+    int* flags_p = reinterpret_cast<int*>(ws_lds + OFF_P + 2 * PBYTES);
+    const unsigned flags = lds0 + (unsigned)(OFF_P + 2 * PBYTES);        // LDS byte address: + 0 / 4 / 8
     const int grid = gridDim.x;
     const int cnt = (p.B - (int)blockIdx.x + grid - 1) / grid;       // samples of this workgroup: blockIdx.x + i grid
+    if (tid < 4) flags_p[tid] = 0;
+    __syncthreads();
 
     if (wave < WS_NPROD) {
         // =====================================================================================  producers
@@ -181,58 +233,91 @@ __global__ __launch_bounds__(WS_THREADS) void mpconv_fwd_ws_kernel(const WsParam
         auto project = [&](int i, int par) {                              // sample i: x buffer i % XBUF -> P image `par`
             const unsigned char* xs = ws_lds + (i % XBUF) * XBYTES;
             unsigned char* ps = ws_lds + OFF_P + par * PBYTES;
+            auto store_tile = [&](unsigned char* pp, const ws_f32x16& acc) {
+                *reinterpret_cast<uint4*>(pp) = make_uint4(ws_pack(acc[0], acc[1]), ws_pack(acc[2], acc[3]),
+                                                           ws_pack(acc[4], acc[5]), ws_pack(acc[6], acc[7]));
+                *reinterpret_cast<uint4*>(pp + 256) = make_uint4(ws_pack(acc[8], acc[9]), ws_pack(acc[10], acc[11]),
+                                                                 ws_pack(acc[12], acc[13]), ws_pack(acc[14], acc[15]));
+            };
+            if constexpr (KS == 4) {
+                // Two accumulator chains (the wave's two column tiles) alternate on the matrix pipe — a chain alone stalls 64 cycles
+                // per link — and the next node tile's operand fragments are in flight under this tile's MFMAs.
+                ws_bf16x8 bfr[2][4];
 #pragma unroll
-            for (int tile = 0; tile < 3; ++tile) {
-                if (tile < ntile) {
-                    // nin = 64: the tile's four operand fragments serve both column tiles.  nin = 128: eight fragments + 64 resident
-                    // A registers + two accumulators do not fit 128 VGPRs, so each column tile re-reads them four at a time.
-                    ws_bf16x8 bfr[4];
-                    if (KS == 4) {
+                for (int kk = 0; kk < 4; ++kk)
+                    bfr[0][kk] = __builtin_bit_cast(ws_bf16x8, *reinterpret_cast<const uint4*>(xs + xoff[kk]));
 #pragma unroll
-                        for (int kk = 0; kk < 4; ++kk)
-                            bfr[kk] = __builtin_bit_cast(ws_bf16x8, *reinterpret_cast<const uint4*>(xs + tile * 32 * XROW + xoff[kk]));
+                for (int tile = 0; tile < 3; ++tile) {
+                    if (tile < ntile) {
+                        if (tile + 1 < ntile) {
+#pragma unroll
+                            for (int kk = 0; kk < 4; ++kk)
+                                bfr[(tile + 1) & 1][kk] = __builtin_bit_cast(ws_bf16x8, *reinterpret_cast<const uint4*>(xs + (tile + 1) * 32 * XROW + xoff[kk]));
+                        }
+                        ws_f32x16 acc0, acc1;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+#pragma unroll
+                        for (int kk = 0; kk < 4; ++kk) {
+                            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(areg[0][kk], bfr[tile & 1][kk], acc0, 0, 0, 0);
+                            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(areg[1][kk], bfr[tile & 1][kk], acc1, 0, 0, 0);
+                        }
+                        store_tile(ps + tile * 32 * WS_PROW + pwo[0], acc0);
+                        store_tile(ps + tile * 32 * WS_PROW + pwo[1], acc1);
                     }
+                }
+            } else {
+                // nin = 128: eight fragments + 64 resident A registers + two accumulators do not fit 128 VGPRs, so each column tile
+                // re-reads its operand fragments four at a time
 #pragma unroll
-                    for (int tc = 0; tc < 2; ++tc) {
-                        ws_f32x16 acc;
+                for (int tile = 0; tile < 3; ++tile) {
+                    if (tile < ntile) {
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+                        for (int tc = 0; tc < 2; ++tc) {
+                            ws_f32x16 acc;
 #pragma unroll
-                        for (int grp = 0; grp < KS / 4; ++grp) {
-                            if (KS != 4) {
+                            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+                            for (int grp = 0; grp < KS / 4; ++grp) {
+                                ws_bf16x8 bfr[4];
 #pragma unroll
                                 for (int kk = 0; kk < 4; ++kk)
                                     bfr[kk] = __builtin_bit_cast(ws_bf16x8, *reinterpret_cast<const uint4*>(xs + tile * 32 * XROW + xoff[grp * 4 + kk]));
-                            }
 #pragma unroll
-                            for (int kk = 0; kk < 4; ++kk)
-                                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(areg[tc][grp * 4 + kk], bfr[kk], acc, 0, 0, 0);
+                                for (int kk = 0; kk < 4; ++kk)
+                                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(areg[tc][grp * 4 + kk], bfr[kk], acc, 0, 0, 0);
+                            }
+                            store_tile(ps + tile * 32 * WS_PROW + pwo[tc], acc);
                         }
-                        unsigned char* pp = ps + tile * 32 * WS_PROW + pwo[tc];
-                        *reinterpret_cast<uint4*>(pp) = make_uint4(ws_pack(acc[0], acc[1]), ws_pack(acc[2], acc[3]),
-                                                                   ws_pack(acc[4], acc[5]), ws_pack(acc[6], acc[7]));
-                        *reinterpret_cast<uint4*>(pp + 256) = make_uint4(ws_pack(acc[8], acc[9]), ws_pack(acc[10], acc[11]),
-                                                                         ws_pack(acc[12], acc[13]), ws_pack(acc[14], acc[15]));
                     }
                 }
             }
         };
-        // ---- pipeline fill: sample 0's inputs, then (stage -1) samples 1 .. XBUF-1 go out while sample 0 is projected ----
-        if (cnt > 0) dma_batch(0);
-        ws_wait_dma<0>();
-        ws_barrier();                                                     // B0
-        for (int t = -1; t < cnt; ++t) {
-            if (t < 0) {
+        // ---- the first XBUF samples' inputs go out at once; from then on sample t - 1 + XBUF is requested when sample t's projection starts
+        WS_STAMP(0);
 #pragma unroll
-                for (int i = 1; i < XBUF; ++i)
-                    if (i < cnt) dma_batch(i);
-            } else if (t + XBUF < cnt) dma_batch(t + XBUF);
-            if (t + 1 < cnt) project(t + 1, (t + 1) & 1);
-            // the next stage projects sample t + 2 and gathers sample t + 1: everything but this stage's own batch has landed
-            if (t + XBUF < cnt) ws_wait_dma<(XBUF - 2) * NDMA>();
+        for (int i = 0; i < XBUF; ++i)
+            if (i < cnt) dma_batch(i);
+        for (int t = 0; t < cnt; ++t) {
+            // this wave's pieces of sample t have landed when at most the younger batches (t + 1 .. t + XBUF - 2) are outstanding
+            if (XBUF > 2 && t + 1 < cnt) ws_wait_dma<(XBUF - 2) * NDMA>();
             else ws_wait_dma<0>();
-            ws_barrier();
+            ws_signal(flags + 0, lane);
+            if (t >= 1) {
+                // P image t & 1 held sample t - 2, edge-type buffer (t - 1 + XBUF) % EBUF sample t - 2: consumers done with it
+                ws_wait_ge(flags + 8, WS_NCONS * (t - 1));
+                if (t - 1 + XBUF < cnt) {
+                    ws_wait_ge(flags + 4, WS_NPROD * t);                  // every producer is done reading x buffer (t - 1) % XBUF
+                    dma_batch(t - 1 + XBUF);
+                }
+            }
+            ws_wait_ge(flags + 0, WS_NPROD * (t + 1));                    // all four waves' pieces of sample t
+            WS_STAMP(4 + 3 * t);
+            project(t, t & 1);
+            ws_signal(flags + 4, lane);
+            WS_STAMP(5 + 3 * t);
         }
+        ws_wait_dma<0>();
     } else {
         // =====================================================================================  consumers
         const int cw = wave - WS_NPROD;
@@ -289,28 +374,60 @@ __global__ __launch_bounds__(WS_THREADS) void mpconv_fwd_ws_kernel(const WsParam
                         pb[j] = *reinterpret_cast<const uint4*>(pr + 256);
                         ev[j] = *reinterpret_cast<const uint2*>(eim + eoff[g] + j * 8);
                     }
-                    float res[4];
-                    unsigned args = 0u;
+                    // the four channels' chains advance together (edge-major): the compare -> select chain of the argmax is serial
+                    // per channel, and left channel-major the compiler pads every link with s_nop instead of another channel's work
+                    float v[4][KC];
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        float v[KC];
+                    for (int j = 0; j < KC; ++j)
 #pragma unroll
-                        for (int j = 0; j < KC; ++j) {
+                        for (int c = 0; c < 4; ++c) {
                             const unsigned w0 = c == 0 ? pa[j].x : (c == 1 ? pa[j].z : (c == 2 ? pb[j].x : pb[j].z));
                             const unsigned w1 = c == 0 ? pa[j].y : (c == 1 ? pa[j].w : (c == 2 ? pb[j].y : pb[j].w));
-                            v[j] = ws_dot2(w1, ev[j].y, ws_dot2(w0, ev[j].x, c_bias[c]));      // the bias rides in the accumulator
+                            v[c][j] = ws_dot2(w1, ev[j].y, ws_dot2_seed(w0, ev[j].x, c_bias[c]));      // the bias rides in the accumulator
                         }
-                        float best = v[0];
+                    float best[4];
 #pragma unroll
-                        for (int j = 1; j + 1 < KC; j += 2) best = fmaxf(fmaxf(best, v[j]), v[j + 1]);      // v_max3_f32
-                        if ((KC & 1) == 0) best = fmaxf(best, v[KC - 1]);
-                        if (WANT_ARG) {                                   // first occurrence of the maximum (torch.max on CPU)
-                            int arg = KC - 1;
+                    for (int c = 0; c < 4; ++c) {
+                        best[c] = ws_max3(v[c][0], v[c][1], v[c][2]);
+                        if constexpr (KC == 6) best[c] = fmaxf(ws_max3(best[c], v[c][3], v[c][4]), v[c][KC - 1]);
+                    }
+                    unsigned args = 0u;
+                    if (WANT_ARG) {                                       // first occurrence of the maximum (torch.max on CPU)
+#if WS_OPT_MASKARG
+                        // eq_j = lanes whose message j equals the maximum (v_cmp into an SGPR pair); "first such j" is resolved on
+                        // the scalar unit, and the three bits of the index come back as three selects per channel
+                        typedef unsigned long long u64;
 #pragma unroll
-                            for (int j = KC - 2; j >= 0; --j) arg = v[j] == best ? j : arg;
-                            args |= (unsigned)arg << (8 * c);
+                        for (int c = 0; c < 4; ++c) {
+                            u64 none = ~0ull, b0 = 0, b1 = 0, b2 = 0;       // none: no earlier message equals the maximum
+#pragma unroll
+                            for (int j = 0; j < KC - 1; ++j) {
+                                const u64 first = __builtin_amdgcn_fcmpf(v[c][j], best[c], 1 /* oeq */) & none;
+                                none &= ~first;
+                                if (j & 1) b0 |= first;
+                                if (j & 2) b1 |= first;
+                                if (j & 4) b2 |= first;
+                            }
+                            if ((KC - 1) & 1) b0 |= none;                    // nothing before the last slot: it is the last slot
+                            if ((KC - 1) & 2) b1 |= none;
+                            if ((KC - 1) & 4) b2 |= none;
+                            const unsigned u1 = 1u << (8 * c), u2 = 2u << (8 * c), u4 = 4u << (8 * c);
+                            args |= (__builtin_amdgcn_inverse_ballot_w64(b0) ? u1 : 0u) | (__builtin_amdgcn_inverse_ballot_w64(b1) ? u2 : 0u);
+                            if (KC > 4) args |= __builtin_amdgcn_inverse_ballot_w64(b2) ? u4 : 0u;
                         }
-                        float r = best;
+#else
+                        int arg[4] = {KC - 1, KC - 1, KC - 1, KC - 1};
+#pragma unroll
+                        for (int j = KC - 2; j >= 0; --j)
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) arg[c] = v[c][j] == best[c] ? j : arg[c];
+                        args = (unsigned)arg[0] | ((unsigned)arg[1] << 8) | ((unsigned)arg[2] << 16) | ((unsigned)arg[3] << 24);
+#endif
+                    }
+                    float res[4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        float r = best[c];
                         if (MODE >= WS_MODE_AFFINE_RELU) r = fmaf(r, c_scale[c], c_shift[c]);
                         if (MODE == WS_MODE_AFFINE_RELU || (MODE == WS_MODE_GENERIC && p.relu)) r = fmaxf(r, 0.f);
                         res[c] = r;
@@ -332,13 +449,18 @@ __global__ __launch_bounds__(WS_THREADS) void mpconv_fwd_ws_kernel(const WsParam
             }
         };
 
-        ws_barrier();                                                     // B0
-        for (int t = -1; t < cnt; t += 2) {                               // stage t gathers sample t out of P image t & 1
-            if (t >= 0) gather(t, std::integral_constant<int, 1>());
-            ws_barrier();
+        for (int t = 0; t < cnt; t += 2) {                                // sample t out of P image t & 1
+            ws_wait_ge(flags + 4, WS_NPROD * (t + 1));
+            WS_STAMP(4 + 3 * t);
+            gather(t, std::integral_constant<int, 0>());
+            ws_signal(flags + 8, lane);
+            WS_STAMP(5 + 3 * t);
             if (t + 1 < cnt) {
-                gather(t + 1, std::integral_constant<int, 0>());
-                ws_barrier();
+                ws_wait_ge(flags + 4, WS_NPROD * (t + 2));
+                WS_STAMP(4 + 3 * (t + 1));
+                gather(t + 1, std::integral_constant<int, 1>());
+                ws_signal(flags + 8, lane);
+                WS_STAMP(5 + 3 * (t + 1));
             }
         }
 
@@ -393,7 +515,7 @@ int fgnn_mpconv_forward_ws(const fgnn_mpconv_desc* d, const void* x, const int64
     if (x && ((((uintptr_t)etype) & 15) || (((uintptr_t)y) & 7) || (argmax && (((uintptr_t)argmax) & 3)))) return 0;
     const int Npad = fgnn_round_up(d->N, 32);
     const int xbuf = d->nin == 64 ? 3 : 2;
-    const int lds = xbuf * WS_MAXN * d->nin * 2 + 2 * Npad * WS_PROW + (xbuf + 1) * WS_ESZ;
+    const int lds = xbuf * WS_MAXN * d->nin * 2 + 2 * Npad * WS_PROW + (xbuf + 1) * WS_ESZ + 64;      // + the dataflow flags
     if (lds > 160 * 1024) return 0;
     void* fn = nullptr;
     if (d->nin == 64) fn = KC == 6 ? ws_pick_mode<64, 6, 3>(mode) : ws_pick_mode<64, 3, 3>(mode);
@@ -412,9 +534,31 @@ int fgnn_mpconv_forward_ws(const fgnn_mpconv_desc* d, const void* x, const int64
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "hipFuncSetAttribute(%d B LDS): %s", lds, hipGetErrorString(e));
     fgnn_note_kernel(split ? "mpconv_fwd_ws_kernel<%d, %d, %d, %d> x2" : "mpconv_fwd_ws_kernel<%d, %d, %d, %d>", d->nin, KC, mode, xbuf);
+    p.prof = nullptr;
+#ifdef FGNN_ENABLE_PROF
+    static long long* prof_buf = nullptr;
+    if (getenv("FGNN_PROF")) {
+        if (!prof_buf) (void)hipMalloc(&prof_buf, 128 * 8);
+        (void)hipMemset(prof_buf, 0, 128 * 8);
+        p.prof = prof_buf;
+    }
+#endif
     void* args[] = {(void*)&p};
     e = hipLaunchKernel(fn, dim3(grid), dim3(WS_THREADS), args, lds, (hipStream_t)stream);
     if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "mpconv ws forward launch: %s", hipGetErrorString(e));
+#ifdef FGNN_ENABLE_PROF
+    if (p.prof) {                                     // tuning aid: per-stage timeline of workgroup 0 (shader clocks)
+        long long h[128];
+        (void)hipDeviceSynchronize();
+        (void)hipMemcpy(h, p.prof, sizeof(h), hipMemcpyDeviceToHost);
+        for (int w = 0; w < 16; ++w) {                 // slots: 0 / 1 = sample 8 started / finished, 3 / 4 = sample 9, 6 / 7 = sample 10
+            fprintf(stderr, "[fgnn prof ws fwd] wave %2d:", w);
+            for (int i = 0; i < 8; ++i) fprintf(stderr, " %6lld", h[w * 8 + i] ? h[w * 8 + i] - h[0] : -1);
+            fprintf(stderr, "\n");
+        }
+        p.prof = nullptr;
+    }
+#endif
     if (split) {                                                      // the upper 64 output channels of a 64 -> 128 call
         p.W += 256; p.y += 64;
         if (p.bias) p.bias += 64;
