@@ -581,6 +581,11 @@ __global__ __launch_bounds__(BS_THREADS, 4) void mpconv_bwd_sg_kernel(const BsPa
 // ----------------------------------------------------------------------------------------
 // host side
 // ----------------------------------------------------------------------------------------
+int fgnn_mpconv_backward_ws(const fgnn_mpconv_desc* d, const void* x, const int64_t* nn_idx, const void* etype,
+                            const float* filters, const void* gz, const uint8_t* argmax, void* gx, void* getype,
+                            float* gfilters, float* gbias, void* workspace, int64_t workspace_bytes,
+                            fgnn_stream_t stream);
+
 #define BS_REJECT(code) do { if (getenv("FGNN_TRACE")) fprintf(stderr, "[fgnn] sg backward rejects shape: rule %d\n", code); return 0; } while (0)
 
 // Returns 1 if launched, 0 if the call is outside this kernel's family, <0 on error.  d->reserved carries the largest
@@ -620,6 +625,11 @@ int fgnn_mpconv_backward_sg(const fgnn_mpconv_desc* d, const void* x, const int6
     else if (KC == 3 && NPW <= 3 && DPW <= 6) fn = GSL == 1 ? (void*)mpconv_bwd_sg_kernel<3, 6, 3, 6, 1> : (void*)mpconv_bwd_sg_kernel<3, 6, 3, 6, 2>;
     if (!fn) BS_REJECT(14);
 
+    if (!split) {                                     // third generation first (mpconv_bwd_ws.hip); 0 = not its shape
+        const int r = fgnn_mpconv_backward_ws(d, x, nn_idx, etype, filters, gz, argmax, gx, getype, gfilters, gbias, workspace,
+                                              workspace_bytes, stream);
+        if (r != 0) return r;
+    }
     BsParams p;
     p.x = (const uint16_t*)x; p.idx = nn_idx; p.et = (const uint16_t*)etype; p.W = filters;
     p.gz = (const uint16_t*)gz; p.argmax = argmax; p.gx = (uint16_t*)gx; p.get = (uint16_t*)getype;

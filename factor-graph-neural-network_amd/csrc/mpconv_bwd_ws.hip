@@ -1,0 +1,598 @@
+// mpconv_bwd_ws.hip — third-generation backward of the VF/FV message operator for the LDPC parity-check calls: bf16
+// channel-fastest x / gz / etype, 64 -> 64 channels, 4 edge types, max aggregation, degree 3 / 6, ONE neighbour table shared
+// by the batch whose transposed incidence has in-degree <= 3 / 6.  Same maths and rounding points as mpconv_bwd_sg.hip
+// (autograd through /root/reference/lib/model/mpnn/mp_nn.py:115-175):
+//
+//     G[(n,q),o]    = gz[m,o] [j == argmax[m,o]]   for the q-th in-edge (m, j) of source node n     (bf16, exact)
+//     P[n,o,e]      = sum_c x[n,c] W[c,o*4+e]                                                      (recomputed, bf16)
+//     detype[(n,q),e] = sum_o G[(n,q),o] P[n,o,e]
+//     dP[n,o,e]     = sum_q G[(n,q),o] etype[(n,q),e]                                              (bf16)
+//     dx[n,c]       = sum_col dP[n,col] W[c,col]      dW[c,col] += sum_n x[n,c] dP[n,col]      dbias[o] += sum_(n,q) G[(n,q),o]
+//
+// Why a third generation (profiles/r03/pmc_bwd_*.json, README): the second one kept the LDS busy 8 700 cycles per sample
+// (46 % of the launch, a quarter of it bank conflicts) and issued 7 400 VALU + 2 250 SALU instructions per wave — the
+// routing was done per (destination, channel lane) with a wave-private zero-restored image and an even/odd selector MFMA
+// (36 LDS cycles per destination), the dP phase re-derived its masks per in-edge and lane, dW transposed its operands in
+// registers.  Here the ROUTED gradient is materialised once per sample as the image G, rows sorted by SOURCE node, by
+// the threads that stage gz / argmax anyway (3 packed-16-bit VALU ops per dword and slot, conflict-free 16-byte stores):
+//   * detype becomes two v_mfma_f32_16x16x32_bf16 per four source nodes (A = 16 rows of G, B = the nodes' P rows kept
+//     edge-type-major): 48 MFMAs and 96 ds_read_b128 per sample, no VALU;
+//   * dP is one v_mfma_f32_4x4x4_16b_bf16 per node whose B operand is ONE ds_read_b64_tr_b16 of the node's G rows (the
+//     hardware transpose gives lane = channel its four in-edges) — no masks, no per-edge reads; a second 4x4x4 with an
+//     all-ones row accumulates dbias in the same pass;
+//   * dW's node-contracted operands come straight out of the row-major x / dP images through ds_read_b64_tr_b16;
+//   * projection, dx and dW use 32x32x16 tiles (half the operand traffic of 16x16x32); x arrives by LDS-DMA.
+// LDS work per sample ~3 600 cycles (was 8 700), VALU ~1 200 wave-instructions per sample and CU (was ~9 000).
+//
+// One 512-thread workgroup per CU (8 waves x 256 VGPRs), four barriers per sample (the P and dP images share their LDS: 49 + 50 KB do not fit
+// beside G's 49 KB):
+//   1  waves 0-7 project sample s                                   (x image -> P, edge-type-major, XOR-swizzled)
+//   2a all waves: detype MFMAs                                      (G, P -> getype staging)
+//   2b all waves: dP per source node; staging -> getype             (G, etT -> dP image, row stride 528 B)
+//   3  waves 0-1 dx, waves 2,3,6,7 dW (48 MFMAs per SIMD), waves 4-5 build G / etT of sample s+1 from registers prefetched in
+//      phase 1 and wait for its x (LDS-DMA)
+#include "fgnn_common.h"
+#include <stdlib.h>
+
+#define BW_THREADS 512       // 8 waves x 256 VGPRs: the roles' resident state (64 MFMA registers, 16 + 48 of the projection, ~60 of the staging) spills at 128
+#define BW_WAVES 8
+#define BW_MAXN 96
+#define BW_XROW 128           // x image row: 64 bf16, linear (LDS-DMA), 16-byte chunks XOR-swizzled by (node >> 1) & 7
+#define BW_GROW 128           // G image row (one in-edge slot of one source node): 64 bf16, chunks swizzled by (row >> 1) & 7
+#define BW_PROW 512           // P image row: [4 edge types][64 channels] bf16, chunks swizzled per (node, edge type)
+#define BW_DROW 528           // dP image row: [64 channels][4 edge types] bf16 + 16 (conflict-free b128 operand reads)
+
+typedef __bf16 bw_bf16x8 __attribute__((ext_vector_type(8)));
+typedef short bw_s16x4 __attribute__((ext_vector_type(4)));
+typedef float bw_f32x16 __attribute__((ext_vector_type(16)));
+
+struct BwParams {
+    const uint16_t* x;
+    const int64_t* idx;
+    const uint16_t* et;
+    const float* W;          // [64][256]
+    const uint16_t* gz;
+    const uint8_t* argmax;
+    uint16_t* gx;
+    uint16_t* get;
+    float* ws;               // per-workgroup slabs [grid][64*256 + 64]
+    int B, N, M, Npad;
+    int y_ld, w_ld;
+    long long x_sb, et_sb, y_sb;     // elements
+    int off_x, off_g, off_pd, off_et, off_gst, off_tab, off_slot, lds_bytes;      // byte offsets into LDS
+};
+
+extern __shared__ __attribute__((aligned(16))) unsigned char bw_lds[];
+
+void fgnn_launch_slab_reduce(const float* ws, int nslab, int64_t slab_len, int64_t nw, float* gW, float* gbias,
+                             hipStream_t st);
+
+__device__ __forceinline__ unsigned bw_pack2(float a, float b) {
+    typedef __bf16 v2 __attribute__((ext_vector_type(2)));
+    const v2 h = {(__bf16)a, (__bf16)b};
+    return __builtin_bit_cast(unsigned, h);
+}
+__device__ __forceinline__ bw_bf16x8 bw_frag_f32(const float* p8) {      // 8 consecutive f32 -> one fragment
+    const f32x4 a = *reinterpret_cast<const f32x4*>(p8), b = *reinterpret_cast<const f32x4*>(p8 + 4);
+    return __builtin_bit_cast(bw_bf16x8, make_uint4(bw_pack2(a[0], a[1]), bw_pack2(a[2], a[3]),
+                                                    bw_pack2(b[0], b[1]), bw_pack2(b[2], b[3])));
+}
+// LDS-DMA piece (64 lanes x 16 B -> lds_dst + 16 lane) and the waits the compiler cannot place (see mpconv_fwd_ws.hip)
+__device__ __forceinline__ void bw_dma16(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ void bw_wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// phase barrier: this wave's LDS operations done, then s_barrier — NOT __syncthreads(), which would also drain the gx /
+// getype stores and the next sample's prefetch loads four times per sample
+__device__ __forceinline__ void bw_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// ds_read_b64_tr_b16: the 16 lanes of a group each name 4 consecutive bf16 of a [4 keys][16 columns] block (lane i: key i >> 2,
+// columns 4 (i & 3) ..), lane c of the group receives column c of the four keys (tools/ubench/lds_dma_tr.hip)
+__device__ __forceinline__ uint2 bw_tr(unsigned lds_addr) {
+    typedef __attribute__((address_space(3))) bw_s16x4 lds_v4;
+    const bw_s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(reinterpret_cast<lds_v4*>(static_cast<uintptr_t>(lds_addr)));
+    return __builtin_bit_cast(uint2, v);
+}
+__device__ __forceinline__ int bw_swz_p(int n, int e) { return ((2 * (n & 3) + (e >> 1)) ^ ((n >> 2) & 1)) & 7; }
+
+// KC = destination degree (3 / 6), DEG = in-edge slots per source node the tables are sized for (6 / 3)
+template <int KC, int DEG>
+__global__ __launch_bounds__(BW_THREADS) void mpconv_bwd_ws_kernel(const BwParams p) {
+    constexpr int QS = DEG <= 4 ? 4 : 8;              // G rows per source node (slots >= DEG stay zero)
+    constexpr int NPG = 16 / QS;                      // source nodes per detype tile
+    constexpr int NSLOT = KC == 3 ? 6 : 3;            // staging items per builder thread (8 M <= 768 / 384 items, 128 builder threads)
+    constexpr int ESLOT = 3;                          // in-edge slots per builder thread (N QS <= 384)
+    constexpr int MAXNPW = KC == 6 ? 12 : 8;          // source nodes per wave in the dP phase: Npad / 8
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int l31 = lane & 31, lh = lane >> 5, i16 = lane & 15, g4 = lane >> 4;
+    const int N = p.N, M = p.M, Npad = p.Npad, mk = M * KC;
+    const unsigned lds0 = (unsigned)(uintptr_t)bw_lds;
+    int* tab = reinterpret_cast<int*>(bw_lds + p.off_tab);                // [N][DEG]   edge id m * KC + j of every in-edge, -1 = none
+    int* slot_of = reinterpret_cast<int*>(bw_lds + p.off_slot);           // [M * KC]   G row n * QS + q of every edge
+
+    // ---- setup: zero every image (pad rows of G / etT / dP are read as zeros for the kernel's lifetime), transposed incidence ----
+    for (int f = tid; f < p.lds_bytes / 4; f += BW_THREADS) reinterpret_cast<unsigned*>(bw_lds)[f] = 0u;
+    __syncthreads();
+    {
+        int* idx_s = reinterpret_cast<int*>(bw_lds + p.off_gst);          // (the getype staging area is free during setup)
+        for (int r = tid; r < mk; r += BW_THREADS) {
+            long long v = p.idx[r];
+            idx_s[r] = (int)(v < 0 ? 0 : (v >= N ? N - 1 : v));
+        }
+        for (int f = tid; f < N * DEG; f += BW_THREADS) tab[f] = -1;
+        __syncthreads();
+        for (int r = tid; r < mk; r += BW_THREADS) {
+            const int n = idx_s[r];
+            int pos = 0;
+            for (int q = 0; q < r; ++q) pos += idx_s[q] == n ? 1 : 0;     // rank among the in-edges of n, in (m, j) order
+            slot_of[r] = pos < DEG ? n * QS + pos : -1;                   // (host guarantees in-degree <= DEG)
+            if (pos < DEG) tab[n * DEG + pos] = r;
+        }
+        __syncthreads();
+        for (int r = tid; r < mk; r += BW_THREADS) idx_s[r] = 0;          // staging area back to zeros
+    }
+
+    // ---- roles ----
+    // phase 3: waves 0-1 dx (48 MFMAs each), waves 2,3,6,7 dW (24 each; waves w and w + 4 share a SIMD: 48 per SIMD either way),
+    // waves 4-5 — the SIMD mates of the dx waves, VALU beside MFMA — stage the next sample and own the LDS-DMA of x
+    const bool dx_wave = wave < 2;
+    const bool dw_wave = wave == 2 || wave == 3 || wave == 6 || wave == 7;
+    const bool build_wave = wave == 4 || wave == 5;
+    const bool dma_wave = build_wave;
+    const int bl = (wave - 4) * 64 + lane;                                // builder-local thread index 0..127
+
+    // builder: staging item (destination m, 8-channel chunk c8) -> the 16-byte piece of each of its KC G rows
+    unsigned goff[NSLOT][KC];
+    unsigned gsrc_el[NSLOT];
+    bool item_ok[NSLOT];
+#pragma unroll
+    for (int sl = 0; sl < NSLOT; ++sl) {
+        const int item = bl + 128 * sl;
+        item_ok[sl] = build_wave && item < 8 * M;
+        const int m = min(item >> 3, M - 1), c8 = item & 7;
+        gsrc_el[sl] = (unsigned)(m * p.y_ld + 8 * c8);
+#pragma unroll
+        for (int j = 0; j < KC; ++j) {
+            const int R = item_ok[sl] ? slot_of[m * KC + j] : -1;
+            goff[sl][j] = R >= 0 ? (unsigned)(p.off_g + R * BW_GROW + ((c8 ^ ((R >> 1) & 7)) << 4)) : 0xffffffffu;
+        }
+    }
+    // builder: in-edge slot (n, q) = bl -> its edge-type row, transposed into etT[n][e][q]
+    int et_src[ESLOT];
+    unsigned et_dst[ESLOT];
+#pragma unroll
+    for (int sl = 0; sl < ESLOT; ++sl) {
+        et_src[sl] = -1;
+        et_dst[sl] = 0;
+        const int is = bl + 128 * sl;
+        if (build_wave && is < N * QS) {
+            const int n = is / QS, q = is - n * QS;
+            if (q < DEG) et_src[sl] = tab[n * DEG + q];
+            et_dst[sl] = (unsigned)(p.off_et + ((n * 4) * QS + q) * 2);
+        }
+    }
+    // LDS-DMA of x: pieces (wave - 4) + 2 u of Npad / 8; rows >= N re-read row N - 1 (finite; their dP rows are zero)
+    unsigned dsrc[6];
+#pragma unroll
+    for (int u = 0; u < 6; ++u) {
+        const int slot = 64 * ((wave - 4) + 2 * u) + lane, row = slot >> 3, pos = slot & 7;
+        dsrc[u] = (unsigned)(min(row, N - 1) * BW_XROW + ((pos ^ ((row >> 1) & 7)) << 4));
+    }
+    const int npieces = Npad / 8;
+
+    // projection (all eight waves): column tile T = wave = (16-channel block ob, edge-type pair ep); A row i = 8 g + 4 h + r is
+    // (edge type 2 ep + (g >> 1), channel 16 ob + 8 h + 4 (g & 1) + r): an output lane (node, h) then holds, per edge type of the
+    // pair, EIGHT consecutive channels = one 16-byte chunk of the node's edge-type-major P row
+    bw_bf16x8 aP[4];
+    unsigned xoff[4], pwo[2];
+    {
+        const int ob = (wave & 7) >> 1, ep = wave & 1;
+        const int g = l31 >> 3, h = (l31 >> 2) & 1, r = l31 & 3;
+        const int col = 4 * (16 * ob + 8 * h + 4 * (g & 1) + r) + 2 * ep + (g >> 1);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            alignas(16) float w8[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) w8[u] = p.W[(int64_t)(16 * kk + 8 * lh + u) * p.w_ld + col];
+            aP[kk] = bw_frag_f32(w8);
+            xoff[kk] = (unsigned)(l31 * BW_XROW + (((2 * kk + lh) ^ ((l31 >> 1) & 7)) << 4));
+        }
+#pragma unroll
+        for (int el = 0; el < 2; ++el)
+            pwo[el] = (unsigned)(p.off_pd + l31 * BW_PROW + (2 * ep + el) * 128 + (((2 * ob + lh) ^ bw_swz_p(l31, 2 * ep + el)) << 4));
+    }
+    // dP phase: address pattern of the transpose read of a node's G rows.  Lane i16 of group g4 names (row n QS + 4 h4 + (i16 >> 2),
+    // chunk 2 g4 + ((i16 & 3) >> 1), half i16 & 1); the row's swizzle (R >> 1) & 7 depends on the node only through n mod (8 / QS),
+    // and a wave's first node is a multiple of 4: one pattern per (i mod 4, h4), the node's base added as a scalar
+    const int npw = Npad / 8;
+    unsigned gpat[4][QS / 4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v)
+#pragma unroll
+        for (int h4 = 0; h4 < QS / 4; ++h4) {
+            const int R = v * QS + 4 * h4 + (i16 >> 2);
+            const int chunk = 2 * g4 + ((i16 & 3) >> 1);
+            gpat[v][h4] = lds0 + (unsigned)(p.off_g + (4 * h4 + (i16 >> 2)) * BW_GROW + ((chunk ^ ((R >> 1) & 7)) << 4) + 8 * (i16 & 1));
+        }
+    // dx (waves 0-1): A of dx^T = W dP^T, channel tile ct = wave: W[32 ct + l31][16 ks + 8 lh ..+7], ks = 0..15 -> RA[0..3] (64 VGPRs)
+    // dW (waves 2,3,6,7): RA = the four 32x32 accumulators (channel tile 0/1) x (column tiles 2 dwi, 2 dwi + 1)
+    bw_f32x16 RA[4];
+    const int dwi = wave < 4 ? wave - 2 : wave - 4;
+    if (dx_wave) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int sub = 0; sub < 4; ++sub) {
+                const f32x4 f = __builtin_bit_cast(f32x4, bw_frag_f32(p.W + (int64_t)(32 * wave + l31) * p.w_ld + 16 * (4 * t + sub) + 8 * lh));
+#pragma unroll
+                for (int u = 0; u < 4; ++u) RA[t][4 * sub + u] = f[u];
+            }
+    } else {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int u = 0; u < 16; ++u) RA[t][u] = 0.f;
+    }
+    // dW transpose-read offsets: segment of lane i16 in group g4 = (node 8 (g4 >> 1) + (i16 >> 2) [+ 4], columns 16 (g4 & 1) + 4 (i16 & 3) ..)
+    unsigned xa[2][2], db[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int nd = 8 * (g4 >> 1) + (i16 >> 2) + 4 * r;
+        const int fx = (nd >> 1) & 7;                                     // (+ 16 ks leaves it unchanged)
+#pragma unroll
+        for (int c2 = 0; c2 < 2; ++c2) {
+            const int chunk = 4 * c2 + 2 * (g4 & 1) + ((i16 & 3) >> 1);
+            xa[c2][r] = (unsigned)(nd * BW_XROW + ((chunk ^ fx) << 4) + 8 * (i16 & 1));
+        }
+        db[r] = lds0 + (unsigned)(p.off_pd + nd * BW_DROW + (64 * dwi + 16 * (g4 & 1) + 4 * (i16 & 3)) * 2);
+    }
+    bw_s16x4 ones_row0;
+    {
+        const short o = (lane & 3) == 0 ? (short)0x3f80 : (short)0;
+        ones_row0 = (bw_s16x4){o, o, o, o};
+    }
+    f32x4 dbacc = {0.f, 0.f, 0.f, 0.f};                // [0]: dbias of channel `lane` over this wave's nodes
+
+    const int chunk_b = (p.B + gridDim.x - 1) / gridDim.x;
+    const int b_begin = blockIdx.x * chunk_b, b_end = min(p.B, b_begin + chunk_b);
+    const unsigned char* xg = reinterpret_cast<const unsigned char*>(p.x);
+
+    // ---- staging pieces ----
+    uint4 pg[NSLOT];
+    uint2 pa[NSLOT], pe[ESLOT];
+    auto prefetch = [&](int b) {                       // builder threads: gz / argmax of their items, the edge-type row of their in-edge
+        const unsigned char* gzb = reinterpret_cast<const unsigned char*>(p.gz + (int64_t)b * p.y_sb);
+        const unsigned char* amb = p.argmax + (int64_t)b * p.y_sb;
+#pragma unroll
+        for (int sl = 0; sl < NSLOT; ++sl) {
+            pg[sl] = make_uint4(0, 0, 0, 0);
+            pa[sl] = make_uint2(0, 0);
+            if (item_ok[sl]) {
+                pg[sl] = *reinterpret_cast<const uint4*>(gzb + gsrc_el[sl] * 2u);
+                pa[sl] = *reinterpret_cast<const uint2*>(amb + gsrc_el[sl]);
+            }
+        }
+#pragma unroll
+        for (int sl = 0; sl < ESLOT; ++sl) {
+            pe[sl] = make_uint2(0, 0);
+            if (et_src[sl] >= 0)
+                pe[sl] = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned char*>(p.et + (int64_t)b * p.et_sb) + et_src[sl] * 8);
+        }
+    };
+    auto dma_x = [&](int b, int buf) {                 // waves 4-5
+        const unsigned char* xb = xg + (int64_t)b * p.x_sb * 2;
+#pragma unroll
+        for (int u = 0; u < 6; ++u) {
+            const int piece = (wave - 4) + 2 * u;
+            if (piece < npieces) bw_dma16(xb + dsrc[u], lds0 + (unsigned)(p.off_x + buf * (BW_MAXN * BW_XROW) + piece * 1024));
+        }
+    };
+    auto build = [&]() {                               // prefetched registers -> etT, G
+#pragma unroll
+        for (int sl = 0; sl < ESLOT; ++sl) {
+            if (et_src[sl] >= 0) {
+                uint16_t* ew = reinterpret_cast<uint16_t*>(bw_lds + et_dst[sl]);
+                ew[0] = (uint16_t)pe[sl].x; ew[QS] = (uint16_t)(pe[sl].x >> 16);
+                ew[2 * QS] = (uint16_t)pe[sl].y; ew[3 * QS] = (uint16_t)(pe[sl].y >> 16);
+            }
+        }
+#pragma unroll
+        for (int sl = 0; sl < NSLOT; ++sl) {
+            if (item_ok[sl]) {
+                // argmax bytes -> 16-bit halves, one-hot per half; slot j keeps a gz half where bit j is set:
+                // (onehot << (15 - j)) >> 15 (arithmetic, per half) is the 16-bit mask
+                typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+                typedef short s16x2 __attribute__((ext_vector_type(2)));
+                const unsigned gq[4] = {pg[sl].x, pg[sl].y, pg[sl].z, pg[sl].w};
+                u16x2 oh[4];
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    const unsigned src = d < 2 ? pa[sl].x : pa[sl].y;
+                    const unsigned a2 = __builtin_amdgcn_perm(0u, src, (d & 1) ? 0x0c030c02u : 0x0c010c00u) & 0x00070007u;
+                    oh[d] = (u16x2){1, 1} << __builtin_bit_cast(u16x2, a2);
+                }
+#pragma unroll
+                for (int j = 0; j < KC; ++j) {
+                    unsigned w[4];
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) {
+                        const s16x2 msk = __builtin_bit_cast(s16x2, (u16x2)(oh[d] << (u16x2){(unsigned short)(15 - j), (unsigned short)(15 - j)})) >> (s16x2){15, 15};
+                        w[d] = gq[d] & __builtin_bit_cast(unsigned, msk);
+                    }
+                    if (goff[sl][j] != 0xffffffffu) *reinterpret_cast<uint4*>(bw_lds + goff[sl][j]) = make_uint4(w[0], w[1], w[2], w[3]);
+                }
+            }
+        }
+    };
+
+    // ---- pipeline fill: sample b_begin staged ----
+    if (b_begin < b_end) {
+        if (dma_wave) dma_x(b_begin, 0);
+        prefetch(b_begin);
+        build();
+        if (dma_wave) bw_wait_vm0();
+    }
+    bw_barrier();
+    const int ntile = Npad / 32;
+    int cur = 0;
+
+    for (int b = b_begin; b < b_end; ++b) {
+        const unsigned char* xs = bw_lds + p.off_x + cur * (BW_MAXN * BW_XROW);
+        const bool has_next = b + 1 < b_end;
+        if (has_next) {
+            if (dma_wave) dma_x(b + 1, cur ^ 1);       // (the other x buffer was last read by dW of sample b - 1)
+            prefetch(b + 1);
+        }
+        // ================= phase 1: P^T tile of this wave (32 columns) for every node tile, three independent chains =================
+        {
+            bw_f32x16 acc[3];
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+#pragma unroll
+                for (int u = 0; u < 16; ++u) acc[t][u] = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    if (t < ntile) {
+                        const bw_bf16x8 bf = __builtin_bit_cast(bw_bf16x8, *reinterpret_cast<const uint4*>(xs + t * 32 * BW_XROW + xoff[kk]));
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aP[kk], bf, acc[t], 0, 0, 0);
+                    }
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                if (t < ntile) {
+                    unsigned char* pp0 = bw_lds + t * 32 * BW_PROW + pwo[0];
+                    unsigned char* pp1 = bw_lds + t * 32 * BW_PROW + pwo[1];
+                    *reinterpret_cast<uint4*>(pp0) = make_uint4(bw_pack2(acc[t][0], acc[t][1]), bw_pack2(acc[t][2], acc[t][3]),
+                                                                bw_pack2(acc[t][4], acc[t][5]), bw_pack2(acc[t][6], acc[t][7]));
+                    *reinterpret_cast<uint4*>(pp1) = make_uint4(bw_pack2(acc[t][8], acc[t][9]), bw_pack2(acc[t][10], acc[t][11]),
+                                                                bw_pack2(acc[t][12], acc[t][13]), bw_pack2(acc[t][14], acc[t][15]));
+                }
+            }
+        }
+        bw_barrier();
+        // ================= phase 2a: detype[(n,q),e] = sum_o G[(n,q),o] P[n,o,e], NPG source nodes per 16x16x32 tile =================
+        {
+            uint16_t* gst = reinterpret_cast<uint16_t*>(bw_lds + p.off_gst);
+#pragma unroll 1
+            for (int sl = 0; sl < 4; ++sl) {
+                const int gi = wave + 8 * sl;
+                if (gi * NPG < Npad) {
+                    const int R = gi * 16 + i16;
+                    const unsigned ab = (unsigned)(p.off_g + R * BW_GROW), as = (unsigned)((g4 ^ ((R >> 1) & 7)) << 4);
+                    const int jn = QS == 4 ? (i16 >> 2) : ((i16 & 7) >> 2), e = i16 & 3;
+                    const int nb = gi * NPG + jn;
+                    const unsigned bb = (unsigned)(p.off_pd + nb * BW_PROW + e * 128), bs = (unsigned)((g4 ^ bw_swz_p(nb, e)) << 4);
+                    const bw_bf16x8 a0 = __builtin_bit_cast(bw_bf16x8, *reinterpret_cast<const uint4*>(bw_lds + ab + as));
+                    const bw_bf16x8 b0 = __builtin_bit_cast(bw_bf16x8, *reinterpret_cast<const uint4*>(bw_lds + bb + bs));
+                    const bw_bf16x8 a1 = __builtin_bit_cast(bw_bf16x8, *reinterpret_cast<const uint4*>(bw_lds + ab + (as ^ 64u)));
+                    const bw_bf16x8 b1 = __builtin_bit_cast(bw_bf16x8, *reinterpret_cast<const uint4*>(bw_lds + bb + (bs ^ 64u)));
+                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b0, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b1, acc, 0, 0, 0);
+                    // D[i = 4 g4 + r][j = i16]: useful where row and column name the same node
+                    bool ok;
+                    int n, q0;
+                    if (QS == 4) { ok = g4 == (i16 >> 2); n = gi * 4 + g4; q0 = 0; }
+                    else { ok = i16 < 8 && (g4 >> 1) == (i16 >> 2); n = gi * 2 + (g4 >> 1); q0 = 4 * (g4 & 1); }
+                    if (ok && n < N) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            if (q0 + r < DEG) {
+                                const int edge = tab[n * DEG + q0 + r];
+                                if (edge >= 0) gst[e * mk + edge] = (uint16_t)(bw_pack2(acc[r], 0.f) & 0xffffu);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        bw_barrier();
+        // ================= phase 2b: dP per source node (one transpose read + one 4x4x4 MFMA per four in-edge slots) =================
+        {
+            static_assert(MAXNPW % 4 == 0, "nodes per wave in groups of four");
+#pragma unroll 1
+            for (int i0 = 0; i0 < npw; i0 += 4) {     // (rolled: unrolled, the scheduler hoists every node's reads and spills)
+#pragma unroll
+              for (int v = 0; v < 4; ++v) {
+                const int i = i0 + v;
+                {
+                    const int n = wave * npw + i;
+                    uint2 outv = make_uint2(0u, 0u);
+                    if (n < N) {
+                        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int h4 = 0; h4 < QS / 4; ++h4) {
+                            const uint2 bv = bw_tr(gpat[v][h4] + (unsigned)(n * QS * BW_GROW));
+                            const uint2 av = *reinterpret_cast<const uint2*>(bw_lds + p.off_et + ((n * 4 + (lane & 3)) * QS + 4 * h4) * 2);
+                            const bw_s16x4 b4 = __builtin_bit_cast(bw_s16x4, bv);
+                            acc = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(__builtin_bit_cast(bw_s16x4, av), b4, acc, 0, 0, 0);
+                            dbacc = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(ones_row0, b4, dbacc, 0, 0, 0);
+                        }
+                        outv = make_uint2(bw_pack2(acc[0], acc[1]), bw_pack2(acc[2], acc[3]));
+                    }
+                    *reinterpret_cast<uint2*>(bw_lds + p.off_pd + n * BW_DROW + lane * 8) = outv;      // (pad nodes: zeros for dW)
+                }
+              }
+            }
+            // edge-type gradient of this sample: staging -> memory, 16 bytes per lane (8 mk bytes; host: mk even, 16-byte aligned)
+            const int nvec = (8 * mk) >> 4;
+            if (tid < nvec) {
+                const uint4 v = *reinterpret_cast<const uint4*>(bw_lds + p.off_gst + tid * 16);
+                *reinterpret_cast<uint4*>(reinterpret_cast<unsigned char*>(p.get + (int64_t)b * 4 * mk) + tid * 16) = v;
+            }
+        }
+        bw_barrier();
+        // ================= phase 3: dx | dW | staging of the next sample =================
+        if (dx_wave) {
+            uint16_t* gxb = p.gx + (int64_t)b * p.x_sb;
+#pragma unroll 1
+            for (int nt = 0; nt < ntile; ++nt) {
+                {
+                    // two chains over the even / odd k-steps: one chain of 16 dependent MFMAs would idle the pipe half the time
+                    bw_f32x16 ae, ao;
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) { ae[u] = 0.f; ao[u] = 0.f; }
+                    const unsigned char* bp = bw_lds + p.off_pd + (nt * 32 + l31) * BW_DROW + lh * 16;
+#pragma unroll
+                    for (int ks = 0; ks < 16; ks += 2) {
+                        const bw_bf16x8 b0 = __builtin_bit_cast(bw_bf16x8, *reinterpret_cast<const uint4*>(bp + 32 * ks));
+                        const bw_bf16x8 b1 = __builtin_bit_cast(bw_bf16x8, *reinterpret_cast<const uint4*>(bp + 32 * ks + 32));
+                        f32x4 f0, f1;
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) { f0[u] = RA[ks >> 2][4 * (ks & 3) + u]; f1[u] = RA[(ks + 1) >> 2][4 * ((ks + 1) & 3) + u]; }
+                        ae = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bw_bf16x8, f0), b0, ae, 0, 0, 0);
+                        ao = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bw_bf16x8, f1), b1, ao, 0, 0, 0);
+                    }
+                    const int n = nt * 32 + l31;
+                    if (n < N) {
+#pragma unroll
+                        for (int g = 0; g < 4; ++g)
+                            *reinterpret_cast<uint2*>(gxb + n * 64 + 32 * wave + 8 * g + 4 * lh) =
+                                make_uint2(bw_pack2(ae[4 * g] + ao[4 * g], ae[4 * g + 1] + ao[4 * g + 1]),
+                                           bw_pack2(ae[4 * g + 2] + ao[4 * g + 2], ae[4 * g + 3] + ao[4 * g + 3]));
+                    }
+                }
+            }
+        } else if (dw_wave) {
+            const unsigned xbase = lds0 + (unsigned)(p.off_x + cur * (BW_MAXN * BW_XROW));
+            const int nks = Npad / 16;
+            for (int ks = 0; ks < nks; ++ks) {
+                bw_bf16x8 fa[2], fb[2];
+#pragma unroll
+                for (int c2 = 0; c2 < 2; ++c2) {
+                    const uint2 lo = bw_tr(xbase + xa[c2][0] + ks * (16 * BW_XROW)), hi = bw_tr(xbase + xa[c2][1] + ks * (16 * BW_XROW));
+                    fa[c2] = __builtin_bit_cast(bw_bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));
+                }
+#pragma unroll
+                for (int cj = 0; cj < 2; ++cj) {
+                    const uint2 lo = bw_tr(db[0] + ks * (16 * BW_DROW) + cj * 64), hi = bw_tr(db[1] + ks * (16 * BW_DROW) + cj * 64);
+                    fb[cj] = __builtin_bit_cast(bw_bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));
+                }
+#pragma unroll
+                for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+                    for (int cj = 0; cj < 2; ++cj)
+                        RA[2 * c2 + cj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[c2], fb[cj], RA[2 * c2 + cj], 0, 0, 0);
+            }
+        } else if (has_next) {
+            build();                                   // G / etT of sample b + 1 (their readers finished in phase 2b)
+        }
+        if (dma_wave && has_next) bw_wait_vm0();       // x of sample b + 1 has landed (these waves store nothing)
+        bw_barrier();
+        cur ^= 1;
+    }   // samples
+
+    // ---- flush dW tiles and dbias into this workgroup's slab (summed by the slab reduce, fixed order) ----
+    if (b_begin < b_end) {
+        float* slab = p.ws + (int64_t)blockIdx.x * (64 * 256 + 64);
+        if (dw_wave) {
+#pragma unroll
+            for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+                for (int cj = 0; cj < 2; ++cj) {
+                    const int col = 32 * (2 * dwi + cj) + l31;
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) {
+                        const int c = 32 * c2 + (u & 3) + 8 * (u >> 2) + 4 * lh;
+                        slab[c * 256 + col] = RA[2 * c2 + cj][u];
+                    }
+                }
+        }
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(bw_lds + p.off_x);          // [8 waves][64 channels]
+        red[wave * 64 + lane] = dbacc[0];
+        __syncthreads();
+        if (tid < 64) {
+            float s = 0.f;
+            for (int w = 0; w < BW_WAVES; ++w) s += red[w * 64 + tid];
+            slab[64 * 256 + tid] = s;
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------------------
+// host side
+// ----------------------------------------------------------------------------------------
+#define BW_REJECT(code) do { if (getenv("FGNN_TRACE")) fprintf(stderr, "[fgnn] ws backward rejects shape: rule %d\n", code); return 0; } while (0)
+
+// Called first by fgnn_mpconv_backward_sg (mpconv_bwd_sg.hip) for the 64 -> 64 calls: 1 = launched, 0 = not this kernel's
+// shape (the second-generation kernel takes it), < 0 = error.
+int fgnn_mpconv_backward_ws(const fgnn_mpconv_desc* d, const void* x, const int64_t* nn_idx, const void* etype,
+                            const float* filters, const void* gz, const uint8_t* argmax, void* gx, void* getype,
+                            float* gfilters, float* gbias, void* workspace, int64_t workspace_bytes,
+                            fgnn_stream_t stream) {
+    static const bool off = getenv("FGNN_NO_WS") != nullptr || getenv("FGNN_NO_WS_BWD") != nullptr;
+    if (off) BW_REJECT(0);
+    if (d->nin != 64 || d->nou != 64) BW_REJECT(1);
+    const int KC = d->k, DEG = KC == 6 ? 3 : 6;
+    const int indeg = d->reserved & 0xffff;
+    if (indeg < 1 || indeg > DEG) BW_REJECT(2);
+    if (KC == 6 ? (d->N > 96 || d->M > 48) : (d->N > 48 || d->M > 96)) BW_REJECT(3);
+    if ((d->M * KC) & 1) BW_REJECT(4);                                  // getype leaves as whole 16-byte lanes
+    if (((uintptr_t)getype & 15) || ((uintptr_t)x & 15) || ((uintptr_t)gz & 15) || ((uintptr_t)argmax & 7) || ((uintptr_t)gx & 7) ||
+        ((uintptr_t)etype & 7)) BW_REJECT(5);
+    if ((d->x_sb % 8) != 0 || (d->y_sb % 8) != 0 || (d->et_sb % 4) != 0) BW_REJECT(6);
+    const int64_t nw = 64 * 256, slab_len = nw + 64;
+    if (!workspace || workspace_bytes < 256 * slab_len * 4) BW_REJECT(7);
+
+    BwParams p;
+    p.x = (const uint16_t*)x; p.idx = nn_idx; p.et = (const uint16_t*)etype; p.W = filters;
+    p.gz = (const uint16_t*)gz; p.argmax = argmax; p.gx = (uint16_t*)gx; p.get = (uint16_t*)getype;
+    p.ws = (float*)workspace;
+    p.B = d->B; p.N = d->N; p.M = d->M; p.Npad = fgnn_round_up(d->N, 32);
+    p.y_ld = d->nou; p.w_ld = d->nou * 4;
+    p.x_sb = d->x_sb; p.et_sb = d->et_sb; p.y_sb = d->y_sb;
+    const int QS = DEG <= 4 ? 4 : 8;
+    int off_b = 0;
+    auto take = [&](int bytes) { const int o = off_b; off_b = fgnn_round_up(off_b + bytes, 16); return o; };
+    p.off_x = take(2 * BW_MAXN * BW_XROW);
+    p.off_g = take(p.Npad * QS * BW_GROW);
+    p.off_pd = take(p.Npad * BW_DROW);
+    p.off_et = take(p.Npad * 4 * QS * 2);
+    p.off_gst = take(fgnn_round_up(8 * d->M * KC, 16) + 16);
+    p.off_tab = take(d->N * DEG * 4);
+    p.off_slot = take(d->M * KC * 4);
+    p.lds_bytes = off_b;
+    if (off_b > 160 * 1024) BW_REJECT(8);
+    void* fn = KC == 6 ? (void*)mpconv_bwd_ws_kernel<6, 3> : (void*)mpconv_bwd_ws_kernel<3, 6>;
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, off_b);
+    if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "hipFuncSetAttribute(%d B LDS): %s", off_b, hipGetErrorString(e));
+    int grid = 256;
+    if (grid > d->B) grid = d->B;
+    const int chunk = (d->B + grid - 1) / grid;
+    grid = (d->B + chunk - 1) / chunk;
+    hipStream_t st = (hipStream_t)stream;
+    fgnn_note_kernel("mpconv_bwd_ws_kernel<%d, %d>", KC, DEG);
+    void* args[] = {(void*)&p};
+    e = hipLaunchKernel(fn, dim3(grid), dim3(BW_THREADS), args, off_b, st);
+    if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "mpconv ws backward launch: %s", hipGetErrorString(e));
+    fgnn_launch_slab_reduce(p.ws, grid, slab_len, nw, gfilters, gbias, st);
+    e = hipGetLastError();
+    if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "mpconv backward helper launch: %s", hipGetErrorString(e));
+    return 1;
+}
