@@ -56,11 +56,20 @@ struct BwParams {
     uint16_t* gx;
     uint16_t* get;
     float* ws;               // per-workgroup slabs [grid][64*256 + 64]
-    int B, N, M, Npad;
+    int B, N, M;
     int y_ld, w_ld;
     long long x_sb, et_sb, y_sb;     // elements
-    int off_x, off_g, off_pd, off_et, off_gst, off_tab, off_slot, lds_bytes;      // byte offsets into LDS
+    long long* prof;         // FGNN_PROF (builds with -DFGNN_ENABLE_PROF only): phase timeline
 };
+
+// phase-timeline stamps (tuning aid): workgroup 0, its fourth sample, every wave: slot k = arrival at / release from the barriers
+#ifdef FGNN_ENABLE_PROF
+#define BW_STAMP(slot) do { if (p.prof && blockIdx.x == 0 && lane == 0 && b == b_begin + 3) p.prof[wave * 16 + (slot)] = __builtin_readcyclecounter(); } while (0)
+#define BW_STAMP_G(slot) do { if (p.prof && blockIdx.x == 0 && tid == 0 && (slot) < 128) p.prof[128 + (slot)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define BW_STAMP(slot) do { } while (0)
+#define BW_STAMP_G(slot) do { } while (0)
+#endif
 
 extern __shared__ __attribute__((aligned(16))) unsigned char bw_lds[];
 
@@ -94,93 +103,90 @@ __device__ __forceinline__ uint2 bw_tr(unsigned lds_addr) {
     const bw_s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(reinterpret_cast<lds_v4*>(static_cast<uintptr_t>(lds_addr)));
     return __builtin_bit_cast(uint2, v);
 }
+// uniform 64-bit base + UNSIGNED 32-bit per-lane byte offset: the form that compiles to `global_load v, v_off, s[base]` (anything
+// else becomes a per-lane 64-bit pointer, hoisted out of the sample loop and spilled)
+template <typename T> __device__ __forceinline__ const T* bw_at(const void* base, unsigned byte_off) {
+    return reinterpret_cast<const T*>(static_cast<const char*>(base) + byte_off);
+}
+template <typename T> __device__ __forceinline__ T* bw_at(void* base, unsigned byte_off) {
+    return reinterpret_cast<T*>(static_cast<char*>(base) + byte_off);
+}
 __device__ __forceinline__ int bw_swz_p(int n, int e) { return ((2 * (n & 3) + (e >> 1)) ^ ((n >> 2) & 1)) & 7; }
+
+// LDS layout, fixed per instance (sized for the largest graph the instance takes: no shape-dependent scalar branches or
+// offsets in the sample loop — as runtime values they cost ~100 live SGPRs, spilled to VGPR lanes, and a branch per node)
+template <int KC> struct BwLayout {
+    static constexpr int DEG = KC == 6 ? 3 : 6, QS = DEG <= 4 ? 4 : 8;
+    static constexpr int NMAX = KC == 6 ? 96 : 64, MMAX = KC == 6 ? 48 : 96;
+    static constexpr int OFF_X = 0;                                            // 3 x [96][128 B]: samples s, s + 1, s + 2
+    static constexpr int OFF_G = OFF_X + 3 * BW_MAXN * BW_XROW;                // [NMAX][QS][128 B]
+    static constexpr int OFF_PD = OFF_G + NMAX * QS * BW_GROW;                 // P [NMAX][512 B], then dP [NMAX][528 B]
+    static constexpr int OFF_ET = OFF_PD + NMAX * BW_DROW;                     // etT [NMAX][4][QS] bf16
+    static constexpr int OFF_GST = OFF_ET + NMAX * 4 * QS * 2;                 // getype staging [4][M KC] bf16
+    static constexpr int OFF_TAB = OFF_GST + 8 * MMAX * KC + 16;               // [NMAX][QS] int (+ one all -1 row)
+    static constexpr int OFF_SLOT = OFF_TAB + NMAX * QS * 4 + 16;              // [M KC] int
+    static constexpr int OFF_GT = OFF_SLOT + MMAX * KC * 4;                    // [8 M][KC] unsigned
+    static constexpr int OFF_DUMP = OFF_GT + 8 * MMAX * KC * 4;                // 16 bytes nobody reads (pieces of in-edges beyond DEG)
+    static constexpr int BYTES = OFF_DUMP + 16;
+};
 
 // KC = destination degree (3 / 6), DEG = in-edge slots per source node the tables are sized for (6 / 3)
 template <int KC, int DEG>
 __global__ __launch_bounds__(BW_THREADS) void mpconv_bwd_ws_kernel(const BwParams p) {
-    constexpr int QS = DEG <= 4 ? 4 : 8;              // G rows per source node (slots >= DEG stay zero)
+    typedef BwLayout<KC> LY;
+    constexpr int QS = LY::QS;                        // G rows per source node (slots >= DEG stay zero)
+    constexpr int NMAX = LY::NMAX;                    // node rows every image is sized (and every loop runs) for
+    constexpr int OFF_X = LY::OFF_X, OFF_G = LY::OFF_G, OFF_PD = LY::OFF_PD, OFF_ET = LY::OFF_ET, OFF_GST = LY::OFF_GST,
+                  OFF_TAB = LY::OFF_TAB, OFF_SLOT = LY::OFF_SLOT, OFF_GT = LY::OFF_GT;
     constexpr int NPG = 16 / QS;                      // source nodes per detype tile
+    constexpr int NG = KC == 6 ? 3 : 4;               // detype tiles per wave: Npad / NPG / 8
     constexpr int NSLOT = KC == 3 ? 6 : 3;            // staging items per builder thread (8 M <= 768 / 384 items, 128 builder threads)
     constexpr int ESLOT = 3;                          // in-edge slots per builder thread (N QS <= 384)
     constexpr int MAXNPW = KC == 6 ? 12 : 8;          // source nodes per wave in the dP phase: Npad / 8
     const int tid = threadIdx.x;
+    BW_STAMP_G(0);
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int l31 = lane & 31, lh = lane >> 5, i16 = lane & 15, g4 = lane >> 4;
-    const int N = p.N, M = p.M, Npad = p.Npad, mk = M * KC;
+    const int N = p.N, M = p.M, mk = M * KC;
+    constexpr int Npad = NMAX;
     const unsigned lds0 = (unsigned)(uintptr_t)bw_lds;
-    int* tab = reinterpret_cast<int*>(bw_lds + p.off_tab);                // [N][DEG]   edge id m * KC + j of every in-edge, -1 = none
-    int* slot_of = reinterpret_cast<int*>(bw_lds + p.off_slot);           // [M * KC]   G row n * QS + q of every edge
+    int* tab = reinterpret_cast<int*>(bw_lds + OFF_TAB);                // [Npad][QS]  edge id m * KC + j of every in-edge slot, -1 = none
+    int* slot_of = reinterpret_cast<int*>(bw_lds + OFF_SLOT);           // [M * KC]    G row n * QS + q of every edge
+    unsigned* gtab = reinterpret_cast<unsigned*>(bw_lds + OFF_GT);      // [8 M][KC]   LDS address of a staging item's piece of each of its KC G rows
 
-    // ---- setup: zero every image (pad rows of G / etT / dP are read as zeros for the kernel's lifetime), transposed incidence ----
-    for (int f = tid; f < p.lds_bytes / 4; f += BW_THREADS) reinterpret_cast<unsigned*>(bw_lds)[f] = 0u;
-    __syncthreads();
-    {
-        int* idx_s = reinterpret_cast<int*>(bw_lds + p.off_gst);          // (the getype staging area is free during setup)
-        for (int r = tid; r < mk; r += BW_THREADS) {
-            long long v = p.idx[r];
-            idx_s[r] = (int)(v < 0 ? 0 : (v >= N ? N - 1 : v));
-        }
-        for (int f = tid; f < N * DEG; f += BW_THREADS) tab[f] = -1;
-        __syncthreads();
-        for (int r = tid; r < mk; r += BW_THREADS) {
-            const int n = idx_s[r];
-            int pos = 0;
-            for (int q = 0; q < r; ++q) pos += idx_s[q] == n ? 1 : 0;     // rank among the in-edges of n, in (m, j) order
-            slot_of[r] = pos < DEG ? n * QS + pos : -1;                   // (host guarantees in-degree <= DEG)
-            if (pos < DEG) tab[n * DEG + pos] = r;
-        }
-        __syncthreads();
-        for (int r = tid; r < mk; r += BW_THREADS) idx_s[r] = 0;          // staging area back to zeros
-    }
-
+    BW_STAMP_G(1);
     // ---- roles ----
     // phase 3: waves 0-1 dx (48 MFMAs each), waves 2,3,6,7 dW (24 each; waves w and w + 4 share a SIMD: 48 per SIMD either way),
     // waves 4-5 — the SIMD mates of the dx waves, VALU beside MFMA — stage the next sample and own the LDS-DMA of x
     const bool dx_wave = wave < 2;
     const bool dw_wave = wave == 2 || wave == 3 || wave == 6 || wave == 7;
     const bool build_wave = wave == 4 || wave == 5;
-    const bool dma_wave = build_wave;
+    const bool dma_wave = wave >= 2;                                      // the LDS-DMA of x: waves that never store (their vmcnt only counts it)
     const int bl = (wave - 4) * 64 + lane;                                // builder-local thread index 0..127
 
-    // builder: staging item (destination m, 8-channel chunk c8) -> the 16-byte piece of each of its KC G rows
-    unsigned goff[NSLOT][KC];
-    unsigned gsrc_el[NSLOT];
-    bool item_ok[NSLOT];
+    // LDS-DMA of x: pieces (wave - 2) + 6 u of Npad / 8; rows >= N re-read row N - 1 (finite; their dP rows are zero)
+    unsigned dsrc[2];
 #pragma unroll
-    for (int sl = 0; sl < NSLOT; ++sl) {
-        const int item = bl + 128 * sl;
-        item_ok[sl] = build_wave && item < 8 * M;
-        const int m = min(item >> 3, M - 1), c8 = item & 7;
-        gsrc_el[sl] = (unsigned)(m * p.y_ld + 8 * c8);
-#pragma unroll
-        for (int j = 0; j < KC; ++j) {
-            const int R = item_ok[sl] ? slot_of[m * KC + j] : -1;
-            goff[sl][j] = R >= 0 ? (unsigned)(p.off_g + R * BW_GROW + ((c8 ^ ((R >> 1) & 7)) << 4)) : 0xffffffffu;
-        }
-    }
-    // builder: in-edge slot (n, q) = bl -> its edge-type row, transposed into etT[n][e][q]
-    int et_src[ESLOT];
-    unsigned et_dst[ESLOT];
-#pragma unroll
-    for (int sl = 0; sl < ESLOT; ++sl) {
-        et_src[sl] = -1;
-        et_dst[sl] = 0;
-        const int is = bl + 128 * sl;
-        if (build_wave && is < N * QS) {
-            const int n = is / QS, q = is - n * QS;
-            if (q < DEG) et_src[sl] = tab[n * DEG + q];
-            et_dst[sl] = (unsigned)(p.off_et + ((n * 4) * QS + q) * 2);
-        }
-    }
-    // LDS-DMA of x: pieces (wave - 4) + 2 u of Npad / 8; rows >= N re-read row N - 1 (finite; their dP rows are zero)
-    unsigned dsrc[6];
-#pragma unroll
-    for (int u = 0; u < 6; ++u) {
-        const int slot = 64 * ((wave - 4) + 2 * u) + lane, row = slot >> 3, pos = slot & 7;
+    for (int u = 0; u < 2; ++u) {
+        const int slot = 64 * ((wave - 2) + 6 * u) + lane, row = slot >> 3, pos = slot & 7;
         dsrc[u] = (unsigned)(min(row, N - 1) * BW_XROW + ((pos ^ ((row >> 1) & 7)) << 4));
     }
-    const int npieces = Npad / 8;
+    constexpr int npieces = 12;                       // both x buffers hold 96 rows; rows >= N are copies of row N - 1
+
+    const int chunk_b = (p.B + gridDim.x - 1) / gridDim.x;
+    const int b_begin = blockIdx.x * chunk_b, b_end = min(p.B, b_begin + chunk_b);
+    const unsigned char* xg = reinterpret_cast<const unsigned char*>(p.x);
+
+    auto dma_x = [&](int b, int buf) {                 // waves 2-7
+        const unsigned char* xb = xg + (int64_t)b * p.x_sb * 2;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int piece = (wave - 2) + 6 * u;
+            if (piece < npieces) bw_dma16(xb + dsrc[u], lds0 + (unsigned)(OFF_X + buf * (BW_MAXN * BW_XROW) + piece * 1024));
+        }
+    };
+    // the first two samples' x: requested before anything else (the tables below take ~5 us)
+    if (b_begin < b_end && dma_wave) { dma_x(b_begin, 0); if (b_begin + 1 < b_end) dma_x(b_begin + 1, 1); }
 
     // projection (all eight waves): column tile T = wave = (16-channel block ob, edge-type pair ep); A row i = 8 g + 4 h + r is
     // (edge type 2 ep + (g >> 1), channel 16 ob + 8 h + 4 (g & 1) + r): an output lane (node, h) then holds, per edge type of the
@@ -201,22 +207,9 @@ __global__ __launch_bounds__(BW_THREADS) void mpconv_bwd_ws_kernel(const BwParam
         }
 #pragma unroll
         for (int el = 0; el < 2; ++el)
-            pwo[el] = (unsigned)(p.off_pd + l31 * BW_PROW + (2 * ep + el) * 128 + (((2 * ob + lh) ^ bw_swz_p(l31, 2 * ep + el)) << 4));
+            pwo[el] = (unsigned)(OFF_PD + l31 * BW_PROW + (2 * ep + el) * 128 + (((2 * ob + lh) ^ bw_swz_p(l31, 2 * ep + el)) << 4));
     }
-    // dP phase: address pattern of the transpose read of a node's G rows.  Lane i16 of group g4 names (row n QS + 4 h4 + (i16 >> 2),
-    // chunk 2 g4 + ((i16 & 3) >> 1), half i16 & 1); the row's swizzle (R >> 1) & 7 depends on the node only through n mod (8 / QS),
-    // and a wave's first node is a multiple of 4: one pattern per (i mod 4, h4), the node's base added as a scalar
-    const int npw = Npad / 8;
-    unsigned gpat[4][QS / 4];
-#pragma unroll
-    for (int v = 0; v < 4; ++v)
-#pragma unroll
-        for (int h4 = 0; h4 < QS / 4; ++h4) {
-            const int R = v * QS + 4 * h4 + (i16 >> 2);
-            const int chunk = 2 * g4 + ((i16 & 3) >> 1);
-            gpat[v][h4] = lds0 + (unsigned)(p.off_g + (4 * h4 + (i16 >> 2)) * BW_GROW + ((chunk ^ ((R >> 1) & 7)) << 4) + 8 * (i16 & 1));
-        }
-    // dx (waves 0-1): A of dx^T = W dP^T, channel tile ct = wave: W[32 ct + l31][16 ks + 8 lh ..+7], ks = 0..15 -> RA[0..3] (64 VGPRs)
+    // dx (waves 0-1): A of dx^T = W dP^T, channel tile ct = wave: W[32 ct + l31][16 ks + 8 lh ..+7], ks = 0..15 -> RA (64 VGPRs)
     // dW (waves 2,3,6,7): RA = the four 32x32 accumulators (channel tile 0/1) x (column tiles 2 dwi, 2 dwi + 1)
     bw_f32x16 RA[4];
     const int dwi = wave < 4 ? wave - 2 : wave - 4;
@@ -235,6 +228,120 @@ __global__ __launch_bounds__(BW_THREADS) void mpconv_bwd_ws_kernel(const BwParam
 #pragma unroll
             for (int u = 0; u < 16; ++u) RA[t][u] = 0.f;
     }
+    auto prefetch_g = [&](int b, uint4 (&pg)[NSLOT], uint2 (&pa)[NSLOT]) {      // builder threads: gz / argmax of their staging items
+        const unsigned char* gzb = reinterpret_cast<const unsigned char*>(p.gz + (int64_t)b * p.y_sb);
+        const unsigned char* amb = p.argmax + (int64_t)b * p.y_sb;
+        int blo = bl;                                  // opaque per call: keeps the per-lane offsets (and six 64-bit pointers) from being hoisted
+        asm volatile("" : "+v"(blo));
+#pragma unroll
+        for (int sl = 0; sl < NSLOT; ++sl) {
+            const int item = blo + 128 * sl;
+            pg[sl] = make_uint4(0, 0, 0, 0);
+            pa[sl] = make_uint2(0, 0);
+            if (build_wave && item < 8 * M) {
+                const unsigned el = (unsigned)((item >> 3) * p.y_ld + 8 * (item & 7));
+                pg[sl] = *bw_at<uint4>(gzb, el * 2u);
+                pa[sl] = *bw_at<uint2>(amb, el);
+            }
+        }
+    };
+    // the neighbour table (M k <= 288 entries: one per thread) and sample 0's gz / argmax: requested now, consumed below
+    long long idx_v = tid < mk ? p.idx[tid] : 0;
+    uint4 pg0[NSLOT];
+    uint2 pa0[NSLOT];
+    if (b_begin < b_end) prefetch_g(b_begin, pg0, pa0);
+
+    // ---- setup: zero every image (pad rows of G / etT / dP are read as zeros for the kernel's lifetime), transposed incidence ----
+    // (bw_barrier, not __syncthreads: the loads requested above stay in flight across it)
+    for (int f = OFF_G / 16 + tid; f < LY::BYTES / 16; f += BW_THREADS) reinterpret_cast<uint4*>(bw_lds)[f] = make_uint4(0, 0, 0, 0);      // (not the x buffers)
+    bw_barrier();
+    {
+        // scratch in the (still unused) P / dP region: in-degree counters and up to 8 edge ids per source node
+        int* cnt = reinterpret_cast<int*>(bw_lds + OFF_PD);
+        int* tmp = cnt + NMAX;
+        for (int f = tid; f < Npad * QS + 4; f += BW_THREADS) tab[f] = -1;            // (+ the all -1 row unused lanes read)
+        if (tid < mk) {
+            const int r = tid;
+            const long long v = idx_v;
+            const int n = (int)(v < 0 ? 0 : (v >= N ? N - 1 : v));
+            slot_of[r] = -1;
+            const int pos = atomicAdd(&cnt[n], 1);                           // arrival order: made deterministic by the sort below
+            if (pos < 8) tmp[n * 8 + pos] = r;
+        }
+        bw_barrier();
+        BW_STAMP_G(2);
+        if (tid < N) {                                                        // the node's in-edges in (m, j) order = ascending edge id
+            const int n = tid, c = min(cnt[n], 8);
+            int e[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) e[q] = q < c ? tmp[n * 8 + q] : 0x7fffffff;
+#pragma unroll
+            for (int a = 0; a < 8; ++a)                                       // (odd-even transposition sort of 8: 8 passes)
+#pragma unroll
+                for (int q = a & 1; q + 1 < 8; q += 2) {
+                    const int lo = min(e[q], e[q + 1]), hi = max(e[q], e[q + 1]);
+                    e[q] = lo; e[q + 1] = hi;
+                }
+#pragma unroll
+            for (int q = 0; q < DEG; ++q)                                     // (host guarantees in-degree <= DEG)
+                if (q < c) { tab[n * QS + q] = e[q]; slot_of[e[q]] = n * QS + q; }
+        }
+        bw_barrier();
+        BW_STAMP_G(6);
+        for (int f = tid; f < (NMAX * 9 + 3) / 4; f += BW_THREADS) reinterpret_cast<uint4*>(cnt)[f] = make_uint4(0, 0, 0, 0);      // scratch back to zeros
+        for (int f = tid; f < 8 * mk; f += BW_THREADS) {                  // (item, j) -> 16-byte piece c8 of G row R, chunk-swizzled
+            const int item = f / KC, j = f - item * KC, m = item >> 3, c8 = item & 7;
+            const int R = slot_of[m * KC + j];
+            gtab[f] = R >= 0 ? (unsigned)(OFF_G + R * BW_GROW + ((c8 ^ ((R >> 1) & 7)) << 4)) : (unsigned)LY::OFF_DUMP;
+        }
+        bw_barrier();
+    }
+
+    BW_STAMP_G(7);
+    // builder: in-edge slot (n, q) -> its edge-type row, transposed into etT[n][e][q]
+    int et_src[ESLOT];
+    unsigned et_dst[ESLOT];
+#pragma unroll
+    for (int sl = 0; sl < ESLOT; ++sl) {
+        et_src[sl] = -1;
+        et_dst[sl] = 0;
+        const int is = bl + 128 * sl;
+        if (build_wave && is < N * QS) {
+            const int n = is / QS, q = is - n * QS;
+            if (q < DEG) et_src[sl] = tab[n * QS + q];
+            et_dst[sl] = (unsigned)(OFF_ET + ((n * 4) * QS + q) * 2);
+        }
+    }
+    // detype tiles of this wave (gi = wave + 8 sl): operand addresses and the output lane's table row, static for the kernel
+    unsigned da[NG], db_[NG], dt[NG];
+#pragma unroll
+    for (int sl = 0; sl < NG; ++sl) {
+        const int gi = wave + 8 * sl;
+        const int R = gi * 16 + i16;
+        da[sl] = (unsigned)(OFF_G + R * BW_GROW + ((g4 ^ ((R >> 1) & 7)) << 4));
+        const int jn = QS == 4 ? (i16 >> 2) : ((i16 & 7) >> 2), e = i16 & 3;
+        const int nb = gi * NPG + jn;
+        db_[sl] = (unsigned)(OFF_PD + nb * BW_PROW + e * 128 + ((g4 ^ bw_swz_p(nb, e)) << 4));
+        // D[i = 4 g4 + r][j = i16] is useful where row and column name the same node: (n, first slot q0) of this lane, or none
+        bool ok;
+        int n, q0;
+        if (QS == 4) { ok = g4 == (i16 >> 2); n = gi * 4 + g4; q0 = 0; }
+        else { ok = i16 < 8 && (g4 >> 1) == (i16 >> 2); n = gi * 2 + (g4 >> 1); q0 = 4 * (g4 & 1); }
+        dt[sl] = (ok && n < N) ? (unsigned)(OFF_TAB + (n * QS + q0) * 4) : (unsigned)(OFF_TAB + NMAX * QS * 4);
+    }
+    // dP phase: address pattern of the transpose read of a node's G rows.  Lane i16 of group g4 names (row n QS + 4 h4 + (i16 >> 2),
+    // chunk 2 g4 + ((i16 & 3) >> 1), half i16 & 1); the row's swizzle (R >> 1) & 7 depends on the node only through n mod (8 / QS),
+    // and a wave's first node is a multiple of 4: one pattern per (i mod 4, h4), the node's base added as a scalar
+    constexpr int npw = MAXNPW;
+    unsigned gpat[4][QS / 4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v)
+#pragma unroll
+        for (int h4 = 0; h4 < QS / 4; ++h4) {
+            const int R = v * QS + 4 * h4 + (i16 >> 2);
+            const int chunk = 2 * g4 + ((i16 & 3) >> 1);
+            gpat[v][h4] = lds0 + (unsigned)(OFF_G + (4 * h4 + (i16 >> 2)) * BW_GROW + ((chunk ^ ((R >> 1) & 7)) << 4) + 8 * (i16 & 1));
+        }
     // dW transpose-read offsets: segment of lane i16 in group g4 = (node 8 (g4 >> 1) + (i16 >> 2) [+ 4], columns 16 (g4 & 1) + 4 (i16 & 3) ..)
     unsigned xa[2][2], db[2];
 #pragma unroll
@@ -246,7 +353,7 @@ __global__ __launch_bounds__(BW_THREADS) void mpconv_bwd_ws_kernel(const BwParam
             const int chunk = 4 * c2 + 2 * (g4 & 1) + ((i16 & 3) >> 1);
             xa[c2][r] = (unsigned)(nd * BW_XROW + ((chunk ^ fx) << 4) + 8 * (i16 & 1));
         }
-        db[r] = lds0 + (unsigned)(p.off_pd + nd * BW_DROW + (64 * dwi + 16 * (g4 & 1) + 4 * (i16 & 3)) * 2);
+        db[r] = lds0 + (unsigned)(OFF_PD + nd * BW_DROW + (64 * dwi + 16 * (g4 & 1) + 4 * (i16 & 3)) * 2);
     }
     bw_s16x4 ones_row0;
     {
@@ -255,41 +362,15 @@ __global__ __launch_bounds__(BW_THREADS) void mpconv_bwd_ws_kernel(const BwParam
     }
     f32x4 dbacc = {0.f, 0.f, 0.f, 0.f};                // [0]: dbias of channel `lane` over this wave's nodes
 
-    const int chunk_b = (p.B + gridDim.x - 1) / gridDim.x;
-    const int b_begin = blockIdx.x * chunk_b, b_end = min(p.B, b_begin + chunk_b);
-    const unsigned char* xg = reinterpret_cast<const unsigned char*>(p.x);
-
     // ---- staging pieces ----
-    uint4 pg[NSLOT];
-    uint2 pa[NSLOT], pe[ESLOT];
-    auto prefetch = [&](int b) {                       // builder threads: gz / argmax of their items, the edge-type row of their in-edge
-        const unsigned char* gzb = reinterpret_cast<const unsigned char*>(p.gz + (int64_t)b * p.y_sb);
-        const unsigned char* amb = p.argmax + (int64_t)b * p.y_sb;
-#pragma unroll
-        for (int sl = 0; sl < NSLOT; ++sl) {
-            pg[sl] = make_uint4(0, 0, 0, 0);
-            pa[sl] = make_uint2(0, 0);
-            if (item_ok[sl]) {
-                pg[sl] = *reinterpret_cast<const uint4*>(gzb + gsrc_el[sl] * 2u);
-                pa[sl] = *reinterpret_cast<const uint2*>(amb + gsrc_el[sl]);
-            }
-        }
+    auto prefetch_e = [&](int b, uint2 (&pe)[ESLOT]) {      // builder threads: the edge-type rows of their in-edge slots
 #pragma unroll
         for (int sl = 0; sl < ESLOT; ++sl) {
             pe[sl] = make_uint2(0, 0);
-            if (et_src[sl] >= 0)
-                pe[sl] = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned char*>(p.et + (int64_t)b * p.et_sb) + et_src[sl] * 8);
+            if (et_src[sl] >= 0) pe[sl] = *bw_at<uint2>(p.et + (int64_t)b * p.et_sb, (unsigned)et_src[sl] * 8u);
         }
     };
-    auto dma_x = [&](int b, int buf) {                 // waves 4-5
-        const unsigned char* xb = xg + (int64_t)b * p.x_sb * 2;
-#pragma unroll
-        for (int u = 0; u < 6; ++u) {
-            const int piece = (wave - 4) + 2 * u;
-            if (piece < npieces) bw_dma16(xb + dsrc[u], lds0 + (unsigned)(p.off_x + buf * (BW_MAXN * BW_XROW) + piece * 1024));
-        }
-    };
-    auto build = [&]() {                               // prefetched registers -> etT, G
+    auto build = [&](const uint4 (&pg)[NSLOT], const uint2 (&pa)[NSLOT], const uint2 (&pe)[ESLOT]) {      // prefetched registers -> etT, G
 #pragma unroll
         for (int sl = 0; sl < ESLOT; ++sl) {
             if (et_src[sl] >= 0) {
@@ -300,12 +381,16 @@ __global__ __launch_bounds__(BW_THREADS) void mpconv_bwd_ws_kernel(const BwParam
         }
 #pragma unroll
         for (int sl = 0; sl < NSLOT; ++sl) {
-            if (item_ok[sl]) {
+            const int item = bl + 128 * sl;
+            if (item < 8 * M) {
                 // argmax bytes -> 16-bit halves, one-hot per half; slot j keeps a gz half where bit j is set:
                 // (onehot << (15 - j)) >> 15 (arithmetic, per half) is the 16-bit mask
                 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
                 typedef short s16x2 __attribute__((ext_vector_type(2)));
                 const unsigned gq[4] = {pg[sl].x, pg[sl].y, pg[sl].z, pg[sl].w};
+                unsigned gofs[KC];
+#pragma unroll
+                for (int j = 0; j < KC; ++j) gofs[j] = gtab[item * KC + j];
                 u16x2 oh[4];
 #pragma unroll
                 for (int d = 0; d < 4; ++d) {
@@ -321,47 +406,51 @@ __global__ __launch_bounds__(BW_THREADS) void mpconv_bwd_ws_kernel(const BwParam
                         const s16x2 msk = __builtin_bit_cast(s16x2, (u16x2)(oh[d] << (u16x2){(unsigned short)(15 - j), (unsigned short)(15 - j)})) >> (s16x2){15, 15};
                         w[d] = gq[d] & __builtin_bit_cast(unsigned, msk);
                     }
-                    if (goff[sl][j] != 0xffffffffu) *reinterpret_cast<uint4*>(bw_lds + goff[sl][j]) = make_uint4(w[0], w[1], w[2], w[3]);
+                    *reinterpret_cast<uint4*>(bw_lds + gofs[j]) = make_uint4(w[0], w[1], w[2], w[3]);
                 }
             }
         }
     };
 
+    BW_STAMP_G(3);
     // ---- pipeline fill: sample b_begin staged ----
     if (b_begin < b_end) {
-        if (dma_wave) dma_x(b_begin, 0);
-        prefetch(b_begin);
-        build();
+        if (build_wave) {
+            uint2 pe[ESLOT];
+            prefetch_e(b_begin, pe); build(pg0, pa0, pe);
+        }
         if (dma_wave) bw_wait_vm0();
     }
     bw_barrier();
-    const int ntile = Npad / 32;
-    int cur = 0;
+    constexpr int ntile = NMAX / 32;
+    int cur = 0;                                       // x buffer of this sample: (b - b_begin) % 3
 
     for (int b = b_begin; b < b_end; ++b) {
-        const unsigned char* xs = bw_lds + p.off_x + cur * (BW_MAXN * BW_XROW);
+        const unsigned char* xs = bw_lds + OFF_X + cur * (BW_MAXN * BW_XROW);
         const bool has_next = b + 1 < b_end;
-        if (has_next) {
-            if (dma_wave) dma_x(b + 1, cur ^ 1);       // (the other x buffer was last read by dW of sample b - 1)
-            prefetch(b + 1);
-        }
+        BW_STAMP(0);
+        BW_STAMP_G(8 + (b - b_begin));
         // ================= phase 1: P^T tile of this wave (32 columns) for every node tile, three independent chains =================
+        // Every phase below issues ALL its LDS reads first and computes behind a scheduling barrier: with two waves per SIMD
+        // nothing else hides an LDS round trip, and left alone the compiler puts each read right in front of its MFMA.
         {
+            uint4 xb[3][4];
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk)
+                    xb[t][kk] = t < ntile ? *reinterpret_cast<const uint4*>(xs + t * 32 * BW_XROW + xoff[kk]) : make_uint4(0, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
             bw_f32x16 acc[3];
 #pragma unroll
             for (int t = 0; t < 3; ++t)
 #pragma unroll
                 for (int u = 0; u < 16; ++u) acc[t][u] = 0.f;
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
+            for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
-                for (int t = 0; t < 3; ++t) {
-                    if (t < ntile) {
-                        const bw_bf16x8 bf = __builtin_bit_cast(bw_bf16x8, *reinterpret_cast<const uint4*>(xs + t * 32 * BW_XROW + xoff[kk]));
-                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aP[kk], bf, acc[t], 0, 0, 0);
-                    }
-                }
-            }
+                for (int t = 0; t < 3; ++t)
+                    if (t < ntile) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aP[kk], __builtin_bit_cast(bw_bf16x8, xb[t][kk]), acc[t], 0, 0, 0);
 #pragma unroll
             for (int t = 0; t < 3; ++t) {
                 if (t < ntile) {
@@ -374,139 +463,201 @@ __global__ __launch_bounds__(BW_THREADS) void mpconv_bwd_ws_kernel(const BwParam
                 }
             }
         }
+        BW_STAMP(1);
         bw_barrier();
-        // ================= phase 2a: detype[(n,q),e] = sum_o G[(n,q),o] P[n,o,e], NPG source nodes per 16x16x32 tile =================
-        {
-            uint16_t* gst = reinterpret_cast<uint16_t*>(bw_lds + p.off_gst);
-#pragma unroll 1
-            for (int sl = 0; sl < 4; ++sl) {
-                const int gi = wave + 8 * sl;
-                if (gi * NPG < Npad) {
-                    const int R = gi * 16 + i16;
-                    const unsigned ab = (unsigned)(p.off_g + R * BW_GROW), as = (unsigned)((g4 ^ ((R >> 1) & 7)) << 4);
-                    const int jn = QS == 4 ? (i16 >> 2) : ((i16 & 7) >> 2), e = i16 & 3;
-                    const int nb = gi * NPG + jn;
-                    const unsigned bb = (unsigned)(p.off_pd + nb * BW_PROW + e * 128), bs = (unsigned)((g4 ^ bw_swz_p(nb, e)) << 4);
-                    const bw_bf16x8 a0 = __builtin_bit_cast(bw_bf16x8, *reinterpret_cast<const uint4*>(bw_lds + ab + as));
-                    const bw_bf16x8 b0 = __builtin_bit_cast(bw_bf16x8, *reinterpret_cast<const uint4*>(bw_lds + bb + bs));
-                    const bw_bf16x8 a1 = __builtin_bit_cast(bw_bf16x8, *reinterpret_cast<const uint4*>(bw_lds + ab + (as ^ 64u)));
-                    const bw_bf16x8 b1 = __builtin_bit_cast(bw_bf16x8, *reinterpret_cast<const uint4*>(bw_lds + bb + (bs ^ 64u)));
-                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b0, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b1, acc, 0, 0, 0);
-                    // D[i = 4 g4 + r][j = i16]: useful where row and column name the same node
-                    bool ok;
-                    int n, q0;
-                    if (QS == 4) { ok = g4 == (i16 >> 2); n = gi * 4 + g4; q0 = 0; }
-                    else { ok = i16 < 8 && (g4 >> 1) == (i16 >> 2); n = gi * 2 + (g4 >> 1); q0 = 4 * (g4 & 1); }
-                    if (ok && n < N) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            if (q0 + r < DEG) {
-                                const int edge = tab[n * DEG + q0 + r];
-                                if (edge >= 0) gst[e * mk + edge] = (uint16_t)(bw_pack2(acc[r], 0.f) & 0xffffu);
-                            }
-                        }
-                    }
+        BW_STAMP(2);
+        // Phases 2a / 2b are written once (lambdas) and instantiated in BOTH arms of the role branch below: the staging waves hold the
+        // next sample's prefetched words in registers from here to phase 3, and values that flow around a branch merge are copied
+        // at the merge — i.e. the wave would wait for its loads right after issuing them (measured: 2 300 cycles per sample).
+        auto phase2a = [&]() {
+            {
+                uint16_t* gst = reinterpret_cast<uint16_t*>(bw_lds + OFF_GST);
+                uint4 fa[NG][2], fb[NG][2];
+                int4 te[NG];
+    #pragma unroll
+                for (int sl = 0; sl < NG; ++sl) {
+                    fa[sl][0] = *reinterpret_cast<const uint4*>(bw_lds + da[sl]);
+                    fb[sl][0] = *reinterpret_cast<const uint4*>(bw_lds + db_[sl]);
+                    fa[sl][1] = *reinterpret_cast<const uint4*>(bw_lds + (da[sl] ^ 64u));
+                    fb[sl][1] = *reinterpret_cast<const uint4*>(bw_lds + (db_[sl] ^ 64u));
+                    te[sl] = *reinterpret_cast<const int4*>(bw_lds + dt[sl]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                f32x4 acc[NG];
+    #pragma unroll
+                for (int sl = 0; sl < NG; ++sl)
+                    acc[sl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bw_bf16x8, fa[sl][0]), __builtin_bit_cast(bw_bf16x8, fb[sl][0]),
+                                                                      (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+    #pragma unroll
+                for (int sl = 0; sl < NG; ++sl)
+                    acc[sl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bw_bf16x8, fa[sl][1]), __builtin_bit_cast(bw_bf16x8, fb[sl][1]),
+                                                                      acc[sl], 0, 0, 0);
+                const int e = i16 & 3;
+    #pragma unroll
+                for (int sl = 0; sl < NG; ++sl) {
+                    const int ed[4] = {te[sl].x, te[sl].y, te[sl].z, te[sl].w};
+    #pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (ed[r] >= 0) gst[e * mk + ed[r]] = (uint16_t)(bw_pack2(acc[sl][r], 0.f) & 0xffffu);
                 }
             }
-        }
-        bw_barrier();
-        // ================= phase 2b: dP per source node (one transpose read + one 4x4x4 MFMA per four in-edge slots) =================
-        {
-            static_assert(MAXNPW % 4 == 0, "nodes per wave in groups of four");
-#pragma unroll 1
-            for (int i0 = 0; i0 < npw; i0 += 4) {     // (rolled: unrolled, the scheduler hoists every node's reads and spills)
-#pragma unroll
-              for (int v = 0; v < 4; ++v) {
-                const int i = i0 + v;
-                {
+        };
+        auto phase2b = [&]() {
+            {
+                uint2 bv[MAXNPW][QS / 4], av[MAXNPW][QS / 4];
+    #pragma unroll
+                for (int i = 0; i < MAXNPW; ++i) {
                     const int n = wave * npw + i;
-                    uint2 outv = make_uint2(0u, 0u);
-                    if (n < N) {
+    #pragma unroll
+                    for (int h4 = 0; h4 < QS / 4; ++h4) {
+                        // (nodes >= N: their G rows and edge-type rows are zero for the kernel's lifetime -> a zero dP row, what dW needs)
+                        bv[i][h4] = bw_tr(gpat[i & 3][h4] + (unsigned)(n * QS * BW_GROW));
+                        av[i][h4] = *reinterpret_cast<const uint2*>(bw_lds + OFF_ET + ((n * 4 + (lane & 3)) * QS + 4 * h4) * 2);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                BW_STAMP(9);
+    #pragma unroll
+                for (int i = 0; i < MAXNPW; ++i) {
+                    {
+                        const int n = wave * npw + i;
                         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
+    #pragma unroll
                         for (int h4 = 0; h4 < QS / 4; ++h4) {
-                            const uint2 bv = bw_tr(gpat[v][h4] + (unsigned)(n * QS * BW_GROW));
-                            const uint2 av = *reinterpret_cast<const uint2*>(bw_lds + p.off_et + ((n * 4 + (lane & 3)) * QS + 4 * h4) * 2);
-                            const bw_s16x4 b4 = __builtin_bit_cast(bw_s16x4, bv);
-                            acc = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(__builtin_bit_cast(bw_s16x4, av), b4, acc, 0, 0, 0);
+                            const bw_s16x4 b4 = __builtin_bit_cast(bw_s16x4, bv[i][h4]);
+                            acc = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(__builtin_bit_cast(bw_s16x4, av[i][h4]), b4, acc, 0, 0, 0);
                             dbacc = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(ones_row0, b4, dbacc, 0, 0, 0);
                         }
-                        outv = make_uint2(bw_pack2(acc[0], acc[1]), bw_pack2(acc[2], acc[3]));
+                        *reinterpret_cast<uint2*>(bw_lds + OFF_PD + n * BW_DROW + lane * 8) = make_uint2(bw_pack2(acc[0], acc[1]), bw_pack2(acc[2], acc[3]));
                     }
-                    *reinterpret_cast<uint2*>(bw_lds + p.off_pd + n * BW_DROW + lane * 8) = outv;      // (pad nodes: zeros for dW)
                 }
-              }
+                BW_STAMP(10);
+                // edge-type gradient of this sample: staging -> memory, 16 bytes per lane (8 mk bytes; host: mk even, 16-byte aligned)
+                const int nvec = (8 * mk) >> 4;
+                if (tid < nvec) {
+                    const uint4 v = *reinterpret_cast<const uint4*>(bw_lds + OFF_GST + tid * 16);
+                    *bw_at<uint4>(p.get + (int64_t)b * 4 * mk, (unsigned)tid * 16u) = v;
+                }
             }
-            // edge-type gradient of this sample: staging -> memory, 16 bytes per lane (8 mk bytes; host: mk even, 16-byte aligned)
-            const int nvec = (8 * mk) >> 4;
-            if (tid < nvec) {
-                const uint4 v = *reinterpret_cast<const uint4*>(bw_lds + p.off_gst + tid * 16);
-                *reinterpret_cast<uint4*>(reinterpret_cast<unsigned char*>(p.get + (int64_t)b * 4 * mk) + tid * 16) = v;
-            }
-        }
-        bw_barrier();
-        // ================= phase 3: dx | dW | staging of the next sample =================
-        if (dx_wave) {
-            uint16_t* gxb = p.gx + (int64_t)b * p.x_sb;
-#pragma unroll 1
-            for (int nt = 0; nt < ntile; ++nt) {
-                {
-                    // two chains over the even / odd k-steps: one chain of 16 dependent MFMAs would idle the pipe half the time
+        };
+        if (build_wave) {
+            // the next sample's gz / argmax / edge types: requested two phases ahead of their use (past the last sample: a harmless re-read)
+            uint4 pg[NSLOT];
+            uint2 pa[NSLOT], pe[ESLOT];
+            prefetch_g(has_next ? b + 1 : b, pg, pa);
+            prefetch_e(has_next ? b + 1 : b, pe);
+            phase2a();
+            BW_STAMP(3);
+            bw_barrier();
+            BW_STAMP(4);
+            phase2b();
+            BW_STAMP(5);
+            bw_barrier();
+            BW_STAMP(6);
+            if (has_next) build(pg, pa, pe);               // G / etT of sample b + 1 (their readers finished in phase 2b)
+        } else {
+            phase2a();
+            BW_STAMP(3);
+            bw_barrier();
+            BW_STAMP(4);
+            phase2b();
+            BW_STAMP(5);
+            bw_barrier();
+            BW_STAMP(6);
+            // ================= phase 3: dx | dW (| staging of the next sample, above) =================
+            if (dx_wave) {
+                uint16_t* gxb = p.gx + (int64_t)b * p.x_sb;
+                    // Software pipeline over the node tiles with no extra registers: the tile's fragments 8..15 are requested when it starts
+                // (they land under the first eight MFMAs), fragments 0..7 of the NEXT tile when those eight are done.  Two chains over the
+                // even / odd k-steps: one chain of 16 dependent MFMAs would idle the pipe half the time.
+                uint4 bf[16];
+                const unsigned char* bp0 = bw_lds + OFF_PD + l31 * BW_DROW + lh * 16;
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) bf[ks] = *reinterpret_cast<const uint4*>(bp0 + 32 * ks);
+#pragma unroll
+                for (int nt = 0; nt < ntile; ++nt) {
+                    const unsigned char* bp = bp0 + nt * 32 * BW_DROW;
+#pragma unroll
+                    for (int ks = 8; ks < 16; ++ks) bf[ks] = *reinterpret_cast<const uint4*>(bp + 32 * ks);
+                    __builtin_amdgcn_sched_barrier(0);
                     bw_f32x16 ae, ao;
 #pragma unroll
                     for (int u = 0; u < 16; ++u) { ae[u] = 0.f; ao[u] = 0.f; }
-                    const unsigned char* bp = bw_lds + p.off_pd + (nt * 32 + l31) * BW_DROW + lh * 16;
 #pragma unroll
                     for (int ks = 0; ks < 16; ks += 2) {
-                        const bw_bf16x8 b0 = __builtin_bit_cast(bw_bf16x8, *reinterpret_cast<const uint4*>(bp + 32 * ks));
-                        const bw_bf16x8 b1 = __builtin_bit_cast(bw_bf16x8, *reinterpret_cast<const uint4*>(bp + 32 * ks + 32));
+                        if (ks == 8) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            if (nt + 1 < ntile) {
+#pragma unroll
+                                for (int k2 = 0; k2 < 8; ++k2) bf[k2] = *reinterpret_cast<const uint4*>(bp + 32 * BW_DROW + 32 * k2);
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
                         f32x4 f0, f1;
 #pragma unroll
                         for (int u = 0; u < 4; ++u) { f0[u] = RA[ks >> 2][4 * (ks & 3) + u]; f1[u] = RA[(ks + 1) >> 2][4 * ((ks + 1) & 3) + u]; }
-                        ae = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bw_bf16x8, f0), b0, ae, 0, 0, 0);
-                        ao = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bw_bf16x8, f1), b1, ao, 0, 0, 0);
+                        ae = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bw_bf16x8, f0), __builtin_bit_cast(bw_bf16x8, bf[ks]), ae, 0, 0, 0);
+                        ao = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bw_bf16x8, f1), __builtin_bit_cast(bw_bf16x8, bf[ks + 1]), ao, 0, 0, 0);
                     }
                     const int n = nt * 32 + l31;
                     if (n < N) {
 #pragma unroll
                         for (int g = 0; g < 4; ++g)
-                            *reinterpret_cast<uint2*>(gxb + n * 64 + 32 * wave + 8 * g + 4 * lh) =
+                            *bw_at<uint2>(gxb, (unsigned)(n * 64 + 32 * wave + 8 * g + 4 * lh) * 2u) =
                                 make_uint2(bw_pack2(ae[4 * g] + ao[4 * g], ae[4 * g + 1] + ao[4 * g + 1]),
                                            bw_pack2(ae[4 * g + 2] + ao[4 * g + 2], ae[4 * g + 3] + ao[4 * g + 3]));
                     }
                 }
-            }
         } else if (dw_wave) {
-            const unsigned xbase = lds0 + (unsigned)(p.off_x + cur * (BW_MAXN * BW_XROW));
-            const int nks = Npad / 16;
-            for (int ks = 0; ks < nks; ++ks) {
-                bw_bf16x8 fa[2], fb[2];
-#pragma unroll
-                for (int c2 = 0; c2 < 2; ++c2) {
-                    const uint2 lo = bw_tr(xbase + xa[c2][0] + ks * (16 * BW_XROW)), hi = bw_tr(xbase + xa[c2][1] + ks * (16 * BW_XROW));
-                    fa[c2] = __builtin_bit_cast(bw_bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));
+                const unsigned xbase = lds0 + (unsigned)(OFF_X + cur * (BW_MAXN * BW_XROW));
+                constexpr int nks = NMAX / 16;            // even
+                uint2 f0[8], f1[8];
+                auto load = [&](uint2 (&f)[8], int ks) {   // A: channel tiles 0 / 1 (two reads each); B: this wave's two column tiles
+    #pragma unroll
+                    for (int c2 = 0; c2 < 2; ++c2) {
+                        f[2 * c2] = bw_tr(xbase + xa[c2][0] + ks * (16 * BW_XROW));
+                        f[2 * c2 + 1] = bw_tr(xbase + xa[c2][1] + ks * (16 * BW_XROW));
+                    }
+    #pragma unroll
+                    for (int cj = 0; cj < 2; ++cj) {
+                        f[4 + 2 * cj] = bw_tr(db[0] + ks * (16 * BW_DROW) + cj * 64);
+                        f[5 + 2 * cj] = bw_tr(db[1] + ks * (16 * BW_DROW) + cj * 64);
+                    }
+                };
+                auto mma = [&](const uint2 (&f)[8]) {
+    #pragma unroll
+                    for (int c2 = 0; c2 < 2; ++c2)
+    #pragma unroll
+                        for (int cj = 0; cj < 2; ++cj)
+                            RA[2 * c2 + cj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                                __builtin_bit_cast(bw_bf16x8, make_uint4(f[2 * c2].x, f[2 * c2].y, f[2 * c2 + 1].x, f[2 * c2 + 1].y)),
+                                __builtin_bit_cast(bw_bf16x8, make_uint4(f[4 + 2 * cj].x, f[4 + 2 * cj].y, f[5 + 2 * cj].x, f[5 + 2 * cj].y)),
+                                RA[2 * c2 + cj], 0, 0, 0);
+                };
+                load(f0, 0);
+    #pragma unroll 1
+                for (int ks = 0; ks < nks; ks += 2) {      // the next k-step's eight transpose reads are in flight under this one's MFMAs
+                    load(f1, ks + 1);
+                    mma(f0);
+                    if (ks + 2 < nks) load(f0, ks + 2);
+                    mma(f1);
                 }
-#pragma unroll
-                for (int cj = 0; cj < 2; ++cj) {
-                    const uint2 lo = bw_tr(db[0] + ks * (16 * BW_DROW) + cj * 64), hi = bw_tr(db[1] + ks * (16 * BW_DROW) + cj * 64);
-                    fb[cj] = __builtin_bit_cast(bw_bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));
-                }
-#pragma unroll
-                for (int c2 = 0; c2 < 2; ++c2)
-#pragma unroll
-                    for (int cj = 0; cj < 2; ++cj)
-                        RA[2 * c2 + cj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[c2], fb[cj], RA[2 * c2 + cj], 0, 0, 0);
             }
-        } else if (has_next) {
-            build();                                   // G / etT of sample b + 1 (their readers finished in phase 2b)
         }
-        if (dma_wave && has_next) bw_wait_vm0();       // x of sample b + 1 has landed (these waves store nothing)
+        // x by LDS-DMA, TWO samples ahead and from the tail of phase 3: the memory pipe takes a piece per ~85 cycles (HBM rate), and
+        // issued in front of phase 1 the twelve pieces held up the projections of the issuing waves by up to 1 000 cycles.  These
+        // waves store nothing, so vmcnt(0) = "x of sample b + 1 (requested a sample ago) has landed".
+        if (dma_wave) {
+            bw_wait_vm0();
+            if (b + 2 < b_end) dma_x(b + 2, cur >= 1 ? cur - 1 : 2);      // buffer (cur + 2) % 3: last read by dW of sample b - 1
+        }
+        BW_STAMP(7);
         bw_barrier();
-        cur ^= 1;
+        BW_STAMP(8);
+        cur = cur == 2 ? 0 : cur + 1;
     }   // samples
 
+    BW_STAMP_G(4);
     // ---- flush dW tiles and dbias into this workgroup's slab (summed by the slab reduce, fixed order) ----
     if (b_begin < b_end) {
         float* slab = p.ws + (int64_t)blockIdx.x * (64 * 256 + 64);
@@ -524,7 +675,7 @@ __global__ __launch_bounds__(BW_THREADS) void mpconv_bwd_ws_kernel(const BwParam
                 }
         }
         __syncthreads();
-        float* red = reinterpret_cast<float*>(bw_lds + p.off_x);          // [8 waves][64 channels]
+        float* red = reinterpret_cast<float*>(bw_lds + OFF_X);          // [8 waves][64 channels]
         red[wave * 64 + lane] = dbacc[0];
         __syncthreads();
         if (tid < 64) {
@@ -533,6 +684,7 @@ __global__ __launch_bounds__(BW_THREADS) void mpconv_bwd_ws_kernel(const BwParam
             slab[64 * 256 + tid] = s;
         }
     }
+    BW_STAMP_G(5);
 }
 
 // ----------------------------------------------------------------------------------------
@@ -552,7 +704,7 @@ int fgnn_mpconv_backward_ws(const fgnn_mpconv_desc* d, const void* x, const int6
     const int KC = d->k, DEG = KC == 6 ? 3 : 6;
     const int indeg = d->reserved & 0xffff;
     if (indeg < 1 || indeg > DEG) BW_REJECT(2);
-    if (KC == 6 ? (d->N > 96 || d->M > 48) : (d->N > 48 || d->M > 96)) BW_REJECT(3);
+    if (KC == 6 ? (d->N > 96 || d->M > 48) : (d->N > 64 || d->M > 96)) BW_REJECT(3);
     if ((d->M * KC) & 1) BW_REJECT(4);                                  // getype leaves as whole 16-byte lanes
     if (((uintptr_t)getype & 15) || ((uintptr_t)x & 15) || ((uintptr_t)gz & 15) || ((uintptr_t)argmax & 7) || ((uintptr_t)gx & 7) ||
         ((uintptr_t)etype & 7)) BW_REJECT(5);
@@ -564,21 +716,11 @@ int fgnn_mpconv_backward_ws(const fgnn_mpconv_desc* d, const void* x, const int6
     p.x = (const uint16_t*)x; p.idx = nn_idx; p.et = (const uint16_t*)etype; p.W = filters;
     p.gz = (const uint16_t*)gz; p.argmax = argmax; p.gx = (uint16_t*)gx; p.get = (uint16_t*)getype;
     p.ws = (float*)workspace;
-    p.B = d->B; p.N = d->N; p.M = d->M; p.Npad = fgnn_round_up(d->N, 32);
+    p.B = d->B; p.N = d->N; p.M = d->M;
     p.y_ld = d->nou; p.w_ld = d->nou * 4;
     p.x_sb = d->x_sb; p.et_sb = d->et_sb; p.y_sb = d->y_sb;
-    const int QS = DEG <= 4 ? 4 : 8;
-    int off_b = 0;
-    auto take = [&](int bytes) { const int o = off_b; off_b = fgnn_round_up(off_b + bytes, 16); return o; };
-    p.off_x = take(2 * BW_MAXN * BW_XROW);
-    p.off_g = take(p.Npad * QS * BW_GROW);
-    p.off_pd = take(p.Npad * BW_DROW);
-    p.off_et = take(p.Npad * 4 * QS * 2);
-    p.off_gst = take(fgnn_round_up(8 * d->M * KC, 16) + 16);
-    p.off_tab = take(d->N * DEG * 4);
-    p.off_slot = take(d->M * KC * 4);
-    p.lds_bytes = off_b;
-    if (off_b > 160 * 1024) BW_REJECT(8);
+    const int off_b = KC == 6 ? BwLayout<6>::BYTES : BwLayout<3>::BYTES;
+    static_assert(BwLayout<6>::BYTES <= 160 * 1024 && BwLayout<3>::BYTES <= 160 * 1024, "LDS");
     void* fn = KC == 6 ? (void*)mpconv_bwd_ws_kernel<6, 3> : (void*)mpconv_bwd_ws_kernel<3, 6>;
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, off_b);
     if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "hipFuncSetAttribute(%d B LDS): %s", off_b, hipGetErrorString(e));
@@ -588,9 +730,34 @@ int fgnn_mpconv_backward_ws(const fgnn_mpconv_desc* d, const void* x, const int6
     grid = (d->B + chunk - 1) / chunk;
     hipStream_t st = (hipStream_t)stream;
     fgnn_note_kernel("mpconv_bwd_ws_kernel<%d, %d>", KC, DEG);
+    p.prof = nullptr;
+#ifdef FGNN_ENABLE_PROF
+    static long long* prof_buf = nullptr;
+    if (getenv("FGNN_PROF")) {
+        if (!prof_buf) (void)hipMalloc(&prof_buf, 256 * 8);
+        (void)hipMemset(prof_buf, 0, 256 * 8);
+        p.prof = prof_buf;
+    }
+#endif
     void* args[] = {(void*)&p};
     e = hipLaunchKernel(fn, dim3(grid), dim3(BW_THREADS), args, off_b, st);
     if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "mpconv ws backward launch: %s", hipGetErrorString(e));
+#ifdef FGNN_ENABLE_PROF
+    if (p.prof) {      // slots: 0 sample start, 1/2 projection done / released, 3/4 detype, 5/6 dP, 7/8 dx | dW | staging
+        long long h[256];
+        (void)hipDeviceSynchronize();
+        (void)hipMemcpy(h, p.prof, sizeof(h), hipMemcpyDeviceToHost);
+        for (int w = 0; w < 8; ++w) {
+            fprintf(stderr, "[fgnn prof ws bwd] wave %d:", w);
+            for (int i = 0; i < 11; ++i) fprintf(stderr, " %6lld", h[w * 16 + i] - h[0]);
+            fprintf(stderr, "\n");
+        }
+        fprintf(stderr, "[fgnn prof ws bwd] kernel: early-dma %lld zero+idx %lld rank %lld gtab %lld consts %lld loop-end %lld end %lld; samples:", h[129] - h[128],
+                h[130] - h[128], h[134] - h[128], h[135] - h[128], h[131] - h[128], h[132] - h[128], h[133] - h[128]);
+        for (int i = 0; i < 20 && h[136 + i]; ++i) fprintf(stderr, " %lld", h[136 + i] - h[128]);
+        fprintf(stderr, "\n");
+    }
+#endif
     fgnn_launch_slab_reduce(p.ws, grid, slab_len, nw, gfilters, gbias, st);
     e = hipGetLastError();
     if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "mpconv backward helper launch: %s", hipGetErrorString(e));
