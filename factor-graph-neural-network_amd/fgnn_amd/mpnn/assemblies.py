@@ -153,7 +153,16 @@ class factor_mpnn(torch.nn.Module):
         return nfeat, ffeat
 
 
-_V2V_MAIN = set(int(v) for v in os.environ.get('FGNN_V2V_MAIN', '').split(',') if v)      # tuning knob: layers whose v2v map stays on the main
+def _parse_layers(text):
+    try:
+        return set(int(v) for v in text.split(',') if v.strip())
+    except ValueError:
+        import warnings
+        warnings.warn('FGNN_V2V_MAIN=%r is not a comma-separated list of layer numbers: ignored' % text)
+        return set()
+
+
+_V2V_MAIN = _parse_layers(os.environ.get('FGNN_V2V_MAIN', ''))      # tuning knob: layers whose v2v map stays on the main
 # stream.  Measured on one box (18.25 ms with none): layers 0,1,7: 18.27; 2-6: 18.47; 3-5: 18.54; all: 18.48 — the map belongs on the side stream.
 
 
@@ -341,6 +350,8 @@ class FactorNN(torch.nn.Module):
             # variables' own node-wise map (v2v) goes with them: that balances the two streams (21.2 -> 20.9 ms; moving the
             # parity factors' f2f map as well serialises the join and costs 2 ms).
             two = _ops.SIDE_STREAM and nft > 1 and var.is_cuda
+            if two:
+                _ops.SIDE_ACTIVE = True        # (weight gradients are only parked once a second stream exists: ops.defer_wgrad)
             new_fac, h = [None] * nft, []
             if two:
                 main, side = torch.cuda.current_stream(var.device), _ops.side_stream(var.device)

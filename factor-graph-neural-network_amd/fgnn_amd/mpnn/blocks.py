@@ -489,7 +489,8 @@ class mp_conv_residual(base_mp_nn):
         mp = self.mp_conv
         bn2, conv2, bn3 = mp.bn, self.conv2[0], self.conv2[1]
         if not (FUSE_TRAIN_TAIL and self.training and torch.is_grad_enabled() and h.is_cuda and h.dtype == torch.bfloat16
-                and mp.nou == 64 and isinstance(mp.aggregtor, str) and isinstance(mp.activation_fn, torch.nn.ReLU)
+                and mp.nou == 64 and mp.extension == mp_conv_type.NO_EXTENSION      # (the operand preparation of the extension branches lives in mp_conv_v2.forward)
+                and isinstance(mp.aggregtor, str) and isinstance(mp.activation_fn, torch.nn.ReLU)
                 and isinstance(bn2, BatchNormAct2d) and bn2.training and isinstance(bn3, BatchNormAct2d) and bn3.training
                 and isinstance(conv2, PointwiseConv2d) and conv2.in_channels == 64 and conv2.out_channels in (64, 128, 256)
                 and all(b.track_running_stats and b.affine and b.momentum is not None for b in (bn2, bn3))

@@ -88,6 +88,8 @@ def timed(symbol, nbytes, fn, nflops=0):
 # backward pass ends (an engine callback, which also joins every such stream into the caller's).  Only gradients that go to
 # a sink (ops.grad_sink: the flat bucket) are deferred: a gradient tensor handed back to autograd must be complete in stream order.
 DEFER_WGRAD = os.environ.get('FGNN_NO_DEFER_WGRAD') is None       # (the variable: an A/B switch for tools / bench runs)
+SIDE_ACTIVE = False         # set by the assemblies the first time a forward actually forks onto the side stream: with ONE stream in
+                            # play parking buys no overlap and only keeps every layer's operands alive until the end of the backward
 _DEFERRED = {}              # stream -> [(launch closure, operands)]
 _DEFER_CALLBACK = [None]     # id of the backward pass (autograd graph task) whose end-of-pass callback is queued
 _DEFER_ISSUED = set()       # streams that got parked launches issued during the current backward pass
@@ -99,7 +101,7 @@ def defer_wgrad(launch, operands=()):
     OTHER stream allocated is otherwise handed back to that stream's allocator the moment the last reference drops — the
     engine's join with this stream happened before the parked kernel went out, so nothing else orders the reuse behind it
     (found as three weight gradients of hyper-factor maps reading overwritten rows on hipGraph replay)."""
-    if not DEFER_WGRAD:
+    if not DEFER_WGRAD or not SIDE_ACTIVE:
         launch()
         return
     st = torch.cuda.current_stream()
@@ -108,9 +110,13 @@ def defer_wgrad(launch, operands=()):
         launch()
         return
     if _DEFER_CALLBACK[0] != task:
-        for lst in _DEFERRED.values():      # a backward pass that died half-way left its launches parked: they belong to no pass
-            lst.clear()
-        _DEFER_ISSUED.clear()
+        # Another backward pass than the one that parked what is in the lists: a NESTED (re-entrant) pass inside it — checkpointing,
+        # a custom Function calling backward() — or a pass that died half-way.  Either way the parked launches are ISSUED, never
+        # dropped (they accumulate into sinked .grad buffers behind autograd's back: dropping them would lose gradients silently;
+        # issuing those of a dead pass only finishes an accumulation its owner discards).  The outer pass re-registers itself
+        # with its next parked launch; its own end-of-pass callback is still queued.
+        if any(_DEFERRED.values()):
+            flush_deferred()
         _DEFER_CALLBACK[0] = task
         torch.autograd.Variable._execution_engine.queue_callback(_flush_at_end_of_backward)
     _DEFERRED.setdefault(st, []).append((launch, tuple(operands)))
@@ -358,6 +364,11 @@ def side_stream(device):
     return st
 
 
+# Test hook (tests/test_parity_pins_gpu.py: routing-forced gradient pin): called with (filters parameter, argmax tensor) by every
+# training-mode operator forward, so that a reference can be run along the SAME max routes.  None in production.
+ROUTE_TAP = None
+
+
 class _MPConv(torch.autograd.Function):
     """z = agg(messages) + bias with the hand-written HIP forward and backward."""
 
@@ -370,6 +381,8 @@ class _MPConv(torch.autograd.Function):
             etype = etype.expand(x.shape[0], -1, -1, -1)
         z, amax = mpconv_forward_raw(x, nn_idx, etype, filters, bias, nou, net, ext, agg, want_stats=want_stats,
                                      want_argmax=True)
+        if ROUTE_TAP is not None:
+            ROUTE_TAP(filters, amax)
         ctx.cfg = (nou, net, ext, agg)
         ctx.has_bias = bias is not None
         ctx.params = (filters, bias)                     # the leaf tensors themselves (for grad_sink)

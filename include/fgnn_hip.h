@@ -78,9 +78,10 @@ int fgnn_mpconv_forward(const fgnn_mpconv_desc* d, const void* x, const int64_t*
  *            hyper-edge kernels of mpconv_bwd_hyper.hip)
  *   gfilters[R, nou*net] float32, ACCUMULATED into (caller zero-fills)
  *   gbias   [nou] float32 or NULL, ACCUMULATED into
- *   workspace / workspace_bytes : optional scratch of fgnn_mpconv_backward_workspace_bytes(d) bytes
- *            (device memory, contents undefined); with it the filter/bias gradients are reduced
- *            through per-workgroup slabs instead of contended global atomics.  NULL is allowed.
+ *   workspace / workspace_bytes : REQUIRED device scratch of fgnn_mpconv_backward_workspace_bytes(d) bytes (ABI >= 6: every backward —
+ *                                 the shape-generic one included — accumulates dW / dbias in per-workgroup slabs there and folds them
+ *                                 in a fixed order; no float atomics).  NULL or too small: FGNN_EINVAL.  Device memory, contents undefined on
+ *                                 entry and exit.
  */
 int fgnn_mpconv_backward(const fgnn_mpconv_desc* d, const void* x, const int64_t* nn_idx,
                          const void* etype, const float* filters, const void* gz,
