@@ -61,7 +61,7 @@ def parse():
     ap.add_argument('--no-dedupe', action='store_true',
                     help='with --tables per_sample: switch the content check off, so the kernels take the general '
                          'per-sample-graph path (a different graph per codeword would run at this speed)')
-    ap.add_argument('--cpu-all-cores', action='store_true', help='(kept for old command lines: the all-cores sample is now part of the default line)')
+    ap.add_argument('--cpu-all-cores', action='store_true', help='add the all-host-cores CPU sample (a child process, 60 s limit) to the line')
     ap.add_argument('--cpu-baseline-only', action='store_true',
                     help='time only the CPU baseline (no GPU needed) with --cpu-batch / --cpu-threads / --mode and print its JSON object')
     ap.add_argument('--cpu-batch', type=int, default=512)
@@ -227,14 +227,20 @@ def dist_report(world, dev, elapsed_local, steps):
 
 def cpu_baseline_suite(args):
     """The default line's CPU legs (rank 0, N = 1), all bounded samples of the benched workload (the oracle's LDPCModel, reference
-    op order).  `cpu_baseline` = BASELINE.md §3's setting for the batch (256 codewords) on `--cpu-threads` (16) threads — the
-    FASTEST CPU configuration measured on the GPU box's host (r03: 3.96 M messages/s; batch 512 on the same threads: 1.17 M,
-    reported as `cpu_baseline_b512`; PyTorch's CPU backend loses to contention beyond ~16 intra-op threads on these small
-    tensors).  `cpu_baseline_all_cores` is §3's `torch.set_num_threads(os.cpu_count())` taken literally, run in a child process
-    with a hard time limit: on the 256-core host one iteration does not finish within a minute."""
+    op order; BASELINE.md §3: eval-mode forward AND train-mode fwd+bwd, batch 256).  `cpu_baseline` = the benched mode on
+    `--cpu-threads` (16) threads — the fastest CPU configuration measured on the GPU boxes' hosts (PyTorch's CPU backend loses to
+    contention beyond ~16 intra-op threads on these small tensors) —, `cpu_baseline_eval` / `cpu_baseline_train` = both modes
+    (one of them is the same sample as `cpu_baseline`).  §3's `torch.set_num_threads(os.cpu_count())` taken literally
+    (`cpu_baseline_all_cores`, a child process under a 60 s limit that one iteration does not finish within on the 224-thread
+    hosts) is behind `--cpu-all-cores`: it cost a minute of every default run to report null."""
     import subprocess
     out = {'cpu_baseline': cpu_baseline(256, args.mode, args.cpu_threads, budget=12.0, max_iters=5)}
-    out['cpu_baseline_b512'] = cpu_baseline(args.cpu_batch, args.mode, args.cpu_threads, budget=12.0, max_iters=3)
+    other = 'fwd' if args.mode == 'train' else 'train'
+    leg = cpu_baseline(256, other, args.cpu_threads, budget=10.0, max_iters=5)
+    out['cpu_baseline_eval'] = leg if other == 'fwd' else out['cpu_baseline']
+    out['cpu_baseline_train'] = leg if other == 'train' else out['cpu_baseline']
+    if not args.cpu_all_cores:
+        return out
     ncores = os.cpu_count() or 1
     limit = 60
     cmd = [sys.executable, os.path.abspath(__file__), '--cpu-baseline-only', '--cpu-batch', '256', '--cpu-threads', str(ncores),
@@ -494,6 +500,7 @@ def main_syn(args):
                        'peak_hbm_GB': round(torch.cuda.max_memory_allocated(dev) / 1e9, 2)},
             'roofline': roofline,
             'kernels': {k: {'launches': v['launches'], 'avg_us': round(v['ms'] / v['launches'] * 1e3, 2),
+                            'avg_us_in_step': round(v.get('ms2', v['ms']) / v['launches'] * 1e3, 2),
                             'total_ms': round(v['ms'], 3),
                             'algorithmic_GBs': round(v['bytes'] / max(v['ms'], 1e-9) / 1e6, 1)}
                         for k, v in sorted(kernels.items(), key=lambda kv: -kv[1]['ms'])},
@@ -628,63 +635,91 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # one instrumented step: per-kernel-symbol launch durations on the launch stream
+    # Instrumented steps: per-kernel-symbol launch durations from events on the launch stream.  TWO passes: (1) one stream —
+    # each kernel alone on the chip ("isolated"); (2) the two streams of the timed step — the side branch's kernels run beside
+    # the operator's, as inside the replayed graph ("in_step").  The roofline fractions quoted are the IN-STEP ones; the
+    # committed rocprofv3 kernel trace of the replayed graph (profiles/r04) carries the in-graph averages they should agree with.
     roofline = None
     kernels = {}
     if rank == 0:
-        ops.SIDE_STREAM = False   # per-kernel durations: one stream, so that no other branch's kernels share the chip
+        ops.SIDE_STREAM = False
         compute()        # untimed eager pass: first eager launches of a kernel variant pay its code-object load (10 ms once seen)
         torch.cuda.synchronize()
         ops.TIMER = ops.KernelTimer()
         compute()        # eager, WITHOUT the collective / optimizer: the other ranks are not taking part
-        ops.SIDE_STREAM = True
         kernels = ops.TIMER.summary()
+        ops.SIDE_STREAM = True
+        compute()
+        torch.cuda.synchronize()
+        ops.TIMER = ops.KernelTimer()
+        compute()
+        kernels2 = ops.TIMER.summary()
         ops.TIMER = None
         if kernels:
-            # the roofline object describes the VF/FV message operator (the hot path of BASELINE.json): its kernel
-            # with the largest total time; every other hand-written kernel is listed under "kernels" with its GB/s
-            sym, r = max(((k, v) for k, v in kernels.items() if k.startswith('mpconv_')), key=lambda kv: kv[1]['ms'])
-            avg_ms = r['ms'] / r['launches']
-            gbs = (r['bytes'] / r['launches']) / (avg_ms * 1e-3) / 1e9
-            tfs = (r['flops'] / r['launches']) / (avg_ms * 1e-3) / 1e12
-            hbm = {'bound': 'hbm', 'achieved': round(gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                   'frac': round(gbs / HBM_PEAK_GBS, 4), 'traffic': None}
-            mfma = {'bound': 'mfma', 'achieved': round(tfs, 2), 'peak': F32_MFMA_PEAK_TFLOPS,
-                    'unit': 'TFLOP/s', 'frac': round(tfs / F32_MFMA_PEAK_TFLOPS, 4), 'traffic': None}
-            # Which roof binds: the f32-MFMA kernels (exact v_mfma_f32_16x16x4_f32; also used with bf16
-            # storage in the backward) sit above the f32 ridge (AI 42-80 FLOP/B vs 157 TF / 8 TB/s = 20):
-            # MFMA-bound.  The bf16-MFMA kernels (mpconv_*_b16 / mpconv_*_sg, AI ~80 << bf16 ridge ~312) are
-            # HBM-bound.  The other figure is reported alongside.
-            if 'b16' in sym or '_sg_' in sym:        # the bf16-storage, bf16-MFMA kernel families
-                mfma['peak'] = BF16_MFMA_PEAK_TFLOPS
-                mfma['frac'] = round(tfs / BF16_MFMA_PEAK_TFLOPS, 4)
-                roofline = dict(hbm)
-                other = ('mfma', mfma)
-            else:
-                roofline = dict(mfma)
-                other = ('hbm', hbm)
-            # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r0N/pmc_traffic.json:
-            # FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE), measured at the kernel's LDPC 64->64
-            # shape; null when this kernel symbol has no committed PMC pass
             try:
                 pmc = {}
-                for rnd in ('r01', 'r02', 'r03'):     # later rounds' passes override (new kernel families; r03: one pass PER INSTANCE)
+                for rnd in ('r01', 'r02', 'r03', 'r04'):     # later rounds' passes override (new kernel families; one pass PER INSTANCE)
                     pth = os.path.join(ROOT, 'profiles', rnd, 'pmc_traffic.json')
                     if os.path.exists(pth):
                         pmc.update(json.load(open(pth))['kernels'])
-                traffic = pmc.get(sym, {}).get('traffic_bytes_per_launch')
-                # matrix-core busy fraction from the same committed PMC passes: SQ_VALU_MFMA_BUSY_CYCLES over the SIMD-cycles of
-                # the launch (SQ_BUSY_CYCLES is counted per shader engine: x 32 SIMDs each)
-                mfma_busy = pmc.get(sym, {}).get('mfma_busy')
             except (OSError, ValueError, KeyError):
-                traffic = mfma_busy = None
-            roofline['traffic'] = traffic
-            roofline['mfma_busy'] = mfma_busy
-            roofline.update({'kernel': sym, 'launches_per_step': r['launches'],
-                             'avg_launch_us': round(avg_ms * 1e3, 2),
-                             'algorithmic_bytes_per_launch': r['bytes'] // r['launches'],
-                             'algorithmic_flops_per_launch': r['flops'] // r['launches'],
-                             other[0]: other[1]})
+                pmc = {}
+            in_graph = {}                                 # kernel symbol -> average ns in the committed trace of the replayed graph
+            try:
+                import csv
+                pth = os.path.join(ROOT, 'profiles', 'r04', 'final_bf16_%s_kernel_stats_top40.csv' % ('train' if train else 'fwd'))
+                for row in csv.DictReader(open(pth)):
+                    in_graph[row['Name']] = float(row['AverageNs'])
+            except (OSError, ValueError, KeyError):
+                pass
+
+            def describe(sym):
+                r, r2 = kernels[sym], kernels2.get(sym)
+                n = r['launches']
+                iso_ms = r['ms'] / n
+                step_ms = (r2['ms'] / r2['launches']) if r2 else iso_ms
+                nb, nf = r['bytes'] / n, r['flops'] / n
+                gbs = nb / (step_ms * 1e-3) / 1e9
+                bf16 = any(t in sym for t in ('b16', '_sg_', '_ws_'))      # the bf16-storage, bf16-MFMA kernel families: HBM-bound (AI ~80 << ridge ~312)
+                d = {'kernel': sym, 'launches_per_step': n, 'bound': 'hbm' if bf16 else 'mfma',
+                     'algorithmic_bytes_per_launch': int(nb), 'algorithmic_flops_per_launch': int(nf),
+                     'avg_launch_us_isolated': round(iso_ms * 1e3, 2), 'avg_launch_us_in_step': round(step_ms * 1e3, 2),
+                     'avg_launch_us_in_graph_rocprof': None,
+                     'achieved': round(gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(gbs / HBM_PEAK_GBS, 4),
+                     'frac_isolated': round(nb / (iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                     'traffic': pmc.get(sym, {}).get('traffic_bytes_per_launch'), 'mfma_busy': pmc.get(sym, {}).get('mfma_busy')}
+                for name, ns in in_graph.items():
+                    if sym.split(' x2')[0].replace(' ', '') in name.replace(' ', ''):
+                        d['avg_launch_us_in_graph_rocprof'] = round(ns / 1e3 * (2 if sym.endswith(' x2') else 1), 2)
+                if not bf16:                              # the f32-MFMA kernels (exact v_mfma_f32_16x16x4_f32) sit above the f32 ridge: matrix-core-bound
+                    tfs = nf / (step_ms * 1e-3) / 1e12
+                    d.update({'achieved': round(tfs, 2), 'peak': F32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                              'frac': round(tfs / F32_MFMA_PEAK_TFLOPS, 4), 'hbm_frac': round(gbs / HBM_PEAK_GBS, 4)})
+                return d
+
+            def family(prefix):
+                syms = [k for k in kernels if k.startswith(prefix)]
+                if not syms:
+                    return None, None
+                top = max(syms, key=lambda k: kernels[k]['ms'])
+                t2 = sum((kernels2.get(k) or kernels[k])['ms'] for k in syms)
+                nb = sum(kernels[k]['bytes'] for k in syms)
+                return describe(top), round(nb / (t2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+
+            fwd, fwd_frac = family('mpconv_fwd')
+            bwd, bwd_frac = family('mpconv_bwd')
+            # the top-level object = the operator kernel with the largest total time (the contract's "dominant kernel"); both
+            # directions ride along, and operator_*_frac = sum of the direction's algorithmic bytes / sum of its in-step time
+            # over ALL its calls
+            dom = max([d for d in (fwd, bwd) if d], key=lambda d: kernels[d['kernel']]['ms'])
+            roofline = dict(dom)
+            roofline.update({'avg_launch_us': dom['avg_launch_us_in_step'], 'forward': fwd, 'backward': bwd,
+                             'operator_fwd_frac': fwd_frac, 'operator_bwd_frac': bwd_frac,
+                             'durations': 'frac / achieved use avg_launch_us_in_step (events around each launch in an eager step on the '
+                                          'two streams of the timed graph); _isolated = the same on one stream; _in_graph_rocprof = '
+                                          'the committed rocprofv3 kernel trace of the replayed graph (profiles/r04)'})
+            for k, v in kernels.items():
+                v['ms2'] = (kernels2.get(k) or v)['ms']
     fence()
 
     if rank == 0:
@@ -716,6 +751,7 @@ def main():
                        'mode': args.mode, 'hip_graph': graphed is not None, 'distributed': dist_info},
             'roofline': roofline,
             'kernels': {k: {'launches': v['launches'], 'avg_us': round(v['ms'] / v['launches'] * 1e3, 2),
+                            'avg_us_in_step': round(v.get('ms2', v['ms']) / v['launches'] * 1e3, 2),
                             'total_ms': round(v['ms'], 3),
                             'algorithmic_GBs': round(v['bytes'] / max(v['ms'], 1e-9) / 1e6, 1)}
                         for k, v in sorted(kernels.items(), key=lambda kv: -kv[1]['ms'])},
