@@ -625,7 +625,7 @@ int fgnn_mpconv_backward_sg(const fgnn_mpconv_desc* d, const void* x, const int6
     else if (KC == 3 && NPW <= 3 && DPW <= 6) fn = GSL == 1 ? (void*)mpconv_bwd_sg_kernel<3, 6, 3, 6, 1> : (void*)mpconv_bwd_sg_kernel<3, 6, 3, 6, 2>;
     if (!fn) BS_REJECT(14);
 
-    if (!split) {                                     // third generation first (mpconv_bwd_ws.hip); 0 = not its shape
+    {                                                 // third generation first (mpconv_bwd_ws.hip; also splits 64 -> 128); 0 = not its shape
         const int r = fgnn_mpconv_backward_ws(d, x, nn_idx, etype, filters, gz, argmax, gx, getype, gfilters, gbias, workspace,
                                               workspace_bytes, stream);
         if (r != 0) return r;

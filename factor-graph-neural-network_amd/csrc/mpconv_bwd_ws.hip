@@ -57,7 +57,7 @@ struct BwParams {
     uint16_t* get;
     float* ws;               // per-workgroup slabs [grid][64*256 + 64]
     int B, N, M;
-    int y_ld, w_ld;
+    int y_ld, w_ld, accum;       // accum: gx and getype are ADDED to (second launch of a 64 -> 128 call, over the upper output channels)
     long long x_sb, et_sb, y_sb;     // elements
     long long* prof;         // FGNN_PROF (builds with -DFGNN_ENABLE_PROF only): phase timeline
 };
@@ -75,11 +75,16 @@ extern __shared__ __attribute__((aligned(16))) unsigned char bw_lds[];
 
 void fgnn_launch_slab_reduce(const float* ws, int nslab, int64_t slab_len, int64_t nw, float* gW, float* gbias,
                              hipStream_t st);
+void fgnn_launch_slab_reduce_ld(const float* ws, int nslab, int64_t slab_len, int64_t nw, int ncols, int ld, float* gW,
+                                float* gbias, hipStream_t st);
 
 __device__ __forceinline__ unsigned bw_pack2(float a, float b) {
     typedef __bf16 v2 __attribute__((ext_vector_type(2)));
     const v2 h = {(__bf16)a, (__bf16)b};
     return __builtin_bit_cast(unsigned, h);
+}
+__device__ __forceinline__ unsigned bw_add2(unsigned a, unsigned b) {      // two bf16 sums, f32 arithmetic, rounded once
+    return bw_pack2(__uint_as_float(a << 16) + __uint_as_float(b << 16), __uint_as_float(a & 0xffff0000u) + __uint_as_float(b & 0xffff0000u));
 }
 __device__ __forceinline__ bw_bf16x8 bw_frag_f32(const float* p8) {      // 8 consecutive f32 -> one fragment
     const f32x4 a = *reinterpret_cast<const f32x4*>(p8), b = *reinterpret_cast<const f32x4*>(p8 + 4);
@@ -535,7 +540,11 @@ __global__ __launch_bounds__(BW_THREADS) void mpconv_bwd_ws_kernel(const BwParam
                 // edge-type gradient of this sample: staging -> memory, 16 bytes per lane (8 mk bytes; host: mk even, 16-byte aligned)
                 const int nvec = (8 * mk) >> 4;
                 if (tid < nvec) {
-                    const uint4 v = *reinterpret_cast<const uint4*>(bw_lds + OFF_GST + tid * 16);
+                    uint4 v = *reinterpret_cast<const uint4*>(bw_lds + OFF_GST + tid * 16);
+                    if (p.accum) {                             // second launch of a split call: add to what the first one stored
+                        const uint4 o = *bw_at<uint4>(p.get + (int64_t)b * 4 * mk, (unsigned)tid * 16u);
+                        v = make_uint4(bw_add2(v.x, o.x), bw_add2(v.y, o.y), bw_add2(v.z, o.z), bw_add2(v.w, o.w));
+                    }
                     *bw_at<uint4>(p.get + (int64_t)b * 4 * mk, (unsigned)tid * 16u) = v;
                 }
             }
@@ -602,10 +611,17 @@ __global__ __launch_bounds__(BW_THREADS) void mpconv_bwd_ws_kernel(const BwParam
                     const int n = nt * 32 + l31;
                     if (n < N) {
 #pragma unroll
-                        for (int g = 0; g < 4; ++g)
-                            *bw_at<uint2>(gxb, (unsigned)(n * 64 + 32 * wave + 8 * g + 4 * lh) * 2u) =
-                                make_uint2(bw_pack2(ae[4 * g] + ao[4 * g], ae[4 * g + 1] + ao[4 * g + 1]),
-                                           bw_pack2(ae[4 * g + 2] + ao[4 * g + 2], ae[4 * g + 3] + ao[4 * g + 3]));
+                        for (int g = 0; g < 4; ++g) {
+                            float v0 = ae[4 * g] + ao[4 * g], v1 = ae[4 * g + 1] + ao[4 * g + 1], v2 = ae[4 * g + 2] + ao[4 * g + 2],
+                                  v3 = ae[4 * g + 3] + ao[4 * g + 3];
+                            uint2* dst = bw_at<uint2>(gxb, (unsigned)(n * 64 + 32 * wave + 8 * g + 4 * lh) * 2u);
+                            if (p.accum) {
+                                const uint2 o = *dst;
+                                v0 += __uint_as_float(o.x << 16); v1 += __uint_as_float(o.x & 0xffff0000u);
+                                v2 += __uint_as_float(o.y << 16); v3 += __uint_as_float(o.y & 0xffff0000u);
+                            }
+                            *dst = make_uint2(bw_pack2(v0, v1), bw_pack2(v2, v3));
+                        }
                     }
                 }
         } else if (dw_wave) {
@@ -700,7 +716,8 @@ int fgnn_mpconv_backward_ws(const fgnn_mpconv_desc* d, const void* x, const int6
                             fgnn_stream_t stream) {
     static const bool off = getenv("FGNN_NO_WS") != nullptr || getenv("FGNN_NO_WS_BWD") != nullptr;
     if (off) BW_REJECT(0);
-    if (d->nin != 64 || d->nou != 64) BW_REJECT(1);
+    const bool split = d->nin == 64 && d->nou == 128;                    // 64 -> 128: two launches over the halves of the output channels
+    if (d->nin != 64 || (d->nou != 64 && !split)) BW_REJECT(1);
     const int KC = d->k, DEG = KC == 6 ? 3 : 6;
     const int indeg = d->reserved & 0xffff;
     if (indeg < 1 || indeg > DEG) BW_REJECT(2);
@@ -717,7 +734,7 @@ int fgnn_mpconv_backward_ws(const fgnn_mpconv_desc* d, const void* x, const int6
     p.gz = (const uint16_t*)gz; p.argmax = argmax; p.gx = (uint16_t*)gx; p.get = (uint16_t*)getype;
     p.ws = (float*)workspace;
     p.B = d->B; p.N = d->N; p.M = d->M;
-    p.y_ld = d->nou; p.w_ld = d->nou * 4;
+    p.y_ld = d->nou; p.w_ld = d->nou * 4; p.accum = 0;
     p.x_sb = d->x_sb; p.et_sb = d->et_sb; p.y_sb = d->y_sb;
     const int off_b = KC == 6 ? BwLayout<6>::BYTES : BwLayout<3>::BYTES;
     static_assert(BwLayout<6>::BYTES <= 160 * 1024 && BwLayout<3>::BYTES <= 160 * 1024, "LDS");
@@ -729,7 +746,7 @@ int fgnn_mpconv_backward_ws(const fgnn_mpconv_desc* d, const void* x, const int6
     const int chunk = (d->B + grid - 1) / grid;
     grid = (d->B + chunk - 1) / chunk;
     hipStream_t st = (hipStream_t)stream;
-    fgnn_note_kernel("mpconv_bwd_ws_kernel<%d, %d>", KC, DEG);
+    fgnn_note_kernel(split ? "mpconv_bwd_ws_kernel<%d, %d> x2" : "mpconv_bwd_ws_kernel<%d, %d>", KC, DEG);
     p.prof = nullptr;
 #ifdef FGNN_ENABLE_PROF
     static long long* prof_buf = nullptr;
@@ -758,7 +775,16 @@ int fgnn_mpconv_backward_ws(const fgnn_mpconv_desc* d, const void* x, const int6
         fprintf(stderr, "\n");
     }
 #endif
-    fgnn_launch_slab_reduce(p.ws, grid, slab_len, nw, gfilters, gbias, st);
+    if (!split) fgnn_launch_slab_reduce(p.ws, grid, slab_len, nw, gfilters, gbias, st);
+    else {
+        // slab rows are 256 columns of gfilters' 512: lower half, then the second launch on the upper 64 output channels, which ADDS
+        // to gx / getype (one more bf16 rounding of those two) and folds its dW / dbias into the upper column / channel blocks
+        fgnn_launch_slab_reduce_ld(p.ws, grid, slab_len, nw, 256, 512, gfilters, gbias, st);
+        p.W += 256; p.gz += 64; p.argmax += 64; p.accum = 1;
+        e = hipLaunchKernel(fn, dim3(grid), dim3(BW_THREADS), args, off_b, st);
+        if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "mpconv ws backward launch (upper half): %s", hipGetErrorString(e));
+        fgnn_launch_slab_reduce_ld(p.ws, grid, slab_len, nw, 256, 512, gfilters + 256, gbias + 64, st);
+    }
     e = hipGetLastError();
     if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "mpconv backward helper launch: %s", hipGetErrorString(e));
     return 1;

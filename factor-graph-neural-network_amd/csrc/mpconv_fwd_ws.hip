@@ -519,7 +519,8 @@ int fgnn_mpconv_forward_ws(const fgnn_mpconv_desc* d, const void* x, const int64
     if (lds > 160 * 1024) return 0;
     void* fn = nullptr;
     if (d->nin == 64) fn = KC == 6 ? ws_pick_mode<64, 6, 3>(mode) : ws_pick_mode<64, 3, 3>(mode);
-    // (nin = 128: the 64 resident A registers of a producer spill under 128 VGPRs — those calls stay on mpconv_fwd_sg.hip)
+    // (nin = 128: 64 resident A registers per producer; what spills under 128 VGPRs is the fragment-loading prologue only — none in the sample loops)
+    else if (d->nin == 128) fn = KC == 6 ? ws_pick_mode<128, 6, 2>(mode) : ws_pick_mode<128, 3, 2>(mode);
     if (!fn) return 0;
     int grid = 256;
     if (grid > d->B) grid = d->B;
