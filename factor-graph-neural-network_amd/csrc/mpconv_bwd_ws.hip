@@ -145,8 +145,8 @@ __global__ __launch_bounds__(BW_THREADS) void mpconv_bwd_ws_kernel(const BwParam
                   OFF_TAB = LY::OFF_TAB, OFF_SLOT = LY::OFF_SLOT, OFF_GT = LY::OFF_GT;
     constexpr int NPG = 16 / QS;                      // source nodes per detype tile
     constexpr int NG = KC == 6 ? 3 : 4;               // detype tiles per wave: Npad / NPG / 8
-    constexpr int NSLOT = KC == 3 ? 6 : 3;            // staging items per builder thread (8 M <= 768 / 384 items, 128 builder threads)
-    constexpr int ESLOT = 3;                          // in-edge slots per builder thread (N QS <= 384)
+    constexpr int NSLOT = KC == 3 ? 2 : 1;            // staging items per staging thread (8 M <= 768 / 384 items, 384 staging threads)
+    constexpr int ESLOT = 1;                          // in-edge slots per staging thread (N QS <= 384)
     constexpr int MAXNPW = KC == 6 ? 12 : 8;          // source nodes per wave in the dP phase: Npad / 8
     const int tid = threadIdx.x;
     BW_STAMP_G(0);
@@ -165,15 +165,16 @@ __global__ __launch_bounds__(BW_THREADS) void mpconv_bwd_ws_kernel(const BwParam
     // waves 4-5 — the SIMD mates of the dx waves, VALU beside MFMA — stage the next sample and own the LDS-DMA of x
     const bool dx_wave = wave < 2;
     const bool dw_wave = wave == 2 || wave == 3 || wave == 6 || wave == 7;
-    const bool build_wave = wave == 4 || wave == 5;
-    const bool dma_wave = wave >= 2;                                      // the LDS-DMA of x: waves that never store (their vmcnt only counts it)
-    const int bl = (wave - 4) * 64 + lane;                                // builder-local thread index 0..127
+    const bool build_wave = wave >= 2;                                    // staging: every wave but the two that run dx (one item per thread)
+    const bool dma_wave = dw_wave;                                        // the LDS-DMA of x: waves that never store (their vmcnt only counts it)
+    const int bl = (wave - 2) * 64 + lane;                                // staging-local thread index 0..383
+    const int dwq = wave < 4 ? wave - 2 : wave - 4;                       // 0..3 among the dW waves
 
-    // LDS-DMA of x: pieces (wave - 2) + 6 u of Npad / 8; rows >= N re-read row N - 1 (finite; their dP rows are zero)
-    unsigned dsrc[2];
+    // LDS-DMA of x: pieces dwq + 4 u of the twelve; rows >= N re-read row N - 1 (finite; their dP rows are zero)
+    unsigned dsrc[3];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        const int slot = 64 * ((wave - 2) + 6 * u) + lane, row = slot >> 3, pos = slot & 7;
+    for (int u = 0; u < 3; ++u) {
+        const int slot = 64 * (dwq + 4 * u) + lane, row = slot >> 3, pos = slot & 7;
         dsrc[u] = (unsigned)(min(row, N - 1) * BW_XROW + ((pos ^ ((row >> 1) & 7)) << 4));
     }
     constexpr int npieces = 12;                       // both x buffers hold 96 rows; rows >= N are copies of row N - 1
@@ -182,11 +183,11 @@ __global__ __launch_bounds__(BW_THREADS) void mpconv_bwd_ws_kernel(const BwParam
     const int b_begin = blockIdx.x * chunk_b, b_end = min(p.B, b_begin + chunk_b);
     const unsigned char* xg = reinterpret_cast<const unsigned char*>(p.x);
 
-    auto dma_x = [&](int b, int buf) {                 // waves 2-7
+    auto dma_x = [&](int b, int buf) {                 // the dW waves
         const unsigned char* xb = xg + (int64_t)b * p.x_sb * 2;
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int piece = (wave - 2) + 6 * u;
+        for (int u = 0; u < 3; ++u) {
+            const int piece = dwq + 4 * u;
             if (piece < npieces) bw_dma16(xb + dsrc[u], lds0 + (unsigned)(OFF_X + buf * (BW_MAXN * BW_XROW) + piece * 1024));
         }
     };
@@ -240,7 +241,7 @@ __global__ __launch_bounds__(BW_THREADS) void mpconv_bwd_ws_kernel(const BwParam
         asm volatile("" : "+v"(blo));
 #pragma unroll
         for (int sl = 0; sl < NSLOT; ++sl) {
-            const int item = blo + 128 * sl;
+            const int item = blo + 384 * sl;
             pg[sl] = make_uint4(0, 0, 0, 0);
             pa[sl] = make_uint2(0, 0);
             if (build_wave && item < 8 * M) {
@@ -310,7 +311,7 @@ __global__ __launch_bounds__(BW_THREADS) void mpconv_bwd_ws_kernel(const BwParam
     for (int sl = 0; sl < ESLOT; ++sl) {
         et_src[sl] = -1;
         et_dst[sl] = 0;
-        const int is = bl + 128 * sl;
+        const int is = bl + 384 * sl;
         if (build_wave && is < N * QS) {
             const int n = is / QS, q = is - n * QS;
             if (q < DEG) et_src[sl] = tab[n * QS + q];
@@ -386,7 +387,7 @@ __global__ __launch_bounds__(BW_THREADS) void mpconv_bwd_ws_kernel(const BwParam
         }
 #pragma unroll
         for (int sl = 0; sl < NSLOT; ++sl) {
-            const int item = bl + 128 * sl;
+            const int item = bl + 384 * sl;
             if (item < 8 * M) {
                 // argmax bytes -> 16-bit halves, one-hot per half; slot j keeps a gz half where bit j is set:
                 // (onehot << (15 - j)) >> 15 (arithmetic, per half) is the 16-bit mask
@@ -549,6 +550,42 @@ __global__ __launch_bounds__(BW_THREADS) void mpconv_bwd_ws_kernel(const BwParam
                 }
             }
         };
+        auto phase3_dw = [&](const uint4 (&pg)[NSLOT], const uint2 (&pa)[NSLOT], const uint2 (&pe)[ESLOT]) {
+                const unsigned xbase = lds0 + (unsigned)(OFF_X + cur * (BW_MAXN * BW_XROW));
+                constexpr int nks = NMAX / 16;            // even
+                uint2 f0[8], f1[8];
+                auto load = [&](uint2 (&f)[8], int ks) {   // A: channel tiles 0 / 1 (two reads each); B: this wave's two column tiles
+    #pragma unroll
+                    for (int c2 = 0; c2 < 2; ++c2) {
+                        f[2 * c2] = bw_tr(xbase + xa[c2][0] + ks * (16 * BW_XROW));
+                        f[2 * c2 + 1] = bw_tr(xbase + xa[c2][1] + ks * (16 * BW_XROW));
+                    }
+    #pragma unroll
+                    for (int cj = 0; cj < 2; ++cj) {
+                        f[4 + 2 * cj] = bw_tr(db[0] + ks * (16 * BW_DROW) + cj * 64);
+                        f[5 + 2 * cj] = bw_tr(db[1] + ks * (16 * BW_DROW) + cj * 64);
+                    }
+                };
+                auto mma = [&](const uint2 (&f)[8]) {
+    #pragma unroll
+                    for (int c2 = 0; c2 < 2; ++c2)
+    #pragma unroll
+                        for (int cj = 0; cj < 2; ++cj)
+                            RA[2 * c2 + cj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                                __builtin_bit_cast(bw_bf16x8, make_uint4(f[2 * c2].x, f[2 * c2].y, f[2 * c2 + 1].x, f[2 * c2 + 1].y)),
+                                __builtin_bit_cast(bw_bf16x8, make_uint4(f[4 + 2 * cj].x, f[4 + 2 * cj].y, f[5 + 2 * cj].x, f[5 + 2 * cj].y)),
+                                RA[2 * c2 + cj], 0, 0, 0);
+                };
+                load(f0, 0);
+                if (has_next) build(pg, pa, pe);           // G / etT of sample b + 1, under the first transpose reads
+    #pragma unroll 1
+                for (int ks = 0; ks < nks; ks += 2) {      // the next k-step's eight transpose reads are in flight under this one's MFMAs
+                    load(f1, ks + 1);
+                    mma(f0);
+                    if (ks + 2 < nks) load(f0, ks + 2);
+                    mma(f1);
+                }
+        };
         if (build_wave) {
             // the next sample's gz / argmax / edge types: requested two phases ahead of their use (past the last sample: a harmless re-read)
             uint4 pg[NSLOT];
@@ -563,7 +600,9 @@ __global__ __launch_bounds__(BW_THREADS) void mpconv_bwd_ws_kernel(const BwParam
             BW_STAMP(5);
             bw_barrier();
             BW_STAMP(6);
-            if (has_next) build(pg, pa, pe);               // G / etT of sample b + 1 (their readers finished in phase 2b)
+            // ================= phase 3 (waves 2-7): dW behind the staging of the next sample (their readers finished in phase 2b) =================
+            if (dw_wave) phase3_dw(pg, pa, pe);
+            else if (has_next) build(pg, pa, pe);
         } else {
             phase2a();
             BW_STAMP(3);
@@ -573,8 +612,8 @@ __global__ __launch_bounds__(BW_THREADS) void mpconv_bwd_ws_kernel(const BwParam
             BW_STAMP(5);
             bw_barrier();
             BW_STAMP(6);
-            // ================= phase 3: dx | dW (| staging of the next sample, above) =================
-            if (dx_wave) {
+            // ================= phase 3 (waves 0-1): dx =================
+            {
                 uint16_t* gxb = p.gx + (int64_t)b * p.x_sb;
                     // Software pipeline over the node tiles with no extra registers: the tile's fragments 8..15 are requested when it starts
                 // (they land under the first eight MFMAs), fragments 0..7 of the NEXT tile when those eight are done.  Two chains over the
@@ -623,40 +662,6 @@ __global__ __launch_bounds__(BW_THREADS) void mpconv_bwd_ws_kernel(const BwParam
                             *dst = make_uint2(bw_pack2(v0, v1), bw_pack2(v2, v3));
                         }
                     }
-                }
-        } else if (dw_wave) {
-                const unsigned xbase = lds0 + (unsigned)(OFF_X + cur * (BW_MAXN * BW_XROW));
-                constexpr int nks = NMAX / 16;            // even
-                uint2 f0[8], f1[8];
-                auto load = [&](uint2 (&f)[8], int ks) {   // A: channel tiles 0 / 1 (two reads each); B: this wave's two column tiles
-    #pragma unroll
-                    for (int c2 = 0; c2 < 2; ++c2) {
-                        f[2 * c2] = bw_tr(xbase + xa[c2][0] + ks * (16 * BW_XROW));
-                        f[2 * c2 + 1] = bw_tr(xbase + xa[c2][1] + ks * (16 * BW_XROW));
-                    }
-    #pragma unroll
-                    for (int cj = 0; cj < 2; ++cj) {
-                        f[4 + 2 * cj] = bw_tr(db[0] + ks * (16 * BW_DROW) + cj * 64);
-                        f[5 + 2 * cj] = bw_tr(db[1] + ks * (16 * BW_DROW) + cj * 64);
-                    }
-                };
-                auto mma = [&](const uint2 (&f)[8]) {
-    #pragma unroll
-                    for (int c2 = 0; c2 < 2; ++c2)
-    #pragma unroll
-                        for (int cj = 0; cj < 2; ++cj)
-                            RA[2 * c2 + cj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                                __builtin_bit_cast(bw_bf16x8, make_uint4(f[2 * c2].x, f[2 * c2].y, f[2 * c2 + 1].x, f[2 * c2 + 1].y)),
-                                __builtin_bit_cast(bw_bf16x8, make_uint4(f[4 + 2 * cj].x, f[4 + 2 * cj].y, f[5 + 2 * cj].x, f[5 + 2 * cj].y)),
-                                RA[2 * c2 + cj], 0, 0, 0);
-                };
-                load(f0, 0);
-    #pragma unroll 1
-                for (int ks = 0; ks < nks; ks += 2) {      // the next k-step's eight transpose reads are in flight under this one's MFMAs
-                    load(f1, ks + 1);
-                    mma(f0);
-                    if (ks + 2 < nks) load(f0, ks + 2);
-                    mma(f1);
                 }
             }
         }
