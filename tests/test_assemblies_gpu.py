@@ -959,3 +959,77 @@ def test_parked_launches_of_a_failed_backward_pass_are_dropped(dev):
     again = run(False)
     assert torch.equal(again, good)                     # not doubled by the stale launch, and a's / b's own gradients are there
     assert not any(lst for lst in ops._DEFERRED.values())
+
+
+def test_fast_path_switch_for_an_unchanged_script(dev):
+    """fgnn_amd.enable_fast_path(): a module composed the way the reference's script composes its model — FactorNN from the
+    `lib.model.mpnn` shim + torch `Sequential(Conv2d, ReLU, Conv2d)` edge models (train_ldpc.py:19-99, restated here) — and
+    a `torch.optim.Adam(model.parameters())` + `LambdaLR` written as the script writes them get: EdgeMLP edge models around the
+    SAME parameters, bf16 autocast inside the model's forward, the flat-bucket one-kernel Adam.  Outputs stay within bf16
+    tolerance of the f32 path, the training steps run and move the parameters."""
+    import sys, os
+    import fgnn_amd
+    from fgnn_amd.edge_mlp import EdgeMLP
+    from fgnn_amd.fastpath import FastAdam
+    from fgnn_amd.ldpc import synthetic_batch
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'factor-graph-neural-network_amd'))
+    from lib.model.mpnn import FactorNN                                            # the documented import shim
+
+    class ScriptModel(torch.nn.Module):                                            # composition of train_ldpc.py's LDPCModel
+        def __init__(self):
+            super().__init__()
+            self.main = FactorNN(2, [6, 96], [64, 64, 64, 128, 256, 256, 128, 64, 64], [4, 1], 2,
+                                 skip_link={4: 3, 5: 2, 7: 0}, ret_high=True, aggregator='max')
+            mk = lambda: torch.nn.Sequential(torch.nn.Conv2d(7, 64, 1), torch.nn.ReLU(inplace=True), torch.nn.Conv2d(64, 4, 1))
+            self.emodel_f2v, self.emodel_v2f = mk(), mk()
+
+        def forward(self, node_feature, hop_feature, nn_idx_f2v, nn_idx_v2f, ef_f2v, ef_v2f):
+            B = node_feature.shape[0]
+            hyper = node_feature[:, 0, :, :].detach().reshape(B, 96, 1, 1)
+            ones = lambda *s: torch.ones(*s, device=node_feature.device, dtype=node_feature.dtype)
+            res, hops = self.main(node_feature, [hop_feature, hyper],
+                                  [nn_idx_f2v, torch.zeros(B, 96, 1, dtype=torch.int64, device=node_feature.device)],
+                                  [nn_idx_v2f, torch.arange(96, device=node_feature.device).reshape(1, 1, 96).repeat(B, 1, 1)],
+                                  [self.emodel_f2v(ef_f2v), ones(B, 1, 96, 1)], [self.emodel_v2f(ef_v2f), ones(B, 1, 1, 96)])
+            return res.reshape(B, 96)[:, :48]
+
+    torch.manual_seed(3)
+    m = ScriptModel().to(dev).train()          # batch statistics, as the script trains (a random-init net in eval mode is unnormalised)
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.modules.batchnorm._BatchNorm):
+            mod.momentum = 0.0                 # the comparison calls below leave the running statistics alone
+    data = synthetic_batch(64, dev, seed=5, dtype=torch.float32)
+    with torch.no_grad():
+        ref = m(*data[:6]).float()
+        with torch.autocast('cuda', dtype=torch.bfloat16):                         # the same regime written by hand in the script
+            ref_bf = m(*[t.to(torch.bfloat16) if t.is_floating_point() else t for t in data[:6]]).float()
+    fgnn_amd.enable_fast_path()
+    try:
+        with torch.no_grad():
+            m(*data[:6])                                                           # the hook optimises the module at this call
+            out = m(*data[:6])
+        assert isinstance(m.emodel_f2v, EdgeMLP) and isinstance(m.emodel_v2f, EdgeMLP)
+        assert out.dtype == torch.float32
+        e_bf = float((out - ref_bf).abs().max() / ref.abs().max())                 # fused EdgeMLP vs torch's two convolutions, both bf16
+        e_32 = float((out - ref).abs().max() / ref.abs().max())
+        print('fast path vs hand-written autocast %.3e, vs f32 %.3e (hand-written autocast vs f32 %.3e)'
+              % (e_bf, e_32, float((ref_bf - ref).abs().max() / ref.abs().max())))
+        assert e_bf <= 3e-2 and e_32 <= 6e-2
+        opt = torch.optim.Adam(m.parameters(), lr=1e-3, weight_decay=1e-8)         # as train_ldpc.py:160-169 writes it
+        sched = torch.optim.lr_scheduler.LambdaLR(opt, lr_lambda=lambda e: 0.5 ** e)
+        assert isinstance(opt, FastAdam)
+        assert any(p is m.emodel_f2v[0].weight for p in opt.param_groups[0]['params'])
+        before = m.emodel_f2v[0].weight.detach().clone()
+        label = (torch.rand(64, 48, device=dev) > 0.5).float()
+        for _ in range(2):
+            opt.zero_grad()
+            loss = torch.nn.functional.binary_cross_entropy_with_logits(m(*data[:6]), label)
+            loss.backward()
+            opt.step()
+        sched.step()
+        assert torch.isfinite(loss) and abs(opt.flat.lr - 1e-3) < 1e-12 and abs(opt.param_groups[0]['lr'] - 5e-4) < 1e-12
+        assert float((m.emodel_f2v[0].weight - before).abs().max()) > 0
+        assert isinstance(torch.optim.Adam([torch.nn.Parameter(torch.zeros(3))], lr=1e-3), torch.optim.Adam.stock)   # CPU parameters: stock
+    finally:
+        fgnn_amd.disable_fast_path()
+    assert not hasattr(torch.optim.Adam, 'stock')
