@@ -51,6 +51,9 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--miopen-bn', action='store_true', help='let torch route BatchNorm to MIOpen')
     ap.add_argument('--no-graph', action='store_true', help='launch every kernel from Python instead of replaying a hipGraph')
+    ap.add_argument('--graph-collective', action='store_true',
+                    help='N > 1: record the RCCL all-reduce and Adam into the step graph as well (default: outside it; at N = 1 '
+                         'Adam is always inside)')
     ap.add_argument('--inputs', choices=['channel', 'features'], default='channel',
                     help='channel: encoded codewords through the reference channel (fgnn_amd/datapath.py); '
                          'features: random bits + unit-gain AWGN built with torch ops (ldpc.synthetic_batch)')
@@ -175,6 +178,9 @@ def self_launch(args):
     return rc
 
 
+AFFINITY = None
+
+
 def dist_setup(args):
     """(rank, world, device) of this process.  world comes from WORLD_SIZE (a launcher's, or self_launch's) and must equal
     --gpus; with N > 1 the process group is RCCL on this rank's own device.  FGNN_BENCH_DEVICE / FGNN_DIST_BACKEND are the
@@ -192,6 +198,17 @@ def dist_setup(args):
         raise SystemExit('rank %d wants device %d but only %d are visible' % (rank, dev_index, torch.cuda.device_count()))
     torch.cuda.set_device(dev_index)
     dev = torch.device('cuda', dev_index)
+    # one rank = one GPU = its share of the cores NUMA-local to that GPU (the launcher, torch.distributed.run or self_launch,
+    # leaves every rank floating over all cores); FGNN_BIND_CPUS=0 keeps the launcher's placement, =1 binds at N = 1 too
+    bind = os.environ.get('FGNN_BIND_CPUS', '')
+    global AFFINITY
+    AFFINITY = None
+    if (world > 1 and bind != '0') or bind == '1':
+        from fgnn_amd.dp import bind_rank_to_local_cores
+        try:
+            AFFINITY = bind_rank_to_local_cores(dev_index, local_rank, int(os.environ.get('LOCAL_WORLD_SIZE', world)))
+        except Exception as e:        # noqa: BLE001 — placement is an optimisation, never a reason to fail the run
+            AFFINITY = {'note': 'binding failed: %s: %s' % (type(e).__name__, e)}
     if world > 1:
         backend = os.environ.get('FGNN_DIST_BACKEND', 'nccl')
         if backend == 'nccl':
@@ -218,8 +235,19 @@ def dist_report(world, dev, elapsed_local, steps):
             ver = '.'.join(str(v) for v in torch.cuda.nccl.version())
         except Exception:       # noqa: BLE001
             ver = None
+    placement = [None] * world
+    dist.all_gather_object(placement, AFFINITY)
+    from fgnn_amd.dp import xgmi_topology
+    peers = None
+    try:
+        n = torch.cuda.device_count()
+        peers = all(torch.cuda.can_device_access_peer(i, j) for i in range(n) for j in range(n) if i != j) if n > 1 else None
+    except Exception:           # noqa: BLE001
+        peers = None
     return {'backend': backend + (' (RCCL)' if backend == 'nccl' else ''), 'rccl_version': ver,
             'devices_visible': torch.cuda.device_count(),
+            'rank_placement': placement, 'kfd_links': xgmi_topology() or None, 'all_peers_accessible': peers,
+            'rccl_env': {k: v for k, v in os.environ.items() if k.startswith(('NCCL_', 'RCCL_', 'HSA_ENABLE_IPC'))},
             'per_rank_ms_per_step': [round(float(e[0]), 4) for e in every],
             'per_rank_device': [int(e[1]) for e in every],
             'launched_by': 'bench.py self_launch' if os.environ.get('FGNN_BENCH_SELF_LAUNCHED') else 'external launcher'}
@@ -560,11 +588,15 @@ def main():
     inputs, label, sigma_b = data[:6], data[6], data[7]
     train = args.mode == 'train'
     model.train(train)
+    # N = 1: the optimizer is recorded into the step graph too (FlatAdam(capturable=True): step count and learning rate in device
+    # memory).  N > 1: the RCCL all-reduce would have to be recorded with it — proven on a one-rank group
+    # (tests/test_dp_two_ranks_gpu.py), never run on N > 1 ranks, hence opt-in (--graph-collective) until it has been.
+    whole_in_graph = train and not args.no_graph and (world == 1 or args.graph_collective)
     if train:
         # parameters and gradients live in two flat f32 buffers: one all-reduce, and Adam (the reference's
         # lr / weight_decay, train_ldpc.py) is eight elementwise kernels instead of a 330-tensor sweep
         bucket = FlatGradBucket(model.parameters(), flatten_params=True)
-        opt = FlatAdam(bucket, lr=1e-4, weight_decay=1e-8)
+        opt = FlatAdam(bucket, lr=1e-4, weight_decay=1e-8, capturable=whole_in_graph)
 
     if not train:
         from fgnn_amd.dp import flatten_parameters
@@ -584,13 +616,20 @@ def main():
             with torch.no_grad(), amp:
                 model(*inputs)
 
+    def update():
+        bucket.all_reduce_sum()                     # one RCCL all-reduce of the flat gradient; the mean is folded into Adam
+        opt.step(grad_scale=1.0 / world)
+
+    def whole():
+        compute()
+        update()
+
     # The step is launch-bound at this batch (~1500 launches): record it once into a hipGraph and replay it.
-    # The gradient all-reduce and Adam stay outside the graph (one collective + a few foreach kernels).
     graphed = None
     if not args.no_graph:
         try:
             from fgnn_amd.graph import StepGraph
-            graphed = StepGraph(compute)
+            graphed = StepGraph(whole if whole_in_graph else compute)
         except Exception as e:           # noqa: BLE001 — report and fall back to eager launches
             print('bench.py: hipGraph capture failed (%s: %s); running eagerly' % (type(e).__name__, e),
                   file=sys.stderr)
@@ -601,11 +640,12 @@ def main():
     def step(eager=False):
         if graphed is not None and not eager:
             graphed.replay()
+            if train and not whole_in_graph:
+                update()
         else:
             compute()
-        if train:
-            bucket.all_reduce_sum()                 # one RCCL all-reduce of the flat gradient; the mean is folded into Adam
-            opt.step(grad_scale=1.0 / world)
+            if train:
+                update()
 
     def fence():
         torch.cuda.synchronize()
@@ -748,7 +788,11 @@ def main():
                        'inputs': ('random messages -> reference G encode -> AWGN+burst channel, on the GPU'
                                   if args.inputs == 'channel' else 'random bits + AWGN (torch ops)'),
                        'peak_hbm_GB': round(torch.cuda.max_memory_allocated(dev) / 1e9, 2),
-                       'mode': args.mode, 'hip_graph': graphed is not None, 'distributed': dist_info},
+                       'mode': args.mode, 'hip_graph': graphed is not None,
+                       'graph_scope': (None if graphed is None else 'forward + backward + all-reduce + Adam' if whole_in_graph and world > 1
+                                       else 'forward + backward + Adam' if whole_in_graph else 'forward + backward'
+                                       if train else 'forward'),
+                       'distributed': dist_info},
             'roofline': roofline,
             'kernels': {k: {'launches': v['launches'], 'avg_us': round(v['ms'] / v['launches'] * 1e3, 2),
                             'avg_us_in_step': round(v.get('ms2', v['ms']) / v['launches'] * 1e3, 2),

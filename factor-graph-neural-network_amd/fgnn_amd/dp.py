@@ -67,6 +67,11 @@ class FlatGradBucket:
         ops.enable_grad_sink(self.params)
 
     def zero(self):
+        # weight-gradient launches a backward pass parked and never issued (it raised half-way, ops.defer_wgrad) add into this
+        # buffer: issue them BEFORE the zeroing, so that they cannot land in the next step's sums
+        from . import ops
+        if any(ops._DEFERRED.values()):
+            ops.flush_deferred()
         self.flat.zero_()
 
     @property
@@ -101,14 +106,48 @@ class FlatAdam:
     parameter tensors.  In-place updates of the flat buffer do not bump the per-parameter version counters,
     so the step also invalidates this package's cached low-precision weight copies."""
 
-    def __init__(self, bucket, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+    def __init__(self, bucket, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, capturable=False):
+        """``capturable=True`` (ROCm device only): the step count and the learning rate live in device memory
+        (``fgnn_flat_adam_dev``), so ``step`` has no step-dependent launch argument and can be recorded into a hipGraph —
+        with the gradient all-reduce in front of it — and replayed.  Assigning ``opt.lr`` between replays still works (it
+        writes the device scalar); ``opt.t`` reads the device counter back (a synchronisation)."""
         if bucket.flat_param is None:
             raise ValueError('FlatAdam needs FlatGradBucket(..., flatten_params=True)')
         self.bucket = bucket
-        self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
+        self.capturable = bool(capturable)
+        if self.capturable:
+            if not bucket.flat_param.is_cuda:
+                raise ValueError('FlatAdam(capturable=True) needs parameters on a ROCm device')
+            dev = bucket.flat_param.device
+            self._lr_dev = torch.full((1,), float(lr), device=dev, dtype=torch.float32)
+            self._step_dev = torch.zeros(1, device=dev, dtype=torch.int64)
+            self._coef_dev = torch.zeros(2, device=dev, dtype=torch.float32)
+        self._lr = float(lr)
+        self.betas, self.eps, self.weight_decay = betas, eps, weight_decay
         self.exp_avg = torch.zeros_like(bucket.flat_param)
         self.exp_avg_sq = torch.zeros_like(bucket.flat_param)
-        self.t = 0
+        self._t = 0
+
+    @property
+    def lr(self):
+        return self._lr
+
+    @lr.setter
+    def lr(self, value):
+        value = float(value)
+        if self.capturable and value != self._lr:
+            self._lr_dev.fill_(value)            # a device write on the current stream: ordered before the next replay
+        self._lr = value
+
+    @property
+    def t(self):
+        return int(self._step_dev.item()) if self.capturable else self._t
+
+    @t.setter
+    def t(self, value):
+        if self.capturable:
+            self._step_dev.fill_(int(value))
+        self._t = int(value)
 
     @torch.no_grad()
     def step(self, grad_scale=1.0):
@@ -117,13 +156,24 @@ class FlatAdam:
         rule as elementwise torch ops."""
         p, g = self.bucket.flat_param, self.bucket.flat
         b1, b2 = self.betas
-        self.t += 1
+        if self.capturable:
+            from . import _hip
+            P = _hip._ptr
+            _hip.check(_hip.lib().fgnn_flat_adam_dev(P(p), P(g), P(self.exp_avg), P(self.exp_avg_sq), None, p.numel(),
+                                                     P(self._lr_dev), float(b1), float(b2), float(self.eps),
+                                                     float(self.weight_decay), float(grad_scale), P(self._step_dev),
+                                                     P(self._coef_dev), _hip.stream_ptr()))
+            from .mpnn import pointwise
+            pointwise.invalidate_casts()
+            pointwise.note_state_change()
+            return
+        self._t += 1
         if p.is_cuda:
             from . import _hip
             P = _hip._ptr
             _hip.check(_hip.lib().fgnn_flat_adam(P(p), P(g), P(self.exp_avg), P(self.exp_avg_sq), None, p.numel(),
                                                  float(self.lr), float(b1), float(b2), float(self.eps),
-                                                 float(self.weight_decay), float(grad_scale), int(self.t),
+                                                 float(self.weight_decay), float(grad_scale), int(self._t),
                                                  _hip.stream_ptr()))
         else:
             if grad_scale != 1.0:
@@ -132,7 +182,7 @@ class FlatAdam:
                 g = g.add(p, alpha=self.weight_decay)
             self.exp_avg.lerp_(g, 1.0 - b1)
             self.exp_avg_sq.mul_(b2).addcmul_(g, g, value=1.0 - b2)
-            bc1, bc2 = 1.0 - b1 ** self.t, 1.0 - b2 ** self.t
+            bc1, bc2 = 1.0 - b1 ** self._t, 1.0 - b2 ** self._t
             denom = (self.exp_avg_sq.sqrt() / (bc2 ** 0.5)).add_(self.eps)
             p.addcdiv_(self.exp_avg, denom, value=-self.lr / bc1)
         from .mpnn import pointwise
@@ -156,6 +206,122 @@ def broadcast_parameters(module, src=0, group=None):
             n = t.numel()
             t.copy_(flat[off:off + n].view_as(t))
             off += n
+
+
+def _cpulist(text):
+    """'0-3,8,10-11' -> [0, 1, 2, 3, 8, 10, 11] (the kernel's cpulist format)."""
+    out = []
+    for part in text.strip().split(','):
+        if not part:
+            continue
+        lo, _, hi = part.partition('-')
+        out.extend(range(int(lo), int(hi or lo) + 1))
+    return out
+
+
+def device_locality(index):
+    """Where device ``index`` sits: PCI address, NUMA node and that node's CPUs, read from sysfs (-1 / [] when the platform
+    does not say — a VM without NUMA information)."""
+    import os
+    pr = torch.cuda.get_device_properties(index)
+    bdf = '%04x:%02x:%02x.0' % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+    node, cpus = -1, []
+    base = '/sys/bus/pci/devices/' + bdf
+    try:
+        node = int(open(base + '/numa_node').read())
+        cpus = _cpulist(open(base + '/local_cpulist').read())
+    except (OSError, ValueError):
+        pass
+    if node >= 0 and not cpus:
+        try:
+            cpus = _cpulist(open('/sys/devices/system/node/node%d/cpulist' % node).read())
+        except OSError:
+            cpus = []
+    return {'pci': bdf, 'numa_node': node, 'local_cpus': cpus}
+
+
+def plan_rank_cpus(allowed, local_cpus, slot, slots):
+    """The cores rank number ``slot`` of the ``slots`` ranks SHARING one locality domain should run on: an equal contiguous
+    share of the domain's allowed cores (``local_cpus`` ∩ ``allowed``; all of ``allowed`` when the platform names no domain).
+    Never empty while ``allowed`` is not: with fewer cores than ranks the ranks share them round-robin."""
+    allowed = sorted(allowed)
+    pool = [c for c in allowed if c in set(local_cpus)] or allowed
+    if not pool:
+        return []
+    if len(pool) < slots:
+        return [pool[slot % len(pool)]]
+    b, e = shard_range(len(pool), slot, slots)
+    return pool[b:e]
+
+
+def bind_rank_to_local_cores(device_index, local_rank, local_world, set_threads=True):
+    """Pin this process (one rank = one GPU) to its share of the cores NUMA-local to its device, and size torch's intra-op
+    pool to that share: eight ranks launched by ``torch.distributed.run`` otherwise all float over every core with
+    ``OMP_NUM_THREADS`` unset or 1 and the host side of a replayed step (graph launch, all-reduce enqueue) migrates between
+    sockets.  The ranks that share a NUMA domain are taken to be the ones whose devices report the same node; without NUMA
+    information the allowed cores are split evenly by local rank.  Returns what was done (for the bench line)."""
+    import os
+    loc = device_locality(device_index)
+    if not hasattr(os, 'sched_setaffinity'):
+        return dict(loc, bound_cpus=None, note='no sched_setaffinity on this platform')
+    allowed = sorted(os.sched_getaffinity(0))
+    slot, slots = local_rank, max(1, local_world)
+    if loc['numa_node'] >= 0 and loc['local_cpus']:
+        # ranks on the same node: those local ranks whose device reports this node (device i <-> local rank i)
+        same = []
+        for r in range(min(local_world, torch.cuda.device_count())):
+            try:
+                if device_locality(r)['numa_node'] == loc['numa_node']:
+                    same.append(r)
+            except Exception:       # noqa: BLE001
+                pass
+        if local_rank in same:
+            slot, slots = same.index(local_rank), len(same)
+    cpus = plan_rank_cpus(allowed, loc['local_cpus'], slot, slots)
+    note = None
+    try:
+        if cpus:
+            os.sched_setaffinity(0, cpus)
+            if set_threads and 'OMP_NUM_THREADS' not in os.environ:
+                torch.set_num_threads(max(1, len(cpus)))
+    except OSError as e:
+        note = 'sched_setaffinity failed: %s' % e
+        cpus = None
+    return dict(loc, local_cpus='%d cores' % len(loc['local_cpus']), bound_cpus=_ranges(cpus) if cpus else None,
+                threads=torch.get_num_threads(), note=note)
+
+
+def _ranges(cpus):
+    """[0, 1, 2, 3, 8] -> '0-3,8'."""
+    out, run = [], []
+    for c in sorted(cpus) + [None]:
+        if run and (c is None or c != run[-1] + 1):
+            out.append('%d-%d' % (run[0], run[-1]) if len(run) > 1 else '%d' % run[0])
+            run = []
+        if c is not None:
+            run.append(c)
+    return ','.join(out)
+
+
+def xgmi_topology():
+    """What the KFD topology says about this node's GPU links (sysfs, no tool needed): per GPU node the number of xGMI
+    (io_link type 11) and PCIe (type 2) links.  {} when the files are absent (container without /sys/class/kfd)."""
+    import glob
+    import os
+    out = {}
+    for nd in sorted(glob.glob('/sys/class/kfd/kfd/topology/nodes/*'), key=lambda p: int(os.path.basename(p))):
+        try:
+            props = dict(l.split()[:2] for l in open(nd + '/properties').read().splitlines() if len(l.split()) >= 2)
+            if int(props.get('simd_count', '0')) == 0:
+                continue                                   # a CPU node
+            kinds = {}
+            for lk in glob.glob(nd + '/io_links/*/properties'):
+                lp = dict(l.split()[:2] for l in open(lk).read().splitlines() if len(l.split()) >= 2)
+                kinds[lp.get('type', '?')] = kinds.get(lp.get('type', '?'), 0) + 1
+            out[os.path.basename(nd)] = {'xgmi_links': kinds.get('11', 0), 'pcie_links': kinds.get('2', 0)}
+        except (OSError, ValueError):
+            continue
+    return out
 
 
 def shard_range(total, rank, world):

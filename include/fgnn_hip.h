@@ -311,6 +311,16 @@ int fgnn_flat_adam(float* param, const float* grad, float* exp_avg, float* exp_a
                    fgnn_stream_t stream);
 
 /*
+ * The same Adam step with nothing step-dependent among the launch arguments, so that it can be recorded into a hipGraph
+ * (together with the gradient all-reduce in front of it) and replayed: *step_dev (int64 in device memory, starts at 0, advanced
+ * by one per call) replaces `step`, *lr_dev (f32 in device memory; a scheduler overwrites it between replays) replaces `lr`,
+ * coef_dev is two floats of device scratch.  Two launches (a one-thread kernel forms the bias-corrected coefficients).
+ */
+int fgnn_flat_adam_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, void* bf16_mirror, int64_t n,
+                       const float* lr_dev, float beta1, float beta2, float eps, float weight_decay, float grad_scale,
+                       int64_t* step_dev, float* coef_dev, fgnn_stream_t stream);
+
+/*
  * The edge-type MLP in front of the operator, etype = W2 ReLU(W1 efeature + b1) + b2 with Cin <= 8 -> 64 -> net <= 4
  * (`emodel_f2v / emodel_v2f`, /root/reference/train_ldpc.py:32-38,68-69), without the 64-channel hidden tensor ever
  * reaching memory.  x is bf16 with element (b, c, r) at b*x_sb + c*x_sc + r*x_sr (r one of the E = M*k edge rows of

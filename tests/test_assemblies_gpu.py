@@ -919,9 +919,10 @@ def test_parked_weight_gradients_equal_inline_ones_bitwise(dev, monkeypatch):
     assert torch.equal(grads(), inline)
 
 
-def test_parked_launches_of_a_failed_backward_pass_are_dropped(dev):
-    """A backward pass that raises half-way never reaches the end-of-pass callback: what it parked must neither be issued by the
-    next pass nor keep that pass from queueing its own callback."""
+def test_parked_launches_of_a_failed_backward_pass_are_dropped(dev, monkeypatch):
+    """A backward pass that raises half-way never reaches the end-of-pass callback: what it parked must not land in the next
+    pass's sums (FlatGradBucket.zero issues it ahead of the zeroing; a pass of another id arriving first would issue it too —
+    parked launches are never silently dropped, a nested pass relies on that) nor keep that pass from queueing its own callback."""
     import fgnn_amd
     from fgnn_amd import ops
     from fgnn_amd.dp import FlatGradBucket
@@ -937,6 +938,7 @@ def test_parked_launches_of_a_failed_backward_pass_are_dropped(dev):
             raise RuntimeError('boom')
 
     torch.manual_seed(3)
+    monkeypatch.setattr(ops, 'SIDE_ACTIVE', True)       # parking is only on while an assembly runs its side stream
     a, b = PointwiseConv2d(64, 64).to(dev), PointwiseConv2d(64, 64).to(dev)
     bucket = FlatGradBucket(list(a.parameters()) + list(b.parameters()))
     x = torch.randn(8, 64, 96, 1, device=dev).bfloat16().contiguous(memory_format=torch.channels_last)
@@ -959,6 +961,45 @@ def test_parked_launches_of_a_failed_backward_pass_are_dropped(dev):
     again = run(False)
     assert torch.equal(again, good)                     # not doubled by the stale launch, and a's / b's own gradients are there
     assert not any(lst for lst in ops._DEFERRED.values())
+
+
+def test_a_nested_backward_pass_does_not_lose_parked_launches(dev, monkeypatch):
+    """a re-entrant backward (checkpointing, a Function that calls backward()) has another graph-task id than the pass
+    that parked weight-gradient launches; those must be ISSUED, not cleared.  Gradients with parking on == with parking off."""
+    from fgnn_amd import ops
+    from fgnn_amd.dp import FlatGradBucket
+    from fgnn_amd.mpnn.pointwise import PointwiseConv2d
+    torch.manual_seed(4)
+    a, b, c = (PointwiseConv2d(64, 64).to(dev) for _ in range(3))
+    bucket = FlatGradBucket(list(a.parameters()) + list(b.parameters()) + list(c.parameters()))
+    x = torch.randn(8, 64, 96, 1, device=dev).bfloat16().contiguous(memory_format=torch.channels_last)
+
+    class Nested(torch.autograd.Function):              # its backward runs a whole inner pass through c
+        @staticmethod
+        def forward(ctx, h):
+            ctx.save_for_backward(h)
+            return h.view_as(h)
+
+        @staticmethod
+        def backward(ctx, g):
+            (h,) = ctx.saved_tensors
+            with torch.enable_grad(), torch.autocast('cuda', dtype=torch.bfloat16):
+                c(h.detach()).float().sum().backward()
+            return g
+
+    def run():
+        bucket.zero()
+        with torch.autocast('cuda', dtype=torch.bfloat16):
+            y = b(Nested.apply(a(x)))
+        y.float().sum().backward()
+        torch.cuda.synchronize()
+        return bucket.flat.clone()
+
+    plain = run()
+    monkeypatch.setattr(ops, 'SIDE_ACTIVE', True)
+    parked = run()
+    assert not any(lst for lst in ops._DEFERRED.values())
+    assert float(plain.abs().max()) > 0 and torch.equal(parked, plain)
 
 
 def test_fast_path_switch_for_an_unchanged_script(dev):

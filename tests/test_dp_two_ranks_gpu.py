@@ -61,7 +61,8 @@ def _train(rank, world, graph, reduce_single_rank=False):
     inputs = tuple(t[lo:hi] for t in data[:6])
     label = data[6][lo:hi, :48].float().contiguous()
     bucket = FlatGradBucket(model.parameters(), flatten_params=True, reduce_single_rank=reduce_single_rank)
-    opt = FlatAdam(bucket, lr=1e-3)
+    full = graph == 'full'                          # the collective and the optimizer recorded into the graph as well
+    opt = FlatAdam(bucket, lr=1e-3, capturable=full)
     amp = torch.autocast('cuda', dtype=torch.bfloat16)
 
     def compute():
@@ -70,17 +71,43 @@ def _train(rank, world, graph, reduce_single_rank=False):
             logits, _ = model(*inputs)
         torch.nn.functional.binary_cross_entropy_with_logits(logits.float().reshape(-1), label.reshape(-1)).backward()
 
-    step = StepGraph(compute) if graph else compute
+    def whole():
+        compute()
+        bucket.all_reduce_sum()
+        opt.step(grad_scale=1.0 / world)
+
     first_grad = first_param = None
+    if full:
+        snap = (bucket.flat_param.clone(), model.state_dict())
+        snap = (snap[0], {k: v.clone() for k, v in snap[1].items()})
+        step = StepGraph(whole, warmup=1)           # the warm-up call and the capture are optimizer steps too: undo them
+        with torch.no_grad():
+            model.load_state_dict(snap[1])
+            bucket.flat_param.copy_(snap[0])
+        opt.exp_avg.zero_(); opt.exp_avg_sq.zero_(); opt.t = 0
+        assert opt.t == 0
+    else:
+        step = StepGraph(compute) if graph is True else compute
     for it in range(STEPS):
         step()
+        if full:
+            if it == 0:
+                first_grad = (bucket.flat / world).detach().cpu().clone()
+                first_param = bucket.flat_param.detach().cpu().clone()
+            if it == 1:
+                opt.lr = 5e-4                       # a scheduler between replays: the device scalar is what the graph reads
+            continue
         bucket.all_reduce_mean()
         if it == 0:
             first_grad = bucket.flat.detach().cpu().clone()
+        if it == 2 and graph == 'sched':
+            opt.lr = 5e-4
         opt.step()
         if it == 0:
             first_param = bucket.flat_param.detach().cpu().clone()
     torch.cuda.synchronize()
+    if full:
+        assert opt.t == STEPS
     return bucket.flat_param.detach().cpu().clone(), first_grad, first_param
 
 
@@ -160,3 +187,15 @@ def test_rccl_backend_runs_the_flat_bucket_all_reduce(graph, tmp_path, dev):
     assert len(a['rccl']) >= 2
     ref_param, ref_grad, ref_p1 = _train(0, 1, graph)       # no process group at all
     assert torch.equal(a['grad'], ref_grad) and torch.equal(a['param1'], ref_p1) and torch.equal(a['param'], ref_param)
+
+
+def test_rccl_all_reduce_and_adam_inside_the_step_graph(tmp_path, dev):
+    """The WHOLE data-parallel step as one hipGraph: forward, backward, the RCCL all-reduce of the flat gradient and the
+    capturable FlatAdam (step count and learning rate in device memory, csrc/flat_adam.hip fgnn_flat_adam_dev) — no host work
+    between replay and update.  One-rank RCCL group (what a one-GPU box can form).  Three replays, the learning rate halved
+    before the third, must end exactly where the eager host-argument form ends."""
+    mp.spawn(_worker_rccl, args=(1, _free_port(), str(tmp_path), 'full'), nprocs=1, join=True)
+    a = torch.load(os.path.join(str(tmp_path), 'rccl_rank0.pt'))
+    ref_param, ref_grad, ref_p1 = _train(0, 1, 'sched')     # eager, host-side Adam, same schedule
+    assert torch.equal(a['grad'], ref_grad) and torch.equal(a['param1'], ref_p1)
+    assert torch.equal(a['param'], ref_param)
