@@ -151,7 +151,7 @@ __device__ __forceinline__ void bn_fold(const float* ws, int nwg, int C, int c, 
     __shared__ double red0[256], red1[256];
     double a = 0.0, b = 0.0;
     if (ok) {
-#pragma unroll 4
+#pragma unroll 16
         for (int w = pg; w < nwg; w += 256 / BN_FC) { a += (double)ws[(int64_t)w * 2 * C + c]; b += (double)ws[(int64_t)w * 2 * C + C + c]; }
     }
     red0[threadIdx.x] = a;

@@ -153,15 +153,17 @@ __global__ __launch_bounds__(WB_THREADS) void linear_wgrad_b16_kernel(const WgbP
     }
 }
 
-// gW[o][c] += sum over slabs; gb[o] += sum over slabs.  One thread per
-// (slice, q, lane) element of a slab; 256 threads = 16 consecutive elements x 16 slab groups (fixed fold order).
-__global__ __launch_bounds__(256) void wgb_reduce_kernel(const float* __restrict__ ws, int nslab, int S, int nso,
-                                                         int Cin, int Cout, float* __restrict__ gW,
-                                                         float* __restrict__ gb) {
-    __shared__ float part[16][17];
-    const int e = threadIdx.x & 15, g = threadIdx.x >> 4;
+// gW[o][c] += sum over slabs;  gb[o] += sum over slabs.  One 1024-thread workgroup per 64 consecutive slab elements (one
+// accumulator register of one slice, lanes 0..63: a 256-byte line per slab): wave w folds slabs w, w+16, ... — at most 16
+// independent line loads, all in flight at once — and wave 0 folds the 16 partial sums in order.  Fixed order: deterministic.
+// (The first form gave each 256-thread block 16 elements: 64-byte pieces, 24 us per call for 4 MB of slabs.)
+__global__ __launch_bounds__(1024) void wgb_reduce_kernel(const float* __restrict__ ws, int nslab, int S, int nso,
+                                                          int Cin, int Cout, float* __restrict__ gW,
+                                                          float* __restrict__ gb) {
+    __shared__ float part[16][64];
+    const int l = threadIdx.x & 63, g = threadIdx.x >> 6;
     const int64_t slab_len = (int64_t)S * WB_NACC * 64;
-    const int64_t i = (int64_t)blockIdx.x * 16 + e;    // i < slab_len (slab_len % 16 == 0)
+    const int64_t i = (int64_t)blockIdx.x * 64 + l;    // i < slab_len (slab_len % 64 == 0)
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     {
         const float* base = ws + i;
@@ -174,13 +176,13 @@ __global__ __launch_bounds__(256) void wgb_reduce_kernel(const float* __restrict
         }
         for (; w < nslab; w += 16) s0 += base[(int64_t)w * slab_len];
     }
-    part[g][e] = (s0 + s1) + (s2 + s3);
+    part[g][l] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (g != 0) return;
     float s = 0.f;
 #pragma unroll
-    for (int q = 0; q < 16; ++q) s += part[q][e];
-    const int l = (int)(i & 63), q = (int)((i >> 6) % WB_NACC), slice = (int)(i / (WB_NACC * 64));
+    for (int q = 0; q < 16; ++q) s += part[q][l];
+    const int q = (int)((i >> 6) % WB_NACC), slice = (int)(i / (WB_NACC * 64));
     const int so = slice % nso, sc = slice / nso;
     const int li = l & 15, lk = l >> 4;
     if (q < 64) {
@@ -291,24 +293,31 @@ __global__ __launch_bounds__(WB_THREADS) void linear_wgrad_b16_narrow_kernel(con
 
 // woff: first channel of the wide operand's 64-channel group this launch covered
 template <bool NARROW_X>
-__global__ __launch_bounds__(256) void wgn_reduce_kernel(const float* __restrict__ ws, int nslab, int Cin, int Cout,
-                                                         int woff, float* __restrict__ gW, float* __restrict__ gb) {
-    __shared__ float part[16][17];
-    const int e = threadIdx.x & 15, g = threadIdx.x >> 4;
+__global__ __launch_bounds__(1024) void wgn_reduce_kernel(const float* __restrict__ ws, int nslab, int Cin, int Cout,
+                                                          int woff, float* __restrict__ gW, float* __restrict__ gb) {
+    __shared__ float part[16][64];
+    const int l = threadIdx.x & 63, g = threadIdx.x >> 6;
     const int slab_len = WN_NACC * 64;
-    const int i = blockIdx.x * 16 + e;
-    float s0 = 0.f, s1 = 0.f;
-    for (int w = g; w < nslab; w += 32) {
-        s0 += ws[(int64_t)w * slab_len + i];
-        if (w + 16 < nslab) s1 += ws[(int64_t)(w + 16) * slab_len + i];
+    const int i = blockIdx.x * 64 + l;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    {
+        const float* base = ws + i;
+        int w = g;
+        for (; w + 48 < nslab; w += 64) {
+            s0 += base[(int64_t)w * slab_len];
+            s1 += base[(int64_t)(w + 16) * slab_len];
+            s2 += base[(int64_t)(w + 32) * slab_len];
+            s3 += base[(int64_t)(w + 48) * slab_len];
+        }
+        for (; w < nslab; w += 16) s0 += base[(int64_t)w * slab_len];
     }
-    part[g][e] = s0 + s1;
+    part[g][l] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (g != 0) return;
     float s = 0.f;
 #pragma unroll
-    for (int q = 0; q < 16; ++q) s += part[q][e];
-    const int l = i & 63, q = i >> 6, li = l & 15, lk = l >> 4;
+    for (int q = 0; q < 16; ++q) s += part[q][l];
+    const int q = i >> 6, li = l & 15, lk = l >> 4;
     if (q < 16) {
         const int r = q & 3, t = q >> 2, row = 4 * lk + r;
         const int o = NARROW_X ? woff + 4 * row + t : row, c = NARROW_X ? li : woff + 4 * li + t;
@@ -374,11 +383,11 @@ int fgnn_linear_wgrad_b16(const void* x, const void* gy, int64_t R, int Cin, int
             if (nx) {
                 p.gy = (const uint16_t*)gy + woff;
                 hipLaunchKernelGGL(linear_wgrad_b16_narrow_kernel<true>, dim3(gx), dim3(WB_THREADS), lds, st, p);
-                hipLaunchKernelGGL(wgn_reduce_kernel<true>, dim3(WN_NACC * 4), dim3(256), 0, st, p.ws, gx, Cin, Cout, woff, gW, gb);
+                hipLaunchKernelGGL(wgn_reduce_kernel<true>, dim3(WN_NACC), dim3(1024), 0, st, p.ws, gx, Cin, Cout, woff, gW, gb);
             } else {
                 p.x = (const uint16_t*)x + woff;
                 hipLaunchKernelGGL(linear_wgrad_b16_narrow_kernel<false>, dim3(gx), dim3(WB_THREADS), lds, st, p);
-                hipLaunchKernelGGL(wgn_reduce_kernel<false>, dim3(WN_NACC * 4), dim3(256), 0, st, p.ws, gx, Cin, Cout, woff, gW, gb);
+                hipLaunchKernelGGL(wgn_reduce_kernel<false>, dim3(WN_NACC), dim3(1024), 0, st, p.ws, gx, Cin, Cout, woff, gW, gb);
             }
         }
         hipError_t e = hipGetLastError();
@@ -402,7 +411,7 @@ int fgnn_linear_wgrad_b16(const void* x, const void* gy, int64_t R, int Cin, int
     hipError_t e = hipLaunchKernel(fn, dim3(gx), dim3(WB_THREADS), args, lds, st);
     if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "linear_wgrad_b16 launch: %s", hipGetErrorString(e));
     const int64_t slab_len = (int64_t)S * WB_NACC * 64;
-    hipLaunchKernelGGL(wgb_reduce_kernel, dim3((unsigned)(slab_len / 16)), dim3(256), 0, st, p.ws, gx, S, nso, Cin,
+    hipLaunchKernelGGL(wgb_reduce_kernel, dim3((unsigned)(slab_len / 64)), dim3(1024), 0, st, p.ws, gx, S, nso, Cin,
                        Cout, gW, gb);
     e = hipGetLastError();
     if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "linear_wgrad_b16 reduce launch: %s", hipGetErrorString(e));

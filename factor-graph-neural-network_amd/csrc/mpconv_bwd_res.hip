@@ -567,14 +567,14 @@ __global__ __launch_bounds__(BR_THREADS) void mpconv_bwd_res_kernel(const BresPa
 }
 
 // Sums the per-workgroup slabs into gW / gbias (accumulating): out[i] += sum_w ws[w][i].
-// 256 threads = 16 consecutive elements x 16 slab groups: group g walks slabs g, g+16, ... (4 loads in flight),
-// the 16 partials of an element are folded in a fixed order through LDS (bit-reproducible).
-__global__ __launch_bounds__(256) void bres_reduce_kernel(const float* __restrict__ ws, int nslab, int64_t slab_len,
-                                                          int64_t nw, float* __restrict__ gW,
-                                                          float* __restrict__ gbias, int overwrite, int ncols, int ld) {
-    __shared__ float part[16][17];
-    const int e = threadIdx.x & 15, g = threadIdx.x >> 4;
-    const int64_t i = (int64_t)blockIdx.x * 16 + e;
+// 1024 threads = 64 consecutive elements (a 256-byte line per slab) x 16 slab groups: wave g walks slabs g, g+16, ... (up to 16
+// independent line loads in flight), the 16 partials of an element are folded in a fixed order through LDS (bit-reproducible).
+__global__ __launch_bounds__(1024) void bres_reduce_kernel(const float* __restrict__ ws, int nslab, int64_t slab_len,
+                                                           int64_t nw, float* __restrict__ gW,
+                                                           float* __restrict__ gbias, int overwrite, int ncols, int ld) {
+    __shared__ float part[16][64];
+    const int e = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int64_t i = (int64_t)blockIdx.x * 64 + e;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     if (i < slab_len) {
         const float* base = ws + i;
@@ -603,20 +603,20 @@ __global__ __launch_bounds__(256) void bres_reduce_kernel(const float* __restric
 // Shared with mpconv_bwd_hyper.hip: fold `nslab` slabs of [nw + nou] floats into gW / gbias.
 void fgnn_launch_slab_reduce(const float* ws, int nslab, int64_t slab_len, int64_t nw, float* gW, float* gbias,
                              hipStream_t st) {
-    hipLaunchKernelGGL(bres_reduce_kernel, dim3((unsigned)((slab_len + 15) / 16)), dim3(256), 0, st, ws, nslab,
+    hipLaunchKernelGGL(bres_reduce_kernel, dim3((unsigned)((slab_len + 63) / 64)), dim3(1024), 0, st, ws, nslab,
                        slab_len, nw, gW, gbias, 0, 1, 1);
 }
 
 // The same with the slab's [nw / ncols][ncols] weight block landing in rows `ld` apart (a column block of a wider gfilters).
 void fgnn_launch_slab_reduce_ld(const float* ws, int nslab, int64_t slab_len, int64_t nw, int ncols, int ld, float* gW,
                                 float* gbias, hipStream_t st) {
-    hipLaunchKernelGGL(bres_reduce_kernel, dim3((unsigned)((slab_len + 15) / 16)), dim3(256), 0, st, ws, nslab,
+    hipLaunchKernelGGL(bres_reduce_kernel, dim3((unsigned)((slab_len + 63) / 64)), dim3(1024), 0, st, ws, nslab,
                        slab_len, nw, gW, gbias, 0, ncols, ld);
 }
 
 // The same fold, STORED (out[i] = sum_w ws[w][i]): for outputs that are not accumulators (the batch-summed edge-type gradient).
 void fgnn_launch_slab_store(const float* ws, int nslab, int64_t slab_len, float* out, hipStream_t st) {
-    hipLaunchKernelGGL(bres_reduce_kernel, dim3((unsigned)((slab_len + 15) / 16)), dim3(256), 0, st, ws, nslab,
+    hipLaunchKernelGGL(bres_reduce_kernel, dim3((unsigned)((slab_len + 63) / 64)), dim3(1024), 0, st, ws, nslab,
                        slab_len, slab_len, out, (float*)nullptr, 1, 1, 1);
 }
 

@@ -164,7 +164,13 @@ __global__ __launch_bounds__(WS_THREADS) void mpconv_fwd_ws_kernel(const WsParam
     const int N = p.N, M = p.M, Npad = p.Npad;
     const int PBYTES = Npad * WS_PROW;
     const int OFF_E = XBUF * XBYTES, OFF_P = OFF_E + EBUF * WS_ESZ;      // DMA targets first: all below 64 KB
-    // flags: [0] x / edge types of a sample landed (4 per sample), [1] P image written (4 per sample), [2] P image consumed (12 per sample)
+    // flags: [0] x / edge types of a sample landed (4 per sample), [1] P image written (4 per sample), [2] / [3] P image 0 / 1
+    // consumed (12 per sample of that parity).  A cumulative count is exact only while no wave can run more than ONE signal ahead
+    // of the slowest: true for the producers (flag 0 gates them together every sample), not for the consumers, which may be a
+    // whole sample ahead of a slow wave — one "consumed" counter over all samples let eleven fast waves' signals for sample t + 1
+    // stand in for the twelfth wave's for sample t, and the producers overwrote the image (and edge-type buffer) it was still
+    // reading (seen as run-to-run differences in the last destinations of a sample, tools/diag_epilogue.py).  Per image parity
+    // the count is exact: nobody can start the next sample of a parity before the producers have rewritten that image.
     const unsigned lds0 = (unsigned)(uintptr_t)ws_lds;
     int* flags_p = reinterpret_cast<int*>(ws_lds + OFF_P + 2 * PBYTES);
     const unsigned flags = lds0 + (unsigned)(OFF_P + 2 * PBYTES);        // LDS byte address: + 0 / 4 / 8
@@ -305,7 +311,7 @@ __global__ __launch_bounds__(WS_THREADS) void mpconv_fwd_ws_kernel(const WsParam
             ws_signal(flags + 0, lane);
             if (t >= 1) {
                 // P image t & 1 held sample t - 2, edge-type buffer (t - 1 + XBUF) % EBUF sample t - 2: consumers done with it
-                ws_wait_ge(flags + 8, WS_NCONS * (t - 1));
+                ws_wait_ge(flags + 8 + 4 * (t & 1), WS_NCONS * (t >> 1));
                 if (t - 1 + XBUF < cnt) {
                     ws_wait_ge(flags + 4, WS_NPROD * t);                  // every producer is done reading x buffer (t - 1) % XBUF
                     dma_batch(t - 1 + XBUF);
@@ -459,7 +465,7 @@ __global__ __launch_bounds__(WS_THREADS) void mpconv_fwd_ws_kernel(const WsParam
                 ws_wait_ge(flags + 4, WS_NPROD * (t + 2));
                 WS_STAMP(4 + 3 * (t + 1));
                 gather(t + 1, std::integral_constant<int, 1>());
-                ws_signal(flags + 8, lane);
+                ws_signal(flags + 12, lane);
                 WS_STAMP(5 + 3 * (t + 1));
             }
         }
