@@ -37,8 +37,8 @@
 #define BW_THREADS 512       // 8 waves x 256 VGPRs: the roles' resident state (64 MFMA registers, 16 + 48 of the projection, ~60 of the staging) spills at 128
 #define BW_WAVES 8
 #define BW_MAXN 96
-#define BW_XROW 128           // x image row: 64 bf16, linear (LDS-DMA), 16-byte chunks XOR-swizzled by (node >> 1) & 7
-#define BW_GROW 128           // G image row (one in-edge slot of one source node): 64 bf16, chunks swizzled by (row >> 1) & 7
+#define BW_XROW 128           // x image row: 64 bf16, linear (LDS-DMA), 16-byte chunks XOR-swizzled by bw_swz_r(node)
+#define BW_GROW 128           // G image row (one in-edge slot of one source node): 64 bf16, chunks swizzled by bw_swz_r(row)
 #define BW_PROW 512           // P image row: [4 edge types][64 channels] bf16, chunks swizzled per (node, edge type)
 #define BW_DROW 528           // dP image row: [64 channels][4 edge types] bf16 + 16 (conflict-free b128 operand reads)
 
@@ -116,6 +116,17 @@ template <typename T> __device__ __forceinline__ const T* bw_at(const void* base
 template <typename T> __device__ __forceinline__ T* bw_at(void* base, unsigned byte_off) {
     return reinterpret_cast<T*>(static_cast<char*>(base) + byte_off);
 }
+// Chunk swizzles of the 128-byte-row images (x, G) and of the dP image.  Each image is read two ways: 16-byte operand reads
+// (ds_read_b128: the 16 lanes of a service group {0-3,12-15,20-27} / ... must land in 16 different 16-byte slots of a 256-byte
+// window) and TRANSPOSE reads (ds_read_b64_tr_b16: a 32-lane pass fetches 4 consecutive rows x two adjacent 32-byte segments =
+// eight 32-byte pieces that must land in the eight 32-byte bank groups).  (row >> 1) & 7 — the first form — satisfies the b128
+// reads only: rows r and r + 2 of a transpose read met in the same banks (26-29 % of the kernel's LDS cycles were conflicts).
+//   128-byte rows: s = (b1, b2^b3, b3) of the row index — bit 2 of s must come from b1 (rows r / r + 2 apart by two segments),
+//     and s^-1(001) must lie in {001,110,111} (the b128 groups mix chunk g of rows {0-3,12-15} with chunk g^1 of rows {4-11});
+//   The dP image keeps its 528-byte rows (b128-conflict-free; its transpose reads stay ~2-way conflicted): 512-byte rows with
+//   chunks swizzled by (b1, b0, b3, b2) of the node make both read kinds conflict-free, but every dx fragment address then
+//   needs its own XOR — 25 spilled registers at the 256-VGPR limit: 106 / 98 us against 89 / 84 (profiles/r04/README.md).
+__device__ __forceinline__ int bw_swz_r(int r) { return (((r >> 1) & 1) << 2) | ((((r >> 2) ^ (r >> 3)) & 1) << 1) | ((r >> 3) & 1); }
 __device__ __forceinline__ int bw_swz_p(int n, int e) { return ((2 * (n & 3) + (e >> 1)) ^ ((n >> 2) & 1)) & 7; }
 
 // LDS layout, fixed per instance (sized for the largest graph the instance takes: no shape-dependent scalar branches or
@@ -175,7 +186,7 @@ __global__ __launch_bounds__(BW_THREADS) void mpconv_bwd_ws_kernel(const BwParam
 #pragma unroll
     for (int u = 0; u < 3; ++u) {
         const int slot = 64 * (dwq + 4 * u) + lane, row = slot >> 3, pos = slot & 7;
-        dsrc[u] = (unsigned)(min(row, N - 1) * BW_XROW + ((pos ^ ((row >> 1) & 7)) << 4));
+        dsrc[u] = (unsigned)(min(row, N - 1) * BW_XROW + ((pos ^ bw_swz_r(row)) << 4));
     }
     constexpr int npieces = 12;                       // both x buffers hold 96 rows; rows >= N are copies of row N - 1
 
@@ -194,6 +205,25 @@ __global__ __launch_bounds__(BW_THREADS) void mpconv_bwd_ws_kernel(const BwParam
     // the first two samples' x: requested before anything else (the tables below take ~5 us)
     if (b_begin < b_end && dma_wave) { dma_x(b_begin, 0); if (b_begin + 1 < b_end) dma_x(b_begin + 1, 1); }
 
+    // W [64][256] f32 -> bf16 in LDS once, by all threads with coalesced 32-byte reads (rows of 528 bytes in the still unused G / P
+    // region), and every wave's resident fragments from there.  Read straight from memory the fragments are gathers — 32 four-byte
+    // loads per lane for the projection's, and for the two dx waves 32 sixteen-byte loads from 32 different rows each: 10 000 cycles
+    // on those two waves with the other six waiting at the first barrier (of ~21 000 cycles of set-up per launch).
+    constexpr int WROW = 528;
+    {
+        unsigned char* wst = bw_lds + OFF_G;
+        static_assert(64 * WROW <= LY::OFF_ET - LY::OFF_G, "W staging fits the G + P region");
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int i = tid + BW_THREADS * it, row = i >> 5, c8 = i & 31;
+            const bw_bf16x8 f = bw_frag_f32(p.W + (int64_t)row * p.w_ld + 8 * c8);
+            *reinterpret_cast<bw_bf16x8*>(wst + row * WROW + c8 * 16) = f;
+        }
+    }
+    // the neighbour table (M k <= 288 entries: one per thread): requested now, consumed by the table pass below
+    long long idx_v = tid < mk ? p.idx[tid] : 0;
+    bw_barrier();
+    BW_STAMP_G(40);
     // projection (all eight waves): column tile T = wave = (16-channel block ob, edge-type pair ep); A row i = 8 g + 4 h + r is
     // (edge type 2 ep + (g >> 1), channel 16 ob + 8 h + 4 (g & 1) + r): an output lane (node, h) then holds, per edge type of the
     // pair, EIGHT consecutive channels = one 16-byte chunk of the node's edge-type-major P row
@@ -205,11 +235,11 @@ __global__ __launch_bounds__(BW_THREADS) void mpconv_bwd_ws_kernel(const BwParam
         const int col = 4 * (16 * ob + 8 * h + 4 * (g & 1) + r) + 2 * ep + (g >> 1);
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
-            alignas(16) float w8[8];
+            unsigned w8[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) w8[u] = p.W[(int64_t)(16 * kk + 8 * lh + u) * p.w_ld + col];
-            aP[kk] = bw_frag_f32(w8);
-            xoff[kk] = (unsigned)(l31 * BW_XROW + (((2 * kk + lh) ^ ((l31 >> 1) & 7)) << 4));
+            for (int u = 0; u < 8; ++u) w8[u] = *reinterpret_cast<const uint16_t*>(bw_lds + OFF_G + (16 * kk + 8 * lh + u) * WROW + col * 2);
+            aP[kk] = __builtin_bit_cast(bw_bf16x8, make_uint4(w8[0] | (w8[1] << 16), w8[2] | (w8[3] << 16), w8[4] | (w8[5] << 16), w8[6] | (w8[7] << 16)));
+            xoff[kk] = (unsigned)(l31 * BW_XROW + (((2 * kk + lh) ^ bw_swz_r(l31)) << 4));
         }
 #pragma unroll
         for (int el = 0; el < 2; ++el)
@@ -224,7 +254,7 @@ __global__ __launch_bounds__(BW_THREADS) void mpconv_bwd_ws_kernel(const BwParam
         for (int t = 0; t < 4; ++t)
 #pragma unroll
             for (int sub = 0; sub < 4; ++sub) {
-                const f32x4 f = __builtin_bit_cast(f32x4, bw_frag_f32(p.W + (int64_t)(32 * wave + l31) * p.w_ld + 16 * (4 * t + sub) + 8 * lh));
+                const f32x4 f = *reinterpret_cast<const f32x4*>(bw_lds + OFF_G + (32 * wave + l31) * WROW + 32 * (4 * t + sub) + 16 * lh);
 #pragma unroll
                 for (int u = 0; u < 4; ++u) RA[t][4 * sub + u] = f[u];
             }
@@ -251,16 +281,20 @@ __global__ __launch_bounds__(BW_THREADS) void mpconv_bwd_ws_kernel(const BwParam
             }
         }
     };
-    // the neighbour table (M k <= 288 entries: one per thread) and sample 0's gz / argmax: requested now, consumed below
-    long long idx_v = tid < mk ? p.idx[tid] : 0;
+    BW_STAMP_G(41);
+    // sample 0's gz / argmax: requested now, consumed below
     uint4 pg0[NSLOT];
     uint2 pa0[NSLOT];
     if (b_begin < b_end) prefetch_g(b_begin, pg0, pa0);
 
     // ---- setup: zero every image (pad rows of G / etT / dP are read as zeros for the kernel's lifetime), transposed incidence ----
     // (bw_barrier, not __syncthreads: the loads requested above stay in flight across it)
+    bw_barrier();                                      // every wave has its fragments: the staged W may go
+    BW_STAMP_G(42);
     for (int f = OFF_G / 16 + tid; f < LY::BYTES / 16; f += BW_THREADS) reinterpret_cast<uint4*>(bw_lds)[f] = make_uint4(0, 0, 0, 0);      // (not the x buffers)
+    BW_STAMP_G(43);
     bw_barrier();
+    BW_STAMP_G(44);
     {
         // scratch in the (still unused) P / dP region: in-degree counters and up to 8 edge ids per source node
         int* cnt = reinterpret_cast<int*>(bw_lds + OFF_PD);
@@ -298,7 +332,7 @@ __global__ __launch_bounds__(BW_THREADS) void mpconv_bwd_ws_kernel(const BwParam
         for (int f = tid; f < 8 * mk; f += BW_THREADS) {                  // (item, j) -> 16-byte piece c8 of G row R, chunk-swizzled
             const int item = f / KC, j = f - item * KC, m = item >> 3, c8 = item & 7;
             const int R = slot_of[m * KC + j];
-            gtab[f] = R >= 0 ? (unsigned)(OFF_G + R * BW_GROW + ((c8 ^ ((R >> 1) & 7)) << 4)) : (unsigned)LY::OFF_DUMP;
+            gtab[f] = R >= 0 ? (unsigned)(OFF_G + R * BW_GROW + ((c8 ^ bw_swz_r(R)) << 4)) : (unsigned)LY::OFF_DUMP;
         }
         bw_barrier();
     }
@@ -324,7 +358,7 @@ __global__ __launch_bounds__(BW_THREADS) void mpconv_bwd_ws_kernel(const BwParam
     for (int sl = 0; sl < NG; ++sl) {
         const int gi = wave + 8 * sl;
         const int R = gi * 16 + i16;
-        da[sl] = (unsigned)(OFF_G + R * BW_GROW + ((g4 ^ ((R >> 1) & 7)) << 4));
+        da[sl] = (unsigned)(OFF_G + R * BW_GROW + ((g4 ^ bw_swz_r(R)) << 4));
         const int jn = QS == 4 ? (i16 >> 2) : ((i16 & 7) >> 2), e = i16 & 3;
         const int nb = gi * NPG + jn;
         db_[sl] = (unsigned)(OFF_PD + nb * BW_PROW + e * 128 + ((g4 ^ bw_swz_p(nb, e)) << 4));
@@ -336,7 +370,7 @@ __global__ __launch_bounds__(BW_THREADS) void mpconv_bwd_ws_kernel(const BwParam
         dt[sl] = (ok && n < N) ? (unsigned)(OFF_TAB + (n * QS + q0) * 4) : (unsigned)(OFF_TAB + NMAX * QS * 4);
     }
     // dP phase: address pattern of the transpose read of a node's G rows.  Lane i16 of group g4 names (row n QS + 4 h4 + (i16 >> 2),
-    // chunk 2 g4 + ((i16 & 3) >> 1), half i16 & 1); the row's swizzle (R >> 1) & 7 depends on the node only through n mod (8 / QS),
+    // chunk 2 g4 + ((i16 & 3) >> 1), half i16 & 1); the row's swizzle (bits 1-3 of R) depends on the node only through n mod (16 / QS),
     // and a wave's first node is a multiple of 4: one pattern per (i mod 4, h4), the node's base added as a scalar
     constexpr int npw = MAXNPW;
     unsigned gpat[4][QS / 4];
@@ -346,14 +380,14 @@ __global__ __launch_bounds__(BW_THREADS) void mpconv_bwd_ws_kernel(const BwParam
         for (int h4 = 0; h4 < QS / 4; ++h4) {
             const int R = v * QS + 4 * h4 + (i16 >> 2);
             const int chunk = 2 * g4 + ((i16 & 3) >> 1);
-            gpat[v][h4] = lds0 + (unsigned)(OFF_G + (4 * h4 + (i16 >> 2)) * BW_GROW + ((chunk ^ ((R >> 1) & 7)) << 4) + 8 * (i16 & 1));
+            gpat[v][h4] = lds0 + (unsigned)(OFF_G + (4 * h4 + (i16 >> 2)) * BW_GROW + ((chunk ^ bw_swz_r(R)) << 4) + 8 * (i16 & 1));
         }
     // dW transpose-read offsets: segment of lane i16 in group g4 = (node 8 (g4 >> 1) + (i16 >> 2) [+ 4], columns 16 (g4 & 1) + 4 (i16 & 3) ..)
     unsigned xa[2][2], db[2];
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
         const int nd = 8 * (g4 >> 1) + (i16 >> 2) + 4 * r;
-        const int fx = (nd >> 1) & 7;                                     // (+ 16 ks leaves it unchanged)
+        const int fx = bw_swz_r(nd);                                      // (+ 16 ks leaves it unchanged)
 #pragma unroll
         for (int c2 = 0; c2 < 2; ++c2) {
             const int chunk = 4 * c2 + 2 * (g4 & 1) + ((i16 & 3) >> 1);
@@ -777,7 +811,8 @@ int fgnn_mpconv_backward_ws(const fgnn_mpconv_desc* d, const void* x, const int6
         fprintf(stderr, "[fgnn prof ws bwd] kernel: early-dma %lld zero+idx %lld rank %lld gtab %lld consts %lld loop-end %lld end %lld; samples:", h[129] - h[128],
                 h[130] - h[128], h[134] - h[128], h[135] - h[128], h[131] - h[128], h[132] - h[128], h[133] - h[128]);
         for (int i = 0; i < 20 && h[136 + i]; ++i) fprintf(stderr, " %lld", h[136 + i] - h[128]);
-        fprintf(stderr, "\n");
+        fprintf(stderr, "\n[fgnn prof ws bwd] setup (thread 0): W-proj frags %lld, dx frags %lld, prefetch issued %lld, zeroed %lld, barrier %lld\n",
+                h[128 + 40] - h[128], h[128 + 41] - h[128], h[128 + 42] - h[128], h[128 + 43] - h[128], h[128 + 44] - h[128]);
     }
 #endif
     if (!split) fgnn_launch_slab_reduce(p.ws, grid, slab_len, nw, gfilters, gbias, st);
