@@ -731,6 +731,7 @@ def main():
                 for name, ns in in_graph.items():
                     if sym.split(' x2')[0].replace(' ', '') in name.replace(' ', ''):
                         d['avg_launch_us_in_graph_rocprof'] = round(ns / 1e3 * (2 if sym.endswith(' x2') else 1), 2)
+                        d['frac_in_graph_rocprof'] = round(nb / (d['avg_launch_us_in_graph_rocprof'] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
                 if not bf16:                              # the f32-MFMA kernels (exact v_mfma_f32_16x16x4_f32) sit above the f32 ridge: matrix-core-bound
                     tfs = nf / (step_ms * 1e-3) / 1e12
                     d.update({'achieved': round(tfs, 2), 'peak': F32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
@@ -757,7 +758,8 @@ def main():
                              'operator_fwd_frac': fwd_frac, 'operator_bwd_frac': bwd_frac,
                              'durations': 'frac / achieved use avg_launch_us_in_step (events around each launch in an eager step on the '
                                           'two streams of the timed graph); _isolated = the same on one stream; _in_graph_rocprof = '
-                                          'the committed rocprofv3 kernel trace of the replayed graph (profiles/r04)'})
+                                          'the committed rocprofv3 kernel trace of the replayed graph (profiles/r04: the average over ALL launches of the symbol, the '
+                                          'accumulating second launches of the 64->128 calls included), frac_in_graph_rocprof = bytes / that'})
             for k, v in kernels.items():
                 v['ms2'] = (kernels2.get(k) or v)['ms']
     fence()

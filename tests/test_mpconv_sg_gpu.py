@@ -296,3 +296,30 @@ def test_sg_backward_is_bitwise_reproducible_and_matches_first_generation(dev, m
     assert 'mpconv_bwd_b16' in c[4]
     for u, v in zip(a[:4], c[:4]):
         assert H.rel_err(u.float(), v.float()) <= 2.0 ** -6
+
+
+@pytest.mark.parametrize('shape', [(96, 48, 6), (48, 96, 3)], ids=['V->F', 'F->V'])
+def test_ws_backward_is_bit_reproducible_over_many_launches(shape, dev):
+    """The third-generation backward moves its inputs by LDS-DMA two samples ahead and hands images between phases and wave roles
+    with four barriers per sample; a missing wait shows as rare run-to-run differences (as the forward's did), not as a parity
+    failure.  40 launches at a batch that gives the workgroups uneven sample counts, all four gradients bit-identical."""
+    from fgnn_amd import _hip, ops
+    N, M, k = shape
+    B = 1100
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(B, N, 1, 64, generator=g).bfloat16().to(dev).permute(0, 3, 1, 2)
+    idx = _regular_table(N, M, k, g).to(dev).expand(B, -1, -1)
+    et = torch.randn(B, M, k, 4, generator=g).bfloat16().to(dev).permute(0, 3, 1, 2)
+    W, bias = (torch.randn(64, 256, generator=g) * 0.1).to(dev), torch.randn(64, generator=g).to(dev)
+    gz = torch.randn(B, M, 1, 64, generator=g).bfloat16().to(dev).permute(0, 3, 1, 2)
+    first = None
+    for r in range(40):
+        xd, ed = x.detach().requires_grad_(True), et.detach().requires_grad_(True)
+        Wd, bd = W.detach().requires_grad_(True), bias.detach().requires_grad_(True)
+        ops.mpconv(xd, idx, ed, Wd, bd, 64, 4, 0, _hip.AGG_MAX).backward(gz)
+        cur = (xd.grad.clone(), ed.grad.clone(), Wd.grad.clone(), bd.grad.clone())
+        if first is None:
+            assert 'mpconv_bwd_ws' in _hip.lib().fgnn_last_kernel().decode()
+            first = cur
+        else:
+            assert all(torch.equal(u, v) for u, v in zip(cur, first)), 'launch %d differs from launch 0' % r
