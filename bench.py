@@ -144,37 +144,47 @@ def self_launch(args):
     if os.environ.get('FGNN_BENCH_DEVICE') is None and have < n:
         raise SystemExit('bench.py --gpus %d: this node exposes %d ROCm device(s); one rank per GPU needs %d '
                          '(no oversubscription, no silent 1-rank run)' % (n, have, n))
-    s = socket.socket()
-    s.bind(('127.0.0.1', 0))
-    port = s.getsockname()[1]
-    s.close()
-    procs = []
-    for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), FGNN_BENCH_SELF_LAUNCHED='1')
-        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')       # dmabuf IPC: what RCCL needs on this driver
-        env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or 8) // n)))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=None if r == 0 else subprocess.DEVNULL))
-    rc = 0
-    try:
-        pending = dict(enumerate(procs))
-        while pending:
-            for r, pr in list(pending.items()):
-                code = pr.poll()
-                if code is None:
-                    continue
-                del pending[r]
-                if code != 0 and rc == 0:
-                    rc = code
-                    print('bench.py: rank %d exited with code %d; stopping the other ranks' % (r, code), file=sys.stderr)
-                    for q in pending.values():
-                        q.terminate()
-            time.sleep(0.05)
-    finally:
-        for pr in procs:
-            if pr.poll() is None:
-                pr.kill()
+    def attempt():
+        s = socket.socket()
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+        s.close()
+        t_start = time.time()
+        procs = []
+        for r in range(n):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                       MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), FGNN_BENCH_SELF_LAUNCHED='1')
+            env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')       # dmabuf IPC: what RCCL needs on this driver
+            env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or 8) // n)))
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                          stdout=None if r == 0 else subprocess.DEVNULL))
+        rc = 0
+        try:
+            pending = dict(enumerate(procs))
+            while pending:
+                for r, pr in list(pending.items()):
+                    code = pr.poll()
+                    if code is None:
+                        continue
+                    del pending[r]
+                    if code != 0 and rc == 0:
+                        rc = code
+                        print('bench.py: rank %d exited with code %d; stopping the other ranks' % (r, code), file=sys.stderr)
+                        for q in pending.values():
+                            q.terminate()
+                time.sleep(0.05)
+        finally:
+            for pr in procs:
+                if pr.poll() is None:
+                    pr.kill()
+        return rc, time.time() - t_start
+
+    # the rendezvous port is found by bind / close: another process can take it before rank 0 binds it again.  A launch that dies
+    # within seconds (nothing has been printed yet: the JSON line comes last) is tried once more on a fresh port.
+    rc, took = attempt()
+    if rc != 0 and took < 30.0:
+        print('bench.py: the ranks failed %.1f s after launch; retrying once on another rendezvous port' % took, file=sys.stderr)
+        rc, took = attempt()
     return rc
 
 
