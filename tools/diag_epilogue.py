@@ -11,7 +11,8 @@ from fgnn_amd import ops, _hip
 dev = torch.device('cuda:0')
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1100
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
-shapes = [(64, 64, 96, 48, 6), (64, 64, 48, 96, 3), (128, 64, 48, 96, 3), (64, 64, 37, 95, 3)]
+shapes = [(64, 64, 96, 48, 6), (64, 64, 48, 96, 3), (128, 64, 48, 96, 3), (64, 64, 37, 95, 3), (128, 64, 96, 48, 6), (64, 128, 96, 48, 6),
+          (64, 128, 48, 96, 3), (64, 64, 40, 20, 3)]
 if len(sys.argv) > 3:
     shapes = [shapes[int(sys.argv[3])]]
 for shape in shapes:
