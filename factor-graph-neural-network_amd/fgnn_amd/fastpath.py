@@ -2,7 +2,7 @@
 
 Through the ``lib.model.mpnn`` shim a reference script (``train_ldpc.py``) gets the hand-written kernels, but in the regime
 its own lines select: f32 activations, ``Sequential(Conv2d, ReLU, Conv2d)`` edge models run by torch, ``torch.optim.Adam``
-over ~330 tensors (56 ms per step at 4096 codewords against 17.6 ms for ``bench.py``'s bf16 line).  ``enable_fast_path()``
+over ~330 tensors (59.3 ms per step at 4096 codewords against 17 ms for ``bench.py``'s bf16 line).  ``enable_fast_path()``
 — or ``FGNN_FAST_PATH=1`` in the environment, read when ``fgnn_amd`` is imported — changes that without touching the script:
 
 * the first time a module that OWNS a ``FactorNN`` (the script's ``LDPCModel``, ``/root/reference/train_ldpc.py:19-99``) is
