@@ -51,9 +51,6 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--miopen-bn', action='store_true', help='let torch route BatchNorm to MIOpen')
     ap.add_argument('--no-graph', action='store_true', help='launch every kernel from Python instead of replaying a hipGraph')
-    ap.add_argument('--graph-collective', action='store_true',
-                    help='N > 1: record the RCCL all-reduce and Adam into the step graph as well (default: outside it; at N = 1 '
-                         'Adam is always inside)')
     ap.add_argument('--inputs', choices=['channel', 'features'], default='channel',
                     help='channel: encoded codewords through the reference channel (fgnn_amd/datapath.py); '
                          'features: random bits + unit-gain AWGN built with torch ops (ldpc.synthetic_batch)')
@@ -599,9 +596,11 @@ def main():
     train = args.mode == 'train'
     model.train(train)
     # N = 1: the optimizer is recorded into the step graph too (FlatAdam(capturable=True): step count and learning rate in device
-    # memory).  N > 1: the RCCL all-reduce would have to be recorded with it — proven on a one-rank group
-    # (tests/test_dp_two_ranks_gpu.py), never run on N > 1 ranks, hence opt-in (--graph-collective) until it has been.
-    whole_in_graph = train and not args.no_graph and (world == 1 or args.graph_collective)
+    # memory).  N > 1: the RCCL all-reduce sits between the backward and Adam, and it must NOT be captured through
+    # torch.distributed: ProcessGroupNCCL's watchdog thread polls the work's completion event, which was recorded on a capturing
+    # stream — hipErrorCapturedEvent, the process aborts (seen in ~1 of 6 runs of a one-rank group on the GPU box).  So with N > 1
+    # the graph ends with the backward and the collective + Adam are two eager launches behind every replay.
+    whole_in_graph = train and not args.no_graph and world == 1
     if train:
         # parameters and gradients live in two flat f32 buffers: one all-reduce, and Adam (the reference's
         # lr / weight_decay, train_ldpc.py) is eight elementwise kernels instead of a 330-tensor sweep
@@ -801,9 +800,8 @@ def main():
                                   if args.inputs == 'channel' else 'random bits + AWGN (torch ops)'),
                        'peak_hbm_GB': round(torch.cuda.max_memory_allocated(dev) / 1e9, 2),
                        'mode': args.mode, 'hip_graph': graphed is not None,
-                       'graph_scope': (None if graphed is None else 'forward + backward + all-reduce + Adam' if whole_in_graph and world > 1
-                                       else 'forward + backward + Adam' if whole_in_graph else 'forward + backward'
-                                       if train else 'forward'),
+                       'graph_scope': (None if graphed is None else 'forward + backward + Adam' if whole_in_graph else
+                                       'forward + backward (all-reduce and Adam eager behind each replay)' if train else 'forward'),
                        'distributed': dist_info},
             'roofline': roofline,
             'kernels': {k: {'launches': v['launches'], 'avg_us': round(v['ms'] / v['launches'] * 1e3, 2),

@@ -159,6 +159,148 @@ __global__ __launch_bounds__(LF_THREADS) void linear_fwd_b16_kernel(const LfPara
     }
 }
 
+// ----------------------------------------------------------------------------------------
+// The node-wise map FOLLOWED BY InstanceNorm (+ ReLU) — `iid_mapping_in`, /root/reference/lib/model/mpnn/base_model.py:82-90
+// (Conv2d(cin, cout, 1) -> InstanceNorm2d(cout) -> ReLU; FactorNN's v2v / f2f maps, factor_mpnn_sp.py:77,140) — in ONE pass:
+// the norm is per (sample, channel) over the sample's N nodes, so a wave that owns all N / 16 row tiles of a sample for its 64
+// output channels has the whole population in its accumulators (NT x 16 registers): per-channel sums fold over the 16 rows
+// of a tile with row-shuffles and over the tiles in registers, no LDS, no second kernel, and the pre-norm tensor z is only
+// WRITTEN (when the backward needs it: zs != NULL), never read back.  Statistics are formed from the bf16-ROUNDED z — the
+// population the staged path (csrc/instnorm.hip on the stored z) and the backward see — two-pass, f32.
+// ----------------------------------------------------------------------------------------
+struct LiParams {
+    LfParams lf;         // x, W, bias, y; R = B * N rows; part unused
+    uint16_t* zs;        // [R][Cout] pre-norm output (bf16) or NULL
+    int B, N;            // N = 16 NT nodes per sample
+    int relu;
+    float eps;
+};
+
+template <int KS, bool WREG, int NT>
+__global__ __launch_bounds__(LF_THREADS) void linear_instnorm_fwd_kernel(const LiParams q) {
+    constexpr int OTW = 4, CIN = 32 * KS, WS = CIN + 8;
+    const LfParams& p = q.lf;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lk = lane >> 4;
+    const int Cout = p.Cout;
+    const int cg = wave % p.CG, rg = wave / p.CG, nrg = LF_WAVES / p.CG;
+    uint16_t* Wl = reinterpret_cast<uint16_t*>(lf_lds);
+    float* bl = reinterpret_cast<float*>(lf_lds + (size_t)Cout * WS * 2);
+    for (int f = tid; f < Cout * (CIN / 2); f += LF_THREADS) {
+        const int o = f / (CIN / 2), c2 = f - o * (CIN / 2);
+        const float2 w = *reinterpret_cast<const float2*>(p.W + (int64_t)o * CIN + 2 * c2);
+        *reinterpret_cast<unsigned*>(Wl + o * WS + 2 * c2) = lf_pack2(w.x, w.y);
+    }
+    for (int f = tid; f < Cout; f += LF_THREADS) bl[f] = p.bias ? p.bias[f] : 0.f;
+    __syncthreads();
+
+    const int o_base = cg * OTW * 16;
+    auto orow = [&](int ot) { return 16 * (li >> 2) + 4 * ot + (li & 3); };     // (the channel permutation of linear_fwd_b16_kernel)
+    auto kcol = [&](int ks) { return 8 * KS * lk + 8 * ks; };
+    lf_bf16x8 aW[WREG ? OTW : 1][WREG ? KS : 1];
+    if constexpr (WREG) {
+#pragma unroll
+        for (int ot = 0; ot < OTW; ++ot)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+                aW[ot][ks] = __builtin_bit_cast(lf_bf16x8, *reinterpret_cast<const uint4*>(Wl + (o_base + orow(ot)) * WS + kcol(ks)));
+    }
+    f32x4 bv[OTW];
+#pragma unroll
+    for (int ot = 0; ot < OTW; ++ot) bv[ot] = *reinterpret_cast<const f32x4*>(bl + o_base + 16 * lk + 4 * ot);
+
+    const int N = q.N;
+    const float invn = 1.0f / (float)N;
+    auto load_tile = [&](int b, int t, uint4 (&bx)[KS]) {
+        const int64_t row = (int64_t)b * N + t * 16 + li;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+            bx[ks] = b < q.B ? *reinterpret_cast<const uint4*>(p.x + row * CIN + kcol(ks)) : make_uint4(0, 0, 0, 0);
+    };
+    for (int b = blockIdx.x * nrg + rg; b < q.B; b += gridDim.x * nrg) {
+        f32x4 acc[NT][OTW];
+        // KS <= 4: the next tile's rows are in flight under this one's products; wider inputs (48 + 96 accumulator registers are
+        // already resident) take a tile at a time and leave the latency to the other seven waves
+        constexpr bool PF = KS <= 4;
+        uint4 nx[PF ? KS : 1];
+        if constexpr (PF) load_tile(b, 0, nx);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            uint4 bx[KS];
+            if constexpr (PF) {
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) bx[ks] = nx[ks];
+                if (t + 1 < NT) load_tile(b, t + 1, nx);
+            } else {
+                __builtin_amdgcn_sched_barrier(0);            // (left alone the scheduler hoists all NT tiles' loads: 192 registers, spilled)
+                load_tile(b, t, bx);
+            }
+#pragma unroll
+            for (int ot = 0; ot < OTW; ++ot) {
+                acc[t][ot] = bv[ot];
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    lf_bf16x8 a;
+                    if constexpr (WREG) a = aW[ot][ks];
+                    else a = __builtin_bit_cast(lf_bf16x8, *reinterpret_cast<const uint4*>(Wl + (o_base + orow(ot)) * WS + kcol(ks)));
+                    acc[t][ot] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, __builtin_bit_cast(lf_bf16x8, bx[ks]), acc[t][ot], 0, 0, 0);
+                }
+            }
+        }
+        // z as stored: bf16.  acc[t][ot][r] = channel o_base + 16 lk + 4 ot + r of row 16 t + li
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            uint4 lo, hi;
+            lo = make_uint4(lf_pack2(acc[t][0][0], acc[t][0][1]), lf_pack2(acc[t][0][2], acc[t][0][3]),
+                            lf_pack2(acc[t][1][0], acc[t][1][1]), lf_pack2(acc[t][1][2], acc[t][1][3]));
+            hi = make_uint4(lf_pack2(acc[t][2][0], acc[t][2][1]), lf_pack2(acc[t][2][2], acc[t][2][3]),
+                            lf_pack2(acc[t][3][0], acc[t][3][1]), lf_pack2(acc[t][3][2], acc[t][3][3]));
+            if (q.zs) {
+                uint16_t* zp = q.zs + ((int64_t)b * N + t * 16 + li) * Cout + o_base + 16 * lk;
+                *reinterpret_cast<uint4*>(zp) = lo;
+                *reinterpret_cast<uint4*>(zp + 8) = hi;
+            }
+            const unsigned w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+            for (int ot = 0; ot < OTW; ++ot) {                 // the rounded values are the population
+                acc[t][ot][0] = __uint_as_float(w[2 * ot] << 16);     acc[t][ot][1] = __uint_as_float(w[2 * ot] & 0xffff0000u);
+                acc[t][ot][2] = __uint_as_float(w[2 * ot + 1] << 16); acc[t][ot][3] = __uint_as_float(w[2 * ot + 1] & 0xffff0000u);
+            }
+        }
+#pragma unroll
+        for (int ot = 0; ot < OTW; ++ot)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float s = 0.f;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) s += acc[t][ot][r];
+#pragma unroll
+                for (int m = 1; m < 16; m <<= 1) s += __shfl_xor(s, m);      // the 16 rows of a tile sit in 16 consecutive lanes
+                const float mean = s * invn;
+                float ss = 0.f;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) { const float dv = acc[t][ot][r] - mean; acc[t][ot][r] = dv; ss = fmaf(dv, dv, ss); }
+#pragma unroll
+                for (int m = 1; m < 16; m <<= 1) ss += __shfl_xor(ss, m);
+                const float rstd = rsqrtf(ss * invn + q.eps);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const float v = acc[t][ot][r] * rstd;
+                    acc[t][ot][r] = q.relu ? fmaxf(v, 0.f) : v;
+                }
+            }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            uint16_t* yp = p.y + ((int64_t)b * N + t * 16 + li) * Cout + o_base + 16 * lk;
+            *reinterpret_cast<uint4*>(yp) = make_uint4(lf_pack2(acc[t][0][0], acc[t][0][1]), lf_pack2(acc[t][0][2], acc[t][0][3]),
+                                                       lf_pack2(acc[t][1][0], acc[t][1][1]), lf_pack2(acc[t][1][2], acc[t][1][3]));
+            *reinterpret_cast<uint4*>(yp + 8) = make_uint4(lf_pack2(acc[t][2][0], acc[t][2][1]), lf_pack2(acc[t][2][2], acc[t][2][3]),
+                                                           lf_pack2(acc[t][3][0], acc[t][3][1]), lf_pack2(acc[t][3][2], acc[t][3][3]));
+        }
+    }
+}
+
 static int lf_plan(int64_t R, int Cin, int Cout, int* CG, int* grid) {
     if (Cin % 64 || Cout % 64 || Cin > 256 || Cout > 256 || R <= 0 || R > 0x7fffffff) return -1;
     *CG = Cout / 64;                                      // <= 64 output channels (4 tiles) per wave
@@ -208,5 +350,46 @@ extern "C" int fgnn_linear_forward(const void* x, const float* W, const float* b
     void* args[] = {(void*)&p};
     hipError_t e = hipLaunchKernel(fn, dim3(grid), dim3(LF_THREADS), args, lds, (hipStream_t)stream);
     if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "linear_forward launch: %s", hipGetErrorString(e));
+    return FGNN_OK;
+}
+
+
+// y = act(InstanceNorm(x W^T + b)) per sample over its N nodes, bf16 rows [B * N][Cin] -> [B * N][Cout]; z (or NULL): the
+// pre-norm map output, stored for the backward (fgnn_instnorm_backward reads it).  N in {48, 96} (a multiple of 16 with an
+// instantiated tile count), Cin / Cout multiples of 64 up to 256.  FGNN_EUNSUPPORTED otherwise (callers run the two kernels).
+extern "C" int fgnn_linear_instnorm_forward(const void* x, const float* W, const float* bias, void* z, void* y, int B, int N,
+                                            int Cin, int Cout, int relu, float eps, fgnn_stream_t stream) {
+    if (!x || !W || !y) FGNN_FAIL(FGNN_EINVAL, "linear_instnorm_forward: null pointer");
+    if (B < 0 || N < 1) FGNN_FAIL(FGNN_EINVAL, "linear_instnorm_forward: bad sizes B=%d N=%d", B, N);
+    int CG, grid;
+    if ((N != 48 && N != 96) || lf_plan((int64_t)(B > 0 ? B : 1) * N, Cin, Cout, &CG, &grid) || ((uintptr_t)x & 15) ||
+        ((uintptr_t)y & 15) || ((uintptr_t)z & 15) || ((uintptr_t)W & 7))
+        FGNN_FAIL(FGNN_EUNSUPPORTED, "linear_instnorm_forward: N=%d Cin=%d Cout=%d outside the fused kernel's family", N, Cin, Cout);
+    if (B == 0) return FGNN_OK;
+    LiParams q;
+    q.lf.x = (const uint16_t*)x; q.lf.W = W; q.lf.bias = bias; q.lf.y = (uint16_t*)y; q.lf.part = nullptr;
+    q.lf.R = B * N; q.lf.Cin = Cin; q.lf.Cout = Cout; q.lf.CG = CG; q.lf.wt = 0;
+    q.zs = (uint16_t*)z; q.B = B; q.N = N; q.relu = relu; q.eps = eps;
+    const int nrg = LF_WAVES / CG;
+    grid = (B + nrg - 1) / nrg;
+    if (grid > LF_MAXGRID) grid = LF_MAXGRID;
+    const int KS = Cin / 32;
+    void* fn = nullptr;
+#define LI_PICK(ks, wreg) fn = N == 96 ? (void*)linear_instnorm_fwd_kernel<ks, wreg, 6> : (void*)linear_instnorm_fwd_kernel<ks, wreg, 3>
+    switch (KS) {
+        case 2: LI_PICK(2, true); break;
+        case 4: LI_PICK(4, true); break;
+        case 6: LI_PICK(6, false); break;
+        default: LI_PICK(8, false); break;
+    }
+#undef LI_PICK
+    const int lds = Cout * (Cin + 8) * 2 + Cout * 4;
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "hipFuncSetAttribute(%d B LDS): %s", lds, hipGetErrorString(e));
+    }
+    void* args[] = {(void*)&q};
+    hipError_t e = hipLaunchKernel(fn, dim3(grid), dim3(LF_THREADS), args, lds, (hipStream_t)stream);
+    if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "linear_instnorm_forward launch: %s", hipGetErrorString(e));
     return FGNN_OK;
 }

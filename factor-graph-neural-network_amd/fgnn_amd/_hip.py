@@ -17,7 +17,7 @@ EXT_NONE, EXT_NEIGHBOR, EXT_DIFF = 0, 1, 2
 DESC_GETYPE_REDUCED = 0x10000
 AGG_MAX, AGG_LSE, AGG_MEAN = 0, 1, 2
 F32, BF16 = 0, 1
-ABI_VERSION = 6              # include/fgnn_hip.h: FGNN_ABI_VERSION (checked before any symbol is bound)
+ABI_VERSION = 7              # include/fgnn_hip.h: FGNN_ABI_VERSION (checked before any symbol is bound)
 EUNSUPPORTED = -3            # FGNN_EUNSUPPORTED: shape outside a kernel's family (callers fall back)
 
 AGG_CODES = {'max': AGG_MAX, 'softmax': AGG_LSE, 'mean': AGG_MEAN}
@@ -26,7 +26,7 @@ EXPORTS = ('fgnn_mpconv_forward', 'fgnn_mpconv_backward', 'fgnn_mpconv_forward_l
            'fgnn_mpconv_backward_workspace_bytes', 'fgnn_mpconv_backward_reduces_getype', 'fgnn_linear_wgrad', 'fgnn_linear_wgrad_workspace_bytes',
            'fgnn_instnorm_forward', 'fgnn_instnorm_backward', 'fgnn_bn_supported', 'fgnn_bn_workspace_bytes',
            'fgnn_bn_stats', 'fgnn_bn_finalize', 'fgnn_bn_apply', 'fgnn_bn_backward',
-           'fgnn_linear_forward', 'fgnn_linear_forward_partials', 'fgnn_sum_n', 'fgnn_flat_adam', 'fgnn_flat_adam_dev', 'fgnn_edge_mlp_forward', 'fgnn_edge_mlp_workspace_bytes', 'fgnn_edge_mlp_backward', 'fgnn_ldpc_encode', 'fgnn_ldpc_channel_features', 'fgnn_ldpc_channel_features_rng', 'fgnn_ldpc_decode', 'fgnn_mpconv_block_forward', 'fgnn_mpconv_block_forward_fanout', 'fgnn_mpconv_block_forward_fanin', 'fgnn_factor_layer_forward', 'fgnn_factor_layer_param_count', 'fgnn_mpconv_forward_stats', 'fgnn_mpconv_forward_stats_partials', 'fgnn_block_tail_partials', 'fgnn_block_tail_stats', 'fgnn_block_tail_apply', 'fgnn_block_tail_backward', 'fgnn_block_tail_backward_partials', 'fgnn_bn_finalize_shifted', 'fgnn_bn_backward_partials', 'fgnn_block_head_backward',
+           'fgnn_linear_forward', 'fgnn_linear_forward_partials', 'fgnn_linear_instnorm_forward', 'fgnn_sum_n', 'fgnn_flat_adam', 'fgnn_flat_adam_dev', 'fgnn_edge_mlp_forward', 'fgnn_edge_mlp_workspace_bytes', 'fgnn_edge_mlp_backward', 'fgnn_ldpc_encode', 'fgnn_ldpc_channel_features', 'fgnn_ldpc_channel_features_rng', 'fgnn_ldpc_decode', 'fgnn_mpconv_block_forward', 'fgnn_mpconv_block_forward_fanout', 'fgnn_mpconv_block_forward_fanin', 'fgnn_factor_layer_forward', 'fgnn_factor_layer_param_count', 'fgnn_mpconv_forward_stats', 'fgnn_mpconv_forward_stats_partials', 'fgnn_block_tail_partials', 'fgnn_block_tail_stats', 'fgnn_block_tail_apply', 'fgnn_block_tail_backward', 'fgnn_block_tail_backward_partials', 'fgnn_bn_finalize_shifted', 'fgnn_bn_backward_partials', 'fgnn_block_head_backward',
            'fgnn_mpconv_algorithmic_bytes', 'fgnn_last_error', 'fgnn_last_kernel', 'fgnn_abi_version')
 
 
@@ -101,6 +101,8 @@ def lib():
     L.fgnn_bn_finalize.argtypes = [vp, i32, i64, i32, vp, vp, vp, vp, f32, f32, vp, vp, vp, vp, vp, vp]
     L.fgnn_linear_forward.restype = ctypes.c_int
     L.fgnn_linear_forward.argtypes = [vp, vp, vp, vp, i64, i32, i32, vp, i32, vp]
+    L.fgnn_linear_instnorm_forward.restype = ctypes.c_int
+    L.fgnn_linear_instnorm_forward.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, vp]
     L.fgnn_linear_forward_partials.restype = ctypes.c_int
     L.fgnn_linear_forward_partials.argtypes = [i64, i32, i32]
     L.fgnn_mpconv_block_forward.restype = ctypes.c_int

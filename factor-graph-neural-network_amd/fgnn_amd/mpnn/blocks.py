@@ -52,7 +52,56 @@ class iid_mapping_in(torch.nn.Module):
         self.main = _conv_norm_act(nin, nout, NodeInstanceNorm(relu=True), torch.nn.Identity(), bias)
 
     def forward(self, x):
-        return self.main(x)
+        y = self._fused(x)
+        return self.main(x) if y is None else y
+
+    def _fused(self, x):
+        """Conv -> InstanceNorm -> ReLU as ONE kernel (csrc/linear_fwd_b16.hip: linear_instnorm_fwd_kernel) for bf16 channel-fastest
+        states of 96 / 48 nodes: the norm is per sample, so the wave that multiplies a sample's rows holds its whole population.
+        The pre-norm tensor is written only when a backward will read it, and never read back in the forward.  The autograd graph
+        is the staged one (the map's and the norm's own Functions, handed their outputs): the backward is unchanged.  None: the
+        staged path runs (other widths / dtypes / layouts, autocast off, CPU)."""
+        from .. import _hip, ops
+        from .pointwise import _InstNormAct, _RowLinear
+        if not FUSE_IID_IN or not x.is_cuda or x.dim() != 4 or x.shape[3] != 1 or x.shape[2] not in (48, 96):
+            return None
+        conv, norm = self.main[0], self.main[1]
+        B, C, N, _ = x.shape
+        cout = conv.out_channels
+        dt = torch.get_autocast_dtype('cuda') if torch.is_autocast_enabled() else x.dtype
+        # inputs wider than 128 channels stay staged: the fused kernel then has no registers left to keep a second row tile in
+        # flight (207 vs 194 us at 256 -> 256, 137 vs 112 at 256 -> 128; 145 vs 168 at 128 -> 256, 47 vs 58 at 64 -> 64: tools/ibench.py)
+        if dt != torch.bfloat16 or C % 64 or cout % 64 or C > _IID_FUSE_MAX_CIN or cout > 256 or conv.weight.dtype != torch.float32:
+            return None
+        rows = x.permute(0, 2, 3, 1)
+        if not rows.is_contiguous():
+            rows = rows.contiguous()
+        rows = rows.view(B * N, C)
+        if rows.dtype != torch.bfloat16:
+            rows = rows.to(torch.bfloat16)
+        weight = conv.weight.view(cout, C)
+        grad = torch.is_grad_enabled() and (weight.requires_grad or rows.requires_grad)
+        w = weight.detach()
+        b = None if conv.bias is None else conv.bias.detach().float().contiguous()
+        z = torch.empty((B * N, cout), device=x.device, dtype=torch.bfloat16) if grad else None
+        y = torch.empty((B, N, 1, cout), device=x.device, dtype=torch.bfloat16)
+        L = _hip.lib()
+        rc = []
+        ops.timed('linear_instnorm_fwd_kernel', 2 * B * N * (C + cout * (2 if grad else 1)),
+                  lambda: rc.append(L.fgnn_linear_instnorm_forward(_hip._ptr(rows), _hip._ptr(w), _hip._ptr(b), _hip._ptr(z), _hip._ptr(y),
+                                                                   B, N, C, cout, int(norm.relu), float(norm.eps), _hip.stream_ptr())),
+                  nflops=2 * B * N * C * cout)
+        if rc[0] == _hip.EUNSUPPORTED:
+            return None
+        _hip.check(rc[0])
+        if not grad:
+            return y.permute(0, 3, 1, 2)
+        zz = _RowLinear.apply(rows, weight, conv.bias, False, z)
+        return _InstNormAct.apply(zz.view(B, N, 1, cout).permute(0, 3, 1, 2), norm.relu, y)
+
+
+_IID_FUSE_MAX_CIN = int(os.environ.get('FGNN_IID_FUSE_MAX_CIN', '128'))
+FUSE_IID_IN = os.environ.get('FGNN_STAGED_IID_IN') is None      # iid_mapping_in: map + InstanceNorm + ReLU as one kernel where the shape allows
 
 
 class max_pool_layer(torch.nn.Module):

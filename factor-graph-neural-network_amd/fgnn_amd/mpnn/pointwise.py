@@ -177,10 +177,13 @@ class _RowLinear(torch.autograd.Function):
     rows and gy)."""
 
     @staticmethod
-    def forward(ctx, rows, weight, bias, want_stats=False):
+    def forward(ctx, rows, weight, bias, want_stats=False, precomputed=None):
+        """``precomputed``: the output, already formed by a fused kernel (blocks.iid_mapping_in): only the graph node is made."""
         ctx.save_for_backward(rows, weight)
         ctx.has_bias = bias is not None
         ctx.params = (weight, bias)                     # leaf tensors (ops.grad_sink)
+        if precomputed is not None:
+            return precomputed
         y = hip_linear(rows, weight, bias, want_stats)
         if y is not None:
             return y
@@ -210,7 +213,7 @@ class _RowLinear(torch.autograd.Function):
                 rows.dtype == torch.float32 and cin % 4 == 0 and cout % 4 == 0 and cin <= 1024 and cout <= 1024 and R >= 2048):
             gw = (gy.t() @ rows).float()                # f32 square 256-wide maps: rocBLAS is ahead there
             gb = gy.float().sum(0) if ctx.has_bias else None
-            return grows, gw.to(weight.dtype), (gb.to(weight.dtype) if gb is not None else None), None
+            return grows, gw.to(weight.dtype), (gb.to(weight.dtype) if gb is not None else None), None, None
         L = _hip.lib()
         wparam, bparam = ctx.params
         # weight may be a [cout,cin,1,1] Conv2d parameter viewed as [cout,cin]: its .grad lives on the base
@@ -235,7 +238,7 @@ class _RowLinear(torch.autograd.Function):
         else:
             launch()
         return (grows, None if gw_sink is not None else gw.to(weight.dtype),
-                None if (gb is None or gb_sink is not None) else gb.to(weight.dtype), None)
+                None if (gb is None or gb_sink is not None) else gb.to(weight.dtype), None, None)
 
 
 class PointwiseConv2d(torch.nn.Conv2d):
@@ -277,19 +280,22 @@ class _InstNormAct(torch.autograd.Function):
     forward, one backward (csrc/instnorm.hip); only x is saved."""
 
     @staticmethod
-    def forward(ctx, x, relu):
+    def forward(ctx, x, relu, precomputed=None):
+        """``precomputed``: the output rows [B,N,1,C], already formed by a fused kernel (blocks.iid_mapping_in)."""
         B, C, N, _ = x.shape
         rows = x.permute(0, 2, 3, 1)                    # [B,N,1,C]
         if not rows.is_contiguous():
             rows = rows.contiguous()
+        ctx.save_for_backward(rows)
+        ctx.relu = relu
+        if precomputed is not None:
+            return precomputed.permute(0, 3, 1, 2)
         y = torch.empty_like(rows)
         from .. import ops
         ops.timed('instnorm_fwd_kernel', 2 * rows.numel() * rows.element_size(),
                   lambda: _hip.check(_hip.lib().fgnn_instnorm_forward(_hip._ptr(rows), _hip._ptr(y), B, N, C,
                                                                       _hip.dtype_code(rows), int(relu),
                                                                       _hip.stream_ptr())))
-        ctx.save_for_backward(rows)
-        ctx.relu = relu
         return y.permute(0, 3, 1, 2)
 
     @staticmethod
@@ -307,7 +313,7 @@ class _InstNormAct(torch.autograd.Function):
                   lambda: _hip.check(_hip.lib().fgnn_instnorm_backward(_hip._ptr(rows), _hip._ptr(g), _hip._ptr(gx), B, N,
                                                                        C, _hip.dtype_code(rows), int(ctx.relu),
                                                                        _hip.stream_ptr())))
-        return gx.permute(0, 3, 1, 2), None
+        return gx.permute(0, 3, 1, 2), None, None
 
 
 class NodeInstanceNorm(torch.nn.Module):

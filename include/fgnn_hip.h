@@ -129,6 +129,17 @@ int64_t fgnn_mpconv_algorithmic_bytes(const fgnn_mpconv_desc* d);
  */
 int fgnn_linear_forward(const void* x, const float* W, const float* bias, void* y, int64_t R, int32_t Cin,
                         int32_t Cout, float* stats_partials, int32_t w_transposed, fgnn_stream_t stream);
+
+/*
+ * The node-wise map FOLLOWED BY InstanceNorm (+ ReLU) in one pass — `iid_mapping_in`, /root/reference/lib/model/mpnn/base_model.py:82-90
+ * (Conv2d(cin, cout, 1) -> InstanceNorm2d(cout) -> ReLU: FactorNN's v2v / f2f maps, factor_mpnn_sp.py:77,140) — for bf16
+ * channel-fastest rows: y[b, n, :] = act((z[b, n, :] - mean_b) * rstd_b), z = x W^T + bias, statistics per (sample, channel) over the
+ * sample's N nodes (biased variance, eps as given), formed from the bf16-rounded z.  z (or NULL): [B * N][Cout] receives the
+ * pre-norm output for the backward (fgnn_instnorm_backward reads it); it is never read here.  N in {48, 96}, Cin / Cout
+ * multiples of 64 up to 256; FGNN_EUNSUPPORTED otherwise (run fgnn_linear_forward + fgnn_instnorm_forward).
+ */
+int fgnn_linear_instnorm_forward(const void* x, const float* W, const float* bias, void* z, void* y, int32_t B, int32_t N,
+                                 int32_t Cin, int32_t Cout, int32_t relu, float eps, fgnn_stream_t stream);
 int fgnn_linear_forward_partials(int64_t R, int32_t Cin, int32_t Cout);
 
 /*
@@ -386,7 +397,7 @@ const char* fgnn_last_kernel(void);
  * mismatch and not as a missing symbol or a misread field.  4: round-2 additions (flat_adam, factor_layer_*,
  * ldpc_channel_features_rng, backward_reduces_getype, desc.reserved = in-degree | GETYPE_REDUCED); 5: fgnn_block_tail_*;
  * 6: fgnn_block_head_backward. */
-#define FGNN_ABI_VERSION 6
+#define FGNN_ABI_VERSION 7
 int fgnn_abi_version(void);
 
 #ifdef __cplusplus

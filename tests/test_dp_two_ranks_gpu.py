@@ -62,7 +62,7 @@ def _train(rank, world, graph, reduce_single_rank=False):
     label = data[6][lo:hi, :48].float().contiguous()
     bucket = FlatGradBucket(model.parameters(), flatten_params=True, reduce_single_rank=reduce_single_rank)
     full = graph == 'full'                          # the collective and the optimizer recorded into the graph as well
-    opt = FlatAdam(bucket, lr=1e-3, capturable=full)
+    opt = FlatAdam(bucket, lr=1e-3, capturable=full or graph == 'capturable')
     amp = torch.autocast('cuda', dtype=torch.bfloat16)
 
     def compute():
@@ -87,7 +87,7 @@ def _train(rank, world, graph, reduce_single_rank=False):
         opt.exp_avg.zero_(); opt.exp_avg_sq.zero_(); opt.t = 0
         assert opt.t == 0
     else:
-        step = StepGraph(compute) if graph is True else compute
+        step = StepGraph(compute) if graph in (True, 'capturable') else compute
     for it in range(STEPS):
         step()
         if full:
@@ -100,7 +100,7 @@ def _train(rank, world, graph, reduce_single_rank=False):
         bucket.all_reduce_mean()
         if it == 0:
             first_grad = bucket.flat.detach().cpu().clone()
-        if it == 2 and graph == 'sched':
+        if it == 2 and graph in ('sched', 'capturable'):
             opt.lr = 5e-4
         opt.step()
         if it == 0:
@@ -189,13 +189,33 @@ def test_rccl_backend_runs_the_flat_bucket_all_reduce(graph, tmp_path, dev):
     assert torch.equal(a['grad'], ref_grad) and torch.equal(a['param1'], ref_p1) and torch.equal(a['param'], ref_param)
 
 
-def test_rccl_all_reduce_and_adam_inside_the_step_graph(tmp_path, dev):
-    """The WHOLE data-parallel step as one hipGraph: forward, backward, the RCCL all-reduce of the flat gradient and the
-    capturable FlatAdam (step count and learning rate in device memory, csrc/flat_adam.hip fgnn_flat_adam_dev) — no host work
-    between replay and update.  One-rank RCCL group (what a one-GPU box can form).  Three replays, the learning rate halved
-    before the third, must end exactly where the eager host-argument form ends."""
-    mp.spawn(_worker_rccl, args=(1, _free_port(), str(tmp_path), 'full'), nprocs=1, join=True)
-    a = torch.load(os.path.join(str(tmp_path), 'rccl_rank0.pt'))
+def test_adam_inside_the_step_graph_equals_the_eager_host_form(dev):
+    """The one-GPU step as ONE hipGraph: forward, backward and the capturable FlatAdam (step count and learning rate in device
+    memory, csrc/flat_adam.hip fgnn_flat_adam_dev) — what bench.py replays at N = 1.  Three replays, the learning rate halved
+    before the third, must end exactly where the eager host-argument form ends.  (With N > 1 the RCCL all-reduce sits between
+    backward and Adam and stays OUTSIDE the graph: captured through torch.distributed, ProcessGroupNCCL's watchdog polls the
+    work's event recorded on the capturing stream — hipErrorCapturedEvent, process abort, ~1 run in 6 on a one-rank group.)"""
+    full_param, full_grad, full_p1 = _train(0, 1, 'full')
     ref_param, ref_grad, ref_p1 = _train(0, 1, 'sched')     # eager, host-side Adam, same schedule
-    assert torch.equal(a['grad'], ref_grad) and torch.equal(a['param1'], ref_p1)
-    assert torch.equal(a['param'], ref_param)
+    assert torch.equal(full_grad, ref_grad) and torch.equal(full_p1, ref_p1)
+    assert torch.equal(full_param, ref_param)
+
+
+def _worker_rccl_capturable(rank, world, port, out):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    torch.cuda.set_device(0)
+    dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', 0))
+    flat, grad, p1 = _train(rank, world, 'capturable', reduce_single_rank=True)
+    torch.save({'param': flat, 'grad': grad, 'param1': p1}, os.path.join(out, 'rccl_cap_rank%d.pt' % rank))
+    dist.destroy_process_group()
+
+
+def test_rccl_all_reduce_then_device_state_adam_behind_graph_replays(tmp_path, dev):
+    """What an N > 1 rank does per step: replay the forward + backward graph, RCCL all-reduce of the flat gradient (eager), the
+    device-state Adam (eager) — on a one-rank RCCL group; same end state as the host-argument form without a process group."""
+    mp.spawn(_worker_rccl_capturable, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True)
+    a = torch.load(os.path.join(str(tmp_path), 'rccl_cap_rank0.pt'))
+    ref_param, ref_grad, ref_p1 = _train(0, 1, 'sched')
+    assert torch.equal(a['grad'], ref_grad) and torch.equal(a['param1'], ref_p1) and torch.equal(a['param'], ref_param)
