@@ -69,9 +69,13 @@ class iid_mapping_in(torch.nn.Module):
         B, C, N, _ = x.shape
         cout = conv.out_channels
         dt = torch.get_autocast_dtype('cuda') if torch.is_autocast_enabled() else x.dtype
-        # inputs wider than 128 channels stay staged: the fused kernel then has no registers left to keep a second row tile in
-        # flight (207 vs 194 us at 256 -> 256, 137 vs 112 at 256 -> 128; 145 vs 168 at 128 -> 256, 47 vs 58 at 64 -> 64: tools/ibench.py)
-        if dt != torch.bfloat16 or C % 64 or cout % 64 or C > _IID_FUSE_MAX_CIN or cout > 256 or conv.weight.dtype != torch.float32:
+        if dt != torch.bfloat16 or C % 64 or cout % 64 or C > 256 or cout > 256 or conv.weight.dtype != torch.float32:
+            return None
+        grad = torch.is_grad_enabled() and (conv.weight.requires_grad or x.requires_grad)
+        # with the pre-norm tensor to store (training), 256-channel inputs stay staged (tools/ibench.py, B = 4096, N = 96, fused with z /
+        # staged: 213 / 199 us at 256 -> 256, 124 / 112 at 256 -> 128; 156 / 164 at 128 -> 256, 47 / 57 at 64 -> 64); without it
+        # (inference) the one-kernel form is ahead at every width (187 / 199, 101 / 112, 116 / 164, 30 / 57)
+        if C > (_IID_FUSE_MAX_CIN if grad else 256):
             return None
         rows = x.permute(0, 2, 3, 1)
         if not rows.is_contiguous():
@@ -80,7 +84,6 @@ class iid_mapping_in(torch.nn.Module):
         if rows.dtype != torch.bfloat16:
             rows = rows.to(torch.bfloat16)
         weight = conv.weight.view(cout, C)
-        grad = torch.is_grad_enabled() and (weight.requires_grad or rows.requires_grad)
         w = weight.detach()
         b = None if conv.bias is None else conv.bias.detach().float().contiguous()
         z = torch.empty((B * N, cout), device=x.device, dtype=torch.bfloat16) if grad else None
