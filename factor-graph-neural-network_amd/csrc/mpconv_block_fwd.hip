@@ -46,6 +46,8 @@ struct KbParams {
     const float* s3;
     const float* t3;
     const uint16_t* addend;   // [B][M][nout] or NULL
+    const uint16_t* addend1;  // two more of the same layout (or NULL): the kernel adds them in f32, one rounding at the output
+    const uint16_t* addend2;
     uint16_t* y;         // [B][M][nout]
     float slope;         // LeakyReLU slope of conv1 / conv2
     int Npad, Mpad;
@@ -192,15 +194,31 @@ __global__ __launch_bounds__(KB_THREADS) void mpconv_block_fwd_kernel(const KbPa
         __syncthreads();                               // P complete; the x image is dead: it becomes a2
 
         // the addend of this wave's first conv2 node tile: asked for here, it lands under the gather
+        // (up to three addends: their pieces are summed in f32 as they arrive — 4 registers per channel tile instead of 2)
         const uint16_t* adb = p.addend ? p.addend + (int64_t)b * M * NOUT : nullptr;
-        uint2 adr[NO];
+        const uint16_t* adb1 = p.addend1 ? p.addend1 + (int64_t)b * M * NOUT : nullptr;
+        const uint16_t* adb2 = p.addend2 ? p.addend2 + (int64_t)b * M * NOUT : nullptr;
+        f32x4 adr[NO];
+        auto ad_fetch = [&](int m0) {
 #pragma unroll
-        for (int q = 0; q < NO; ++q) adr[q] = make_uint2(0, 0);
-        if (adb && (wave >> 2) * 16 + li < M) {
-            const uint2* ap = reinterpret_cast<const uint2*>(adb + (int64_t)((wave >> 2) * 16 + li) * NOUT + cbase);
+            for (int q = 0; q < NO; ++q) adr[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            const int64_t off = (int64_t)m0 * NOUT + cbase;
+            const uint16_t* src[3] = {adb, adb1, adb2};
 #pragma unroll
-            for (int q = 0; q < NO; ++q) adr[q] = ap[q];
-        }
+            for (int a = 0; a < 3; ++a)
+                if (src[a]) {
+                    const uint2* ap = reinterpret_cast<const uint2*>(src[a] + off);
+#pragma unroll
+                    for (int q = 0; q < NO; ++q) {
+                        const uint2 w = ap[q];
+                        adr[q][0] += __uint_as_float(w.x << 16); adr[q][1] += __uint_as_float(w.x & 0xffff0000u);
+                        adr[q][2] += __uint_as_float(w.y << 16); adr[q][3] += __uint_as_float(w.y & 0xffff0000u);
+                    }
+                }
+        };
+#pragma unroll
+        for (int q = 0; q < NO; ++q) adr[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (adb && (wave >> 2) * 16 + li < M) ad_fetch((wave >> 2) * 16 + li);
         // ---- gather + edge-type contraction + max, two destinations in flight per wave; a2 = ReLU(BN2(z)) -> LDS ----
         {
             const unsigned* et_w = reinterpret_cast<const unsigned*>(et_s);
@@ -251,14 +269,10 @@ __global__ __launch_bounds__(KB_THREADS) void mpconv_block_fwd_kernel(const KbPa
                 const kb_bf16x8 b0 = __builtin_bit_cast(kb_bf16x8, *reinterpret_cast<const uint4*>(bp));
                 const kb_bf16x8 b1 = __builtin_bit_cast(kb_bf16x8, *reinterpret_cast<const uint4*>(bp + 32));
                 const int m = mt * 16 + li;
-                uint2 acur[NO];
+                f32x4 acur[NO];
 #pragma unroll
                 for (int q = 0; q < NO; ++q) acur[q] = adr[q];
-                if (adb && mt + 2 < mtile && m + 32 < M) {                // the next node tile's addend travels under this one's products
-                    const uint2* ap = reinterpret_cast<const uint2*>(adb + (int64_t)(m + 32) * NOUT + cbase);
-#pragma unroll
-                    for (int q = 0; q < NO; ++q) adr[q] = ap[q];
-                }
+                if (adb && mt + 2 < mtile && m + 32 < M) ad_fetch(m + 32);        // the next node tile's addends travel under this one's products
                 f32x4 acc[NO];
 #pragma unroll
                 for (int q = 0; q < NO; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aW2[q][0], b0, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
@@ -271,10 +285,7 @@ __global__ __launch_bounds__(KB_THREADS) void mpconv_block_fwd_kernel(const KbPa
                         float v[4];
 #pragma unroll
                         for (int r = 0; r < 4; ++r) { const float u = fmaf(acc[q][r], c3s[q][r], c3t[q][r]); v[r] = u > 0.f ? u : u * p.slope; }
-                        if (adb) {
-                            v[0] += __uint_as_float(acur[q].x << 16); v[1] += __uint_as_float(acur[q].x & 0xffff0000u);
-                            v[2] += __uint_as_float(acur[q].y << 16); v[3] += __uint_as_float(acur[q].y & 0xffff0000u);
-                        }
+                        if (adb) { v[0] += acur[q][0]; v[1] += acur[q][1]; v[2] += acur[q][2]; v[3] += acur[q][3]; }
                         ow[2 * q] = kb_pack2(v[0], v[1]);
                         ow[2 * q + 1] = kb_pack2(v[2], v[3]);
                     }
@@ -301,7 +312,7 @@ extern "C" int fgnn_mpconv_block_forward(const fgnn_mpconv_desc* d, const void* 
                                          const void* etype, const float* W1, const float* s1, const float* t1,
                                          const float* filters, const float* s2, const float* t2, const float* W2,
                                          const float* s3, const float* t3, float slope, int nin, int nout,
-                                         const void* addend, void* y, fgnn_stream_t stream) {
+                                         const void* addend, const void* addend1, const void* addend2, void* y, fgnn_stream_t stream) {
     if (!d || !x || !nn_idx || !etype || !W1 || !s1 || !t1 || !filters || !s2 || !t2 || !W2 || !s3 || !t3 || !y)
         FGNN_FAIL(FGNN_EINVAL, "mpconv_block_forward: null pointer");
     const bool ok = d->dtype == FGNN_BF16 && d->ext == FGNN_EXT_NONE && d->agg == FGNN_AGG_MAX && d->net == 4 &&
@@ -311,14 +322,16 @@ extern "C" int fgnn_mpconv_block_forward(const fgnn_mpconv_desc* d, const void* 
                     d->x_sc == 1 && d->x_sn == nin && d->x_sb % 8 == 0 &&
                     d->y_sc == 1 && d->y_sm == nout && d->y_sb == (int64_t)d->M * nout &&
                     d->et_se == 1 && d->et_sk == 4 && d->et_sm == 4 * d->k && d->et_sb % 4 == 0 &&
-                    !((uintptr_t)x & 15) && !((uintptr_t)etype & 7) && !((uintptr_t)y & 15) && !((uintptr_t)addend & 7);
+                    !((uintptr_t)x & 15) && !((uintptr_t)etype & 7) && !((uintptr_t)y & 15) &&
+                    !(((uintptr_t)addend | (uintptr_t)addend1 | (uintptr_t)addend2) & 7) && (addend || (!addend1 && !addend2));
     if (!ok) FGNN_FAIL(FGNN_EUNSUPPORTED, "mpconv_block_forward: outside the fused block's family");
     if (d->B == 0) return FGNN_OK;
     KbParams p;
     p.d = *d;
     p.x = (const uint16_t*)x; p.idx = nn_idx; p.et = (const uint16_t*)etype;
     p.W1 = W1; p.s1 = s1; p.t1 = t1; p.F = filters; p.s2 = s2; p.t2 = t2; p.W2 = W2; p.s3 = s3; p.t3 = t3;
-    p.addend = (const uint16_t*)addend; p.y = (uint16_t*)y; p.slope = slope;
+    p.addend = (const uint16_t*)addend; p.addend1 = (const uint16_t*)addend1; p.addend2 = (const uint16_t*)addend2;
+    p.y = (uint16_t*)y; p.slope = slope;
     p.Npad = fgnn_round_up(d->N, 16);
     p.Mpad = fgnn_round_up(d->M, 16);
     const int img0 = p.Npad * (nin + 8) > p.Mpad * KB_XSB ? p.Npad * (nin + 8) : p.Mpad * KB_XSB;   // x, later a2
@@ -369,6 +382,8 @@ struct KfParams {
     const float* W2;     // [nout][64]
     const float* s3; const float* t3;
     const uint16_t* addend;
+    const uint16_t* addend1;
+    const uint16_t* addend2;
     uint16_t* y;         // [B][M][nout]
     float slope;
     int nin, nout, Mpad;
@@ -420,7 +435,8 @@ __global__ __launch_bounds__(512) void mpconv_block_fanout_kernel(const KfParams
         pw[64 + lane] = c2t;
         const uint16_t* eb = p.et + (int64_t)b * d.et_sb;
         uint16_t* yb = p.y + (int64_t)b * M * nout;
-        const uint16_t* adb = p.addend ? p.addend + (int64_t)b * M * nout : nullptr;
+        const uint16_t* adbs[3] = {p.addend ? p.addend + (int64_t)b * M * nout : nullptr, p.addend1 ? p.addend1 + (int64_t)b * M * nout : nullptr,
+                                   p.addend2 ? p.addend2 + (int64_t)b * M * nout : nullptr};
         for (int mt = 0; mt < mtile; ++mt) {
             const int m = mt * 16 + li;
             const float e = m < M ? __uint_as_float((unsigned)eb[(int64_t)m * d.et_sm] << 16) : 0.f;
@@ -456,12 +472,14 @@ __global__ __launch_bounds__(512) void mpconv_block_fanout_kernel(const KfParams
                         for (int r = 0; r < 4; ++r) { const float u = fmaf(acc[qt][r], s3[r], t3[r]); v[4 * qt + r] = u > 0.f ? u : u * p.slope; }
                     }
                     const int64_t off = (int64_t)m * nout + ch;
-                    if (adb) {
-                        const uint4 a0 = *reinterpret_cast<const uint4*>(adb + off), a1 = *reinterpret_cast<const uint4*>(adb + off + 8);
-                        const unsigned aw[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
 #pragma unroll
-                        for (int u = 0; u < 8; ++u) { v[2 * u] += __uint_as_float(aw[u] << 16); v[2 * u + 1] += __uint_as_float(aw[u] & 0xffff0000u); }
-                    }
+                    for (int a = 0; a < 3; ++a)
+                        if (adbs[a]) {
+                            const uint4 a0 = *reinterpret_cast<const uint4*>(adbs[a] + off), a1 = *reinterpret_cast<const uint4*>(adbs[a] + off + 8);
+                            const unsigned aw[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+                            for (int u = 0; u < 8; ++u) { v[2 * u] += __uint_as_float(aw[u] << 16); v[2 * u + 1] += __uint_as_float(aw[u] & 0xffff0000u); }
+                        }
                     *reinterpret_cast<uint4*>(yb + off) = make_uint4(kb_pack2(v[0], v[1]), kb_pack2(v[2], v[3]), kb_pack2(v[4], v[5]), kb_pack2(v[6], v[7]));
                     *reinterpret_cast<uint4*>(yb + off + 8) = make_uint4(kb_pack2(v[8], v[9]), kb_pack2(v[10], v[11]), kb_pack2(v[12], v[13]), kb_pack2(v[14], v[15]));
                 }
@@ -599,14 +617,17 @@ __global__ __launch_bounds__(512) void mpconv_block_fanin_kernel(const KfParams 
                 if (q < NQ) acc3[q] = fmaf(zb, __uint_as_float((unsigned)wr[64 * q] << 16), acc3[q]);
         }
         uint16_t* yb = p.y + (int64_t)b * nout;
-        const uint16_t* adb = p.addend ? p.addend + (int64_t)b * nout : nullptr;
+        const uint16_t* adbs[3] = {p.addend ? p.addend + (int64_t)b * nout : nullptr, p.addend1 ? p.addend1 + (int64_t)b * nout : nullptr,
+                                   p.addend2 ? p.addend2 + (int64_t)b * nout : nullptr};
 #pragma unroll
         for (int q = 0; q < 4; ++q)
             if (q < NQ) {
                 const int oo = 64 * q + lane;
                 float v = fmaf(acc3[q], p.s3[oo], p.t3[oo]);
                 v = v > 0.f ? v : v * p.slope;
-                if (adb) v += __uint_as_float((unsigned)adb[oo] << 16);
+#pragma unroll
+                for (int a = 0; a < 3; ++a)
+                    if (adbs[a]) v += __uint_as_float((unsigned)adbs[a][oo] << 16);
                 const __bf16 h = (__bf16)v;
                 yb[oo] = __builtin_bit_cast(uint16_t, h);
             }
@@ -619,20 +640,20 @@ extern "C" int fgnn_mpconv_block_forward_fanout(const fgnn_mpconv_desc* d, const
                                                 const float* W1, const float* s1, const float* t1, const float* filters,
                                                 const float* s2, const float* t2, const float* W2, const float* s3,
                                                 const float* t3, float slope, int nin, int nout, const void* addend,
-                                                void* y, fgnn_stream_t stream) {
+                                                const void* addend1, const void* addend2, void* y, fgnn_stream_t stream) {
     if (!d || !x || !etype || !W1 || !s1 || !t1 || !filters || !s2 || !t2 || !W2 || !s3 || !t3 || !y)
         FGNN_FAIL(FGNN_EINVAL, "mpconv_block_forward_fanout: null pointer");
     const bool ok = d->dtype == FGNN_BF16 && d->ext == FGNN_EXT_NONE && d->net == 1 && d->nin == 64 && d->nou == 64 &&
                     d->N == 1 && d->k == 1 && d->M >= 1 && d->M <= 256 &&
                     (nin == 64 || nin == 128 || nin == 256) && (nout == 64 || nout == 128 || nout == 256) &&
                     d->x_sc == 1 && d->y_sc == 1 && d->y_sm == nout && d->y_sb == (int64_t)d->M * nout &&
-                    !((uintptr_t)y & 15) && !((uintptr_t)addend & 15);
+                    !((uintptr_t)y & 15) && !(((uintptr_t)addend | (uintptr_t)addend1 | (uintptr_t)addend2) & 15);
     if (!ok) FGNN_FAIL(FGNN_EUNSUPPORTED, "mpconv_block_forward_fanout: outside the fused block's family");
     if (d->B == 0) return FGNN_OK;
     KfParams p;
     p.d = *d;
     p.x = (const uint16_t*)x; p.et = (const uint16_t*)etype; p.W1 = W1; p.s1 = s1; p.t1 = t1; p.F = filters;
-    p.s2 = s2; p.t2 = t2; p.W2 = W2; p.s3 = s3; p.t3 = t3; p.addend = (const uint16_t*)addend; p.y = (uint16_t*)y;
+    p.s2 = s2; p.t2 = t2; p.W2 = W2; p.s3 = s3; p.t3 = t3; p.addend = (const uint16_t*)addend; p.addend1 = (const uint16_t*)addend1; p.addend2 = (const uint16_t*)addend2; p.y = (uint16_t*)y;
     p.slope = slope; p.nin = nin; p.nout = nout; p.Mpad = fgnn_round_up(d->M, 16);
     const int lds = nin * 64 * 4 + 64 * 64 * 4 + nout * KB_XSB * 2 + 8 * 128 * 4;
     void* fn = nin == 64 ? (void*)mpconv_block_fanout_kernel<1> : nin == 128 ? (void*)mpconv_block_fanout_kernel<2>
@@ -657,7 +678,7 @@ extern "C" int fgnn_mpconv_block_forward_fanin(const fgnn_mpconv_desc* d, const 
                                                const float* W1, const float* s1, const float* t1, const float* filters,
                                                const float* s2, const float* t2, const float* W2, const float* s3,
                                                const float* t3, float slope, int nin, int nout, const void* addend,
-                                               void* y, fgnn_stream_t stream) {
+                                               const void* addend1, const void* addend2, void* y, fgnn_stream_t stream) {
     if (!d || !x || !etype || !W1 || !s1 || !t1 || !filters || !s2 || !t2 || !W2 || !s3 || !t3 || !y)
         FGNN_FAIL(FGNN_EINVAL, "mpconv_block_forward_fanin: null pointer");
     const bool ok = d->dtype == FGNN_BF16 && d->ext == FGNN_EXT_NONE && d->agg == FGNN_AGG_MAX && d->net == 1 &&
@@ -669,7 +690,7 @@ extern "C" int fgnn_mpconv_block_forward_fanin(const fgnn_mpconv_desc* d, const 
     KfParams p;
     p.d = *d;
     p.x = (const uint16_t*)x; p.et = (const uint16_t*)etype; p.W1 = W1; p.s1 = s1; p.t1 = t1; p.F = filters;
-    p.s2 = s2; p.t2 = t2; p.W2 = W2; p.s3 = s3; p.t3 = t3; p.addend = (const uint16_t*)addend; p.y = (uint16_t*)y;
+    p.s2 = s2; p.t2 = t2; p.W2 = W2; p.s3 = s3; p.t3 = t3; p.addend = (const uint16_t*)addend; p.addend1 = (const uint16_t*)addend1; p.addend2 = (const uint16_t*)addend2; p.y = (uint16_t*)y;
     p.slope = slope; p.nin = nin; p.nout = nout; p.Mpad = 16;
     const int lds = 64 * (nin + 8) * 2 + 64 * nout * 2 + 8 * 64 * 4;
     void* fn = nin == 64 ? (void*)mpconv_block_fanin_kernel<1> : nin == 128 ? (void*)mpconv_block_fanin_kernel<2>

@@ -106,11 +106,11 @@ def lib():
     L.fgnn_linear_forward_partials.restype = ctypes.c_int
     L.fgnn_linear_forward_partials.argtypes = [i64, i32, i32]
     L.fgnn_mpconv_block_forward.restype = ctypes.c_int
-    L.fgnn_mpconv_block_forward.argtypes = [dp] + [vp] * 12 + [f32, i32, i32, vp, vp, vp]
+    L.fgnn_mpconv_block_forward.argtypes = [dp] + [vp] * 12 + [f32, i32, i32, vp, vp, vp, vp, vp]
     L.fgnn_mpconv_block_forward_fanout.restype = ctypes.c_int
-    L.fgnn_mpconv_block_forward_fanout.argtypes = [dp] + [vp] * 11 + [f32, i32, i32, vp, vp, vp]
+    L.fgnn_mpconv_block_forward_fanout.argtypes = [dp] + [vp] * 11 + [f32, i32, i32, vp, vp, vp, vp, vp]
     L.fgnn_mpconv_block_forward_fanin.restype = ctypes.c_int
-    L.fgnn_mpconv_block_forward_fanin.argtypes = [dp] + [vp] * 11 + [f32, i32, i32, vp, vp, vp]
+    L.fgnn_mpconv_block_forward_fanin.argtypes = [dp] + [vp] * 11 + [f32, i32, i32, vp, vp, vp, vp, vp]
     L.fgnn_factor_layer_param_count.restype = ctypes.c_int64
     L.fgnn_factor_layer_param_count.argtypes = []
     L.fgnn_factor_layer_forward.restype = ctypes.c_int

@@ -443,10 +443,13 @@ class mp_conv_residual(base_mp_nn):
         et = etype.permute(0, 2, 3, 1)                                   # [B, M, k, net]
         if not xr.is_contiguous() or not (et.is_contiguous() or (etype.stride(0) == 0 and et[0].is_contiguous())):
             return None
-        if addend is not None:
-            ar = addend.permute(0, 2, 3, 1)
-            if addend.dtype != x.dtype or not ar.is_contiguous():
+        adds = as_addends(addend)
+        if len(adds) > 3:
+            return None
+        for a in adds:
+            if a.dtype != x.dtype or not a.permute(0, 2, 3, 1).is_contiguous():
                 return None
+        a0, a1, a2 = (adds + [None, None, None])[:3]
         W1, s1, t1, F, s2, t2, W2, s3, t3 = self.folded_for_inference(x.device)
         y = torch.empty((B, M, 1, nout), device=x.device, dtype=x.dtype).permute(0, 3, 1, 2)
         d = _hip.make_desc(x, nn_idx, etype, 64, mp.nedge_types, _hip.EXT_NONE, _hip.AGG_MAX, True, y)
@@ -455,7 +458,7 @@ class mp_conv_residual(base_mp_nn):
         if fanin:
             rc = _hip.lib().fgnn_mpconv_block_forward_fanin(ctypes.byref(d), P(x), P(etype), P(W1), P(s1), P(t1), P(F),
                                                             P(s2), P(t2), P(W2), P(s3), P(t3), float(bn1.slope), nin, nout,
-                                                            P(addend), P(y), _hip.stream_ptr())
+                                                            P(a0), P(a1), P(a2), P(y), _hip.stream_ptr())
             if rc == _hip.EUNSUPPORTED:
                 return None
             _hip.check(rc)
@@ -463,15 +466,14 @@ class mp_conv_residual(base_mp_nn):
         if fanout:
             rc = _hip.lib().fgnn_mpconv_block_forward_fanout(ctypes.byref(d), P(x), P(etype), P(W1), P(s1), P(t1), P(F),
                                                              P(s2), P(t2), P(W2), P(s3), P(t3), float(bn1.slope), nin, nout,
-                                                             P(addend), P(y), _hip.stream_ptr())
+                                                             P(a0), P(a1), P(a2), P(y), _hip.stream_ptr())
             if rc == _hip.EUNSUPPORTED:
                 return None
             _hip.check(rc)
             return y
         rc = _hip.lib().fgnn_mpconv_block_forward(ctypes.byref(d), P(x), P(nn_idx), P(etype), P(W1), P(s1), P(t1), P(F),
-                                                  P(s2), P(t2), P(W2), P(s3), P(t3), float(bn1.slope), nin, nout, P(addend),
-                                                  P(y),
-                                                  _hip.stream_ptr())
+                                                  P(s2), P(t2), P(W2), P(s3), P(t3), float(bn1.slope), nin, nout, P(a0), P(a1),
+                                                  P(a2), P(y), _hip.stream_ptr())
         if rc == _hip.EUNSUPPORTED:
             return None
         _hip.check(rc)
@@ -487,8 +489,10 @@ class mp_conv_residual(base_mp_nn):
             addend = addend()                                            # the one-kernel block needs it up front
         if isinstance(addend, (list, tuple)):
             addend = as_addends(addend)
-            if not staged:                                               # ... and takes one addend
-                addend = ops.add_n(addend) if addend else None
+            if not staged:                                               # ... and takes up to three (a fourth joins the third first)
+                if len(addend) > 3:
+                    addend = addend[:2] + [ops.add_n(addend[2:])]
+                addend = addend if addend else None
         if not staged:
             y = self._fused_eval(node_feature, nn_idx, etype, addend)
             if y is not None:

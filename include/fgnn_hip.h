@@ -253,17 +253,18 @@ int fgnn_bn_backward(const void* x, const void* gy, void* gx, int64_t R, int32_t
 /*
  * Inference forward of a whole mp_conv_residual block (mp_nn_residual.py:39-56) in one kernel:
  *   a1 = LeakyReLU(s1 * (x W1^T) + t1)  ->  z = max_j sum_e etype * (a1 filters)[idx]  ->  a2 = ReLU(s2 * z + t2)
- *   y  = LeakyReLU(s3 * (a2 W2^T) + t3) (+ addend)
+ *   y  = LeakyReLU(s3 * (a2 W2^T) + t3) (+ addend + addend1 + addend2)
  * with every eval-mode BatchNorm and bias folded into the per-channel float32 affines (s, t).  d describes the inner
  * message operator (nin = nou = 64, net = 4, max, NO_EXTENSION, bf16, edge-type-fastest etype, k in {3, 6}) but its
  * x / y strides those of the BLOCK's channel-fastest input x [B,N,nin] and output y [B,M,nout], nin / nout in
  * {64,128,256}; W1 [64][nin] and W2 [nout][64] are float32 conv weights [out][in]; s1,t1,s2,t2 are [64], s3,t3
- * [nout]; addend (or NULL) has y's layout.  FGNN_EUNSUPPORTED outside that family.
+ * [nout]; addend, addend1, addend2 (each or NULL; addend first) have y's layout and are summed in f32 — the layer's running
+ * sum, residual and skip terms (factor_mpnn_sp.py:139-168) without a separate sum pass.  FGNN_EUNSUPPORTED outside that family.
  */
 int fgnn_mpconv_block_forward(const fgnn_mpconv_desc* d, const void* x, const int64_t* nn_idx, const void* etype,
                               const float* W1, const float* s1, const float* t1, const float* filters,
                               const float* s2, const float* t2, const float* W2, const float* s3, const float* t3,
-                              float slope, int32_t nin, int32_t nout, const void* addend, void* y,
+                              float slope, int32_t nin, int32_t nout, const void* addend, const void* addend1, const void* addend2, void* y,
                               fgnn_stream_t stream);
 
 /* The same block around the hyper-factor FAN-OUT call: inner operator with N = 1 source, k = 1, one edge type
@@ -271,14 +272,14 @@ int fgnn_mpconv_block_forward(const fgnn_mpconv_desc* d, const void* x, const in
 int fgnn_mpconv_block_forward_fanout(const fgnn_mpconv_desc* d, const void* x, const void* etype, const float* W1,
                                      const float* s1, const float* t1, const float* filters, const float* s2,
                                      const float* t2, const float* W2, const float* s3, const float* t3, float slope,
-                                     int32_t nin, int32_t nout, const void* addend, void* y, fgnn_stream_t stream);
+                                     int32_t nin, int32_t nout, const void* addend, const void* addend1, const void* addend2, void* y, fgnn_stream_t stream);
 /* Fan-in form (variables -> one factor listening to ALL N nodes in order): d has M = 1, k = N, net = 1, nin = nou = 64
  * and the neighbour list must be the identity (the kernel does not read nn_idx; the caller checks); etype [B][k]
  * (et_sb / et_sk strides, et_sb may be 0); x [B][N][nin] channel-fastest; y / addend [B][nout]. */
 int fgnn_mpconv_block_forward_fanin(const fgnn_mpconv_desc* d, const void* x, const void* etype, const float* W1,
                                      const float* s1, const float* t1, const float* filters, const float* s2,
                                      const float* t2, const float* W2, const float* s3, const float* t3, float slope,
-                                     int32_t nin, int32_t nout, const void* addend, void* y, fgnn_stream_t stream);
+                                     int32_t nin, int32_t nout, const void* addend, const void* addend1, const void* addend2, void* y, fgnn_stream_t stream);
 
 /*
  * §8f-3 — ONE WHOLE 64 -> 64 `FactorNN` layer of the LDPC model in one kernel, inference
