@@ -11,8 +11,15 @@ import torch
 
 
 class StepGraph:
-    def __init__(self, fn, warmup=2):
-        """``fn()`` is run ``warmup`` times (allocator / workspace / autotune warm-up), then captured — both on ONE side
+    def __init__(self, fn, warmup=2, static_params=False):
+        """``static_params=True`` (inference of a frozen model): the parameter-derived tensors — folded BatchNorm affines, bf16
+        weight copies — are the ones the warm-up runs left in their caches, and the graph holds no kernels that rebuild them
+        (the LDPC inference forward otherwise replays ~260 tiny fold / cast / copy kernels per step beside ~60 real ones).
+        Replays then do NOT see parameter changes made after the capture: build a new StepGraph after loading other weights.
+        Default (False): the caches are invalidated before the capture, so the refresh kernels are recorded and every replay
+        derives them from the parameters as they are at that moment (what a training step needs).
+
+        ``fn()`` is run ``warmup`` times (allocator / workspace / autotune warm-up), then captured — both on ONE side
         stream.  Autograd runs a leaf's gradient accumulation on the stream the leaf was first used on; if the warm-up ran
         on another stream than the capture, parameters whose gradients come through autograd (plain torch modules such as
         the edge models of train_syn_*.py, not this package's gradient-sink kernels) would be accumulated on a branch of
@@ -28,13 +35,17 @@ class StepGraph:
         # cached low-precision weight copies are refreshed in place where they are stale: make them stale now, so the
         # refresh kernels are captured and every replay casts the parameters as they are at that moment
         from .mpnn import pointwise
-        pointwise.invalidate_casts()
+        self.static_params = bool(static_params)
+        if not self.static_params:
+            pointwise.invalidate_casts()
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph, stream=self.stream):
             fn()
 
     def replay(self):
         self.graph.replay()
+        if self.static_params:
+            return
         from .mpnn import pointwise
         pointwise.note_state_change()       # the replayed kernels may have changed parameters / BatchNorm buffers
         pointwise.invalidate_casts()        # ... and with them the low-precision weight copies eager code reads next
