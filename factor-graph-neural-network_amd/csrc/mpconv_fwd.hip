@@ -431,3 +431,23 @@ extern "C" int fgnn_mpconv_forward_stats(const fgnn_mpconv_desc* d, const void* 
     if (rc == 0) FGNN_FAIL(FGNN_EUNSUPPORTED, "mpconv_forward_stats: this shape has no statistics epilogue");
     return rc;
 }
+
+
+// fgnn_mpconv_forward with up to three ADDENDS of y's layout (the caller's running sum, residual, skip term: factor_mpnn_sp.py:139-168
+// adds them to the operator's activated output) folded into the kernel's epilogue where the kernel family supports it — the
+// third-generation bf16 parity kernel in its inference mode (post_scale / post_shift + ReLU).  Returns 1 when the addends were
+// added by the kernel, 0 when y was computed WITHOUT them (the caller adds them: one more pass), < 0 on error.
+void fgnn_ws_set_pending_addends(const void* a0, const void* a1, const void* a2);
+int fgnn_ws_pending_addends_taken(void);
+extern "C" int fgnn_mpconv_forward_addends(const fgnn_mpconv_desc* d, const void* x, const int64_t* nn_idx, const void* etype,
+                                           const float* filters, const float* bias, const float* post_scale,
+                                           const float* post_shift, const void* addend0, const void* addend1, const void* addend2,
+                                           void* y, fgnn_stream_t stream) {
+    if (!addend0 && (addend1 || addend2)) FGNN_FAIL(FGNN_EINVAL, "mpconv_forward_addends: addend0 first");
+    fgnn_ws_set_pending_addends(addend0, addend1, addend2);
+    const int rc = fgnn_mpconv_forward(d, x, nn_idx, etype, filters, bias, post_scale, post_shift, y, nullptr, stream);
+    const int taken = fgnn_ws_pending_addends_taken();
+    fgnn_ws_set_pending_addends(nullptr, nullptr, nullptr);
+    if (rc != FGNN_OK) return rc;
+    return (addend0 && taken) ? 1 : 0;
+}

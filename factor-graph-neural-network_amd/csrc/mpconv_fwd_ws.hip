@@ -54,6 +54,7 @@ struct WsParams {
     unsigned short* y;
     uint8_t* argmax;
     float* stats;
+    const unsigned short* add[3];                 // MODE AFFINE_RELU only: up to three tensors of y's layout added after the activation (or NULL)
     int B, N, M, Npad, relu;
     int y_ld, w_ld, st_ld;                        // row strides (elements) of y / argmax, of W, of a statistics partial row
     long long x_sb, et_sb, y_sb;                  // elements
@@ -373,6 +374,12 @@ __global__ __launch_bounds__(WS_THREADS) void mpconv_fwd_ws_kernel(const WsParam
                 if ((cw + WS_NCONS * g) * 4 < M) {                        // wave-uniform
                     uint4 pa[KC], pb[KC];
                     uint2 ev[KC];
+                    uint2 av[3] = {make_uint2(0, 0), make_uint2(0, 0), make_uint2(0, 0)};
+                    if constexpr (MODE == WS_MODE_AFFINE_RELU) {          // the caller's addends: requested first, consumed last
+#pragma unroll
+                        for (int a = 0; a < 3; ++a)
+                            if (p.add[a] && valid[g]) av[a] = *reinterpret_cast<const uint2*>(p.add[a] + b * p.y_sb + yoff[g]);
+                    }
 #pragma unroll
                     for (int j = 0; j < KC; ++j) {
                         const unsigned char* pr = pim + addr[g][j];
@@ -437,6 +444,14 @@ __global__ __launch_bounds__(WS_THREADS) void mpconv_fwd_ws_kernel(const WsParam
                         if (MODE >= WS_MODE_AFFINE_RELU) r = fmaf(r, c_scale[c], c_shift[c]);
                         if (MODE == WS_MODE_AFFINE_RELU || (MODE == WS_MODE_GENERIC && p.relu)) r = fmaxf(r, 0.f);
                         res[c] = r;
+                    }
+                    if constexpr (MODE == WS_MODE_AFFINE_RELU) {
+#pragma unroll
+                        for (int a = 0; a < 3; ++a)
+                            if (p.add[a]) {
+                                res[0] += __uint_as_float(av[a].x << 16); res[1] += __uint_as_float(av[a].x & 0xffff0000u);
+                                res[2] += __uint_as_float(av[a].y << 16); res[3] += __uint_as_float(av[a].y & 0xffff0000u);
+                            }
                     }
                     const uint2 packed = make_uint2(ws_pack(res[0], res[1]), ws_pack(res[2], res[3]));
                     if (MODE == WS_MODE_TRAIN_STATS && valid[g]) {        // of the values as stored
@@ -508,6 +523,15 @@ static void* ws_pick_mode(int mode) {
 
 // Same contract as fgnn_mpconv_forward_sg (mpconv_fwd_sg.hip), which calls this first: 1 = launched, 0 = shape outside this
 // kernel's family (the second-generation kernel takes it), < 0 = error.  grid_out: the number of statistics partial rows.
+// Addends of the NEXT inference-mode launch on this thread (fgnn_mpconv_forward_addends sets them around its call of the ordinary
+// entry point; `taken` tells it whether this kernel consumed them or the caller has to add them itself).
+static thread_local const void* ws_pending_add[3] = {nullptr, nullptr, nullptr};
+static thread_local int ws_pending_taken = 0;
+void fgnn_ws_set_pending_addends(const void* a0, const void* a1, const void* a2) {
+    ws_pending_add[0] = a0; ws_pending_add[1] = a1; ws_pending_add[2] = a2; ws_pending_taken = 0;
+}
+int fgnn_ws_pending_addends_taken(void) { return ws_pending_taken; }
+
 int fgnn_mpconv_forward_ws(const fgnn_mpconv_desc* d, const void* x, const int64_t* nn_idx, const void* etype,
                            const float* filters, const float* bias, const float* post_scale, const float* post_shift,
                            void* y, uint8_t* argmax, fgnn_stream_t stream, float* stats, int* plan_grid, int mode, int split) {
@@ -538,6 +562,15 @@ int fgnn_mpconv_forward_ws(const fgnn_mpconv_desc* d, const void* x, const int64
     p.B = d->B; p.N = d->N; p.M = d->M; p.Npad = Npad; p.relu = d->relu;
     p.x_sb = d->x_sb; p.et_sb = d->et_sb; p.y_sb = d->y_sb;
     p.y_ld = d->nou; p.w_ld = d->nou * 4; p.st_ld = d->nou;
+    for (int a = 0; a < 3; ++a) p.add[a] = nullptr;
+    if (mode == WS_MODE_AFFINE_RELU && ws_pending_add[0]) {
+        bool ok = true;
+        for (int a = 0; a < 3; ++a) ok = ok && !(((uintptr_t)ws_pending_add[a]) & 7);
+        if (ok) {
+            for (int a = 0; a < 3; ++a) p.add[a] = static_cast<const unsigned short*>(ws_pending_add[a]);
+            ws_pending_taken = 1;
+        }
+    }
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "hipFuncSetAttribute(%d B LDS): %s", lds, hipGetErrorString(e));
     fgnn_note_kernel(split ? "mpconv_fwd_ws_kernel<%d, %d, %d, %d> x2" : "mpconv_fwd_ws_kernel<%d, %d, %d, %d>", d->nin, KC, mode, xbuf);
@@ -568,6 +601,8 @@ int fgnn_mpconv_forward_ws(const fgnn_mpconv_desc* d, const void* x, const int64
 #endif
     if (split) {                                                      // the upper 64 output channels of a 64 -> 128 call
         p.W += 256; p.y += 64;
+        for (int a = 0; a < 3; ++a)
+            if (p.add[a]) p.add[a] += 64;
         if (p.bias) p.bias += 64;
         if (p.pscale) { p.pscale += 64; p.pshift += 64; }
         if (p.argmax) p.argmax += 64;

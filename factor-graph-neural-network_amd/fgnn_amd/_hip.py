@@ -27,7 +27,7 @@ EXPORTS = ('fgnn_mpconv_forward', 'fgnn_mpconv_backward', 'fgnn_mpconv_forward_l
            'fgnn_instnorm_forward', 'fgnn_instnorm_backward', 'fgnn_bn_supported', 'fgnn_bn_workspace_bytes',
            'fgnn_bn_stats', 'fgnn_bn_finalize', 'fgnn_bn_apply', 'fgnn_bn_backward',
            'fgnn_linear_forward', 'fgnn_linear_forward_partials', 'fgnn_linear_instnorm_forward', 'fgnn_sum_n', 'fgnn_flat_adam', 'fgnn_flat_adam_dev', 'fgnn_edge_mlp_forward', 'fgnn_edge_mlp_workspace_bytes', 'fgnn_edge_mlp_backward', 'fgnn_ldpc_encode', 'fgnn_ldpc_channel_features', 'fgnn_ldpc_channel_features_rng', 'fgnn_ldpc_decode', 'fgnn_mpconv_block_forward', 'fgnn_mpconv_block_forward_fanout', 'fgnn_mpconv_block_forward_fanin', 'fgnn_factor_layer_forward', 'fgnn_factor_layer_param_count', 'fgnn_mpconv_forward_stats', 'fgnn_mpconv_forward_stats_partials', 'fgnn_block_tail_partials', 'fgnn_block_tail_stats', 'fgnn_block_tail_apply', 'fgnn_block_tail_backward', 'fgnn_block_tail_backward_partials', 'fgnn_bn_finalize_shifted', 'fgnn_bn_backward_partials', 'fgnn_block_head_backward',
-           'fgnn_mpconv_algorithmic_bytes', 'fgnn_last_error', 'fgnn_last_kernel', 'fgnn_abi_version')
+           'fgnn_mpconv_algorithmic_bytes', 'fgnn_mpconv_forward_addends', 'fgnn_last_error', 'fgnn_last_kernel', 'fgnn_abi_version')
 
 
 class MPConvDesc(ctypes.Structure):
@@ -67,6 +67,8 @@ def lib():
     vp, dp = ctypes.c_void_p, ctypes.POINTER(MPConvDesc)
     L.fgnn_mpconv_forward.restype = ctypes.c_int
     L.fgnn_mpconv_forward.argtypes = [dp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.fgnn_mpconv_forward_addends.restype = ctypes.c_int
+    L.fgnn_mpconv_forward_addends.argtypes = [dp] + [vp] * 12
     L.fgnn_mpconv_forward_stats.restype = ctypes.c_int
     L.fgnn_mpconv_forward_stats.argtypes = [dp] + [vp] * 9
     L.fgnn_mpconv_forward_stats_partials.restype = ctypes.c_int

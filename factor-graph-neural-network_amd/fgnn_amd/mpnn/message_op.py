@@ -110,14 +110,19 @@ class mp_conv_v2(base_mp_nn):
                 scale, shift = fold_batchnorm(self.bn)
             if etype.shape[0] == 1 and x.shape[0] > 1:      # shared edge weights handed over un-expanded
                 etype = etype.expand(x.shape[0], -1, -1, -1)
+            from .pointwise import as_addends
+            adds = as_addends(addend() if callable(addend) else addend)
+            # the caller's running sums ride in the kernel's epilogue (third-generation parity kernels) or join in ONE n-input pass
+            # behind it (csrc/sum_n.hip) rather than one elementwise add each
+            in_kernel = plain_relu and scale is not None and 0 < len(adds) <= 3
             y, _ = ops.mpconv_forward_raw(x, nn_idx, etype, self.filters, self.bias, self.nou,
                                           self.nedge_types, ext, agg, post_scale=scale,
-                                          post_shift=shift, relu=plain_relu)
+                                          post_shift=shift, relu=plain_relu, addends=adds if in_kernel else None)
+            if in_kernel:
+                return y
             if self.activation_fn is not None and not plain_relu:
                 y = self.activation_fn(y)
-            from .pointwise import as_addends
-            # the caller's running sums join in ONE n-input pass (csrc/sum_n.hip) rather than one elementwise add each
-            return ops.add_n([y] + as_addends(addend() if callable(addend) else addend))
+            return ops.add_n([y] + adds)
         # a training-mode BatchNorm right behind the operator takes its batch statistics from the kernel's epilogue
         z = ops.mpconv(x, nn_idx, etype, self.filters, self.bias, self.nou,
                        self.nedge_types, ext, agg, want_stats=bn_batch_stats and self.bn is not None and self.bn.training)

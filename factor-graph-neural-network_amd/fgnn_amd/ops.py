@@ -261,7 +261,7 @@ def max_in_degree(nn_idx, N):
 
 
 def mpconv_forward_raw(x, nn_idx, etype, filters, bias, nou, net, ext, agg, *,
-                       post_scale=None, post_shift=None, relu=False, want_argmax=False, want_stats=False):
+                       post_scale=None, post_shift=None, relu=False, want_argmax=False, want_stats=False, addends=None):
     """One launch of fgnn_mpconv_forward.  Returns (y, argmax-or-None).  ``want_stats``: where the shape has a
     statistics epilogue, the launch also leaves the BatchNorm batch statistics of y in the stream's workspace and
     announces them to the BatchNorm that follows (pointwise.set_pending_stats)."""
@@ -292,10 +292,28 @@ def mpconv_forward_raw(x, nn_idx, etype, filters, bias, nou, net, ext, agg, *,
         from .mpnn import pointwise
         pointwise.set_pending_stats(y.permute(0, 2, 3, 1).reshape(x.shape[0] * M, nou), npart)
         return y, amax
+    if addends:
+        # inference: the caller's running sums ride in the kernel's epilogue where it has one for them (``addends``: up to three
+        # tensors of y's layout and dtype); otherwise they join in ONE n-input pass behind it (csrc/sum_n.hip)
+        fits = (amax is None and post_scale is not None and relu and len(addends) <= 3 and
+                all(a.dtype == y.dtype and a.shape == y.shape and a.stride() == y.stride() for a in addends))
+        took = []
+        if fits:
+            ap = [_hip._ptr(a) for a in addends] + [None] * (3 - len(addends))
+            _launch('fwd', d, nbytes + sum(a.numel() * a.element_size() for a in addends), lambda: took.append(L.fgnn_mpconv_forward_addends(
+                ctypes.byref(d), _hip._ptr(x), _hip._ptr(nn_idx), _hip._ptr(etype), _hip._ptr(filters), _hip._ptr(bias),
+                _hip._ptr(post_scale), _hip._ptr(post_shift), ap[0], ap[1], ap[2], _hip._ptr(y), _hip.stream_ptr())))
+            if took[0] < 0:
+                _hip.check(took[0])
+            if took[0] == 1:
+                return y, amax
+            return add_n([y] + list(addends)), amax
     _launch('fwd', d, nbytes, lambda: _hip.check(L.fgnn_mpconv_forward(
         ctypes.byref(d), _hip._ptr(x), _hip._ptr(nn_idx), _hip._ptr(etype), _hip._ptr(filters),
         _hip._ptr(bias), _hip._ptr(post_scale), _hip._ptr(post_shift), _hip._ptr(y),
         _hip._ptr(amax), _hip.stream_ptr())))
+    if addends:
+        return add_n([y] + list(addends)), amax
     return y, amax
 
 

@@ -67,6 +67,17 @@ int fgnn_mpconv_forward(const fgnn_mpconv_desc* d, const void* x, const int64_t*
                         uint8_t* argmax, fgnn_stream_t stream);
 
 /*
+ * fgnn_mpconv_forward (inference form: post_scale / post_shift given, d->relu) with up to three ADDENDS of y's layout — the
+ * layer's running sum, residual and skip terms, which /root/reference/lib/model/mpnn/factor_mpnn_sp.py:139-168 adds to the
+ * operator's activated output — folded into the kernel's epilogue where the kernel family has one for them (the bf16
+ * parity-check kernels of csrc/mpconv_fwd_ws.hip).  Returns 1: y = act(...) + addend0 (+ addend1 + addend2); 0: y was
+ * computed WITHOUT the addends (the caller adds them); < 0: error.  addend0 first; NULL = absent.
+ */
+int fgnn_mpconv_forward_addends(const fgnn_mpconv_desc* d, const void* x, const int64_t* nn_idx, const void* etype,
+                                const float* filters, const float* bias, const float* post_scale, const float* post_shift,
+                                const void* addend0, const void* addend1, const void* addend2, void* y, fgnn_stream_t stream);
+
+/*
  * Backward of z = agg(...) + bias w.r.t. x, etype, filters, bias (mp_conv_v2 is trained through
  * autograd in the reference; this is the hand-written counterpart).
  *   gz      [B, nou, M]  upstream gradient w.r.t. the pre-BN output z (strides y_s* of d)

@@ -323,3 +323,37 @@ def test_ws_backward_is_bit_reproducible_over_many_launches(shape, dev):
             first = cur
         else:
             assert all(torch.equal(u, v) for u, v in zip(cur, first)), 'launch %d differs from launch 0' % r
+
+
+@pytest.mark.parametrize('shape', SHAPES[:6] + [SHAPES[9]], ids=IDS[:6] + [IDS[9]])
+@pytest.mark.parametrize('nadd', [1, 3])
+def test_inference_forward_with_addends_in_the_epilogue(shape, nadd, dev):
+    """fgnn_mpconv_forward_addends: y = ReLU(scale * (operator + bias) + shift) + addends (the layer's running sum / residual / skip
+    terms) from ONE launch of the third-generation kernel in its inference mode — against the plain launch plus an f32 sum of the
+    same bf16 tensors, rounded once.  Shapes the kernel family does not take return 0 and leave y without the addends."""
+    import ctypes
+    from fgnn_amd import _hip, ops
+    nin, nou, N, M, k = shape
+    B = 300
+    x, idx, et, W, bias, g = _problem(shape, B, dev, seed=3)
+    xd, idxd, etd = _dev_views(x, idx, et, dev)
+    Wd, bd = W.to(dev), bias.to(dev)
+    sc, sh = (torch.rand(nou, generator=g) + 0.5).to(dev), (torch.randn(nou, generator=g) * 0.2).to(dev)
+    y0, _ = ops.mpconv_forward_raw(xd, idxd, etd, Wd, bd, nou, 4, 0, _hip.AGG_MAX, post_scale=sc, post_shift=sh, relu=True)
+    adds = [torch.randn(B, M, 1, nou, generator=g).bfloat16().to(dev).permute(0, 3, 1, 2) for _ in range(nadd)]
+    assert all(a.stride() == y0.stride() for a in adds)
+    y1, _ = ops.mpconv_forward_raw(xd, idxd, etd, Wd, bd, nou, 4, 0, _hip.AGG_MAX, post_scale=sc, post_shift=sh, relu=True, addends=adds)
+    kern = _hip.lib().fgnn_last_kernel().decode()
+    ref = y0.float()
+    for a in adds:
+        ref = ref + a.float()
+    # the kernel adds to the UNROUNDED activation (one rounding), the reference to the rounded one: one bf16 ulp of the sum
+    assert float((y1.float() - ref).abs().max()) <= 2.0 ** -7 * max(1.0, float(ref.abs().max())), kern
+    if 'mpconv_fwd_ws' in kern:
+        d = _hip.make_desc(xd, ops.shared_graph_view(idxd), etd, nou, 4, 0, _hip.AGG_MAX, True, y1)
+        y2 = torch.empty_like(y1)
+        P = _hip._ptr
+        ap = [P(a) for a in adds] + [None] * (3 - nadd)
+        rc = _hip.lib().fgnn_mpconv_forward_addends(ctypes.byref(d), P(xd), P(ops.shared_graph_view(idxd)), P(etd), P(Wd), P(bd), P(sc), P(sh),
+                                                    ap[0], ap[1], ap[2], P(y2), _hip.stream_ptr())
+        assert rc == 1 and torch.equal(y2, y1)
