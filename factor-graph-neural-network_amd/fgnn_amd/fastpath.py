@@ -60,9 +60,10 @@ def fast_path(module):
 
 def _pre_hook(module, args):
     from .mpnn import FactorNN
-    if getattr(module, '_fgnn_fast', False) or isinstance(module, FactorNN):
+    if getattr(module, '_fgnn_fast_seen', False):      # one look per module: the hook runs in front of every module call
         return None
-    if any(isinstance(c, FactorNN) for c in module.children()):
+    module._fgnn_fast_seen = True
+    if not isinstance(module, FactorNN) and any(isinstance(c, FactorNN) for c in module.children()):
         fast_path(module)          # (this call still runs the old forward — torch bound it before the hooks; the next one is fast)
     return None
 
