@@ -27,6 +27,7 @@
 // A wave owns 16-row tiles and walks all Cout / 64 slabs of its tile (W2 / W2^T fragments and the per-channel constants
 // come from LDS, stored in fragment order: conflict-free 16-byte reads; the stream stays HBM-bound).
 #include "fgnn_common.h"
+#include "fgnn_gridfold.h"
 #include <stdlib.h>
 
 #define BT_THREADS 256
@@ -55,6 +56,14 @@ struct BtParams {
     float* part2;            // [grid][2][64] BatchNorm2's backward sums (sum g2', sum g2' e), or NULL      (mode 3)
     int R, Cout;
     float slope2, slope3;
+    int aperiod[3];          // mode 1: rows of out per addend row (1 = a tensor of out's shape; m = a per-sample row broadcast over m nodes)
+    // the reducing modes finalise their own sums in the last workgroup (fgnn_gridfold.h) when fold.tickets != NULL:
+    FgnnFold fold;
+    fgnn_bn_final fin;       // mode 0: BatchNorm3's forward statistics (shift_k = b2)
+    const float* mean3; const float* invstd3; const float* gamma3;     // mode 2: -> A, Bc [Cout] (the grad pass's constants), gweight3 / gbias3 +=
+    float* A; float* Bc; float* gweight3; float* gbias3;
+    const float* mean2; const float* invstd2;                           // mode 3: BatchNorm2's sums -> dsum2 [2][64], gweight2 / gbias2 +=
+    float* dsum2; float* gweight2; float* gbias2;
 };
 
 extern __shared__ __attribute__((aligned(16))) unsigned char bt_lds[];
@@ -271,7 +280,10 @@ __global__ __launch_bounds__(BT_THREADS, MODE == 1 ? 3 : 2) void block_tail_kern
 #pragma unroll
                 for (int a = 0; a < 3; ++a) {
                     aq[a][0] = aq[a][1] = zq4;
-                    if (a < NA) { aq[a][0] = *reinterpret_cast<const uint4*>(ads[a] + eoff); aq[a][1] = *reinterpret_cast<const uint4*>(ads[a] + eoff + 8); }
+                    if (a < NA) {
+                        const int64_t aoff = p.aperiod[a] > 1 ? (int64_t)(crow / p.aperiod[a]) * COUT + o_base + 16 * lk : eoff;
+                        aq[a][0] = *reinterpret_cast<const uint4*>(ads[a] + aoff); aq[a][1] = *reinterpret_cast<const uint4*>(ads[a] + aoff + 8);
+                    }
                 }
             }
             f32x4 acc[4];
@@ -414,6 +426,29 @@ __global__ __launch_bounds__(BT_THREADS, MODE == 1 ? 3 : 2) void block_tail_kern
             for (int w = 0; w < NRG; ++w) s += redf[w * 2 * CF + f];
             dst[(int64_t)blockIdx.x * 2 * CF + f] = s;
         }
+        if (p.fold.tickets) {            // no finaliser launch: the last workgroup folds every workgroup's row and finalises
+            double* sums = reinterpret_cast<double*>(bt_lds);      // (the fragments are dead; the fold starts with a barrier)
+            if (fgnn_grid_fold(p.fold, sums, blockIdx.x)) {
+                if (MODE == 0) fgnn_bn_final_apply(p.fin, COUT, sums);
+                else if (MODE == 3) fgnn_bn_bwd_final_apply(64, sums, p.mean2, p.invstd2, p.dsum2, p.gweight2, p.gbias2);
+                else {
+                    // BatchNorm3's backward sums and the per-channel constants of the closed-form input gradient:
+                    //   S0 = sum g', S1 = sum g' (z3 - b2)   ->   dbeta = S0,  dgamma = invstd (S1 + (b2 - mean) S0)
+                    //   gz3 = s3 (g' - dbeta / R - zhat dgamma / R) = s3 g' + A z3 + Bc,  A = -s3 invstd dgamma / R,  Bc = -s3 dbeta / R - A mean
+                    for (int c = tid; c < COUT; c += BT_THREADS) {
+                        const double S0 = sums[c], S1 = sums[COUT + c];
+                        const double mu = (double)p.mean3[c], is = (double)p.invstd3[c], bb = p.b2 ? (double)p.b2[c] : 0.0;
+                        const double dbeta = S0, dgamma = is * (S1 + (bb - mu) * S0);
+                        const double s3 = (double)p.gamma3[c] * is, n = (double)p.R;
+                        const double Ac = -s3 * is * dgamma / n;
+                        p.A[c] = (float)Ac;
+                        p.Bc[c] = (float)(-s3 * dbeta / n - Ac * mu);
+                        if (p.gbias3) p.gbias3[c] += (float)dbeta;
+                        if (p.gweight3) p.gweight3[c] += (float)dgamma;
+                    }
+                }
+            }
+        }
     }
 }
 
@@ -498,21 +533,35 @@ static int bt_check(const char* who, const void* e, const float* s2, const float
     return FGNN_OK;
 }
 
+int fgnn_bn_finalize_launch(const float* partials, int npartials, int C, const fgnn_bn_final* fin, hipStream_t st);
+int fgnn_bn_bwd_final_raw_launch(const float* partials, int npartials, int C, const float* mean, const float* invstd, float* dsum,
+                                 float* gweight, float* gbias, hipStream_t st);
+
 extern "C" int fgnn_block_tail_stats(const void* e, const float* scale2, const float* shift2, float slope2, const float* W2,
-                                     const float* b2, int64_t R, int Cout, float* partials, fgnn_stream_t stream) {
+                                     const float* b2, int64_t R, int Cout, float* partials, const fgnn_bn_final* fin,
+                                     void* fold_scratch, fgnn_stream_t stream) {
     int grid, rc;
     if ((rc = bt_check("block_tail_stats", e, scale2, shift2, W2, R, Cout, &grid))) return rc;
-    if (!partials) FGNN_FAIL(FGNN_EINVAL, "block_tail_stats: null partials");
+    if (!partials || !fin || !fin->mean || !fin->invstd || !fin->scale || !fin->shift) FGNN_FAIL(FGNN_EINVAL, "block_tail_stats: null pointer");
+    if (fin->shift_k) FGNN_FAIL(FGNN_EINVAL, "block_tail_stats: shift_k is this kernel's own (b2)");
+    if (fin->count != R || (fin->population != 0 && fin->population < R)) FGNN_FAIL(FGNN_EINVAL, "block_tail_stats: fin->count must be R");
     BtParams p = {};
     p.e = (const uint16_t*)e; p.s2 = scale2; p.t2 = shift2; p.W2 = W2; p.b2 = b2; p.part = partials;
     p.R = (int)R; p.Cout = Cout; p.slope2 = slope2;
-    return bt_launch<0>(p, grid, (hipStream_t)stream);
+    p.fin = *fin;
+    p.fin.shift_k = b2;                       // the kernel sums z3 - b2
+    const bool inkernel = fold_scratch && !fgnn_separate_finalisers();
+    p.fold = fgnn_fold_make(partials, inkernel ? fold_scratch : nullptr, grid, Cout);
+    if ((rc = bt_launch<0>(p, grid, (hipStream_t)stream))) return rc;
+    if (!inkernel && fgnn_bn_finalize_launch(partials, grid, Cout, &p.fin, (hipStream_t)stream))
+        FGNN_FAIL(FGNN_ELAUNCH, "block_tail_stats finaliser launch: %s", hipGetErrorString(hipGetLastError()));
+    return FGNN_OK;
 }
 
 extern "C" int fgnn_block_tail_apply(const void* e, const float* scale2, const float* shift2, float slope2, const float* W2,
                                      const float* b2, const float* scale3, const float* shift3, float slope3,
-                                     const void* addend0, const void* addend1, const void* addend2, void* out, void* a2_out,
-                                     int64_t R, int Cout, fgnn_stream_t stream) {
+                                     const void* addend0, const void* addend1, const void* addend2, const int32_t* addend_period,
+                                     void* out, void* a2_out, int64_t R, int Cout, fgnn_stream_t stream) {
     int grid, rc;
     if ((rc = bt_check("block_tail_apply", e, scale2, shift2, W2, R, Cout, &grid))) return rc;
     if (!scale3 || !shift3 || !out) FGNN_FAIL(FGNN_EINVAL, "block_tail_apply: null pointer");
@@ -521,10 +570,17 @@ extern "C" int fgnn_block_tail_apply(const void* e, const float* scale2, const f
     BtParams p = {};
     p.e = (const uint16_t*)e; p.s2 = scale2; p.t2 = shift2; p.W2 = W2; p.b2 = b2; p.s3 = scale3; p.t3 = shift3;
     const void* ads[3] = {addend0, addend1, addend2};      // packed to the front: the kernel is specialised on their number
+    int per[3] = {1, 1, 1};
     int na = 0;
-    for (int a = 0; a < 3; ++a) if (ads[a]) ads[na++] = ads[a];
+    for (int a = 0; a < 3; ++a)
+        if (ads[a]) {
+            const int pr = addend_period ? addend_period[a] : 1;
+            if (pr < 1) FGNN_FAIL(FGNN_EINVAL, "block_tail_apply: addend period < 1");
+            ads[na] = ads[a]; per[na] = pr; ++na;
+        }
     p.add0 = (const uint16_t*)(na > 0 ? ads[0] : nullptr); p.add1 = (const uint16_t*)(na > 1 ? ads[1] : nullptr);
     p.add2 = (const uint16_t*)(na > 2 ? ads[2] : nullptr);
+    for (int a = 0; a < 3; ++a) p.aperiod[a] = a < na ? per[a] : 1;
     p.out = (uint16_t*)out; p.out2 = (uint16_t*)a2_out; p.R = (int)R; p.Cout = Cout; p.slope2 = slope2; p.slope3 = slope3;
     hipStream_t st = (hipStream_t)stream;
     switch (na) {
@@ -539,28 +595,40 @@ extern "C" int fgnn_block_tail_backward(const void* e, const float* scale2, cons
                                         const float* W2, const float* b2, const float* mean3, const float* invstd3,
                                         const float* gamma3, const float* scale3, const float* shift3, float slope3,
                                         const void* gout, void* gz3, void* ga2, float* gweight3, float* gbias3,
-                                        float* bn2_partials, int64_t R, int Cout, void* workspace, int64_t workspace_bytes,
+                                        const float* mean2, const float* invstd2, float* gweight2, float* gbias2, float* bn2_dsum,
+                                        int64_t R, int Cout, void* workspace, int64_t workspace_bytes, void* fold_scratch,
                                         fgnn_stream_t stream) {
     int grid, rc;
     if ((rc = bt_check("block_tail_backward", e, scale2, shift2, W2, R, Cout, &grid))) return rc;
     if (!mean3 || !invstd3 || !gamma3 || !scale3 || !shift3 || !gout || !gz3 || !ga2 || !workspace)
         FGNN_FAIL(FGNN_EINVAL, "block_tail_backward: null pointer");
+    if (bn2_dsum && (!mean2 || !invstd2)) FGNN_FAIL(FGNN_EINVAL, "block_tail_backward: bn2_dsum needs mean2 / invstd2");
     if (((uintptr_t)gout | (uintptr_t)gz3 | (uintptr_t)ga2) & 15) FGNN_FAIL(FGNN_EUNSUPPORTED, "block_tail_backward: misaligned operand");
-    if (workspace_bytes < ((int64_t)BT_MAXGRID * 2 * Cout + 2 * Cout) * 4) FGNN_FAIL(FGNN_EINVAL, "block_tail_backward: workspace too small");
+    if (workspace_bytes < ((int64_t)BT_MAXGRID * 2 * Cout + 2 * Cout + (int64_t)BT_MAXGRID * 128) * 4)
+        FGNN_FAIL(FGNN_EINVAL, "block_tail_backward: workspace too small");
     float* ws = (float*)workspace;
     float* A = ws + (int64_t)BT_MAXGRID * 2 * Cout;
     float* Bc = A + Cout;
+    float* part2 = Bc + Cout;                              // [grid3][2][64] BatchNorm2's partial rows
     hipStream_t st = (hipStream_t)stream;
+    const bool inkernel = fold_scratch && !fgnn_separate_finalisers();
     BtParams p = {};
     p.e = (const uint16_t*)e; p.s2 = scale2; p.t2 = shift2; p.W2 = W2; p.b2 = b2; p.s3 = scale3; p.t3 = shift3;
     p.gout = (const uint16_t*)gout; p.part = ws; p.R = (int)R; p.Cout = Cout; p.slope2 = slope2; p.slope3 = slope3;
+    p.mean3 = mean3; p.invstd3 = invstd3; p.gamma3 = gamma3; p.A = A; p.Bc = Bc; p.gweight3 = gweight3; p.gbias3 = gbias3;
+    p.fold = fgnn_fold_make(ws, inkernel ? fold_scratch : nullptr, grid, Cout);
     if ((rc = bt_launch<2>(p, grid, st))) return rc;
     int grid3;
     (void)bt_plan(R, Cout, &grid3, false);
-    hipLaunchKernelGGL(block_tail_bwd_final_kernel, dim3((Cout + 3) / 4), dim3(256), 0, st, ws, grid, Cout, R, b2, mean3,
-                       invstd3, gamma3, A, Bc, gweight3, gbias3);
-    p.ga = A; p.gb = Bc; p.out = (uint16_t*)gz3; p.out2 = (uint16_t*)ga2; p.part = nullptr; p.part2 = bn2_partials;
+    if (!inkernel)
+        hipLaunchKernelGGL(block_tail_bwd_final_kernel, dim3((Cout + 3) / 4), dim3(256), 0, st, ws, grid, Cout, R, b2, mean3,
+                           invstd3, gamma3, A, Bc, gweight3, gbias3);
+    p.ga = A; p.gb = Bc; p.out = (uint16_t*)gz3; p.out2 = (uint16_t*)ga2; p.part = nullptr; p.part2 = bn2_dsum ? part2 : nullptr;
+    p.mean2 = mean2; p.invstd2 = invstd2; p.dsum2 = bn2_dsum; p.gweight2 = gweight2; p.gbias2 = gbias2;
+    p.fold = fgnn_fold_make(part2, (inkernel && bn2_dsum) ? fold_scratch : nullptr, grid3, 64);
     if ((rc = bt_launch<3>(p, grid3, st))) return rc;
+    if (!inkernel && bn2_dsum && fgnn_bn_bwd_final_raw_launch(part2, grid3, 64, mean2, invstd2, bn2_dsum, gweight2, gbias2, st))
+        FGNN_FAIL(FGNN_ELAUNCH, "block_tail_backward finaliser launch: %s", hipGetErrorString(hipGetLastError()));
     hipError_t e2 = hipGetLastError();
     if (e2 != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "block_tail_backward launch: %s", hipGetErrorString(e2));
     return FGNN_OK;
@@ -704,7 +772,7 @@ __global__ __launch_bounds__(BT_THREADS, 3) void block_head_bwd_kernel(const BhP
 
 int fgnn_bn_backward_sums_bf16(const void* x, const void* gy, int64_t R, int C, const float* mean, const float* invstd,
                                const float* gamma, const float* beta, float slope, float* gweight, float* gbias,
-                               void* workspace, hipStream_t st, const float** dsum_out);
+                               void* workspace, void* fold_scratch, hipStream_t st, const float** dsum_out);
 
 // BatchNorm1 + activation backward and conv1's input gradient (see above).  z1 / ga1 [R][64] bf16, W1 [64][Cin] f32 (Cin in
 // {64, 128, 256}), gz1 [R][64] and gx [R][Cin] bf16 out, gweight / gbias [64] ACCUMULATED into (BatchNorm1's parameter gradients).
@@ -712,7 +780,7 @@ int fgnn_bn_backward_sums_bf16(const void* x, const void* gy, int64_t R, int C, 
 extern "C" int fgnn_block_head_backward(const void* z1, const void* ga1, const float* mean, const float* invstd,
                                         const float* gamma, const float* beta, float slope, const float* W1, void* gz1,
                                         void* gx, float* gweight, float* gbias, int64_t R, int Cin, void* workspace,
-                                        int64_t workspace_bytes, fgnn_stream_t stream) {
+                                        int64_t workspace_bytes, void* fold_scratch, fgnn_stream_t stream) {
     if (!z1 || !ga1 || !mean || !invstd || !gamma || !beta || !W1 || !gz1 || !gx || !workspace)
         FGNN_FAIL(FGNN_EINVAL, "block_head_backward: null pointer");
     int grid;
@@ -721,7 +789,7 @@ extern "C" int fgnn_block_head_backward(const void* z1, const void* ga1, const f
     if (workspace_bytes < (int64_t)BT_MAXGRID * 2 * 64 * 4 + 2 * 64 * 4) FGNN_FAIL(FGNN_EINVAL, "block_head_backward: workspace too small");
     hipStream_t st = (hipStream_t)stream;
     const float* dsum = nullptr;
-    if (fgnn_bn_backward_sums_bf16(z1, ga1, R, 64, mean, invstd, gamma, beta, slope, gweight, gbias, workspace, st, &dsum))
+    if (fgnn_bn_backward_sums_bf16(z1, ga1, R, 64, mean, invstd, gamma, beta, slope, gweight, gbias, workspace, fold_scratch, st, &dsum))
         FGNN_FAIL(FGNN_EUNSUPPORTED, "block_head_backward: BatchNorm reduction plan failed");
     BhParams p = {};
     p.z = (const uint16_t*)z1; p.g = (const uint16_t*)ga1; p.mean = mean; p.invstd = invstd; p.gamma = gamma; p.beta = beta;

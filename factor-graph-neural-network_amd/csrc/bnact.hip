@@ -13,6 +13,7 @@
 // partial sums live in registers) + two tiny finalisers; partials of the ~1000 workgroups go through a
 // workspace, never through atomics.  Replaces 4 ATen kernels + 2 activation kernels per layer per step.
 #include "fgnn_common.h"
+#include "fgnn_gridfold.h"
 #include <stdlib.h>
 
 #define BN_THREADS 256
@@ -33,6 +34,8 @@ struct BnParams {
     const void* addend;        // forward apply: y = act(...) + addend (+ addend2 + addend3), each y's layout or NULL
     const void* addend2;
     const void* addend3;
+    int aperiod[3];            // rows of y per addend row (1 = a tensor of y's shape; m = one row per m consecutive rows: a per-sample
+                               // vector broadcast over the sample's m nodes)
     int64_t R;
     int C, cshift;             // cshift = log2(C / EPC)
     int rows_per_wg;
@@ -40,6 +43,12 @@ struct BnParams {
     float dsum_scale;          // backward apply: 1 / R
     const float* dgamma;
     const float* dbeta;
+    // the reducing kernels finalise their own sums in the last workgroup (fgnn_gridfold.h) when fold.tickets != NULL
+    FgnnFold fold;
+    fgnn_bn_final fin;         // MODE 0: the forward statistics
+    float* dsum;               // MODE 1: [2][C] dbeta, dgamma out
+    float* gweight;            // MODE 1: ACCUMULATED into, or NULL
+    float* gbias;
 };
 
 template <typename T> struct Chunk;
@@ -80,7 +89,7 @@ template <> struct Chunk<bf16_t> {
 template <typename T, int MODE>
 __global__ __launch_bounds__(BN_THREADS) void bn_reduce_kernel(const BnParams p) {
     constexpr int EPC = Chunk<T>::EPC;
-    __shared__ float red[BN_THREADS * 2 * EPC];
+    __shared__ __attribute__((aligned(16))) float red[BN_THREADS * 2 * EPC];
     const int tid = threadIdx.x;
     const int cpr = 1 << p.cshift;                        // chunks per row
     const int cg = tid & (cpr - 1), rg = tid >> p.cshift; // channel group, row group
@@ -135,6 +144,13 @@ __global__ __launch_bounds__(BN_THREADS) void bn_reduce_kernel(const BnParams p)
 #pragma unroll
         for (int e = 0; e < EPC; ++e) { w[c0 + e] = s0[e]; w[p.C + c0 + e] = s1[e]; }
     }
+    if (p.fold.tickets) {                                 // no finaliser launch: the last workgroup folds all rows and finalises
+        double* sums = reinterpret_cast<double*>(red);    // (red is free: the fold starts with a barrier)
+        if (fgnn_grid_fold(p.fold, sums, blockIdx.x)) {
+            if (MODE == 0) fgnn_bn_final_apply(p.fin, p.C, sums);
+            else fgnn_bn_bwd_final_apply(p.C, sums, nullptr, nullptr, p.dsum, p.gweight, p.gbias);
+        }
+    }
 }
 
 // K = row 0 of x (f32 path)
@@ -169,33 +185,30 @@ __device__ __forceinline__ void bn_fold(const float* ws, int nwg, int C, int c, 
         for (int q = 0; q < 8; ++q) { s0 += red0[q * BN_FC + cc]; s1 += red1[q * BN_FC + cc]; }
 }
 
-// forward finaliser: mean / invstd / scale / shift and the running statistics
-__global__ __launch_bounds__(256) void bn_stats_final_kernel(const float* ws, int nwg, int C, int64_t R,
-                                                             const float* ref, const float* gamma,
-                                                             const float* beta, float* rmean, float* rvar,
-                                                             float momentum, float eps, float* mean,
-                                                             float* invstd, float* scale, float* shift,
-                                                             long long* nbt) {
-    if (nbt && blockIdx.x == 0 && threadIdx.x == 0) *nbt += 1;      // BatchNorm2d.num_batches_tracked
+// forward finaliser (FGNN_SEPARATE_FINALISERS=1, and partials produced outside this library): mean / invstd / scale / shift and
+// the running statistics — the arithmetic of fgnn_bn_final_apply (fgnn_gridfold.h), 4 channels per workgroup
+__global__ __launch_bounds__(256) void bn_stats_final_kernel(const float* ws, int nwg, int C, const fgnn_bn_final fin) {
+    if (fin.num_batches_tracked && blockIdx.x == 0 && threadIdx.x == 0) *fin.num_batches_tracked += 1;      // BatchNorm2d.num_batches_tracked
     const int c = blockIdx.x * BN_FC + (threadIdx.x & (BN_FC - 1)), pg = threadIdx.x / BN_FC;
     double s0, s1;
     bn_fold(ws, nwg, C, c, pg, c < C, s0, s1);
     if (pg != 0 || c >= C) return;
-    const double n = (double)R;
+    const double n = (double)fin.count;
     const double m0 = s0 / n;                             // mean of (x - K)
     double var = s1 / n - m0 * m0;
     if (var < 0.0) var = 0.0;
-    const float mu = (float)(m0 + (ref ? (double)ref[c] : 0.0));
-    const float is = (float)(1.0 / sqrt(var + (double)eps));
-    mean[c] = mu;
-    invstd[c] = is;
-    const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
-    scale[c] = g * is;
-    shift[c] = b - mu * g * is;
-    if (rmean) {
-        const double unbiased = R > 1 ? var * n / (n - 1.0) : var;
-        rmean[c] = (1.f - momentum) * rmean[c] + momentum * mu;
-        rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unbiased;
+    const float mu = (float)(m0 + (fin.shift_k ? (double)fin.shift_k[c] : 0.0));
+    const float is = (float)(1.0 / sqrt(var + (double)fin.eps));
+    fin.mean[c] = mu;
+    fin.invstd[c] = is;
+    const float g = fin.gamma ? fin.gamma[c] : 1.f, b = fin.beta ? fin.beta[c] : 0.f;
+    fin.scale[c] = g * is;
+    fin.shift[c] = b - mu * g * is;
+    if (fin.running_mean) {
+        const double np = (double)(fin.population > 0 ? fin.population : fin.count);
+        const double unbiased = np > 1.0 ? var * np / (np - 1.0) : var;
+        fin.running_mean[c] = (1.f - fin.momentum) * fin.running_mean[c] + fin.momentum * mu;
+        fin.running_var[c] = (1.f - fin.momentum) * fin.running_var[c] + fin.momentum * (float)unbiased;
     }
 }
 
@@ -252,7 +265,8 @@ __global__ __launch_bounds__(BN_THREADS) void bn_apply_kernel(const BnParams p) 
             for (int a = 0; a < 3; ++a) {
                 if (ads[a]) {
                     float ad[EPC];
-                    Chunk<T>::load(static_cast<const T*>(ads[a]) + r * p.C + c0, ad);
+                    const int64_t ar = p.aperiod[a] > 1 ? r / p.aperiod[a] : r;
+                    Chunk<T>::load(static_cast<const T*>(ads[a]) + ar * p.C + c0, ad);
 #pragma unroll
                     for (int e = 0; e < EPC; ++e) o[e] += ad[e];
                 }
@@ -309,14 +323,32 @@ extern "C" int fgnn_bn_supported(int64_t R, int C, int dtype) {
 
 extern "C" int64_t fgnn_bn_workspace_bytes(int64_t R, int C) { return (int64_t)BN_MAXPART * 2 * C * 4 + 2 * C * 4; }
 
-// Forward statistics: fills mean, invstd, scale, shift [C]; updates running_mean / running_var when given.
-extern "C" int fgnn_bn_stats(const void* x, int64_t R, int C, int dtype, const float* gamma, const float* beta,
-                             float* running_mean, float* running_var, float momentum, float eps, float* mean,
-                             float* invstd, float* scale, float* shift, int64_t* num_batches_tracked,
-                             void* workspace, int64_t workspace_bytes, fgnn_stream_t stream) {
+int fgnn_separate_finalisers(void) {
+    static const int v = getenv("FGNN_SEPARATE_FINALISERS") ? atoi(getenv("FGNN_SEPARATE_FINALISERS")) : 0;
+    return v;
+}
+
+static int bn_check_final(const char* who, const fgnn_bn_final* fin) {
+    if (!fin || !fin->mean || !fin->invstd || !fin->scale || !fin->shift) FGNN_FAIL(FGNN_EINVAL, "%s: null pointer in fgnn_bn_final", who);
+    if (fin->count < 1 || (fin->population != 0 && fin->population < fin->count)) FGNN_FAIL(FGNN_EINVAL, "%s: bad row counts in fgnn_bn_final", who);
+    if ((fin->running_mean == nullptr) != (fin->running_var == nullptr)) FGNN_FAIL(FGNN_EINVAL, "%s: running_mean and running_var go together", who);
+    return FGNN_OK;
+}
+
+// Host-side helper of the other translation units (FGNN_SEPARATE_FINALISERS=1): the stand-alone forward finaliser.
+int fgnn_bn_finalize_launch(const float* partials, int npartials, int C, const fgnn_bn_final* fin, hipStream_t st) {
+    hipLaunchKernelGGL(bn_stats_final_kernel, dim3((C + BN_FC - 1) / BN_FC), dim3(256), 0, st, partials, npartials, C, *fin);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+// Forward statistics of x [R][C] (count = R rows): one reducing launch whose last workgroup finalises (fgnn_bn_final).
+extern "C" int fgnn_bn_stats(const void* x, int64_t R, int C, int dtype, const fgnn_bn_final* fin, void* workspace,
+                             int64_t workspace_bytes, void* fold_scratch, fgnn_stream_t stream) {
     BnParams p = {};
-    int grid;
-    if (!x || !mean || !invstd || !scale || !shift || !workspace) FGNN_FAIL(FGNN_EINVAL, "bn_stats: null pointer");
+    int grid, rc;
+    if (!x || !workspace) FGNN_FAIL(FGNN_EINVAL, "bn_stats: null pointer");
+    if ((rc = bn_check_final("bn_stats", fin))) return rc;
+    if (fin->count != R) FGNN_FAIL(FGNN_EINVAL, "bn_stats: fin->count must be R");
     if (bn_plan(R, C, dtype, &p, &grid)) FGNN_FAIL(FGNN_EUNSUPPORTED, "bn: C=%d not a supported channel count", C);
     if (workspace_bytes < fgnn_bn_workspace_bytes(R, C)) FGNN_FAIL(FGNN_EINVAL, "bn: workspace too small");
     float* ws = (float*)workspace;
@@ -327,56 +359,49 @@ extern "C" int fgnn_bn_stats(const void* x, int64_t R, int C, int dtype, const f
     if (dtype == FGNN_F32) hipLaunchKernelGGL(bn_ref_kernel, dim3((C + 255) / 256), dim3(256), 0, st, (const float*)x, ref, C);
     else ref = nullptr;      // bf16: accumulate against K = 0 (values are O(1) after the preceding map; f32 sums, f64 finaliser)
     p.x = x; p.ws = ws; p.ref = ref;
+    p.fin = *fin;
+    if (ref) {
+        if (fin->shift_k) FGNN_FAIL(FGNN_EINVAL, "bn_stats: shift_k is for partials produced elsewhere");
+        p.fin.shift_k = ref;
+    }
+    const bool inkernel = fold_scratch && 2 * C <= FGNN_FOLD_MAXJ && !fgnn_separate_finalisers();
+    p.fold = fgnn_fold_make(ws, inkernel ? fold_scratch : nullptr, grid, C);
     if (dtype == FGNN_F32) hipLaunchKernelGGL((bn_reduce_kernel<float, 0>), dim3(grid), dim3(BN_THREADS), 0, st, p);
     else hipLaunchKernelGGL((bn_reduce_kernel<bf16_t, 0>), dim3(grid), dim3(BN_THREADS), 0, st, p);
-    hipLaunchKernelGGL(bn_stats_final_kernel, dim3((C + BN_FC - 1) / BN_FC), dim3(256), 0, st, ws, grid, C, R, ref, gamma,
-                       beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift,
-                       (long long*)num_batches_tracked);
+    if (!inkernel) hipLaunchKernelGGL(bn_stats_final_kernel, dim3((C + BN_FC - 1) / BN_FC), dim3(256), 0, st, ws, grid, C, p.fin);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "bn_stats launch: %s", hipGetErrorString(e));
     return FGNN_OK;
 }
 
-// Forward statistics from per-workgroup partials somebody else produced (fgnn_linear_forward's epilogue):
-// partials[w][0][c] = sum y, partials[w][1][c] = sum y^2 over that workgroup's rows.  Same outputs as fgnn_bn_stats.
-extern "C" int fgnn_bn_finalize(const float* partials, int npartials, int64_t R, int C, const float* gamma,
-                                const float* beta, float* running_mean, float* running_var, float momentum,
-                                float eps, float* mean, float* invstd, float* scale, float* shift,
-                                int64_t* num_batches_tracked, fgnn_stream_t stream) {
-    if (!partials || !mean || !invstd || !scale || !shift) FGNN_FAIL(FGNN_EINVAL, "bn_finalize: null pointer");
-    if (npartials < 1 || npartials > BN_MAXPART || R < 1 || C < 1) FGNN_FAIL(FGNN_EINVAL, "bn_finalize: bad sizes");
-    hipLaunchKernelGGL(bn_stats_final_kernel, dim3((C + BN_FC - 1) / BN_FC), dim3(256), 0, (hipStream_t)stream, partials,
-                       npartials, C, R, (const float*)nullptr, gamma, beta, running_mean, running_var, momentum, eps,
-                       mean, invstd, scale, shift, (long long*)num_batches_tracked);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "bn_finalize launch: %s", hipGetErrorString(e));
+// Forward statistics from per-workgroup partials somebody else produced: partials[w][0][c] = sum (y - K), partials[w][1][c] =
+// sum (y - K)^2 over that workgroup's rows, K = fin->shift_k (NULL = 0).  One small launch.  (The producers of this library take the
+// fgnn_bn_final themselves and need no such call; this entry point serves partials formed elsewhere.)
+extern "C" int fgnn_bn_finalize(const float* partials, int npartials, int C, const fgnn_bn_final* fin, fgnn_stream_t stream) {
+    int rc;
+    if (!partials) FGNN_FAIL(FGNN_EINVAL, "bn_finalize: null pointer");
+    if ((rc = bn_check_final("bn_finalize", fin))) return rc;
+    if (npartials < 1 || npartials > BN_MAXPART || C < 1) FGNN_FAIL(FGNN_EINVAL, "bn_finalize: bad sizes");
+    if (fgnn_bn_finalize_launch(partials, npartials, C, fin, (hipStream_t)stream))
+        FGNN_FAIL(FGNN_ELAUNCH, "bn_finalize launch: %s", hipGetErrorString(hipGetLastError()));
     return FGNN_OK;
 }
 
-// The same with partials of (y - K[c]): the producer summed its values before adding a per-channel constant K (a bias).
-extern "C" int fgnn_bn_finalize_shifted(const float* partials, int npartials, int64_t R, int C, const float* K, const float* gamma,
-                                        const float* beta, float* running_mean, float* running_var, float momentum,
-                                        float eps, float* mean, float* invstd, float* scale, float* shift,
-                                        int64_t* num_batches_tracked, fgnn_stream_t stream) {
-    if (!partials || !mean || !invstd || !scale || !shift) FGNN_FAIL(FGNN_EINVAL, "bn_finalize_shifted: null pointer");
-    if (npartials < 1 || npartials > BN_MAXPART || R < 1 || C < 1) FGNN_FAIL(FGNN_EINVAL, "bn_finalize_shifted: bad sizes");
-    hipLaunchKernelGGL(bn_stats_final_kernel, dim3((C + BN_FC - 1) / BN_FC), dim3(256), 0, (hipStream_t)stream, partials,
-                       npartials, C, R, K, gamma, beta, running_mean, running_var, momentum, eps,
-                       mean, invstd, scale, shift, (long long*)num_batches_tracked);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "bn_finalize_shifted launch: %s", hipGetErrorString(e));
-    return FGNN_OK;
-}
-
-// y = act(x * scale + shift) [+ addend + addend2 + addend3], act = LeakyReLU(slope) (slope 0: ReLU, slope 1: identity)
+// y = act(x * scale + shift) [+ addend + addend2 + addend3], act = LeakyReLU(slope) (slope 0: ReLU, slope 1: identity).
+// addend_period[a] (or NULL = all 1): addend a has one row per `period` consecutive rows of y (a per-sample vector broadcast over
+// the sample's nodes: row r reads addend row r / period).
 extern "C" int fgnn_bn_apply(const void* x, void* y, int64_t R, int C, int dtype, const float* scale,
                              const float* shift, float slope, const void* addend, const void* addend2,
-                             const void* addend3, fgnn_stream_t stream) {
+                             const void* addend3, const int32_t* addend_period, fgnn_stream_t stream) {
     BnParams p = {};
     int grid;
     if (!x || !y || !scale || !shift) FGNN_FAIL(FGNN_EINVAL, "bn_apply: null pointer");
     if (bn_plan(R, C, dtype, &p, &grid, bn_apply_grid())) FGNN_FAIL(FGNN_EUNSUPPORTED, "bn: C=%d not a supported channel count", C);
     p.x = x; p.out = y; p.a = scale; p.b = shift; p.slope = slope; p.addend = addend; p.addend2 = addend2; p.addend3 = addend3;
+    for (int a = 0; a < 3; ++a) {
+        p.aperiod[a] = addend_period ? addend_period[a] : 1;
+        if (p.aperiod[a] < 1) FGNN_FAIL(FGNN_EINVAL, "bn_apply: addend period < 1");
+    }
     hipStream_t st = (hipStream_t)stream;
     if (dtype == FGNN_F32) hipLaunchKernelGGL((bn_apply_kernel<float, 0>), dim3(grid), dim3(BN_THREADS), 0, st, p);
     else hipLaunchKernelGGL((bn_apply_kernel<bf16_t, 0>), dim3(grid), dim3(BN_THREADS), 0, st, p);
@@ -385,27 +410,54 @@ extern "C" int fgnn_bn_apply(const void* x, void* y, int64_t R, int C, int dtype
     return FGNN_OK;
 }
 
-// gx, and gweight / gbias (ACCUMULATED into, may be NULL)
+// The reduction half of the backward: per-channel dbeta / dgamma -> dsum [2][C] (in the workspace, behind the partial rows) and
+// ACCUMULATED into gweight / gbias (may be NULL); one launch (the last workgroup finalises).  Host-side helper of this library
+// (csrc/block_tail.hip: BatchNorm1's sums in front of the fused head kernel), not C ABI.
+int fgnn_bn_backward_sums(const void* x, const void* gy, int64_t R, int C, int dtype, const float* mean, const float* invstd,
+                          const float* gamma, const float* beta, float slope, float* gweight, float* gbias,
+                          void* workspace, void* fold_scratch, hipStream_t st, BnParams* out, const float** dsum_out) {
+    BnParams p = {};
+    int grid;
+    if (bn_plan(R, C, dtype, &p, &grid)) return -1;
+    float* ws = (float*)workspace;
+    float* dsum = ws + (int64_t)BN_MAXPART * 2 * C;
+    p.x = x; p.gy = gy; p.out = nullptr; p.ws = ws; p.a = mean; p.b = invstd; p.gamma = gamma; p.beta = beta;
+    p.slope = slope; p.dsum_scale = 1.0f / (float)R; p.dbeta = dsum; p.dgamma = dsum + C;
+    p.dsum = dsum; p.gweight = gweight; p.gbias = gbias;
+    const bool inkernel = fold_scratch && 2 * C <= FGNN_FOLD_MAXJ && !fgnn_separate_finalisers();
+    p.fold = fgnn_fold_make(ws, inkernel ? fold_scratch : nullptr, grid, C);
+    if (dtype == FGNN_F32) hipLaunchKernelGGL((bn_reduce_kernel<float, 1>), dim3(grid), dim3(BN_THREADS), 0, st, p);
+    else hipLaunchKernelGGL((bn_reduce_kernel<bf16_t, 1>), dim3(grid), dim3(BN_THREADS), 0, st, p);
+    if (!inkernel) hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((C + BN_FC - 1) / BN_FC), dim3(256), 0, st, ws, grid, C, dsum, gweight, gbias);
+    if (out) *out = p;
+    if (dsum_out) *dsum_out = dsum;
+    return 0;
+}
+
+int fgnn_bn_backward_sums_bf16(const void* x, const void* gy, int64_t R, int C, const float* mean, const float* invstd,
+                               const float* gamma, const float* beta, float slope, float* gweight, float* gbias,
+                               void* workspace, void* fold_scratch, hipStream_t st, const float** dsum_out) {
+    return fgnn_bn_backward_sums(x, gy, R, C, FGNN_BF16, mean, invstd, gamma, beta, slope, gweight, gbias, workspace, fold_scratch, st,
+                                 nullptr, dsum_out);
+}
+
+// gx, and gweight / gbias (ACCUMULATED into, may be NULL): a reducing launch (its last workgroup finalises the sums) + the
+// element-wise pass
 extern "C" int fgnn_bn_backward(const void* x, const void* gy, void* gx, int64_t R, int C, int dtype,
                                 const float* mean, const float* invstd, const float* gamma, const float* beta,
                                 float slope, float* gweight, float* gbias, void* workspace,
-                                int64_t workspace_bytes, fgnn_stream_t stream) {
-    BnParams p = {};
-    int grid;
+                                int64_t workspace_bytes, void* fold_scratch, fgnn_stream_t stream) {
     if (!x || !gy || !gx || !mean || !invstd || !gamma || !beta || !workspace)
         FGNN_FAIL(FGNN_EINVAL, "bn_backward: null pointer");
-    if (bn_plan(R, C, dtype, &p, &grid)) FGNN_FAIL(FGNN_EUNSUPPORTED, "bn: C=%d not a supported channel count", C);
     if (workspace_bytes < fgnn_bn_workspace_bytes(R, C)) FGNN_FAIL(FGNN_EINVAL, "bn: workspace too small");
-    float* ws = (float*)workspace;
-    float* dsum = ws + (int64_t)BN_MAXPART * 2 * C;
     hipStream_t st = (hipStream_t)stream;
-    p.x = x; p.gy = gy; p.out = gx; p.ws = ws; p.a = mean; p.b = invstd; p.gamma = gamma; p.beta = beta;
-    p.slope = slope; p.dsum_scale = 1.0f / (float)R; p.dbeta = dsum; p.dgamma = dsum + C;
-    if (dtype == FGNN_F32) hipLaunchKernelGGL((bn_reduce_kernel<float, 1>), dim3(grid), dim3(BN_THREADS), 0, st, p);
-    else hipLaunchKernelGGL((bn_reduce_kernel<bf16_t, 1>), dim3(grid), dim3(BN_THREADS), 0, st, p);
-    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((C + BN_FC - 1) / BN_FC), dim3(256), 0, st, ws, grid, C, dsum, gweight, gbias);
+    BnParams p;
+    if (fgnn_bn_backward_sums(x, gy, R, C, dtype, mean, invstd, gamma, beta, slope, gweight, gbias, workspace, fold_scratch, st, &p, nullptr))
+        FGNN_FAIL(FGNN_EUNSUPPORTED, "bn: C=%d not a supported channel count", C);
     int agrid;
     BnParams pa = p;
+    pa.out = gx;
+    pa.fold.tickets = nullptr;
     (void)bn_plan(R, C, dtype, &pa, &agrid, bn_apply_grid());   // same fields, finer row split
     if (dtype == FGNN_F32) hipLaunchKernelGGL((bn_apply_kernel<float, 1>), dim3(agrid), dim3(BN_THREADS), 0, st, pa);
     else hipLaunchKernelGGL((bn_apply_kernel<bf16_t, 1>), dim3(agrid), dim3(BN_THREADS), 0, st, pa);
@@ -414,26 +466,8 @@ extern "C" int fgnn_bn_backward(const void* x, const void* gy, void* gx, int64_t
     return FGNN_OK;
 }
 
-// The reduction half of fgnn_bn_backward (bf16): per-channel dbeta / dgamma into workspace (returned through `dsum`:
-// [2][C] floats) and ACCUMULATED into gweight / gbias.  For callers that fuse the element-wise half with something else
-// (csrc/block_tail.hip: BatchNorm1's input gradient + conv1's input gradient in one pass).  Host-side helper, not C ABI.
-int fgnn_bn_backward_sums_bf16(const void* x, const void* gy, int64_t R, int C, const float* mean, const float* invstd,
-                               const float* gamma, const float* beta, float slope, float* gweight, float* gbias,
-                               void* workspace, hipStream_t st, const float** dsum_out) {
-    BnParams p = {};
-    int grid;
-    if (bn_plan(R, C, FGNN_BF16, &p, &grid)) return -1;
-    float* ws = (float*)workspace;
-    float* dsum = ws + (int64_t)BN_MAXPART * 2 * C;
-    p.x = x; p.gy = gy; p.out = nullptr; p.ws = ws; p.a = mean; p.b = invstd; p.gamma = gamma; p.beta = beta;
-    p.slope = slope; p.dsum_scale = 1.0f / (float)R; p.dbeta = dsum; p.dgamma = dsum + C;
-    hipLaunchKernelGGL((bn_reduce_kernel<bf16_t, 1>), dim3(grid), dim3(BN_THREADS), 0, st, p);
-    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((C + BN_FC - 1) / BN_FC), dim3(256), 0, st, ws, grid, C, dsum, gweight, gbias);
-    *dsum_out = dsum;
-    return 0;
-}
-
 // backward finaliser for partials of (sum g, sum g * x) with the RAW x: dbeta = S0, dgamma = invstd (S1 - mean S0)
+// (FGNN_SEPARATE_FINALISERS=1 only: csrc/block_tail.hip's grad kernel finalises its own)
 __global__ __launch_bounds__(256) void bn_bwd_final_raw_kernel(const float* ws, int nwg, int C, const float* mean,
                                                                const float* invstd, float* dsum, float* gweight, float* gbias) {
     const int c = blockIdx.x * BN_FC + (threadIdx.x & (BN_FC - 1)), pg = threadIdx.x / BN_FC;
@@ -447,27 +481,29 @@ __global__ __launch_bounds__(256) void bn_bwd_final_raw_kernel(const float* ws, 
     if (gweight) gweight[c] += (float)dg;
 }
 
-// fgnn_bn_backward without its reduction pass: somebody else (csrc/block_tail.hip's grad kernel) already left per-workgroup
-// partials [npartials][2][C] of (sum g, sum g * x), g = gy * act'(pre), x raw.  workspace: >= 2 * C floats.
-extern "C" int fgnn_bn_backward_partials(const void* x, const void* gy, void* gx, int64_t R, int C, int dtype,
-                                         const float* mean, const float* invstd, const float* gamma, const float* beta,
-                                         float slope, float* gweight, float* gbias, const float* partials, int npartials,
-                                         void* workspace, fgnn_stream_t stream) {
-    BnParams p = {};
-    int grid;
-    if (!x || !gy || !gx || !mean || !invstd || !gamma || !beta || !partials || !workspace)
-        FGNN_FAIL(FGNN_EINVAL, "bn_backward_partials: null pointer");
-    if (npartials < 1 || npartials > BN_MAXPART) FGNN_FAIL(FGNN_EINVAL, "bn_backward_partials: bad partial count");
-    if (bn_plan(R, C, dtype, &p, &grid, bn_apply_grid())) FGNN_FAIL(FGNN_EUNSUPPORTED, "bn: C=%d not a supported channel count", C);
-    float* dsum = (float*)workspace;
-    hipStream_t st = (hipStream_t)stream;
+int fgnn_bn_bwd_final_raw_launch(const float* partials, int npartials, int C, const float* mean, const float* invstd, float* dsum,
+                                 float* gweight, float* gbias, hipStream_t st) {
     hipLaunchKernelGGL(bn_bwd_final_raw_kernel, dim3((C + BN_FC - 1) / BN_FC), dim3(256), 0, st, partials, npartials, C, mean,
                        invstd, dsum, gweight, gbias);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+// The element-wise half of the backward alone: gx = gamma invstd (g - dbeta / R - xhat dgamma / R), g = gy act'(pre), from sums
+// somebody else finalised (dsum [2][C] = dbeta, dgamma: fgnn_block_tail_backward leaves BatchNorm2's).
+extern "C" int fgnn_bn_backward_apply(const void* x, const void* gy, void* gx, int64_t R, int C, int dtype,
+                                      const float* mean, const float* invstd, const float* gamma, const float* beta,
+                                      float slope, const float* dsum, fgnn_stream_t stream) {
+    BnParams p = {};
+    int grid;
+    if (!x || !gy || !gx || !mean || !invstd || !gamma || !beta || !dsum)
+        FGNN_FAIL(FGNN_EINVAL, "bn_backward_apply: null pointer");
+    if (bn_plan(R, C, dtype, &p, &grid, bn_apply_grid())) FGNN_FAIL(FGNN_EUNSUPPORTED, "bn: C=%d not a supported channel count", C);
+    hipStream_t st = (hipStream_t)stream;
     p.x = x; p.gy = gy; p.out = gx; p.a = mean; p.b = invstd; p.gamma = gamma; p.beta = beta;
     p.slope = slope; p.dsum_scale = 1.0f / (float)R; p.dbeta = dsum; p.dgamma = dsum + C;
     if (dtype == FGNN_F32) hipLaunchKernelGGL((bn_apply_kernel<float, 1>), dim3(grid), dim3(BN_THREADS), 0, st, p);
     else hipLaunchKernelGGL((bn_apply_kernel<bf16_t, 1>), dim3(grid), dim3(BN_THREADS), 0, st, p);
     hipError_t e = hipGetLastError();
-    if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "bn_backward_partials launch: %s", hipGetErrorString(e));
+    if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "bn_backward_apply launch: %s", hipGetErrorString(e));
     return FGNN_OK;
 }

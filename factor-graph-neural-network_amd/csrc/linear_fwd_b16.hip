@@ -14,6 +14,7 @@
 // outputs are split over the waves of a workgroup (<= 64 output channels per wave), which then share the x rows
 // through L1.  No barriers in the streaming loop.
 #include "fgnn_common.h"
+#include "fgnn_gridfold.h"
 #include <stdlib.h>
 
 #define LF_THREADS 512
@@ -31,6 +32,8 @@ struct LfParams {
     int R, Cin, Cout;
     int CG;              // output-channel groups per workgroup (waves = CG x 8/CG row groups)
     int wt;              // W is stored transposed, [Cin][Cout] (the grad-input product gy W of a [Cout'][Cin'] weight)
+    FgnnFold fold;       // fold.tickets != NULL: the last workgroup folds the partial rows and finalises the BatchNorm statistics itself
+    fgnn_bn_final fin;
 };
 
 extern __shared__ __attribute__((aligned(16))) unsigned char lf_lds[];
@@ -155,6 +158,10 @@ __global__ __launch_bounds__(LF_THREADS) void linear_fwd_b16_kernel(const LfPara
             float s = 0.f;
             for (int g = 0; g < nrg; ++g) s += red[g * 2 * Cout + f];
             p.part[(int64_t)blockIdx.x * 2 * Cout + f] = s;
+        }
+        if (p.fold.tickets) {
+            double* sums = reinterpret_cast<double*>(lf_lds);     // (W's image is dead; the fold starts with a barrier)
+            if (fgnn_grid_fold(p.fold, sums, blockIdx.x)) fgnn_bn_final_apply(p.fin, Cout, sums);
         }
     }
 }
@@ -327,15 +334,23 @@ extern "C" int fgnn_linear_forward_partials(int64_t R, int Cin, int Cout) {
 // fgnn_linear_forward_partials(..) * 2 * Cout floats receiving per-workgroup (sum y, sum y^2) per channel —
 // feed it to fgnn_bn_finalize.  w_transposed: W is [Cin][Cout] in memory (y = x W; the grad-input product of a
 // map whose weight is [Cin][Cout] = [cout'][cin']).  Returns FGNN_EUNSUPPORTED for other shapes (callers fall back to a library GEMM).
+int fgnn_bn_finalize_launch(const float* partials, int npartials, int C, const fgnn_bn_final* fin, hipStream_t st);
+
 extern "C" int fgnn_linear_forward(const void* x, const float* W, const float* bias, void* y, int64_t R, int Cin,
-                                   int Cout, float* stats_partials, int w_transposed, fgnn_stream_t stream) {
+                                   int Cout, float* stats_partials, const fgnn_bn_final* fin, void* fold_scratch,
+                                   int w_transposed, fgnn_stream_t stream) {
     if (!x || !W || !y) FGNN_FAIL(FGNN_EINVAL, "linear_forward: null pointer");
     int CG, grid;
     if (lf_plan(R, Cin, Cout, &CG, &grid) || ((uintptr_t)x & 15) || ((uintptr_t)y & 15) || ((uintptr_t)W & 7))
         FGNN_FAIL(FGNN_EUNSUPPORTED, "linear_forward: Cin=%d Cout=%d outside the bf16 streaming kernel's family", Cin, Cout);
-    LfParams p;
+    if (fin && (!stats_partials || !fin->mean || !fin->invstd || !fin->scale || !fin->shift || fin->count != R || fin->shift_k))
+        FGNN_FAIL(FGNN_EINVAL, "linear_forward: fgnn_bn_final needs stats_partials, its outputs, count == R and no shift_k");
+    LfParams p = {};
     p.x = (const uint16_t*)x; p.W = W; p.bias = bias; p.y = (uint16_t*)y; p.part = stats_partials;
     p.R = (int)R; p.Cin = Cin; p.Cout = Cout; p.CG = CG; p.wt = w_transposed;
+    const bool inkernel = fin && fold_scratch && !fgnn_separate_finalisers();
+    if (fin) p.fin = *fin;
+    p.fold = fgnn_fold_make(stats_partials, inkernel ? fold_scratch : nullptr, grid, Cout);
     const int KS = Cin / 32;
     void* fn;
     switch (KS) {       // OTW == 4 always (64 output channels per wave); fragments stay in registers up to Cin 128
@@ -352,6 +367,8 @@ extern "C" int fgnn_linear_forward(const void* x, const float* W, const float* b
     void* args[] = {(void*)&p};
     hipError_t e = hipLaunchKernel(fn, dim3(grid), dim3(LF_THREADS), args, lds, (hipStream_t)stream);
     if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "linear_forward launch: %s", hipGetErrorString(e));
+    if (fin && !inkernel && fgnn_bn_finalize_launch(stats_partials, grid, Cout, fin, (hipStream_t)stream))
+        FGNN_FAIL(FGNN_ELAUNCH, "linear_forward finaliser launch: %s", hipGetErrorString(hipGetLastError()));
     return FGNN_OK;
 }
 
@@ -370,7 +387,7 @@ extern "C" int fgnn_linear_instnorm_forward(const void* x, const float* W, const
     if (B == 0) return FGNN_OK;
     LiParams q;
     q.lf.x = (const uint16_t*)x; q.lf.W = W; q.lf.bias = bias; q.lf.y = (uint16_t*)y; q.lf.part = nullptr;
-    q.lf.R = B * N; q.lf.Cin = Cin; q.lf.Cout = Cout; q.lf.CG = CG; q.lf.wt = 0;
+    q.lf.R = B * N; q.lf.Cin = Cin; q.lf.Cout = Cout; q.lf.CG = CG; q.lf.wt = 0; q.lf.fold = fgnn_fold_make(nullptr, nullptr, 0, Cout);
     q.zs = (uint16_t*)z; q.B = B; q.N = N; q.relu = relu; q.eps = eps;
     const int nrg = LF_WAVES / CG;
     grid = (B + nrg - 1) / nrg;

@@ -22,6 +22,7 @@
 // HBM traffic per call = x + etype + nn_idx read once, y written once, filters from L2:
 // the algorithmic bytes of SURVEY §8d.
 #include "fgnn_common.h"
+#include "fgnn_gridfold.h"
 #include <stdlib.h>
 
 struct FwdParams {
@@ -417,19 +418,48 @@ extern "C" int fgnn_mpconv_forward_stats_partials(const fgnn_mpconv_desc* d) {
                                    nullptr, nullptr, &grid) == 1 ? grid : 0;
 }
 
+// The BatchNorm finalisation of the NEXT statistics launch on this thread: fgnn_mpconv_forward_stats sets it around its call of
+// the kernel families' host entry points (b16 -> sg -> ws), whichever launches picks it up (as the inference addends travel).
+static thread_local const fgnn_bn_final* stats_pending_fin = nullptr;
+static thread_local void* stats_pending_scratch = nullptr;
+void fgnn_stats_pending(const fgnn_bn_final** fin, void** scratch) { *fin = stats_pending_fin; *scratch = stats_pending_scratch; }
+// second launch of a 64 -> 128 call: the upper 64 channels of every per-channel vector (num_batches_tracked was counted by the first)
+void fgnn_stats_upper_half(FgnnFold* fold, fgnn_bn_final* fin) {
+    if (!fold->tickets) return;
+    fold->part += 64;
+    if (fin->gamma) fin->gamma += 64;
+    if (fin->beta) fin->beta += 64;
+    if (fin->running_mean) { fin->running_mean += 64; fin->running_var += 64; }
+    fin->mean += 64; fin->invstd += 64; fin->scale += 64; fin->shift += 64;
+    if (fin->shift_k) fin->shift_k += 64;
+    fin->num_batches_tracked = nullptr;
+}
+int fgnn_bn_finalize_launch(const float* partials, int npartials, int C, const fgnn_bn_final* fin, hipStream_t st);
+
 extern "C" int fgnn_mpconv_forward_stats(const fgnn_mpconv_desc* d, const void* x, const int64_t* nn_idx,
                                          const void* etype, const float* filters, const float* bias, void* y,
-                                         uint8_t* argmax, float* stats_partials, fgnn_stream_t stream) {
+                                         uint8_t* argmax, float* stats_partials, const fgnn_bn_final* fin, void* fold_scratch,
+                                         fgnn_stream_t stream) {
     int rc = fgnn_check_desc(d);
     if (rc) return rc;
     if (!x || !nn_idx || !etype || !filters || !y || !stats_partials) FGNN_FAIL(FGNN_EINVAL, "null tensor pointer");
-    if (fgnn_mpconv_forward_stats_partials(d) == 0)
+    const int rows = fgnn_mpconv_forward_stats_partials(d);
+    if (rows == 0)
         FGNN_FAIL(FGNN_EUNSUPPORTED, "mpconv_forward_stats: this shape has no statistics epilogue");
+    if (fin && (!fin->mean || !fin->invstd || !fin->scale || !fin->shift || fin->shift_k || fin->count != (int64_t)d->B * d->M))
+        FGNN_FAIL(FGNN_EINVAL, "mpconv_forward_stats: fgnn_bn_final needs its outputs, count == B * M and no shift_k");
+    const bool inkernel = fin && fold_scratch && !fgnn_separate_finalisers();
+    stats_pending_fin = inkernel ? fin : nullptr;
+    stats_pending_scratch = inkernel ? fold_scratch : nullptr;
     rc = fgnn_mpconv_forward_b16(d, x, nn_idx, etype, filters, bias, nullptr, nullptr, y, argmax, stream, stats_partials,
                                  nullptr);
-    if (rc == 1) return FGNN_OK;
+    stats_pending_fin = nullptr;
+    stats_pending_scratch = nullptr;
     if (rc == 0) FGNN_FAIL(FGNN_EUNSUPPORTED, "mpconv_forward_stats: this shape has no statistics epilogue");
-    return rc;
+    if (rc != 1) return rc;
+    if (fin && !inkernel && fgnn_bn_finalize_launch(stats_partials, rows, d->nou, fin, (hipStream_t)stream))
+        FGNN_FAIL(FGNN_ELAUNCH, "mpconv_forward_stats finaliser launch: %s", hipGetErrorString(hipGetLastError()));
+    return FGNN_OK;
 }
 
 

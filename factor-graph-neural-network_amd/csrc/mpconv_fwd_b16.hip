@@ -15,6 +15,7 @@
 //     per (edge, channel), lanes = channels, destinations walk across the 4 waves;
 //   * next sample's x / etype / nn_idx are prefetched into registers during the current sample.
 #include "fgnn_common.h"
+#include "fgnn_gridfold.h"
 #ifndef B16_XPAD
 #define B16_XPAD 16
 #endif
@@ -54,6 +55,8 @@ struct B16Params {
     long long* prof;                      // FGNN_PROF: phase timeline of one sample of workgroup 0 (tuning only)
     int JP;                               // neighbour-list split over waves (1 = off)
     int off_xs, off_ps, off_idx, off_et, off_red;  // byte offsets into LDS
+    FgnnFold fold;                        // fold.tickets != NULL: the last workgroup finalises the BatchNorm statistics (fgnn_gridfold.h)
+    fgnn_bn_final fin;
 };
 
 extern __shared__ __attribute__((aligned(16))) unsigned char fgnn_lds_h[];
@@ -452,6 +455,10 @@ __global__ __launch_bounds__(B16_THREADS) void mpconv_fwd_b16_kernel(const B16Pa
             for (int w = 0; w < B16_WAVES; ++w) sum += red[(w * 2 + which) * 64 + c];
             if (c < nou) p.stats[((int64_t)blockIdx.x * 2 + which) * nou + c] = sum;
         }
+        if (p.fold.tickets) {
+            double* sums = reinterpret_cast<double*>(reinterpret_cast<unsigned char*>(ps) + B16_WAVES * 2 * 64 * 4);   // (past the fold's own floats)
+            if (fgnn_grid_fold(p.fold, sums, blockIdx.x)) fgnn_bn_final_apply(p.fin, nou, sums);
+        }
     }
 }
 
@@ -521,7 +528,7 @@ int fgnn_mpconv_forward_b16(const fgnn_mpconv_desc* d, const void* x, const int6
     } else {
         return 0;
     }
-    B16Params p;
+    B16Params p = {};
     p.d = *d;
     p.x = x; p.idx = nn_idx; p.et = etype; p.W = filters; p.bias = bias;
     p.pscale = post_scale; p.pshift = post_shift; p.y = y; p.argmax = argmax; p.stats = stats;
@@ -571,6 +578,13 @@ int fgnn_mpconv_forward_b16(const fgnn_mpconv_desc* d, const void* x, const int6
     int grid = 256 * wg_per_cu;
     if (grid > d->B) grid = d->B;
     if (plan_grid) { *plan_grid = grid; return 1; }
+    {   // the BatchNorm behind the operator, finalised by this launch (fgnn_mpconv_forward_stats set it for this call)
+        const fgnn_bn_final* fin = nullptr;
+        void* scratch = nullptr;
+        fgnn_stats_pending(&fin, &scratch);
+        p.fold = fgnn_fold_make(stats, (stats && fin) ? scratch : nullptr, grid, d->nou);
+        if (fin) p.fin = *fin;
+    }
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "hipFuncSetAttribute(%d B LDS): %s", lds, hipGetErrorString(e));

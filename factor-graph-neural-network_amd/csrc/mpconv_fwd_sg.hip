@@ -26,6 +26,7 @@
 // [w*DPW, (w+1)*DPW).  Per sample: x (prefetched into registers one sample ahead) -> LDS image; MFMA projection ->
 // P[N][64 ch][4 et] bf16 in LDS; barrier; gather with lane = channel; barrier.
 #include "fgnn_common.h"
+#include "fgnn_gridfold.h"
 #include <stdlib.h>
 
 typedef __bf16 sg_bf16x8 __attribute__((ext_vector_type(8)));
@@ -65,6 +66,8 @@ struct SgParams {
                                                   // over the halves of a 128-wide output (y_ld = st_ld = 128, w_ld = 512)
     long long x_sb, et_sb, y_sb;                  // elements
     long long* prof;                              // FGNN_PROF (builds with -DFGNN_ENABLE_PROF only): phase timeline
+    FgnnFold fold;                                // fold.tickets != NULL: the last workgroup finalises the BatchNorm statistics (fgnn_gridfold.h)
+    fgnn_bn_final fin;
 };
 
 extern __shared__ __attribute__((aligned(16))) unsigned char sg_lds[];
@@ -378,6 +381,10 @@ __global__ __launch_bounds__(SG_THREADS, 4) void mpconv_fwd_sg_kernel(const SgPa
             for (int w = 0; w < SG_WAVES; ++w) sum += red[((w * 2 + which) * NPASS + (c >> 6)) * 64 + (c & 63)];
             p.stats[((int64_t)blockIdx.x * 2 + which) * p.st_ld + c] = sum;
         }
+        if (p.fold.tickets) {
+            double* sums = reinterpret_cast<double*>(sg_lds + SG_WAVES * 2 * NPASS * 64 * 4);     // (past the fold's own floats)
+            if (fgnn_grid_fold(p.fold, sums, blockIdx.x)) fgnn_bn_final_apply(p.fin, NOU, sums);
+        }
     }
 }
 
@@ -403,6 +410,8 @@ static void* sg_pick_width(int nin, int nou, int mode) {
 int fgnn_mpconv_forward_ws(const fgnn_mpconv_desc* d, const void* x, const int64_t* nn_idx, const void* etype,
                            const float* filters, const float* bias, const float* post_scale, const float* post_shift,
                            void* y, uint8_t* argmax, fgnn_stream_t stream, float* stats, int* plan_grid, int mode, int split);
+void fgnn_stats_pending(const fgnn_bn_final** fin, void** scratch);
+void fgnn_stats_upper_half(FgnnFold* fold, fgnn_bn_final* fin);
 
 // Same contract as fgnn_mpconv_forward_b16 (mpconv_fwd_b16.hip): 1 = launched, 0 = shape outside this kernel's family,
 // < 0 = error; stats / plan_grid as there.
@@ -456,13 +465,20 @@ int fgnn_mpconv_forward_sg(const fgnn_mpconv_desc* d, const void* x, const int64
     int grid = 256 * 2;
     if (grid > d->B) grid = d->B;
     if (plan_grid) { *plan_grid = grid; return 1; }
-    SgParams p;
+    SgParams p = {};
     p.x = static_cast<const unsigned short*>(x); p.idx = nn_idx; p.et = static_cast<const unsigned short*>(etype);
     p.W = filters; p.bias = bias; p.pscale = post_scale; p.pshift = post_shift;
     p.y = static_cast<unsigned short*>(y); p.argmax = argmax; p.stats = stats;
     p.B = d->B; p.N = d->N; p.M = d->M; p.Npad = Npad; p.DPW = DPW; p.relu = d->relu;
     p.x_sb = d->x_sb; p.et_sb = d->et_sb; p.y_sb = d->y_sb;
     p.y_ld = d->nou; p.w_ld = d->nou * 4; p.st_ld = d->nou;
+    {   // the BatchNorm behind the operator, finalised by this launch (fgnn_mpconv_forward_stats set it for this call)
+        const fgnn_bn_final* fin = nullptr;
+        void* scratch = nullptr;
+        fgnn_stats_pending(&fin, &scratch);
+        p.fold = fgnn_fold_make(stats, (stats && fin) ? scratch : nullptr, grid, knou, 2 * d->nou, d->nou);
+        if (fin) p.fin = *fin;
+    }
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "hipFuncSetAttribute(%d B LDS): %s", lds, hipGetErrorString(e));
@@ -486,6 +502,7 @@ int fgnn_mpconv_forward_sg(const fgnn_mpconv_desc* d, const void* x, const int64
         if (p.pscale) { p.pscale += 64; p.pshift += 64; }
         if (p.argmax) p.argmax += 64;
         if (p.stats) p.stats += 64;
+        fgnn_stats_upper_half(&p.fold, &p.fin);
         e = hipLaunchKernel(fn, dim3(grid), dim3(SG_THREADS), args, lds, (hipStream_t)stream);
         if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "mpconv sg forward launch (upper half): %s", hipGetErrorString(e));
     }

@@ -26,6 +26,7 @@
 //     32 nodes on 2 bank groups, so the DMA's per-lane SOURCE addresses apply the XOR swizzle (chunk ^ (node >> 1 & 7))
 //     instead and the readers undo it.
 #include "fgnn_common.h"
+#include "fgnn_gridfold.h"
 #include <stdlib.h>
 #include <type_traits>
 
@@ -59,6 +60,8 @@ struct WsParams {
     int y_ld, w_ld, st_ld;                        // row strides (elements) of y / argmax, of W, of a statistics partial row
     long long x_sb, et_sb, y_sb;                  // elements
     long long* prof;                              // FGNN_PROF (builds with -DFGNN_ENABLE_PROF only): stage timeline
+    FgnnFold fold;                                // fold.tickets != NULL: the last workgroup finalises the BatchNorm statistics (fgnn_gridfold.h)
+    fgnn_bn_final fin;
 };
 
 // stage-timeline stamps (tuning aid): workgroup 0, waves 0 (producer) and 4 (consumer), one stamp per barrier
@@ -506,6 +509,10 @@ __global__ __launch_bounds__(WS_THREADS) void mpconv_fwd_ws_kernel(const WsParam
                 for (int s = 0; s < 4; ++s) sum += red[(w * 64 + ws_lane_of(s, q)) * 8 + which * 4 + i];
             p.stats[((int64_t)blockIdx.x * 2 + which) * p.st_ld + c] = sum;
         }
+        if (p.fold.tickets) {
+            double* sums = reinterpret_cast<double*>(ws_lds + 32768);     // (past the fold's own [12][64][8] floats; the images are dead)
+            if (fgnn_grid_fold(p.fold, sums, blockIdx.x)) fgnn_bn_final_apply(p.fin, 64, sums);
+        }
     }
 }
 
@@ -532,6 +539,9 @@ void fgnn_ws_set_pending_addends(const void* a0, const void* a1, const void* a2)
 }
 int fgnn_ws_pending_addends_taken(void) { return ws_pending_taken; }
 
+void fgnn_stats_pending(const fgnn_bn_final** fin, void** scratch);
+void fgnn_stats_upper_half(FgnnFold* fold, fgnn_bn_final* fin);
+
 int fgnn_mpconv_forward_ws(const fgnn_mpconv_desc* d, const void* x, const int64_t* nn_idx, const void* etype,
                            const float* filters, const float* bias, const float* post_scale, const float* post_shift,
                            void* y, uint8_t* argmax, fgnn_stream_t stream, float* stats, int* plan_grid, int mode, int split) {
@@ -555,13 +565,20 @@ int fgnn_mpconv_forward_ws(const fgnn_mpconv_desc* d, const void* x, const int64
     int grid = 256;
     if (grid > d->B) grid = d->B;
     if (plan_grid) { *plan_grid = grid; return 1; }
-    WsParams p;
+    WsParams p = {};
     p.x = static_cast<const unsigned short*>(x); p.idx = nn_idx; p.et = static_cast<const unsigned short*>(etype);
     p.W = filters; p.bias = bias; p.pscale = post_scale; p.pshift = post_shift;
     p.y = static_cast<unsigned short*>(y); p.argmax = argmax; p.stats = stats;
     p.B = d->B; p.N = d->N; p.M = d->M; p.Npad = Npad; p.relu = d->relu;
     p.x_sb = d->x_sb; p.et_sb = d->et_sb; p.y_sb = d->y_sb;
     p.y_ld = d->nou; p.w_ld = d->nou * 4; p.st_ld = d->nou;
+    {   // the BatchNorm behind the operator, finalised by this launch (fgnn_mpconv_forward_stats set it for this call)
+        const fgnn_bn_final* fin = nullptr;
+        void* scratch = nullptr;
+        fgnn_stats_pending(&fin, &scratch);
+        p.fold = fgnn_fold_make(stats, (stats && fin) ? scratch : nullptr, grid, 64, 2 * d->nou, d->nou);
+        if (fin) p.fin = *fin;
+    }
     for (int a = 0; a < 3; ++a) p.add[a] = nullptr;
     if (mode == WS_MODE_AFFINE_RELU && ws_pending_add[0]) {
         bool ok = true;
@@ -607,6 +624,7 @@ int fgnn_mpconv_forward_ws(const fgnn_mpconv_desc* d, const void* x, const int64
         if (p.pscale) { p.pscale += 64; p.pshift += 64; }
         if (p.argmax) p.argmax += 64;
         if (p.stats) p.stats += 64;
+        fgnn_stats_upper_half(&p.fold, &p.fin);
         e = hipLaunchKernel(fn, dim3(grid), dim3(WS_THREADS), args, lds, (hipStream_t)stream);
         if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "mpconv ws forward launch (upper half): %s", hipGetErrorString(e));
     }

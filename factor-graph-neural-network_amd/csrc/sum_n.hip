@@ -72,3 +72,70 @@ extern "C" int fgnn_sum_n(const void* const* inputs, int n, int64_t numel, int d
     if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "sum_n launch: %s", hipGetErrorString(e));
     return FGNN_OK;
 }
+
+
+// ----------------------------------------------------------------------------------------
+// node_sum: out[b][c] = sum_m g[b][m][c] over dense channel-fastest rows — the backward of a per-sample row BROADCAST over the
+// sample's M nodes.  The LDPC hyper-factor's message to the variables (/root/reference/train_ldpc.py:40-46,82-88: one source node,
+// hetype == 1, hnn_idx_f2v == 0) is the same C-vector for all 96 variables of a codeword, so this build carries it as [B][C] and
+// lets the consumer add it as a broadcast (fgnn_block_tail_apply / fgnn_bn_apply, addend_period); its gradient is this sum.
+// A thread owns one 16-byte channel chunk of one sample and walks the sample's M rows (f32 accumulation, one pass over g).
+// ----------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void node_sum_kernel(const T* g, T* out, int64_t B, int M, int C) {
+    constexpr int EPC = 16 / sizeof(T);
+    const int cpr = C / EPC;
+    const int64_t total = B * cpr;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+        const int64_t b = t / cpr;
+        const int ch = (int)(t - b * cpr);
+        const uint4* src = reinterpret_cast<const uint4*>(g + (b * M) * C) + ch;
+        float acc[EPC];
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) acc[e] = 0.f;
+#pragma unroll 8
+        for (int m = 0; m < M; ++m) {
+            const uint4 v = src[(int64_t)m * cpr];
+            if constexpr (sizeof(T) == 2) {
+                acc[0] += __uint_as_float(v.x << 16); acc[1] += __uint_as_float(v.x & 0xffff0000u);
+                acc[2] += __uint_as_float(v.y << 16); acc[3] += __uint_as_float(v.y & 0xffff0000u);
+                acc[4] += __uint_as_float(v.z << 16); acc[5] += __uint_as_float(v.z & 0xffff0000u);
+                acc[6] += __uint_as_float(v.w << 16); acc[7] += __uint_as_float(v.w & 0xffff0000u);
+            } else {
+                acc[0] += __uint_as_float(v.x); acc[1] += __uint_as_float(v.y);
+                acc[2] += __uint_as_float(v.z); acc[3] += __uint_as_float(v.w);
+            }
+        }
+        uint4 o;
+        if constexpr (sizeof(T) == 2) {
+            typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+            b2 h;
+            h[0] = (__bf16)acc[0]; h[1] = (__bf16)acc[1]; o.x = __builtin_bit_cast(unsigned, h);
+            h[0] = (__bf16)acc[2]; h[1] = (__bf16)acc[3]; o.y = __builtin_bit_cast(unsigned, h);
+            h[0] = (__bf16)acc[4]; h[1] = (__bf16)acc[5]; o.z = __builtin_bit_cast(unsigned, h);
+            h[0] = (__bf16)acc[6]; h[1] = (__bf16)acc[7]; o.w = __builtin_bit_cast(unsigned, h);
+        } else {
+            o = make_uint4(__float_as_uint(acc[0]), __float_as_uint(acc[1]), __float_as_uint(acc[2]), __float_as_uint(acc[3]));
+        }
+        reinterpret_cast<uint4*>(out + b * C)[ch] = o;
+    }
+}
+
+// out [B][C] = sum over the M rows of each sample of g [B][M][C] (dense, 16-byte aligned, C * elem size a multiple of 16).
+extern "C" int fgnn_node_sum(const void* g, void* out, int64_t B, int M, int C, int dtype, fgnn_stream_t stream) {
+    if (!g || !out) FGNN_FAIL(FGNN_EINVAL, "node_sum: null pointer");
+    if (dtype != FGNN_F32 && dtype != FGNN_BF16) FGNN_FAIL(FGNN_EINVAL, "node_sum: unknown dtype %d", dtype);
+    const int epc = dtype == FGNN_F32 ? 4 : 8;
+    if (B < 0 || M < 1 || C < 1 || C % epc || ((uintptr_t)g & 15) || ((uintptr_t)out & 15))
+        FGNN_FAIL(FGNN_EUNSUPPORTED, "node_sum: C must be a multiple of %d and the tensors 16-byte aligned", epc);
+    if (B == 0) return FGNN_OK;
+    int64_t grid = (B * (C / epc) + 255) / 256;
+    if (grid > 8192) grid = 8192;
+    if (dtype == FGNN_F32) hipLaunchKernelGGL(node_sum_kernel<float>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream,
+                                              (const float*)g, (float*)out, B, M, C);
+    else hipLaunchKernelGGL(node_sum_kernel<bf16_t>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream,
+                            (const bf16_t*)g, (bf16_t*)out, B, M, C);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "node_sum launch: %s", hipGetErrorString(e));
+    return FGNN_OK;
+}

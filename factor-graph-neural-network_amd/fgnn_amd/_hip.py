@@ -17,7 +17,7 @@ EXT_NONE, EXT_NEIGHBOR, EXT_DIFF = 0, 1, 2
 DESC_GETYPE_REDUCED = 0x10000
 AGG_MAX, AGG_LSE, AGG_MEAN = 0, 1, 2
 F32, BF16 = 0, 1
-ABI_VERSION = 7              # include/fgnn_hip.h: FGNN_ABI_VERSION (checked before any symbol is bound)
+ABI_VERSION = 8              # include/fgnn_hip.h: FGNN_ABI_VERSION (checked before any symbol is bound)
 EUNSUPPORTED = -3            # FGNN_EUNSUPPORTED: shape outside a kernel's family (callers fall back)
 
 AGG_CODES = {'max': AGG_MAX, 'softmax': AGG_LSE, 'mean': AGG_MEAN}
@@ -26,7 +26,7 @@ EXPORTS = ('fgnn_mpconv_forward', 'fgnn_mpconv_backward', 'fgnn_mpconv_forward_l
            'fgnn_mpconv_backward_workspace_bytes', 'fgnn_mpconv_backward_reduces_getype', 'fgnn_linear_wgrad', 'fgnn_linear_wgrad_workspace_bytes',
            'fgnn_instnorm_forward', 'fgnn_instnorm_backward', 'fgnn_bn_supported', 'fgnn_bn_workspace_bytes',
            'fgnn_bn_stats', 'fgnn_bn_finalize', 'fgnn_bn_apply', 'fgnn_bn_backward',
-           'fgnn_linear_forward', 'fgnn_linear_forward_partials', 'fgnn_linear_instnorm_forward', 'fgnn_sum_n', 'fgnn_flat_adam', 'fgnn_flat_adam_dev', 'fgnn_edge_mlp_forward', 'fgnn_edge_mlp_workspace_bytes', 'fgnn_edge_mlp_backward', 'fgnn_ldpc_encode', 'fgnn_ldpc_channel_features', 'fgnn_ldpc_channel_features_rng', 'fgnn_ldpc_decode', 'fgnn_mpconv_block_forward', 'fgnn_mpconv_block_forward_fanout', 'fgnn_mpconv_block_forward_fanin', 'fgnn_factor_layer_forward', 'fgnn_factor_layer_param_count', 'fgnn_mpconv_forward_stats', 'fgnn_mpconv_forward_stats_partials', 'fgnn_block_tail_partials', 'fgnn_block_tail_stats', 'fgnn_block_tail_apply', 'fgnn_block_tail_backward', 'fgnn_block_tail_backward_partials', 'fgnn_bn_finalize_shifted', 'fgnn_bn_backward_partials', 'fgnn_block_head_backward',
+           'fgnn_linear_forward', 'fgnn_linear_forward_partials', 'fgnn_linear_instnorm_forward', 'fgnn_sum_n', 'fgnn_flat_adam', 'fgnn_flat_adam_dev', 'fgnn_edge_mlp_forward', 'fgnn_edge_mlp_workspace_bytes', 'fgnn_edge_mlp_backward', 'fgnn_ldpc_encode', 'fgnn_ldpc_channel_features', 'fgnn_ldpc_channel_features_rng', 'fgnn_ldpc_decode', 'fgnn_mpconv_block_forward', 'fgnn_mpconv_block_forward_fanout', 'fgnn_mpconv_block_forward_fanin', 'fgnn_factor_layer_forward', 'fgnn_factor_layer_param_count', 'fgnn_mpconv_forward_stats', 'fgnn_mpconv_forward_stats_partials', 'fgnn_block_tail_partials', 'fgnn_block_tail_stats', 'fgnn_block_tail_apply', 'fgnn_block_tail_backward', 'fgnn_block_tail_backward_partials', 'fgnn_bn_backward_apply', 'fgnn_block_head_backward', 'fgnn_node_sum',
            'fgnn_mpconv_algorithmic_bytes', 'fgnn_mpconv_forward_addends', 'fgnn_last_error', 'fgnn_last_kernel', 'fgnn_abi_version')
 
 
@@ -36,6 +36,30 @@ class MPConvDesc(ctypes.Structure):
                [(n, ctypes.c_int64) for n in
                 ('x_sb', 'x_sc', 'x_sn', 'idx_sb', 'idx_sm', 'idx_sk',
                  'et_sb', 'et_se', 'et_sm', 'et_sk', 'y_sb', 'y_sc', 'y_sm')]
+
+
+class BnFinal(ctypes.Structure):
+    """include/fgnn_hip.h: fgnn_bn_final — what a statistics-producing launch finalises in its last workgroup."""
+    _fields_ = [(n, ctypes.c_void_p) for n in ('gamma', 'beta', 'running_mean', 'running_var', 'num_batches_tracked',
+                                               'mean', 'invstd', 'scale', 'shift', 'shift_k')] + \
+               [('count', ctypes.c_int64), ('population', ctypes.c_int64), ('momentum', ctypes.c_float), ('eps', ctypes.c_float)]
+
+
+FOLD_SCRATCH_BYTES = 512 + 64 * 512 * 8       # include/fgnn_hip.h: FGNN_FOLD_SCRATCH_BYTES
+
+
+def bn_final(stats, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, count, population=0):
+    """fgnn_bn_final for a BatchNorm whose outputs go to ``stats`` [4, C] f32 (rows: mean, invstd, scale, shift).  The caller keeps
+    the tensors alive until the launch is enqueued."""
+    f = BnFinal()
+    dp = lambda t: None if t is None else t.data_ptr()
+    f.gamma, f.beta = dp(gamma), dp(beta)
+    f.running_mean, f.running_var, f.num_batches_tracked = dp(running_mean), dp(running_var), dp(num_batches_tracked)
+    f.mean, f.invstd, f.scale, f.shift = (stats[i].data_ptr() for i in range(4))
+    f.shift_k = None
+    f.count, f.population = int(count), int(population)
+    f.momentum, f.eps = float(momentum), float(eps)
+    return f
 
 
 class FgnnHipError(RuntimeError):
@@ -70,7 +94,8 @@ def lib():
     L.fgnn_mpconv_forward_addends.restype = ctypes.c_int
     L.fgnn_mpconv_forward_addends.argtypes = [dp] + [vp] * 12
     L.fgnn_mpconv_forward_stats.restype = ctypes.c_int
-    L.fgnn_mpconv_forward_stats.argtypes = [dp] + [vp] * 9
+    fp = ctypes.POINTER(BnFinal)
+    L.fgnn_mpconv_forward_stats.argtypes = [dp] + [vp] * 8 + [fp, vp, vp]
     L.fgnn_mpconv_forward_stats_partials.restype = ctypes.c_int
     L.fgnn_mpconv_forward_stats_partials.argtypes = [dp]
     L.fgnn_mpconv_backward.restype = ctypes.c_int
@@ -98,11 +123,13 @@ def lib():
     L.fgnn_bn_workspace_bytes.restype = i64
     L.fgnn_bn_workspace_bytes.argtypes = [i64, i32]
     L.fgnn_bn_stats.restype = ctypes.c_int
-    L.fgnn_bn_stats.argtypes = [vp, i64, i32, i32, vp, vp, vp, vp, f32, f32, vp, vp, vp, vp, vp, vp, i64, vp]
+    L.fgnn_bn_stats.argtypes = [vp, i64, i32, i32, fp, vp, i64, vp, vp]
     L.fgnn_bn_finalize.restype = ctypes.c_int
-    L.fgnn_bn_finalize.argtypes = [vp, i32, i64, i32, vp, vp, vp, vp, f32, f32, vp, vp, vp, vp, vp, vp]
+    L.fgnn_bn_finalize.argtypes = [vp, i32, i32, fp, vp]
     L.fgnn_linear_forward.restype = ctypes.c_int
-    L.fgnn_linear_forward.argtypes = [vp, vp, vp, vp, i64, i32, i32, vp, i32, vp]
+    L.fgnn_linear_forward.argtypes = [vp, vp, vp, vp, i64, i32, i32, vp, fp, vp, i32, vp]
+    L.fgnn_node_sum.restype = ctypes.c_int
+    L.fgnn_node_sum.argtypes = [vp, vp, i64, i32, i32, i32, vp]
     L.fgnn_linear_instnorm_forward.restype = ctypes.c_int
     L.fgnn_linear_instnorm_forward.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, vp]
     L.fgnn_linear_forward_partials.restype = ctypes.c_int
@@ -143,23 +170,22 @@ def lib():
     L.fgnn_block_tail_partials.restype = ctypes.c_int
     L.fgnn_block_tail_partials.argtypes = [i64, i32]
     L.fgnn_block_tail_stats.restype = ctypes.c_int
-    L.fgnn_block_tail_stats.argtypes = [vp, vp, vp, f32, vp, vp, i64, i32, vp, vp]
+    L.fgnn_block_tail_stats.argtypes = [vp, vp, vp, f32, vp, vp, i64, i32, vp, fp, vp, vp]
     L.fgnn_block_tail_apply.restype = ctypes.c_int
-    L.fgnn_block_tail_apply.argtypes = [vp, vp, vp, f32, vp, vp, vp, vp, f32, vp, vp, vp, vp, vp, i64, i32, vp]
+    L.fgnn_block_tail_apply.argtypes = [vp, vp, vp, f32, vp, vp, vp, vp, f32, vp, vp, vp, vp, vp, vp, i64, i32, vp]
     L.fgnn_block_tail_backward.restype = ctypes.c_int
-    L.fgnn_block_tail_backward.argtypes = [vp, vp, vp, f32, vp, vp, vp, vp, vp, vp, vp, f32, vp, vp, vp, vp, vp, vp, i64, i32, vp, i64, vp]
+    L.fgnn_block_tail_backward.argtypes = [vp, vp, vp, f32, vp, vp, vp, vp, vp, vp, vp, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp,
+                                           i64, i32, vp, i64, vp, vp]
     L.fgnn_block_tail_backward_partials.restype = ctypes.c_int
     L.fgnn_block_tail_backward_partials.argtypes = [i64, i32]
     L.fgnn_block_head_backward.restype = ctypes.c_int
-    L.fgnn_block_head_backward.argtypes = [vp, vp, vp, vp, vp, vp, f32, vp, vp, vp, vp, vp, i64, i32, vp, i64, vp]
-    L.fgnn_bn_finalize_shifted.restype = ctypes.c_int
-    L.fgnn_bn_finalize_shifted.argtypes = [vp, i32, i64, i32, vp, vp, vp, vp, vp, f32, f32, vp, vp, vp, vp, vp, vp]
-    L.fgnn_bn_backward_partials.restype = ctypes.c_int
-    L.fgnn_bn_backward_partials.argtypes = [vp, vp, vp, i64, i32, i32, vp, vp, vp, vp, f32, vp, vp, vp, i32, vp, vp]
+    L.fgnn_block_head_backward.argtypes = [vp, vp, vp, vp, vp, vp, f32, vp, vp, vp, vp, vp, i64, i32, vp, i64, vp, vp]
+    L.fgnn_bn_backward_apply.restype = ctypes.c_int
+    L.fgnn_bn_backward_apply.argtypes = [vp, vp, vp, i64, i32, i32, vp, vp, vp, vp, f32, vp, vp]
     L.fgnn_bn_apply.restype = ctypes.c_int
-    L.fgnn_bn_apply.argtypes = [vp, vp, i64, i32, i32, vp, vp, f32, vp, vp, vp, vp]
+    L.fgnn_bn_apply.argtypes = [vp, vp, i64, i32, i32, vp, vp, f32, vp, vp, vp, vp, vp]
     L.fgnn_bn_backward.restype = ctypes.c_int
-    L.fgnn_bn_backward.argtypes = [vp, vp, vp, i64, i32, i32, vp, vp, vp, vp, f32, vp, vp, vp, i64, vp]
+    L.fgnn_bn_backward.argtypes = [vp, vp, vp, i64, i32, i32, vp, vp, vp, vp, f32, vp, vp, vp, i64, vp, vp]
     L.fgnn_last_error.restype = ctypes.c_char_p
     L.fgnn_last_kernel.restype = ctypes.c_char_p
     L.fgnn_abi_version.restype = ctypes.c_int

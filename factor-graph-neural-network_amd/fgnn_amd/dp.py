@@ -72,6 +72,14 @@ class FlatGradBucket:
         from . import ops
         if any(ops._DEFERRED.values()):
             ops.flush_deferred()
+        # flush_deferred issues each launch on ITS stream; the zeroing below runs on the current one: join them first (the
+        # engine's end-of-pass join never ran for a pass that died), or a parked kernel could still add behind the memset
+        if ops._DEFER_ISSUED and self.flat.is_cuda:
+            cur = torch.cuda.current_stream(self.flat.device)
+            for st in ops._DEFER_ISSUED:
+                if st != cur:
+                    cur.wait_stream(st)
+            ops._DEFER_ISSUED.clear()
         self.flat.zero_()
 
     @property

@@ -18,10 +18,13 @@ What the switch cannot give an unchanged script is the hipGraph replay (``graph.
 eager step is launch-bound at ~25-30 ms.  ``disable_fast_path()`` undoes both patches (modules already optimised stay so).
 """
 import os
+import threading
+import weakref
 
 import torch
 
 _STATE = {'hook': None, 'adam': None}
+_SEEN = weakref.WeakSet()      # modules the global hook has looked at (kept here, not as an attribute on every nn.Module of the process)
 
 
 def _is_edge_model(m):
@@ -30,6 +33,34 @@ def _is_edge_model(m):
     c1, act, c2 = m[0], m[1], m[2]
     ok = lambda c: isinstance(c, torch.nn.Conv2d) and c.kernel_size == (1, 1) and c.stride == (1, 1) and c.groups == 1
     return ok(c1) and isinstance(act, torch.nn.ReLU) and ok(c2) and c1.out_channels == c2.in_channels
+
+
+_AUTOCAST = threading.local()      # per thread: the autocast contexts the fast modules' pre-hooks opened (closed by their post-hooks)
+
+
+def _fast_pre(module, args, kwargs):
+    """Forward pre-hook of an optimised module: f32 CUDA inputs -> bf16, and the call runs under bf16 autocast (closed by
+    ``_fast_post``).  Hooks — module-level functions, registered on the module — instead of a replaced ``forward``: the module
+    stays picklable and ``copy.deepcopy``-able (a closure installed as ``module.forward`` is neither)."""
+    cast = lambda t: t.to(torch.bfloat16) if torch.is_tensor(t) and t.is_cuda and t.dtype == torch.float32 else t
+    ctx = torch.autocast('cuda', dtype=torch.bfloat16)
+    ctx.__enter__()
+    stack = getattr(_AUTOCAST, 'stack', None)
+    if stack is None:
+        stack = _AUTOCAST.stack = []
+    stack.append((id(module), ctx))
+    return tuple(cast(a) for a in args), {k: cast(v) for k, v in kwargs.items()}
+
+
+def _fast_post(module, args, kwargs, out):
+    """Closes the autocast region (also when the forward raised: registered with ``always_call``); bf16 outputs -> f32."""
+    stack = getattr(_AUTOCAST, 'stack', None)
+    if stack and stack[-1][0] == id(module):      # (not at the call during which the hooks were registered: its pre-hook never ran)
+        stack.pop()[1].__exit__(None, None, None)
+    back = lambda t: t.float() if torch.is_tensor(t) and t.dtype == torch.bfloat16 else t
+    if isinstance(out, (tuple, list)):
+        return tuple(back(o) for o in out)
+    return back(out)
 
 
 def fast_path(module):
@@ -45,31 +76,34 @@ def fast_path(module):
             new[0].weight, new[0].bias, new[2].weight, new[2].bias = c1.weight, c1.bias, c2.weight, c2.bias      # the SAME Parameters
             new.train(child.training)
             setattr(module, name, new)
-    inner = module.forward
-
-    def fast_forward(*args, **kwargs):
-        cast = lambda t: t.to(torch.bfloat16) if torch.is_tensor(t) and t.is_cuda and t.dtype == torch.float32 else t
-        back = lambda t: t.float() if torch.is_tensor(t) and t.dtype == torch.bfloat16 else t
-        with torch.autocast('cuda', dtype=torch.bfloat16):
-            out = inner(*[cast(a) for a in args], **{k: cast(v) for k, v in kwargs.items()})
-        return tuple(back(o) for o in out) if isinstance(out, (tuple, list)) else back(out)
-
-    module.forward = fast_forward
+    module.register_forward_pre_hook(_fast_pre, with_kwargs=True)
+    module.register_forward_hook(_fast_post, with_kwargs=True, always_call=True)
     return module
 
 
 def _pre_hook(module, args):
     from .mpnn import FactorNN
-    if getattr(module, '_fgnn_fast_seen', False):      # one look per module: the hook runs in front of every module call
+    if module in _SEEN:            # one look per module: the hook runs in front of every module call
         return None
-    module._fgnn_fast_seen = True
+    _SEEN.add(module)
     if not isinstance(module, FactorNN) and any(isinstance(c, FactorNN) for c in module.children()):
-        fast_path(module)          # (this call still runs the old forward — torch bound it before the hooks; the next one is fast)
+        fast_path(module)          # (the hooks registered here take effect from the NEXT call: this one's hook list is already fixed)
     return None
 
 
 class FastAdam(torch.optim.Optimizer):
-    """``torch.optim.Adam``'s update (no amsgrad) on flat parameter / gradient buffers: one kernel per step."""
+    """``torch.optim.Adam``'s update (no amsgrad) on flat parameter / gradient buffers: one kernel per step.
+
+    Persistence (``/root/reference/train_ldpc.py:179-181,187`` saves and restores ``optimizer.state_dict()``): the moments and
+    the step count live in ``self.flat`` (``dp.FlatAdam``), not in ``self.state``; ``state_dict()`` exports them in STOCK Adam's
+    layout — per parameter ``step`` (a float32 scalar tensor), ``exp_avg``, ``exp_avg_sq`` (clones, shaped like the parameter) — and
+    ``load_state_dict()`` accepts that layout, whether it was written by this class or by ``torch.optim.Adam`` itself, and
+    copies it into the flat buffers.  A checkpoint therefore moves freely between the two.
+
+    Differences from the stock class that remain: the update is DENSE — every parameter of the flat buffer is updated every
+    step with whatever its gradient slice holds (zero for a parameter the loss did not reach), whereas ``torch.optim.Adam``
+    skips parameters whose ``.grad`` is None; with ``weight_decay`` != 0 an unused parameter therefore decays here and not
+    there.  One hyper-parameter set for all parameters (the first group's); ``zero_grad(set_to_none=True)`` zeroes."""
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
         from .dp import FlatAdam, FlatGradBucket
@@ -93,15 +127,82 @@ class FastAdam(torch.optim.Optimizer):
     def zero_grad(self, set_to_none=False):          # the gradients are views of one buffer: never set to None
         self.bucket.zero()
 
+    def _slices(self):
+        off = 0
+        for q in self.bucket.params:
+            n = q.numel()
+            yield q, off, n
+            off += n
+
+    @torch.no_grad()
+    def state_dict(self):
+        """Stock Adam's layout (see the class docstring).  Before the first step the state is empty, as the stock class's is."""
+        t = self.flat.t
+        self.state.clear()
+        if t > 0:
+            for q, off, n in self._slices():
+                self.state[q] = {'step': torch.tensor(float(t), dtype=torch.float32),
+                                 'exp_avg': self.flat.exp_avg[off:off + n].view_as(q).clone(),
+                                 'exp_avg_sq': self.flat.exp_avg_sq[off:off + n].view_as(q).clone()}
+        try:
+            return super().state_dict()
+        finally:
+            self.state.clear()                       # the live state stays in the flat buffers only
+
+    @torch.no_grad()
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)          # (validates group sizes, restores the hyper-parameters, casts to the parameters' device)
+        steps = set()
+        for q, off, n in self._slices():
+            st = self.state.get(q)
+            if not st:                               # no entry: a parameter the saved optimizer never stepped
+                self.flat.exp_avg[off:off + n].zero_()
+                self.flat.exp_avg_sq[off:off + n].zero_()
+                continue
+            if st.get('amsgrad') or 'max_exp_avg_sq' in st:
+                raise ValueError('FastAdam cannot resume an amsgrad checkpoint')
+            self.flat.exp_avg[off:off + n].copy_(st['exp_avg'].reshape(-1))
+            self.flat.exp_avg_sq[off:off + n].copy_(st['exp_avg_sq'].reshape(-1))
+            steps.add(int(float(st['step'])))
+        if len(steps) > 1:
+            raise ValueError('FastAdam keeps ONE step count for all parameters; the checkpoint holds %s' % sorted(steps))
+        self.flat.t = steps.pop() if steps else 0
+        self.state.clear()
+        g = self.param_groups[0]
+        self.flat.lr, self.flat.betas, self.flat.eps, self.flat.weight_decay = g['lr'], g['betas'], g['eps'], g['weight_decay']
+
+
+def _wants_fast_adam(params, amsgrad, kw):
+    """Every parameter a trainable CUDA f32 tensor, one group, nothing exotic asked for."""
+    plain = bool(params) and all(torch.is_tensor(p) for p in params)
+    return (plain and not amsgrad and not kw and
+            all(p.is_cuda and p.dtype == torch.float32 and p.requires_grad for p in params))
+
 
 def _adam_factory(stock):
-    def Adam(params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=False, **kw):
-        """torch.optim.Adam, or FastAdam when every parameter is a CUDA f32 tensor (and nothing exotic is asked for)."""
-        params = list(params)
-        plain = bool(params) and all(torch.is_tensor(p) for p in params)
-        if plain and not amsgrad and not kw and all(p.is_cuda and p.dtype == torch.float32 for p in params):
-            return FastAdam(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
-        return stock(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=amsgrad, **kw)
+    """A CLASS that stands in for ``torch.optim.Adam`` while the fast path is on: constructing it returns ``FastAdam`` where
+    that applies (see ``_wants_fast_adam``; frozen parameters, parameter groups, amsgrad / fused / foreach requests keep the
+    stock class) and a stock Adam otherwise.  It stays a type — ``class MyAdam(torch.optim.Adam)`` and
+    ``isinstance(opt, torch.optim.Adam)`` keep working (a ``FastAdam`` passes the check too)."""
+
+    class _Meta(type(stock)):
+        def __instancecheck__(cls, obj):
+            return isinstance(obj, FastAdam) or type.__instancecheck__(cls, obj) or isinstance(obj, stock)
+
+    class Adam(stock, metaclass=_Meta):
+        __doc__ = stock.__doc__
+
+        def __new__(cls, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=False, **kw):
+            if cls is Adam:                          # (a user's subclass is built as what it is)
+                params = list(params)
+                if _wants_fast_adam(params, amsgrad, kw):
+                    return FastAdam(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)      # not a cls instance: __init__ is skipped
+                obj = stock.__new__(stock)
+                stock.__init__(obj, params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=amsgrad, **kw)
+                return obj                           # a plain stock instance (again not a cls instance)
+            return stock.__new__(cls)
+
+    Adam.__name__, Adam.__qualname__ = 'Adam', 'Adam'
     Adam.stock = stock
     return Adam
 

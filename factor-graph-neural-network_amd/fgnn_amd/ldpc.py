@@ -10,6 +10,7 @@ import numpy as np
 import torch
 
 from .mpnn.assemblies import FactorNN
+from .mpnn.pointwise import cast_cached
 from .edge_mlp import EdgeMLP
 from .tables import LdpcGraph
 
@@ -39,6 +40,21 @@ class LDPCModel(torch.nn.Module):
             torch.nn.Linear(64, 128), torch.nn.BatchNorm1d(128), torch.nn.ReLU(),
             torch.nn.Linear(128, 128), torch.nn.ReLU(), torch.nn.Linear(128, 1), torch.nn.ReLU())
 
+    def _fanout_weights(self, dt):
+        """``hetype_f2v`` [1, 1, 96, 1] in the activations' dtype.  When its 96 weights are equal (they are ones unless a checkpoint
+        says otherwise; checked on the device ONCE per version of the frozen parameter, remembered on it) the tensor handed on has a
+        stride-0 node axis: that is how the operator knows — also while a hipGraph is being captured — that the hyper-factor sends
+        every variable the same message and computes it once per codeword (ops.single_source_fanout)."""
+        p = self.hetype_f2v
+        w = cast_cached(p, dt)
+        memo = getattr(p, '_fgnn_equal_weights', None)
+        if memo is None or memo[0] != (p._version, p.data_ptr()):
+            if p.is_cuda and torch.cuda.is_current_stream_capturing():
+                return w
+            memo = ((p._version, p.data_ptr()), bool((p == p[:, :, :1, :]).all().item()))
+            p._fgnn_equal_weights = memo
+        return w[:, :, :1, :].expand(-1, -1, p.shape[2], -1) if memo[1] else w
+
     def forward(self, node_feature, hop_feature, nn_idx_f2v, nn_idx_v2f, efeature_f2v,
                 efeature_v2f):
         B = node_feature.shape[0]
@@ -52,8 +68,8 @@ class LDPCModel(torch.nn.Module):
             node_feature, [hop_feature, hyper_in],
             [nn_idx_f2v, self.hnn_idx_f2v.expand(B, -1, -1)],
             [nn_idx_v2f, self.hnn_idx_v2f.expand(B, -1, -1)],
-            [etype_f2v, self.hetype_f2v.to(dt).expand(B, -1, -1, -1)],
-            [etype_v2f, self.hetype_v2f.to(dt).expand(B, -1, -1, -1)])
+            [etype_f2v, self._fanout_weights(dt).expand(B, -1, -1, -1)],
+            [etype_v2f, cast_cached(self.hetype_v2f, dt).expand(B, -1, -1, -1)])
         if self.with_residual:
             res = res + node_feature[:, :1, :, :]
         res = res.reshape(B, 96)

@@ -42,7 +42,7 @@ class iid_mapping_bn(torch.nn.Module):
         self.main = _conv_norm_act(nin, nout, BatchNormAct2d(nout, slope=0.0), torch.nn.Identity(), bias)
 
     def forward(self, x):
-        return self.main[1](self.main[0](x, want_stats=self.training))
+        return self.main[1](self.main[0](x, bn=self.main[1]))
 
 
 class iid_mapping_in(torch.nn.Module):
@@ -52,6 +52,10 @@ class iid_mapping_in(torch.nn.Module):
         self.main = _conv_norm_act(nin, nout, NodeInstanceNorm(relu=True), torch.nn.Identity(), bias)
 
     def forward(self, x):
+        if x.dim() == 4 and x.shape[2] * x.shape[3] == 1:
+            # a single node (the LDPC hyper-factor's f2f map, factor_mpnn_sp.py:77,140): InstanceNorm of one value is exactly 0
+            # whatever the map produced, ReLU(0) = 0, and no gradient reaches the map — nothing to launch
+            return x.new_zeros((x.shape[0], self.main[0].out_channels, 1, 1))
         y = self._fused(x)
         return self.main(x) if y is None else y
 
@@ -163,24 +167,15 @@ class _BlockHead(torch.autograd.Function):
         from . import pointwise
         L = _hip.lib()
         P = _hip._ptr
-        z1 = pointwise.hip_linear(rows, weight, bias, want_stats=True)
+        spec = (bn_w, bn_b, rm, rv, nbt, momentum, eps)
+        z1 = pointwise.hip_linear(rows, weight, bias, bn=spec)          # the map's last workgroup finalises BatchNorm1's statistics
         if z1 is None:
             raise _hip.FgnnHipError('fused block head: the 1x1 map is outside csrc/linear_fwd_b16.hip (checked by the caller)')
-        R, dev = rows.shape[0], rows.device
-        stats = torch.empty((4, 64), device=dev, dtype=torch.float32)       # mean, invstd, scale, shift
-        ws = ops._workspace(dev, int(L.fgnn_bn_workspace_bytes(R, 64)))
-        npart = pointwise.take_pending_stats(z1)
-        if npart:
-            _hip.check(L.fgnn_bn_finalize(P(ws), npart, R, 64, P(bn_w), P(bn_b), P(rm), P(rv), momentum, eps, P(stats[0]), P(stats[1]),
-                                          P(stats[2]), P(stats[3]), P(nbt), _hip.stream_ptr()))
-        else:
-            ops.timed('bn_stats (reduce + finalise)', z1.numel() * 2, lambda: _hip.check(L.fgnn_bn_stats(
-                P(z1), R, 64, _hip.BF16, P(bn_w), P(bn_b), P(rm), P(rv), momentum, eps, P(stats[0]), P(stats[1]), P(stats[2]),
-                P(stats[3]), P(nbt), P(ws), ws.numel() * 4, _hip.stream_ptr())))
+        R = rows.shape[0]
+        stats = pointwise.batch_stats(z1, spec)                       # [4, 64] mean, invstd, scale, shift
         a1 = torch.empty_like(z1)
-        pointwise.note_state_change()
         ops.timed('bn_apply (forward)', 2 * z1.numel() * 2, lambda: _hip.check(L.fgnn_bn_apply(
-            P(z1), P(a1), R, 64, _hip.BF16, P(stats[2]), P(stats[3]), slope, None, None, None, _hip.stream_ptr())))
+            P(z1), P(a1), R, 64, _hip.BF16, P(stats[2]), P(stats[3]), slope, None, None, None, None, _hip.stream_ptr())))
         ctx.save_for_backward(rows, z1, stats, weight, bn_w, bn_b)
         ctx.slope = slope
         ctx.params = (weight, bias, bn_w, bn_b)
@@ -213,7 +208,7 @@ class _BlockHead(torch.autograd.Function):
         ws = ops._workspace(dev, int(L.fgnn_bn_workspace_bytes(R, 64)))
         ops.timed('block_head_backward (reduce + finalise + grad)', 2 * R * (5 * 64 + cin), lambda: _hip.check(L.fgnn_block_head_backward(
             P(z1), P(ga1), P(stats[0]), P(stats[1]), P(bn_w.detach()), P(bn_b.detach()), ctx.slope, P(weight.detach()), P(gz1), P(gx),
-            P(gw1), P(gb1), R, cin, P(ws), ws.numel() * 4, _hip.stream_ptr())), nflops=2 * R * 64 * cin)
+            P(gw1), P(gb1), R, cin, P(ws), ws.numel() * 4, P(ops._fold_scratch(dev)), _hip.stream_ptr())), nflops=2 * R * 64 * cin)
 
         def launch(rows=rows, gz1=gz1, gW=gW, gbias=gbias):
             wsw = ops._workspace(dev, int(L.fgnn_linear_wgrad_workspace_bytes(R, cin, 64)))
@@ -242,24 +237,40 @@ class _AddendRoute(torch.autograd.Function):
     profiles/r03/README.md).  No kernel runs here."""
 
     @staticmethod
-    def forward(ctx, out, *adds):
-        ctx.n = len(adds)
+    def forward(ctx, out, periods, *adds):
+        """``periods[i]`` > 1: addend i is a per-sample row [R / period, C] the apply kernel broadcast over the sample's nodes; its
+        gradient is the node sum of the output's (one pass, csrc/sum_n.hip)."""
+        ctx.periods = tuple(periods)[:len(adds)]
         return out.view_as(out)
 
     @staticmethod
     def backward(ctx, g):
-        return (g,) + (g,) * ctx.n
+        from .pointwise import node_sum
+        outs = []
+        for i, q in enumerate(ctx.periods):
+            if not ctx.needs_input_grad[2 + i]:
+                outs.append(None)
+            elif q == 1:
+                outs.append(g)
+            else:
+                ops.backward_node_begins()
+                outs.append(node_sum(g.contiguous(), q))
+        return (g, None) + tuple(outs)
 
 
 class _BlockTail(torch.autograd.Function):
     """Everything behind the message operator in a training-mode ``mp_conv_residual`` (mp_nn.py:165-175 BatchNorm + ReLU,
     mp_nn_residual.py:31-35,49-51 conv2 + BatchNorm + LeakyReLU, + the caller's addends) through csrc/block_tail.hip: the
     Cout-wide pre-BatchNorm tensor of conv2 is recomputed from the operator's 64-channel output wherever it is needed
-    (statistics, normalisation, BatchNorm3's backward sums and input gradient) instead of being stored and re-read."""
+    (statistics, normalisation, BatchNorm3's backward sums and input gradient) instead of being stored and re-read.  Every
+    reducing launch finalises its own sums (csrc/fgnn_gridfold.h): forward = statistics + apply (+ BatchNorm2's statistics pass where the
+    operator's epilogue did not bring them), backward = reduce + grad + the 64-channel BatchNorm's apply."""
 
     @staticmethod
     def forward(ctx, e, w2, b2, slope2, slope3, momentum2, eps2, momentum3, eps3, W2, bias2, w3, b3, rm2, rv2, nbt2, rm3, rv3,
-                nbt3, add0=None, add1=None, add2=None):
+                nbt3, population, add0=None, add1=None, add2=None, periods=(1, 1, 1)):
+        """``population``: rows the batch statistics stand for in the running variances (0 = R; R * m for a per-sample vector the
+        reference broadcasts over m nodes).  ``periods``: see ``_AddendRoute``."""
         import ctypes
         from .. import _hip
         from . import pointwise
@@ -267,38 +278,30 @@ class _BlockTail(torch.autograd.Function):
         P = _hip._ptr
         R, Cout = e.shape[0], W2.shape[0]
         dev = e.device
-        st2 = torch.empty((4, 64), device=dev, dtype=torch.float32)         # mean, invstd, scale, shift
-        st3 = torch.empty((4, Cout), device=dev, dtype=torch.float32)
+        # BatchNorm2: the operator's epilogue finalised it (pending), else one reducing launch
+        st2 = pointwise.batch_stats(e, (w2, b2, rm2, rv2, nbt2, momentum2, eps2), population)         # mean, invstd, scale, shift
         ws = ops._workspace(dev, int(L.fgnn_bn_workspace_bytes(R, Cout)))
-        npart = pointwise.take_pending_stats(e)
-        if npart:           # the operator's epilogue left (sum, sum of squares) partials of e
-            _hip.check(L.fgnn_bn_finalize(P(ws), npart, R, 64, P(w2), P(b2), P(rm2), P(rv2), momentum2, eps2, P(st2[0]), P(st2[1]),
-                                          P(st2[2]), P(st2[3]), P(nbt2), _hip.stream_ptr()))
-        else:
-            ops.timed('bn_stats (reduce + finalise)', e.numel() * 2, lambda: _hip.check(L.fgnn_bn_stats(
-                P(e), R, 64, _hip.BF16, P(w2), P(b2), P(rm2), P(rv2), momentum2, eps2, P(st2[0]), P(st2[1]), P(st2[2]), P(st2[3]),
-                P(nbt2), P(ws), ws.numel() * 4, _hip.stream_ptr())))
+        fold = ops._fold_scratch(dev)
         a2 = torch.empty_like(e)
         W2c = W2.detach()
         bias2c = None if bias2 is None else bias2.detach()
         flops = 2 * R * 64 * Cout
+        st3, fin3 = pointwise.make_final((w3, b3, rm3, rv3, nbt3, momentum3, eps3), Cout, dev, R, population)
         ops.timed('block_tail_stats_kernel', 2 * R * 64, lambda: _hip.check(L.fgnn_block_tail_stats(
-            P(e), P(st2[2]), P(st2[3]), slope2, P(W2c), P(bias2c), R, Cout, P(ws), _hip.stream_ptr())), nflops=flops)
-        _hip.check(L.fgnn_bn_finalize_shifted(P(ws), int(L.fgnn_block_tail_partials(R, Cout)), R, Cout, P(bias2c), P(w3), P(b3), P(rm3),
-                                              P(rv3), momentum3, eps3, P(st3[0]), P(st3[1]), P(st3[2]), P(st3[3]), P(nbt3),
-                                              _hip.stream_ptr()))
+            P(e), P(st2[2]), P(st2[3]), slope2, P(W2c), P(bias2c), R, Cout, P(ws), fin3, P(fold), _hip.stream_ptr())), nflops=flops)
         out = torch.empty((R, Cout), device=dev, dtype=e.dtype)
         if callable(add0):          # the addends come from another stream: asked for (and waited on) only HERE, behind the statistics
-            add0, add1, add2 = add0()   # pass, which does not read them (the join used to sit in front of it)
+            (add0, add1, add2), periods = add0()   # pass, which does not read them (the join used to sit in front of it)
         adds = (add0, add1, add2)
         nadd = sum(a is not None for a in adds)
         ops.timed('block_tail_apply_kernel', 2 * R * (2 * 64 + (1 + nadd) * Cout), lambda: _hip.check(L.fgnn_block_tail_apply(
-            P(e), P(st2[2]), P(st2[3]), slope2, P(W2c), P(bias2c), P(st3[2]), P(st3[3]), slope3, P(add0), P(add1), P(add2), P(out), P(a2),
-            R, Cout, _hip.stream_ptr())), nflops=flops)
+            P(e), P(st2[2]), P(st2[3]), slope2, P(W2c), P(bias2c), P(st3[2]), P(st3[3]), slope3, P(add0), P(add1), P(add2),
+            pointwise.period_array(periods), P(out), P(a2), R, Cout, _hip.stream_ptr())), nflops=flops)
         pointwise.note_state_change()                   # running statistics / num_batches_tracked were just updated in place
         ctx.save_for_backward(e, a2, st2, st3, w2, b2, W2, w3)
         ctx.slopes = (slope2, slope3)
         ctx.has_add = tuple(a is not None and a.requires_grad for a in adds)
+        ctx.periods = tuple(periods)
         ctx.has_bias2 = bias2 is not None
         ctx.params = (w2, b2, W2, bias2, w3, b3)
         return out
@@ -306,6 +309,7 @@ class _BlockTail(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gout):
         from .. import _hip
+        from . import pointwise
         ops.backward_node_begins()
         L = _hip.lib()
         P = _hip._ptr
@@ -330,23 +334,23 @@ class _BlockTail(torch.autograd.Function):
         gbias2, s_bias2 = sink(pbias2, (Cout,)) if ctx.has_bias2 else (None, True)
         gz3 = torch.empty((R, Cout), device=dev, dtype=e.dtype)
         ga2 = torch.empty_like(e)
-        nb3 = int(L.fgnn_bn_workspace_bytes(R, Cout))
-        np2 = int(L.fgnn_block_tail_backward_partials(R, Cout))
-        ws = ops._workspace(dev, max(nb3 + (np2 * 128 + 128) * 4, int(L.fgnn_linear_wgrad_workspace_bytes(R, 64, Cout))))
-        part2 = ws[nb3 // 4: nb3 // 4 + np2 * 128]          # BatchNorm2's backward sums, left by the grad kernel
-        dsum2 = ws[nb3 // 4 + np2 * 128:]
+        nws = (2048 * Cout + 2 * Cout + 1024 * 128) * 4
+        ws = ops._workspace(dev, max(nws, int(L.fgnn_linear_wgrad_workspace_bytes(R, 64, Cout))))
+        dsum2 = torch.empty((2, 64), device=dev, dtype=torch.float32)       # BatchNorm2's backward sums, finalised by the grad kernel
         bias2c = None if pbias2 is None else pbias2.detach()
-        # BatchNorm3 backward (sums, parameter gradients, input gradient gz3) + ga2 = gz3 W2 + BatchNorm2's backward sums
-        ops.timed('block_tail_backward (reduce + finalise + grad)', 2 * R * (2 * 64 + 2 * Cout + 64 + Cout),
+        # BatchNorm3 backward (sums, parameter gradients, input gradient gz3) + ga2 = gz3 W2 + BatchNorm2's backward sums and
+        # parameter gradients: two launches
+        ops.timed('block_tail_backward (reduce + grad)', 2 * R * (2 * 64 + 2 * Cout + 64 + Cout),
                   lambda: _hip.check(L.fgnn_block_tail_backward(
                       P(e), P(st2[2]), P(st2[3]), slope2, P(W2.detach()), P(bias2c), P(st3[0]), P(st3[1]), P(w3.detach()), P(st3[2]),
-                      P(st3[3]), slope3, P(gout), P(gz3), P(ga2), P(gw3), P(gb3), P(part2), R, Cout, P(ws), nb3, _hip.stream_ptr())),
+                      P(st3[3]), slope3, P(gout), P(gz3), P(ga2), P(gw3), P(gb3), P(st2[0]), P(st2[1]), P(gw2), P(gb2), P(dsum2),
+                      R, Cout, P(ws), ws.numel() * 4, P(ops._fold_scratch(dev)), _hip.stream_ptr())),
                   nflops=6 * R * 64 * Cout)
-        # BatchNorm2 + activation backward on the 64-channel tensor: finaliser + one element-wise pass (no reduction pass)
+        # BatchNorm2 + activation backward on the 64-channel tensor: one element-wise pass (no reduction pass, no finaliser)
         ge = torch.empty_like(e)
-        ops.timed('bn_backward (finalise + apply)', 3 * e.numel() * 2, lambda: _hip.check(L.fgnn_bn_backward_partials(
-            P(e), P(ga2), P(ge), R, 64, _hip.BF16, P(st2[0]), P(st2[1]), P(w2.detach()), P(b2.detach()), slope2, P(gw2), P(gb2),
-            P(part2), np2, P(dsum2), _hip.stream_ptr())))
+        ops.timed('bn_backward (apply)', 3 * e.numel() * 2, lambda: _hip.check(L.fgnn_bn_backward_apply(
+            P(e), P(ga2), P(ge), R, 64, _hip.BF16, P(st2[0]), P(st2[1]), P(w2.detach()), P(b2.detach()), slope2, P(dsum2),
+            _hip.stream_ptr())))
         # conv2's weight / bias gradient: gz3^T a2 over the R rows (csrc/linear_wgrad_b16.hip); parked when it goes to the flat
         # bucket (ops.defer_wgrad: nothing in the backward reads it)
         def launch(a2=a2, gz3=gz3, gW2=gW2, gbias2=gbias2):
@@ -359,10 +363,14 @@ class _BlockTail(torch.autograd.Function):
         else:
             launch()
         ha = ctx.has_add
+        gadd = [None, None, None]
+        for i in range(3):
+            if ha[i]:
+                gadd[i] = gout if ctx.periods[i] == 1 else pointwise.node_sum(gout, ctx.periods[i])
         return (ge, None if s_w2 else gw2, None if s_b2 else gb2, None, None, None, None, None, None,
                 None if s_W2 else gW2.view(pW2.shape).to(pW2.dtype), None if (s_bias2 or gbias2 is None) else gbias2,
-                None if s_w3 else gw3, None if s_b3 else gb3, None, None, None, None, None, None,
-                gout if ha[0] else None, gout if ha[1] else None, gout if ha[2] else None)
+                None if s_w3 else gw3, None if s_b3 else gb3, None, None, None, None, None, None, None,
+                gadd[0], gadd[1], gadd[2], None)
 
 
 class mp_conv_residual(base_mp_nn):
@@ -497,18 +505,33 @@ class mp_conv_residual(base_mp_nn):
             y = self._fused_eval(node_feature, nn_idx, etype, addend)
             if y is not None:
                 return y
+        # ONE source node feeding every destination through identical edges (the LDPC hyper-factor -> variables call): the whole
+        # block's output is a per-sample vector — conv1 on the single source, the message, BatchNorm + ReLU, conv2, BatchNorm +
+        # LeakyReLU all act on M identical rows — so it is computed on ONE row per sample and handed on as a broadcast
+        # (ops.broadcast_nodes).  The batch statistics of M identical rows per sample are those of one row per sample (same mean and
+        # biased variance); only the running variance's unbiased correction counts the rows: population_mult = M.
+        M = ops.single_source_fanout(node_feature, nn_idx, etype) if (staged and not self.with_residual and not addend
+                                                                     and node_feature.shape[0] > 1) else 0
+        if M:
+            B, C = node_feature.shape[:2]
+            one = node_feature.reshape(B, 1, 1, C).permute(0, 3, 1, 2)   # canonical channel-fastest strides for the one-node tensor
+            y1 = self._forward_staged(one, nn_idx[:, :1, :], etype[:, :, :1, :], None, M)
+            return ops.broadcast_nodes(y1, M)
+        return self._forward_staged(node_feature, nn_idx, etype, addend, 1)
+
+    def _forward_staged(self, node_feature, nn_idx, etype, addend, mult):
         fuse = self.training            # BatchNorm statistics ride in the 1x1 map's epilogue when training
         h = self._fused_train_head(node_feature)
         if h is None:
-            h = self.conv1[1](self.conv1[0](node_feature, want_stats=fuse))
-        y = self._fused_train_tail(h, nn_idx, etype, addend)
+            h = self.conv1[1](self.conv1[0](node_feature, bn=self.conv1[1] if fuse else None))
+        y = self._fused_train_tail(h, nn_idx, etype, addend, mult)
         if y is not None:
             return y + node_feature if self.with_residual else y
-        h = self.mp_conv(h, nn_idx, etype)
-        h = self.conv2[0](h, want_stats=fuse)
+        h = self.mp_conv(h, nn_idx, etype, population_mult=mult)
+        h = self.conv2[0](h, bn=self.conv2[1] if (fuse and mult == 1) else None)
         if callable(addend):            # produced on another stream: asked for (and waited on) only where it is consumed
             addend = addend()
-        h = self.conv2[1](h, addend=addend)
+        h = self.conv2[1](h, addend=addend, population_mult=mult)
         return h + node_feature if self.with_residual else h
 
     def _fused_train_head(self, x):
@@ -536,7 +559,7 @@ class mp_conv_residual(base_mp_nn):
                               bn.num_batches_tracked, bn.momentum, bn.eps, float(bn.slope))
         return a1.view(B, H, W, 64).permute(0, 3, 1, 2)
 
-    def _fused_train_tail(self, h, nn_idx, etype, addend):
+    def _fused_train_tail(self, h, nn_idx, etype, addend, mult=1):
         """Training, bf16: the operator's pre-BatchNorm output goes straight into csrc/block_tail.hip (``_BlockTail``) —
         BatchNorm + ReLU, conv2, BatchNorm + LeakyReLU and the addends without conv2's Cout-wide output ever being stored.
         None = not this family (the staged path runs)."""
@@ -555,47 +578,51 @@ class mp_conv_residual(base_mp_nn):
         B, M = h.shape[0], nn_idx.shape[1]
         if B * M < 2 or not _hip.lib().fgnn_block_tail_partials(B * M, conv2.out_channels):
             return None
-        # the operator's epilogue leaves BatchNorm2's statistics partials in the stream's workspace: size it for the whole
-        # tail FIRST (a later, larger request would move the buffer and orphan them)
-        ops._workspace(h.device, int(_hip.lib().fgnn_bn_workspace_bytes(B * M, conv2.out_channels)))
+        from . import pointwise
         z = ops.mpconv(h, nn_idx, etype, mp.filters, mp.bias, mp.nou, mp.nedge_types, _EXT_CODE[mp.extension],
-                       _hip.AGG_CODES[mp.aggregtor], want_stats=True)
+                       _hip.AGG_CODES[mp.aggregtor], bn=pointwise.bn_spec(bn2) if mult == 1 else None)
         rows = z.permute(0, 2, 3, 1)
         if not rows.is_contiguous():
-            from .pointwise import take_pending_stats
-            take_pending_stats(rows)                        # (drop them: they describe another buffer)
+            pointwise.take_pending_stats(rows)                        # (drop them: they describe another buffer)
             rows = rows.contiguous()
         rows = rows.view(B * M, 64)
         Cout = conv2.out_channels
         got = {}
 
         def addend_rows():
-            """Evaluates the caller's addend (a callable joins the stream that produced it) and returns the three row views the
-            apply kernel reads; the differentiable tensors stay in `got` for the gradient route."""
+            """Evaluates the caller's addend (a callable joins the stream that produced it) and returns (the three row views the
+            apply kernel reads, their periods); the differentiable tensors stay in `got` for the gradient route."""
             with torch.enable_grad():
                 a = addend() if callable(addend) else addend
                 addends = as_addends(a)
                 if len(addends) > 3:
                     addends = addends[:2] + [ops.add_n(addends[2:])]
+                addends, periods = pointwise.split_broadcast(addends)
                 arows = [None, None, None]
                 for i, t in enumerate(addends):
                     ar = t.permute(0, 2, 3, 1)
                     if ar.dtype != rows.dtype or not ar.is_contiguous():
                         ar = ar.to(rows.dtype).contiguous()
-                    arows[i] = ar.view(B * M, Cout)
+                    arows[i] = ar.view(-1, Cout)
             got['arows'] = arows
-            return arows
+            got['periods'] = tuple((periods + [1, 1, 1])[:3])
+            return arows, got['periods']
 
         late = ROUTE_ADDEND_GRADS and LATE_JOIN and callable(addend) and torch.is_grad_enabled()
-        arows = None if late else addend_rows()
+        arows, periods = (None, (1, 1, 1)) if late else addend_rows()
         route = late or (ROUTE_ADDEND_GRADS and torch.is_grad_enabled() and any(a is not None and a.requires_grad for a in arows))
         if late:
-            tail_adds = [lambda: [None if a is None else a.detach() for a in addend_rows()], None, None]
+            def detached():
+                ar, pr = addend_rows()
+                return [None if a is None else a.detach() for a in ar], pr
+            tail_adds = [detached, None, None]
         else:
             tail_adds = [(a.detach() if (route and a is not None) else a) for a in arows]
         y = _BlockTail.apply(rows, bn2.weight, bn2.bias, 0.0, float(bn3.slope), bn2.momentum, bn2.eps, bn3.momentum, bn3.eps,
                              conv2.weight.view(Cout, 64), conv2.bias, bn3.weight, bn3.bias, bn2.running_mean, bn2.running_var,
-                             bn2.num_batches_tracked, bn3.running_mean, bn3.running_var, bn3.num_batches_tracked, *tail_adds)
+                             bn2.num_batches_tracked, bn3.running_mean, bn3.running_var, bn3.num_batches_tracked,
+                             0 if mult == 1 else B * M * mult, *tail_adds, periods)
         if route:
-            y = _AddendRoute.apply(y, *[a for a in got['arows'] if a is not None])
+            pairs = [(a, q) for a, q in zip(got['arows'], got['periods']) if a is not None]
+            y = _AddendRoute.apply(y, tuple(q for _, q in pairs), *[a for a, _ in pairs])
         return y.view(B, M, 1, Cout).permute(0, 3, 1, 2)

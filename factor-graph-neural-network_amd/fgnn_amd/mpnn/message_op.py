@@ -90,9 +90,10 @@ class mp_conv_v2(base_mp_nn):
         return 'nin=%d, nou=%d, nedge_types=%d, %s, aggregtor=%s' % (
             self.nin, self.nou, self.nedge_types, self.extension.name, self.aggregtor)
 
-    def forward(self, x, nn_idx, etype, addend=None):
+    def forward(self, x, nn_idx, etype, addend=None, population_mult=1):
         """``addend``: optional tensor of the output's shape (or a list of them) added after the activation (fused
-        into the BatchNorm kernel when training with the plain ReLU)."""
+        into the BatchNorm kernel when training with the plain ReLU).  ``population_mult``: see BatchNormAct2d.forward (set by
+        callers that run the operator on ONE row per sample in place of m identical ones)."""
         if not isinstance(self.aggregtor, str):
             return self._forward_custom_aggregator(x, nn_idx, etype, addend)
         ext, agg = _EXT_CODE[self.extension], _hip.AGG_CODES[self.aggregtor]
@@ -123,15 +124,27 @@ class mp_conv_v2(base_mp_nn):
             if self.activation_fn is not None and not plain_relu:
                 y = self.activation_fn(y)
             return ops.add_n([y] + adds)
-        # a training-mode BatchNorm right behind the operator takes its batch statistics from the kernel's epilogue
-        z = ops.mpconv(x, nn_idx, etype, self.filters, self.bias, self.nou,
-                       self.nedge_types, ext, agg, want_stats=bn_batch_stats and self.bn is not None and self.bn.training)
+        # ONE source node feeding every destination through identical edges (the LDPC hyper-factor -> variables call of the plain
+        # layers, factor_mpnn_sp.py:88-91): every destination receives the same message, so the operator, its BatchNorm and its ReLU
+        # run on one row per sample and the result travels as a broadcast (see mp_conv_residual.forward)
+        from .pointwise import BatchNormAct2d, bn_spec
+        M = 0
+        if (population_mult == 1 and ext == _hip.EXT_NONE and addend is None and needs_grad and bn_batch_stats and plain_relu
+                and isinstance(self.bn, BatchNormAct2d) and x.shape[0] > 1):
+            M = ops.single_source_fanout(x, nn_idx, etype)
+        if M:
+            B, C = x.shape[:2]
+            one = x.reshape(B, 1, 1, C).permute(0, 3, 1, 2)
+            return ops.broadcast_nodes(self.forward(one, nn_idx[:, :1, :], etype[:, :, :1, :], None, M), M)
+        # a training-mode BatchNorm right behind the operator is finalised by the operator's own launch where it has the epilogue
+        spec = bn_spec(self.bn) if (self.bn is not None and isinstance(self.bn, BatchNormAct2d) and population_mult == 1) else None
+        z = ops.mpconv(x, nn_idx, etype, self.filters, self.bias, self.nou, self.nedge_types, ext, agg, bn=spec)
         if callable(addend):
             addend = addend()
         if self.bn is not None:
             if plain_relu:                      # BatchNorm + ReLU (+ addend) in one fused kernel pair
-                return self.bn(z, addend=addend, slope=0.0)
-            z = self.bn(z)
+                return self.bn(z, addend=addend, slope=0.0, population_mult=population_mult)
+            z = self.bn(z, population_mult=population_mult)
         if self.activation_fn is not None:
             z = self.activation_fn(z)
         return add_all(z, addend)

@@ -112,14 +112,34 @@ def cast_cached(t, dtype):
     return out
 
 
-_PENDING_STATS = None     # (rows tensor, number of partials) of the last hip_linear(..., want_stats=True)
+_PENDING_STATS = None     # (rows tensor, stats [4, C]) finalised batch statistics of the last statistics-producing launch
 
 
-def hip_linear(rows, weight, bias, want_stats=False, transposed=False):
+def bn_spec(bn):
+    """(gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps) of a training-mode BatchNorm module the
+    hand-written kernels can finalise themselves, else None (eval mode, no running statistics, cumulative momentum, ...)."""
+    if bn is None or not bn.training or not bn.track_running_stats or not bn.affine or bn.momentum is None:
+        return None
+    if bn.weight.dtype != torch.float32 or not bn.weight.is_cuda:
+        return None
+    return (bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked, float(bn.momentum), float(bn.eps))
+
+
+def make_final(spec, C, device, count, population=0):
+    """(stats [4, C] f32 — rows mean, invstd, scale, shift —, the fgnn_bn_final describing it) for a BatchNorm ``spec`` (bn_spec) whose
+    statistics run over ``count`` rows standing for ``population`` rows of the reference's tensor (0 = count)."""
+    gamma, beta, rm, rv, nbt, momentum, eps = spec
+    stats = torch.empty((4, C), device=device, dtype=torch.float32)
+    fin = _hip.bn_final(stats, gamma.detach(), beta.detach(), rm, rv, nbt, momentum, eps, count, population)
+    return stats, fin
+
+
+def hip_linear(rows, weight, bias, bn=None, transposed=False):
     """``rows @ weight.T + bias`` through csrc/linear_fwd_b16.hip (bf16 rows, f32 parameters, channel counts in
-    multiples of 64): one pass over rows and the output at HBM rate, no cast of the weights.  With
-    ``want_stats`` the kernel's epilogue also leaves the per-channel batch statistics of the output in the
-    shared workspace for the BatchNorm that follows (``take_pending_stats``).  None = shape not handled."""
+    multiples of 64): one pass over rows and the output at HBM rate, no cast of the weights.  With ``bn`` (a ``bn_spec``
+    tuple) the launch also forms the per-channel batch statistics of the output and FINALISES that BatchNorm itself (its last
+    workgroup: csrc/fgnn_gridfold.h) — running statistics, num_batches_tracked, scale / shift; the result waits for the
+    BatchNorm that follows (``take_pending_stats``).  None = shape not handled."""
     global _PENDING_STATS
     _PENDING_STATS = None
     if not (rows.is_cuda and rows.dtype == torch.bfloat16 and weight.dtype == torch.float32 and rows.is_contiguous()):
@@ -130,11 +150,11 @@ def hip_linear(rows, weight, bias, want_stats=False, transposed=False):
     # (23.7 vs 34.4 us at 64x64, 37.7 vs 45.9 at 64x128, 52.7 vs 57.6 at 128x128: the step time does not move with that last
     # one); at 64x256 / 256x64 it loses 10 us (72 vs 61) but with the statistics epilogue saves the BatchNorm's own 25 us pass
     # over the output; wider maps stay with hipBLASLt (4 TB/s there)
-    if cin * cout > (16384 if want_stats else 8192):
+    if cin * cout > (16384 if bn is not None else 8192):
         return None
     L = _hip.lib()
     npart = L.fgnn_linear_forward_partials(R, cin, cout)
-    if npart == 0:
+    if npart == 0 or (bn is not None and R < 2):
         return None
     from .. import ops
     w = weight.detach()
@@ -142,31 +162,64 @@ def hip_linear(rows, weight, bias, want_stats=False, transposed=False):
         w = w.contiguous()
     b = None if bias is None else bias.detach().float().contiguous()
     y = torch.empty((R, cout), device=rows.device, dtype=rows.dtype)
-    ws = None
-    if want_stats:
+    ws = fold = fin = stats = None
+    if bn is not None:
         ws = ops._workspace(rows.device, int(L.fgnn_bn_workspace_bytes(R, cout)))
+        fold = ops._fold_scratch(rows.device)
+        stats, fin = make_final(bn, cout, rows.device, R)
     ops.timed('linear_fwd_b16_kernel', 2 * R * (cin + cout),
               lambda: _hip.check(L.fgnn_linear_forward(_hip._ptr(rows), _hip._ptr(w), _hip._ptr(b), _hip._ptr(y), R, cin,
-                                                       cout, _hip._ptr(ws), int(transposed), _hip.stream_ptr())),
+                                                       cout, _hip._ptr(ws), fin, _hip._ptr(fold), int(transposed), _hip.stream_ptr())),
               nflops=2 * R * cin * cout)
-    if want_stats:
-        _PENDING_STATS = (y, npart)
+    if bn is not None:
+        note_state_change()                 # running statistics / num_batches_tracked were just updated in place
+        _PENDING_STATS = (y, stats)
     return y
 
 
-def set_pending_stats(rows, npart):
-    """A kernel just left ``npart`` statistics partials of ``rows`` ([R, C]) in the current stream's workspace."""
+def set_pending_stats(rows, stats):
+    """A kernel just finalised the batch statistics ``stats`` [4, C] of ``rows`` ([R, C]) for the BatchNorm that follows."""
     global _PENDING_STATS
-    _PENDING_STATS = (rows, npart)
+    _PENDING_STATS = (rows, stats)
 
 
 def take_pending_stats(rows):
-    """Number of statistics partials waiting in the shared workspace for exactly this tensor, else 0."""
+    """The finalised statistics [4, C] waiting for exactly this tensor, else None."""
     global _PENDING_STATS
     pend, _PENDING_STATS = _PENDING_STATS, None
     if pend is not None and pend[0].data_ptr() == rows.data_ptr() and pend[0].shape == rows.shape:
         return pend[1]
-    return 0
+    return None
+
+
+def batch_stats(rows, spec, population=0):
+    """stats [4, C] of a training-mode BatchNorm over ``rows`` [R, C]: the producer's (take_pending_stats) when it finalised them,
+    else one reducing launch of csrc/bnact.hip (its last workgroup finalises)."""
+    from .. import ops
+    stats = take_pending_stats(rows)
+    if stats is not None:
+        return stats
+    L = _hip.lib()
+    R, C = rows.shape
+    stats, fin = make_final(spec, C, rows.device, R, population)
+    ws = ops._workspace(rows.device, int(L.fgnn_bn_workspace_bytes(R, C)))
+    fold = ops._fold_scratch(rows.device)
+    ops.timed('bn_stats (reduce + finalise)', rows.numel() * rows.element_size(), lambda: _hip.check(L.fgnn_bn_stats(
+        _hip._ptr(rows), R, C, _hip.dtype_code(rows), fin, _hip._ptr(ws), ws.numel() * 4, _hip._ptr(fold), _hip.stream_ptr())))
+    note_state_change()
+    return stats
+
+
+def node_sum(g, M):
+    """[R, C] -> [R / M, C]: sum over each sample's M consecutive rows (the gradient of a per-sample row that was broadcast over the
+    sample's nodes), one pass (csrc/sum_n.hip: node_sum_kernel)."""
+    from .. import ops
+    R, C = g.shape
+    g = g.contiguous()
+    out = torch.empty((R // M, C), device=g.device, dtype=g.dtype)
+    ops.timed('node_sum_kernel', g.numel() * g.element_size(), lambda: _hip.check(_hip.lib().fgnn_node_sum(
+        _hip._ptr(g), _hip._ptr(out), R // M, M, C, _hip.dtype_code(g), _hip.stream_ptr())))
+    return out
 
 
 class _RowLinear(torch.autograd.Function):
@@ -177,14 +230,15 @@ class _RowLinear(torch.autograd.Function):
     rows and gy)."""
 
     @staticmethod
-    def forward(ctx, rows, weight, bias, want_stats=False, precomputed=None):
-        """``precomputed``: the output, already formed by a fused kernel (blocks.iid_mapping_in): only the graph node is made."""
+    def forward(ctx, rows, weight, bias, bn=None, precomputed=None):
+        """``bn``: a ``bn_spec`` tuple — the training-mode BatchNorm behind the map, finalised by the map's own launch.
+        ``precomputed``: the output, already formed by a fused kernel (blocks.iid_mapping_in): only the graph node is made."""
         ctx.save_for_backward(rows, weight)
         ctx.has_bias = bias is not None
         ctx.params = (weight, bias)                     # leaf tensors (ops.grad_sink)
         if precomputed is not None:
             return precomputed
-        y = hip_linear(rows, weight, bias, want_stats)
+        y = hip_linear(rows, weight, bias, bn)
         if y is not None:
             return y
         w = cast_cached(weight._base if weight._base is not None else weight, rows.dtype).view(weight.shape)
@@ -246,9 +300,11 @@ class PointwiseConv2d(torch.nn.Conv2d):
         assert kernel_size in (1, (1, 1)), 'PointwiseConv2d is a 1x1 map'
         super().__init__(in_channels, out_channels, 1, bias=bias)
 
-    def forward(self, x, want_stats=False):
-        """``want_stats``: the caller promises to hand the result straight to a training-mode BatchNormAct2d,
-        which then takes its batch statistics from this map's epilogue instead of re-reading the tensor."""
+    def forward(self, x, bn=None):
+        """``bn``: the BatchNormAct2d module the caller hands the result straight to.  In training mode the map's launch then forms
+        that BatchNorm's batch statistics in its epilogue and finalises them (running statistics included): the BatchNorm neither
+        re-reads the tensor for them nor launches a finaliser."""
+        bn = bn_spec(bn)
         B, C, H, W = x.shape
         rows = x.permute(0, 2, 3, 1)                    # [B,H,W,C] view; free when channels-last
         if not rows.is_contiguous():
@@ -259,7 +315,7 @@ class PointwiseConv2d(torch.nn.Conv2d):
         weight = self.weight.view(self.out_channels, C)
         if rows.is_cuda and rows.dtype in (torch.float32, torch.bfloat16) and torch.is_grad_enabled() and (
                 weight.requires_grad or rows.requires_grad):
-            y = _RowLinear.apply(rows, weight, self.bias, want_stats)
+            y = _RowLinear.apply(rows, weight, self.bias, bn)
         else:
             needs_grad = torch.is_grad_enabled() and (weight.requires_grad or rows.requires_grad)
             y = hip_linear(rows, weight, self.bias) if rows.is_cuda and not needs_grad else None
@@ -357,39 +413,48 @@ def add_all(y, addend):
     return y
 
 
+def split_broadcast(addends):
+    """``addends`` (tensors [B, C, N, 1]) -> (tensors, periods): an addend that is a per-sample vector broadcast over the N nodes
+    (``ops.broadcast_nodes``: the LDPC hyper-factor's message to the variables) is replaced by its [B, C, 1, 1] source with period N —
+    the apply kernels read it as one row per N output rows and its gradient is the node sum of the output's."""
+    ts, periods = [], []
+    for a in addends:
+        src = getattr(a, '_fgnn_bcast_src', None)
+        if src is not None and a.shape[2] > 1:
+            ts.append(src)
+            periods.append(int(a.shape[2]))
+        else:
+            ts.append(a)
+            periods.append(1)
+    return ts, periods
+
+
+def period_array(periods):
+    import ctypes
+    periods = (list(periods) + [1, 1, 1])[:3]
+    return None if all(q == 1 for q in periods) else (ctypes.c_int32 * 3)(*periods)
+
+
 class _BatchNormAct(torch.autograd.Function):
     """Train-mode BatchNorm + LeakyReLU(slope) on channel-fastest rows [R, C] (csrc/bnact.hip)."""
 
     @staticmethod
     def forward(ctx, rows, weight, bias, running_mean, running_var, momentum, eps, slope, addend=None, nbt=None,
-                addend2=None, addend3=None):
+                addend2=None, addend3=None, periods=(1, 1, 1), population=0):
+        """``periods``: an addend with period m has one row per m rows of the output (a per-sample vector broadcast over the
+        sample's m nodes).  ``population``: rows the statistics stand for in the running variance's unbiased correction (0 = R)."""
         from .. import ops
         L = _hip.lib()
         R, C = rows.shape
-        dev = rows.device
-        stats = torch.empty((4, C), device=dev, dtype=torch.float32)      # mean, invstd, scale, shift
-        ws = ops._workspace(dev, int(L.fgnn_bn_workspace_bytes(R, C)))
         dt = _hip.dtype_code(rows)
-        npart = take_pending_stats(rows)
-        if npart:       # the producing map's epilogue already left (sum, sum of squares) partials in the workspace
-            _hip.check(L.fgnn_bn_finalize(_hip._ptr(ws), npart, R, C, _hip._ptr(weight), _hip._ptr(bias),
-                                          _hip._ptr(running_mean), _hip._ptr(running_var), momentum, eps,
-                                          _hip._ptr(stats[0]), _hip._ptr(stats[1]), _hip._ptr(stats[2]),
-                                          _hip._ptr(stats[3]), _hip._ptr(nbt), _hip.stream_ptr()))
-        else:
-            ops.timed('bn_stats (reduce + finalise)', rows.numel() * rows.element_size(),
-                      lambda: _hip.check(L.fgnn_bn_stats(
-                          _hip._ptr(rows), R, C, dt, _hip._ptr(weight), _hip._ptr(bias), _hip._ptr(running_mean),
-                          _hip._ptr(running_var), momentum, eps, _hip._ptr(stats[0]), _hip._ptr(stats[1]),
-                          _hip._ptr(stats[2]), _hip._ptr(stats[3]), _hip._ptr(nbt), _hip._ptr(ws), ws.numel() * 4,
-                          _hip.stream_ptr())))
+        stats = batch_stats(rows, (weight, bias, running_mean, running_var, nbt, momentum, eps), population)
         y = torch.empty_like(rows)
-        note_state_change()                             # running statistics / num_batches_tracked were just updated in place
         ctx.has_addend = tuple(a is not None for a in (addend, addend2, addend3))
+        ctx.periods = tuple(periods)
         ops.timed('bn_apply (forward)', (2 + sum(ctx.has_addend)) * rows.numel() * rows.element_size(),
                   lambda: _hip.check(L.fgnn_bn_apply(_hip._ptr(rows), _hip._ptr(y), R, C, dt, _hip._ptr(stats[2]),
                                                      _hip._ptr(stats[3]), slope, _hip._ptr(addend),
-                                                     _hip._ptr(addend2), _hip._ptr(addend3), _hip.stream_ptr())))
+                                                     _hip._ptr(addend2), _hip._ptr(addend3), period_array(periods), _hip.stream_ptr())))
         ctx.save_for_backward(rows, weight, bias, stats)
         ctx.slope = slope
         ctx.params = (weight, bias)
@@ -410,14 +475,18 @@ class _BatchNormAct(torch.autograd.Function):
         gw = gw_sink if gw_sink is not None else torch.zeros(C, device=rows.device, dtype=torch.float32)
         gb = gb_sink if gb_sink is not None else torch.zeros(C, device=rows.device, dtype=torch.float32)
         ws = ops._workspace(rows.device, int(L.fgnn_bn_workspace_bytes(R, C)))
+        fold = ops._fold_scratch(rows.device)
         ops.timed('bn_backward (reduce + finalise + apply)', 5 * rows.numel() * rows.element_size(),
                   lambda: _hip.check(L.fgnn_bn_backward(
                       _hip._ptr(rows), _hip._ptr(gy), _hip._ptr(gx), R, C, _hip.dtype_code(rows), _hip._ptr(stats[0]),
                       _hip._ptr(stats[1]), _hip._ptr(weight), _hip._ptr(bias), ctx.slope, _hip._ptr(gw), _hip._ptr(gb),
-                      _hip._ptr(ws), ws.numel() * 4, _hip.stream_ptr())))
+                      _hip._ptr(ws), ws.numel() * 4, _hip._ptr(fold), _hip.stream_ptr())))
+        ga = [None, None, None]
+        for i in range(3):
+            if ctx.has_addend[i] and ctx.needs_input_grad[(8, 10, 11)[i]]:
+                ga[i] = gy if ctx.periods[i] == 1 else node_sum(gy, ctx.periods[i])
         return (gx, None if gw_sink is not None else gw, None if gb_sink is not None else gb,
-                None, None, None, None, None, gy if ctx.has_addend[0] else None, None,
-                gy if ctx.has_addend[1] else None, gy if ctx.has_addend[2] else None)
+                None, None, None, None, None, ga[0], None, ga[1], ga[2], None, None)
 
 
 class BatchNormAct2d(torch.nn.BatchNorm2d):
@@ -438,11 +507,13 @@ class BatchNormAct2d(torch.nn.BatchNorm2d):
             return y
         return torch.nn.functional.leaky_relu(y, slope)
 
-    def forward(self, x, addend=None, slope=None):
+    def forward(self, x, addend=None, slope=None, population_mult=1):
         """``addend`` (a tensor of the output's shape, or a list of up to three) is added AFTER the activation — the
         ``acc + block(x) (+ residual + skip)`` that follows every block in FactorNN rides in the apply kernel
         instead of being separate passes.  ``slope`` overrides the module's activation for this call (mp_conv_v2 asks its
-        plain BatchNorm for the fused ReLU this way: an argument, not a toggled attribute)."""
+        plain BatchNorm for the fused ReLU this way: an argument, not a toggled attribute).  ``population_mult`` = m: every row of
+        ``x`` stands for m identical rows of the reference's tensor (a per-sample vector the reference broadcasts over m nodes
+        before this BatchNorm): same mean and biased variance, the running variance's unbiased correction counts m times the rows."""
         slope = self.slope if slope is None else float(slope)
         B, C, H, W = x.shape
         addends = as_addends(addend)
@@ -456,27 +527,31 @@ class BatchNormAct2d(torch.nn.BatchNorm2d):
         wants_grad = torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad or
                                                   any(a.requires_grad for a in addends))
         if not ok or (not self.training and wants_grad):
+            if population_mult != 1 and self.training:
+                raise _hip.FgnnHipError('BatchNormAct2d: population_mult needs the HIP path (a ROCm tensor, running statistics)')
             return add_all(self._activate(super().forward(x), slope), addends)
         rows = x.permute(0, 2, 3, 1)
         if not rows.is_contiguous():
             rows = rows.contiguous()
         rows = rows.view(B * H * W, C)
+        addends, periods = split_broadcast(addends)
         arows = [None, None, None]
         for i, a in enumerate(addends):
             ar = a.permute(0, 2, 3, 1)
             if ar.dtype != rows.dtype or not ar.is_contiguous():
                 ar = ar.to(rows.dtype).contiguous()
-            arows[i] = ar.view(B * H * W, C)
+            arows[i] = ar.view(-1, C)
+        periods = tuple((periods + [1, 1, 1])[:3])
         if self.training:                               # num_batches_tracked += 1 rides in the statistics finaliser
             y = _BatchNormAct.apply(rows, self.weight, self.bias, self.running_mean, self.running_var,
                                     self.momentum, self.eps, slope, arows[0], self.num_batches_tracked,
-                                    arows[1], arows[2])
+                                    arows[1], arows[2], periods, 0 if population_mult == 1 else B * H * W * population_mult)
         else:                                           # eval: folded affine + activation in one pass
             scale, shift = self._folded()
             y = torch.empty_like(rows)
             _hip.check(_hip.lib().fgnn_bn_apply(_hip._ptr(rows), _hip._ptr(y), B * H * W, C, _hip.dtype_code(rows),
                                                 _hip._ptr(scale), _hip._ptr(shift), slope, _hip._ptr(arows[0]),
-                                                _hip._ptr(arows[1]), _hip._ptr(arows[2]), _hip.stream_ptr()))
+                                                _hip._ptr(arows[1]), _hip._ptr(arows[2]), period_array(periods), _hip.stream_ptr()))
         return y.view(B, H, W, C).permute(0, 3, 1, 2)
 
     def _folded(self):

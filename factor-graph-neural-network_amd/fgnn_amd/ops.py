@@ -261,10 +261,10 @@ def max_in_degree(nn_idx, N):
 
 
 def mpconv_forward_raw(x, nn_idx, etype, filters, bias, nou, net, ext, agg, *,
-                       post_scale=None, post_shift=None, relu=False, want_argmax=False, want_stats=False, addends=None):
-    """One launch of fgnn_mpconv_forward.  Returns (y, argmax-or-None).  ``want_stats``: where the shape has a
-    statistics epilogue, the launch also leaves the BatchNorm batch statistics of y in the stream's workspace and
-    announces them to the BatchNorm that follows (pointwise.set_pending_stats)."""
+                       post_scale=None, post_shift=None, relu=False, want_argmax=False, bn=None, addends=None):
+    """One launch of fgnn_mpconv_forward.  Returns (y, argmax-or-None).  ``bn`` (a ``pointwise.bn_spec`` tuple: the training-mode
+    BatchNorm behind the operator): where the shape has a statistics epilogue, the launch also forms the batch statistics of y,
+    finalises that BatchNorm in its last workgroup and announces the result to it (pointwise.set_pending_stats)."""
     _require_device(x, nn_idx, etype, filters, bias)
     _check_shapes(x, nn_idx, etype, filters, nou, net, ext)
     nn_idx = shared_graph_view(nn_idx)
@@ -282,15 +282,19 @@ def mpconv_forward_raw(x, nn_idx, etype, filters, bias, nou, net, ext, agg, *,
     d = _hip.make_desc(x, nn_idx, etype, nou, net, ext, agg, relu, y)
     nbytes = int(L.fgnn_mpconv_algorithmic_bytes(ctypes.byref(d))) if TIMER is not None else 0
     npart = 0
-    if want_stats and STATS_EPILOGUE and post_scale is None and not relu:
+    if bn is not None and STATS_EPILOGUE and post_scale is None and not relu:
         npart = int(L.fgnn_mpconv_forward_stats_partials(ctypes.byref(d)))
     if npart > 0:
-        ws = _workspace(x.device, int(L.fgnn_bn_workspace_bytes(x.shape[0] * M, nou)))
+        from .mpnn import pointwise
+        R = x.shape[0] * M
+        ws = _workspace(x.device, int(L.fgnn_bn_workspace_bytes(R, nou)))
+        stats, fin = pointwise.make_final(bn, nou, x.device, R)
+        fold = _fold_scratch(x.device)
         _launch('fwd', d, nbytes, lambda: _hip.check(L.fgnn_mpconv_forward_stats(
             ctypes.byref(d), _hip._ptr(x), _hip._ptr(nn_idx), _hip._ptr(etype), _hip._ptr(filters),
-            _hip._ptr(bias), _hip._ptr(y), _hip._ptr(amax), _hip._ptr(ws), _hip.stream_ptr())))
-        from .mpnn import pointwise
-        pointwise.set_pending_stats(y.permute(0, 2, 3, 1).reshape(x.shape[0] * M, nou), npart)
+            _hip._ptr(bias), _hip._ptr(y), _hip._ptr(amax), _hip._ptr(ws), fin, _hip._ptr(fold), _hip.stream_ptr())))
+        pointwise.note_state_change()
+        pointwise.set_pending_stats(y.permute(0, 2, 3, 1).reshape(R, nou), stats)
         return y, amax
     if addends:
         # inference: the caller's running sums ride in the kernel's epilogue where it has one for them (``addends``: up to three
@@ -368,6 +372,23 @@ def _workspace(device, nbytes):
 
 
 _WS_CAPTURED = []       # workspaces whose addresses live in captured graphs
+_FOLD = {}
+
+
+def _fold_scratch(device):
+    """The ticket counters + second-level rows of the in-kernel grid folds (csrc/fgnn_gridfold.h), one zero-initialised buffer per
+    (device, stream), never freed or moved (captured graphs hold its address).  Kernels of one stream never overlap, so they share
+    it; every user leaves the counters at zero."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    buf = _FOLD.get(key)
+    if buf is None:
+        # allocated (and zeroed) outside any capture: a capture that meets an unseen stream first would record the memset into the
+        # graph (every replay would zero live counters — harmless — but the block would come from the graph's private pool)
+        if torch.cuda.is_current_stream_capturing():
+            raise _hip.FgnnHipError('fgnn_amd: first use of a stream inside hipGraph capture — run the step once eagerly on the capture '
+                                    'stream first (graph.StepGraph does)')
+        buf = _FOLD[key] = torch.zeros(_hip.FOLD_SCRATCH_BYTES // 4, device=device, dtype=torch.int32)
+    return buf
 
 
 _SIDE = {}
@@ -391,14 +412,13 @@ class _MPConv(torch.autograd.Function):
     """z = agg(messages) + bias with the hand-written HIP forward and backward."""
 
     @staticmethod
-    def forward(ctx, x, nn_idx, etype, filters, bias, nou, net, ext, agg, want_stats=False):
+    def forward(ctx, x, nn_idx, etype, filters, bias, nou, net, ext, agg, bn=None):
         nn_idx = shared_graph_view(nn_idx)               # saved in this form: the backward takes the same fast path
         # edge weights shared by the batch arrive un-expanded ([1, net, M, k], see mpconv()): their gradient is the batch SUM
         ctx.shared_et = etype.shape[0] == 1 and x.shape[0] > 1
         if ctx.shared_et:
             etype = etype.expand(x.shape[0], -1, -1, -1)
-        z, amax = mpconv_forward_raw(x, nn_idx, etype, filters, bias, nou, net, ext, agg, want_stats=want_stats,
-                                     want_argmax=True)
+        z, amax = mpconv_forward_raw(x, nn_idx, etype, filters, bias, nou, net, ext, agg, bn=bn, want_argmax=True)
         if ROUTE_TAP is not None:
             ROUTE_TAP(filters, amax)
         ctx.cfg = (nou, net, ext, agg)
@@ -498,15 +518,77 @@ def _unexpanded(etype):
     return etype[:1]
 
 
-def mpconv(x, nn_idx, etype, filters, bias, nou, net, ext, agg, want_stats=False):
-    """Differentiable pre-BatchNorm operator output z [B, nou, M, 1]."""
+def mpconv(x, nn_idx, etype, filters, bias, nou, net, ext, agg, bn=None):
+    """Differentiable pre-BatchNorm operator output z [B, nou, M, 1].  ``bn``: see mpconv_forward_raw."""
     if ext != _hip.EXT_NONE:                             # a [1, net, M, k] etype (shared edge weights, not expanded) is taken as is
         base = _unexpanded(etype)
         if base is not None:
             etype = base
     elif etype.shape[0] == 1 and x.shape[0] > 1:
         etype = etype.expand(x.shape[0], -1, -1, -1)
-    return _MPConv.apply(x, nn_idx, etype, filters, bias, nou, net, ext, agg, want_stats)
+    return _MPConv.apply(x, nn_idx, etype, filters, bias, nou, net, ext, agg, bn)
+
+
+def single_source_fanout(x, nn_idx, etype):
+    """M when the call is ONE source node feeding M > 1 destinations through identical single edges — x [B, C, 1, 1], nn_idx
+    [B, M, 1], etype [B, net, M, 1] equal for all m — so that every destination receives the same message and the operator's
+    output is a per-sample vector broadcast over the nodes (the LDPC hyper-factor's call, /root/reference/train_ldpc.py:40-46,82-88:
+    `hnn_idx_f2v` == 0, `hetype_f2v` == 1); else 0.  Equality of the edge weights over the nodes is read from a stride-0 node axis,
+    or checked on the device once per tensor WITHOUT a gradient (remembered on the tensor that owns the memory, as
+    blocks._is_identity_list; never while a hipGraph is being captured: an unseen tensor is then taken as general)."""
+    if not FANOUT_BROADCAST or x.dim() != 4 or x.shape[2] != 1 or x.shape[3] != 1 or nn_idx.dim() != 3:
+        return 0
+    B, M, k = nn_idx.shape
+    if k != 1 or M <= 1 or not x.is_cuda or etype.shape[2] != M:
+        return 0
+    if etype.stride(2) == 0:
+        return M
+    if etype.requires_grad:
+        return 0
+    owner = etype._base if etype._base is not None else etype
+    key = (etype._version, etype.data_ptr(), tuple(etype.shape), tuple(etype.stride()))
+    memo = getattr(owner, '_fgnn_node_invariant', None)
+    if memo is None or memo[0] != key:
+        if torch.cuda.is_current_stream_capturing():
+            return 0
+        memo = (key, bool((etype == etype[:, :, :1, :]).all().item()))
+        owner._fgnn_node_invariant = memo
+    return M if memo[1] else 0
+
+
+FANOUT_BROADCAST = os.environ.get('FGNN_NO_FANOUT_BROADCAST') is None     # (the variable: an A/B switch for tools / bench runs)
+
+
+class _BroadcastNodes(torch.autograd.Function):
+    """y1 [B, C, 1, 1] -> a stride-0 view [B, C, M, 1]; backward = one node-sum pass (csrc/sum_n.hip).  The view carries its source
+    (``_fgnn_bcast_src``): consumers that can add a per-sample row themselves (the fused BatchNorm / block-tail apply kernels,
+    ``addend_period``) take the [B, C] source directly — nothing of size [B, C, M] is then written or read for this tensor, forward or
+    backward — and every other consumer sees an ordinary (expanded) tensor."""
+
+    @staticmethod
+    def forward(ctx, y1, M):
+        ctx.M = M
+        return y1.expand(-1, -1, M, -1)
+
+    @staticmethod
+    def backward(ctx, g):
+        backward_node_begins()
+        from .mpnn import pointwise
+        B, C, M, _ = g.shape
+        rows = g.permute(0, 2, 3, 1)
+        if not rows.is_contiguous():
+            rows = rows.contiguous()
+        return pointwise.node_sum(rows.reshape(B * M, C), M).view(B, 1, 1, C).permute(0, 3, 1, 2), None
+
+
+def broadcast_nodes(y1, M):
+    """The per-sample vector ``y1`` [B, C, 1, 1] as the [B, C, M, 1] tensor the reference materialises (see _BroadcastNodes)."""
+    if torch.is_grad_enabled() and y1.requires_grad:
+        out = _BroadcastNodes.apply(y1, M)
+    else:
+        out = y1.expand(-1, -1, M, -1)
+    out._fgnn_bcast_src = y1
+    return out
 
 
 def _dense_same_layout(ts):

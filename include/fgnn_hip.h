@@ -54,6 +54,30 @@ typedef struct fgnn_mpconv_desc {
 } fgnn_mpconv_desc;
 
 /*
+ * Batch-statistics BatchNorm, forward finalisation (torch.nn.BatchNorm2d semantics: the reference's conv1 / conv2 BatchNorms,
+ * mp_nn_residual.py:25-35, mp_conv_v2.bn, mp_nn.py:57-58,170-173, iid_mapping_bn, base_model.py:62-79): what to compute from the
+ * per-channel sums a kernel has formed over `count` rows.  All vectors float32 [C].  Kernels that take a `fgnn_bn_final` together
+ * with a `fold_scratch` finalise the statistics THEMSELVES — their last workgroup folds the per-workgroup partial rows in a fixed
+ * order (csrc/fgnn_gridfold.h) — so no finaliser launch follows them.
+ *   fold_scratch: FGNN_FOLD_SCRATCH_BYTES of device memory, ZERO when first handed over and only ever passed to kernels of one
+ *   stream at a time (ticket counters, reset by their last user, and second-level rows).
+ */
+typedef struct fgnn_bn_final {
+    const float* gamma;            /* or NULL = 1 */
+    const float* beta;             /* or NULL = 0 */
+    float* running_mean;           /* updated in place with `momentum`, or NULL */
+    float* running_var;            /* ... with the UNBIASED variance over `population` rows */
+    int64_t* num_batches_tracked;  /* += 1, or NULL */
+    float* mean; float* invstd; float* scale; float* shift;   /* outputs: scale = gamma invstd, shift = beta - mean scale */
+    const float* shift_k;          /* per-channel constant the producer left out of its sums (a bias added later), or NULL */
+    int64_t count;                 /* rows the sums run over */
+    int64_t population;            /* rows the statistics stand for in the unbiased running variance (0 = count): a tensor that is ONE row
+                                      broadcast over m nodes has count rows but count * m of them in the reference's BatchNorm */
+    float momentum, eps;
+} fgnn_bn_final;
+#define FGNN_FOLD_SCRATCH_BYTES (512 + 64 * 512 * 8)
+
+/*
  * Forward: y = act( post_scale * (agg_j sum_e etype[e,m,j] * msg[m,j,:,e] + bias) + post_shift )
  * Replaces mp_conv_v2.forward steps a-k: gather -> matmul(filters) -> bmm(etype)
  * -> aggregate -> +bias -> (eval-mode BatchNorm folded into post_scale/post_shift) -> ReLU.
@@ -123,7 +147,8 @@ int fgnn_mpconv_backward_reduces_getype(const fgnn_mpconv_desc* d);
 int fgnn_mpconv_forward_stats_partials(const fgnn_mpconv_desc* d);
 int fgnn_mpconv_forward_stats(const fgnn_mpconv_desc* d, const void* x, const int64_t* nn_idx, const void* etype,
                               const float* filters, const float* bias, void* y, uint8_t* argmax, float* stats_partials,
-                              fgnn_stream_t stream);
+                              const fgnn_bn_final* fin, void* fold_scratch, fgnn_stream_t stream);
+/* fin (with fold_scratch; or NULL): the BatchNorm behind the operator is finalised by this launch (fgnn_bn_final: count = B * M). */
 
 int64_t fgnn_mpconv_forward_lds_bytes(const fgnn_mpconv_desc* d);
 
@@ -139,7 +164,9 @@ int64_t fgnn_mpconv_algorithmic_bytes(const fgnn_mpconv_desc* d);
  * (y = x W) — the grad-input product gy W of a map whose own weight is stored [cout'][cin'].
  */
 int fgnn_linear_forward(const void* x, const float* W, const float* bias, void* y, int64_t R, int32_t Cin,
-                        int32_t Cout, float* stats_partials, int32_t w_transposed, fgnn_stream_t stream);
+                        int32_t Cout, float* stats_partials, const fgnn_bn_final* fin, void* fold_scratch, int32_t w_transposed,
+                        fgnn_stream_t stream);
+/* fin (with stats_partials and fold_scratch; or NULL): the BatchNorm behind the map is finalised by this launch (see fgnn_bn_final). */
 
 /*
  * The node-wise map FOLLOWED BY InstanceNorm (+ ReLU) in one pass — `iid_mapping_in`, /root/reference/lib/model/mpnn/base_model.py:82-90
@@ -181,33 +208,36 @@ int fgnn_instnorm_backward(const void* x, const void* gy, void* gx, int32_t B, i
  *     a2 = act2(e * scale2 + shift2);   z3 = a2 W2^T + b2  (W2 [Cout][64] f32, Cout in {64, 128, 256});
  *     out = act3(z3 * scale3 + shift3) + addend0 + addend1 + addend2
  * with batch-statistics BatchNorms, WITHOUT storing the Cout-wide z3: every pass recomputes it from e on the matrix cores.
- *   fgnn_block_tail_stats   : per-workgroup (sum z3, sum z3^2) partials [fgnn_block_tail_partials(R, Cout)][2][Cout] for
- *                             fgnn_bn_finalize_shifted (BatchNorm3's batch statistics).
- *   fgnn_block_tail_apply   : out [R][Cout] bf16 (addends: bf16 [R][Cout] or NULL); a2_out (or NULL) receives a2 [R][64]
- *                             bf16 for the weight-gradient kernel of the backward.
+ *   fgnn_block_tail_stats   : BatchNorm3's batch statistics -> *fin (count = R; the kernel sums z3 - b2 and finalises with
+ *                             K = b2 itself: pass fin->shift_k = NULL); partials: fgnn_block_tail_partials(R, Cout) rows of
+ *                             [2][Cout] floats of scratch.
+ *   fgnn_block_tail_apply   : out [R][Cout] bf16 (addends: bf16 [R][Cout], or [R / period][Cout] with addend_period, or NULL);
+ *                             a2_out (or NULL) receives a2 [R][64] bf16 for the weight-gradient kernel of the backward.
  *   fgnn_block_tail_backward: from gout [R][Cout]: BatchNorm3's parameter gradients (ACCUMULATED into gweight3 / gbias3, may
  *                             be NULL), gz3 [R][Cout] = the gradient of z3 (bf16; what fgnn_linear_wgrad contracts with a2)
- *                             and ga2 [R][64] = gz3 W2 (the gradient of a2, before act2' / BatchNorm2).  Three launches
- *                             (reduce, finalise, grad).  workspace: >= (2048 * Cout + 2 * Cout) * 4 bytes.  bn2_partials (or
- *                             NULL): fgnn_block_tail_backward_partials(R, Cout) rows of [2][64] floats receiving BatchNorm2's
- *                             backward sums (sum g2', sum g2' e; g2' = ga2 act2'(.)) for fgnn_bn_backward_partials — the
- *                             64-channel BatchNorm then needs no reduction pass of its own.
- *   The statistics partials of fgnn_block_tail_stats are sums of z3 - b2: finalise them with fgnn_bn_finalize_shifted(K = b2).
+ *                             and ga2 [R][64] = gz3 W2 (the gradient of a2, before act2' / BatchNorm2).
+ *                             workspace: >= (2048 * Cout + 2 * Cout + 1024 * 128) * 4 bytes.
  * slope: LeakyReLU slope of the activation (0 = ReLU, 1 = none).  FGNN_EUNSUPPORTED outside this family.
  */
 int fgnn_block_tail_partials(int64_t R, int32_t Cout);
 int fgnn_block_tail_stats(const void* e, const float* scale2, const float* shift2, float slope2, const float* W2,
-                          const float* b2, int64_t R, int32_t Cout, float* partials, fgnn_stream_t stream);
+                          const float* b2, int64_t R, int32_t Cout, float* partials, const fgnn_bn_final* fin,
+                          void* fold_scratch, fgnn_stream_t stream);
+/* addend_period (NULL = {1,1,1}): see fgnn_bn_apply. */
 int fgnn_block_tail_apply(const void* e, const float* scale2, const float* shift2, float slope2, const float* W2,
                           const float* b2, const float* scale3, const float* shift3, float slope3, const void* addend0,
-                          const void* addend1, const void* addend2, void* out, void* a2_out, int64_t R, int32_t Cout,
-                          fgnn_stream_t stream);
+                          const void* addend1, const void* addend2, const int32_t* addend_period, void* out, void* a2_out,
+                          int64_t R, int32_t Cout, fgnn_stream_t stream);
+/* bn2_dsum (or NULL, with mean2 / invstd2; gweight2 / gbias2 ACCUMULATED into, may be NULL): [2][64] floats receiving BatchNorm2's
+ * backward sums (dbeta, dgamma) for fgnn_bn_backward_apply — the 64-channel BatchNorm then needs no reduction pass of its own.
+ * Two launches (reduce, grad), each finalising its sums in its last workgroup. */
 int fgnn_block_tail_backward(const void* e, const float* scale2, const float* shift2, float slope2, const float* W2,
                              const float* b2, const float* mean3, const float* invstd3, const float* gamma3,
                              const float* scale3, const float* shift3, float slope3, const void* gout, void* gz3, void* ga2,
-                             float* gweight3, float* gbias3, float* bn2_partials, int64_t R, int32_t Cout, void* workspace,
-                             int64_t workspace_bytes, fgnn_stream_t stream);
-int fgnn_block_tail_backward_partials(int64_t R, int32_t Cout);
+                             float* gweight3, float* gbias3, const float* mean2, const float* invstd2, float* gweight2,
+                             float* gbias2, float* bn2_dsum, int64_t R, int32_t Cout, void* workspace, int64_t workspace_bytes,
+                             void* fold_scratch, fgnn_stream_t stream);
+int fgnn_block_tail_backward_partials(int64_t R, int32_t Cout);   /* workgroups (= BatchNorm2 partial rows) of the backward's grad launch */
 
 /*
  * HEAD of a training-mode `mp_conv_residual`, backward: autograd through `self.conv1` = Conv2d(nin, nmed, 1) -> BatchNorm2d ->
@@ -221,7 +251,7 @@ int fgnn_block_tail_backward_partials(int64_t R, int32_t Cout);
 int fgnn_block_head_backward(const void* z1, const void* ga1, const float* mean, const float* invstd, const float* gamma,
                              const float* beta, float slope, const float* W1, void* gz1, void* gx, float* gweight,
                              float* gbias, int64_t R, int32_t Cin, void* workspace, int64_t workspace_bytes,
-                             fgnn_stream_t stream);
+                             void* fold_scratch, fgnn_stream_t stream);
 
 /*
  * Train-mode BatchNorm fused with the LeakyReLU(slope) behind it (slope 0 = ReLU, 1 = none) on dense
@@ -231,35 +261,28 @@ int fgnn_block_head_backward(const void* z1, const void* ga1, const float* mean,
  */
 int fgnn_bn_supported(int64_t R, int32_t C, int32_t dtype);
 int64_t fgnn_bn_workspace_bytes(int64_t R, int32_t C);
-int fgnn_bn_stats(const void* x, int64_t R, int32_t C, int32_t dtype, const float* gamma, const float* beta,
-                  float* running_mean, float* running_var, float momentum, float eps, float* mean,
-                  float* invstd, float* scale, float* shift, int64_t* num_batches_tracked, void* workspace,
-                  int64_t workspace_bytes, fgnn_stream_t stream);
-/* Same outputs as fgnn_bn_stats from per-workgroup (sum, sum of squares) partials [npartials][2][C] written by
- * fgnn_linear_forward's epilogue: the BatchNorm behind a node-wise map needs no statistics pass of its own. */
-int fgnn_bn_finalize(const float* partials, int32_t npartials, int64_t R, int32_t C, const float* gamma,
-                     const float* beta, float* running_mean, float* running_var, float momentum, float eps,
-                     float* mean, float* invstd, float* scale, float* shift, int64_t* num_batches_tracked,
-                     fgnn_stream_t stream);
+int fgnn_bn_stats(const void* x, int64_t R, int32_t C, int32_t dtype, const fgnn_bn_final* fin, void* workspace,
+                  int64_t workspace_bytes, void* fold_scratch, fgnn_stream_t stream);
+/* The same outputs from per-workgroup partials [npartials][2][C] of (sum (y - K), sum (y - K)^2), K = fin->shift_k or 0, formed
+ * OUTSIDE this library (its own producers — fgnn_linear_forward, fgnn_mpconv_forward_stats, fgnn_block_tail_stats — take the
+ * fgnn_bn_final themselves). */
+int fgnn_bn_finalize(const float* partials, int32_t npartials, int32_t C, const fgnn_bn_final* fin, fgnn_stream_t stream);
 /* y = act(x*scale + shift) + addend + addend2 + addend3: up to three tensors of y's layout (NULL = absent) ride in
- * the apply pass — the `acc + block(x) + residual + skip` sums of factor_mpnn_sp.py:139-170. */
-/* fgnn_bn_finalize for partials of (y - K[c]) (the producer summed before adding a per-channel constant K, e.g. a bias). */
-int fgnn_bn_finalize_shifted(const float* partials, int32_t npartials, int64_t R, int32_t C, const float* K, const float* gamma,
-                             const float* beta, float* running_mean, float* running_var, float momentum, float eps,
-                             float* mean, float* invstd, float* scale, float* shift, int64_t* num_batches_tracked,
-                             fgnn_stream_t stream);
-/* fgnn_bn_backward without its reduction pass: partials [npartials][2][C] of (sum g, sum g * x) (g = gy * act'(pre), x raw)
- * were left by the producer of gy (fgnn_block_tail_backward).  workspace: >= 2 * C floats. */
-int fgnn_bn_backward_partials(const void* x, const void* gy, void* gx, int64_t R, int32_t C, int32_t dtype, const float* mean,
-                              const float* invstd, const float* gamma, const float* beta, float slope, float* gweight,
-                              float* gbias, const float* partials, int32_t npartials, void* workspace, fgnn_stream_t stream);
+ * the apply pass — the `acc + block(x) + residual + skip` sums of factor_mpnn_sp.py:139-170.  addend_period (NULL = {1,1,1}):
+ * addend a has ONE row per addend_period[a] consecutive rows of y — a per-sample vector broadcast over the sample's nodes (the
+ * hyper-factor's message to the variables, train_ldpc.py:40-46,82-88: one source, hetype == 1, the same row for all 96 nodes). */
 int fgnn_bn_apply(const void* x, void* y, int64_t R, int32_t C, int32_t dtype, const float* scale,
                   const float* shift, float slope, const void* addend, const void* addend2, const void* addend3,
-                  fgnn_stream_t stream);
+                  const int32_t* addend_period, fgnn_stream_t stream);
 int fgnn_bn_backward(const void* x, const void* gy, void* gx, int64_t R, int32_t C, int32_t dtype,
                      const float* mean, const float* invstd, const float* gamma, const float* beta, float slope,
-                     float* gweight, float* gbias, void* workspace, int64_t workspace_bytes,
+                     float* gweight, float* gbias, void* workspace, int64_t workspace_bytes, void* fold_scratch,
                      fgnn_stream_t stream);
+/* The element-wise half of fgnn_bn_backward alone, from sums somebody else finalised: dsum [2][C] = (dbeta, dgamma), as
+ * fgnn_block_tail_backward leaves them for the 64-channel BatchNorm in front of conv2. */
+int fgnn_bn_backward_apply(const void* x, const void* gy, void* gx, int64_t R, int32_t C, int32_t dtype, const float* mean,
+                           const float* invstd, const float* gamma, const float* beta, float slope, const float* dsum,
+                           fgnn_stream_t stream);
 
 /*
  * Inference forward of a whole mp_conv_residual block (mp_nn_residual.py:39-56) in one kernel:
@@ -321,6 +344,12 @@ int fgnn_factor_layer_forward(int32_t B, const void* var, const void* fac0, cons
  * a state that fans out into several consumers (factor_mpnn_sp.py:139-170) instead of autograd's pairwise adds.
  */
 int fgnn_sum_n(const void* const* inputs, int32_t n, int64_t numel, int32_t dtype, void* out, fgnn_stream_t stream);
+/*
+ * out [B][C] = sum over the M rows of each sample of g [B][M][C] (dense channel-fastest rows): the backward of a per-sample row
+ * broadcast over the sample's nodes — the LDPC hyper-factor's message to the variables (train_ldpc.py:40-46,82-88: one source node,
+ * hetype == 1) is carried as [B][C] and added by the consumer with `addend_period` (fgnn_block_tail_apply, fgnn_bn_apply).
+ */
+int fgnn_node_sum(const void* g, void* out, int64_t B, int32_t M, int32_t C, int32_t dtype, fgnn_stream_t stream);
 
 /*
  * One Adam step (torch.optim.Adam's rule, no amsgrad — the optimizer of the reference's training scripts, e.g.
@@ -409,7 +438,7 @@ const char* fgnn_last_kernel(void);
  * mismatch and not as a missing symbol or a misread field.  4: round-2 additions (flat_adam, factor_layer_*,
  * ldpc_channel_features_rng, backward_reduces_getype, desc.reserved = in-degree | GETYPE_REDUCED); 5: fgnn_block_tail_*;
  * 6: fgnn_block_head_backward. */
-#define FGNN_ABI_VERSION 7
+#define FGNN_ABI_VERSION 8
 int fgnn_abi_version(void);
 
 #ifdef __cplusplus

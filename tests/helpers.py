@@ -101,3 +101,12 @@ def syn_edge_models(hi_ef):
     em_pw.load_state_dict(syn_fill(em_pw.state_dict()))
     em_hi.load_state_dict(syn_fill(em_hi.state_dict()))
     return em_pw, em_hi
+
+
+def bn_spec_for(C, dev, seed=0):
+    """A ``pointwise.bn_spec`` tuple (gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps) with fresh buffers:
+    what a statistics-producing launch needs to finalise the BatchNorm behind it."""
+    import torch
+    g = torch.Generator().manual_seed(seed)
+    return ((torch.rand(C, generator=g) + 0.5).to(dev), (torch.randn(C, generator=g) * 0.3).to(dev), torch.zeros(C, device=dev),
+            torch.ones(C, device=dev), torch.zeros((), device=dev, dtype=torch.int64), 0.1, 1e-5)

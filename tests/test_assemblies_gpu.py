@@ -1071,6 +1071,37 @@ def test_fast_path_switch_for_an_unchanged_script(dev):
         assert torch.isfinite(loss) and abs(opt.flat.lr - 1e-3) < 1e-12 and abs(opt.param_groups[0]['lr'] - 5e-4) < 1e-12
         assert float((m.emodel_f2v[0].weight - before).abs().max()) > 0
         assert isinstance(torch.optim.Adam([torch.nn.Parameter(torch.zeros(3))], lr=1e-3), torch.optim.Adam.stock)   # CPU parameters: stock
+        # checkpoint round trip as train_ldpc.py:179-181,187 does it (model + optimizer state_dict): 2 steps, save, rebuild, load,
+        # 1 step == 3 straight steps, bit for bit (the moments and the step count travel in stock Adam's layout)
+        import copy, io
+        buf = io.BytesIO()
+        torch.save({'model': m.state_dict(), 'opt': opt.state_dict()}, buf)
+        sd = opt.state_dict()
+        assert len(sd['state']) == len(opt.param_groups[0]['params']) and float(sd['state'][0]['step']) == 2.0
+        assert float(sd['state'][0]['exp_avg'].abs().max()) > 0
+
+        def third_step(model, optimizer):
+            optimizer.zero_grad()
+            torch.nn.functional.binary_cross_entropy_with_logits(model(*data[:6]), label).backward()
+            optimizer.step()
+        third_step(m, opt)
+        buf.seek(0)
+        ck = torch.load(buf)
+        torch.manual_seed(11)
+        m2 = ScriptModel().to(dev).train()
+        for mod in m2.modules():
+            if isinstance(mod, torch.nn.modules.batchnorm._BatchNorm):
+                mod.momentum = 0.0
+        m2.load_state_dict(ck['model'])
+        fgnn_amd.fastpath.fast_path(m2)
+        opt2 = torch.optim.Adam(m2.parameters(), lr=1e-3, weight_decay=1e-8)
+        assert isinstance(opt2, FastAdam)
+        opt2.load_state_dict(ck['opt'])
+        assert opt2.flat.t == 2 and abs(opt2.param_groups[0]['lr'] - 5e-4) < 1e-12
+        third_step(m2, opt2)
+        torch.cuda.synchronize()
+        for (k, a), (_, b) in zip(m.state_dict().items(), m2.state_dict().items()):
+            assert torch.equal(a, b), k
     finally:
         fgnn_amd.disable_fast_path()
     assert not hasattr(torch.optim.Adam, 'stock')

@@ -37,18 +37,23 @@ def test_block_tail_kernels_vs_torch(R, Cout, dev):
     ws = torch.zeros(int(L.fgnn_bn_workspace_bytes(R, Cout)) // 4, device=dev)
     a2 = torch.empty_like(e)
     st = _hip.stream_ptr()
-    # ---- mode 0: statistics partials ----
-    _hip.check(L.fgnn_block_tail_stats(P(e), P(s2), P(t2), slope2, P(W2), P(b2), R, Cout, P(ws), st))
+    # ---- mode 0: statistics partials, and BatchNorm3 finalised by the SAME launch (its last workgroup: csrc/fgnn_gridfold.h) ----
+    from fgnn_amd import ops
+    fold = ops._fold_scratch(dev)
+    gamma3, beta3 = (torch.rand(Cout, generator=g) + 0.5).to(dev), torch.randn(Cout, generator=g).to(dev)
+    rm, rv = torch.zeros(Cout, device=dev), torch.ones(Cout, device=dev)
+    nbt = torch.zeros((), device=dev, dtype=torch.int64)
+    st3 = torch.full((4, Cout), float('nan'), device=dev)
+    fin = _hip.bn_final(st3, gamma3, beta3, rm, rv, nbt, 0.1, 1e-5, R, 3 * R)       # (population 3 R: as if every row stood for three)
+    _hip.check(L.fgnn_block_tail_stats(P(e), P(s2), P(t2), slope2, P(W2), P(b2), R, Cout, P(ws), fin, P(fold), st))
     part = ws[:npart * 2 * Cout].reshape(npart, 2, Cout).double().sum(0)      # sums of z3 - b2
     zz = z3.double()
     z0 = zz - b2.double()
     assert H.rel_err(part[0], z0.sum(0)) <= 1e-4 and H.rel_err(part[1], (z0 * z0).sum(0)) <= 1e-4
-    # BatchNorm3 through the library's finaliser on those partials
-    gamma3, beta3 = (torch.rand(Cout, generator=g) + 0.5).to(dev), torch.randn(Cout, generator=g).to(dev)
-    rm, rv = torch.zeros(Cout, device=dev), torch.ones(Cout, device=dev)
-    st3 = torch.empty(4, Cout, device=dev)
-    _hip.check(L.fgnn_bn_finalize_shifted(P(ws), npart, R, Cout, P(b2), P(gamma3), P(beta3), P(rm), P(rv), 0.1, 1e-5, P(st3[0]),
-                                          P(st3[1]), P(st3[2]), P(st3[3]), None, st))
+    assert int(nbt) == 1 and int(fold[:65].abs().sum()) == 0               # the ticket counters are back at zero
+    n3 = 3.0 * R
+    assert H.rel_err(rm, 0.1 * zz.mean(0)) <= 1e-4
+    assert H.rel_err(rv - 0.9, 0.1 * zz.var(0, unbiased=False) * n3 / (n3 - 1.0)) <= 2e-3
     mean, var = zz.mean(0), zz.var(0, unbiased=False)
     assert H.rel_err(st3[0], mean) <= 1e-4
     if R > 1:               # (a single row: variance 0 on one side, rounding noise on the other — invstd ~ eps^-1/2 either way)
@@ -60,7 +65,7 @@ def test_block_tail_kernels_vs_torch(R, Cout, dev):
         ap = [P(a) for a in adds[:nadd]] + [None] * (3 - nadd)
         a2.zero_()
         _hip.check(L.fgnn_block_tail_apply(P(e), P(s2), P(t2), slope2, P(W2), P(b2), P(st3[2]), P(st3[3]), slope3, ap[0], ap[1],
-                                           ap[2], P(out), P(a2) if nadd != 1 else None, R, Cout, st))
+                                           ap[2], None, P(out), P(a2) if nadd != 1 else None, R, Cout, st))
         if nadd != 1:
             assert H.rel_err(a2.float(), a2_ref.float()) <= 2.0 ** -8        # (the kernel's affine is one fused multiply-add)
         ref = torch.nn.functional.leaky_relu(z3 * st3[2] + st3[3], slope3)
@@ -71,11 +76,15 @@ def test_block_tail_kernels_vs_torch(R, Cout, dev):
     gout = torch.randn(R, Cout, generator=g).bfloat16().to(dev)
     gz3, ga2 = torch.empty(R, Cout, device=dev, dtype=torch.bfloat16), torch.empty(R, 64, device=dev, dtype=torch.bfloat16)
     gw3, gb3 = torch.zeros(Cout, device=dev), torch.zeros(Cout, device=dev)
-    np2 = int(L.fgnn_block_tail_backward_partials(R, Cout))
-    part2 = torch.zeros(np2, 2, 64, device=dev)
+    # BatchNorm2's statistics as the forward would have left them (any values do for the arithmetic under test)
+    mean2, invstd2 = (torch.randn(64, generator=g) * 0.1).to(dev), (torch.rand(64, generator=g) + 0.5).to(dev)
+    gw2, gb2 = torch.zeros(64, device=dev), torch.zeros(64, device=dev)
+    dsum2 = torch.full((2, 64), float('nan'), device=dev)
+    wsb = torch.zeros((2048 * Cout + 2 * Cout + 1024 * 128), device=dev)
     _hip.check(L.fgnn_block_tail_backward(P(e), P(s2), P(t2), slope2, P(W2), P(b2), P(st3[0]), P(st3[1]), P(gamma3), P(st3[2]),
-                                          P(st3[3]), slope3, P(gout), P(gz3), P(ga2), P(gw3), P(gb3), P(part2), R, Cout, P(ws),
-                                          ws.numel() * 4, st))
+                                          P(st3[3]), slope3, P(gout), P(gz3), P(ga2), P(gw3), P(gb3), P(mean2), P(invstd2), P(gw2),
+                                          P(gb2), P(dsum2), R, Cout, P(wsb), wsb.numel() * 4, P(fold), st))
+    assert int(fold[:65].abs().sum()) == 0
     zl = z3.detach().clone().requires_grad_(True)
     gam, bet = gamma3.clone().requires_grad_(True), beta3.clone().requires_grad_(True)
     zh = (zl - zl.mean(0)) * torch.rsqrt(zl.var(0, unbiased=False) + 1e-5)
@@ -86,11 +95,53 @@ def test_block_tail_kernels_vs_torch(R, Cout, dev):
         assert H.rel_err(gw3, gam.grad) <= 2e-3 and H.rel_err(gb3, bet.grad) <= 2e-3
     ga_ref = gz3.float() @ W2.bfloat16().float()
     assert H.rel_err(ga2.float(), ga_ref) <= 2.0 ** -7
-    # BatchNorm2's backward sums ride along: sum g2', sum g2' e with g2' = ga2 act2'(pre2) (from the f32 accumulators)
+    # BatchNorm2's backward sums ride along, finalised by the grad kernel: dbeta = sum g2', dgamma = invstd2 (sum g2' e - mean2 sum g2'),
+    # g2' = ga2 act2'(pre2) (from the f32 accumulators)
     pos = (e.float() * s2 + t2) > 0
     g2 = torch.where(pos, ga_ref, ga_ref * slope2).double()
-    p2 = part2.double().sum(0)
-    assert H.rel_err(p2[0], g2.sum(0)) <= 2e-3 and H.rel_err(p2[1], (g2 * e.double()).sum(0)) <= 2e-3
+    dbeta = g2.sum(0)
+    dgamma = invstd2.double() * ((g2 * e.double()).sum(0) - mean2.double() * dbeta)
+    tol = 2e-3 * max(1.0, float(dgamma.abs().max()), float((g2 * e.double()).sum(0).abs().max()))
+    assert H.rel_err(dsum2[0], dbeta) <= 2e-3 and float((dsum2[1].double() - dgamma).abs().max()) <= tol
+    assert torch.equal(gb2, dsum2[0]) and torch.equal(gw2, dsum2[1])
+
+
+@pytest.mark.parametrize('Cout', [64, 256])
+def test_block_tail_apply_broadcasts_a_per_sample_addend(Cout, dev):
+    """fgnn_block_tail_apply / fgnn_bn_apply with `addend_period`: an addend of ONE row per `period` output rows (the hyper-factor's
+    message to the 96 variables of a codeword, carried as [B][C]) == the same addend materialised."""
+    from fgnn_amd import _hip
+    L = _hip.lib()
+    P = _hip._ptr
+    Bn, M = 37, 96
+    R = Bn * M
+    g = torch.Generator().manual_seed(Cout)
+    e = torch.randn(R, 64, generator=g).bfloat16().to(dev)
+    s2, t2 = (torch.rand(64, generator=g) + 0.5).to(dev), (torch.randn(64, generator=g) * 0.3).to(dev)
+    W2, b2 = (torch.randn(Cout, 64, generator=g) * 0.2).to(dev), torch.randn(Cout, generator=g).to(dev)
+    s3, t3 = (torch.rand(Cout, generator=g) + 0.5).to(dev), torch.randn(Cout, generator=g).to(dev)
+    full = torch.randn(R, Cout, generator=g).bfloat16().to(dev)
+    small = torch.randn(Bn, Cout, generator=g).bfloat16().to(dev)
+    big = small[:, None, :].expand(Bn, M, Cout).reshape(R, Cout).contiguous()
+    st = _hip.stream_ptr()
+    outs = []
+    for adds, periods in (((full, big, None), None), ((full, small, None), (ctypes.c_int32 * 3)(1, M, 1)),
+                          ((small, full, None), (ctypes.c_int32 * 3)(M, 1, 1))):
+        out = torch.empty(R, Cout, device=dev, dtype=torch.bfloat16)
+        _hip.check(L.fgnn_block_tail_apply(P(e), P(s2), P(t2), 0.0, P(W2), P(b2), P(s3), P(t3), 0.01, P(adds[0]), P(adds[1]), None,
+                                           periods, P(out), None, R, Cout, st))
+        outs.append(out)
+    assert torch.equal(outs[0], outs[1])
+    assert H.rel_err(outs[2].float(), outs[0].float()) <= 2.0 ** -7          # (the other order of two bf16-exact f32 additions)
+    x = torch.randn(R, Cout, generator=g).bfloat16().to(dev)
+    ya, yb = torch.empty_like(x), torch.empty_like(x)
+    _hip.check(L.fgnn_bn_apply(P(x), P(ya), R, Cout, _hip.BF16, P(s3), P(t3), 0.0, P(big), P(full), None, None, st))
+    _hip.check(L.fgnn_bn_apply(P(x), P(yb), R, Cout, _hip.BF16, P(s3), P(t3), 0.0, P(small), P(full), None, (ctypes.c_int32 * 3)(M, 1, 1), st))
+    assert torch.equal(ya, yb)
+    # and the backward of the broadcast: the node sum
+    gs = torch.empty(Bn, Cout, device=dev, dtype=torch.bfloat16)
+    _hip.check(L.fgnn_node_sum(P(full), P(gs), Bn, M, Cout, _hip.BF16, st))
+    assert H.rel_err(gs.float(), full.float().reshape(Bn, M, Cout).sum(1)) <= 2.0 ** -8
 
 
 CASES = [  # nin, nout, N, M, k, net
@@ -212,15 +263,16 @@ def test_block_head_backward_kernel_vs_torch(R, Cin, dev):
     gw, gb = torch.zeros(64, device=dev), torch.zeros(64, device=dev)
     ws = ops._workspace(dev, int(L.fgnn_bn_workspace_bytes(R, 64)))
     z1d, gad, md, isd, gd, bd, Wd = d(z1), d(ga1), d(mean.detach()), d(invstd.detach()), d(gamma), d(beta), d(W1)
+    fold = ops._fold_scratch(dev)
     _hip.check(L.fgnn_block_head_backward(P(z1d), P(gad), P(md), P(isd), P(gd), P(bd), slope, P(Wd), P(gz), P(gx), P(gw), P(gb), R, Cin,
-                                          P(ws), ws.numel() * 4, _hip.stream_ptr()))
+                                          P(ws), ws.numel() * 4, P(fold), _hip.stream_ptr()))
     assert _hip.lib().fgnn_last_kernel().decode() == 'block_head_bwd_kernel<%d>' % (Cin // 64)
     assert H.rel_err(gz.float().cpu(), gz_ref) <= 2.0 ** -7
     assert H.rel_err(gx.float().cpu(), gx_ref) <= 2.0 ** -7
     assert H.rel_err(gw.cpu(), gam.grad) <= 1e-3 and H.rel_err(gb.cpu(), bet.grad) <= 1e-3
     with pytest.raises(_hip.FgnnHipError):
         _hip.check(L.fgnn_block_head_backward(P(z1d), P(gad), P(md), P(isd), P(gd), P(bd), slope, P(Wd), P(gz), P(gx), P(gw), P(gb), R, 96,
-                                              P(ws), ws.numel() * 4, _hip.stream_ptr()))
+                                              P(ws), ws.numel() * 4, P(fold), _hip.stream_ptr()))
 
 
 @pytest.mark.parametrize('case', CASES[:5], ids=lambda c: 'x'.join(map(str, c)))
@@ -273,3 +325,85 @@ def test_fused_training_head_matches_staged_head(case, dev, monkeypatch):
             assert torch.equal(f[n], s[n]), n                 # everything behind the head sees the same tensors
     for n in ('gx', 'conv1.0.weight', 'conv1.1.weight', 'conv1.1.bias'):
         assert H.rel_err(f[n], s[n]) <= 2.0 ** -7, (n, H.rel_err(f[n], s[n]))
+
+
+@pytest.mark.parametrize('width', [(64, 64), (128, 256), (256, 256), (256, 128), 'plain64to128', 'plain128to64'], ids=str)
+def test_single_source_fanout_runs_on_one_row_per_sample(width, dev, monkeypatch):
+    """The LDPC hyper-factor -> variables call (/root/reference/train_ldpc.py:40-46,82-88: ONE source node, `hnn_idx_f2v` == 0,
+    `hetype_f2v` == 1): every one of the 96 destinations receives the same message, so the block (or the plain operator of the
+    64 <-> 128 layers, factor_mpnn_sp.py:88-91) is computed on one row per sample and handed on as a broadcast
+    (ops.single_source_fanout / ops.broadcast_nodes).  Against the SAME module run on the 96 materialised rows (switch off):
+    output, BatchNorm running statistics — the unbiased variance counts B * 96 rows either way —, the gradient of the input and of
+    every parameter; and against the f32 oracle's block."""
+    from fgnn_amd import ops
+    from fgnn_amd.mpnn import mp_conv_residual, mp_conv_type, mp_conv_v2
+    B, M = 48, 96
+    plain = isinstance(width, str)
+    nin, nout = ((64, 128) if width == 'plain64to128' else (128, 64)) if plain else width
+    g = torch.Generator().manual_seed(nin + 3 * nout)
+    torch.manual_seed(7)
+    if plain:
+        m = mp_conv_v2(nin, nout, 1, extension=mp_conv_type.NO_EXTENSION, aggregtor='max').to(dev).train()
+        filt = m.filters
+    else:
+        m = mp_conv_residual(nin, 64, 1, extension=mp_conv_type.NO_EXTENSION, with_residual=False, aggregator='max',
+                             nout=None if nout == nin else nout).to(dev).train()
+        filt = m.mp_conv.filters
+    with torch.no_grad():
+        filt.mul_(10.0)
+    x = torch.randn(B, 1, 1, nin, generator=g).bfloat16().to(dev).permute(0, 3, 1, 2)
+    idx = torch.zeros(1, M, 1, dtype=torch.int64, device=dev).expand(B, -1, -1)
+    w = torch.full((1, 1, 1, 1), 1.0, device=dev, dtype=torch.bfloat16)
+    et = w.expand(B, 1, M, 1)                                   # one weight for all destinations: a stride-0 node axis
+    gy = torch.randn(B, M, 1, nout, generator=g).bfloat16().to(dev).permute(0, 3, 1, 2)
+    sd0 = {k_: v.clone() for k_, v in m.state_dict().items()}
+
+    def run(broadcast):
+        monkeypatch.setattr(ops, 'FANOUT_BROADCAST', broadcast)
+        m.load_state_dict(sd0)
+        for q in m.parameters():
+            q.grad = None
+        xd = x.detach().requires_grad_(True)
+        with torch.autocast('cuda', dtype=torch.bfloat16):
+            y = m(xd, idx, et)
+        assert (getattr(y, '_fgnn_bcast_src', None) is not None) == broadcast and tuple(y.shape) == (B, nout, M, 1)
+        y.backward(gy)
+        out = {'y': y.detach().float().cpu(), 'gx': xd.grad.float().cpu()}
+        out.update({n: q.grad.detach().float().cpu() for n, q in m.named_parameters() if q.grad is not None})
+        stats = {n: v.detach().double().cpu().clone() for n, v in m.state_dict().items() if 'running' in n or 'tracked' in n}
+        return out, stats
+
+    b, bs = run(True)
+    f, fs = run(False)
+    assert H.rel_err(b['y'], f['y']) <= 2.0 ** -6
+    assert float((b['y'] - b['y'][:, :, :1, :]).abs().max()) == 0.0
+    for n in fs:        # (the conv1 BatchNorm sees B rows either way; the two behind the operator B x 96 identical ones)
+        assert H.rel_err(bs[n], fs[n]) <= 1e-3, n
+    # the f32 oracle on the same (bf16-rounded) inputs, the 96 rows materialised as the reference does
+    sd = {k_: v.detach().cpu().float().clone() for k_, v in sd0.items()}
+    names = [n for n, _ in m.named_parameters()]
+    for n in names:
+        sd[n].requires_grad_(True)
+    xo = x.float().cpu().contiguous().requires_grad_(True)
+    eo = et.float().cpu().contiguous()
+    if plain:
+        ref = O.mp_conv(sd, '', xo, idx.cpu().contiguous(), eo, nou=nout, net=1, extension=0, aggregator='max', relu=True, training=True)
+    else:
+        ref = O.residual_block(sd, '', xo, idx.cpu().contiguous(), eo, net=1, extension=0, aggregator='max', with_residual=False,
+                               training=True)
+    ref.backward(gy.float().cpu())
+    assert H.rel_err(b['y'], ref) <= 2.0 ** -5
+    for n, v in bs.items():
+        if 'running' in n:
+            assert H.rel_err(v, sd[n].double()) <= 2e-2, n     # (the oracle updated its running statistics in place)
+    r = {'gx': xo.grad}
+    r.update({n: sd[n].grad for n in names})
+    gmax = max(float(v.abs().max()) for v in r.values() if v is not None)
+    checked = 0
+    for n, ref_g in r.items():
+        if ref_g is None or n not in b or float(ref_g.abs().max()) < 1e-3 * gmax:
+            continue                 # pure cancellation noise (a bias in front of a batch-statistics BatchNorm)
+        db, df = H.rel_err(b[n], ref_g), H.rel_err(f[n], ref_g)
+        assert db <= 1.5 * df + 2.0 ** -5, (n, db, df)
+        checked += 1
+    assert checked >= 3

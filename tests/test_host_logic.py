@@ -141,20 +141,40 @@ def test_side_entry_points_validate_their_arguments_without_a_gpu():
     assert 1 <= L.fgnn_block_tail_partials(393216, 256) <= 1024 and 1 <= L.fgnn_block_tail_backward_partials(393216, 64) <= 1024
     assert L.fgnn_block_tail_partials(393216, 96) == 0 and L.fgnn_block_tail_partials(0, 64) == 0
     assert L.fgnn_block_tail_partials(5, 64) == 1
-    stats = lambda e, part, Cout=64: L.fgnn_block_tail_stats(e, big, big, 0.0, big, None, 4096, Cout, part, None)
+    fin = _hip.BnFinal()
+    fin.mean = fin.invstd = fin.scale = fin.shift = 4096
+    fin.count = 4096
+    fref = ctypes.byref(fin)
+    stats = lambda e, part, Cout=64, f=fref: L.fgnn_block_tail_stats(e, big, big, 0.0, big, None, 4096, Cout, part, f, big, None)
     assert stats(None, big) == -1 and b'null pointer' in L.fgnn_last_error()
-    assert stats(big, None) == -1
+    assert stats(big, None) == -1 and stats(big, big, f=None) == -1
     assert stats(big, big, Cout=96) == _hip.EUNSUPPORTED and stats(ctypes.c_void_p(4100), big) == _hip.EUNSUPPORTED
-    apply = lambda out, add0=None: L.fgnn_block_tail_apply(big, big, big, 0.0, big, None, big, big, 0.01, add0, None, None, out, None,
-                                                           4096, 128, None)
+    fin.count = 4095
+    assert stats(big, big) == -1 and b'count' in L.fgnn_last_error()          # the statistics run over exactly R rows
+    fin.count = 4096
+    apply = lambda out, add0=None, per=None: L.fgnn_block_tail_apply(big, big, big, 0.0, big, None, big, big, 0.01, add0, None, None, per,
+                                                                     out, None, 4096, 128, None)
     assert apply(None) == -1 and apply(ctypes.c_void_p(4104)) == _hip.EUNSUPPORTED
     assert apply(big, add0=ctypes.c_void_p(4104)) == _hip.EUNSUPPORTED and b'misaligned' in L.fgnn_last_error()
-    bwd = lambda gout, ws, nbytes: L.fgnn_block_tail_backward(big, big, big, 0.0, big, None, big, big, big, big, big, 0.01, gout, big, big,
-                                                              None, None, None, 4096, 256, ws, nbytes, None)
+    assert apply(big, add0=big, per=(ctypes.c_int32 * 3)(0, 1, 1)) == -1 and b'period' in L.fgnn_last_error()
+    bwd = lambda gout, ws, nbytes, dsum=None: L.fgnn_block_tail_backward(big, big, big, 0.0, big, None, big, big, big, big, big, 0.01, gout,
+                                                                         big, big, None, None, None, None, None, None, dsum, 4096, 256,
+                                                                         ws, nbytes, big, None)
     assert bwd(None, big, 1 << 30) == -1
     assert bwd(big, big, 1024) == -1 and b'workspace too small' in L.fgnn_last_error()
-    assert L.fgnn_bn_backward_partials(big, big, big, 4096, 64, 1, big, big, big, big, 0.0, None, None, big, 0, big, None) == -1
-    assert L.fgnn_bn_finalize_shifted(big, 2000, 4096, 64, None, None, None, None, None, 0.1, 1e-5, big, big, big, big, None, None) == -1
+    assert bwd(big, big, 1 << 30, dsum=big) == -1 and b'mean2' in L.fgnn_last_error()
+    # the BatchNorm entry points take ONE description of what to finalise (fgnn_bn_final) and check it before any launch
+    assert L.fgnn_bn_finalize(big, 2000, 64, fref, None) == -1 and b'bad sizes' in L.fgnn_last_error()
+    assert L.fgnn_bn_finalize(big, 16, 64, None, None) == -1
+    fin.population = 5
+    assert L.fgnn_bn_finalize(big, 16, 64, fref, None) == -1 and b'row counts' in L.fgnn_last_error()
+    fin.population = 0
+    assert L.fgnn_bn_stats(big, 4000, 64, 1, fref, big, 1 << 30, big, None) == -1 and b'count' in L.fgnn_last_error()
+    assert L.fgnn_bn_backward_apply(big, big, big, 4096, 64, 1, big, big, big, big, 0.0, None, None) == -1
+    assert L.fgnn_linear_forward(big, big, None, big, 4096, 64, 64, None, fref, big, 0, None) == -1 and b'stats_partials' in L.fgnn_last_error()
+    assert L.fgnn_node_sum(big, big, 16, 96, 60, 1, None) == _hip.EUNSUPPORTED and L.fgnn_node_sum(None, big, 16, 96, 64, 1, None) == -1
+    assert L.fgnn_node_sum(big, big, 0, 96, 64, 1, None) == 0
+    assert L.fgnn_bn_apply(big, big, 4096, 64, 1, big, big, 0.0, big, None, None, (ctypes.c_int32 * 3)(0, 1, 1), None) == -1
 
 
 def test_flat_adam_matches_torch_adam():
@@ -186,6 +206,105 @@ def test_flat_adam_matches_torch_adam():
     assert all(p.data_ptr() >= bucket.flat_param.data_ptr() for p in b.parameters())
     b.load_state_dict(a.state_dict())
     assert torch.equal(bucket.flat_param[:35].view(7, 5), a[0].weight)
+
+
+def test_fast_adam_checkpoint_round_trip_and_stock_compatibility():
+    """fastpath.FastAdam persists its moments and step count in stock Adam's state_dict layout
+    (/root/reference/train_ldpc.py:179-181,187 saves and restores ``optimizer.state_dict()``):
+    2 steps -> save -> rebuild -> load -> 1 step  ==  3 straight steps, bit for bit; a stock torch.optim.Adam checkpoint
+    resumes in FastAdam and a FastAdam checkpoint resumes in the stock class."""
+    import copy
+    import io
+    import torch
+    from fgnn_amd.fastpath import FastAdam
+
+    def make():
+        torch.manual_seed(3)
+        return torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.Tanh(), torch.nn.Linear(7, 3))
+
+    torch.manual_seed(0)
+    x, y = torch.randn(11, 5), torch.randn(11, 3)
+
+    def steps(model, opt, n):
+        for _ in range(n):
+            opt.zero_grad()
+            torch.nn.functional.mse_loss(model(x), y).backward()
+            opt.step()
+
+    kw = dict(lr=1e-2, weight_decay=1e-3)
+    straight = make()
+    steps(straight, FastAdam(straight.parameters(), **kw), 3)
+
+    first = make()
+    opt = FastAdam(first.parameters(), **kw)
+    assert opt.state_dict()['state'] == {}                      # nothing to save before the first step (as the stock class)
+    steps(first, opt, 2)
+    buf = io.BytesIO()
+    torch.save({'model': first.state_dict(), 'opt': opt.state_dict()}, buf)
+    sd = opt.state_dict()
+    assert sorted(sd['state']) == [0, 1, 2, 3] and set(sd['state'][0]) == {'step', 'exp_avg', 'exp_avg_sq'}
+    assert float(sd['state'][0]['step']) == 2.0 and sd['state'][0]['exp_avg'].shape == first[0].weight.shape
+    buf.seek(0)
+    ck = torch.load(buf)
+    resumed = make()
+    resumed.load_state_dict(ck['model'])
+    opt2 = FastAdam(resumed.parameters(), lr=5.0)               # (the saved hyper-parameters win, as in the stock class)
+    opt2.load_state_dict(ck['opt'])
+    assert opt2.param_groups[0]['lr'] == 1e-2 and opt2.flat.t == 2
+    steps(resumed, opt2, 1)
+    for a, b in zip(straight.parameters(), resumed.parameters()):
+        assert torch.equal(a, b)
+
+    # stock -> fast and fast -> stock
+    sm = make()
+    so = torch.optim.Adam(sm.parameters(), **kw)
+    steps(sm, so, 2)
+    fm = make()
+    fm.load_state_dict(sm.state_dict())
+    fo = FastAdam(fm.parameters(), **kw)
+    fo.load_state_dict(copy.deepcopy(so.state_dict()))
+    steps(sm, so, 1)
+    steps(fm, fo, 1)
+    for a, b in zip(sm.parameters(), fm.parameters()):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-7)
+    back = make()
+    back.load_state_dict(first.state_dict())
+    bo = torch.optim.Adam(back.parameters(), **kw)
+    bo.load_state_dict(ck['opt'])
+    steps(back, bo, 1)
+    for a, b in zip(straight.parameters(), back.parameters()):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-7)
+
+
+def test_fast_path_keeps_adam_a_class_and_modules_copyable():
+    """enable_fast_path(): ``torch.optim.Adam`` stays a TYPE (subclassing and isinstance keep working), frozen parameters keep
+    the stock optimizer, and an optimised module is deepcopy-able and picklable (hooks, not a replaced ``forward``)."""
+    import copy
+    import pickle
+    import torch
+    from fgnn_amd import fastpath
+    stock = torch.optim.Adam
+    fastpath.enable_fast_path()
+    try:
+        assert isinstance(torch.optim.Adam, type) and torch.optim.Adam is not stock
+
+        class Mine(torch.optim.Adam):
+            pass
+        w = torch.nn.Parameter(torch.zeros(3))
+        assert isinstance(Mine([w]), stock)
+        cpu = torch.optim.Adam([w], lr=0.1)
+        assert type(cpu) is stock and isinstance(cpu, torch.optim.Adam)          # CPU parameters: the stock class
+        assert isinstance(fastpath.FastAdam([torch.nn.Parameter(torch.zeros(2))]), torch.optim.Adam)
+        frozen = torch.nn.Parameter(torch.zeros(3), requires_grad=False)
+        assert not fastpath._wants_fast_adam([w, frozen], False, {})
+        m = torch.nn.Sequential(torch.nn.Linear(2, 2))
+        fastpath.fast_path(m)
+        m2 = copy.deepcopy(m)
+        m3 = pickle.loads(pickle.dumps(m))
+        assert torch.equal(m2(torch.ones(1, 2)), m(torch.ones(1, 2))) and torch.equal(m3[0].weight, m[0].weight)
+    finally:
+        fastpath.disable_fast_path()
+    assert torch.optim.Adam is stock
 
 
 def test_low_precision_weight_copies_are_refreshed_in_place():

@@ -149,14 +149,29 @@ def test_ws_forward_is_bit_reproducible_run_to_run(shape, dev):
     x, idx, et, W, bias, g = _problem(shape, B, dev, seed=B)
     xd, idxd, etd = _dev_views(x, idx, et, dev)
     Wd, bd = W.to(dev), bias.to(dev)
+    from fgnn_amd.mpnn import pointwise
     for stats in (True, False):
         first = None
+        spec = H.bn_spec_for(nou, dev) if stats else None
         for r in range(60):
-            y, am = ops.mpconv_forward_raw(xd, idxd, etd, Wd, bd, nou, 4, 0, _hip.AGG_MAX, want_argmax=True, want_stats=stats)
+            y, am = ops.mpconv_forward_raw(xd, idxd, etd, Wd, bd, nou, 4, 0, _hip.AGG_MAX, want_argmax=True, bn=spec)
+            st = pointwise.take_pending_stats(y.permute(0, 2, 3, 1).reshape(B * M, nou)) if stats else None
+            assert (st is not None) == stats
             if first is None:
-                first = (y.clone(), am.clone())
+                first = (y.clone(), am.clone(), None if st is None else st.clone())
+                if stats:
+                    # the launch's LAST workgroup folded the 256 partial rows and finalised the BatchNorm (csrc/fgnn_gridfold.h):
+                    # against an f64 restatement on the stored (bf16) output
+                    rows = y.permute(0, 2, 3, 1).reshape(B * M, nou).double()
+                    mean, var = rows.mean(0), rows.var(0, unbiased=False)
+                    assert H.rel_err(st[0], mean) <= 1e-5 and H.rel_err(st[1], torch.rsqrt(var + 1e-5)) <= 1e-5
+                    assert H.rel_err(st[2], spec[0].double() * torch.rsqrt(var + 1e-5)) <= 1e-5
             else:
                 assert torch.equal(y, first[0]) and torch.equal(am, first[1]), 'launch %d differs from launch 0' % r
+                if stats:            # ... whichever workgroup arrived last: bit-identical statistics
+                    assert torch.equal(st, first[2]), 'statistics of launch %d differ from launch 0' % r
+        if stats:
+            assert int(spec[4]) == 60 and int(ops._fold_scratch(dev)[:65].abs().sum()) == 0
 
 
 def _regular_table(N, M, k, g):
@@ -217,9 +232,21 @@ ORACLE_BWD_SHAPES = [(64, 64, 96, 48, 6), (64, 64, 48, 96, 3), (64, 128, 96, 48,
                      (128, 64, 48, 96, 3)]
 
 
+@pytest.mark.parametrize('shape', ORACLE_BWD_SHAPES[:2], ids=lambda s: 'x'.join(map(str, s)))
+def test_bf16_backward_vs_oracle_autograd_at_the_benched_batch(shape, dev):
+    """The same check at BASELINE config 3's batch, 4096 codewords, for the two 64 -> 64 parity shapes: there a workgroup of the
+    third-generation kernels walks 16 samples (LDS-DMA two ahead, images handed between phases), which the small batches above
+    never exercise against VALUES — only the bit-reproducibility tests ran that regime."""
+    _backward_vs_oracle_autograd(shape, 4096, dev)
+
+
 @pytest.mark.parametrize('shape', ORACLE_BWD_SHAPES, ids=lambda s: 'x'.join(map(str, s)))
 @pytest.mark.parametrize('B', [37, 600])
 def test_bf16_backward_vs_oracle_autograd(shape, B, dev):
+    _backward_vs_oracle_autograd(shape, B, dev)
+
+
+def _backward_vs_oracle_autograd(shape, B, dev):
     """The bf16 backward kernels of the parity calls against the ORACLE's autograd directly — `O.mp_conv` in f32 on the same
     bf16-rounded inputs, routing by the oracle's OWN maxima (not by the kernel's argmax).  The upstream gradient is zero on
     the outputs whose best two messages lie closer than the bf16 rounding of P can resolve (a coin flip for any finite

@@ -23,7 +23,7 @@ for shape in shapes:
     for stats in (True, False):
         first, nbad = None, 0
         for r in range(reps):
-            y, am = ops.mpconv_forward_raw(xd, idxd, etd, Wd, bd, nou, 4, 0, _hip.AGG_MAX, want_argmax=True, want_stats=stats)
+            y, am = ops.mpconv_forward_raw(xd, idxd, etd, Wd, bd, nou, 4, 0, _hip.AGG_MAX, want_argmax=True, bn=T.H.bn_spec_for(nou, dev) if stats else None)
             torch.cuda.synchronize()
             cur = (y.clone(), am.clone())
             if first is None:

@@ -87,10 +87,15 @@ def main():
         ets = [et] + [(et.clone(memory_format=torch.preserve_format) if et.stride(0) != 0 else et) for _ in range(K - 1)]
         turn = [0]
 
+        spec = None
+        if a.stats:     # the BatchNorm behind the operator, finalised by the operator's own launch
+            spec = (torch.ones(nou, device=dev), torch.zeros(nou, device=dev), torch.zeros(nou, device=dev), torch.ones(nou, device=dev),
+                    torch.zeros((), device=dev, dtype=torch.int64), 0.1, 1e-5)
+
         def fwd():
             turn[0] = (turn[0] + 1) % K
             return ops.mpconv_forward_raw(xs[turn[0]], idx, ets[turn[0]], W, bias, nou, net, ext, agg,
-                                          want_argmax=a.bwd or a.stats or a.argmax, want_stats=a.stats)
+                                          want_argmax=a.bwd or a.stats or a.argmax, bn=spec)
 
         if not a.bwd:
             run = fwd

@@ -41,7 +41,7 @@ for N in (96, 48):
             return st['i']
         def f_hip():
             i = nxt()
-            _hip.check(L.fgnn_linear_forward(_hip._ptr(xs[i]), _hip._ptr(W), _hip._ptr(bias), _hip._ptr(ys[i]), R, cin, cout, None, 0, _hip.stream_ptr()))
+            _hip.check(L.fgnn_linear_forward(_hip._ptr(xs[i]), _hip._ptr(W), _hip._ptr(bias), _hip._ptr(ys[i]), R, cin, cout, None, None, None, 0, _hip.stream_ptr()))
         def f_t():
             i = nxt()
             torch.addmm(bb, xs[i], Wb.t(), out=ys[i])

@@ -50,12 +50,13 @@ for dt in (torch.bfloat16,):
         code = _hip.dtype_code(x)
         t_copy = graph_time(lambda: y.copy_(x))
         t_app = graph_time(lambda: _hip.check(L.fgnn_bn_apply(_hip._ptr(x), _hip._ptr(y), R, C, code, _hip._ptr(scale), _hip._ptr(shift),
-                                                              0.01, None, None, None, _hip.stream_ptr())))
+                                                              0.01, None, None, None, None, _hip.stream_ptr())))
         t_app1 = graph_time(lambda: _hip.check(L.fgnn_bn_apply(_hip._ptr(x), _hip._ptr(y), R, C, code, _hip._ptr(scale), _hip._ptr(shift),
-                                                               0.01, _hip._ptr(gy), None, None, _hip.stream_ptr())))
+                                                               0.01, _hip._ptr(gy), None, None, None, _hip.stream_ptr())))
         t_bwd = graph_time(lambda: _hip.check(L.fgnn_bn_backward(_hip._ptr(x), _hip._ptr(gy), _hip._ptr(y), R, C, code, _hip._ptr(mean),
                                                                  _hip._ptr(invstd), _hip._ptr(gamma), _hip._ptr(beta), 0.01,
-                                                                 _hip._ptr(gw), _hip._ptr(gb), _hip._ptr(ws), ws.numel() * 4, _hip.stream_ptr())))
+                                                                 _hip._ptr(gw), _hip._ptr(gb), _hip._ptr(ws), ws.numel() * 4,
+                                                                 _hip._ptr(ops._fold_scratch(dev)), _hip.stream_ptr())))
         print('bf16 R=%d C=%3d (%.0f MB): copy %5.1f us (%.2f TB/s) | bn_apply %5.1f us (%.2f TB/s) | +1 addend %5.1f us (%.2f TB/s) | '
               'bn_backward (reduce+final+apply) %5.1f us (%.2f TB/s of 5T)'
               % (R, C, mb, t_copy, 2 * mb / t_copy, t_app, 2 * mb / t_app, t_app1, 3 * mb / t_app1, t_bwd, 5 * mb / t_bwd))
@@ -87,13 +88,13 @@ for C, N in [(64, 96), (128, 96)]:
     def f_app():
         i = nxt()
         _hip.check(L.fgnn_bn_apply(_hip._ptr(xs[i]), _hip._ptr(ys[i]), R, C, code, _hip._ptr(scale), _hip._ptr(shift), 0.01, None, None,
-                                   None, _hip.stream_ptr()))
+                                   None, None, _hip.stream_ptr()))
 
     def f_bwd():
         i = nxt()
         _hip.check(L.fgnn_bn_backward(_hip._ptr(xs[i]), _hip._ptr(xs[(i + 7) % K]), _hip._ptr(ys[i]), R, C, code, _hip._ptr(mean), _hip._ptr(invstd),
                                       _hip._ptr(gamma), _hip._ptr(beta), 0.01, _hip._ptr(gw), _hip._ptr(gb), _hip._ptr(ws), ws.numel() * 4,
-                                      _hip.stream_ptr()))
+                                      _hip._ptr(ops._fold_scratch(dev)), _hip.stream_ptr()))
 
     t_copy, t_app, t_bwd = graph_time(f_copy, 48), graph_time(f_app, 48), graph_time(f_bwd, 48)
     print('bf16 R=%d C=%3d (%.0f MB): copy %5.1f us (%.2f TB/s) | bn_apply %5.1f us (%.2f TB/s) | bn_backward %5.1f us (%.2f TB/s of 5T)'
@@ -110,6 +111,9 @@ for Cin, Cout, N in [(64, 64, 96), (64, 64, 48), (128, 64, 96), (64, 128, 96)]:
     bias = torch.randn(Cout, device=dev)
     npart = int(L.fgnn_linear_forward_partials(R, Cin, Cout))
     parts = torch.empty(max(npart, 1) * 2 * Cout, device=dev)
+    stats4 = torch.empty(4, Cout, device=dev)         # the BatchNorm behind the map, finalised by the map's last workgroup
+    fin = _hip.bn_final(stats4, torch.ones(Cout, device=dev), torch.zeros(Cout, device=dev), torch.zeros(Cout, device=dev),
+                        torch.ones(Cout, device=dev), torch.zeros((), device=dev, dtype=torch.int64), 0.1, 1e-5, R)
     gW, gb = torch.zeros(Cout, Cin, device=dev), torch.zeros(Cout, device=dev)
     wsb = int(L.fgnn_linear_wgrad_workspace_bytes(R, Cin, Cout))
     ws = torch.empty(max(wsb, 4) // 4, device=dev)
@@ -122,7 +126,8 @@ for Cin, Cout, N in [(64, 64, 96), (64, 64, 48), (128, 64, 96), (64, 128, 96)]:
     def f_fwd(stats):
         i = nxt()
         _hip.check(L.fgnn_linear_forward(_hip._ptr(xs[i]), _hip._ptr(W), _hip._ptr(bias), _hip._ptr(ys[i]), R, Cin, Cout,
-                                         _hip._ptr(parts) if stats else None, 0, _hip.stream_ptr()))
+                                         _hip._ptr(parts) if stats else None, fin if stats else None,
+                                         _hip._ptr(ops._fold_scratch(dev)) if stats else None, 0, _hip.stream_ptr()))
 
     def f_wg():
         i = nxt()

@@ -44,18 +44,23 @@ for R, Cout in SHAPES:
     gam = torch.rand(Cout, device=dev) + 0.5
     ws = torch.zeros(int(L.fgnn_bn_workspace_bytes(R, Cout)) // 4, device=dev)
     np2 = int(L.fgnn_block_tail_backward_partials(R, Cout))
-    part2 = torch.zeros(np2 * 128, device=dev)
+    part2 = torch.zeros(128, device=dev)              # BatchNorm2's backward sums [2][64], finalised by the grad kernel
+    wsb = torch.zeros(2048 * Cout + 2 * Cout + 1024 * 128, device=dev)
     gw, gb = torch.zeros(Cout, device=dev), torch.zeros(Cout, device=dev)
     st = _hip.stream_ptr()
-    t_stats = 0.0 if 'stats' not in MODES else timeit(lambda i: _hip.check(L.fgnn_block_tail_stats(P(e[i]), P(s2), P(t2), 0.0, P(W2), P(b2), R, Cout, P(ws), st)))
+    from fgnn_amd import ops
+    fold = ops._fold_scratch(dev)
+    stf = torch.empty(4, Cout, device=dev)
+    fin = _hip.bn_final(stf, gam, gb, torch.zeros(Cout, device=dev), torch.ones(Cout, device=dev), None, 0.1, 1e-5, R)
+    t_stats = 0.0 if 'stats' not in MODES else timeit(lambda i: _hip.check(L.fgnn_block_tail_stats(P(e[i]), P(s2), P(t2), 0.0, P(W2), P(b2), R, Cout, P(ws), fin, P(fold), st)))
     res = ['stats %6.1f us (%4.2f TB/s)' % (t_stats, 2 * R * 64 / max(t_stats, 1e-9) / 1e6)]
     for nadd in ((0, 3) if 'apply' in MODES else ()):
         ap = [P(a) for a in adds[0][:nadd]] + [None] * (3 - nadd)
         t = timeit(lambda i: _hip.check(L.fgnn_block_tail_apply(P(e[i]), P(s2), P(t2), 0.0, P(W2), P(b2), P(st3[2]), P(st3[3]), 0.01,
-                                                                *([P(a) for a in adds[i][:nadd]] + [None] * (3 - nadd)), P(out[i]), P(a2[i]), R, Cout, st)))
+                                                                *([P(a) for a in adds[i][:nadd]] + [None] * (3 - nadd)), None, P(out[i]), P(a2[i]), R, Cout, st)))
         res.append('apply+%d %6.1f us (%4.2f TB/s)' % (nadd, t, 2 * R * (64 + (1 + nadd) * Cout) / t / 1e6))
     t = 1e-9 if 'backward' not in MODES else timeit(lambda i: _hip.check(L.fgnn_block_tail_backward(P(e[i]), P(s2), P(t2), 0.0, P(W2), P(b2), P(st3[0]), P(st3[1]), P(gam), P(st3[2]),
-                                                               P(st3[3]), 0.01, P(gout[i]), P(out[i]), P(a2[i]), P(gw), P(gb), P(part2), R,
-                                                               Cout, P(ws), ws.numel() * 4, st)))
+                                                               P(st3[3]), 0.01, P(gout[i]), P(out[i]), P(a2[i]), P(gw), P(gb), P(s2), P(t2), None, None, P(part2), R,
+                                                               Cout, P(wsb), wsb.numel() * 4, P(fold), st)))
     res.append('backward %6.1f us (%4.2f TB/s)' % (t, 2 * R * (3 * 64 + 3 * Cout) / t / 1e6))
     print('R %6d Cout %3d: ' % (R, Cout) + ' | '.join(res), flush=True)
