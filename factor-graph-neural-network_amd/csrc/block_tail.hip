@@ -424,7 +424,7 @@ __global__ __launch_bounds__(BT_THREADS, MODE == 1 ? 3 : 2) void block_tail_kern
             float s = 0.f;
 #pragma unroll
             for (int w = 0; w < NRG; ++w) s += redf[w * 2 * CF + f];
-            dst[(int64_t)blockIdx.x * 2 * CF + f] = s;
+            fgnn_fold_store(dst + (int64_t)blockIdx.x * 2 * CF + f, s);
         }
         if (p.fold.tickets) {            // no finaliser launch: the last workgroup folds every workgroup's row and finalises
             double* sums = reinterpret_cast<double*>(bt_lds);      // (the fragments are dead; the fold starts with a barrier)

@@ -142,7 +142,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_reduce_kernel(const BnParams p)
         }
         float* w = p.ws + (int64_t)blockIdx.x * 2 * p.C;
 #pragma unroll
-        for (int e = 0; e < EPC; ++e) { w[c0 + e] = s0[e]; w[p.C + c0 + e] = s1[e]; }
+        for (int e = 0; e < EPC; ++e) { fgnn_fold_store(w + c0 + e, s0[e]); fgnn_fold_store(w + p.C + c0 + e, s1[e]); }
     }
     if (p.fold.tickets) {                                 // no finaliser launch: the last workgroup folds all rows and finalises
         double* sums = reinterpret_cast<double*>(red);    // (red is free: the fold starts with a barrier)
@@ -185,7 +185,7 @@ __device__ __forceinline__ void bn_fold(const float* ws, int nwg, int C, int c, 
         for (int q = 0; q < 8; ++q) { s0 += red0[q * BN_FC + cc]; s1 += red1[q * BN_FC + cc]; }
 }
 
-// forward finaliser (FGNN_SEPARATE_FINALISERS=1, and partials produced outside this library): mean / invstd / scale / shift and
+// forward finaliser (the default; also serves partials produced outside this library): mean / invstd / scale / shift and
 // the running statistics — the arithmetic of fgnn_bn_final_apply (fgnn_gridfold.h), 4 channels per workgroup
 __global__ __launch_bounds__(256) void bn_stats_final_kernel(const float* ws, int nwg, int C, const fgnn_bn_final fin) {
     if (fin.num_batches_tracked && blockIdx.x == 0 && threadIdx.x == 0) *fin.num_batches_tracked += 1;      // BatchNorm2d.num_batches_tracked
@@ -323,9 +323,20 @@ extern "C" int fgnn_bn_supported(int64_t R, int C, int dtype) {
 
 extern "C" int64_t fgnn_bn_workspace_bytes(int64_t R, int C) { return (int64_t)BN_MAXPART * 2 * C * 4 + 2 * C * 4; }
 
+// Who finalises a reduction: the producing launch's last workgroup (csrc/fgnn_gridfold.h) or a small launch of its own.  Measured on
+// MI355X (gpurun_out/r05b, LDPC step, 4096 codewords): the in-kernel fold is six serialised memory-side round trips (store
+// acknowledgement, ticket, loads — twice) = 8-10 us at the tail of EVERY producer (block_tail_stats 35.6 vs 27.9 us with its finaliser
+// launch included, mpconv_fwd_ws 54 vs 47 us, the step 15.66 vs 15.50 ms) against ~7 us for a finaliser kernel inside the replayed
+// graph: the separate launch is the default, FGNN_INKERNEL_FINALISERS=1 / fgnn_set_inkernel_finalisers(1) selects the fold.
+static int g_inkernel_finalisers = -1;
 int fgnn_separate_finalisers(void) {
-    static const int v = getenv("FGNN_SEPARATE_FINALISERS") ? atoi(getenv("FGNN_SEPARATE_FINALISERS")) : 0;
-    return v;
+    if (g_inkernel_finalisers < 0) g_inkernel_finalisers = getenv("FGNN_INKERNEL_FINALISERS") ? atoi(getenv("FGNN_INKERNEL_FINALISERS")) : 0;
+    return !g_inkernel_finalisers;
+}
+extern "C" int fgnn_set_inkernel_finalisers(int on) {
+    const int was = !fgnn_separate_finalisers();
+    g_inkernel_finalisers = on ? 1 : 0;
+    return was;
 }
 
 static int bn_check_final(const char* who, const fgnn_bn_final* fin) {
@@ -335,7 +346,7 @@ static int bn_check_final(const char* who, const fgnn_bn_final* fin) {
     return FGNN_OK;
 }
 
-// Host-side helper of the other translation units (FGNN_SEPARATE_FINALISERS=1): the stand-alone forward finaliser.
+// Host-side helper of the other translation units: the stand-alone forward finaliser.
 int fgnn_bn_finalize_launch(const float* partials, int npartials, int C, const fgnn_bn_final* fin, hipStream_t st) {
     hipLaunchKernelGGL(bn_stats_final_kernel, dim3((C + BN_FC - 1) / BN_FC), dim3(256), 0, st, partials, npartials, C, *fin);
     return hipGetLastError() == hipSuccess ? 0 : -1;
@@ -467,7 +478,7 @@ extern "C" int fgnn_bn_backward(const void* x, const void* gy, void* gx, int64_t
 }
 
 // backward finaliser for partials of (sum g, sum g * x) with the RAW x: dbeta = S0, dgamma = invstd (S1 - mean S0)
-// (FGNN_SEPARATE_FINALISERS=1 only: csrc/block_tail.hip's grad kernel finalises its own)
+// (the default; with the in-kernel fold csrc/block_tail.hip's grad kernel finalises its own)
 __global__ __launch_bounds__(256) void bn_bwd_final_raw_kernel(const float* ws, int nwg, int C, const float* mean,
                                                                const float* invstd, float* dsum, float* gweight, float* gbias) {
     const int c = blockIdx.x * BN_FC + (threadIdx.x & (BN_FC - 1)), pg = threadIdx.x / BN_FC;

@@ -4,20 +4,26 @@
 // /root/reference/lib/model/mpnn/mp_nn_residual.py:25-35, and mp_conv_v2.bn, mp_nn.py:57-58,170-173) needs per-channel sums over ALL
 // rows between the kernel that produces a tensor and the kernel that normalises it.  Rounds 1-4 wrote one partial row per
 // workgroup and folded them in a separate 4-10 us kernel: 160 such launches per LDPC step, each a node of the replayed hipGraph
-// (profiles/r04/train_step_timeline.txt).  Here the PRODUCING kernel folds its own partials: the workgroup that finishes last does
-// it ("last block done", two levels so that no workgroup ever reads more than FGNN_FOLD_GROUP + FGNN_FOLD_MAXGROUPS rows):
+// (profiles/r04/train_step_timeline.txt).  This file is the alternative round 5 built and measured (OFF by default: it lost, see
+// bnact.hip): the PRODUCING kernel folds its own partials, the workgroup that finishes last does it ("last block done", two levels
+// so that no workgroup ever reads more than FGNN_FOLD_GROUP + FGNN_FOLD_MAXGROUPS rows):
 //
 //   level 1: workgroups are grouped by row index, FGNN_FOLD_GROUP consecutive rows per group; the last workgroup of a group to
 //            arrive (a ticket counter per group) sums the group's rows in row order into one f64 row of `part2`;
 //   level 2: the last GROUP to finish (one more ticket) sums the part2 rows in group order -> `sums` in LDS, and the caller's
 //            finaliser (BatchNorm statistics, backward sums, ...) runs in that one workgroup.
 //
-// Fixed grouping + fixed summation order = bit-reproducible whatever the arrival order.  Visibility: each thread fences
-// (agent scope: L2 write-back on the producing XCD) before its workgroup takes a ticket with an acq_rel atomic, and the reading
-// workgroup fences again before it loads (agent-scope acquire: invalidates this CU's L1 and non-local L2 lines) — the memory
-// model's release/acquire chain across the 8 XCDs' L2s.  The ticket counters are zero between launches (the last arrival resets
-// them); they live in a small zero-initialised buffer per (device, stream) owned by the host side (ops._fold_scratch), so kernels of
-// one stream — which never overlap — share it.
+// Fixed grouping + fixed summation order = bit-reproducible whatever the arrival order.
+//
+// Visibility across the 8 XCDs' L2s WITHOUT cache maintenance: the partial rows, the second-level rows and the tickets are only ever
+// touched with AGENT-SCOPE relaxed atomics (gfx950: the sc1 bit on the store / load / RMW: written through to, and read from, the
+// memory side of the non-coherent L2s); a workgroup waits for its stores to be acknowledged (s_waitcnt vmcnt(0)) and meets at a
+// barrier before ONE thread takes the ticket, and the reading workgroup issues its loads only after it has seen the last ticket.
+// The first form of this file used __threadfence() (agent-scope release / acquire fences: buffer_wbl2 + buffer_inv by every wave
+// of every workgroup): each one writes back the XCD's whole L2 under the kernel's own output stream — the LDPC step went from
+// 15.3 to 29.7 ms (gpurun_out/r05a).  The ticket counters are zero between launches (the last arrival resets them); they live
+// in a small zero-initialised buffer per (device, stream) owned by the host side (ops._fold_scratch), so kernels of one stream —
+// which never overlap — share it.
 #pragma once
 #include "fgnn_common.h"
 
@@ -46,8 +52,9 @@ static inline FgnnFold fgnn_fold_make(float* part, void* scratch, int rows, int 
     return f;
 }
 
-// FGNN_SEPARATE_FINALISERS=1: A/B switch (and fallback) — producers only write their partial rows and the host launches the
-// finaliser kernels as rounds 1-4 did.
+// Default: producers only write their partial rows and the host launches the small finaliser kernels (bnact.hip) behind them.
+// FGNN_INKERNEL_FINALISERS=1 / fgnn_set_inkernel_finalisers(1): the fold below runs in the producer instead (fewer graph nodes, but
+// measured SLOWER on MI355X: see bnact.hip).
 int fgnn_separate_finalisers(void);
 
 // host-side plumbing shared by the translation units (not C ABI)
@@ -58,10 +65,16 @@ int fgnn_bn_bwd_final_raw_launch(const float* partials, int npartials, int C, co
                                  float* gweight, float* gbias, hipStream_t st);
 
 #ifdef __HIPCC__
-// Called by ALL threads of EVERY workgroup of the launch, after the workgroup's partial row `row` has been written (by any of its
-// threads; no barrier needed in between — this function fences and synchronises).  Returns true in exactly ONE workgroup, the
-// last to arrive, with sums[0 .. 2 ch) (LDS, >= 2 * ch doubles, provided by the caller) = the fold of all rows.  All threads of a
-// workgroup get the same answer.  The workgroup's own LDS may be reused for `sums` as long as nothing else reads it afterwards.
+// A partial-row element: written through to the memory side (agent scope), whichever XCD the writer runs on.
+__device__ __forceinline__ void fgnn_fold_store(float* p, float v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Called by ALL threads of EVERY workgroup of the launch, after the workgroup's partial row `row` has been written WITH
+// fgnn_fold_store (by any of its threads; no barrier needed in between — this function waits for the stores and synchronises).
+// Returns true in exactly ONE workgroup, the last to arrive, with sums[0 .. 2 ch) (LDS, >= 2 * ch doubles, provided by the
+// caller) = the fold of all rows.  All threads of a workgroup get the same answer.  The workgroup's own LDS may be reused for
+// `sums` as long as nothing else reads it afterwards.
 __device__ __forceinline__ bool fgnn_grid_fold(const FgnnFold& f, double* sums, int row) {
     __shared__ unsigned fgnn_fold_flag;
     const int tid = threadIdx.x, T = blockDim.x;
@@ -70,39 +83,41 @@ __device__ __forceinline__ bool fgnn_grid_fold(const FgnnFold& f, double* sums, 
     const int ng = (f.rows + FGNN_FOLD_GROUP - 1) / FGNN_FOLD_GROUP;
     const int gfirst = g * FGNN_FOLD_GROUP;
     const int gsize = f.rows - gfirst < FGNN_FOLD_GROUP ? f.rows - gfirst : FGNN_FOLD_GROUP;
-    __threadfence();                                  // this thread's partial-row stores: visible device-wide before the ticket
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this thread's partial-row stores have been acknowledged by the memory side
     __syncthreads();
     if (tid == 0) {
-        const unsigned old = __hip_atomic_fetch_add(f.tickets + 1 + g, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned old = __hip_atomic_fetch_add(f.tickets + 1 + g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         fgnn_fold_flag = old == (unsigned)(gsize - 1) ? 1u : 0u;
     }
     __syncthreads();
     if (!fgnn_fold_flag) return false;
-    __threadfence();                                  // acquire: the other workgroups' rows, not stale cache lines
-    for (int j = tid; j < J; j += T) {
+    for (int j = tid; j < J; j += T) {                 // level 1: this group's rows, in row order
         const int off = (j / f.ch) * f.half_stride + (j % f.ch);
+        float v[FGNN_FOLD_GROUP];
+#pragma unroll
+        for (int w = 0; w < FGNN_FOLD_GROUP; ++w)
+            v[w] = w < gsize ? __hip_atomic_load(f.part + (int64_t)(gfirst + w) * f.row_stride + off, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
         double a = 0.0;
-#pragma unroll 4
-        for (int w = 0; w < gsize; ++w) a += (double)f.part[(int64_t)(gfirst + w) * f.row_stride + off];
-        f.part2[(int64_t)g * J + j] = a;
+#pragma unroll
+        for (int w = 0; w < FGNN_FOLD_GROUP; ++w) a += (double)v[w];
+        __hip_atomic_store(f.part2 + (int64_t)g * J + j, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    __threadfence();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) {
-        f.tickets[1 + g] = 0u;                        // (nobody else touches this counter any more in this launch)
-        const unsigned old = __hip_atomic_fetch_add(f.tickets, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(f.tickets + 1 + g, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // (nobody else touches this counter any more in this launch)
+        const unsigned old = __hip_atomic_fetch_add(f.tickets, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         fgnn_fold_flag = old == (unsigned)(ng - 1) ? 1u : 0u;
     }
     __syncthreads();
     if (!fgnn_fold_flag) return false;
-    __threadfence();
-    for (int j = tid; j < J; j += T) {
+    for (int j = tid; j < J; j += T) {                 // level 2: the groups' rows, in group order
         double a = 0.0;
-#pragma unroll 4
-        for (int q = 0; q < ng; ++q) a += f.part2[(int64_t)q * J + j];
+#pragma unroll 8
+        for (int q = 0; q < ng; ++q) a += __hip_atomic_load(f.part2 + (int64_t)q * J + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         sums[j] = a;
     }
-    if (tid == 0) f.tickets[0] = 0u;
+    if (tid == 0) __hip_atomic_store(f.tickets, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     return true;
 }

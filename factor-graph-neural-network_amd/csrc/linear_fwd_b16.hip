@@ -157,7 +157,7 @@ __global__ __launch_bounds__(LF_THREADS) void linear_fwd_b16_kernel(const LfPara
         for (int f = tid; f < 2 * Cout; f += LF_THREADS) {
             float s = 0.f;
             for (int g = 0; g < nrg; ++g) s += red[g * 2 * Cout + f];
-            p.part[(int64_t)blockIdx.x * 2 * Cout + f] = s;
+            fgnn_fold_store(p.part + (int64_t)blockIdx.x * 2 * Cout + f, s);
         }
         if (p.fold.tickets) {
             double* sums = reinterpret_cast<double*>(lf_lds);     // (W's image is dead; the fold starts with a barrier)

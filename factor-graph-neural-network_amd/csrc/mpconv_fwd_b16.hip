@@ -453,7 +453,7 @@ __global__ __launch_bounds__(B16_THREADS) void mpconv_fwd_b16_kernel(const B16Pa
             float sum = 0.f;
 #pragma unroll
             for (int w = 0; w < B16_WAVES; ++w) sum += red[(w * 2 + which) * 64 + c];
-            if (c < nou) p.stats[((int64_t)blockIdx.x * 2 + which) * nou + c] = sum;
+            if (c < nou) fgnn_fold_store(p.stats + ((int64_t)blockIdx.x * 2 + which) * nou + c, sum);
         }
         if (p.fold.tickets) {
             double* sums = reinterpret_cast<double*>(reinterpret_cast<unsigned char*>(ps) + B16_WAVES * 2 * 64 * 4);   // (past the fold's own floats)

@@ -379,7 +379,7 @@ __global__ __launch_bounds__(SG_THREADS, 4) void mpconv_fwd_sg_kernel(const SgPa
             float sum = 0.f;
 #pragma unroll
             for (int w = 0; w < SG_WAVES; ++w) sum += red[((w * 2 + which) * NPASS + (c >> 6)) * 64 + (c & 63)];
-            p.stats[((int64_t)blockIdx.x * 2 + which) * p.st_ld + c] = sum;
+            fgnn_fold_store(p.stats + ((int64_t)blockIdx.x * 2 + which) * p.st_ld + c, sum);
         }
         if (p.fold.tickets) {
             double* sums = reinterpret_cast<double*>(sg_lds + SG_WAVES * 2 * NPASS * 64 * 4);     // (past the fold's own floats)

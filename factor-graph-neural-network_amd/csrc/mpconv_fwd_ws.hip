@@ -507,7 +507,7 @@ __global__ __launch_bounds__(WS_THREADS) void mpconv_fwd_ws_kernel(const WsParam
             for (int w = 0; w < WS_NCONS; ++w)
 #pragma unroll
                 for (int s = 0; s < 4; ++s) sum += red[(w * 64 + ws_lane_of(s, q)) * 8 + which * 4 + i];
-            p.stats[((int64_t)blockIdx.x * 2 + which) * p.st_ld + c] = sum;
+            fgnn_fold_store(p.stats + ((int64_t)blockIdx.x * 2 + which) * p.st_ld + c, sum);
         }
         if (p.fold.tickets) {
             double* sums = reinterpret_cast<double*>(ws_lds + 32768);     // (past the fold's own [12][64][8] floats; the images are dead)

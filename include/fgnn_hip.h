@@ -56,9 +56,10 @@ typedef struct fgnn_mpconv_desc {
 /*
  * Batch-statistics BatchNorm, forward finalisation (torch.nn.BatchNorm2d semantics: the reference's conv1 / conv2 BatchNorms,
  * mp_nn_residual.py:25-35, mp_conv_v2.bn, mp_nn.py:57-58,170-173, iid_mapping_bn, base_model.py:62-79): what to compute from the
- * per-channel sums a kernel has formed over `count` rows.  All vectors float32 [C].  Kernels that take a `fgnn_bn_final` together
- * with a `fold_scratch` finalise the statistics THEMSELVES — their last workgroup folds the per-workgroup partial rows in a fixed
- * order (csrc/fgnn_gridfold.h) — so no finaliser launch follows them.
+ * per-channel sums a kernel has formed over `count` rows.  All vectors float32 [C].  Entry points that take a `fgnn_bn_final` leave
+ * the BatchNorm FINALISED: by a small launch of their own behind the producing kernel (default), or — fgnn_set_inkernel_finalisers(1),
+ * with a `fold_scratch` — by the producer's last workgroup, which folds the per-workgroup partial rows in a fixed order
+ * (csrc/fgnn_gridfold.h).  Either way the caller launches nothing else.
  *   fold_scratch: FGNN_FOLD_SCRATCH_BYTES of device memory, ZERO when first handed over and only ever passed to kernels of one
  *   stream at a time (ticket counters, reset by their last user, and second-level rows).
  */
@@ -76,6 +77,10 @@ typedef struct fgnn_bn_final {
     float momentum, eps;
 } fgnn_bn_final;
 #define FGNN_FOLD_SCRATCH_BYTES (512 + 64 * 512 * 8)
+/* Who finalises: 0 (default) = a small finaliser launch behind the producer (rounds 1-4; measured faster on MI355X: the in-kernel
+ * fold is six serialised memory-side round trips at the producer's tail), 1 = the producer's last workgroup.  Returns the previous
+ * setting.  Also FGNN_INKERNEL_FINALISERS=1 in the environment. */
+int fgnn_set_inkernel_finalisers(int32_t on);
 
 /*
  * Forward: y = act( post_scale * (agg_j sum_e etype[e,m,j] * msg[m,j,:,e] + bias) + post_shift )

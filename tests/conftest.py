@@ -20,3 +20,14 @@ def dev():
     if not torch.cuda.is_available():
         pytest.skip('no ROCm device')
     return torch.device('cuda:0')
+
+
+@pytest.fixture(params=['finaliser_launch', 'in_kernel_fold'])
+def finaliser_mode(request, dev):
+    """Both ways a statistics-producing launch can be finalised (include/fgnn_hip.h: fgnn_set_inkernel_finalisers): the small
+    finaliser launch behind it (the default) and the producer's last workgroup (csrc/fgnn_gridfold.h)."""
+    from fgnn_amd import _hip
+    L = _hip.lib()
+    was = L.fgnn_set_inkernel_finalisers(1 if request.param == 'in_kernel_fold' else 0)
+    yield request.param
+    L.fgnn_set_inkernel_finalisers(was)

@@ -137,7 +137,7 @@ def test_sg_statistics_epilogue(shape, B, dev):
 
 
 @pytest.mark.parametrize('shape', SHAPES[:2], ids=IDS[:2])
-def test_ws_forward_is_bit_reproducible_run_to_run(shape, dev):
+def test_ws_forward_is_bit_reproducible_run_to_run(shape, dev, finaliser_mode):
     """The wave-specialised forward synchronises its producer and consumer waves with LDS counters, not barriers: a protocol error
     shows as rare run-to-run differences, not as a parity failure (round 4: a single cumulative "image consumed" counter let fast
     consumer waves' signals for the next sample stand in for a slow wave's, the image was overwritten under it: ~1 launch in 3 at
@@ -160,8 +160,8 @@ def test_ws_forward_is_bit_reproducible_run_to_run(shape, dev):
             if first is None:
                 first = (y.clone(), am.clone(), None if st is None else st.clone())
                 if stats:
-                    # the launch's LAST workgroup folded the 256 partial rows and finalised the BatchNorm (csrc/fgnn_gridfold.h):
-                    # against an f64 restatement on the stored (bf16) output
+                    # the 256 partial rows folded and the BatchNorm finalised by the same call (a finaliser launch, or the launch's
+                    # LAST workgroup: csrc/fgnn_gridfold.h): against an f64 restatement on the stored (bf16) output
                     rows = y.permute(0, 2, 3, 1).reshape(B * M, nou).double()
                     mean, var = rows.mean(0), rows.var(0, unbiased=False)
                     assert H.rel_err(st[0], mean) <= 1e-5 and H.rel_err(st[1], torch.rsqrt(var + 1e-5)) <= 1e-5
