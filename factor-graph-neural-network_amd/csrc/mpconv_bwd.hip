@@ -513,6 +513,27 @@ extern "C" int fgnn_mpconv_backward_reduces_getype(const fgnn_mpconv_desc* d) {
     return fgnn_mpconv_backward_ext_accepts(d);
 }
 
+void fgnn_bw_set_pending_tables(const void* t);
+
+// fgnn_mpconv_backward with the per-graph tables of fgnn_mpconv_backward_tables (NULL = none): the table-driven kernel then
+// copies them instead of rebuilding the transposed incidence in every workgroup of every launch.
+extern "C" int fgnn_mpconv_backward(const fgnn_mpconv_desc* d, const void* x, const int64_t* nn_idx,
+                                    const void* etype, const float* filters, const void* gz,
+                                    const void* z, const uint8_t* argmax, void* gx, void* getype,
+                                    float* gfilters, float* gbias, void* workspace,
+                                    int64_t workspace_bytes, fgnn_stream_t stream);
+extern "C" int fgnn_mpconv_backward_with_tables(const fgnn_mpconv_desc* d, const void* x, const int64_t* nn_idx,
+                                                const void* etype, const float* filters, const void* gz,
+                                                const void* z, const uint8_t* argmax, void* gx, void* getype,
+                                                float* gfilters, float* gbias, void* workspace,
+                                                int64_t workspace_bytes, const void* tables, fgnn_stream_t stream) {
+    fgnn_bw_set_pending_tables(tables);
+    const int rc = fgnn_mpconv_backward(d, x, nn_idx, etype, filters, gz, z, argmax, gx, getype, gfilters, gbias, workspace,
+                                        workspace_bytes, stream);
+    fgnn_bw_set_pending_tables(nullptr);
+    return rc;
+}
+
 extern "C" int fgnn_mpconv_backward(const fgnn_mpconv_desc* d, const void* x, const int64_t* nn_idx,
                                     const void* etype, const float* filters, const void* gz,
                                     const void* z, const uint8_t* argmax, void* gx, void* getype,

@@ -59,6 +59,8 @@ struct BwParams {
     int B, N, M;
     int y_ld, w_ld, accum;       // accum: gx and getype are ADDED to (second launch of a 64 -> 128 call, over the upper output channels)
     long long x_sb, et_sb, y_sb;     // elements
+    const int* tables;       // the transposed incidence, built ONCE per graph by mpconv_bwd_ws_tables_kernel (or NULL: every workgroup
+                             // of every launch rebuilds it — 17 400 of a launch's ~23 000 set-up cycles, profiles/r04/README.md)
     long long* prof;         // FGNN_PROF (builds with -DFGNN_ENABLE_PROF only): phase timeline
 };
 
@@ -145,6 +147,67 @@ template <int KC> struct BwLayout {
     static constexpr int OFF_DUMP = OFF_GT + 8 * MMAX * KC * 4;                // 16 bytes nobody reads (pieces of in-edges beyond DEG)
     static constexpr int BYTES = OFF_DUMP + 16;
 };
+
+// The transposed incidence of a batch-shared neighbour table, in LDS: tab [NMAX][QS] = edge id m * KC + j of every in-edge slot of
+// every source node (-1 = none; + one all -1 row), slot_of [M KC] = G row n * QS + q of every edge, gtab [8 M][KC] = LDS byte address of
+// a staging item's 16-byte piece of each of its KC G rows.  cnt: NMAX * 9 ints of zeroed scratch.  Called by all BW_THREADS threads;
+// idx_v = the thread's table entry (tid < M KC).  Deterministic: the arrival order of the counters is undone by a sort.
+template <int KC, int DEG>
+__device__ __forceinline__ void bw_build_tables(long long idx_v, int N, int M, int tid, int* tab, int* slot_of, unsigned* gtab, int* cnt) {
+    typedef BwLayout<KC> LY;
+    constexpr int QS = LY::QS, NMAX = LY::NMAX;
+    const int mk = M * KC;
+    int* tmp = cnt + NMAX;
+    for (int f = tid; f < NMAX * QS + 4; f += BW_THREADS) tab[f] = -1;            // (+ the all -1 row unused lanes read)
+    if (tid < mk) {
+        const int r = tid;
+        const long long v = idx_v;
+        const int n = (int)(v < 0 ? 0 : (v >= N ? N - 1 : v));
+        slot_of[r] = -1;
+        const int pos = atomicAdd(&cnt[n], 1);                           // arrival order: made deterministic by the sort below
+        if (pos < 8) tmp[n * 8 + pos] = r;
+    }
+    bw_barrier();
+    if (tid < N) {                                                        // the node's in-edges in (m, j) order = ascending edge id
+        const int n = tid, c = min(cnt[n], 8);
+        int e[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) e[q] = q < c ? tmp[n * 8 + q] : 0x7fffffff;
+#pragma unroll
+        for (int a = 0; a < 8; ++a)                                       // (odd-even transposition sort of 8: 8 passes)
+#pragma unroll
+            for (int q = a & 1; q + 1 < 8; q += 2) {
+                const int lo = min(e[q], e[q + 1]), hi = max(e[q], e[q + 1]);
+                e[q] = lo; e[q + 1] = hi;
+            }
+#pragma unroll
+        for (int q = 0; q < DEG; ++q)                                     // (host guarantees in-degree <= DEG)
+            if (q < c) { tab[n * QS + q] = e[q]; slot_of[e[q]] = n * QS + q; }
+    }
+    bw_barrier();
+    for (int f = tid; f < 8 * mk; f += BW_THREADS) {                  // (item, j) -> 16-byte piece c8 of G row R, chunk-swizzled
+        const int item = f / KC, j = f - item * KC, m = item >> 3, c8 = item & 7;
+        const int R = slot_of[m * KC + j];
+        gtab[f] = R >= 0 ? (unsigned)(LY::OFF_G + R * BW_GROW + ((c8 ^ bw_swz_r(R)) << 4)) : (unsigned)LY::OFF_DUMP;
+    }
+    bw_barrier();
+}
+
+// The same tables, ONCE per graph, into global memory: out [NMAX QS + 4] tab, then [8 M KC] gtab (one workgroup).
+template <int KC, int DEG>
+__global__ __launch_bounds__(BW_THREADS) void mpconv_bwd_ws_tables_kernel(const int64_t* idx, int N, int M, int* out) {
+    typedef BwLayout<KC> LY;
+    constexpr int QS = LY::QS, NMAX = LY::NMAX, MMAX = LY::MMAX;
+    __shared__ int tab[NMAX * QS + 4], slot_of[MMAX * KC], cnt[NMAX * 9];
+    __shared__ unsigned gtab[8 * MMAX * KC];
+    const int tid = threadIdx.x, mk = M * KC;
+    for (int f = tid; f < NMAX * 9; f += BW_THREADS) cnt[f] = 0;
+    const long long idx_v = tid < mk ? idx[tid] : 0;
+    bw_barrier();
+    bw_build_tables<KC, DEG>(idx_v, N, M, tid, tab, slot_of, gtab, cnt);
+    for (int f = tid; f < NMAX * QS + 4; f += BW_THREADS) out[f] = tab[f];
+    for (int f = tid; f < 8 * mk; f += BW_THREADS) out[NMAX * QS + 4 + f] = (int)gtab[f];
+}
 
 // KC = destination degree (3 / 6), DEG = in-edge slots per source node the tables are sized for (6 / 3)
 template <int KC, int DEG>
@@ -295,45 +358,20 @@ __global__ __launch_bounds__(BW_THREADS) void mpconv_bwd_ws_kernel(const BwParam
     BW_STAMP_G(43);
     bw_barrier();
     BW_STAMP_G(44);
-    {
-        // scratch in the (still unused) P / dP region: in-degree counters and up to 8 edge ids per source node
-        int* cnt = reinterpret_cast<int*>(bw_lds + OFF_PD);
-        int* tmp = cnt + NMAX;
-        for (int f = tid; f < Npad * QS + 4; f += BW_THREADS) tab[f] = -1;            // (+ the all -1 row unused lanes read)
-        if (tid < mk) {
-            const int r = tid;
-            const long long v = idx_v;
-            const int n = (int)(v < 0 ? 0 : (v >= N ? N - 1 : v));
-            slot_of[r] = -1;
-            const int pos = atomicAdd(&cnt[n], 1);                           // arrival order: made deterministic by the sort below
-            if (pos < 8) tmp[n * 8 + pos] = r;
-        }
+    if (p.tables) {
+        // the graph is static: its tables were built once (fgnn_mpconv_backward_tables) — two coalesced copies instead of counters,
+        // a sort and three barriers in every workgroup of every launch
+        for (int f = tid; f < Npad * QS + 4; f += BW_THREADS) tab[f] = p.tables[f];
+        for (int f = tid; f < 8 * mk; f += BW_THREADS) gtab[f] = (unsigned)p.tables[Npad * QS + 4 + f];
         bw_barrier();
         BW_STAMP_G(2);
-        if (tid < N) {                                                        // the node's in-edges in (m, j) order = ascending edge id
-            const int n = tid, c = min(cnt[n], 8);
-            int e[8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) e[q] = q < c ? tmp[n * 8 + q] : 0x7fffffff;
-#pragma unroll
-            for (int a = 0; a < 8; ++a)                                       // (odd-even transposition sort of 8: 8 passes)
-#pragma unroll
-                for (int q = a & 1; q + 1 < 8; q += 2) {
-                    const int lo = min(e[q], e[q + 1]), hi = max(e[q], e[q + 1]);
-                    e[q] = lo; e[q + 1] = hi;
-                }
-#pragma unroll
-            for (int q = 0; q < DEG; ++q)                                     // (host guarantees in-degree <= DEG)
-                if (q < c) { tab[n * QS + q] = e[q]; slot_of[e[q]] = n * QS + q; }
-        }
-        bw_barrier();
+        BW_STAMP_G(6);
+    } else {
+        // scratch in the (still unused) P / dP region: in-degree counters and up to 8 edge ids per source node
+        int* cnt = reinterpret_cast<int*>(bw_lds + OFF_PD);
+        bw_build_tables<KC, DEG>(idx_v, N, M, tid, tab, slot_of, gtab, cnt);
         BW_STAMP_G(6);
         for (int f = tid; f < (NMAX * 9 + 3) / 4; f += BW_THREADS) reinterpret_cast<uint4*>(cnt)[f] = make_uint4(0, 0, 0, 0);      // scratch back to zeros
-        for (int f = tid; f < 8 * mk; f += BW_THREADS) {                  // (item, j) -> 16-byte piece c8 of G row R, chunk-swizzled
-            const int item = f / KC, j = f - item * KC, m = item >> 3, c8 = item & 7;
-            const int R = slot_of[m * KC + j];
-            gtab[f] = R >= 0 ? (unsigned)(OFF_G + R * BW_GROW + ((c8 ^ bw_swz_r(R)) << 4)) : (unsigned)LY::OFF_DUMP;
-        }
         bw_barrier();
     }
 
@@ -749,6 +787,47 @@ __global__ __launch_bounds__(BW_THREADS) void mpconv_bwd_ws_kernel(const BwParam
 
 // Called first by fgnn_mpconv_backward_sg (mpconv_bwd_sg.hip) for the 64 -> 64 calls: 1 = launched, 0 = not this kernel's
 // shape (the second-generation kernel takes it), < 0 = error.
+int fgnn_check_desc(const fgnn_mpconv_desc* d);
+
+// Does this descriptor go to the kernel above, and with how many table entries?  (The shape rules of fgnn_mpconv_backward_ws that do
+// not depend on pointers.)
+static int bw_tables_count(const fgnn_mpconv_desc* d) {
+    static const bool off = getenv("FGNN_NO_WS") != nullptr || getenv("FGNN_NO_WS_BWD") != nullptr || getenv("FGNN_NO_BWD_TABLES") != nullptr;
+    if (off || d->dtype != FGNN_BF16 || d->ext != FGNN_EXT_NONE || d->net != 4 || d->agg != FGNN_AGG_MAX) return 0;
+    if (d->nin != 64 || (d->nou != 64 && d->nou != 128) || (d->k != 3 && d->k != 6)) return 0;
+    if (d->idx_sb != 0 && d->B > 1) return 0;
+    if (!(d->idx_sk == 1 && d->idx_sm == d->k)) return 0;
+    const int KC = d->k;
+    if (KC == 6 ? (d->N > 96 || d->M > 48) : (d->N > 64 || d->M > 96)) return 0;
+    if ((d->M * KC) & 1) return 0;
+    return (KC == 6 ? BwLayout<6>::NMAX * BwLayout<6>::QS : BwLayout<3>::NMAX * BwLayout<3>::QS) + 4 + 8 * d->M * KC;
+}
+
+// Bytes of the per-graph tables the backward of this descriptor can take (0: the shape does not use any).
+extern "C" int64_t fgnn_mpconv_backward_tables_bytes(const fgnn_mpconv_desc* d) {
+    if (fgnn_check_desc(d)) return 0;
+    return (int64_t)bw_tables_count(d) * 4;
+}
+
+// Builds them (one small launch; the in-degree bound travels in d->reserved as for fgnn_mpconv_backward).
+extern "C" int fgnn_mpconv_backward_tables(const fgnn_mpconv_desc* d, const int64_t* nn_idx, void* tables, fgnn_stream_t stream) {
+    int rc = fgnn_check_desc(d);
+    if (rc) return rc;
+    if (!nn_idx || !tables) FGNN_FAIL(FGNN_EINVAL, "mpconv_backward_tables: null pointer");
+    const int KC = d->k, DEG = KC == 6 ? 3 : 6, indeg = d->reserved & 0xffff;
+    if (bw_tables_count(d) == 0 || indeg < 1 || indeg > DEG)
+        FGNN_FAIL(FGNN_EUNSUPPORTED, "mpconv_backward_tables: not a shape / in-degree of the table-driven backward");
+    if (KC == 6) hipLaunchKernelGGL((mpconv_bwd_ws_tables_kernel<6, 3>), dim3(1), dim3(BW_THREADS), 0, (hipStream_t)stream, nn_idx, d->N, d->M, (int*)tables);
+    else hipLaunchKernelGGL((mpconv_bwd_ws_tables_kernel<3, 6>), dim3(1), dim3(BW_THREADS), 0, (hipStream_t)stream, nn_idx, d->N, d->M, (int*)tables);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "mpconv_backward_tables launch: %s", hipGetErrorString(e));
+    return FGNN_OK;
+}
+
+// The tables of the NEXT backward launch on this thread (fgnn_mpconv_backward_with_tables sets them around its call).
+static thread_local const void* bw_pending_tables = nullptr;
+void fgnn_bw_set_pending_tables(const void* t) { bw_pending_tables = t; }
+
 int fgnn_mpconv_backward_ws(const fgnn_mpconv_desc* d, const void* x, const int64_t* nn_idx, const void* etype,
                             const float* filters, const void* gz, const uint8_t* argmax, void* gx, void* getype,
                             float* gfilters, float* gbias, void* workspace, int64_t workspace_bytes,
@@ -775,6 +854,7 @@ int fgnn_mpconv_backward_ws(const fgnn_mpconv_desc* d, const void* x, const int6
     p.B = d->B; p.N = d->N; p.M = d->M;
     p.y_ld = d->nou; p.w_ld = d->nou * 4; p.accum = 0;
     p.x_sb = d->x_sb; p.et_sb = d->et_sb; p.y_sb = d->y_sb;
+    p.tables = (bw_pending_tables && bw_tables_count(d) > 0) ? (const int*)bw_pending_tables : nullptr;
     const int off_b = KC == 6 ? BwLayout<6>::BYTES : BwLayout<3>::BYTES;
     static_assert(BwLayout<6>::BYTES <= 160 * 1024 && BwLayout<3>::BYTES <= 160 * 1024, "LDS");
     void* fn = KC == 6 ? (void*)mpconv_bwd_ws_kernel<6, 3> : (void*)mpconv_bwd_ws_kernel<3, 6>;

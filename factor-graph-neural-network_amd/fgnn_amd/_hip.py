@@ -26,7 +26,7 @@ EXPORTS = ('fgnn_mpconv_forward', 'fgnn_mpconv_backward', 'fgnn_mpconv_forward_l
            'fgnn_mpconv_backward_workspace_bytes', 'fgnn_mpconv_backward_reduces_getype', 'fgnn_linear_wgrad', 'fgnn_linear_wgrad_workspace_bytes',
            'fgnn_instnorm_forward', 'fgnn_instnorm_backward', 'fgnn_bn_supported', 'fgnn_bn_workspace_bytes',
            'fgnn_bn_stats', 'fgnn_bn_finalize', 'fgnn_bn_apply', 'fgnn_bn_backward',
-           'fgnn_linear_forward', 'fgnn_linear_forward_partials', 'fgnn_linear_instnorm_forward', 'fgnn_sum_n', 'fgnn_flat_adam', 'fgnn_flat_adam_dev', 'fgnn_edge_mlp_forward', 'fgnn_edge_mlp_workspace_bytes', 'fgnn_edge_mlp_backward', 'fgnn_ldpc_encode', 'fgnn_ldpc_channel_features', 'fgnn_ldpc_channel_features_rng', 'fgnn_ldpc_decode', 'fgnn_mpconv_block_forward', 'fgnn_mpconv_block_forward_fanout', 'fgnn_mpconv_block_forward_fanin', 'fgnn_factor_layer_forward', 'fgnn_factor_layer_param_count', 'fgnn_mpconv_forward_stats', 'fgnn_mpconv_forward_stats_partials', 'fgnn_block_tail_partials', 'fgnn_block_tail_stats', 'fgnn_block_tail_apply', 'fgnn_block_tail_backward', 'fgnn_block_tail_backward_partials', 'fgnn_bn_backward_apply', 'fgnn_block_head_backward', 'fgnn_node_sum', 'fgnn_set_inkernel_finalisers',
+           'fgnn_linear_forward', 'fgnn_linear_forward_partials', 'fgnn_linear_instnorm_forward', 'fgnn_sum_n', 'fgnn_flat_adam', 'fgnn_flat_adam_dev', 'fgnn_edge_mlp_forward', 'fgnn_edge_mlp_workspace_bytes', 'fgnn_edge_mlp_backward', 'fgnn_ldpc_encode', 'fgnn_ldpc_channel_features', 'fgnn_ldpc_channel_features_rng', 'fgnn_ldpc_decode', 'fgnn_mpconv_block_forward', 'fgnn_mpconv_block_forward_fanout', 'fgnn_mpconv_block_forward_fanin', 'fgnn_factor_layer_forward', 'fgnn_factor_layer_param_count', 'fgnn_mpconv_forward_stats', 'fgnn_mpconv_forward_stats_partials', 'fgnn_block_tail_partials', 'fgnn_block_tail_stats', 'fgnn_block_tail_apply', 'fgnn_block_tail_backward', 'fgnn_block_tail_backward_partials', 'fgnn_bn_backward_apply', 'fgnn_block_head_backward', 'fgnn_node_sum', 'fgnn_set_inkernel_finalisers', 'fgnn_mpconv_backward_tables_bytes', 'fgnn_mpconv_backward_tables', 'fgnn_mpconv_backward_with_tables',
            'fgnn_mpconv_algorithmic_bytes', 'fgnn_mpconv_forward_addends', 'fgnn_last_error', 'fgnn_last_kernel', 'fgnn_abi_version')
 
 
@@ -100,6 +100,12 @@ def lib():
     L.fgnn_mpconv_forward_stats_partials.argtypes = [dp]
     L.fgnn_mpconv_backward.restype = ctypes.c_int
     L.fgnn_mpconv_backward.argtypes = [dp] + [vp] * 12 + [ctypes.c_int64, vp]
+    L.fgnn_mpconv_backward_with_tables.restype = ctypes.c_int
+    L.fgnn_mpconv_backward_with_tables.argtypes = [dp] + [vp] * 12 + [ctypes.c_int64, vp, vp]
+    L.fgnn_mpconv_backward_tables_bytes.restype = ctypes.c_int64
+    L.fgnn_mpconv_backward_tables_bytes.argtypes = [dp]
+    L.fgnn_mpconv_backward_tables.restype = ctypes.c_int
+    L.fgnn_mpconv_backward_tables.argtypes = [dp, vp, vp, vp]
     L.fgnn_mpconv_backward_reduces_getype.restype = ctypes.c_int
     L.fgnn_mpconv_backward_reduces_getype.argtypes = [dp]
     L.fgnn_mpconv_backward_workspace_bytes.restype = ctypes.c_int64

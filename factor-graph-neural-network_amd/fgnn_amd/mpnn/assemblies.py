@@ -166,6 +166,9 @@ _V2V_MAIN = _parse_layers(os.environ.get('FGNN_V2V_MAIN', ''))      # tuning kno
 # stream.  Measured on one box (18.25 ms with none): layers 0,1,7: 18.27; 2-6: 18.47; 3-5: 18.54; all: 18.48 — the map belongs on the side stream.
 
 
+_F2F_SIDE = os.environ.get('FGNN_F2F_SIDE', '0') not in ('', '0')      # tuning knob: the parity factors' f2f map on the side stream
+
+
 class FactorNN(torch.nn.Module):
     """LDPC body ("sp" variant): per layer and factor type an F->V block (factors are the
     sources, variables the destinations) and a V->F block, plus node-wise v2v / f2f maps."""
@@ -356,6 +359,16 @@ class FactorNN(torch.nn.Module):
             if two:
                 main, side = torch.cuda.current_stream(var.device), _ops.side_stream(var.device)
                 side.wait_stream(main)
+            f2f_side = two and _F2F_SIDE
+            if f2f_side:
+                # round 5 (tuning knob): with the hyper-factor's message carried as a per-sample vector the side branch is the lighter
+                # one (11.1 vs 15.0 ms busy, gpurun_out/r05b/timeline): the parity factors' own node-wise map can move over too — FIRST
+                # in the side stream's order; the main stream asks for it (an event, not a full join) only where the V->F block's
+                # tail adds it
+                with torch.cuda.stream(side):
+                    nf0 = self.f2f_modules[L][0](fac_c[0][0])
+                    f2f_done = torch.cuda.Event()
+                    f2f_done.record(side)
             for j in range(1, nft):
                 with (torch.cuda.stream(side) if two else contextlib.nullcontext()):
                     nf = self.f2f_modules[L][j](fac_c[j][0])
@@ -364,9 +377,15 @@ class FactorNN(torch.nn.Module):
                     h.append(_call(self.f2v_modules[L][j], fac_c[j][1], nn_idx_f2v[j], etype_f2v[j][L]))
             with (torch.cuda.stream(side) if (two and L not in _V2V_MAIN) else contextlib.nullcontext()):
                 new_var = self.v2v_modules[L](var_c[0])        # the variables' node-wise map rides with the side branch
-            nf = self.f2f_modules[L][0](fac_c[0][0])
-            new_fac[0] = _call(self.v2f_modules[L][0], var_c[1], nn_idx_v2f[0], etype_v2f[0][L],
-                               addend=[nf, fac_c[0][-1] if same_width else None, skip[1][0] if skip else None])
+            if f2f_side:
+                def fac_addends(nf=nf0, f2f_done=f2f_done, same_width=same_width, skip=skip, fac_c=fac_c):
+                    main.wait_event(f2f_done)
+                    return [nf, fac_c[0][-1] if same_width else None, skip[1][0] if skip else None]
+                new_fac[0] = _call(self.v2f_modules[L][0], var_c[1], nn_idx_v2f[0], etype_v2f[0][L], addend=fac_addends)
+            else:
+                nf = self.f2f_modules[L][0](fac_c[0][0])
+                new_fac[0] = _call(self.v2f_modules[L][0], var_c[1], nn_idx_v2f[0], etype_v2f[0][L],
+                                   addend=[nf, fac_c[0][-1] if same_width else None, skip[1][0] if skip else None])
             def joined(new_var=new_var, h=h, L=L, same_width=same_width, skip=skip, var_c=var_c):
                 # called by the block right before its closing BatchNorm consumes the addends: only there does the main
                 # stream wait for the side branch

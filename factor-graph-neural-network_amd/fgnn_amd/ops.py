@@ -260,6 +260,35 @@ def max_in_degree(nn_idx, N):
     return memo[1]
 
 
+BACKWARD_TABLES = os.environ.get('FGNN_NO_BWD_TABLES') is None      # (the variable: an A/B switch for tools / bench runs)
+
+
+def backward_tables(nn_idx, d):
+    """The per-graph tables of the table-driven backward (include/fgnn_hip.h: fgnn_mpconv_backward_tables) for the batch-SHARED
+    neighbour table ``nn_idx`` and the descriptor ``d`` of the backward call, or None (another kernel family, a per-sample table, an
+    unknown in-degree).  Built once per table — one small launch, remembered on the tensor that owns the memory next to its
+    in-degree (``max_in_degree``), keyed by version, view geometry and (N, M, k) — so a training run, whose graph never changes, pays
+    for the transposed incidence once instead of in every workgroup of every backward launch."""
+    if not BACKWARD_TABLES or (d.reserved & 0xffff) == 0 or (nn_idx.shape[0] > 1 and nn_idx.stride(0) != 0):
+        return None
+    L = _hip.lib()
+    nbytes = int(L.fgnn_mpconv_backward_tables_bytes(ctypes.byref(d)))
+    if nbytes == 0:
+        return None
+    owner = nn_idx._base if nn_idx._base is not None else nn_idx
+    key = (nn_idx._version, nn_idx.data_ptr(), tuple(nn_idx.shape), tuple(nn_idx.stride()), d.N, d.M, d.k, d.reserved & 0xffff)
+    memo = getattr(owner, '_fgnn_bwd_tables', None)
+    if memo is None or memo[0] != key:
+        if torch.cuda.is_current_stream_capturing():
+            return None          # (a first sight during capture: the launch would be recorded and its buffer owned by the graph's pool)
+        t = torch.empty(nbytes // 4, device=nn_idx.device, dtype=torch.int32)
+        _hip.check(L.fgnn_mpconv_backward_tables(ctypes.byref(d), _hip._ptr(nn_idx), _hip._ptr(t), _hip.stream_ptr()))
+        torch.cuda.current_stream(nn_idx.device).synchronize()      # other streams will read it
+        memo = (key, t)
+        owner._fgnn_bwd_tables = memo
+    return memo[1]
+
+
 def mpconv_forward_raw(x, nn_idx, etype, filters, bias, nou, net, ext, agg, *,
                        post_scale=None, post_shift=None, relu=False, want_argmax=False, bn=None, addends=None):
     """One launch of fgnn_mpconv_forward.  Returns (y, argmax-or-None).  ``bn`` (a ``pointwise.bn_spec`` tuple: the training-mode
@@ -470,10 +499,11 @@ class _MPConv(torch.autograd.Function):
                       + 8 * M * k * (1 if shared_idx else B)
                       + (B * nou * M if amax is not None else 0)
                       + (get.element_size() * get.numel() if want_get else 0) + 8 * w.numel())
-        _launch('bwd', d, nbytes, lambda: _hip.check(L.fgnn_mpconv_backward(
+        tables = backward_tables(nn_idx, d)           # the transposed incidence, built once per graph (None: the kernel builds its own)
+        _launch('bwd', d, nbytes, lambda: _hip.check(L.fgnn_mpconv_backward_with_tables(
             ctypes.byref(d), _hip._ptr(xx), _hip._ptr(nn_idx), _hip._ptr(etype), _hip._ptr(w),
             _hip._ptr(gz), None, _hip._ptr(amax), _hip._ptr(gx), _hip._ptr(get),
-            _hip._ptr(gw), _hip._ptr(gb), _hip._ptr(ws), ws.numel() * 4, _hip.stream_ptr())))
+            _hip._ptr(gw), _hip._ptr(gb), _hip._ptr(ws), ws.numel() * 4, _hip._ptr(tables), _hip.stream_ptr())))
         if want_get and ctx.shared_et and not reduced:
             get = get.sum(dim=0, keepdim=True)
         if want_get and get.dtype != etype.dtype:

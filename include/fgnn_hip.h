@@ -130,6 +130,22 @@ int fgnn_mpconv_backward(const fgnn_mpconv_desc* d, const void* x, const int64_t
                          fgnn_stream_t stream);
 
 int64_t fgnn_mpconv_backward_workspace_bytes(const fgnn_mpconv_desc* d);
+/*
+ * The graph of a training run is static (the reference hands the same nn_idx every step, train_ldpc.py:209-216): the table-driven
+ * backward of the bf16 parity shapes (64 -> 64 / 64 -> 128 channels, degree 3 / 6, one table shared by the batch) can take the
+ * transposed incidence it works from — which source node feeds which (destination, slot) — PRE-BUILT:
+ *   fgnn_mpconv_backward_tables_bytes(d)  bytes of the tables for this descriptor (0 = this shape does not use any);
+ *   fgnn_mpconv_backward_tables(...)      builds them (one small launch; d->reserved carries the in-degree bound as for the backward);
+ *   fgnn_mpconv_backward_with_tables(...) = fgnn_mpconv_backward with `tables` (NULL = none, identical results either way): without
+ *                                         them every workgroup of every launch rebuilds the tables (~7 us of a ~80 us launch).
+ * The tables depend on nn_idx's contents, N, M and k only.
+ */
+int64_t fgnn_mpconv_backward_tables_bytes(const fgnn_mpconv_desc* d);
+int fgnn_mpconv_backward_tables(const fgnn_mpconv_desc* d, const int64_t* nn_idx, void* tables, fgnn_stream_t stream);
+int fgnn_mpconv_backward_with_tables(const fgnn_mpconv_desc* d, const void* x, const int64_t* nn_idx, const void* etype,
+                                     const float* filters, const void* gz, const void* z, const uint8_t* argmax, void* gx,
+                                     void* getype, float* gfilters, float* gbias, void* workspace, int64_t workspace_bytes,
+                                     const void* tables, fgnn_stream_t stream);
 
 /*
  * Edge weights shared by the batch (et_sb == 0; every reference script builds them from one [1, ., M, k] feature table,

@@ -384,3 +384,35 @@ def test_inference_forward_with_addends_in_the_epilogue(shape, nadd, dev):
         rc = _hip.lib().fgnn_mpconv_forward_addends(ctypes.byref(d), P(xd), P(ops.shared_graph_view(idxd)), P(etd), P(Wd), P(bd), P(sc), P(sh),
                                                     ap[0], ap[1], ap[2], P(y2), _hip.stream_ptr())
         assert rc == 1 and torch.equal(y2, y1)
+
+
+@pytest.mark.parametrize('shape', [(64, 96, 48, 6), (64, 48, 96, 3), (128, 96, 48, 6), (64, 64, 32, 6), (64, 16, 32, 3)],
+                         ids=lambda s: 'x'.join(map(str, s)))
+def test_ws_backward_with_prebuilt_tables_is_bit_identical(shape, dev, monkeypatch):
+    """fgnn_mpconv_backward_with_tables: the transposed incidence built ONCE per graph (one small launch, remembered on the table's
+    owner) and copied by the backward's workgroups == the tables every workgroup of every launch used to build for itself: all four
+    gradients bit-identical, for the 64 -> 64 shapes, the two-launch 64 -> 128 form and graphs smaller than the LDS layout."""
+    from fgnn_amd import _hip, ops
+    nou, N, M, k = shape
+    B = 300
+    g = torch.Generator().manual_seed(N + M)
+    x = torch.randn(B, N, 1, 64, generator=g).bfloat16().to(dev).permute(0, 3, 1, 2)
+    idx = _regular_table(N, M, k, g).to(dev).expand(B, -1, -1)
+    et = torch.randn(B, M, k, 4, generator=g).bfloat16().to(dev).permute(0, 3, 1, 2)
+    W, bias = (torch.randn(64, nou * 4, generator=g) * 0.1).to(dev), torch.randn(nou, generator=g).to(dev)
+    gz = torch.randn(B, M, 1, nou, generator=g).bfloat16().to(dev).permute(0, 3, 1, 2)
+
+    def run(tables):
+        monkeypatch.setattr(ops, 'BACKWARD_TABLES', tables)
+        xd, ed = x.detach().requires_grad_(True), et.detach().requires_grad_(True)
+        Wd, bd = W.detach().requires_grad_(True), bias.detach().requires_grad_(True)
+        ops.mpconv(xd, idx, ed, Wd, bd, nou, 4, 0, _hip.AGG_MAX).backward(gz)
+        return xd.grad, ed.grad, Wd.grad, bd.grad, _hip.lib().fgnn_last_kernel().decode()
+
+    a = run(True)
+    assert 'mpconv_bwd_ws' in a[4], a[4]
+    owner = idx._base if idx._base is not None else idx
+    assert getattr(owner, '_fgnn_bwd_tables', None) is not None
+    b, c = run(False), run(True)
+    for u, v, w in zip(a[:4], b[:4], c[:4]):
+        assert torch.equal(u, v) and torch.equal(u, w)

@@ -118,16 +118,17 @@ def main():
                       + 8 * W.numel())
             flops *= 3.0
             wsb = ops._workspace(dev, int(L.fgnn_mpconv_backward_workspace_bytes(ctypes.byref(dsc))))
+            tables = ops.backward_tables(idx, dsc)          # per-graph tables (FGNN_NO_BWD_TABLES=1: every launch builds its own)
             cp = lambda t: None if t is None else t.clone(memory_format=torch.preserve_format)
             sets = [(x, et, gz, amax, gx, get)] + [(xs[i], ets[i], cp(gz), cp(amax), cp(gx), cp(get)) for i in range(1, K)]
 
             def run():
                 turn[0] = (turn[0] + 1) % K
                 x_, et_, gz_, am_, gx_, get_ = sets[turn[0]]
-                _hip.check(L.fgnn_mpconv_backward(
+                _hip.check(L.fgnn_mpconv_backward_with_tables(
                     ctypes.byref(dsc), _hip._ptr(x_), _hip._ptr(idx), _hip._ptr(et_), _hip._ptr(W),
                     _hip._ptr(gz_), None, _hip._ptr(am_), _hip._ptr(gx_), _hip._ptr(get_), _hip._ptr(gw),
-                    _hip._ptr(gb), _hip._ptr(wsb), wsb.numel() * 4, _hip.stream_ptr()))
+                    _hip._ptr(gb), _hip._ptr(wsb), wsb.numel() * 4, _hip._ptr(tables), _hip.stream_ptr()))
         for _ in range(3):
             run()
         torch.cuda.synchronize()
