@@ -59,8 +59,9 @@ struct BwParams {
     int B, N, M;
     int y_ld, w_ld, accum;       // accum: gx and getype are ADDED to (second launch of a 64 -> 128 call, over the upper output channels)
     long long x_sb, et_sb, y_sb;     // elements
-    const int* tables;       // the transposed incidence, built ONCE per graph by mpconv_bwd_ws_tables_kernel (or NULL: every workgroup
-                             // of every launch rebuilds it — 17 400 of a launch's ~23 000 set-up cycles, profiles/r04/README.md)
+    const int* tables;       // the transposed incidence, built ONCE per graph by mpconv_bwd_ws_tables_kernel, or NULL (the default): every
+                             // workgroup builds its own — 17 400 of a launch's ~23 000 set-up cycles (profiles/r04), but NOT on its critical
+                             // path: they overlap the first samples' LDS-DMA; with the tables 90.3 / 79.9 us, without 87.8 / 81.5 (gpurun_out/r05c)
     long long* prof;         // FGNN_PROF (builds with -DFGNN_ENABLE_PROF only): phase timeline
 };
 

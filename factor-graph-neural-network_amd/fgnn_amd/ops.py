@@ -88,6 +88,7 @@ def timed(symbol, nbytes, fn, nflops=0):
 # backward pass ends (an engine callback, which also joins every such stream into the caller's).  Only gradients that go to
 # a sink (ops.grad_sink: the flat bucket) are deferred: a gradient tensor handed back to autograd must be complete in stream order.
 DEFER_WGRAD = os.environ.get('FGNN_NO_DEFER_WGRAD') is None       # (the variable: an A/B switch for tools / bench runs)
+WGRAD_TO_SIDE = os.environ.get('FGNN_WGRAD_SIDE', '0') not in ('', '0')     # tuning knob (round 5): see defer_wgrad
 SIDE_ACTIVE = False         # set by the assemblies the first time a forward actually forks onto the side stream: with ONE stream in
                             # play parking buys no overlap and only keeps every layer's operands alive until the end of the backward
 _DEFERRED = {}              # stream -> [(launch closure, operands)]
@@ -109,6 +110,25 @@ def defer_wgrad(launch, operands=()):
     if task < 0:
         launch()
         return
+    if WGRAD_TO_SIDE and operands and operands[0].is_cuda:
+        # round 5 (tuning knob): the main stream is the critical one (15.0 vs 11.1 ms busy, gpurun_out/r05b/timeline) — ITS
+        # weight-gradient kernels go to the side stream at once, behind an event on what they read
+        side = side_stream(operands[0].device)
+        if st != side:
+            if _DEFER_CALLBACK[0] != task:
+                if any(_DEFERRED.values()):
+                    flush_deferred()
+                _DEFER_CALLBACK[0] = task
+                torch.autograd.Variable._execution_engine.queue_callback(_flush_at_end_of_backward)
+            ready = torch.cuda.Event()
+            ready.record(st)
+            with torch.cuda.stream(side):
+                side.wait_event(ready)
+                launch()
+                for t in operands:
+                    t.record_stream(side)
+            _DEFER_ISSUED.add(side)
+            return
     if _DEFER_CALLBACK[0] != task:
         # Another backward pass than the one that parked what is in the lists: a NESTED (re-entrant) pass inside it — checkpointing,
         # a custom Function calling backward() — or a pass that died half-way.  Either way the parked launches are ISSUED, never
@@ -260,7 +280,11 @@ def max_in_degree(nn_idx, N):
     return memo[1]
 
 
-BACKWARD_TABLES = os.environ.get('FGNN_NO_BWD_TABLES') is None      # (the variable: an A/B switch for tools / bench runs)
+# Off by default: measured on MI355X (gpurun_out/r05c, 4096 codewords) the pre-built tables change nothing — stand-alone 90.3 / 79.9 us
+# with them against 87.8 / 81.5 us without (V->F / F->V 64 -> 64), the training step 15.49 against 15.46 ms: the ~17 k cycles a
+# workgroup spends building its tables (profiles/r04) overlap the first samples' LDS-DMA and the staging of W, they are not on the
+# launch's critical path.  FGNN_BWD_TABLES=1 turns them on (identical results).
+BACKWARD_TABLES = os.environ.get('FGNN_BWD_TABLES', '0') not in ('', '0')
 
 
 def backward_tables(nn_idx, d):
@@ -282,8 +306,12 @@ def backward_tables(nn_idx, d):
         if torch.cuda.is_current_stream_capturing():
             return None          # (a first sight during capture: the launch would be recorded and its buffer owned by the graph's pool)
         t = torch.empty(nbytes // 4, device=nn_idx.device, dtype=torch.int32)
-        _hip.check(L.fgnn_mpconv_backward_tables(ctypes.byref(d), _hip._ptr(nn_idx), _hip._ptr(t), _hip.stream_ptr()))
-        torch.cuda.current_stream(nn_idx.device).synchronize()      # other streams will read it
+        rc = L.fgnn_mpconv_backward_tables(ctypes.byref(d), _hip._ptr(nn_idx), _hip._ptr(t), _hip.stream_ptr())
+        if rc == _hip.EUNSUPPORTED:
+            t = None             # (an in-degree beyond the table-driven kernel's slots: the call goes to another kernel anyway)
+        else:
+            _hip.check(rc)
+            torch.cuda.current_stream(nn_idx.device).synchronize()      # other streams will read it
         memo = (key, t)
         owner._fgnn_bwd_tables = memo
     return memo[1]

@@ -137,7 +137,8 @@ int64_t fgnn_mpconv_backward_workspace_bytes(const fgnn_mpconv_desc* d);
  *   fgnn_mpconv_backward_tables_bytes(d)  bytes of the tables for this descriptor (0 = this shape does not use any);
  *   fgnn_mpconv_backward_tables(...)      builds them (one small launch; d->reserved carries the in-degree bound as for the backward);
  *   fgnn_mpconv_backward_with_tables(...) = fgnn_mpconv_backward with `tables` (NULL = none, identical results either way): without
- *                                         them every workgroup of every launch rebuilds the tables (~7 us of a ~80 us launch).
+ *                                         them every workgroup of every launch builds its own (17 k cycles, which — measured — hide
+ *                                         under the first samples' loads: the tables buy nothing on MI355X and are off by default).
  * The tables depend on nn_idx's contents, N, M and k only.
  */
 int64_t fgnn_mpconv_backward_tables_bytes(const fgnn_mpconv_desc* d);

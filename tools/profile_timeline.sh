@@ -10,7 +10,7 @@ cd $R
 rm -rf /tmp/tl
 timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/tl -o tl -- python bench.py --steps 4 --warmup 2 --mode train --no-cpu-baseline "$@" > $O/bench.log 2>&1
 T=$(find /tmp/tl -name "*kernel_trace.csv" | head -1)
-python tools/timeline.py $T --marker flat_adam_kernel --json $O/timeline.json > $O/timeline.txt 2>&1     # (the capturable optimizer is two kernels: name the update itself)
+python tools/timeline.py $T --marker flat_adam_kernel --json $O/timeline.json --seq $O/step_sequence.csv > $O/timeline.txt 2>&1     # (the capturable optimizer is two kernels: name the update itself)
 tail -n 2000 $T > $O/trace_tail.csv
 head -1 $T > $O/trace_head.csv
 cat $O/timeline.txt | head -60

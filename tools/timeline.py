@@ -29,6 +29,7 @@ def main():
     ap.add_argument('--dump', default=None, help='kernel-name substring: list, per queue, what runs between consecutive launches of it')
     ap.add_argument('--dump-from', type=int, default=0)
     ap.add_argument('--dump-count', type=int, default=2)
+    ap.add_argument('--seq', default=None, help='write the step window launch by launch (start offset us, duration us, queue, kernel) as CSV')
     a = ap.parse_args()
     rows = []
     with open(a.csv) as f:
@@ -123,6 +124,11 @@ def main():
                         continue
                     print('    +%7.1f  %6.1f us  %s%s' % ((s_ - w0) / 1e3, (e_ - s_) / 1e3, short(n_), ('   [gap %.1f]' % ((s_ - last) / 1e3)) if s_ - last > 4000 else ''))
                     last = e_
+    if a.seq:
+        with open(a.seq, 'w') as f:
+            f.write('start_us,dur_us,queue,kernel\n')
+            for s_, e_, n_, q3, q4 in win:
+                f.write('%.2f,%.2f,%s/%s,"%s"\n' % ((s_ - t0) / 1e3, (e_ - s_) / 1e3, q3, q4, short(n_)))
     if a.json:
         out['kernels'] = {n: {'n': cnt[n], 'attr_ms': attr[n] / 1e6, 'sum_ms': dur[n] / 1e6, 'gap_before_ms': gap_before[n] / 1e6} for n in dur}
         json.dump(out, open(a.json, 'w'), indent=1)
