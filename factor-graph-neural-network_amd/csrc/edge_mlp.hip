@@ -235,6 +235,263 @@ __global__ __launch_bounds__(EM_BWD_THREADS) void edge_mlp_bwd_kernel(const EmPa
     }
 }
 
+// ----------------------------------------------------------------------------------------
+// Round 5: the same MLP on the MATRIX cores (profiles/r04: the VALU kernels above ran at 0.06 / 0.03 of HBM — 57 / 97 us for 26 MB —
+// at the serial head and tail of the training step).  A wave owns 16-row tiles; Cin (<= 8) and net (<= 4) are zero-padded to the
+// K = 16 of v_mfma_f32_16x16x16_bf16.  Orientations are chosen so that every product's D fragment IS the next product's operand:
+//   forward : H^T tile [hidden][row] = W1 X^T  ->  + b1, ReLU  ->  B operand (k = hidden) of  Y^T [q][row] += W2 H^T;
+//   backward: H [row][hidden] = X W1^T and dH [row][hidden] = dY W2 (masked by H > 0): a lane then holds FOUR CONSECUTIVE ROWS of one
+//             hidden unit = the k = row operand layout of  dW1^T [hidden][c] += dH^T X  (A) and  dW2 [q][hidden] += dY^T H  (B).
+// Precision: x / gy are bf16 already; every f32 quantity that enters a product (W1, W2, H, dH) goes in as bf16 hi + bf16 lo (two
+// MFMAs): 2^-17 relative, f32 accumulation — the tests' bounds (2^-8 of the output, 1e-4 of the gradients) are those of the VALU form.
+// ----------------------------------------------------------------------------------------
+typedef short em_s4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void em_split4(const float (&v)[4], em_s4& hi, em_s4& lo) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const __bf16 h = (__bf16)v[r];
+        const __bf16 l = (__bf16)(v[r] - (float)h);
+        hi[r] = __builtin_bit_cast(short, h);
+        lo[r] = __builtin_bit_cast(short, l);
+    }
+}
+#define EM_MMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x16bf16_1k((a), (b), (c), 0, 0, 0)
+// Both tensors arrive PLANE-major per sample (x [B][Cin][E] as the reference's DataLoader collates it, the edge-type gradient
+// [B][net][E] as the operator's backward writes it): a sample's block is one contiguous run, so a workgroup stages TWO samples
+// (2 E / 16 row tiles over its four waves) with 16-byte loads, the next pair in flight in registers, and takes its MFMA operands from
+// LDS: (row, four channels) = four 2-byte reads from four planes, (channel, four rows) = one 8-byte read.  Other layouts keep the
+// VALU kernels (host dispatch).
+#define EM_PAIR 2
+#define EM_MAXCHUNK 4     // 16-byte chunks a thread stages per pair and tensor (2 samples x 8 planes x 512 rows x 2 B / 16 / 256 threads)
+#define EM_MAXE_ROWS 512  // rows per sample the staging is sized for
+
+template <bool BWD>
+__device__ __forceinline__ void em_stage_load(const EmParams& p, int64_t pair, int tid, uint4 (&vx)[EM_MAXCHUNK], uint4 (&vg)[EM_MAXCHUNK]) {
+    const int E = p.E;
+    const int cx = p.Cin * E / 8, cg = p.net * E / 8;              // 16-byte chunks of one sample's x / gy block
+#pragma unroll
+    for (int k = 0; k < EM_MAXCHUNK; ++k) {
+        const int i = tid + 256 * k;
+        vx[k] = make_uint4(0, 0, 0, 0);
+        if (i < EM_PAIR * cx) {
+            const int smp = i / cx, ch = i - smp * cx;
+            const int64_t b = pair * EM_PAIR + smp;
+            if (b * E < p.R) vx[k] = reinterpret_cast<const uint4*>(p.x + b * p.x_sb)[ch];
+        }
+        if (BWD) {
+            vg[k] = make_uint4(0, 0, 0, 0);
+            if (i < EM_PAIR * cg) {
+                const int smp = i / cg, ch = i - smp * cg;
+                const int64_t b = pair * EM_PAIR + smp;
+                if (b * E < p.R) vg[k] = reinterpret_cast<const uint4*>(p.gy + b * p.gy_sb)[ch];
+            }
+        }
+    }
+}
+template <bool BWD>
+__device__ __forceinline__ void em_stage_store(const EmParams& p, int tid, const uint4 (&vx)[EM_MAXCHUNK], const uint4 (&vg)[EM_MAXCHUNK],
+                                               uint16_t* xs, uint16_t* gs) {
+    const int E = p.E;
+    const int cx = p.Cin * E / 8, cg = p.net * E / 8;
+#pragma unroll
+    for (int k = 0; k < EM_MAXCHUNK; ++k) {
+        const int i = tid + 256 * k;
+        if (i < EM_PAIR * cx) {
+            const int smp = i / cx, ch = i - smp * cx;
+            reinterpret_cast<uint4*>(xs + smp * (EM_MAXC * EM_MAXE_ROWS))[ch] = vx[k];       // planes keep their stride E inside the sample's slot
+        }
+        if (BWD && i < EM_PAIR * cg) {
+            const int smp = i / cg, ch = i - smp * cg;
+            reinterpret_cast<uint4*>(gs + smp * (EM_MAXE * EM_MAXE_ROWS))[ch] = vg[k];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void edge_mlp_fwd_mfma_kernel(const EmParams p) {
+    __shared__ __attribute__((aligned(16))) uint16_t xs[EM_PAIR * EM_MAXC * EM_MAXE_ROWS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, kg = lane >> 4;
+    const int Cin = p.Cin, net = p.net, E = p.E;
+    // resident operands: W1 rows as A (i = hidden, k = channel), W2 rows as A (i = q, k = hidden); hi / lo halves
+    em_s4 a1h[4], a1l[4], a2h[4], a2l[4];
+    float bias1[4][4], bias2[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        float w1[4], w2[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int c = 4 * kg + r;
+            w1[r] = c < Cin ? p.W1[(16 * t + li) * Cin + c] : 0.f;
+            w2[r] = li < net ? p.W2[li * EM_HID + 16 * t + 4 * kg + r] : 0.f;
+            bias1[t][r] = p.b1[16 * t + 4 * kg + r];
+        }
+        em_split4(w1, a1h[t], a1l[t]);
+        em_split4(w2, a2h[t], a2l[t]);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bias2[r] = r < net ? p.b2[r] : 0.f;
+    const int64_t B = p.R / E, npair = (B + EM_PAIR - 1) / EM_PAIR;
+    const int tps = E / 16;                                  // row tiles per sample
+    uint4 vx[EM_MAXCHUNK], vg[EM_MAXCHUNK];
+    if ((int64_t)blockIdx.x < npair) em_stage_load<false>(p, blockIdx.x, tid, vx, vg);
+    for (int64_t pair = blockIdx.x; pair < npair; pair += gridDim.x) {
+        __syncthreads();                                     // the previous pair's readers are done
+        em_stage_store<false>(p, tid, vx, vg, xs, nullptr);
+        __syncthreads();
+        if (pair + gridDim.x < npair) em_stage_load<false>(p, pair + gridDim.x, tid, vx, vg);      // in flight under this pair's MFMAs
+        for (int tt = wave; tt < EM_PAIR * tps; tt += 4) {
+            const int smp = tt / tps, tl = tt - smp * tps;
+            const int64_t b = pair * EM_PAIR + smp;
+            if (b >= B) continue;                            // (wave-uniform)
+            const uint16_t* xp = xs + smp * (EM_MAXC * EM_MAXE_ROWS) + tl * 16 + li;
+            em_s4 bx;                                        // X^T as B: lane (row li, k-group kg) holds channels 4 kg .. 4 kg + 3
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const int c = 4 * kg + r; bx[r] = c < Cin ? (short)xp[c * E] : (short)0; }
+            f32x4 y = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                f32x4 h = EM_MMA(a1h[t], bx, ((f32x4){0.f, 0.f, 0.f, 0.f}));
+                h = EM_MMA(a1l[t], bx, h);                    // h[r] = hidden unit 16 t + 4 kg + r of row li
+                float hv[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) hv[r] = fmaxf(h[r] + bias1[t][r], 0.f);
+                em_s4 hh, hl;
+                em_split4(hv, hh, hl);
+                y = EM_MMA(a2h[t], hh, y);
+                y = EM_MMA(a2h[t], hl, y);
+                y = EM_MMA(a2l[t], hh, y);
+            }
+            if (kg == 0) {                                   // y[r] = output q = r of row li (k-group 0)
+                uint16_t o[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { const __bf16 hq = (__bf16)(y[q] + bias2[q]); o[q] = __builtin_bit_cast(uint16_t, hq); }
+                uint16_t* yr = p.y + (b * E + tl * 16 + li) * net;
+                if (net == 4) *reinterpret_cast<uint2*>(yr) = make_uint2(o[0] | ((unsigned)o[1] << 16), o[2] | ((unsigned)o[3] << 16));
+                else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) if (q < net) yr[q] = o[q];
+                }
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void edge_mlp_bwd_mfma_kernel(const EmParams p) {
+    __shared__ __attribute__((aligned(16))) uint16_t xs[EM_PAIR * EM_MAXC * EM_MAXE_ROWS];
+    __shared__ __attribute__((aligned(16))) uint16_t gs[EM_PAIR * EM_MAXE * EM_MAXE_ROWS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, kg = lane >> 4;
+    const int Cin = p.Cin, net = p.net, E = p.E;
+    // resident operands: W1^T as B (k = channel, j = hidden li), W2 as B (k = q, j = hidden li)
+    em_s4 b1h[4], b1l[4], b2h[4], b2l[4];
+    float bias1[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        float w1[4], w2[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int c = 4 * kg + r;
+            w1[r] = c < Cin ? p.W1[(16 * t + li) * Cin + c] : 0.f;
+            w2[r] = c < net ? p.W2[c * EM_HID + 16 * t + li] : 0.f;
+        }
+        em_split4(w1, b1h[t], b1l[t]);
+        em_split4(w2, b2h[t], b2l[t]);
+        bias1[t] = p.b1[16 * t + li];
+    }
+    f32x4 dW1[4], dW2[4];
+    float db1[4], db2 = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { dW1[t] = (f32x4){0.f, 0.f, 0.f, 0.f}; dW2[t] = (f32x4){0.f, 0.f, 0.f, 0.f}; db1[t] = 0.f; }
+    const int64_t B = p.R / E, npair = (B + EM_PAIR - 1) / EM_PAIR;
+    const int tps = E / 16;
+    uint4 vx[EM_MAXCHUNK], vg[EM_MAXCHUNK];
+    if ((int64_t)blockIdx.x < npair) em_stage_load<true>(p, blockIdx.x, tid, vx, vg);
+    for (int64_t pair = blockIdx.x; pair < npair; pair += gridDim.x) {
+        __syncthreads();
+        em_stage_store<true>(p, tid, vx, vg, xs, gs);
+        __syncthreads();
+        if (pair + gridDim.x < npair) em_stage_load<true>(p, pair + gridDim.x, tid, vx, vg);
+        for (int tt = wave; tt < EM_PAIR * tps; tt += 4) {
+            const int smp = tt / tps, tl = tt - smp * tps;
+            if (pair * EM_PAIR + smp >= B) continue;
+            const uint16_t* xp = xs + smp * (EM_MAXC * EM_MAXE_ROWS) + tl * 16;
+            const uint16_t* gp = gs + smp * (EM_MAXE * EM_MAXE_ROWS) + tl * 16;
+            em_s4 ax, ay, bxr, ayt;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {                   // this lane's row li: channels 4 kg .. (A of H = X W1^T), net gradients (A of dH = dY W2)
+                const int c = 4 * kg + r;
+                ax[r] = c < Cin ? (short)xp[c * E + li] : (short)0;
+                ay[r] = c < net ? (short)gp[c * E + li] : (short)0;
+            }
+            {   // rows 4 kg .. 4 kg + 3 of the tile: channel li of x (B of dW1^T = dH^T X), net gradient li (A of dW2 = dY^T H)
+                const uint2 vxr = li < Cin ? *reinterpret_cast<const uint2*>(xp + li * E + 4 * kg) : make_uint2(0, 0);
+                const uint2 vgr = li < net ? *reinterpret_cast<const uint2*>(gp + li * E + 4 * kg) : make_uint2(0, 0);
+                bxr = __builtin_bit_cast(em_s4, vxr);
+                ayt = __builtin_bit_cast(em_s4, vgr);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) db2 += __uint_as_float((unsigned)(uint16_t)ayt[r] << 16);      // (lanes li < net: q = li, rows of k-group kg)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                f32x4 h = EM_MMA(ax, b1h[t], ((f32x4){0.f, 0.f, 0.f, 0.f}));
+                h = EM_MMA(ax, b1l[t], h);                  // h[r] = hidden unit 16 t + li of row 4 kg + r
+                f32x4 g = EM_MMA(ay, b2h[t], ((f32x4){0.f, 0.f, 0.f, 0.f}));
+                g = EM_MMA(ay, b2l[t], g);                  // dH before the ReLU mask, same layout
+                float hv[4], gv[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float pre = h[r] + bias1[t];
+                    hv[r] = fmaxf(pre, 0.f);
+                    gv[r] = pre > 0.f ? g[r] : 0.f;
+                    db1[t] += gv[r];
+                }
+                em_s4 gh, gl, hh, hl;
+                em_split4(gv, gh, gl);
+                em_split4(hv, hh, hl);
+                dW1[t] = EM_MMA(gh, bxr, dW1[t]);           // D[i = hidden 16 t + 4 kg + r][j = channel li]
+                dW1[t] = EM_MMA(gl, bxr, dW1[t]);
+                dW2[t] = EM_MMA(ayt, hh, dW2[t]);           // D[i = q 4 kg + r][j = hidden 16 t + li]
+                dW2[t] = EM_MMA(ayt, hl, dW2[t]);
+            }
+        }
+    }
+    // this wave's sums -> its row of the fold (the staging buffer is free); the four waves in a fixed order -> the workgroup's slab
+    __syncthreads();
+    float* fold = reinterpret_cast<float*>(xs);
+    float* mine = fold + wave * EM_SLAB;
+    for (int f = lane; f < EM_SLAB; f += 64) mine[f] = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        float s1 = db1[t];
+        s1 += __shfl_xor(s1, 16);
+        s1 += __shfl_xor(s1, 32);
+        if (kg == 0) mine[EM_HID * EM_MAXC + 16 * t + li] = s1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (li < EM_MAXC) mine[(16 * t + 4 * kg + r) * EM_MAXC + li] = dW1[t][r];
+            if (kg == 0) mine[EM_HID * EM_MAXC + EM_HID + r * EM_HID + 16 * t + li] = dW2[t][r];
+        }
+    }
+    {
+        float s2 = db2;
+        s2 += __shfl_xor(s2, 16);
+        s2 += __shfl_xor(s2, 32);
+        if (kg == 0 && li < EM_MAXE) mine[EM_HID * EM_MAXC + EM_HID + EM_MAXE * EM_HID + li] = s2;
+    }
+    __syncthreads();
+    float* slab = p.ws + (int64_t)blockIdx.x * EM_SLAB;
+    for (int f = tid; f < EM_SLAB; f += 256) slab[f] = (fold[f] + fold[EM_SLAB + f]) + (fold[2 * EM_SLAB + f] + fold[3 * EM_SLAB + f]);
+}
+
+// the layouts the MFMA kernels stage: plane-major sample blocks, 16-byte aligned, whole 16-row tiles per sample
+static bool em_mfma_ok(const EmParams& p, bool bwd) {
+    static const bool valu = getenv("FGNN_EDGE_MLP_VALU") != nullptr;       // (A/B switch: the round 1-4 VALU kernels)
+    if (valu || p.E % 16 || p.E > EM_MAXE_ROWS || p.R >= (int64_t)0x7fffffff) return false;
+    if (p.x_sr != 1 || p.x_sc != p.E || p.x_sb % 8 || ((uintptr_t)p.x & 15) || p.x_sb < (int64_t)p.Cin * p.E) return false;
+    if (EM_PAIR * p.Cin * p.E / 8 > 256 * EM_MAXCHUNK) return false;
+    if (bwd && (p.gy_sr != 1 || p.gy_se != p.E || p.gy_sb % 8 || ((uintptr_t)p.gy & 15) || p.gy_sb < (int64_t)p.net * p.E)) return false;
+    return true;
+}
+
 // out += sum over slabs, slab element i -> (dW1 | db1 | dW2 | db2) with the padded slab strides undone
 __global__ __launch_bounds__(256) void edge_mlp_reduce_kernel(const float* __restrict__ ws, int nslab, int Cin, int net,
                                                               float* dW1, float* db1, float* dW2, float* db2) {
@@ -281,11 +538,18 @@ extern "C" int fgnn_edge_mlp_forward(const void* x, int64_t x_sb, int64_t x_sc, 
     EmParams p = {};
     p.x = (const uint16_t*)x; p.y = (uint16_t*)y; p.W1 = W1; p.b1 = b1; p.W2 = W2; p.b2 = b2;
     p.R = B * E; p.E = E; p.Cin = Cin; p.net = net; p.x_sb = x_sb; p.x_sc = x_sc; p.x_sr = x_sr;
-    int64_t g = (p.R + EM_THREADS * EM_RPT - 1) / (EM_THREADS * EM_RPT);
-    if (g > 4096) g = 4096;
-    fgnn_note_kernel("edge_mlp_fwd_kernel");
-    if (Cin == 7) hipLaunchKernelGGL(edge_mlp_fwd_kernel<7>, dim3((unsigned)g), dim3(EM_THREADS), 0, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL(edge_mlp_fwd_kernel<8>, dim3((unsigned)g), dim3(EM_THREADS), 0, (hipStream_t)stream, p);
+    if (em_mfma_ok(p, false)) {
+        int64_t g = (B + EM_PAIR - 1) / EM_PAIR;
+        if (g > 1024) g = 1024;
+        fgnn_note_kernel("edge_mlp_fwd_mfma_kernel");
+        hipLaunchKernelGGL(edge_mlp_fwd_mfma_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, p);
+    } else {
+        int64_t g = (p.R + EM_THREADS * EM_RPT - 1) / (EM_THREADS * EM_RPT);
+        if (g > 4096) g = 4096;
+        fgnn_note_kernel("edge_mlp_fwd_kernel");
+        if (Cin == 7) hipLaunchKernelGGL(edge_mlp_fwd_kernel<7>, dim3((unsigned)g), dim3(EM_THREADS), 0, (hipStream_t)stream, p);
+        else hipLaunchKernelGGL(edge_mlp_fwd_kernel<8>, dim3((unsigned)g), dim3(EM_THREADS), 0, (hipStream_t)stream, p);
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "edge_mlp_forward launch: %s", hipGetErrorString(e));
     return FGNN_OK;
@@ -322,15 +586,20 @@ extern "C" int fgnn_edge_mlp_backward(const void* x, int64_t x_sb, int64_t x_sc,
     p.rows_per_wg = (int)((p.R + grid - 1) / grid);
     const size_t lds = (size_t)p.rows_per_wg * 24;
     hipStream_t st = (hipStream_t)stream;
-    fgnn_note_kernel("edge_mlp_bwd_kernel");
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)edge_mlp_bwd_kernel<7>, hipFuncAttributeMaxDynamicSharedMemorySize, EM_LDS_ROWS * 24);
-        (void)hipFuncSetAttribute((const void*)edge_mlp_bwd_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, EM_LDS_ROWS * 24);
-        attr_done = true;
+    if (em_mfma_ok(p, true)) {
+        fgnn_note_kernel("edge_mlp_bwd_mfma_kernel");
+        hipLaunchKernelGGL(edge_mlp_bwd_mfma_kernel, dim3(grid), dim3(256), 0, st, p);
+    } else {
+        fgnn_note_kernel("edge_mlp_bwd_kernel");
+        static bool attr_done = false;
+        if (!attr_done) {
+            (void)hipFuncSetAttribute((const void*)edge_mlp_bwd_kernel<7>, hipFuncAttributeMaxDynamicSharedMemorySize, EM_LDS_ROWS * 24);
+            (void)hipFuncSetAttribute((const void*)edge_mlp_bwd_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, EM_LDS_ROWS * 24);
+            attr_done = true;
+        }
+        if (Cin == 7) hipLaunchKernelGGL(edge_mlp_bwd_kernel<7>, dim3(grid), dim3(EM_BWD_THREADS), lds, st, p);
+        else hipLaunchKernelGGL(edge_mlp_bwd_kernel<8>, dim3(grid), dim3(EM_BWD_THREADS), lds, st, p);
     }
-    if (Cin == 7) hipLaunchKernelGGL(edge_mlp_bwd_kernel<7>, dim3(grid), dim3(EM_BWD_THREADS), lds, st, p);
-    else hipLaunchKernelGGL(edge_mlp_bwd_kernel<8>, dim3(grid), dim3(EM_BWD_THREADS), lds, st, p);
     hipLaunchKernelGGL(edge_mlp_reduce_kernel, dim3((EM_SLAB + 15) / 16), dim3(256), 0, st, p.ws, grid, Cin, net, gW1, gb1,
                        gW2, gb2);
     hipError_t e = hipGetLastError();

@@ -25,7 +25,7 @@ class _EdgeMLPFn(torch.autograd.Function):
         x_sr = x.stride(3) if k > 1 else x.stride(2)
         y = torch.empty((B, M, k, net), device=x.device, dtype=x.dtype)
         L = _hip.lib()
-        ops.timed('edge_mlp_fwd_kernel', 2 * B * E * (cin + net),
+        ops.timed('edge_mlp_fwd_kernel (MFMA where the layout allows)', 2 * B * E * (cin + net),
                   lambda: _hip.check(L.fgnn_edge_mlp_forward(
                       _hip._ptr(x), x.stride(0), x.stride(1), x_sr, _hip._ptr(w1), _hip._ptr(b1), _hip._ptr(w2),
                       _hip._ptr(b2), _hip._ptr(y), B, E, cin, net, _hip.stream_ptr())),
@@ -55,7 +55,7 @@ class _EdgeMLPFn(torch.autograd.Function):
                 for s, shp in zip(sinks, shapes)]
         L = _hip.lib()
         ws = ops._workspace(x.device, int(L.fgnn_edge_mlp_workspace_bytes(B, E)))
-        ops.timed('edge_mlp_bwd_kernel', 2 * B * E * (cin + net),
+        ops.timed('edge_mlp_bwd_kernel (MFMA where the layout allows)', 2 * B * E * (cin + net),
                   lambda: _hip.check(L.fgnn_edge_mlp_backward(
                       _hip._ptr(x), x.stride(0), x.stride(1), ctx.x_sr, _hip._ptr(gy), gy.stride(0), gy.stride(1),
                       gy_sr, _hip._ptr(w1), _hip._ptr(b1), _hip._ptr(w2), B, E, cin, net, _hip._ptr(outs[0]),

@@ -166,7 +166,7 @@ _V2V_MAIN = _parse_layers(os.environ.get('FGNN_V2V_MAIN', ''))      # tuning kno
 # stream.  Measured on one box (18.25 ms with none): layers 0,1,7: 18.27; 2-6: 18.47; 3-5: 18.54; all: 18.48 — the map belongs on the side stream.
 
 
-_F2F_SIDE = os.environ.get('FGNN_F2F_SIDE', '0') not in ('', '0')      # tuning knob: the parity factors' f2f map on the side stream
+_F2F_SIDE = os.environ.get('FGNN_F2F_SIDE', '1') not in ('', '0')      # tuning knob: the parity factors' f2f map on the side stream
 
 
 class FactorNN(torch.nn.Module):
