@@ -600,11 +600,23 @@ def main():
     # torch.distributed: ProcessGroupNCCL's watchdog thread polls the work's completion event, which was recorded on a capturing
     # stream — hipErrorCapturedEvent, the process aborts (seen in ~1 of 6 runs of a one-rank group on the GPU box).  So with N > 1
     # the graph ends with the backward and the collective + Adam are two eager launches behind every replay.
-    whole_in_graph = train and not args.no_graph and world == 1
+    # Round 5: with N > 1 the all-reduce goes through RCCL's C API on the capture stream (dp.DirectAllReduce: a communicator of its
+    # own, no torch.distributed work object for the watchdog to poll), so the WHOLE step — forward, backward, collective, Adam — is one
+    # graph at every N.  FGNN_NO_RCCL_DIRECT=1 (or a non-RCCL backend) keeps the round-4 form: graph = forward + backward, then two
+    # eager launches.
+    direct = train and world > 1 and dist.get_backend() == 'nccl' and os.environ.get('FGNN_NO_RCCL_DIRECT') is None
+    whole_in_graph = train and not args.no_graph and (world == 1 or direct)
     if train:
         # parameters and gradients live in two flat f32 buffers: one all-reduce, and Adam (the reference's
         # lr / weight_decay, train_ldpc.py) is eight elementwise kernels instead of a 330-tensor sweep
         bucket = FlatGradBucket(model.parameters(), flatten_params=True)
+        if direct:
+            try:
+                bucket.use_direct_all_reduce()
+            except Exception as e:      # noqa: BLE001 — report, keep the eager collective
+                print('bench.py: RCCL C-API communicator failed (%s: %s); the all-reduce stays outside the graph' % (type(e).__name__, e), file=sys.stderr)
+                direct = False
+                whole_in_graph = train and not args.no_graph and world == 1
         opt = FlatAdam(bucket, lr=1e-4, weight_decay=1e-8, capturable=whole_in_graph)
 
     if not train:
@@ -641,10 +653,18 @@ def main():
             # inference: the model is frozen — its folded BatchNorm affines and bf16 weight copies are built once (by the warm-up
             # runs), not re-derived inside every replay; training re-derives them every step (the parameters move)
             graphed = StepGraph(whole if whole_in_graph else compute, static_params=not train)
-        except Exception as e:           # noqa: BLE001 — report and fall back to eager launches
-            print('bench.py: hipGraph capture failed (%s: %s); running eagerly' % (type(e).__name__, e),
-                  file=sys.stderr)
+        except Exception as e:           # noqa: BLE001 — report and fall back
             graphed = None
+            if whole_in_graph and world > 1:      # the collective would not capture: the round-4 form (graph = forward + backward)
+                print('bench.py: capturing the step WITH the RCCL all-reduce failed (%s: %s); capturing forward + backward only'
+                      % (type(e).__name__, e), file=sys.stderr)
+                whole_in_graph = False
+                try:
+                    graphed = StepGraph(compute, static_params=not train)
+                except Exception as e2:  # noqa: BLE001
+                    print('bench.py: hipGraph capture failed (%s: %s); running eagerly' % (type(e2).__name__, e2), file=sys.stderr)
+            else:
+                print('bench.py: hipGraph capture failed (%s: %s); running eagerly' % (type(e).__name__, e), file=sys.stderr)
 
     _trace('graph captured: %s' % (graphed is not None))
 
@@ -803,7 +823,7 @@ def main():
                        'peak_hbm_GB': round(torch.cuda.max_memory_allocated(dev) / 1e9, 2),
                        'mode': args.mode, 'hip_graph': graphed is not None,
                        'parameters': 'updated every step' if train else 'frozen: BatchNorm folding and bf16 weight copies made once, outside the replayed graph',
-                       'graph_scope': (None if graphed is None else 'forward + backward + Adam' if whole_in_graph else
+                       'graph_scope': (None if graphed is None else ('forward + backward + RCCL all-reduce (C API) + Adam' if world > 1 else 'forward + backward + Adam') if whole_in_graph else
                                        'forward + backward (all-reduce and Adam eager behind each replay)' if train else 'forward'),
                        'distributed': dist_info},
             'roofline': roofline,

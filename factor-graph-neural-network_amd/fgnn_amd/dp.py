@@ -38,6 +38,71 @@ def flatten_parameters(params):
     return flat
 
 
+class DirectAllReduce:
+    """The flat bucket's all-reduce through RCCL's C API (``ncclAllReduce`` on torch's CURRENT stream, ctypes on librccl.so), with a
+    communicator of its own — no ``torch.distributed`` work object, no watchdog thread polling an event: the form that can be
+    RECORDED INTO the step's hipGraph with the optimizer behind it.  (Captured through ``torch.distributed`` the collective works
+    most of the time, but ProcessGroupNCCL's watchdog polls the work's completion event, which was recorded on a capturing
+    stream: hipErrorCapturedEvent, process abort, ~1 run in 6 — profiles/r04/README.md.)  The 128-byte unique id travels from rank 0
+    through the existing process group (any backend: one ``broadcast_object_list``), then every rank calls ``ncclCommInitRank``
+    on its current device.  xGMI note: one 5.5 MB in-place sum per step; nothing to bucket."""
+
+    _NCCL_FLOAT32, _NCCL_SUM = 7, 0
+
+    def __init__(self, group=None, library=None):
+        import ctypes
+        import os
+        if not (dist.is_available() and dist.is_initialized()):
+            raise RuntimeError('DirectAllReduce needs an initialised torch.distributed group to exchange the communicator id')
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        path = library or os.environ.get('FGNN_RCCL_LIB')
+        if path is None:
+            # the RCCL torch itself links (same ROCm runtime objects), else the ROCm installation's
+            cand = [os.path.join(os.path.dirname(torch.__file__), 'lib', 'librccl.so'), '/opt/rocm/lib/librccl.so', 'librccl.so']
+            path = next((c for c in cand if c == 'librccl.so' or os.path.exists(c)), 'librccl.so')
+        self._lib = L = ctypes.CDLL(path)
+
+        class UniqueId(ctypes.Structure):
+            _fields_ = [('internal', ctypes.c_char * 128)]
+        L.ncclGetUniqueId.restype = ctypes.c_int
+        L.ncclGetUniqueId.argtypes = [ctypes.POINTER(UniqueId)]
+        L.ncclCommInitRank.restype = ctypes.c_int
+        L.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, UniqueId, ctypes.c_int]
+        L.ncclAllReduce.restype = ctypes.c_int
+        L.ncclAllReduce.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
+                                    ctypes.c_void_p]
+        L.ncclCommDestroy.restype = ctypes.c_int
+        L.ncclCommDestroy.argtypes = [ctypes.c_void_p]
+        L.ncclGetErrorString.restype = ctypes.c_char_p
+        L.ncclGetErrorString.argtypes = [ctypes.c_int]
+        uid = UniqueId()
+        if self.rank == 0:
+            self._check(L.ncclGetUniqueId(ctypes.byref(uid)), 'ncclGetUniqueId')
+        # (a ctypes c_char array read as .value stops at the first NUL: take the raw 128 bytes)
+        box = [ctypes.string_at(ctypes.addressof(uid), 128) if self.rank == 0 else None]
+        dist.broadcast_object_list(box, src=0, group=group)
+        ctypes.memmove(ctypes.addressof(uid), box[0], 128)
+        self._comm = ctypes.c_void_p()
+        self._check(L.ncclCommInitRank(ctypes.byref(self._comm), self.world, uid, self.rank), 'ncclCommInitRank')
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise RuntimeError('%s failed: %s' % (what, self._lib.ncclGetErrorString(rc).decode()))
+
+    def all_reduce_sum_(self, flat):
+        """In-place sum of the contiguous f32 tensor ``flat`` over the ranks, enqueued on torch's current stream."""
+        if not (flat.is_cuda and flat.dtype == torch.float32 and flat.is_contiguous()):
+            raise ValueError('DirectAllReduce takes a contiguous float32 tensor on the device')
+        st = torch.cuda.current_stream(flat.device).cuda_stream
+        self._check(self._lib.ncclAllReduce(flat.data_ptr(), flat.data_ptr(), flat.numel(), self._NCCL_FLOAT32, self._NCCL_SUM,
+                                            self._comm, st), 'ncclAllReduce')
+
+    def close(self):
+        if getattr(self, '_comm', None):
+            self._lib.ncclCommDestroy(self._comm)
+            self._comm = None
+
+
 class FlatGradBucket:
     """Owns one contiguous gradient buffer; ``param.grad`` are views into it."""
 
@@ -86,10 +151,19 @@ class FlatGradBucket:
     def world(self):
         return dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
 
+    def use_direct_all_reduce(self, library=None):
+        """Route ``all_reduce_sum`` through RCCL's C API (``DirectAllReduce``): the collective can then be captured into the step's
+        hipGraph.  Collective: every rank of the group calls this once, outside any capture."""
+        self.direct = DirectAllReduce(self.group, library)
+        return self.direct
+
     def all_reduce_sum(self):
         """Sum over ranks, nothing else: the division by the world size rides in ``FlatAdam.step(grad_scale=1/world)``."""
         if self.world > 1 or (self.reduce_single_rank and dist.is_initialized()):
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+            if getattr(self, 'direct', None) is not None:
+                self.direct.all_reduce_sum_(self.flat)
+            else:
+                dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
 
     def all_reduce_mean(self, async_op=False):
         """Sum over ranks then divide by world size (mean gradient of the global batch)."""

@@ -35,8 +35,9 @@ def _setup_paths():
             sys.path.insert(0, p)
 
 
-def _train(rank, world, graph, reduce_single_rank=False):
+def _train(rank, world, graph, reduce_single_rank=False, direct=False, steps=None):
     """3 steps on this rank's shard; returns the flat parameter buffer (a CPU tensor)."""
+    STEPS = steps or globals()['STEPS']
     _setup_paths()
     import contextlib
     import io
@@ -61,6 +62,8 @@ def _train(rank, world, graph, reduce_single_rank=False):
     inputs = tuple(t[lo:hi] for t in data[:6])
     label = data[6][lo:hi, :48].float().contiguous()
     bucket = FlatGradBucket(model.parameters(), flatten_params=True, reduce_single_rank=reduce_single_rank)
+    if direct:
+        bucket.use_direct_all_reduce()               # RCCL's C API on the current stream: recordable into the step graph
     full = graph == 'full'                          # the collective and the optimizer recorded into the graph as well
     opt = FlatAdam(bucket, lr=1e-3, capturable=full or graph == 'capturable')
     amp = torch.autocast('cuda', dtype=torch.bfloat16)
@@ -218,4 +221,27 @@ def test_rccl_all_reduce_then_device_state_adam_behind_graph_replays(tmp_path, d
     mp.spawn(_worker_rccl_capturable, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True)
     a = torch.load(os.path.join(str(tmp_path), 'rccl_cap_rank0.pt'))
     ref_param, ref_grad, ref_p1 = _train(0, 1, 'sched')
+    assert torch.equal(a['grad'], ref_grad) and torch.equal(a['param1'], ref_p1) and torch.equal(a['param'], ref_param)
+
+
+def _worker_rccl_in_graph(rank, world, port, out):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    torch.cuda.set_device(0)
+    dist.init_process_group('gloo', rank=rank, world_size=world)      # (only carries the communicator id: the collective itself is RCCL's)
+    flat, grad, p1 = _train(rank, world, 'full', reduce_single_rank=True, direct=True, steps=200)
+    torch.save({'param': flat, 'grad': grad, 'param1': p1}, os.path.join(out, 'rccl_graph_rank%d.pt' % rank))
+    dist.destroy_process_group()
+
+
+def test_rccl_all_reduce_inside_the_step_graph(tmp_path, dev):
+    """The N > 1 step as ONE hipGraph: forward, backward, the flat gradient's all-reduce and the device-state Adam — with the
+    collective issued through RCCL's C API on the capture stream (dp.DirectAllReduce: a communicator of its own, no
+    torch.distributed work object for a watchdog to poll).  A one-rank communicator (what a one-GPU box can form), 200 replays
+    without an abort, the learning rate changed between replays; the reduction over one rank is the identity, so the end state
+    must be EXACTLY the one of the same 200 steps without any process group."""
+    mp.spawn(_worker_rccl_in_graph, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True)
+    a = torch.load(os.path.join(str(tmp_path), 'rccl_graph_rank0.pt'))
+    ref_param, ref_grad, ref_p1 = _train(0, 1, 'full', steps=200)
     assert torch.equal(a['grad'], ref_grad) and torch.equal(a['param1'], ref_p1) and torch.equal(a['param'], ref_param)
