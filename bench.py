@@ -729,18 +729,28 @@ def main():
         if kernels:
             try:
                 pmc = {}
-                for rnd in ('r01', 'r02', 'r03', 'r04'):     # later rounds' passes override (new kernel families; one pass PER INSTANCE)
+                for rnd in ('r01', 'r02', 'r03', 'r04', 'r05'):     # later rounds' passes override (new kernel families; one pass PER INSTANCE)
                     pth = os.path.join(ROOT, 'profiles', rnd, 'pmc_traffic.json')
                     if os.path.exists(pth):
                         pmc.update(json.load(open(pth))['kernels'])
             except (OSError, ValueError, KeyError):
                 pmc = {}
-            in_graph = {}                                 # kernel symbol -> average ns in the committed trace of the replayed graph
+            # Figures of an EARLIER run — the committed rocprofv3 kernel trace of the replayed graph — ride along under their own key
+            # (`from_committed_profile`: file, and the library kernels of the step that `kernels` below cannot see because they are not
+            # launched through ops.timed); everything else in this line was measured by THIS run.
+            in_graph, in_graph_file, library = {}, None, []
             try:
                 import csv
-                pth = os.path.join(ROOT, 'profiles', 'r04', 'final_bf16_%s_kernel_stats_top40.csv' % ('train' if train else 'fwd'))
-                for row in csv.DictReader(open(pth)):
-                    in_graph[row['Name']] = float(row['AverageNs'])
+                for rnd in ('r05', 'r04'):
+                    pth = os.path.join(ROOT, 'profiles', rnd, 'final_bf16_%s_kernel_stats_top40.csv' % ('train' if train else 'fwd'))
+                    if os.path.exists(pth):
+                        in_graph_file = os.path.relpath(pth, ROOT)
+                        for row in csv.DictReader(open(pth)):
+                            in_graph[row['Name']] = float(row['AverageNs'])
+                            if row['Name'].startswith(('Cijk_', 'void at::native', 'at::native', 'void rocblas', 'rocblas')):
+                                library.append({'kernel': row['Name'][:60], 'calls_in_trace': int(row['Calls']),
+                                                'avg_us': round(float(row['AverageNs']) / 1e3, 2), 'pct_of_trace': float(row['Percentage'])})
+                        break
             except (OSError, ValueError, KeyError):
                 pass
 
@@ -755,14 +765,17 @@ def main():
                 d = {'kernel': sym, 'launches_per_step': n, 'bound': 'hbm' if bf16 else 'mfma',
                      'algorithmic_bytes_per_launch': int(nb), 'algorithmic_flops_per_launch': int(nf),
                      'avg_launch_us_isolated': round(iso_ms * 1e3, 2), 'avg_launch_us_in_step': round(step_ms * 1e3, 2),
-                     'avg_launch_us_in_graph_rocprof': None,
                      'achieved': round(gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(gbs / HBM_PEAK_GBS, 4),
                      'frac_isolated': round(nb / (iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                      'traffic': pmc.get(sym, {}).get('traffic_bytes_per_launch'), 'mfma_busy': pmc.get(sym, {}).get('mfma_busy')}
-                for name, ns in in_graph.items():
-                    if sym.split(' x2')[0].replace(' ', '') in name.replace(' ', ''):
-                        d['avg_launch_us_in_graph_rocprof'] = round(ns / 1e3 * (2 if sym.endswith(' x2') else 1), 2)
-                        d['frac_in_graph_rocprof'] = round(nb / (d['avg_launch_us_in_graph_rocprof'] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
+                # (two-launch calls — ' x2' — and launches with addends have no one-to-one row in a per-symbol average: no figure)
+                if in_graph_file and not sym.endswith(' x2'):
+                    for name, ns in in_graph.items():
+                        if sym.replace(' ', '') in name.replace(' ', ''):
+                            us = round(ns / 1e3, 2)
+                            d['from_committed_profile'] = {'file': in_graph_file, 'avg_launch_us_in_graph_rocprof': us,
+                                                           'frac_in_graph_rocprof': round(nb / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                                                           'note': 'average over ALL launches of the symbol in an earlier, committed trace of the replayed graph'}
                 if not bf16:                              # the f32-MFMA kernels (exact v_mfma_f32_16x16x4_f32) sit above the f32 ridge: matrix-core-bound
                     tfs = nf / (step_ms * 1e-3) / 1e12
                     d.update({'achieved': round(tfs, 2), 'peak': F32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
@@ -788,9 +801,9 @@ def main():
             roofline.update({'avg_launch_us': dom['avg_launch_us_in_step'], 'forward': fwd, 'backward': bwd,
                              'operator_fwd_frac': fwd_frac, 'operator_bwd_frac': bwd_frac,
                              'durations': 'frac / achieved use avg_launch_us_in_step (events around each launch in an eager step on the '
-                                          'two streams of the timed graph); _isolated = the same on one stream; _in_graph_rocprof = '
-                                          'the committed rocprofv3 kernel trace of the replayed graph (profiles/r04: the average over ALL launches of the symbol, the '
-                                          'accumulating second launches of the 64->128 calls included), frac_in_graph_rocprof = bytes / that'})
+                                          'two streams of the timed graph); _isolated = the same on one stream; from_committed_profile = '
+                                          'the rocprofv3 kernel trace of the replayed graph committed under profiles/ (an earlier run)',
+                             'library_kernels_from_committed_profile': {'file': in_graph_file, 'kernels': library}})
             for k, v in kernels.items():
                 v['ms2'] = (kernels2.get(k) or v)['ms']
     fence()

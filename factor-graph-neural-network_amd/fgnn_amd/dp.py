@@ -348,8 +348,12 @@ def bind_rank_to_local_cores(device_index, local_rank, local_world, set_threads=
         return dict(loc, bound_cpus=None, note='no sched_setaffinity on this platform')
     allowed = sorted(os.sched_getaffinity(0))
     slot, slots = local_rank, max(1, local_world)
-    if loc['numa_node'] >= 0 and loc['local_cpus']:
-        # ranks on the same node: those local ranks whose device reports this node (device i <-> local rank i)
+    # ranks on the same node: those local ranks whose device reports this node.  That needs the device of every local rank: known
+    # only under the launchers' convention "local rank i drives device i" — with a device override (FGNN_BENCH_DEVICE) or one visible
+    # device per rank the identity does not hold, and the node's cores are then split evenly by local rank instead
+    identity = (device_index == local_rank and torch.cuda.device_count() >= local_world
+                and os.environ.get('FGNN_BENCH_DEVICE') is None)
+    if identity and loc['numa_node'] >= 0 and loc['local_cpus']:
         same = []
         for r in range(min(local_world, torch.cuda.device_count())):
             try:
