@@ -602,6 +602,11 @@ int fgnn_mpconv_backward_sg(const fgnn_mpconv_desc* d, const void* x, const int6
     // rounding of those two) and its dW / dbias land in the upper halves of gfilters' columns / gbias.
     static const bool no_split = getenv("FGNN_SG_NOSPLIT") != nullptr;
     const bool split = d->nin == 64 && d->nou == 128 && !no_split;
+    if (d->nin == 128 && d->nou == 64) {              // third generation, two launches over the input-channel halves (mpconv_bwd_ws.hip); 0 = not its shape
+        const int r = fgnn_mpconv_backward_ws(d, x, nn_idx, etype, filters, gz, argmax, gx, getype, gfilters, gbias, workspace,
+                                              workspace_bytes, stream);
+        if (r != 0) return r;
+    }
     if (d->nin != 64 || (d->nou != 64 && !split)) BS_REJECT(2);
     if (d->k != 3 && d->k != 6) BS_REJECT(3);
     if (d->idx_sb != 0 && d->B > 1) BS_REJECT(4);

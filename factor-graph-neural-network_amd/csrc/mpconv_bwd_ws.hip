@@ -57,7 +57,9 @@ struct BwParams {
     uint16_t* get;
     float* ws;               // per-workgroup slabs [grid][64*256 + 64]
     int B, N, M;
-    int y_ld, w_ld, accum;       // accum: gx and getype are ADDED to (second launch of a 64 -> 128 call, over the upper output channels)
+    int y_ld, w_ld, x_ld;        // row strides (elements): gz / argmax, W, and x / gx in MEMORY (64, or 128 when the call's 128 input channels
+                                 // run as two launches over their halves)
+    int accum;                   // bit 0: gx is ADDED to, bit 1: getype is ADDED to (the second launch of a two-launch call)
     long long x_sb, et_sb, y_sb;     // elements
     const int* tables;       // the transposed incidence, built ONCE per graph by mpconv_bwd_ws_tables_kernel, or NULL (the default): every
                              // workgroup builds its own — 17 400 of a launch's ~23 000 set-up cycles (profiles/r04), but NOT on its critical
@@ -211,7 +213,9 @@ __global__ __launch_bounds__(BW_THREADS) void mpconv_bwd_ws_tables_kernel(const 
 }
 
 // KC = destination degree (3 / 6), DEG = in-edge slots per source node the tables are sized for (6 / 3)
-template <int KC, int DEG>
+// XLD = row stride (elements) of x / gx in memory: 64, or 128 for one half of a 128-channel call (compile-time: as a runtime value
+// it cost 14 - 20 spilled registers at the 256-VGPR limit)
+template <int KC, int DEG, int XLD = 64>
 __global__ __launch_bounds__(BW_THREADS) void mpconv_bwd_ws_kernel(const BwParams p) {
     typedef BwLayout<KC> LY;
     constexpr int QS = LY::QS;                        // G rows per source node (slots >= DEG stay zero)
@@ -250,7 +254,7 @@ __global__ __launch_bounds__(BW_THREADS) void mpconv_bwd_ws_kernel(const BwParam
 #pragma unroll
     for (int u = 0; u < 3; ++u) {
         const int slot = 64 * (dwq + 4 * u) + lane, row = slot >> 3, pos = slot & 7;
-        dsrc[u] = (unsigned)(min(row, N - 1) * BW_XROW + ((pos ^ bw_swz_r(row)) << 4));
+        dsrc[u] = (unsigned)(min(row, N - 1) * (XLD * 2) + ((pos ^ bw_swz_r(row)) << 4));
     }
     constexpr int npieces = 12;                       // both x buffers hold 96 rows; rows >= N are copies of row N - 1
 
@@ -615,7 +619,7 @@ __global__ __launch_bounds__(BW_THREADS) void mpconv_bwd_ws_kernel(const BwParam
                 const int nvec = (8 * mk) >> 4;
                 if (tid < nvec) {
                     uint4 v = *reinterpret_cast<const uint4*>(bw_lds + OFF_GST + tid * 16);
-                    if (p.accum) {                             // second launch of a split call: add to what the first one stored
+                    if (p.accum & 2) {                         // second launch of a split call: add to what the first one stored
                         const uint4 o = *bw_at<uint4>(p.get + (int64_t)b * 4 * mk, (unsigned)tid * 16u);
                         v = make_uint4(bw_add2(v.x, o.x), bw_add2(v.y, o.y), bw_add2(v.z, o.z), bw_add2(v.w, o.w));
                     }
@@ -726,8 +730,8 @@ __global__ __launch_bounds__(BW_THREADS) void mpconv_bwd_ws_kernel(const BwParam
                         for (int g = 0; g < 4; ++g) {
                             float v0 = ae[4 * g] + ao[4 * g], v1 = ae[4 * g + 1] + ao[4 * g + 1], v2 = ae[4 * g + 2] + ao[4 * g + 2],
                                   v3 = ae[4 * g + 3] + ao[4 * g + 3];
-                            uint2* dst = bw_at<uint2>(gxb, (unsigned)(n * 64 + 32 * wave + 8 * g + 4 * lh) * 2u);
-                            if (p.accum) {
+                            uint2* dst = bw_at<uint2>(gxb, (unsigned)(n * XLD + 32 * wave + 8 * g + 4 * lh) * 2u);
+                            if (p.accum & 1) {
                                 const uint2 o = *dst;
                                 v0 += __uint_as_float(o.x << 16); v1 += __uint_as_float(o.x & 0xffff0000u);
                                 v2 += __uint_as_float(o.y << 16); v3 += __uint_as_float(o.y & 0xffff0000u);
@@ -836,7 +840,20 @@ int fgnn_mpconv_backward_ws(const fgnn_mpconv_desc* d, const void* x, const int6
     static const bool off = getenv("FGNN_NO_WS") != nullptr || getenv("FGNN_NO_WS_BWD") != nullptr;
     if (off) BW_REJECT(0);
     const bool split = d->nin == 64 && d->nou == 128;                    // 64 -> 128: two launches over the halves of the output channels
-    if (d->nin != 64 || (d->nou != 64 && !split)) BW_REJECT(1);
+    // 128 -> 64 (round 5): two launches over the halves of the INPUT channels.  Everything the kernel computes is linear in the
+    // input-channel block it is given — P = P_lo + P_hi, so detype = sum_o G P splits into two addends (the second launch ADDS to
+    // getype); dP depends on G and etype only; dx and dW are per input channel — so the 64-channel kernel runs twice on x / W / gx /
+    // gfilters offset by 64 channels / rows (x and gx rows stay 128 apart in memory: x_ld), dbias counted once.  Replaces the
+    // first-generation mpconv_bwd_b16_kernel<4,2> for these calls (245 us at 4096 codewords, profiles/r04).
+    static const bool no_ksplit = getenv("FGNN_NO_WS_KSPLIT") != nullptr;
+    const bool ksplit = d->nin == 128 && d->nou == 64 && !no_ksplit;
+    if (ksplit) {      // (the layout rules fgnn_mpconv_backward_sg checks for its callers)
+        if (d->dtype != FGNN_BF16 || d->ext != FGNN_EXT_NONE || d->agg != FGNN_AGG_MAX || d->net != 4 || (d->k != 3 && d->k != 6)) BW_REJECT(10);
+        if ((d->idx_sb != 0 && d->B > 1) || !(d->idx_sk == 1 && d->idx_sm == d->k) || !getype || !argmax || !gbias) BW_REJECT(11);
+        if (!(d->x_sc == 1 && d->x_sn == d->nin) || !(d->y_sc == 1 && (d->y_sm == d->nou || d->M == 1))) BW_REJECT(12);
+        if (!(d->et_se == 1 && d->et_sk == 4 && (d->et_sm == 4 * d->k || d->M == 1))) BW_REJECT(13);
+    }
+    if (!ksplit && (d->nin != 64 || (d->nou != 64 && !split))) BW_REJECT(1);
     const int KC = d->k, DEG = KC == 6 ? 3 : 6;
     const int indeg = d->reserved & 0xffff;
     if (indeg < 1 || indeg > DEG) BW_REJECT(2);
@@ -853,12 +870,13 @@ int fgnn_mpconv_backward_ws(const fgnn_mpconv_desc* d, const void* x, const int6
     p.gz = (const uint16_t*)gz; p.argmax = argmax; p.gx = (uint16_t*)gx; p.get = (uint16_t*)getype;
     p.ws = (float*)workspace;
     p.B = d->B; p.N = d->N; p.M = d->M;
-    p.y_ld = d->nou; p.w_ld = d->nou * 4; p.accum = 0;
+    p.y_ld = d->nou; p.w_ld = d->nou * 4; p.x_ld = d->nin; p.accum = 0;
     p.x_sb = d->x_sb; p.et_sb = d->et_sb; p.y_sb = d->y_sb;
     p.tables = (bw_pending_tables && bw_tables_count(d) > 0) ? (const int*)bw_pending_tables : nullptr;
     const int off_b = KC == 6 ? BwLayout<6>::BYTES : BwLayout<3>::BYTES;
     static_assert(BwLayout<6>::BYTES <= 160 * 1024 && BwLayout<3>::BYTES <= 160 * 1024, "LDS");
-    void* fn = KC == 6 ? (void*)mpconv_bwd_ws_kernel<6, 3> : (void*)mpconv_bwd_ws_kernel<3, 6>;
+    void* fn = ksplit ? (KC == 6 ? (void*)mpconv_bwd_ws_kernel<6, 3, 128> : (void*)mpconv_bwd_ws_kernel<3, 6, 128>)
+                      : (KC == 6 ? (void*)mpconv_bwd_ws_kernel<6, 3> : (void*)mpconv_bwd_ws_kernel<3, 6>);
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, off_b);
     if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "hipFuncSetAttribute(%d B LDS): %s", off_b, hipGetErrorString(e));
     int grid = 256;
@@ -866,7 +884,7 @@ int fgnn_mpconv_backward_ws(const fgnn_mpconv_desc* d, const void* x, const int6
     const int chunk = (d->B + grid - 1) / grid;
     grid = (d->B + chunk - 1) / chunk;
     hipStream_t st = (hipStream_t)stream;
-    fgnn_note_kernel(split ? "mpconv_bwd_ws_kernel<%d, %d> x2" : "mpconv_bwd_ws_kernel<%d, %d>", KC, DEG);
+    fgnn_note_kernel(split ? "mpconv_bwd_ws_kernel<%d, %d> x2" : (ksplit ? "mpconv_bwd_ws_kernel<%d, %d> k2" : "mpconv_bwd_ws_kernel<%d, %d>"), KC, DEG);
     p.prof = nullptr;
 #ifdef FGNN_ENABLE_PROF
     static long long* prof_buf = nullptr;
@@ -896,12 +914,18 @@ int fgnn_mpconv_backward_ws(const fgnn_mpconv_desc* d, const void* x, const int6
                 h[128 + 40] - h[128], h[128 + 41] - h[128], h[128 + 42] - h[128], h[128 + 43] - h[128], h[128 + 44] - h[128]);
     }
 #endif
-    if (!split) fgnn_launch_slab_reduce(p.ws, grid, slab_len, nw, gfilters, gbias, st);
+    if (ksplit) {
+        fgnn_launch_slab_reduce(p.ws, grid, slab_len, nw, gfilters, gbias, st);                  // rows 0..63 of gfilters, dbias
+        p.x += 64; p.W += 64 * (int64_t)p.w_ld; p.gx += 64; p.accum = 2;                          // input channels 64..127: getype accumulates
+        e = hipLaunchKernel(fn, dim3(grid), dim3(BW_THREADS), args, off_b, st);
+        if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "mpconv ws backward launch (upper input channels): %s", hipGetErrorString(e));
+        fgnn_launch_slab_reduce(p.ws, grid, slab_len, nw, gfilters + nw, nullptr, st);           // rows 64..127 (dbias was counted by the first launch)
+    } else if (!split) fgnn_launch_slab_reduce(p.ws, grid, slab_len, nw, gfilters, gbias, st);
     else {
         // slab rows are 256 columns of gfilters' 512: lower half, then the second launch on the upper 64 output channels, which ADDS
         // to gx / getype (one more bf16 rounding of those two) and folds its dW / dbias into the upper column / channel blocks
         fgnn_launch_slab_reduce_ld(p.ws, grid, slab_len, nw, 256, 512, gfilters, gbias, st);
-        p.W += 256; p.gz += 64; p.argmax += 64; p.accum = 1;
+        p.W += 256; p.gz += 64; p.argmax += 64; p.accum = 3;
         e = hipLaunchKernel(fn, dim3(grid), dim3(BW_THREADS), args, off_b, st);
         if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "mpconv ws backward launch (upper half): %s", hipGetErrorString(e));
         fgnn_launch_slab_reduce_ld(p.ws, grid, slab_len, nw, 256, 512, gfilters + 256, gbias + 64, st);

@@ -47,6 +47,8 @@ class LDPCModel(torch.nn.Module):
         every variable the same message and computes it once per codeword (ops.single_source_fanout)."""
         p = self.hetype_f2v
         w = cast_cached(p, dt)
+        if not (self.training and torch.is_grad_enabled()):
+            return w             # (inference: the one-kernel layer / block paths read the 96 weights as they lie in memory)
         memo = getattr(p, '_fgnn_equal_weights', None)
         if memo is None or memo[0] != (p._version, p.data_ptr()):
             if p.is_cuda and torch.cuda.is_current_stream_capturing():

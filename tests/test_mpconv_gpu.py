@@ -244,7 +244,8 @@ def test_bf16_mfma_backward_vs_routed_reference(shape, shared, dev):
     _, am = ops.mpconv_forward_raw(xd.detach(), idxd, etd.detach(), W.to(dev), bias.to(dev), nou, net, 0,
                                    _hip.AGG_MAX, want_argmax=True)
     z.backward(gz.to(dev))
-    assert 'mpconv_bwd_b16' in _hip.lib().fgnn_last_kernel().decode()
+    kern = _hip.lib().fgnn_last_kernel().decode()       # (a random table whose in-degree happens to fit goes to the later generations)
+    assert 'mpconv_bwd_b16' in kern or 'mpconv_bwd_sg' in kern or 'mpconv_bwd_ws' in kern, kern
     xr = x.float().detach().clone().requires_grad_(True)
     er = et.float().detach().clone().requires_grad_(True)                    # [B,M,k,net]
     Wr, br = W.clone().requires_grad_(True), bias.clone().requires_grad_(True)

@@ -287,8 +287,8 @@ def _backward_vs_oracle_autograd(shape, B, dev):
         assert ('mpconv_bwd_ws' in kern or 'mpconv_bwd_sg' in kern) and kern.endswith(' x2') == (nou == 128), kern
         if nou == 64:
             assert 'mpconv_bwd_ws' in kern, kern
-    else:
-        assert 'mpconv_bwd_b16' in kern, kern
+    else:               # 128 -> 64 (round 5): the third-generation kernel, two launches over the halves of the input channels
+        assert 'mpconv_bwd_ws' in kern and kern.endswith(' k2'), kern
     assert H.rel_err(z.float(), zo) <= 2.0 ** -6
     tol = 2.0 ** -6
     assert H.rel_err(xd.grad.float(), xo.grad) <= tol, kern
