@@ -198,7 +198,7 @@ def test_fused_training_tail_matches_staged_path_and_oracle(case, nadd, dev):
         return out, [a.grad.float() for a in ad], stats
 
     rec = []
-    ops.TIMER = type('T', (), {'run': staticmethod(lambda sym, nb, nf, launch, use_note=True: (rec.append(sym), launch()))})()
+    ops.TIMER = type('T', (), {'run': staticmethod(lambda sym, nb, nf, launch, use_note=True, **kw: (rec.append(sym), launch()))})()
     try:
         f, fa, fs = run(True)
     finally:
@@ -303,7 +303,7 @@ def test_fused_training_head_matches_staged_head(case, dev, monkeypatch):
         monkeypatch.setattr(blocks, "FUSE_TRAIN_HEAD", fused)
         monkeypatch.setattr(blocks, "_HEAD_WIDTHS", (64, 128, 256))
         rec = []
-        ops.TIMER = type('T', (), {'run': staticmethod(lambda sym, nb, nf, launch, use_note=True: (rec.append(sym), launch()))})()
+        ops.TIMER = type('T', (), {'run': staticmethod(lambda sym, nb, nf, launch, use_note=True, **kw: (rec.append(sym), launch()))})()
         try:
             xd, ed = x.detach().requires_grad_(True), et.detach().requires_grad_(True)
             with torch.autocast('cuda', dtype=torch.bfloat16):
