@@ -595,7 +595,7 @@ def test_iid_mapping_in_as_one_kernel(cin, cout, N, dev, monkeypatch):
     def run(fused, grad=True):
         monkeypatch.setattr(blocks, 'FUSE_IID_IN', fused)
         rec = []
-        ops.TIMER = type('T', (), {'run': staticmethod(lambda sym, nb, nf, launch, use_note=True: (rec.append(sym), launch()))})()
+        ops.TIMER = type('T', (), {'run': staticmethod(lambda sym, nb, nf, launch, use_note=True, **kw: (rec.append(sym), launch()))})()
         try:
             for q in m.parameters():
                 q.grad = None
