@@ -156,116 +156,6 @@ __global__ __launch_bounds__(512) void mpconv_fwd_fanin_kernel(const FhParams p)
 }
 
 // ----------------------------------------------------------------------------------------
-// fan-in, max aggregation, IDENTITY neighbour list (k == N, idx[j] == j: the LDPC hyper-factor listens to every variable in
-// order, /root/reference/train_ldpc.py:40-46) — round 5.  The kernel above writes P to LDS and then walks the 96 neighbours one
-// by one per output-channel lane (2 readlanes + an LDS read + 3 VALU ops per neighbour: ~33 us for 50 MB at 4096 codewords,
-// 0.19 of HBM).  With the neighbours in node order the reduction can stay in the MFMA accumulators: D[i = channel][j = node] of a
-// node tile gives lane (node li, ig) four channels of ONE node, so a lane keeps a running (max, first argmax) over its node
-// position across the node tiles, and ONE cross-lane fold over the 16 node lanes (value, then smaller index) closes the sample.
-// Same values as above (P rounded to bf16, times the edge weight in f32, strict > / smaller index = first occurrence).
-// ----------------------------------------------------------------------------------------
-template <int KS2, int OT>
-__global__ __launch_bounds__(256) void mpconv_fwd_fanin_id_kernel(const FhParams p) {
-    constexpr int NIN = 32 * KS2, NOU = 16 * OT, MAXT = 8;      // up to 128 nodes
-    const fgnn_mpconv_desc& d = p.d;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int li = lane & 15, lk = lane >> 4;
-    const int N = d.N;
-    fh_bf16x8 aP[OT][KS2];                                      // A[i = o][k = c] = W[c][o]
-#pragma unroll
-    for (int ot = 0; ot < OT; ++ot)
-#pragma unroll
-        for (int ks = 0; ks < KS2; ++ks) {
-            float w8[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) w8[u] = p.W[(int64_t)(32 * ks + 8 * lk + u) * NOU + ot * 16 + li];
-            aP[ot][ks] = __builtin_bit_cast(fh_bf16x8, make_uint4(fh_pack2(w8[0], w8[1]), fh_pack2(w8[2], w8[3]),
-                                                                  fh_pack2(w8[4], w8[5]), fh_pack2(w8[6], w8[7])));
-        }
-    const int ntile = p.Npad16 / 16;
-    const int nwaves = gridDim.x * 4;
-    for (int b = blockIdx.x * 4 + wave; b < d.B; b += nwaves) {
-        const uint16_t* xb = p.x + (int64_t)b * d.x_sb;
-        const uint16_t* eb = p.et + (int64_t)b * d.et_sb;
-        float best[OT][4];
-        int arg[OT][4];
-#pragma unroll
-        for (int ot = 0; ot < OT; ++ot)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { best[ot][r] = -__builtin_huge_valf(); arg[ot][r] = 0x7fffffff; }
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {                  // node tiles in two batches of <= 4: all their loads in flight together
-            uint4 bx[MAXT / 2][KS2];
-            float ew[MAXT / 2];
-#pragma unroll
-            for (int t = 0; t < MAXT / 2; ++t) {
-                const int nt = half * (MAXT / 2) + t, n = nt * 16 + li;
-                const bool ok = nt < ntile && n < N;
-#pragma unroll
-                for (int ks = 0; ks < KS2; ++ks)
-                    bx[t][ks] = ok ? *reinterpret_cast<const uint4*>(xb + (int64_t)n * NIN + 32 * ks + 8 * lk) : make_uint4(0, 0, 0, 0);
-                ew[t] = ok ? __uint_as_float((unsigned)eb[(int64_t)n * d.et_sk] << 16) : 0.f;
-            }
-#pragma unroll
-            for (int t = 0; t < MAXT / 2; ++t) {
-                const int nt = half * (MAXT / 2) + t, n = nt * 16 + li;
-                if (nt < ntile) {                                // (wave-uniform)
-#pragma unroll
-                    for (int ot = 0; ot < OT; ++ot) {
-                        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                        for (int ks = 0; ks < KS2; ++ks)
-                            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aP[ot][ks], __builtin_bit_cast(fh_bf16x8, bx[t][ks]), acc, 0, 0, 0);
-                        // acc[r] = P[node n][channel 16 ot + 4 lk + r]
-                        const unsigned q0 = fh_pack2(acc[0], acc[1]), q1 = fh_pack2(acc[2], acc[3]);
-                        const float pv[4] = {fh_lo(q0), fh_hi(q0), fh_lo(q1), fh_hi(q1)};
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const float v = ew[t] * pv[r];
-                            const bool take = n < N && v > best[ot][r];                 // strict >: the lane's first occurrence (tiles ascend)
-                            best[ot][r] = take ? v : best[ot][r];
-                            arg[ot][r] = take ? n : arg[ot][r];
-                        }
-                    }
-                }
-            }
-        }
-        // fold the 16 node lanes of each k-group: larger value, then smaller node index
-#pragma unroll
-        for (int m = 1; m < 16; m <<= 1)
-#pragma unroll
-            for (int ot = 0; ot < OT; ++ot)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float ov = __shfl_xor(best[ot][r], m);
-                    const int oa = __shfl_xor(arg[ot][r], m);
-                    const bool take = ov > best[ot][r] || (ov == best[ot][r] && oa < arg[ot][r]);
-                    best[ot][r] = take ? ov : best[ot][r];
-                    arg[ot][r] = take ? oa : arg[ot][r];
-                }
-        if (li == 0) {                                          // lane (0, lk): channels 16 ot + 4 lk .. + 3
-#pragma unroll
-            for (int ot = 0; ot < OT; ++ot) {
-                const int o = 16 * ot + 4 * lk;
-                float res[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float v = best[ot][r] + (p.bias ? p.bias[o + r] : 0.f);
-                    if (p.pscale) v = v * p.pscale[o + r] + p.pshift[o + r];
-                    res[r] = d.relu ? fmaxf(v, 0.f) : v;
-                }
-                const int64_t off = (int64_t)b * d.y_sb + o;
-                *reinterpret_cast<uint2*>(p.y + off) = make_uint2(fh_pack2(res[0], res[1]), fh_pack2(res[2], res[3]));
-                if (p.argmax)
-                    *reinterpret_cast<unsigned*>(p.argmax + off) = (unsigned)arg[ot][0] | ((unsigned)arg[ot][1] << 8) |
-                                                                    ((unsigned)arg[ot][2] << 16) | ((unsigned)arg[ot][3] << 24);
-            }
-        }
-    }
-}
-
-// ----------------------------------------------------------------------------------------
 // fan-out: N == 1, k == 1; y channel-fastest [M][nou].  CH = nou / 16 channels per lane.
 // ----------------------------------------------------------------------------------------
 template <int NI, int CH>
@@ -370,22 +260,6 @@ int fgnn_mpconv_forward_hyper(const fgnn_mpconv_desc* d, const void* x, const in
     if (fanin) {
         if (!(d->x_sc == 1 && d->x_sn == d->nin && d->x_sb % 8 == 0) || ((uintptr_t)x & 15)) FH_REJECT(4);
         const int KS2 = d->nin / 32, OT = d->nou / 16;
-        static const bool no_id = getenv("FGNN_NO_FANIN_ID") != nullptr;
-        // the caller vouches for an identity neighbour list (FGNN_DESC_IDENTITY_LIST): the reduction stays in the MFMA accumulators
-        if (!no_id && (d->reserved & FGNN_DESC_IDENTITY_LIST) && d->agg == FGNN_AGG_MAX && d->k == d->N && d->N <= 128 && d->y_sc == 1 &&
-            d->y_sb % 4 == 0 && !((uintptr_t)y & 7) && !(argmax && ((uintptr_t)argmax & 3))) {
-            void* idfn = (KS2 == 2 && OT == 4) ? (void*)mpconv_fwd_fanin_id_kernel<2, 4> : (KS2 == 2 && OT == 8) ? (void*)mpconv_fwd_fanin_id_kernel<2, 8>
-                       : (KS2 == 4 && OT == 4) ? (void*)mpconv_fwd_fanin_id_kernel<4, 4> : nullptr;
-            if (idfn) {
-                int g = (d->B + 3) / 4;
-                if (g > 2048) g = 2048;
-                fgnn_note_kernel("mpconv_fwd_fanin_id_kernel<%d, %d>", KS2, OT);
-                void* args[] = {(void*)&p};
-                hipError_t e = hipLaunchKernel(idfn, dim3(g), dim3(256), args, 0, (hipStream_t)stream);
-                if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "mpconv hyper-edge forward launch: %s", hipGetErrorString(e));
-                return 1;
-            }
-        }
         fn = d->agg == FGNN_AGG_MAX ? fh_pick_fanin<FGNN_AGG_MAX>(KS2, OT)
            : d->agg == FGNN_AGG_LSE ? fh_pick_fanin<FGNN_AGG_LSE>(KS2, OT) : fh_pick_fanin<FGNN_AGG_MEAN>(KS2, OT);
         const int per_wave = p.Npad16 * d->nou * 2;
