@@ -314,3 +314,209 @@ extern "C" int fgnn_instnorm_backward(const void* x, const void* gy, void* gx, i
     if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "instnorm backward launch: %s", hipGetErrorString(e));
     return FGNN_OK;
 }
+
+// ----------------------------------------------------------------------------------------
+// The classifier's closing pair as ONE pass (round 5): InstanceNorm + ReLU + the 128 -> 1 map that reads it
+// (/root/reference/lib/model/mpnn/factor_mpnn_sp.py:104-108: Conv2d(dim,128,1) -> InstanceNorm2d -> ReLU -> Dropout/Identity ->
+// Conv2d(128, 1, 1); the LDPC decoder's logit per variable).  Staged, the normalised [B][N][128] tensor is written, read back by a
+// one-column library GEMM (hipBLASLt MT1x4x256: 79 us for 101 MB), and in the backward its gradient — the outer product
+// gout[b,n] * w[c] — is written by another GEMM and read by the InstanceNorm backward, with a third pass for the map's weight
+// gradient (profiles/r05/train_step_sequence.csv: 115 us forward + 150 us backward on the step's critical path).  Here:
+//   forward : out[b,n] = bias + sum_c w[c] * relu(xhat[b,n,c])                                   reads x once, writes B*N values
+//   backward: g = gout[b,n] * w[c] * [xhat > 0] formed in registers -> gx as in instnorm_vec_kernel;  gw[c] += sum gout * relu(xhat),
+//             gbias += sum gout (per-workgroup partial rows, folded in fixed order by instnorm_dot_reduce_kernel)
+// One workgroup owns whole samples (C == 128 == one channel block); the backward's workgroups walk the batch with a grid
+// stride so that the weight-gradient partials are a few hundred rows.  y = relu(xhat) and g stay f32 (the staged path rounds
+// both to the activations' dtype in between).
+// ----------------------------------------------------------------------------------------
+#define IND_CH 128
+#define IND_PSTRIDE 132         // floats per partial row: 128 weight-gradient slots, the bias gradient, padding
+#define IND_MAXGRID 512
+
+struct IndParams {
+    const void* x;
+    const float* w;             // [128]
+    const float* bias;          // [1] or NULL
+    const void* gout;           // backward: [B][N]
+    void* out;                  // forward: [B][N]; backward: gx [B][N][128]
+    float* partials;            // backward: [grid][IND_PSTRIDE]
+    int B, N;
+};
+
+template <typename T, bool BWD, int MAXR>
+__global__ __launch_bounds__(IN_THREADS) void instnorm_dot_kernel(const IndParams p) {
+    constexpr int CH = IND_CH, EPC = InChunk<T>::EPC, CPR = CH / EPC, RG = IN_THREADS / CPR;
+    __shared__ float red[8 * CH];
+    const int tid = threadIdx.x, wave = tid >> 6;
+    const int cg = tid & (CPR - 1), rg = tid / CPR;
+    const int N = p.N;
+    const float invn = 1.0f / (float)N;
+    float w[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) w[e] = p.w[cg * EPC + e];
+    float gwacc[EPC], gbacc[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) { gwacc[e] = 0.f; gbacc[e] = 0.f; }
+    for (int b = blockIdx.x; b < p.B; b += gridDim.x) {
+        const T* xb = static_cast<const T*>(p.x) + (int64_t)b * N * CH + cg * EPC;
+        float x[MAXR][EPC], go[BWD ? MAXR : 1], K[EPC];
+        InChunk<T>::load(xb, K);
+#pragma unroll
+        for (int i = 0; i < MAXR; ++i) {
+            const int n = rg + i * RG;
+            if (n < N) {
+                InChunk<T>::load(xb + (int64_t)n * CH, x[i]);
+                if constexpr (BWD) go[i] = fgnn_ld(static_cast<const T*>(p.gout) + (int64_t)b * N + n);
+            } else {
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) x[i][e] = K[e];
+                if constexpr (BWD) go[i] = 0.f;
+            }
+        }
+        float mean[EPC], rstd[EPC];
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            float s = 0.f, ss = 0.f;
+#pragma unroll
+            for (int i = 0; i < MAXR; ++i) { const float dv = x[i][e] - K[e]; x[i][e] = dv; s += dv; ss = fmaf(dv, dv, ss); }
+            mean[e] = s; rstd[e] = ss;
+        }
+        in_fold2<EPC, CPR, CH>(mean, rstd, red, cg, wave);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            const float m = mean[e] * invn;
+            const float var = fmaxf(rstd[e] * invn - m * m, 0.f);
+            mean[e] = m;
+            rstd[e] = rsqrtf(var + IN_EPS);
+        }
+        if constexpr (!BWD) {
+            const float bias = p.bias ? p.bias[0] : 0.f;
+#pragma unroll
+            for (int i = 0; i < MAXR; ++i) {
+                float d = 0.f;
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) d = fmaf(fmaxf((x[i][e] - mean[e]) * rstd[e], 0.f), w[e], d);
+#pragma unroll
+                for (int m = 1; m < CPR; m <<= 1) d += __shfl_xor(d, m);       // the row's 128 channels: CPR neighbouring lanes
+                const int n = rg + i * RG;
+                if (cg == 0 && n < N) fgnn_st(static_cast<T*>(p.out) + (int64_t)b * N + n, d + bias);
+            }
+        } else {
+            T* ob = static_cast<T*>(p.out) + (int64_t)b * N * CH + cg * EPC;
+            float sg[EPC], sgx[EPC], g[MAXR][EPC];
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+                sg[e] = 0.f; sgx[e] = 0.f;
+#pragma unroll
+                for (int i = 0; i < MAXR; ++i) {
+                    const float xh = (x[i][e] - mean[e]) * rstd[e];
+                    x[i][e] = xh;
+                    const bool on = xh > 0.f;
+                    gwacc[e] = fmaf(go[i], on ? xh : 0.f, gwacc[e]);            // padding rows carry gout = 0
+                    const float gv = on ? go[i] * w[e] : 0.f;
+                    g[i][e] = gv;
+                    sg[e] += gv;
+                    sgx[e] = fmaf(gv, xh, sgx[e]);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < MAXR; ++i) gbacc[0] += go[i];
+            in_fold2<EPC, CPR, CH>(sg, sgx, red, cg, wave);
+#pragma unroll
+            for (int i = 0; i < MAXR; ++i) {
+                const int n = rg + i * RG;
+                if (n < N) {
+                    float o[EPC];
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) o[e] = rstd[e] * (g[i][e] - sg[e] * invn - x[i][e] * sgx[e] * invn);
+                    InChunk<T>::store(ob + (int64_t)n * CH, o);
+                }
+            }
+        }
+    }
+    if constexpr (BWD) {
+        in_fold2<EPC, CPR, CH>(gwacc, gbacc, red, cg, wave);          // over the workgroup's row groups, per channel
+        if (rg == 0) {
+            float* pr = p.partials + (int64_t)blockIdx.x * IND_PSTRIDE;
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) pr[cg * EPC + e] = gwacc[e];
+            if (cg == 0) pr[CH] = gbacc[0];                            // (column 0 of the second fold: the sum of gout over the rows)
+        }
+    }
+}
+
+// gw[c] += sum over the partial rows (fixed order: 7 interleaved row groups, then the groups), gbias likewise
+__global__ __launch_bounds__(1024) void instnorm_dot_reduce_kernel(const float* partials, int nrows, float* gw, float* gbias) {
+    constexpr int COLS = IND_CH + 1, GROUPS = 7;
+    __shared__ float red[GROUPS * COLS];
+    const int tid = threadIdx.x, rgp = tid / COLS, c = tid - rgp * COLS;
+    if (rgp < GROUPS) {
+        float a = 0.f;
+        for (int r = rgp; r < nrows; r += GROUPS) a += partials[(int64_t)r * IND_PSTRIDE + c];
+        red[rgp * COLS + c] = a;
+    }
+    __syncthreads();
+    if (tid < COLS) {
+        float a = 0.f;
+#pragma unroll
+        for (int q = 0; q < GROUPS; ++q) a += red[q * COLS + tid];
+        if (tid < IND_CH) gw[tid] += a;
+        else if (gbias) gbias[0] += a;
+    }
+}
+
+static int ind_check(const void* x, const float* w, const void* o, int B, int N, int C, int dtype) {
+    if (!x || !w || !o) FGNN_FAIL(FGNN_EINVAL, "instnorm_dot: null pointer");
+    if (B < 0 || N < 1 || C < 1) FGNN_FAIL(FGNN_EINVAL, "instnorm_dot: bad sizes B=%d N=%d C=%d", B, N, C);
+    if (dtype != FGNN_F32 && dtype != FGNN_BF16) FGNN_FAIL(FGNN_EINVAL, "instnorm_dot: unknown dtype %d", dtype);
+    if (C != IND_CH || N > 128 || N < 2) FGNN_FAIL(FGNN_EUNSUPPORTED, "instnorm_dot: C=%d N=%d (C == 128, 2 <= N <= 128)", C, N);
+    if ((uintptr_t)x & 15) FGNN_FAIL(FGNN_EUNSUPPORTED, "instnorm_dot: x is not 16-byte aligned");
+    return FGNN_OK;
+}
+
+template <typename T, bool BWD>
+static void ind_launch(int grid, int N, hipStream_t st, const IndParams& p) {
+    constexpr int RG = IN_THREADS / (IND_CH / InChunk<T>::EPC), FULL = 128 / RG;
+    const int need = (N + RG - 1) / RG;
+    if (need * 2 <= FULL) hipLaunchKernelGGL((instnorm_dot_kernel<T, BWD, FULL / 2>), dim3(grid), dim3(IN_THREADS), 0, st, p);
+    else if (need * 4 <= FULL * 3) hipLaunchKernelGGL((instnorm_dot_kernel<T, BWD, FULL * 3 / 4>), dim3(grid), dim3(IN_THREADS), 0, st, p);
+    else hipLaunchKernelGGL((instnorm_dot_kernel<T, BWD, FULL>), dim3(grid), dim3(IN_THREADS), 0, st, p);
+}
+
+extern "C" int fgnn_instnorm_dot_forward(const void* x, const float* w, const float* bias, void* out, int B, int N, int C,
+                                         int dtype, fgnn_stream_t stream) {
+    int rc = ind_check(x, w, out, B, N, C, dtype);
+    if (rc) return rc;
+    if (B == 0) return FGNN_OK;
+    IndParams p = {x, w, bias, nullptr, out, nullptr, B, N};
+    if (dtype == FGNN_F32) ind_launch<float, false>(B, N, (hipStream_t)stream, p);
+    else ind_launch<bf16_t, false>(B, N, (hipStream_t)stream, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "instnorm_dot forward launch: %s", hipGetErrorString(e));
+    fgnn_note_kernel("instnorm_dot_kernel<fwd>");
+    return FGNN_OK;
+}
+
+extern "C" int64_t fgnn_instnorm_dot_workspace_bytes(int B) {
+    const int grid = B < IND_MAXGRID ? (B > 0 ? B : 1) : IND_MAXGRID;
+    return (int64_t)grid * IND_PSTRIDE * (int64_t)sizeof(float);
+}
+
+extern "C" int fgnn_instnorm_dot_backward(const void* x, const float* w, const void* gout, void* gx, float* gw, float* gbias,
+                                          int B, int N, int C, int dtype, void* ws, int64_t ws_bytes, fgnn_stream_t stream) {
+    int rc = ind_check(x, w, gx, B, N, C, dtype);
+    if (rc) return rc;
+    if (!gout || !gw) FGNN_FAIL(FGNN_EINVAL, "instnorm_dot: null pointer");
+    if ((uintptr_t)gx & 15) FGNN_FAIL(FGNN_EUNSUPPORTED, "instnorm_dot: gx is not 16-byte aligned");
+    if (B == 0) return FGNN_OK;
+    if (!ws || ws_bytes < fgnn_instnorm_dot_workspace_bytes(B)) FGNN_FAIL(FGNN_EINVAL, "instnorm_dot backward: workspace too small");
+    const int grid = B < IND_MAXGRID ? B : IND_MAXGRID;
+    IndParams p = {x, w, nullptr, gout, gx, static_cast<float*>(ws), B, N};
+    if (dtype == FGNN_F32) ind_launch<float, true>(grid, N, (hipStream_t)stream, p);
+    else ind_launch<bf16_t, true>(grid, N, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(instnorm_dot_reduce_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, static_cast<const float*>(ws), grid, gw, gbias);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "instnorm_dot backward launch: %s", hipGetErrorString(e));
+    fgnn_note_kernel("instnorm_dot_kernel<bwd>");
+    return FGNN_OK;
+}

@@ -75,6 +75,9 @@ class LDPCModel(torch.nn.Module):
         if self.with_residual:
             res = res + node_feature[:, :1, :, :]
         res = res.reshape(B, 96)
+        # (round 5, measured and dropped: the regressor's ~50 short launches on the side stream, beside the main stream's closing block +
+        # classifier + loss — 15.22 vs 15.05 ms per step, gpurun_out/r05m: the extra cross-queue joins at the step's turn-around cost
+        # more than the overlap of 5 us launches buys)
         snr_pred = self.nhop_regressor(hops[1].reshape(B, -1).float())
         return res[:, :48].contiguous(), snr_pred
 

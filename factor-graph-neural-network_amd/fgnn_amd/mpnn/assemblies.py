@@ -13,7 +13,7 @@ import os
 import torch
 
 from .blocks import iid_mapping, iid_mapping_bn, iid_mapping_in, mp_conv_residual
-from .pointwise import NodeInstanceNorm, PointwiseConv2d as _Conv, add_all
+from .pointwise import NodeInstanceNorm, PointwiseConv2d as _Conv, add_all, instnorm_relu_dot
 from .message_op import base_mp_nn, mp_conv_type, mp_conv_v2
 
 
@@ -223,6 +223,16 @@ class FactorNN(torch.nn.Module):
             _Conv(dim_mapping_list[-1], 128, 1), NodeInstanceNorm(relu=True),
             torch.nn.Identity(), _Conv(128, final_dim, 1, bias=True))
 
+    def _classify(self, var):
+        """``final_classifier`` (factor_mpnn_sp.py:104-108); its InstanceNorm2d -> ReLU -> Identity -> Conv2d(128, 1, 1) as one kernel
+        where the shape allows (two classes: one logit per variable)."""
+        fc = self.final_classifier
+        if len(fc) == 4 and isinstance(fc[1], NodeInstanceNorm) and fc[1].relu and isinstance(fc[2], torch.nn.Identity):
+            h = fc[0](var)
+            out = instnorm_relu_dot(h, fc[3])
+            return out if out is not None else fc[3](fc[2](fc[1](h)))
+        return fc(var)
+
     def _fused_layer(self, L, var, fac, skip, nn_idx_f2v, nn_idx_v2f, etype_f2v, etype_v2f):
         """Inference: layer ``L`` as one kernel (csrc/factor_layer_fwd.hip) when it is a 64 -> 64 layer of the
         LDPC shape — bf16 channel-fastest states of 96 variables / 48 degree-6 checks / one hyper-factor, neighbour tables
@@ -394,7 +404,7 @@ class FactorNN(torch.nn.Module):
                 return [new_var] + h + [var_c[-1] if same_width else None, skip[0] if skip else None]
             new_var = _call(self.f2v_modules[L][0], fac_c[0][1], nn_idx_f2v[0], etype_f2v[0][L], addend=joined)
             var, fac = new_var, new_fac
-        out = self.final_classifier(var)
+        out = self._classify(var)
         if self.final_filter is not None:
             out = self.final_filter(out, node_feature)
         return (out, fac) if self.ret_high else out

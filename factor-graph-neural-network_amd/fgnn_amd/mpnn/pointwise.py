@@ -9,6 +9,7 @@ dominate the step).  ``PointwiseConv2d`` keeps Conv2d's parameters / state_dict 
 kernel reads and writes without a transpose.  Outputs are logical [B,C,N,W] with
 channels-last strides; every consumer in this package is stride-agnostic.
 """
+import os
 import weakref
 
 import torch
@@ -370,6 +371,79 @@ class _InstNormAct(torch.autograd.Function):
                                                                        C, _hip.dtype_code(rows), int(ctx.relu),
                                                                        _hip.stream_ptr())))
         return gx.permute(0, 3, 1, 2), None, None
+
+
+class _InstNormDot(torch.autograd.Function):
+    """out[b,0,n,0] = bias + sum_c w[c] relu(InstanceNorm(x)[b,c,n,0]) — the classifier's InstanceNorm2d -> ReLU -> Conv2d(128, 1, 1)
+    (factor_mpnn_sp.py:104-108) as one kernel forward and one backward (csrc/instnorm.hip: instnorm_dot_kernel); only x is saved,
+    neither the normalised tensor nor its gradient exists in memory."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        B, C, N, _ = x.shape
+        rows = x.permute(0, 2, 3, 1)
+        if not rows.is_contiguous():
+            rows = rows.contiguous()
+        w = weight.detach().reshape(C)
+        out = torch.empty((B, 1, N, 1), device=x.device, dtype=x.dtype)
+        from .. import ops
+        ops.timed('instnorm_dot_kernel<fwd>', rows.numel() * rows.element_size(), lambda: _hip.check(
+            _hip.lib().fgnn_instnorm_dot_forward(_hip._ptr(rows), _hip._ptr(w), _hip._ptr(None if bias is None else bias.detach()),
+                                                 _hip._ptr(out), B, N, C, _hip.dtype_code(rows), _hip.stream_ptr())))
+        ctx.save_for_backward(rows, weight)
+        ctx.params = (weight, bias)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        rows, weight = ctx.saved_tensors
+        from .. import ops
+        ops.backward_node_begins()
+        B, N, _, C = rows.shape
+        L = _hip.lib()
+        g = gout.reshape(B, N)
+        if not g.is_contiguous() or g.dtype != rows.dtype:
+            g = g.to(rows.dtype).contiguous()
+        wparam, bparam = ctx.params
+        gw_sink, gb_sink = ops.grad_sink(wparam), ops.grad_sink(bparam)
+        gw = gw_sink if gw_sink is not None else torch.zeros(wparam.shape, device=rows.device, dtype=torch.float32)
+        gb = None
+        if bparam is not None:
+            gb = gb_sink if gb_sink is not None else torch.zeros((1,), device=rows.device, dtype=torch.float32)
+        gx = torch.empty_like(rows)
+        ws = ops._workspace(rows.device, int(L.fgnn_instnorm_dot_workspace_bytes(B)))
+        ops.timed('instnorm_dot_kernel<bwd>', 2 * rows.numel() * rows.element_size(), lambda: _hip.check(
+            L.fgnn_instnorm_dot_backward(_hip._ptr(rows), _hip._ptr(weight.detach()), _hip._ptr(g), _hip._ptr(gx), _hip._ptr(gw),
+                                         _hip._ptr(gb), B, N, C, _hip.dtype_code(rows), _hip._ptr(ws), ws.numel() * 4,
+                                         _hip.stream_ptr())))
+        return (gx.permute(0, 3, 1, 2), None if gw_sink is not None else gw.to(wparam.dtype),
+                None if (gb is None or gb_sink is not None) else gb.to(bparam.dtype))
+
+
+INSTNORM_DOT = os.environ.get('FGNN_NO_INSTNORM_DOT', '') in ('', '0')       # tuning knob: the classifier's closing pair staged
+
+
+def instnorm_relu_dot(x, conv):
+    """``conv(relu(InstanceNorm2d(x)))`` for a one-output 1x1 ``conv`` over 128 channels (the classifier head's closing pair) as
+    one kernel, or None when the shape / dtype / device is not the kernel's (the caller then runs the staged modules)."""
+    if not (INSTNORM_DOT and x.is_cuda and x.dim() == 4 and x.shape[3] == 1 and x.shape[1] == 128 and 2 <= x.shape[2] <= 128
+            and x.dtype in (torch.float32, torch.bfloat16) and isinstance(conv, torch.nn.Conv2d) and conv.out_channels == 1
+            and conv.in_channels == 128 and conv.weight.dtype == torch.float32 and conv.weight.is_contiguous()
+            and (conv.bias is None or conv.bias.dtype == torch.float32)):
+        return None
+    if torch.is_grad_enabled() and (x.requires_grad or conv.weight.requires_grad):
+        return _InstNormDot.apply(x, conv.weight, conv.bias)
+    B, C, N, _ = x.shape
+    rows = x.permute(0, 2, 3, 1)
+    if not rows.is_contiguous():
+        rows = rows.contiguous()
+    out = torch.empty((B, 1, N, 1), device=x.device, dtype=x.dtype)
+    from .. import ops
+    ops.timed('instnorm_dot_kernel<fwd>', rows.numel() * rows.element_size(), lambda: _hip.check(
+        _hip.lib().fgnn_instnorm_dot_forward(_hip._ptr(rows), _hip._ptr(conv.weight.detach()),
+                                             _hip._ptr(None if conv.bias is None else conv.bias.detach()),
+                                             _hip._ptr(out), B, N, C, _hip.dtype_code(rows), _hip.stream_ptr())))
+    return out
 
 
 class NodeInstanceNorm(torch.nn.Module):

@@ -224,6 +224,23 @@ int fgnn_instnorm_backward(const void* x, const void* gy, void* gx, int32_t B, i
                            int32_t dtype, int32_t relu, fgnn_stream_t stream);
 
 /*
+ * The classifier's closing pair as one pass: InstanceNorm2d + ReLU + the one-column map behind it
+ * (/root/reference/lib/model/mpnn/factor_mpnn_sp.py:104-108: ... InstanceNorm2d -> ReLU -> Dropout/Identity -> Conv2d(128, 1, 1),
+ * the decoder's logit per variable) on dense channel-fastest x[B][N][128]:
+ *     out[b][n] = bias + sum_c w[c] * relu(instnorm(x)[b][n][c])          (out: dtype of x; w [128], bias [1] or NULL: f32)
+ * backward, given gout[B][N] (dtype of x): gx[B][N][128]; gw[128] += d/dw, gbias[0] += sum gout (f32, ACCUMULATED into; gbias may
+ * be NULL).  Only x is needed (statistics and the normalised tensor are recomputed; neither it nor its gradient ever exists in
+ * memory).  workspace: fgnn_instnorm_dot_workspace_bytes(B) bytes.  C == 128 and 2 <= N <= 128, x / gx 16-byte aligned; anything
+ * else: FGNN_EUNSUPPORTED (run fgnn_instnorm_forward + a linear map).
+ */
+int fgnn_instnorm_dot_forward(const void* x, const float* w, const float* bias, void* out, int32_t B, int32_t N, int32_t C,
+                              int32_t dtype, fgnn_stream_t stream);
+int fgnn_instnorm_dot_backward(const void* x, const float* w, const void* gout, void* gx, float* gw, float* gbias,
+                               int32_t B, int32_t N, int32_t C, int32_t dtype, void* workspace, int64_t workspace_bytes,
+                               fgnn_stream_t stream);
+int64_t fgnn_instnorm_dot_workspace_bytes(int32_t B);
+
+/*
  * TRAINING-mode fusion of the tail of `mp_conv_residual` (reference mp_nn.py:165-175 = the operator's
  * BatchNorm + ReLU, mp_nn_residual.py:31-35,49-51 = conv2 + BatchNorm + LeakyReLU): behind the message operator's
  * 64-channel output e [R][64] (bf16, R = B * M destination rows)
@@ -460,7 +477,7 @@ const char* fgnn_last_kernel(void);
  * mismatch and not as a missing symbol or a misread field.  4: round-2 additions (flat_adam, factor_layer_*,
  * ldpc_channel_features_rng, backward_reduces_getype, desc.reserved = in-degree | GETYPE_REDUCED); 5: fgnn_block_tail_*;
  * 6: fgnn_block_head_backward. */
-#define FGNN_ABI_VERSION 8
+#define FGNN_ABI_VERSION 9
 int fgnn_abi_version(void);
 
 #ifdef __cplusplus

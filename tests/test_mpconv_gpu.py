@@ -444,6 +444,48 @@ def test_instance_norm_kernel_vs_torch(C, N, relu, dtype, dev):
     assert H.rel_err(xm.grad.float(), xr.grad) <= tol * 5
 
 
+@pytest.mark.parametrize('N,B', [(96, 5), (48, 3), (128, 2), (2, 4), (37, 700)])
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_classifier_instnorm_relu_dot_kernel_vs_torch(N, B, dtype, dev):
+    """The classifier's closing pair InstanceNorm2d -> ReLU -> Conv2d(128, 1, 1) (factor_mpnn_sp.py:104-108) as one kernel
+    (csrc/instnorm.hip: instnorm_dot_kernel) against the same three torch ops in f32: logits, input gradient, the map's weight and
+    bias gradients (B = 700: more samples than backward workgroups, so the grid-stride walk and the partial-row fold are on)."""
+    from fgnn_amd import ops
+    from fgnn_amd.mpnn.pointwise import instnorm_relu_dot, PointwiseConv2d
+    g = torch.Generator().manual_seed(N * 10 + B)
+    x = (torch.randn(B, 128, N, 1, generator=g) * 2 + 0.5).to(dtype)
+    gout = torch.randn(B, 1, N, 1, generator=g).to(dtype)
+    conv = PointwiseConv2d(128, 1, 1, bias=True)
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(1, 128, 1, 1, generator=g) * 0.2)
+        conv.bias.fill_(0.3)
+    xr = x.detach().float().clone().requires_grad_(True)
+    wr, br = conv.weight.detach().clone().requires_grad_(True), conv.bias.detach().clone().requires_grad_(True)
+    ref = torch.nn.functional.conv2d(torch.relu(torch.nn.functional.instance_norm(xr, eps=1e-5)), wr, br)
+    ref.backward(gout.float())
+    conv = conv.to(dev)
+    xm = x.detach().clone().to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    rec = []
+    ops.TIMER = type('T', (), {'run': staticmethod(lambda sym, nb, nf, launch, use_note=True, **kw: (rec.append(sym), launch()))})()
+    try:
+        out = instnorm_relu_dot(xm, conv)
+        out.backward(gout.to(dev))
+    finally:
+        ops.TIMER = None
+    assert rec == ['instnorm_dot_kernel<fwd>', 'instnorm_dot_kernel<bwd>'], rec
+    tol = 2e-5 if dtype == torch.float32 else 1e-2
+    assert out.shape == ref.shape and out.dtype == dtype
+    assert H.rel_err(out.float(), ref) <= tol
+    assert H.rel_err(xm.grad.float(), xr.grad) <= tol * 5
+    assert H.rel_err(conv.weight.grad, wr.grad) <= tol
+    assert H.rel_err(conv.bias.grad, br.grad) <= tol
+    with torch.no_grad():                                    # the no-grad form (inference) is the same launch
+        assert torch.equal(instnorm_relu_dot(xm.detach(), conv), out.detach())
+    # shapes outside the kernel's: None, the caller runs the staged modules
+    assert instnorm_relu_dot(torch.zeros(2, 64, N, 1, device=dev), conv) is None
+    assert instnorm_relu_dot(xm.detach().cpu(), conv.cpu()) is None
+
+
 @pytest.mark.parametrize('C', [64, 128, 256, 8, 96])
 @pytest.mark.parametrize('slope', [0.0, 0.01, 1.0])
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
