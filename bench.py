@@ -74,12 +74,10 @@ def parse():
 
 
 def loss_fn(logits, snr_pred, label, sigma_b):
-    """train_ldpc.py:222-227: BCE-with-logits + 0.1 * MSE on the burst-noise regressor."""
-    bce = torch.nn.functional.binary_cross_entropy_with_logits(logits.reshape(-1).float(),
-                                                               label.reshape(-1).float())
-    mse = torch.nn.functional.mse_loss(snr_pred.reshape(-1).float(),
-                                       torch.pow(10.0, sigma_b.float() / 20).reshape(-1))
-    return bce + 0.1 * mse
+    """train_ldpc.py:222-227: BCE-with-logits + 0.1 * MSE on the burst-noise regressor (on the GPU: one launch forward, one backward —
+    fgnn_amd.ldpc.decoding_loss; on the CPU the same torch expression the reference writes)."""
+    from fgnn_amd.ldpc import decoding_loss
+    return decoding_loss(logits, snr_pred, label, sigma_b, 0.1)
 
 
 def cpu_baseline(batch, mode, threads, budget=20.0, max_iters=5):

@@ -193,3 +193,83 @@ extern "C" int fgnn_ldpc_channel_features_rng(const uint8_t* cw, const float* sn
     return ld_channel_launch(true, cw, snr_db, sigma_b, rho, nullptr, nullptr, nullptr, seed, offset, var_to_factors,
                              factor_to_vars, B, nvar, nchk, dv, dc, dtype, y, node, hop, ef_f2v, ef_v2f, stream);
 }
+
+// ---- the training loss behind the decoder (round 5) --------------------------------------------------------------------------------
+// /root/reference/train_ldpc.py:222-227:  loss = BCEWithLogits(decoded bits, message bits) + w * MSE(predicted burst amplitude,
+// 10^(sigma_b / 20)), both means.  Through torch that is ~12 five-microsecond launches forward and ~13 backward (casts, log-sigmoid,
+// two reductions, pow, scalar arithmetic) alone on the GPU between the model's forward and its backward; here one launch each
+// way.  The forward is ONE workgroup (B * n = 196 608 logits at the benched size: 192 per thread) summing in double in a fixed order.
+#define LL_THREADS 1024
+
+__device__ __forceinline__ float ll_bce(float x, float y) {       // torch's stable form: max(x,0) - x y + log(1 + exp(-|x|))
+    return fmaxf(x, 0.f) - x * y + log1pf(expf(-fabsf(x)));
+}
+
+template <typename T>
+__global__ __launch_bounds__(LL_THREADS) void ldpc_loss_fwd_kernel(const T* __restrict__ logits, const float* __restrict__ label,
+                                                                   const float* __restrict__ pred, const float* __restrict__ sigma_b,
+                                                                   int64_t nlogit, int64_t B, float w, float* __restrict__ loss) {
+    __shared__ double red[2 * LL_THREADS];
+    const int tid = threadIdx.x;
+    double a = 0.0, m = 0.0;
+    for (int64_t i = tid; i < nlogit; i += LL_THREADS) a += (double)ll_bce(fgnn_ld(logits + i), label[i]);
+    for (int64_t b = tid; b < B; b += LL_THREADS) { const float d = pred[b] - powf(10.f, sigma_b[b] * 0.05f); m += (double)(d * d); }
+    red[tid] = a; red[LL_THREADS + tid] = m;
+    __syncthreads();
+    for (int s = LL_THREADS / 2; s > 0; s >>= 1) {
+        if (tid < s) { red[tid] += red[tid + s]; red[LL_THREADS + tid] += red[LL_THREADS + tid + s]; }
+        __syncthreads();
+    }
+    if (tid == 0) loss[0] = (float)(red[0] / (double)nlogit + (double)w * red[LL_THREADS] / (double)B);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void ldpc_loss_bwd_kernel(const T* __restrict__ logits, const float* __restrict__ label,
+                                                            const float* __restrict__ pred, const float* __restrict__ sigma_b,
+                                                            const float* __restrict__ gloss, int64_t nlogit, int64_t B, float w,
+                                                            T* __restrict__ glogits, float* __restrict__ gpred) {
+    const float g = gloss[0];
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < nlogit) {
+        const float x = fgnn_ld(logits + i);
+        const float sg = 1.f / (1.f + expf(-x));
+        fgnn_st(glogits + i, g * (sg - label[i]) / (float)nlogit);
+    }
+    if (i < B) gpred[i] = g * w * 2.f * (pred[i] - powf(10.f, sigma_b[i] * 0.05f)) / (float)B;
+}
+
+static int ll_check(const void* logits, const float* label, const float* pred, const float* sigma_b, int64_t B, int n, int dtype) {
+    if (!logits || !label || !pred || !sigma_b) FGNN_FAIL(FGNN_EINVAL, "ldpc_loss: null pointer");
+    if (B < 1 || n < 1) FGNN_FAIL(FGNN_EINVAL, "ldpc_loss: bad sizes B=%lld n=%d", (long long)B, n);
+    if (dtype != FGNN_F32 && dtype != FGNN_BF16) FGNN_FAIL(FGNN_EINVAL, "ldpc_loss: unknown dtype %d", dtype);
+    return FGNN_OK;
+}
+
+extern "C" int fgnn_ldpc_loss_forward(const void* logits, const float* label, const float* pred, const float* sigma_b, int64_t B,
+                                      int n, int dtype, float mse_weight, float* loss, fgnn_stream_t stream) {
+    int rc = ll_check(logits, label, pred, sigma_b, B, n, dtype);
+    if (rc) return rc;
+    if (!loss) FGNN_FAIL(FGNN_EINVAL, "ldpc_loss: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == FGNN_F32) hipLaunchKernelGGL(ldpc_loss_fwd_kernel<float>, dim3(1), dim3(LL_THREADS), 0, st, (const float*)logits, label, pred, sigma_b, B * n, B, mse_weight, loss);
+    else hipLaunchKernelGGL(ldpc_loss_fwd_kernel<bf16_t>, dim3(1), dim3(LL_THREADS), 0, st, (const bf16_t*)logits, label, pred, sigma_b, B * n, B, mse_weight, loss);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "ldpc_loss forward launch: %s", hipGetErrorString(e));
+    return FGNN_OK;
+}
+
+extern "C" int fgnn_ldpc_loss_backward(const void* logits, const float* label, const float* pred, const float* sigma_b,
+                                       const float* gloss, int64_t B, int n, int dtype, float mse_weight, void* glogits, float* gpred,
+                                       fgnn_stream_t stream) {
+    int rc = ll_check(logits, label, pred, sigma_b, B, n, dtype);
+    if (rc) return rc;
+    if (!gloss || !glogits || !gpred) FGNN_FAIL(FGNN_EINVAL, "ldpc_loss: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t nl = B * n;
+    const int grid = (int)((nl + 255) / 256);
+    if (dtype == FGNN_F32) hipLaunchKernelGGL(ldpc_loss_bwd_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)logits, label, pred, sigma_b, gloss, nl, B, mse_weight, (float*)glogits, gpred);
+    else hipLaunchKernelGGL(ldpc_loss_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t*)logits, label, pred, sigma_b, gloss, nl, B, mse_weight, (bf16_t*)glogits, gpred);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "ldpc_loss backward launch: %s", hipGetErrorString(e));
+    return FGNN_OK;
+}

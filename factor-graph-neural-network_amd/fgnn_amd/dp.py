@@ -15,6 +15,21 @@ import torch
 import torch.distributed as dist
 
 
+FLAT_ALIGN = 4      # elements: every parameter starts on a 16-byte boundary of the flat buffers (the kernels read filters with vector loads)
+
+
+def flat_layout(params, align=FLAT_ALIGN):
+    """(offsets, total): where each of ``params`` starts in a flat buffer, each start rounded up to ``align`` elements — a one-element
+    bias in the middle of a model would otherwise leave every later filter on an odd 4-byte boundary (the padding holds zeros: zero
+    gradients, zero moments, a zero Adam update)."""
+    offsets, off = [], 0
+    for p in params:
+        off = (off + align - 1) // align * align
+        offsets.append(off)
+        off += p.numel()
+    return offsets, (off + align - 1) // align * align
+
+
 def flatten_parameters(params):
     """Move float32 parameters into ONE flat buffer (every ``p.data`` becomes a view of it) and register it with the
     low-precision weight cache: the bf16 copies the library GEMMs read are then views of one mirror that a single cast
@@ -24,15 +39,13 @@ def flatten_parameters(params):
         raise ValueError('no parameters')
     if any(p.dtype != torch.float32 for p in params):
         raise ValueError('flatten_parameters needs float32 parameters')
-    flat = torch.empty(sum(p.numel() for p in params), device=params[0].device, dtype=torch.float32)
-    off = 0
+    offsets, total = flat_layout(params)
+    flat = torch.zeros(total, device=params[0].device, dtype=torch.float32)
     with torch.no_grad():
-        for p in params:
-            n = p.numel()
-            view = flat[off:off + n].view_as(p)
+        for p, off in zip(params, offsets):
+            view = flat[off:off + p.numel()].view_as(p)
             view.copy_(p.data)
             p.data = view
-            off += n
     from .mpnn import pointwise
     pointwise.register_flat_parameters(flat, params)
     return flat
@@ -118,14 +131,11 @@ class FlatGradBucket:
         if not self.params:
             raise ValueError('no trainable parameters')
         dev, dt = self.params[0].device, torch.float32
-        self.numel = sum(p.numel() for p in self.params)
+        self.offsets, self.numel = flat_layout(self.params)          # (numel: with the alignment padding)
         self.flat = torch.zeros(self.numel, device=dev, dtype=dt)
         self.flat_param = flatten_parameters(self.params) if flatten_params else None
-        off = 0
-        for p in self.params:
-            n = p.numel()
-            p.grad = self.flat[off:off + n].view_as(p)
-            off += n
+        for p, off in zip(self.params, self.offsets):
+            p.grad = self.flat[off:off + p.numel()].view_as(p)
         # the gradient kernels may add straight into these slices (ops.grad_sink): the bucket's contract is a plain
         # loss.backward() per step, which is what makes that safe
         from . import ops

@@ -128,11 +128,8 @@ class FastAdam(torch.optim.Optimizer):
         self.bucket.zero()
 
     def _slices(self):
-        off = 0
-        for q in self.bucket.params:
-            n = q.numel()
-            yield q, off, n
-            off += n
+        for q, off in zip(self.bucket.params, self.bucket.offsets):
+            yield q, off, q.numel()
 
     @torch.no_grad()
     def state_dict(self):

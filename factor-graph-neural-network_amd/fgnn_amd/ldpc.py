@@ -6,15 +6,18 @@ dims [64,64,64,128,256,256,128,64,64], 4 edge types on the 288 parity edges plus
 "hyper-factor" touching every variable, two edge-type MLPs and an SNR regressor head.
 32 message-operator calls per forward = 6144 VF+FV messages per codeword.
 """
+import os
+
 import numpy as np
 import torch
 
 from .mpnn.assemblies import FactorNN
-from .mpnn.pointwise import cast_cached
+from .mpnn.pointwise import cast_cached, bn_spec, _RowLinear, _BatchNormAct
 from .edge_mlp import EdgeMLP
 from .tables import LdpcGraph
 
 MESSAGES_PER_CODEWORD = 8 * (288 + 288 + 96 + 96)
+_FAST_REGRESSOR = os.environ.get('FGNN_NO_FAST_REGRESSOR', '') in ('', '0')      # tuning knob: the regressor head through torch's modules
 
 
 def _edge_mlp(cin, hidden, cout):
@@ -39,6 +42,25 @@ class LDPCModel(torch.nn.Module):
         self.nhop_regressor = torch.nn.Sequential(
             torch.nn.Linear(64, 128), torch.nn.BatchNorm1d(128), torch.nn.ReLU(),
             torch.nn.Linear(128, 128), torch.nn.ReLU(), torch.nn.Linear(128, 1), torch.nn.ReLU())
+
+    def _regress(self, hop):
+        """``nhop_regressor`` (train_ldpc.py:48-54,93: Linear -> BatchNorm1d -> ReLU -> Linear -> ReLU -> Linear -> ReLU on the
+        hyper-factor's state).  Training on bf16 activations: the same seven steps through this package's node-wise map / BatchNorm
+        kernels (statistics in the first map's epilogue, running statistics in their finaliser, weight gradients straight into the
+        flat bucket) — 8 + 16 launches instead of the ~30 + ~35 five-microsecond ones autocast + autograd issue for the seven torch
+        modules, all of them alone on the GPU at the step's turn-around (profiles/r05/train_step_sequence.csv; round 5 also tried
+        them on the side stream: slower, the joins cost more than the overlap buys)."""
+        reg = self.nhop_regressor
+        spec = bn_spec(reg[1]) if (_FAST_REGRESSOR and hop.is_cuda and hop.dtype == torch.bfloat16 and self.training
+                                   and torch.is_grad_enabled() and hop.shape[0] > 1) else None
+        if spec is None:
+            return reg(hop.float())
+        bn = reg[1]
+        z = _RowLinear.apply(hop.contiguous(), reg[0].weight, reg[0].bias, spec)
+        a = _BatchNormAct.apply(z, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps, 0.0, None,
+                                bn.num_batches_tracked, None, None, (1, 1, 1), 0)
+        a = torch.relu(_RowLinear.apply(a, reg[3].weight, reg[3].bias))
+        return torch.relu(_RowLinear.apply(a, reg[5].weight, reg[5].bias)).float()
 
     def _fanout_weights(self, dt):
         """``hetype_f2v`` [1, 1, 96, 1] in the activations' dtype.  When its 96 weights are equal (they are ones unless a checkpoint
@@ -75,11 +97,46 @@ class LDPCModel(torch.nn.Module):
         if self.with_residual:
             res = res + node_feature[:, :1, :, :]
         res = res.reshape(B, 96)
-        # (round 5, measured and dropped: the regressor's ~50 short launches on the side stream, beside the main stream's closing block +
-        # classifier + loss — 15.22 vs 15.05 ms per step, gpurun_out/r05m: the extra cross-queue joins at the step's turn-around cost
-        # more than the overlap of 5 us launches buys)
-        snr_pred = self.nhop_regressor(hops[1].reshape(B, -1).float())
+        snr_pred = self._regress(hops[1].reshape(B, -1))
         return res[:, :48].contiguous(), snr_pred
+
+
+class _DecodingLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, pred, label, sigma_b, mse_weight):
+        from . import _hip
+        B, n = logits.shape
+        loss = torch.empty((), device=logits.device, dtype=torch.float32)
+        _hip.check(_hip.lib().fgnn_ldpc_loss_forward(_hip._ptr(logits), _hip._ptr(label), _hip._ptr(pred), _hip._ptr(sigma_b), B, n,
+                                                     _hip.dtype_code(logits), mse_weight, _hip._ptr(loss), _hip.stream_ptr()))
+        ctx.save_for_backward(logits, pred, label, sigma_b)
+        ctx.mse_weight = mse_weight
+        return loss
+
+    @staticmethod
+    def backward(ctx, gloss):
+        from . import _hip
+        logits, pred, label, sigma_b = ctx.saved_tensors
+        B, n = logits.shape
+        gl, gp = torch.empty_like(logits), torch.empty_like(pred)
+        gloss = gloss.float().contiguous()
+        _hip.check(_hip.lib().fgnn_ldpc_loss_backward(_hip._ptr(logits), _hip._ptr(label), _hip._ptr(pred), _hip._ptr(sigma_b),
+                                                      _hip._ptr(gloss), B, n, _hip.dtype_code(logits), ctx.mse_weight, _hip._ptr(gl),
+                                                      _hip._ptr(gp), _hip.stream_ptr()))
+        return gl, gp, None, None, None
+
+
+def decoding_loss(logits, snr_pred, label, sigma_b, mse_weight=0.1):
+    """The training loss of /root/reference/train_ldpc.py:222-227 — BCE-with-logits on the decoded message bits + ``mse_weight`` x MSE of the
+    burst-amplitude regressor against 10^(sigma_b / 20), both means — as one launch forward and one backward on a ROCm device
+    (csrc/ldpc_datapath.hip: ldpc_loss_*_kernel; ~25 short torch launches otherwise); the same torch expression elsewhere."""
+    if (logits.is_cuda and logits.dim() == 2 and logits.dtype in (torch.float32, torch.bfloat16) and snr_pred.dtype == torch.float32
+            and snr_pred.numel() == logits.shape[0] and label.shape == logits.shape and sigma_b.numel() == logits.shape[0]):
+        return _DecodingLoss.apply(logits.contiguous(), snr_pred.contiguous(), label.float().contiguous(),
+                                   sigma_b.float().contiguous(), float(mse_weight))
+    bce = torch.nn.functional.binary_cross_entropy_with_logits(logits.reshape(-1).float(), label.reshape(-1).float())
+    mse = torch.nn.functional.mse_loss(snr_pred.reshape(-1).float(), torch.pow(10.0, sigma_b.float() / 20).reshape(-1))
+    return bce + mse_weight * mse
 
 
 def synthetic_batch(B, device, seed=0, dtype=torch.float32, shared_graph=True):

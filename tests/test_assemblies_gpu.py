@@ -224,9 +224,10 @@ def test_gradients_accumulated_in_place_equal_returned_gradients(dtype, dev):
     backward()
     assert float(bucket.flat.abs().max()) > 0
     tol = 1e-6 if dtype == 'f32' else 1e-5             # same kernels, same data: only 0 + s vs s
-    assert float((bucket.flat - want).abs().max()) <= tol * float(want.abs().max())
+    got = lambda: torch.cat([p.grad.reshape(-1) for p in bucket.params])       # (the flat buffer itself pads to 16-byte boundaries)
+    assert float((got() - want).abs().max()) <= tol * float(want.abs().max())
     backward()                                          # accumulates
-    assert float((bucket.flat - 2 * want).abs().max()) <= 2 * tol * float(want.abs().max())
+    assert float((got() - 2 * want).abs().max()) <= 2 * tol * float(want.abs().max())
 
 
 @pytest.mark.parametrize('shape', [(96, 48, 6), (48, 96, 3), (91, 47, 6), (37, 95, 3)], ids=lambda s: 'x'.join(map(str, s)))
@@ -1011,6 +1012,78 @@ def test_a_nested_backward_pass_does_not_lose_parked_launches(dev, monkeypatch):
     parked = run()
     assert not any(lst for lst in ops._DEFERRED.values())
     assert float(plain.abs().max()) > 0 and torch.equal(parked, plain)
+
+
+def test_regressor_head_through_the_map_kernels_matches_the_torch_modules(dev):
+    """LDPCModel._regress: the burst-noise regressor (train_ldpc.py:48-54,93) through this package's node-wise map / BatchNorm
+    kernels when training on bf16 activations, against the seven torch modules in f32 on the same input: prediction, input
+    gradient, every parameter's gradient, BatchNorm1d's running statistics and step counter."""
+    import copy
+    import fgnn_amd
+    from fgnn_amd import ldpc
+    torch.manual_seed(5)
+    m = fgnn_amd.LDPCModel(2, 6, 4).to(dev).train()
+    with torch.no_grad():
+        m.nhop_regressor[5].bias.fill_(2.0)      # the closing ReLU away from its kink (a bf16 / f32 sign flip there moves a whole row's gradient)
+    ref = copy.deepcopy(m.nhop_regressor).float()
+    fro = lambda a, b: float((a.float() - b.float()).norm() / b.float().norm())
+    g = torch.Generator().manual_seed(6)
+    hop = torch.randn(512, 64, generator=g).to(dev).to(torch.bfloat16)
+    gout = torch.randn(512, 1, generator=g).to(dev)
+    x1 = hop.clone().requires_grad_(True)
+    with torch.autocast('cuda', dtype=torch.bfloat16):
+        y1 = m._regress(x1)
+    assert y1.dtype == torch.float32 and y1.shape == (512, 1)
+    y1.backward(gout)
+    x2 = hop.float().requires_grad_(True)
+    y2 = ref(x2)
+    y2.backward(gout)
+    assert float(y2.abs().max()) > 0
+    assert float(y2.min()) > 0 and H.rel_err(y1, y2) <= 2e-2
+    # (bf16 activations between the maps against f32 ones; ReLU-kink flips of hidden units included: Frobenius norms)
+    assert fro(x1.grad, x2.grad) <= 8e-2
+    for (k, p1), (_, p2) in zip(m.nhop_regressor.named_parameters(), ref.named_parameters()):
+        if k == '0.bias':          # a bias in front of a batch-statistics BatchNorm: its true gradient is 0, both sides hold rounding noise
+            assert float(p1.grad.abs().max()) <= 1e-2 and float(p2.grad.abs().max()) <= 1e-5
+        else:
+            assert fro(p1.grad, p2.grad) <= 8e-2, k
+    assert int(m.nhop_regressor[1].num_batches_tracked) == 1
+    assert H.rel_err(m.nhop_regressor[1].running_mean, ref[1].running_mean) <= 1e-2
+    assert H.rel_err(m.nhop_regressor[1].running_var, ref[1].running_var) <= 1e-2
+    # eval mode / f32 activations / the switch: the torch modules
+    ldpc._FAST_REGRESSOR = False
+    try:
+        with torch.autocast('cuda', dtype=torch.bfloat16):
+            y3 = m._regress(hop)
+    finally:
+        ldpc._FAST_REGRESSOR = True
+    assert H.rel_err(y3.float(), y2) <= 3e-2
+    assert int(m.nhop_regressor[1].num_batches_tracked) == 2
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('B', [1, 7, 4096])
+def test_decoding_loss_kernel_vs_torch(B, dtype, dev):
+    """ldpc.decoding_loss (train_ldpc.py:222-227) as one launch each way against the torch expression in f32 on the same values:
+    the loss, the logits' and the regressor's gradients, under a non-unit upstream gradient; bit-reproducible."""
+    from fgnn_amd.ldpc import decoding_loss
+    g = torch.Generator().manual_seed(B)
+    logits = (torch.randn(B, 48, generator=g) * 4).to(dtype).to(dev)
+    pred = torch.rand(B, 1, generator=g).mul(3).to(dev)
+    label = torch.randint(0, 2, (B, 48), generator=g).float().to(dev)
+    sigma_b = torch.randint(0, 6, (B,), generator=g).float().to(dev)
+    l1, p1 = logits.clone().requires_grad_(True), pred.clone().requires_grad_(True)
+    loss = decoding_loss(l1, p1, label, sigma_b)
+    (loss * 1.5).backward()
+    l2, p2 = logits.float().clone().requires_grad_(True), pred.clone().requires_grad_(True)
+    ref = (torch.nn.functional.binary_cross_entropy_with_logits(l2.view(-1), label.view(-1)) +
+           0.1 * torch.nn.functional.mse_loss(p2.view(-1), torch.pow(10.0, sigma_b / 20).view(-1)))
+    (ref * 1.5).backward()
+    assert loss.shape == () and abs(float(loss) - float(ref)) <= 1e-5 * max(1.0, abs(float(ref)))
+    tol = 1e-6 if dtype == torch.float32 else 2.0 ** -8
+    assert float((l1.grad.float() - l2.grad).abs().max()) <= tol * float(l2.grad.abs().max())
+    assert float((p1.grad - p2.grad).abs().max()) <= 1e-6 * max(1e-3, float(p2.grad.abs().max()))
+    assert torch.equal(decoding_loss(logits, pred, label, sigma_b), loss.detach())
 
 
 def test_fast_path_switch_for_an_unchanged_script(dev):

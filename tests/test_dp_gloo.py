@@ -99,7 +99,12 @@ def _worker_adam(rank, world, port, out):
         (((net(X[lo:hi]) - Y[lo:hi]) ** 2).sum() * (world / 10.0)).backward()
         bucket.all_reduce_mean()
         opt.step()
-    torch.save(bucket.flat_param.clone(), os.path.join(out, 'adam%d.pt' % rank))
+    # (the flat buffers pad every parameter to a 16-byte boundary — dp.flat_layout; the padding must still be zero after 4 steps)
+    used = torch.zeros(bucket.numel, dtype=torch.bool)
+    for p, off in zip(bucket.params, bucket.offsets):
+        used[off:off + p.numel()] = True
+    assert float(bucket.flat_param[~used].abs().sum()) == 0
+    torch.save(torch.cat([p.detach().reshape(-1) for p in net.parameters()]), os.path.join(out, 'adam%d.pt' % rank))
     dist.destroy_process_group()
 
 
@@ -145,11 +150,9 @@ def test_flat_bucket_views_survive_backward():
     net = _net()
     bucket = FlatGradBucket(net.parameters())
     net(torch.ones(2, 6)).sum().backward()
-    off = 0
-    for p in bucket.params:
-        n = p.numel()
-        assert p.grad.data_ptr() == bucket.flat[off:off + n].data_ptr()     # still a view
-        off += n
+    for p, off in zip(bucket.params, bucket.offsets):
+        assert off % 4 == 0                                                   # every parameter on a 16-byte boundary (dp.flat_layout)
+        assert p.grad.data_ptr() == bucket.flat[off:off + p.numel()].data_ptr()     # still a view
     assert float(bucket.flat.abs().sum()) > 0
     bucket.zero()
     assert all(float(p.grad.abs().sum()) == 0 for p in bucket.params)

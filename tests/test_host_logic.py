@@ -330,7 +330,9 @@ def test_low_precision_weight_copies_are_refreshed_in_place():
     lin = torch.nn.Sequential(torch.nn.Linear(4, 3), torch.nn.Linear(3, 2))
     flat = flatten_parameters(lin.parameters())
     ps = list(lin.parameters())
-    assert flat.numel() == sum(p.numel() for p in ps) and all(p.data_ptr() >= flat.data_ptr() for p in ps)
+    # Linear(4,3), Linear(3,2): 12 + 3 (+1 pad) + 6 (+2) + 2 (+2) elements — every parameter starts on a 16-byte boundary
+    assert flat.numel() == 28 and [(p.data_ptr() - flat.data_ptr()) // 4 for p in ps] == [0, 12, 16, 24]
+    assert float(flat[15]) == 0 and float(flat[22:24].abs().sum()) == 0 and float(flat[26:].abs().sum()) == 0
     m0 = pointwise.cast_cached(ps[0], torch.bfloat16)
     m2 = pointwise.cast_cached(ps[2], torch.bfloat16)
     assert m0.shape == ps[0].shape and torch.equal(m0, ps[0].detach().bfloat16()) and torch.equal(m2, ps[2].detach().bfloat16())
@@ -456,3 +458,19 @@ def test_bench_gpus_n_never_degrades_to_one_rank():
     r = subprocess.run([sys.executable, bench, '--gpus', '1', '--steps', '1', '--warmup', '0'],
                        env=dict(env, WORLD_SIZE='2', RANK='0', LOCAL_RANK='0'), capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and 'WORLD_SIZE=2' in r.stderr and r.stdout.strip() == ''
+
+
+def test_decoding_loss_on_the_cpu_is_the_reference_expression():
+    """ldpc.decoding_loss off the GPU: train_ldpc.py:222-227's two torch calls, differentiable."""
+    from fgnn_amd.ldpc import decoding_loss
+    g = torch.Generator().manual_seed(0)
+    logits = torch.randn(5, 48, generator=g, requires_grad=True)
+    pred = torch.rand(5, 1, generator=g, requires_grad=True)
+    label = torch.randint(0, 2, (5, 48), generator=g).float()
+    sigma_b = torch.randint(0, 6, (5,), generator=g).float()
+    loss = decoding_loss(logits, pred, label, sigma_b)
+    ref = (torch.nn.functional.binary_cross_entropy_with_logits(logits.view(-1), label.view(-1)) +
+           0.1 * torch.nn.functional.mse_loss(pred.view(-1), torch.pow(10.0, sigma_b / 20).view(-1)))
+    assert torch.equal(loss, ref)
+    loss.backward()
+    assert logits.grad is not None and pred.grad is not None
