@@ -34,7 +34,6 @@ struct WgbParams {
     float* ws;           // [gridDim.x][S][WB_NACC][64]
     int R, Cin, Cout;
     int nso, S, RW;      // output-channel slices, slices per workgroup, row-waves per slice (S * RW == 16)
-    int stagger;
 };
 
 extern __shared__ __attribute__((aligned(16))) float wb_lds[];
@@ -93,16 +92,10 @@ __global__ __launch_bounds__(WB_THREADS) void linear_wgrad_b16_kernel(const WgbP
     };
     // no software prefetch: 16 waves per CU with 8 KB of loads each keep ~128 KB in flight per CU, and a
     // second register set would not fit the 128-VGPR budget of a 1024-thread workgroup
-    // The S slice-waves of a row-wave all need the same blocks.  Walking them in lock step keeps only 32 rows x (Cin + Cout) unique
-    // bytes in flight per CU (a 256 x 256 map: 32 KB -> 2.3 TB/s by Little's law, tools/wbench.py); with p.stagger every slice
-    // starts at its own offset of the (cyclic) walk, so the S waves have S different blocks in flight and the repeats hit L2 / MALL.
-    const int first = blockIdx.x * p.RW + rw;
-    const int nk = first < nblk ? (nblk - first + stride - 1) / stride : 0;
-    const int k0 = p.stagger ? (int)(((int64_t)slice * nk) / p.S) : 0;
-    for (int k = 0; k < nk; ++k) {
-        int kk = k0 + k;
-        if (kk >= nk) kk -= nk;
-        const int blk = first + kk * stride;
+    // (round 5, measured and dropped, gpurun_out/r05p / r05q: (a) staggering the S slice-waves of a row-wave over different blocks so
+    // that a 256 x 256 map has 16 blocks instead of one in flight per CU — 250 vs 178 us: the repeats then miss L1 and queue on L2;
+    // (b) folding the slabs in 2 KB contiguous pieces instead of 256-byte lines — no change for the wide maps, +5 us for 64 x 64)
+    for (int blk = blockIdx.x * p.RW + rw; blk < nblk; blk += stride) {
         load(blk);
         uint4 A[4], Bf[4];
         A[0] = wb_pack<0>(rg); A[1] = wb_pack<1>(rg); A[2] = wb_pack<2>(rg); A[3] = wb_pack<3>(rg);
@@ -385,7 +378,7 @@ int fgnn_linear_wgrad_b16(const void* x, const void* gy, int64_t R, int Cin, int
         if (workspace_bytes < (int64_t)gx * WN_NACC * 64 * 4) return 0;
         WgbParams p;
         p.x = (const uint16_t*)x; p.gy = (const uint16_t*)gy; p.ws = (float*)workspace;
-        p.R = (int)R; p.Cin = Cin; p.Cout = Cout; p.nso = 1; p.S = 1; p.RW = WB_WAVES; p.stagger = 0;
+        p.R = (int)R; p.Cin = Cin; p.Cout = Cout; p.nso = 1; p.S = 1; p.RW = WB_WAVES;
         const int lds = (WB_WAVES / 2) * WN_NACC * 64 * 4;
         hipStream_t st = (hipStream_t)stream;
         const int wide_c = nx ? Cout : Cin;
@@ -410,8 +403,6 @@ int fgnn_linear_wgrad_b16(const void* x, const void* gy, int64_t R, int Cin, int
     WgbParams p;
     p.x = (const uint16_t*)x; p.gy = (const uint16_t*)gy; p.ws = (float*)workspace;
     p.R = (int)R; p.Cin = Cin; p.Cout = Cout; p.nso = nso; p.S = S; p.RW = RW;
-    static const int stagger_min = getenv("FGNN_WB_STAGGER") ? atoi(getenv("FGNN_WB_STAGGER")) : 0;     // slices per workgroup from which the walk is staggered (0 = never)
-    p.stagger = stagger_min > 0 && S >= stagger_min;
     const int lds = S * (RW / 2) * WB_NACC * 64 * 4;                   // 0 when every slice has one row-wave
     void* fn = (void*)linear_wgrad_b16_kernel;
     if (lds > 48 * 1024) {
