@@ -85,22 +85,36 @@ __global__ __launch_bounds__(512) void mpconv_fwd_fanin_kernel(const FhParams p)
     const int nwaves = gridDim.x * p.waves;
     for (int b = blockIdx.x * p.waves + wave; b < d.B; b += nwaves) {
         const uint16_t* xb = p.x + (int64_t)b * d.x_sb;
-        // ---- P[n][o] for all nodes: B[k = c][j = n] straight from global (16 bytes per lane) ----
-        for (int nt = 0; nt < ntile; ++nt) {
-            const int n = nt * 16 + li;
-            uint4 bx[KS2];
+        // ---- P[n][o] for all nodes: B[k = c][j = n] straight from global (16 bytes per lane).  The launch gives every wave ONE
+        //      sample (4096 waves at the benched batch), so the kernel's duration is one wave's dependency chain: all the loads of
+        //      TB node tiles (the whole sample at 64 input channels) are in flight together (tile by tile: six HBM round trips; 33.3 ->
+        //      30.0 us per launch for 51 MB).  Measured with the phases switched off (gpurun_out/r05s): 4 us fixed (W fragments), + 13 us
+        //      projection, + 12 us neighbour walk; a persistent grid (256 / 512 workgroups) is slower (44 / 31 us) ----
+        constexpr int TB = KS2 == 2 ? 6 : 3;
+        for (int nt0 = 0; nt0 < ntile; nt0 += TB) {
+            uint4 bx[TB][KS2];
 #pragma unroll
-            for (int ks = 0; ks < KS2; ++ks)
-                bx[ks] = n < N ? *reinterpret_cast<const uint4*>(xb + (int64_t)n * NIN + 32 * ks + 8 * lk) : make_uint4(0, 0, 0, 0);
-#pragma unroll
-            for (int ot = 0; ot < OT; ++ot) {
-                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            for (int t = 0; t < TB; ++t) {
+                const int n = (nt0 + t) * 16 + li;
 #pragma unroll
                 for (int ks = 0; ks < KS2; ++ks)
-                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aP[ot][ks], __builtin_bit_cast(fh_bf16x8, bx[ks]), acc, 0, 0, 0);
-                // D[i = o 4lk+r][j = n]: four consecutive channels of node n
-                *reinterpret_cast<uint2*>(Pl + n * NOU + ot * 16 + 4 * lk) =
-                    make_uint2(fh_pack2(acc[0], acc[1]), fh_pack2(acc[2], acc[3]));
+                    bx[t][ks] = n < N ? *reinterpret_cast<const uint4*>(xb + (int64_t)n * NIN + 32 * ks + 8 * lk) : make_uint4(0, 0, 0, 0);
+            }
+#pragma unroll
+            for (int t = 0; t < TB; ++t) {
+                const int n = (nt0 + t) * 16 + li;
+                if (nt0 + t < ntile) {
+#pragma unroll
+                    for (int ot = 0; ot < OT; ++ot) {
+                        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int ks = 0; ks < KS2; ++ks)
+                            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aP[ot][ks], __builtin_bit_cast(fh_bf16x8, bx[t][ks]), acc, 0, 0, 0);
+                        // D[i = o 4lk+r][j = n]: four consecutive channels of node n
+                        *reinterpret_cast<uint2*>(Pl + n * NOU + ot * 16 + 4 * lk) =
+                            make_uint2(fh_pack2(acc[0], acc[1]), fh_pack2(acc[2], acc[3]));
+                    }
+                }
             }
         }
         // ---- neighbour reduction, lane <-> output channel (wave-private LDS image: no barrier needed, but the
@@ -121,21 +135,34 @@ __global__ __launch_bounds__(512) void mpconv_fwd_fanin_kernel(const FhParams p)
                 ew = __uint_as_float((unsigned)eb[(int64_t)(j0 + lane) * d.et_sk] << 16);
             }
             const int jn = min(64, k - j0);
-            for (int j = 0; j < jn; ++j) {
-                const int n = __builtin_amdgcn_readlane(nid, j);
-                const float e = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ew), j));
+            for (int jg = 0; jg < jn; jg += 8) {           // eight neighbours at a time: their P reads are issued together
+                float e8[8], pv[8][NO];
 #pragma unroll
-                for (int q = 0; q < NO; ++q) {
-                    float v = e * __uint_as_float((unsigned)Pl[n * NOU + lane + 64 * q] << 16);
-                    if constexpr (AGG == FGNN_AGG_MAX) {
-                        if (j0 + j == 0 || v > best[q]) { best[q] = v; arg[q] = j0 + j; }   // strict >: first occurrence
-                    } else if constexpr (AGG == FGNN_AGG_LSE) {
-                        v *= 3.0f;
-                        if (j0 + j == 0) { best[q] = v; ssum[q] = 1.0f; }
-                        else if (v > best[q]) { ssum[q] = ssum[q] * expf(best[q] - v) + 1.0f; best[q] = v; }
-                        else ssum[q] += expf(v - best[q]);
-                    } else {
-                        ssum[q] += v;
+                for (int u = 0; u < 8; ++u) {
+                    const int j = min(jg + u, jn - 1);
+                    const int n = __builtin_amdgcn_readlane(nid, j);
+                    e8[u] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ew), j));
+#pragma unroll
+                    for (int q = 0; q < NO; ++q) pv[u][q] = __uint_as_float((unsigned)Pl[n * NOU + lane + 64 * q] << 16);
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    if (jg + u < jn) {
+                        const int jj = j0 + jg + u;
+#pragma unroll
+                        for (int q = 0; q < NO; ++q) {
+                            float v = e8[u] * pv[u][q];
+                            if constexpr (AGG == FGNN_AGG_MAX) {
+                                if (jj == 0 || v > best[q]) { best[q] = v; arg[q] = jj; }   // strict >: first occurrence
+                            } else if constexpr (AGG == FGNN_AGG_LSE) {
+                                v *= 3.0f;
+                                if (jj == 0) { best[q] = v; ssum[q] = 1.0f; }
+                                else if (v > best[q]) { ssum[q] = ssum[q] * expf(best[q] - v) + 1.0f; best[q] = v; }
+                                else ssum[q] += expf(v - best[q]);
+                            } else {
+                                ssum[q] += v;
+                            }
+                        }
                     }
                 }
             }
