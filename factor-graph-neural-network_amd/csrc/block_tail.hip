@@ -751,6 +751,7 @@ __global__ __launch_bounds__(BT_THREADS, 3) void block_head_bwd_kernel(const BhP
         }
         load2(it + HD, rz[d], rgq[d]);
         __builtin_amdgcn_sched_barrier(0);
+        if (!p.gx) continue;                              // gz1 only: conv1's input gradient is formed elsewhere (fgnn_linear_multi_forward)
         f32x4 acc[4];
 #pragma unroll
         for (int ot = 0; ot < 4; ++ot) {
@@ -775,13 +776,14 @@ int fgnn_bn_backward_sums_bf16(const void* x, const void* gy, int64_t R, int C, 
                                void* workspace, void* fold_scratch, hipStream_t st, const float** dsum_out);
 
 // BatchNorm1 + activation backward and conv1's input gradient (see above).  z1 / ga1 [R][64] bf16, W1 [64][Cin] f32 (Cin in
-// {64, 128, 256}), gz1 [R][64] and gx [R][Cin] bf16 out, gweight / gbias [64] ACCUMULATED into (BatchNorm1's parameter gradients).
+// {64, 128, 256}), gz1 [R][64] and gx [R][Cin] bf16 out (gx NULL: only gz1 — the caller multiplies it by W1 together with the state's
+// other gradients, fgnn_linear_multi_forward), gweight / gbias [64] ACCUMULATED into (BatchNorm1's parameter gradients).
 // workspace: fgnn_bn_workspace_bytes(R, 64).
 extern "C" int fgnn_block_head_backward(const void* z1, const void* ga1, const float* mean, const float* invstd,
                                         const float* gamma, const float* beta, float slope, const float* W1, void* gz1,
                                         void* gx, float* gweight, float* gbias, int64_t R, int Cin, void* workspace,
                                         int64_t workspace_bytes, void* fold_scratch, fgnn_stream_t stream) {
-    if (!z1 || !ga1 || !mean || !invstd || !gamma || !beta || !W1 || !gz1 || !gx || !workspace)
+    if (!z1 || !ga1 || !mean || !invstd || !gamma || !beta || !W1 || !gz1 || !workspace)
         FGNN_FAIL(FGNN_EINVAL, "block_head_backward: null pointer");
     int grid;
     if (bt_plan(R, Cin, &grid) || (((uintptr_t)z1 | (uintptr_t)ga1 | (uintptr_t)gz1 | (uintptr_t)gx) & 15))

@@ -412,3 +412,169 @@ extern "C" int fgnn_linear_instnorm_forward(const void* x, const float* W, const
     if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "linear_instnorm_forward launch: %s", hipGetErrorString(e));
     return FGNN_OK;
 }
+
+// ----------------------------------------------------------------------------------------
+// Several maps INTO ONE tensor (round 5): y[r][o] = sum_s sum_c x_s[r][c] W_s[c][o] + addend_0[r][o] + addend_1[r][o] + addend_2[r][o].
+//
+// In a FactorNN layer (/root/reference/lib/model/mpnn/factor_mpnn_sp.py:136-168) the variables' state feeds the v2v map and one
+// block per factor type, so its gradient is the sum of their input gradients — each one `gz_s W_s` with a different gz (64 channels
+// behind a block's conv1, the next layer's width behind the node-wise map) — plus the gradients that arrive unchanged (the residual,
+// a skip link).  Staged, every consumer wrote its [R][C] product and an n-input sum read them all back: 5.7 GB of sum_n traffic +
+// 3 x [R][C] of writes per layer state out of the step's 52 GB (gpurun_out/r05p/traffic).  Here the narrow gz_s are the operands and
+// the sum never leaves the accumulators: one K-concatenated product, the addends joined in f32 before the one rounding.
+// Up to three sources (KS0 / KS1 / KS2 k-steps of 32 channels; 0 = absent), W_s [K_s][Cout] f32 row-major (a map's [cout'][cin']
+// weight as it lies in memory), Cout in {64, 128, 256}; wide products are split over the grid's y dimension so that the bf16 image
+// of the stacked W stays under 150 KB of LDS.
+// ----------------------------------------------------------------------------------------
+struct LmParams {
+    const uint16_t* x[3];    // [R][K_s] bf16
+    const float* W[3];       // [K_s][Cout] f32
+    const uint16_t* add[3];  // [R][Cout] bf16 or NULL
+    uint16_t* y;             // [R][Cout]
+    int R, Cout;             // Cout: full row width of y / W / addends
+    int NW;                  // output channels per workgroup (64 CG): blockIdx.y selects the slice
+    int CG;
+};
+
+template <int KS0, int KS1, int KS2>
+__global__ __launch_bounds__(LF_THREADS) void linear_multi_b16_kernel(const LmParams p) {
+    constexpr int KS = KS0 + KS1 + KS2, KT = 32 * KS, WS = KT + 8, OTW = 4;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lk = lane >> 4;
+    const int R = p.R, Cout = p.Cout, NW = p.NW;
+    const int n0 = blockIdx.y * NW;
+    const int cg = wave % p.CG, rg = wave / p.CG, nrg = LF_WAVES / p.CG;
+    uint16_t* Wl = reinterpret_cast<uint16_t*>(lf_lds);                    // [NW][WS] bf16: row o = output channel n0 + o, column = stacked k
+    {
+        constexpr int K0 = 32 * KS0, K1 = 32 * KS1, K2 = 32 * KS2;
+        for (int f = tid; f < K0 * NW; f += LF_THREADS) { const int c = f / NW, o = f - c * NW; const __bf16 h = (__bf16)p.W[0][(int64_t)c * Cout + n0 + o]; Wl[o * WS + c] = __builtin_bit_cast(uint16_t, h); }
+        for (int f = tid; f < K1 * NW; f += LF_THREADS) { const int c = f / NW, o = f - c * NW; const __bf16 h = (__bf16)p.W[1][(int64_t)c * Cout + n0 + o]; Wl[o * WS + K0 + c] = __builtin_bit_cast(uint16_t, h); }
+        for (int f = tid; f < K2 * NW; f += LF_THREADS) { const int c = f / NW, o = f - c * NW; const __bf16 h = (__bf16)p.W[2][(int64_t)c * Cout + n0 + o]; Wl[o * WS + K0 + K1 + c] = __builtin_bit_cast(uint16_t, h); }
+    }
+    __syncthreads();
+    const int o_base = cg * OTW * 16;                     // this wave's first channel inside the slice
+    auto orow = [&](int ot) { return 16 * (li >> 2) + 4 * ot + (li & 3); };     // (the channel permutation of linear_fwd_b16_kernel)
+    // k-step ks of source s, k-group lk  <->  that source's channels 8 KS_s lk + 8 ks .. + 7: one contiguous 16 KS_s-byte run per lane and source
+    auto wcol = [&](int g) {                                // stacked column of global k-step g
+        return g < KS0 ? 8 * KS0 * lk + 8 * g : (g < KS0 + KS1 ? 32 * KS0 + 8 * KS1 * lk + 8 * (g - KS0) : 32 * (KS0 + KS1) + 8 * KS2 * lk + 8 * (g - KS0 - KS1));
+    };
+    const int ntile = (R + 15) / 16;
+    const int stride = gridDim.x * nrg;
+    auto load_tile = [&](int tile, uint4 (&bx)[KS]) {
+        const int row = tile * 16 + li;
+        const bool ok = tile < ntile && row < R;
+#pragma unroll
+        for (int g = 0; g < KS; ++g) {
+            const uint16_t* src = g < KS0 ? p.x[0] + (int64_t)row * (32 * KS0) + 8 * KS0 * lk + 8 * g
+                                : (g < KS0 + KS1 ? p.x[1] + (int64_t)row * (32 * KS1) + 8 * KS1 * lk + 8 * (g - KS0)
+                                                 : p.x[2] + (int64_t)row * (32 * KS2) + 8 * KS2 * lk + 8 * (g - KS0 - KS1));
+            bx[g] = ok ? *reinterpret_cast<const uint4*>(src) : make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto unpack8 = [](const uint4& q, float (&v)[8]) {
+        v[0] = __uint_as_float(q.x << 16); v[1] = __uint_as_float(q.x & 0xffff0000u); v[2] = __uint_as_float(q.y << 16); v[3] = __uint_as_float(q.y & 0xffff0000u);
+        v[4] = __uint_as_float(q.z << 16); v[5] = __uint_as_float(q.z & 0xffff0000u); v[6] = __uint_as_float(q.w << 16); v[7] = __uint_as_float(q.w & 0xffff0000u);
+    };
+    uint4 nx[KS];
+    load_tile(blockIdx.x * nrg + rg, nx);
+    for (int tile = blockIdx.x * nrg + rg; tile < ntile; tile += stride) {
+        const int row = tile * 16 + li;
+        const bool ok = row < R;
+        uint4 bx[KS];
+#pragma unroll
+        for (int g = 0; g < KS; ++g) bx[g] = nx[g];
+        // the addends of this lane's 16 output channels (two 16-byte pieces per addend), in flight with the next tile's rows
+        uint4 ad[3][2];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const uint16_t* ap = p.add[a] ? p.add[a] + (int64_t)row * Cout + n0 + o_base + 16 * lk : nullptr;
+            ad[a][0] = (ap && ok) ? *reinterpret_cast<const uint4*>(ap) : make_uint4(0, 0, 0, 0);
+            ad[a][1] = (ap && ok) ? *reinterpret_cast<const uint4*>(ap + 8) : make_uint4(0, 0, 0, 0);
+        }
+        load_tile(tile + stride, nx);
+        const uint16_t* wl = Wl;
+        if constexpr (KS > 4) asm volatile("" : "+v"(wl));     // W fragments are re-read from LDS per tile: hoisted out of the loop they are 16 KS registers (spills from 10 k-steps on)
+        f32x4 acc[OTW];
+#pragma unroll
+        for (int ot = 0; ot < OTW; ++ot) {
+            acc[ot] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int g = 0; g < KS; ++g) {
+                const lf_bf16x8 a = __builtin_bit_cast(lf_bf16x8, *reinterpret_cast<const uint4*>(wl + (o_base + orow(ot)) * WS + wcol(g)));
+                acc[ot] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, __builtin_bit_cast(lf_bf16x8, bx[g]), acc[ot], 0, 0, 0);
+            }
+        }
+        if (ok) {       // acc[ot][r] = channel n0 + o_base + 16 lk + 4 ot + r of this lane's row
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                if (p.add[a]) {
+                    float v0[8], v1[8];
+                    unpack8(ad[a][0], v0); unpack8(ad[a][1], v1);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { acc[0][r] += v0[r]; acc[1][r] += v0[4 + r]; acc[2][r] += v1[r]; acc[3][r] += v1[4 + r]; }
+                }
+            }
+            uint16_t* yp = p.y + (int64_t)row * Cout + n0 + o_base + 16 * lk;
+            *reinterpret_cast<uint4*>(yp) = make_uint4(lf_pack2(acc[0][0], acc[0][1]), lf_pack2(acc[0][2], acc[0][3]),
+                                                       lf_pack2(acc[1][0], acc[1][1]), lf_pack2(acc[1][2], acc[1][3]));
+            *reinterpret_cast<uint4*>(yp + 8) = make_uint4(lf_pack2(acc[2][0], acc[2][1]), lf_pack2(acc[2][2], acc[2][3]),
+                                                           lf_pack2(acc[3][0], acc[3][1]), lf_pack2(acc[3][2], acc[3][3]));
+        }
+    }
+}
+
+static void* lm_pick(int k0, int k1, int k2) {
+#define LM_CASE(a, b, c) if (k0 == a && k1 == b && k2 == c) return (void*)linear_multi_b16_kernel<a, b, c>;
+    LM_CASE(2, 0, 0) LM_CASE(2, 0, 2)
+    LM_CASE(2, 2, 0) LM_CASE(2, 4, 0) LM_CASE(2, 8, 0)
+    LM_CASE(2, 2, 2) LM_CASE(2, 4, 2) LM_CASE(2, 8, 2)
+    LM_CASE(0, 2, 0) LM_CASE(0, 4, 0) LM_CASE(0, 8, 0)
+#undef LM_CASE
+    return nullptr;
+}
+
+// 1 if the source widths (slot 0 and 2: 0 or 64 channels; slot 1: 0, 64, 128 or 256) and the output width are the kernel's.
+extern "C" int fgnn_linear_multi_supported(int64_t R, const int32_t* K, int Cout) {
+    if (!K || R <= 0 || R > 0x7fffffff || (Cout != 64 && Cout != 128 && Cout != 256)) return 0;
+    for (int s = 0; s < 3; ++s) if (K[s] % 32) return 0;
+    return lm_pick(K[0] / 32, K[1] / 32, K[2] / 32) != nullptr;
+}
+
+extern "C" int fgnn_linear_multi_forward(const void* const* x, const int32_t* K, const float* const* W, const void* const* addend,
+                                         void* y, int64_t R, int Cout, fgnn_stream_t stream) {
+    if (!x || !K || !W || !addend || !y) FGNN_FAIL(FGNN_EINVAL, "linear_multi_forward: null pointer");
+    if (!fgnn_linear_multi_supported(R, K, Cout))
+        FGNN_FAIL(FGNN_EUNSUPPORTED, "linear_multi_forward: K = (%d, %d, %d) -> %d outside the kernel's family", K[0], K[1], K[2], Cout);
+    LmParams p = {};
+    int kt = 0;
+    for (int s = 0; s < 3; ++s) {
+        p.x[s] = (const uint16_t*)x[s]; p.W[s] = W[s]; p.add[s] = (const uint16_t*)addend[s];
+        if (K[s] && (!x[s] || !W[s] || ((uintptr_t)x[s] & 15))) FGNN_FAIL(FGNN_EINVAL, "linear_multi_forward: source %d missing or misaligned", s);
+        if (addend[s] && ((uintptr_t)addend[s] & 15)) FGNN_FAIL(FGNN_EUNSUPPORTED, "linear_multi_forward: addend %d is not 16-byte aligned", s);
+        kt += K[s];
+    }
+    if ((uintptr_t)y & 15) FGNN_FAIL(FGNN_EUNSUPPORTED, "linear_multi_forward: y is not 16-byte aligned");
+    p.y = (uint16_t*)y; p.R = (int)R; p.Cout = Cout;
+    int NW = Cout;
+    while ((int64_t)NW * (kt + 8) * 2 > 150 * 1024 && NW > 64) NW /= 2;
+    p.NW = NW; p.CG = NW / 64;
+    const int nrg = LF_WAVES / p.CG;
+    const int64_t ntile = (R + 15) / 16;
+    int64_t g = (ntile + 2 * nrg - 1) / (2 * nrg);
+    const int ny = Cout / NW;
+    const int maxg = LF_MAXGRID / ny > 0 ? LF_MAXGRID / ny : 1;
+    if (g > maxg) g = maxg;
+    if (g < 1) g = 1;
+    void* fn = lm_pick(K[0] / 32, K[1] / 32, K[2] / 32);
+    const int lds = NW * (kt + 8) * 2;
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "hipFuncSetAttribute(%d B LDS): %s", lds, hipGetErrorString(e));
+    }
+    fgnn_note_kernel("linear_multi_b16_kernel<%d, %d, %d>", K[0] / 32, K[1] / 32, K[2] / 32);
+    void* args[] = {(void*)&p};
+    hipError_t e = hipLaunchKernel(fn, dim3((unsigned)g, (unsigned)ny), dim3(LF_THREADS), args, lds, (hipStream_t)stream);
+    if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "linear_multi_forward launch: %s", hipGetErrorString(e));
+    return FGNN_OK;
+}

@@ -21,6 +21,8 @@
 #include "fgnn_common.h"
 #include <stdlib.h>
 
+bool fgnn_fold_push(const float* ws, int nslab, int64_t slab_len, int64_t nw, float* gW, float* gb, int kind, int a, int b, int c, int d);   // fold_batch.hip
+
 #define WB_THREADS 1024
 #define WB_WAVES 16
 #define WB_NACC 68       // 64 gW accumulators + 4 dbias partials per lane
@@ -414,6 +416,7 @@ int fgnn_linear_wgrad_b16(const void* x, const void* gy, int64_t R, int Cin, int
     hipError_t e = hipLaunchKernel(fn, dim3(gx), dim3(WB_THREADS), args, lds, st);
     if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "linear_wgrad_b16 launch: %s", hipGetErrorString(e));
     const int64_t slab_len = (int64_t)S * WB_NACC * 64;
+    if (fgnn_fold_push(p.ws, gx, slab_len, slab_len, gW, gb, 1, S, nso, Cin, Cout)) return 1;      // recorded (fold_batch.hip)
     hipLaunchKernelGGL(wgb_reduce_kernel, dim3((unsigned)(slab_len / 64)), dim3(1024), 0, st, p.ws, gx, S, nso, Cin,
                        Cout, gW, gb);
     e = hipGetLastError();

@@ -601,8 +601,11 @@ __global__ __launch_bounds__(1024) void bres_reduce_kernel(const float* __restri
 }
 
 // Shared with mpconv_bwd_hyper.hip: fold `nslab` slabs of [nw + nou] floats into gW / gbias.
+bool fgnn_fold_push(const float* ws, int nslab, int64_t slab_len, int64_t nw, float* gW, float* gb, int kind, int a, int b, int c, int d);   // fold_batch.hip
+
 void fgnn_launch_slab_reduce(const float* ws, int nslab, int64_t slab_len, int64_t nw, float* gW, float* gbias,
                              hipStream_t st) {
+    if (fgnn_fold_push(ws, nslab, slab_len, nw, gW, gbias, 0, 1, 1, 0, 0)) return;       // recorded: one launch folds every slab set of the pass
     hipLaunchKernelGGL(bres_reduce_kernel, dim3((unsigned)((slab_len + 63) / 64)), dim3(1024), 0, st, ws, nslab,
                        slab_len, nw, gW, gbias, 0, 1, 1);
 }
@@ -610,6 +613,7 @@ void fgnn_launch_slab_reduce(const float* ws, int nslab, int64_t slab_len, int64
 // The same with the slab's [nw / ncols][ncols] weight block landing in rows `ld` apart (a column block of a wider gfilters).
 void fgnn_launch_slab_reduce_ld(const float* ws, int nslab, int64_t slab_len, int64_t nw, int ncols, int ld, float* gW,
                                 float* gbias, hipStream_t st) {
+    if (fgnn_fold_push(ws, nslab, slab_len, nw, gW, gbias, 0, ncols, ld, 0, 0)) return;
     hipLaunchKernelGGL(bres_reduce_kernel, dim3((unsigned)((slab_len + 63) / 64)), dim3(1024), 0, st, ws, nslab,
                        slab_len, nw, gW, gbias, 0, ncols, ld);
 }

@@ -622,7 +622,7 @@ int fgnn_mpconv_backward_sg(const fgnn_mpconv_desc* d, const void* x, const int6
     if (((uintptr_t)x & 15) || ((uintptr_t)gz & 15) || ((uintptr_t)etype & 7) || ((uintptr_t)argmax & 7) ||
         ((uintptr_t)gx & 7)) BS_REJECT(12);
     const int64_t nw = (int64_t)d->nin * 64 * 4, slab_len = nw + 64;                  // of ONE launch (64 output channels)
-    if (!workspace || workspace_bytes < 256 * slab_len * 4) BS_REJECT(13);
+    if (!workspace || workspace_bytes < (split ? 2 : 1) * 256 * slab_len * 4) BS_REJECT(13);
     const int NPW = (d->N + BS_WAVES - 1) / BS_WAVES, DPW = (d->M + BS_WAVES - 1) / BS_WAVES;
     void* fn = nullptr;
     const int GSL = (d->M * 16 + BS_THREADS - 1) / BS_THREADS;
@@ -693,6 +693,7 @@ int fgnn_mpconv_backward_sg(const fgnn_mpconv_desc* d, const void* x, const int6
     else {
         // slab rows are 256 columns of gfilters' 512: lower half, then the second launch on the upper 64 output channels
         fgnn_launch_slab_reduce_ld(p.ws, grid, slab_len, nw, 256, 512, gfilters, gbias, st);
+        p.ws += (int64_t)grid * slab_len;            // (its own slabs: the first launch's fold may be a recorded one, fold_batch.hip)
         p.W += 256; p.gz += 64; p.argmax += 64; p.accum = 1;
         e = hipLaunchKernel(fn, dim3(grid), dim3(BS_THREADS), args, lds, st);
         if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "mpconv sg backward launch (upper half): %s", hipGetErrorString(e));

@@ -863,7 +863,7 @@ int fgnn_mpconv_backward_ws(const fgnn_mpconv_desc* d, const void* x, const int6
         ((uintptr_t)etype & 7)) BW_REJECT(5);
     if ((d->x_sb % 8) != 0 || (d->y_sb % 8) != 0 || (d->et_sb % 4) != 0) BW_REJECT(6);
     const int64_t nw = 64 * 256, slab_len = nw + 64;
-    if (!workspace || workspace_bytes < 256 * slab_len * 4) BW_REJECT(7);
+    if (!workspace || workspace_bytes < ((split || ksplit) ? 2 : 1) * 256 * slab_len * 4) BW_REJECT(7);
 
     BwParams p;
     p.x = (const uint16_t*)x; p.idx = nn_idx; p.et = (const uint16_t*)etype; p.W = filters;
@@ -916,6 +916,7 @@ int fgnn_mpconv_backward_ws(const fgnn_mpconv_desc* d, const void* x, const int6
 #endif
     if (ksplit) {
         fgnn_launch_slab_reduce(p.ws, grid, slab_len, nw, gfilters, gbias, st);                  // rows 0..63 of gfilters, dbias
+        p.ws += (int64_t)grid * slab_len;                                                         // (its own slabs: the first launch's fold may be a recorded one)
         p.x += 64; p.W += 64 * (int64_t)p.w_ld; p.gx += 64; p.accum = 2;                          // input channels 64..127: getype accumulates
         e = hipLaunchKernel(fn, dim3(grid), dim3(BW_THREADS), args, off_b, st);
         if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "mpconv ws backward launch (upper input channels): %s", hipGetErrorString(e));
@@ -925,6 +926,7 @@ int fgnn_mpconv_backward_ws(const fgnn_mpconv_desc* d, const void* x, const int6
         // slab rows are 256 columns of gfilters' 512: lower half, then the second launch on the upper 64 output channels, which ADDS
         // to gx / getype (one more bf16 rounding of those two) and folds its dW / dbias into the upper column / channel blocks
         fgnn_launch_slab_reduce_ld(p.ws, grid, slab_len, nw, 256, 512, gfilters, gbias, st);
+        p.ws += (int64_t)grid * slab_len;
         p.W += 256; p.gz += 64; p.argmax += 64; p.accum = 3;
         e = hipLaunchKernel(fn, dim3(grid), dim3(BW_THREADS), args, off_b, st);
         if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "mpconv ws backward launch (upper half): %s", hipGetErrorString(e));

@@ -155,6 +155,7 @@ class FlatGradBucket:
                 if st != cur:
                     cur.wait_stream(st)
             ops._DEFER_ISSUED.clear()
+        ops.flush_folds()        # (folds a dead pass recorded and never flushed: in front of the zeroing, like its parked launches)
         self.flat.zero_()
 
     @property

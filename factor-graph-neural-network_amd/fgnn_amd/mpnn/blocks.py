@@ -103,7 +103,7 @@ class iid_mapping_in(torch.nn.Module):
         _hip.check(rc[0])
         if not grad:
             return y.permute(0, 3, 1, 2)
-        zz = _RowLinear.apply(rows, weight, conv.bias, False, z)
+        zz = _RowLinear.apply(rows, weight, conv.bias, False, z, ops.fan_box(x))
         return _InstNormAct.apply(zz.view(B, N, 1, cout).permute(0, 3, 1, 2), norm.relu, y)
 
 
@@ -162,7 +162,8 @@ class _BlockHead(torch.autograd.Function):
     in the input-gradient GEMM.  gz1 is still stored once for conv1's weight-gradient kernel, which is parked like every other."""
 
     @staticmethod
-    def forward(ctx, rows, weight, bias, bn_w, bn_b, rm, rv, nbt, momentum, eps, slope):
+    def forward(ctx, rows, weight, bias, bn_w, bn_b, rm, rv, nbt, momentum, eps, slope, box=None):
+        ctx.box = box                   # the ops.FanBox of the state `rows` views: the backward deposits (gz1, W1) there instead of forming gx
         from .. import _hip
         from . import pointwise
         L = _hip.lib()
@@ -204,24 +205,36 @@ class _BlockHead(torch.autograd.Function):
         gW, s_W = sink(Wbase, (64, cin))
         gbias, s_bias = sink(pbias, (64,)) if pbias is not None else (None, True)
         gz1 = torch.empty_like(z1)
-        gx = torch.empty((R, cin), device=dev, dtype=z1.dtype)
+        lazy = ctx.needs_input_grad[0] and ctx.box is not None and weight.is_contiguous() and weight.dtype == torch.float32
+        gx = None if lazy else torch.empty((R, cin), device=dev, dtype=z1.dtype)
         ws = ops._workspace(dev, int(L.fgnn_bn_workspace_bytes(R, 64)))
         ops.timed('block_head_backward (reduce + finalise + grad)', 2 * R * (5 * 64 + cin), lambda: _hip.check(L.fgnn_block_head_backward(
             P(z1), P(ga1), P(stats[0]), P(stats[1]), P(bn_w.detach()), P(bn_b.detach()), ctx.slope, P(weight.detach()), P(gz1), P(gx),
             P(gw1), P(gb1), R, cin, P(ws), ws.numel() * 4, P(ops._fold_scratch(dev)), _hip.stream_ptr())), nflops=2 * R * 64 * cin)
 
+        record = s_W and s_bias and ops.folds_deferrable()
+
         def launch(rows=rows, gz1=gz1, gW=gW, gbias=gbias):
-            wsw = ops._workspace(dev, int(L.fgnn_linear_wgrad_workspace_bytes(R, cin, 64)))
-            ops.timed('linear_wgrad_b16_kernel', 2 * R * (cin + 64), lambda: _hip.check(L.fgnn_linear_wgrad(
-                P(rows), P(gz1), R, cin, 64, _hip.BF16, P(gW.view(64, cin)), P(gbias), P(wsw), wsw.numel() * 4, _hip.stream_ptr())),
-                nflops=2 * R * cin * 64)
+            with ops.fold_scope(record) as scope:
+                wsw = scope.slabs(dev, int(L.fgnn_linear_wgrad_workspace_bytes(R, cin, 64)))
+                ops.timed('linear_wgrad_b16_kernel', 2 * R * (cin + 64), lambda: _hip.check(L.fgnn_linear_wgrad(
+                    P(rows), P(gz1), R, cin, 64, _hip.BF16, P(gW.view(64, cin)), P(gbias), P(wsw), wsw.numel() * 4, _hip.stream_ptr())),
+                    nflops=2 * R * cin * 64)
         if s_W and s_bias:
             ops.defer_wgrad(launch, (rows, gz1))
         else:
             launch()
+        if lazy:
+            if ctx.box.deposit(gz1, weight.detach()):
+                gx = ctx.box.placeholder(rows.shape)
+            else:                                        # no slot: the product after all (gz1 is in the infinity cache)
+                from . import pointwise
+                gx = pointwise.hip_linear(gz1, weight.detach(), None, transposed=True)
+                if gx is None:
+                    gx = gz1 @ pointwise.cast_cached(pW._base if pW._base is not None else pW, gz1.dtype).view(weight.shape)
         return (gx if ctx.needs_input_grad[0] else None, None if s_W else gW.view(pW.shape).to(pW.dtype),
                 None if (s_bias or gbias is None) else gbias, None if s_w1 else gw1, None if s_b1 else gb1,
-                None, None, None, None, None, None)
+                None, None, None, None, None, None, None)
 
 
 LATE_JOIN = os.environ.get('FGNN_EARLY_JOIN') is None     # the tail asks for addends of another stream behind its statistics pass
@@ -353,11 +366,14 @@ class _BlockTail(torch.autograd.Function):
             _hip.stream_ptr())))
         # conv2's weight / bias gradient: gz3^T a2 over the R rows (csrc/linear_wgrad_b16.hip); parked when it goes to the flat
         # bucket (ops.defer_wgrad: nothing in the backward reads it)
+        record = s_W2 and s_bias2 and ops.folds_deferrable()
+
         def launch(a2=a2, gz3=gz3, gW2=gW2, gbias2=gbias2):
-            wsw = ops._workspace(dev, int(L.fgnn_linear_wgrad_workspace_bytes(R, 64, Cout)))
-            ops.timed('linear_wgrad_b16_kernel', 2 * R * (64 + Cout), lambda: _hip.check(L.fgnn_linear_wgrad(
-                P(a2), P(gz3), R, 64, Cout, _hip.BF16, P(gW2.view(Cout, 64)), P(gbias2), P(wsw), wsw.numel() * 4, _hip.stream_ptr())),
-                nflops=2 * R * 64 * Cout)
+            with ops.fold_scope(record) as scope:
+                wsw = scope.slabs(dev, int(L.fgnn_linear_wgrad_workspace_bytes(R, 64, Cout)))
+                ops.timed('linear_wgrad_b16_kernel', 2 * R * (64 + Cout), lambda: _hip.check(L.fgnn_linear_wgrad(
+                    P(a2), P(gz3), R, 64, Cout, _hip.BF16, P(gW2.view(Cout, 64)), P(gbias2), P(wsw), wsw.numel() * 4, _hip.stream_ptr())),
+                    nflops=2 * R * 64 * Cout)
         if s_W2 and s_bias2:
             ops.defer_wgrad(launch, (a2, gz3))
         else:
@@ -556,7 +572,7 @@ class mp_conv_residual(base_mp_nn):
         if rows.dtype != torch.bfloat16 or R < 2 or not L.fgnn_block_tail_partials(R, C) or not L.fgnn_linear_forward_partials(R, C, 64):
             return None
         a1 = _BlockHead.apply(rows, conv.weight.view(64, C), conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
-                              bn.num_batches_tracked, bn.momentum, bn.eps, float(bn.slope))
+                              bn.num_batches_tracked, bn.momentum, bn.eps, float(bn.slope), ops.fan_box(x))
         return a1.view(B, H, W, 64).permute(0, 3, 1, 2)
 
     def _fused_train_tail(self, h, nn_idx, etype, addend, mult=1):

@@ -231,9 +231,12 @@ class _RowLinear(torch.autograd.Function):
     rows and gy)."""
 
     @staticmethod
-    def forward(ctx, rows, weight, bias, bn=None, precomputed=None):
+    def forward(ctx, rows, weight, bias, bn=None, precomputed=None, box=None):
         """``bn``: a ``bn_spec`` tuple — the training-mode BatchNorm behind the map, finalised by the map's own launch.
-        ``precomputed``: the output, already formed by a fused kernel (blocks.iid_mapping_in): only the graph node is made."""
+        ``precomputed``: the output, already formed by a fused kernel (blocks.iid_mapping_in): only the graph node is made.
+        ``box``: the ``ops.FanBox`` of the state ``rows`` views — the backward deposits (gy, weight) there instead of forming
+        ``gy @ weight`` (the fan-out's backward multiplies all its consumers' pairs in one launch)."""
+        ctx.box = box
         ctx.save_for_backward(rows, weight)
         ctx.has_bias = bias is not None
         ctx.params = (weight, bias)                     # leaf tensors (ops.grad_sink)
@@ -255,7 +258,9 @@ class _RowLinear(torch.autograd.Function):
         if gy.dtype != rows.dtype:
             gy = gy.to(rows.dtype)
         grows = None
-        if ctx.needs_input_grad[0]:
+        if ctx.needs_input_grad[0] and ctx.box is not None and ctx.box.deposit(gy, weight):
+            grows = ctx.box.placeholder(rows.shape)                    # (gy @ weight joins the state's other gradients in the fan-out's backward)
+        elif ctx.needs_input_grad[0]:
             grows = hip_linear(gy, weight, None, transposed=True)      # gy [R,cout] @ weight [cout,cin]
             if grows is None:
                 grows = gy @ cast_cached(weight._base if weight._base is not None else weight, gy.dtype).view(weight.shape)
@@ -268,7 +273,7 @@ class _RowLinear(torch.autograd.Function):
                 rows.dtype == torch.float32 and cin % 4 == 0 and cout % 4 == 0 and cin <= 1024 and cout <= 1024 and R >= 2048):
             gw = (gy.t() @ rows).float()                # f32 square 256-wide maps: rocBLAS is ahead there
             gb = gy.float().sum(0) if ctx.has_bias else None
-            return grows, gw.to(weight.dtype), (gb.to(weight.dtype) if gb is not None else None), None, None
+            return grows, gw.to(weight.dtype), (gb.to(weight.dtype) if gb is not None else None), None, None, None
         L = _hip.lib()
         wparam, bparam = ctx.params
         # weight may be a [cout,cin,1,1] Conv2d parameter viewed as [cout,cin]: its .grad lives on the base
@@ -278,22 +283,26 @@ class _RowLinear(torch.autograd.Function):
         gb = None
         if ctx.has_bias:
             gb = gb_sink if gb_sink is not None else torch.zeros((cout,), device=rows.device, dtype=torch.float32)
+        sinks = gw_sink is not None and (gb is None or gb_sink is not None)
+        record = sinks and ops.folds_deferrable()        # (decided here, inside the pass: a parked launch may go out from its end-of-pass callback)
+
         def launch(rows=rows, gy=gy, gw=gw, gb=gb):      # (the closure keeps rows / gy alive until the kernel is issued)
-            ws = ops._workspace(rows.device, int(L.fgnn_linear_wgrad_workspace_bytes(R, cin, cout)))
-            ops.timed('linear_wgrad_b16_kernel' if rows.dtype == torch.bfloat16 else 'linear_wgrad_kernel',
-                      rows.element_size() * R * (cin + cout),
-                      lambda: _hip.check(L.fgnn_linear_wgrad(_hip._ptr(rows), _hip._ptr(gy), R, cin, cout,
-                                                             _hip.dtype_code(rows), _hip._ptr(gw), _hip._ptr(gb),
-                                                             _hip._ptr(ws), ws.numel() * 4, _hip.stream_ptr())),
-                      nflops=2 * R * cin * cout)
+            with ops.fold_scope(record) as scope:
+                ws = scope.slabs(rows.device, int(L.fgnn_linear_wgrad_workspace_bytes(R, cin, cout)))
+                ops.timed('linear_wgrad_b16_kernel' if rows.dtype == torch.bfloat16 else 'linear_wgrad_kernel',
+                          rows.element_size() * R * (cin + cout),
+                          lambda: _hip.check(L.fgnn_linear_wgrad(_hip._ptr(rows), _hip._ptr(gy), R, cin, cout,
+                                                                 _hip.dtype_code(rows), _hip._ptr(gw), _hip._ptr(gb),
+                                                                 _hip._ptr(ws), ws.numel() * 4, _hip.stream_ptr())),
+                          nflops=2 * R * cin * cout)
         # nothing in the backward reads a weight gradient: with both gradients going to the flat bucket the kernel is parked
         # and issued where its stream would otherwise wait for the other one (ops.defer_wgrad)
-        if gw_sink is not None and (gb is None or gb_sink is not None):
+        if sinks:
             ops.defer_wgrad(launch, (rows, gy))
         else:
             launch()
         return (grows, None if gw_sink is not None else gw.to(weight.dtype),
-                None if (gb is None or gb_sink is not None) else gb.to(weight.dtype), None, None)
+                None if (gb is None or gb_sink is not None) else gb.to(weight.dtype), None, None, None)
 
 
 class PointwiseConv2d(torch.nn.Conv2d):
@@ -316,7 +325,8 @@ class PointwiseConv2d(torch.nn.Conv2d):
         weight = self.weight.view(self.out_channels, C)
         if rows.is_cuda and rows.dtype in (torch.float32, torch.bfloat16) and torch.is_grad_enabled() and (
                 weight.requires_grad or rows.requires_grad):
-            y = _RowLinear.apply(rows, weight, self.bias, bn)
+            from .. import ops
+            y = _RowLinear.apply(rows, weight, self.bias, bn, None, ops.fan_box(x))
         else:
             needs_grad = torch.is_grad_enabled() and (weight.requires_grad or rows.requires_grad)
             y = hip_linear(rows, weight, self.bias) if rows.is_cuda and not needs_grad else None

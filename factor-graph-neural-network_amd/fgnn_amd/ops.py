@@ -115,11 +115,7 @@ def defer_wgrad(launch, operands=()):
         # weight-gradient kernels go to the side stream at once, behind an event on what they read
         side = side_stream(operands[0].device)
         if st != side:
-            if _DEFER_CALLBACK[0] != task:
-                if any(_DEFERRED.values()):
-                    flush_deferred()
-                _DEFER_CALLBACK[0] = task
-                torch.autograd.Variable._execution_engine.queue_callback(_flush_at_end_of_backward)
+            _register_backward_callback(task)
             ready = torch.cuda.Event()
             ready.record(st)
             with torch.cuda.stream(side):
@@ -129,6 +125,11 @@ def defer_wgrad(launch, operands=()):
                     t.record_stream(side)
             _DEFER_ISSUED.add(side)
             return
+    _register_backward_callback(task)
+    _DEFERRED.setdefault(st, []).append((launch, tuple(operands)))
+
+
+def _register_backward_callback(task):
     if _DEFER_CALLBACK[0] != task:
         # Another backward pass than the one that parked what is in the lists: a NESTED (re-entrant) pass inside it — checkpointing,
         # a custom Function calling backward() — or a pass that died half-way.  Either way the parked launches are ISSUED, never
@@ -137,9 +138,67 @@ def defer_wgrad(launch, operands=()):
         # with its next parked launch; its own end-of-pass callback is still queued.
         if any(_DEFERRED.values()):
             flush_deferred()
+        flush_folds()
         _DEFER_CALLBACK[0] = task
         torch.autograd.Variable._execution_engine.queue_callback(_flush_at_end_of_backward)
-    _DEFERRED.setdefault(st, []).append((launch, tuple(operands)))
+
+
+# ---- recorded parameter-gradient folds -------------------------------------------------------------------------------------------
+# Every weight / filter gradient kernel leaves per-workgroup slabs that a small launch folds into the accumulator: ~100 launches of
+# 5-15 us per LDPC step, a third of them in the main stream's dependent chain (csrc/fold_batch.hip).  When the gradient goes to a
+# sink (ops.grad_sink: nothing in the pass reads it) the fold is RECORDED instead — the call gets a slab buffer of its own, kept
+# alive here — and ONE launch at the end of the pass folds them all (a fixed summation order of its own: reproducible, equal to the
+# immediate folds' sums to f32 rounding).
+DEFER_FOLDS = os.environ.get('FGNN_NO_DEFER_FOLDS') is None        # (the variable: an A/B switch for tools / bench runs)
+_FOLD_KEEP = []
+
+
+def folds_deferrable():
+    """True inside a backward pass whose end this module gets to see (the engine callback that flushes the recorded folds)."""
+    if not DEFER_FOLDS:
+        return False
+    task = torch._C._current_graph_task_id()
+    if task < 0:
+        return False
+    _register_backward_callback(task)
+    return True
+
+
+class fold_scope:
+    """``with fold_scope(defer):`` — the gradient entry points called inside record their slab folds (csrc/fold_batch.hip) when
+    ``defer``; ``slabs(device, nbytes)`` is the workspace to hand them: a private buffer (alive until the flush) then, else the
+    stream's shared scratch."""
+
+    def __init__(self, defer):
+        self.defer = bool(defer)
+
+    def slabs(self, device, nbytes):
+        if not self.defer:
+            return _workspace(device, nbytes)
+        t = torch.empty((nbytes + 3) // 4, device=device, dtype=torch.float32)
+        _FOLD_KEEP.append(t)
+        return t
+
+    def __enter__(self):
+        if self.defer:
+            _hip.lib().fgnn_fold_defer(1)
+        return self
+
+    def __exit__(self, *exc):
+        if self.defer:
+            _hip.lib().fgnn_fold_defer(0)
+        return False
+
+
+def flush_folds():
+    """Fold everything recorded, on the current stream (the caller has ordered it behind every producer)."""
+    L = _hip.lib()
+    if L.fgnn_fold_pending():
+        _hip.check(L.fgnn_fold_flush(_hip.stream_ptr()))
+        cur = torch.cuda.current_stream()
+        for t in _FOLD_KEEP:            # slabs another stream allocated are read by this stream's launch: not that stream's to reuse yet
+            t.record_stream(cur)
+    _FOLD_KEEP.clear()
 
 
 def flush_deferred(except_stream=None):
@@ -163,6 +222,7 @@ def _flush_at_end_of_backward():
     for st in _DEFER_ISSUED:    # the engine joined its streams BEFORE this callback: what was issued since needs its own join
         if st != cur:
             cur.wait_stream(st)
+    flush_folds()               # every producer is now in front of the current stream: one launch folds all their slabs
     _DEFER_ISSUED.clear()
 
 
@@ -515,7 +575,8 @@ class _MPConv(torch.autograd.Function):
         if reduced:
             d.reserved |= _hip.DESC_GETYPE_REDUCED
             get = torch.empty((1, net, M, k), device=x.device, dtype=torch.float32)
-        ws = _workspace(x.device, int(L.fgnn_mpconv_backward_workspace_bytes(ctypes.byref(d))))
+        scope = fold_scope(gw_sink is not None and (gb is None or gb_sink is not None) and folds_deferrable())
+        ws = scope.slabs(x.device, int(L.fgnn_mpconv_backward_workspace_bytes(ctypes.byref(d))))
         nbytes = 0
         if TIMER is not None:
             # algorithmic bytes of the backward: x, etype, nn_idx, gz, argmax read once;
@@ -528,10 +589,11 @@ class _MPConv(torch.autograd.Function):
                       + (B * nou * M if amax is not None else 0)
                       + (get.element_size() * get.numel() if want_get else 0) + 8 * w.numel())
         tables = backward_tables(nn_idx, d)           # the transposed incidence, built once per graph (None: the kernel builds its own)
-        _launch('bwd', d, nbytes, lambda: _hip.check(L.fgnn_mpconv_backward_with_tables(
-            ctypes.byref(d), _hip._ptr(xx), _hip._ptr(nn_idx), _hip._ptr(etype), _hip._ptr(w),
-            _hip._ptr(gz), None, _hip._ptr(amax), _hip._ptr(gx), _hip._ptr(get),
-            _hip._ptr(gw), _hip._ptr(gb), _hip._ptr(ws), ws.numel() * 4, _hip._ptr(tables), _hip.stream_ptr())))
+        with scope:
+            _launch('bwd', d, nbytes, lambda: _hip.check(L.fgnn_mpconv_backward_with_tables(
+                ctypes.byref(d), _hip._ptr(xx), _hip._ptr(nn_idx), _hip._ptr(etype), _hip._ptr(w),
+                _hip._ptr(gz), None, _hip._ptr(amax), _hip._ptr(gx), _hip._ptr(get),
+                _hip._ptr(gw), _hip._ptr(gb), _hip._ptr(ws), ws.numel() * 4, _hip._ptr(tables), _hip.stream_ptr())))
         if want_get and ctx.shared_et and not reduced:
             get = get.sum(dim=0, keepdim=True)
         if want_get and get.dtype != etype.dtype:
@@ -680,19 +742,103 @@ def sum_tensors(ts):
     return out
 
 
+MERGE_FAN_GRADS = os.environ.get('FGNN_NO_MERGED_FAN_GRADS') is None      # (the variable: an A/B switch for tools / bench runs)
+
+
+class FanBox:
+    """The gradient of a state with several consumers (``fan_out``) as ONE product.  A consumer whose input gradient is
+    ``gz @ W`` — a node-wise map or the 1x1 map in front of a block's operator — does not form it: its backward DEPOSITS (gz, W)
+    here and returns ``placeholder`` (a zero tensor without memory traffic: one element, expanded) to autograd; the fan-out's own
+    backward then runs csrc/linear_fwd_b16.hip::linear_multi_b16_kernel over the deposited pairs with the gradients that did arrive
+    as tensors (the residual, a skip link) as addends — instead of one [R, C] tensor per consumer and an n-input sum over them.
+    Slots: 0 and 2 take 64-channel sources, 1 takes 64 / 128 / 256; a deposit that finds no slot is refused and its consumer forms
+    the gradient itself (a real tensor: an addend)."""
+
+    def __init__(self, x):
+        self.shape, self.dtype, self.device = tuple(x.shape), x.dtype, x.device
+        B, C, H, W = x.shape
+        self.R, self.C = B * H * W, C
+        self.ok = (MERGE_FAN_GRADS and x.is_cuda and x.dtype == torch.bfloat16 and C in (64, 128, 256) and self.R >= 1024
+                   and (x.permute(0, 2, 3, 1).is_contiguous() or x.is_contiguous() and H * W == 1))
+        self.slots = [None, None, None]
+        self._ph = None
+
+    def placeholder(self, shape):
+        if self._ph is None:
+            self._ph = torch.zeros(1, device=self.device, dtype=self.dtype)
+        return self._ph.expand(shape)
+
+    def is_placeholder(self, g):
+        return self._ph is not None and g.data_ptr() == self._ph.data_ptr()
+
+    def deposit(self, gz, weight):
+        """gz [R, K] bf16 dense rows, weight [K, C] f32 (a map's [cout, cin] weight as it lies in memory).  True = taken."""
+        if not self.ok or gz.dim() != 2 or gz.shape[0] != self.R or gz.dtype != torch.bfloat16 or not gz.is_contiguous():
+            return False
+        K = gz.shape[1]
+        if tuple(weight.shape) != (K, self.C) or weight.dtype != torch.float32 or not weight.is_contiguous() or gz.data_ptr() % 16:
+            return False
+        order = (0, 2, 1) if K == 64 else ((1,) if K in (128, 256) else ())
+        for i in order:
+            if self.slots[i] is None:
+                self.slots[i] = (gz, weight)
+                return True
+        return False
+
+    def merge(self, grads):
+        """The state's gradient from the deposits + the gradients that arrived as tensors."""
+        real = [g for g in grads if g is not None and not self.is_placeholder(g)]
+        slots, self.slots = self.slots, [None, None, None]
+        if not any(slots):
+            return sum_tensors(real) if real else None
+        if slots[0] is None and slots[2] is not None:      # (a lone 64-channel source sits in slot 0 by construction; keep the kernel's rule anyway)
+            slots[0], slots[2] = slots[2], None
+        B, C, H, W = self.shape
+        adds = []
+        for g in real:
+            rows = g.permute(0, 2, 3, 1)
+            if rows.dtype != self.dtype or not rows.is_contiguous():
+                rows = rows.to(self.dtype).contiguous()
+            adds.append(rows.view(self.R, C))
+        if len(adds) > 3:
+            adds = adds[:2] + [sum_tensors(adds[2:])]
+        cur = torch.cuda.current_stream(self.device)
+        for sl in slots:
+            if sl is not None:
+                sl[0].record_stream(cur)                   # (a side-stream consumer allocated it; this stream's launch reads it)
+        out = torch.empty((self.R, C), device=self.device, dtype=self.dtype)
+        P = _hip._ptr
+        xs = (ctypes.c_void_p * 3)(*[P(sl[0]) if sl else None for sl in slots])
+        ws = (ctypes.c_void_p * 3)(*[P(sl[1]) if sl else None for sl in slots])
+        ks = (ctypes.c_int32 * 3)(*[sl[0].shape[1] if sl else 0 for sl in slots])
+        ad = (ctypes.c_void_p * 3)(*([P(a) for a in adds] + [None] * (3 - len(adds))))
+        ktot = sum(ks)
+        timed('linear_multi_b16_kernel', 2 * self.R * (ktot + C * (1 + len(adds))),
+              lambda: _hip.check(_hip.lib().fgnn_linear_multi_forward(xs, ks, ws, ad, P(out), self.R, C, _hip.stream_ptr())),
+              nflops=2 * self.R * ktot * C)
+        return out.view(B, H, W, C).permute(0, 3, 1, 2)
+
+
+def fan_box(x):
+    """The FanBox a consumer may deposit its input gradient into, or None (``x`` is not a fan-out handle / merging is off)."""
+    box = getattr(x, '_fgnn_box', None)
+    return box if (box is not None and box.ok) else None
+
+
 class _FanOut(torch.autograd.Function):
-    """n aliases of x whose gradients come back TOGETHER: one n-input sum instead of autograd's n-1 adds."""
+    """n aliases of x whose gradients come back TOGETHER: one n-input sum instead of autograd's n-1 adds — or, where the consumers
+    deposited their (gz, W) pairs in the handles' FanBox, one product over them."""
 
     @staticmethod
-    def forward(ctx, x, n):
+    def forward(ctx, x, n, box):
         ctx.set_materialize_grads(False)                 # an unused alias contributes nothing, not a zero tensor
+        ctx.box = box
         return tuple(x.view_as(x) for _ in range(n))
 
     @staticmethod
     def backward(ctx, *grads):
         backward_node_begins()
-        grads = [g for g in grads if g is not None]
-        return (sum_tensors(grads) if grads else None), None
+        return ctx.box.merge(grads), None, None
 
 
 class _SumN(torch.autograd.Function):
@@ -709,7 +855,16 @@ def fan_out(x, n):
     """``n`` handles on ``x`` for ``n`` consumers (a single fused gradient sum in the backward)."""
     if n <= 1 or not (torch.is_grad_enabled() and x.requires_grad and x.is_cuda):
         return [x] * n
-    return list(_FanOut.apply(x, n))
+    box = FanBox(x) if x.dim() == 4 else None
+    if box is None:
+        class _Plain:       # (a non-4-D state: nothing to deposit into)
+            ok = False
+            merge = staticmethod(lambda grads: (lambda gs: sum_tensors(gs) if gs else None)([g for g in grads if g is not None]))
+        box = _Plain()
+    outs = list(_FanOut.apply(x, n, box))
+    for o in outs:
+        o._fgnn_box = box
+    return outs
 
 
 def add_n(ts):

@@ -200,7 +200,36 @@ int fgnn_linear_forward(const void* x, const float* W, const float* bias, void* 
  */
 int fgnn_linear_instnorm_forward(const void* x, const float* W, const float* bias, void* z, void* y, int32_t B, int32_t N,
                                  int32_t Cin, int32_t Cout, int32_t relu, float eps, fgnn_stream_t stream);
+
+/*
+ * Several node-wise maps into ONE tensor: y[r][:] = sum_s x_s[r][:] W_s + addend_0[r][:] + addend_1[r][:] + addend_2[r][:] — the
+ * gradient of a FactorNN state that feeds several consumers (factor_mpnn_sp.py:136-168: the v2v / f2f map and one block per factor
+ * type, each contributing `gz_s W_s`, plus the residual / skip gradients that arrive unchanged) as one K-concatenated product
+ * instead of one [R][Cout] tensor per consumer and an n-input sum.  x_s [R][K[s]] bf16 dense, W_s [K[s]][Cout] f32 row-major (a
+ * map's [cout'][cin'] weight as it lies in memory), addends / y [R][Cout] bf16; three slots each (K[s] == 0 / NULL = absent).
+ * K[0], K[2] in {0, 64}, K[1] in {0, 64, 128, 256} (K[0] == 0 only with K[2] == 0), Cout in {64, 128, 256}: fgnn_linear_multi_supported;
+ * FGNN_EUNSUPPORTED otherwise.  f32 accumulation, one rounding of the sum.
+ */
+int fgnn_linear_multi_supported(int64_t R, const int32_t* K, int32_t Cout);
+int fgnn_linear_multi_forward(const void* const* x, const int32_t* K, const float* const* W, const void* const* addend, void* y,
+                              int64_t R, int32_t Cout, fgnn_stream_t stream);
 int fgnn_linear_forward_partials(int64_t R, int32_t Cin, int32_t Cout);
+
+/*
+ * Parameter-gradient folds as ONE launch per backward pass.  Every gradient entry point that sums over the batch rows (fgnn_mpconv_backward*,
+ * fgnn_linear_wgrad) writes per-workgroup partial slabs into the caller's workspace and folds them into gfilters / gbias / gW / gb with
+ * a small launch of its own.  After fgnn_fold_defer(1) those entry points RECORD their fold instead (process-wide list; the caller
+ * must then give each call a workspace of its own and keep it alive and untouched), and fgnn_fold_flush(stream) — `stream` ordered
+ * behind every producer — folds everything recorded with one launch per 48 jobs (jobs that accumulate into overlapping targets go to
+ * separate launches, in recording order).  A fixed per-element summation order (bit-reproducible), not the immediate folds' one: the two
+ * agree to f32 rounding.  The
+ * accumulators are complete only after the flush.  fgnn_fold_defer returns the previous setting; fgnn_fold_pending the number of
+ * recorded jobs; fgnn_fold_discard forgets them (a pass that died).
+ */
+int fgnn_fold_defer(int32_t on);
+int fgnn_fold_pending(void);
+void fgnn_fold_discard(void);
+int fgnn_fold_flush(fgnn_stream_t stream);
 
 /*
  * Weight / bias gradient of a node-wise linear map y[r,:] = W x[r,:] + b over R = B*N rows
@@ -286,6 +315,8 @@ int fgnn_block_tail_backward_partials(int64_t R, int32_t Cout);   /* workgroups 
  *   Writes gz1 [R][64] (BatchNorm1's input gradient: conv1's weight-gradient kernel reads it) and gx [R][Cin] = gz1 W1 (conv1's
  *   input gradient) in ONE element pass — gz1 is not read back — after BatchNorm1's reduction pass; gweight / gbias [64]
  *   (BatchNorm1's parameter gradients) are ACCUMULATED into.  Cin in {64, 128, 256}; workspace: fgnn_bn_workspace_bytes(R, 64).
+ *   gx may be NULL: only gz1 is formed (the caller multiplies it by W1 together with the state's other gradients:
+ *   fgnn_linear_multi_forward).
  */
 int fgnn_block_head_backward(const void* z1, const void* ga1, const float* mean, const float* invstd, const float* gamma,
                              const float* beta, float slope, const float* W1, void* gz1, void* gx, float* gweight,

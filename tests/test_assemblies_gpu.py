@@ -1014,6 +1014,82 @@ def test_a_nested_backward_pass_does_not_lose_parked_launches(dev, monkeypatch):
     assert float(plain.abs().max()) > 0 and torch.equal(parked, plain)
 
 
+def test_recorded_gradient_folds_equal_immediate_ones(dev):
+    """csrc/fold_batch.hip: with the parameter gradients going to the flat bucket, every slab fold of a backward pass (the operator's
+    filter / bias gradients, the node-wise maps' weight gradients) is recorded and ONE launch at the end of the pass folds them: the
+    gradients of the folds launched one by one up to the f32 rounding of a different (fixed) summation order, bit-reproducible run to
+    run; nothing stays recorded, and a second pass accumulates on top (two folds into the same accumulators: separate launches)."""
+    import fgnn_amd
+    from fgnn_amd import _hip, ops
+    from fgnn_amd.dp import FlatGradBucket
+    from fgnn_amd.ldpc import synthetic_batch
+    torch.manual_seed(3)
+    m = fgnn_amd.LDPCModel(2, 6, 4).to(dev).train()
+    bucket = FlatGradBucket(m.parameters())
+    data = synthetic_batch(48, dev, seed=11, dtype=torch.bfloat16)
+    state = {k: v.clone() for k, v in m.state_dict().items()}
+
+    def grads(defer, passes=1):
+        m.load_state_dict(state)
+        bucket.zero()
+        ops.DEFER_FOLDS = defer
+        try:
+            for _ in range(passes):
+                with torch.autocast('cuda', dtype=torch.bfloat16):
+                    logits, snr = m(*data[:6])
+                (torch.nn.functional.binary_cross_entropy_with_logits(logits.float(), data[6]) + 0.1 * snr.float().pow(2).mean()).backward()
+                assert _hip.lib().fgnn_fold_pending() == 0 and not ops._FOLD_KEEP
+        finally:
+            ops.DEFER_FOLDS = True
+        torch.cuda.synchronize()
+        return bucket.flat.clone()
+
+    a, b = grads(False), grads(True)
+    scale = float(a.abs().max())
+    assert scale > 0 and float((a - b).abs().max()) <= 1e-5 * scale
+    assert torch.equal(b, grads(True))
+    a2, b2 = grads(False, passes=2), grads(True, passes=2)
+    assert float((a2 - b2).abs().max()) <= 2e-5 * scale and float((b2 - 2 * b).abs().max()) <= 2e-5 * scale
+
+
+def test_merged_fan_out_gradients_match_the_per_consumer_sums(dev):
+    """ops.FanBox: the gradient of a layer state that feeds the node-wise map and one block per factor type is ONE product over the
+    consumers' (gz, W) pairs with the residual / skip gradients as addends (csrc/linear_fwd_b16.hip::linear_multi_b16_kernel), not one
+    [R, C] tensor per consumer and an n-input sum.  Same gradients up to bf16 rounding (the merged form rounds the sum once), for
+    every parameter of the LDPC model and for the input features; the kernel really ran; bit-reproducible."""
+    import fgnn_amd
+    from fgnn_amd import ops
+    from fgnn_amd.dp import FlatGradBucket
+    from fgnn_amd.ldpc import synthetic_batch
+    torch.manual_seed(4)
+    m = fgnn_amd.LDPCModel(2, 6, 4).to(dev).train()
+    bucket = FlatGradBucket(m.parameters())
+    data = synthetic_batch(64, dev, seed=12, dtype=torch.bfloat16)
+    state = {k: v.clone() for k, v in m.state_dict().items()}
+
+    def grads(merge):
+        m.load_state_dict(state)
+        bucket.zero()
+        ops.MERGE_FAN_GRADS = merge
+        rec = []
+        ops.TIMER = type('T', (), {'run': staticmethod(lambda sym, nb, nf, launch, use_note=True, **kw: (rec.append(sym), launch()))})()
+        try:
+            with torch.autocast('cuda', dtype=torch.bfloat16):
+                logits, snr = m(*data[:6])
+            (torch.nn.functional.binary_cross_entropy_with_logits(logits.float(), data[6]) + 0.1 * snr.float().pow(2).mean()).backward()
+        finally:
+            ops.MERGE_FAN_GRADS = True
+            ops.TIMER = None
+        torch.cuda.synchronize()
+        return bucket.flat.clone(), rec
+
+    (a, ra), (b, rb) = grads(False), grads(True)
+    assert 'linear_multi_b16_kernel' not in ra and rb.count('linear_multi_b16_kernel') >= 12 and rb.count('sum_n_kernel') < ra.count('sum_n_kernel')
+    fro = float((a - b).norm() / a.norm())
+    assert float(a.abs().max()) > 0 and fro <= 3e-2, fro
+    assert torch.equal(b, grads(True)[0])
+
+
 def test_regressor_head_through_the_map_kernels_matches_the_torch_modules(dev):
     """LDPCModel._regress: the burst-noise regressor (train_ldpc.py:48-54,93) through this package's node-wise map / BatchNorm
     kernels when training on bf16 activations, against the seven torch modules in f32 on the same input: prediction, input

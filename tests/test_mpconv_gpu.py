@@ -486,6 +486,36 @@ def test_classifier_instnorm_relu_dot_kernel_vs_torch(N, B, dtype, dev):
     assert instnorm_relu_dot(xm.detach().cpu(), conv.cpu()) is None
 
 
+@pytest.mark.parametrize('K,C', [((64, 0, 0), 64), ((64, 64, 64), 64), ((64, 128, 64), 64), ((64, 256, 64), 128), ((64, 256, 64), 256),
+                                 ((64, 128, 64), 256), ((64, 64, 0), 128), ((0, 256, 0), 256), ((64, 0, 64), 64), ((64, 256, 0), 256)])
+@pytest.mark.parametrize('nadd', [0, 2, 3])
+def test_linear_multi_kernel_vs_torch(K, C, nadd, dev):
+    """csrc/linear_fwd_b16.hip::linear_multi_b16_kernel — y = sum_s x_s W_s + addends, the gradient of a FactorNN state with several
+    consumers as one K-concatenated product (ops.FanBox) — against the same sum of f32 matmuls on the same bf16 operands; R not a
+    multiple of the 16-row tile; wide products run as two output-channel slices."""
+    import ctypes
+    from fgnn_amd import _hip
+    L = _hip.lib()
+    R = 1000 + 7
+    g = torch.Generator().manual_seed(sum(K) + C + nadd)
+    xs = [torch.randn(R, k, generator=g).bfloat16().to(dev) if k else None for k in K]
+    Ws = [(torch.randn(k, C, generator=g) * 0.1).to(dev) if k else None for k in K]
+    adds = [torch.randn(R, C, generator=g).bfloat16().to(dev) for _ in range(nadd)]
+    ks = (ctypes.c_int32 * 3)(*K)
+    assert L.fgnn_linear_multi_supported(R, ks, C) == 1
+    y = torch.empty(R, C, device=dev, dtype=torch.bfloat16)
+    P = _hip._ptr
+    arr = lambda ts: (ctypes.c_void_p * 3)(*([P(t) for t in ts] + [None] * (3 - len(ts))))
+    _hip.check(L.fgnn_linear_multi_forward(arr(xs), ks, arr(Ws), arr(adds), P(y), R, C, _hip.stream_ptr()))
+    ref = sum(x.float() @ w.bfloat16().float() for x, w in zip(xs, Ws) if x is not None)
+    for a in adds:
+        ref = ref + a.float()
+    err = float((y.float() - ref).abs().max() / ref.abs().max())
+    assert err <= 2.0 ** -7, err
+    bad = (ctypes.c_int32 * 3)(0, 64, 64)
+    assert L.fgnn_linear_multi_supported(R, bad, C) == 0 and L.fgnn_linear_multi_supported(R, ks, 96) == 0
+
+
 @pytest.mark.parametrize('C', [64, 128, 256, 8, 96])
 @pytest.mark.parametrize('slope', [0.0, 0.01, 1.0])
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
