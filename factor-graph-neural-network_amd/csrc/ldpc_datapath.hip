@@ -197,30 +197,44 @@ extern "C" int fgnn_ldpc_channel_features_rng(const uint8_t* cw, const float* sn
 // ---- the training loss behind the decoder (round 5) --------------------------------------------------------------------------------
 // /root/reference/train_ldpc.py:222-227:  loss = BCEWithLogits(decoded bits, message bits) + w * MSE(predicted burst amplitude,
 // 10^(sigma_b / 20)), both means.  Through torch that is ~12 five-microsecond launches forward and ~13 backward (casts, log-sigmoid,
-// two reductions, pow, scalar arithmetic) alone on the GPU between the model's forward and its backward; here one launch each
-// way.  The forward is ONE workgroup (B * n = 196 608 logits at the benched size: 192 per thread) summing in double in a fixed order.
+// two reductions, pow, scalar arithmetic) alone on the GPU between the model's forward and its backward; here two short launches
+// forward (per-workgroup sums in double, then the partials in order: a fixed order, bit-reproducible; ONE workgroup for all
+// 196 608 logits of the benched size took 193 us, gpurun_out/r05t/timeline) and one backward.
 #define LL_THREADS 1024
 
 __device__ __forceinline__ float ll_bce(float x, float y) {       // torch's stable form: max(x,0) - x y + log(1 + exp(-|x|))
     return fmaxf(x, 0.f) - x * y + log1pf(expf(-fabsf(x)));
 }
 
+#define LL_MAXGRID 128
+
+// stage 1: workgroup w sums its grid-stride share of the two terms (double, fixed order) -> part[w][2]
 template <typename T>
 __global__ __launch_bounds__(LL_THREADS) void ldpc_loss_fwd_kernel(const T* __restrict__ logits, const float* __restrict__ label,
                                                                    const float* __restrict__ pred, const float* __restrict__ sigma_b,
-                                                                   int64_t nlogit, int64_t B, float w, float* __restrict__ loss) {
+                                                                   int64_t nlogit, int64_t B, double* __restrict__ part) {
     __shared__ double red[2 * LL_THREADS];
     const int tid = threadIdx.x;
+    const int64_t step = (int64_t)gridDim.x * LL_THREADS;
     double a = 0.0, m = 0.0;
-    for (int64_t i = tid; i < nlogit; i += LL_THREADS) a += (double)ll_bce(fgnn_ld(logits + i), label[i]);
-    for (int64_t b = tid; b < B; b += LL_THREADS) { const float d = pred[b] - powf(10.f, sigma_b[b] * 0.05f); m += (double)(d * d); }
+    for (int64_t i = (int64_t)blockIdx.x * LL_THREADS + tid; i < nlogit; i += step) a += (double)ll_bce(fgnn_ld(logits + i), label[i]);
+    for (int64_t b = (int64_t)blockIdx.x * LL_THREADS + tid; b < B; b += step) { const float d = pred[b] - powf(10.f, sigma_b[b] * 0.05f); m += (double)(d * d); }
     red[tid] = a; red[LL_THREADS + tid] = m;
     __syncthreads();
     for (int s = LL_THREADS / 2; s > 0; s >>= 1) {
         if (tid < s) { red[tid] += red[tid + s]; red[LL_THREADS + tid] += red[LL_THREADS + tid + s]; }
         __syncthreads();
     }
-    if (tid == 0) loss[0] = (float)(red[0] / (double)nlogit + (double)w * red[LL_THREADS] / (double)B);
+    if (tid == 0) { part[2 * blockIdx.x] = red[0]; part[2 * blockIdx.x + 1] = red[LL_THREADS]; }
+}
+
+// stage 2: the partials in workgroup order
+__global__ __launch_bounds__(64) void ldpc_loss_final_kernel(const double* __restrict__ part, int n, int64_t nlogit, int64_t B, float w,
+                                                             float* __restrict__ loss) {
+    if (threadIdx.x != 0) return;
+    double a = 0.0, m = 0.0;
+    for (int i = 0; i < n; ++i) { a += part[2 * i]; m += part[2 * i + 1]; }
+    loss[0] = (float)(a / (double)nlogit + (double)w * m / (double)B);
 }
 
 template <typename T>
@@ -245,14 +259,25 @@ static int ll_check(const void* logits, const float* label, const float* pred, c
     return FGNN_OK;
 }
 
+extern "C" int64_t fgnn_ldpc_loss_workspace_bytes(void) { return (int64_t)LL_MAXGRID * 2 * sizeof(double); }
+
 extern "C" int fgnn_ldpc_loss_forward(const void* logits, const float* label, const float* pred, const float* sigma_b, int64_t B,
-                                      int n, int dtype, float mse_weight, float* loss, fgnn_stream_t stream) {
+                                      int n, int dtype, float mse_weight, float* loss, void* workspace, int64_t workspace_bytes,
+                                      fgnn_stream_t stream) {
     int rc = ll_check(logits, label, pred, sigma_b, B, n, dtype);
     if (rc) return rc;
     if (!loss) FGNN_FAIL(FGNN_EINVAL, "ldpc_loss: null pointer");
+    if (!workspace || workspace_bytes < fgnn_ldpc_loss_workspace_bytes() || ((uintptr_t)workspace & 7))
+        FGNN_FAIL(FGNN_EINVAL, "ldpc_loss: workspace of fgnn_ldpc_loss_workspace_bytes() bytes needed");
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == FGNN_F32) hipLaunchKernelGGL(ldpc_loss_fwd_kernel<float>, dim3(1), dim3(LL_THREADS), 0, st, (const float*)logits, label, pred, sigma_b, B * n, B, mse_weight, loss);
-    else hipLaunchKernelGGL(ldpc_loss_fwd_kernel<bf16_t>, dim3(1), dim3(LL_THREADS), 0, st, (const bf16_t*)logits, label, pred, sigma_b, B * n, B, mse_weight, loss);
+    const int64_t nl = B * n;
+    int grid = (int)((nl + 4 * LL_THREADS - 1) / (4 * LL_THREADS));      // ~4 logits per thread (196 608 logits at the benched size: 48 workgroups)
+    if (grid > LL_MAXGRID) grid = LL_MAXGRID;
+    if (grid < 1) grid = 1;
+    double* part = (double*)workspace;
+    if (dtype == FGNN_F32) hipLaunchKernelGGL(ldpc_loss_fwd_kernel<float>, dim3(grid), dim3(LL_THREADS), 0, st, (const float*)logits, label, pred, sigma_b, nl, B, part);
+    else hipLaunchKernelGGL(ldpc_loss_fwd_kernel<bf16_t>, dim3(grid), dim3(LL_THREADS), 0, st, (const bf16_t*)logits, label, pred, sigma_b, nl, B, part);
+    hipLaunchKernelGGL(ldpc_loss_final_kernel, dim3(1), dim3(64), 0, st, part, grid, nl, B, mse_weight, loss);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "ldpc_loss forward launch: %s", hipGetErrorString(e));
     return FGNN_OK;

@@ -106,9 +106,12 @@ class _DecodingLoss(torch.autograd.Function):
     def forward(ctx, logits, pred, label, sigma_b, mse_weight):
         from . import _hip
         B, n = logits.shape
+        from . import ops
         loss = torch.empty((), device=logits.device, dtype=torch.float32)
+        ws = ops._workspace(logits.device, int(_hip.lib().fgnn_ldpc_loss_workspace_bytes()))
         _hip.check(_hip.lib().fgnn_ldpc_loss_forward(_hip._ptr(logits), _hip._ptr(label), _hip._ptr(pred), _hip._ptr(sigma_b), B, n,
-                                                     _hip.dtype_code(logits), mse_weight, _hip._ptr(loss), _hip.stream_ptr()))
+                                                     _hip.dtype_code(logits), mse_weight, _hip._ptr(loss), _hip._ptr(ws), ws.numel() * 4,
+                                                     _hip.stream_ptr()))
         ctx.save_for_backward(logits, pred, label, sigma_b)
         ctx.mse_weight = mse_weight
         return loss
@@ -128,7 +131,7 @@ class _DecodingLoss(torch.autograd.Function):
 
 def decoding_loss(logits, snr_pred, label, sigma_b, mse_weight=0.1):
     """The training loss of /root/reference/train_ldpc.py:222-227 — BCE-with-logits on the decoded message bits + ``mse_weight`` x MSE of the
-    burst-amplitude regressor against 10^(sigma_b / 20), both means — as one launch forward and one backward on a ROCm device
+    burst-amplitude regressor against 10^(sigma_b / 20), both means — as two short launches forward and one backward on a ROCm device
     (csrc/ldpc_datapath.hip: ldpc_loss_*_kernel; ~25 short torch launches otherwise); the same torch expression elsewhere."""
     if (logits.is_cuda and logits.dim() == 2 and logits.dtype in (torch.float32, torch.bfloat16) and snr_pred.dtype == torch.float32
             and snr_pred.numel() == logits.shape[0] and label.shape == logits.shape and sigma_b.numel() == logits.shape[0]):

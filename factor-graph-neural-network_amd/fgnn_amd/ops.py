@@ -743,6 +743,7 @@ def sum_tensors(ts):
 
 
 MERGE_FAN_GRADS = os.environ.get('FGNN_NO_MERGED_FAN_GRADS') is None      # (the variable: an A/B switch for tools / bench runs)
+_PLACEHOLDERS = {}
 
 
 class FanBox:
@@ -765,7 +766,11 @@ class FanBox:
 
     def placeholder(self, shape):
         if self._ph is None:
-            self._ph = torch.zeros(1, device=self.device, dtype=self.dtype)
+            key = (self.device, self.dtype)
+            ph = _PLACEHOLDERS.get(key)
+            if ph is None:                     # one element per (device, dtype) for the life of the process: no fill launch per step
+                ph = _PLACEHOLDERS[key] = torch.zeros(1, device=self.device, dtype=self.dtype)
+            self._ph = ph
         return self._ph.expand(shape)
 
     def is_placeholder(self, g):

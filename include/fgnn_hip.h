@@ -488,13 +488,14 @@ int fgnn_ldpc_channel_features_rng(const uint8_t* cw, const float* snr_db, const
                                    void* hop, void* ef_f2v, void* ef_v2f, fgnn_stream_t stream);
 
 /*
- * The training loss behind the decoder (/root/reference/train_ldpc.py:222-227), one launch each way:
+ * The training loss behind the decoder (/root/reference/train_ldpc.py:222-227), two short launches forward and one backward:
  *     loss[0] = mean_{b,j} BCEWithLogits(logits[b][j], label[b][j]) + mse_weight * mean_b (pred[b] - 10^(sigma_b[b] / 20))^2
- * logits [B][n] dense, `dtype` FGNN_F32 / FGNN_BF16; label [B][n], pred [B], sigma_b [B], loss [1]: f32.  Summed in double by one
- * workgroup in a fixed order (bit-reproducible).  backward: glogits [B][n] (dtype of logits) and gpred [B] (f32) = gloss[0] * d loss.
+* logits [B][n] dense, `dtype` FGNN_F32 / FGNN_BF16; label [B][n], pred [B], sigma_b [B], loss [1]: f32.  Summed in double, per
+ * workgroup and then over the workgroups in order (bit-reproducible); workspace: fgnn_ldpc_loss_workspace_bytes() bytes, 8-byte aligned.  backward: glogits [B][n] (dtype of logits) and gpred [B] (f32) = gloss[0] * d loss.
  */
 int fgnn_ldpc_loss_forward(const void* logits, const float* label, const float* pred, const float* sigma_b, int64_t B, int32_t n,
-                           int32_t dtype, float mse_weight, float* loss, fgnn_stream_t stream);
+                           int32_t dtype, float mse_weight, float* loss, void* workspace, int64_t workspace_bytes, fgnn_stream_t stream);
+int64_t fgnn_ldpc_loss_workspace_bytes(void);
 int fgnn_ldpc_loss_backward(const void* logits, const float* label, const float* pred, const float* sigma_b, const float* gloss,
                             int64_t B, int32_t n, int32_t dtype, float mse_weight, void* glogits, float* gpred, fgnn_stream_t stream);
 
