@@ -56,17 +56,34 @@ __global__ __launch_bounds__(LF_THREADS) void linear_fwd_b16_kernel(const LfPara
     uint16_t* Wl = reinterpret_cast<uint16_t*>(lf_lds);                    // [Cout][WS] bf16
     float* bl = reinterpret_cast<float*>(lf_lds + (size_t)Cout * WS * 2);    // [Cout] bias
     float* red = bl + Cout;                                                // [nrg][2][Cout] statistics fold
+    // (four independent loads in flight per thread and pass: one value per iteration made the prologue a chain of up to 128 L2
+    // round trips — tools/mbench.py found it as 90 us of a 384 -> 128 product in linear_multi_b16_kernel below)
     if (!p.wt) {
-        for (int f = tid; f < Cout * (CIN / 2); f += LF_THREADS) {
-            const int o = f / (CIN / 2), c2 = f - o * (CIN / 2);
-            const float2 w = *reinterpret_cast<const float2*>(p.W + (int64_t)o * CIN + 2 * c2);
-            *reinterpret_cast<unsigned*>(Wl + o * WS + 2 * c2) = lf_pack2(w.x, w.y);
+        const int total = Cout * (CIN / 2);
+        for (int f0 = tid; f0 < total; f0 += 4 * LF_THREADS) {
+            float2 w[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int f = f0 + u * LF_THREADS;
+                if (f < total) { const int o = f / (CIN / 2), c2 = f - o * (CIN / 2); w[u] = *reinterpret_cast<const float2*>(p.W + (int64_t)o * CIN + 2 * c2); }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int f = f0 + u * LF_THREADS;
+                if (f < total) { const int o = f / (CIN / 2), c2 = f - o * (CIN / 2); *reinterpret_cast<unsigned*>(Wl + o * WS + 2 * c2) = lf_pack2(w[u].x, w[u].y); }
+            }
         }
     } else {                                              // memory is [c][o]: coalesced reads, 2-byte LDS writes
-        for (int f = tid; f < Cout * CIN; f += LF_THREADS) {
-            const int c = f / Cout, o = f - c * Cout;
-            const __bf16 h = (__bf16)p.W[f];
-            Wl[o * WS + c] = __builtin_bit_cast(uint16_t, h);
+        const int total = Cout * CIN;
+        for (int f0 = tid; f0 < total; f0 += 4 * LF_THREADS) {
+            float w[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const int f = f0 + u * LF_THREADS; if (f < total) w[u] = p.W[f]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int f = f0 + u * LF_THREADS;
+                if (f < total) { const int c = f / Cout, o = f - c * Cout; const __bf16 h = (__bf16)w[u]; Wl[o * WS + c] = __builtin_bit_cast(uint16_t, h); }
+            }
         }
     }
     for (int f = tid; f < Cout; f += LF_THREADS) bl[f] = p.bias ? p.bias[f] : 0.f;
@@ -438,7 +455,12 @@ struct LmParams {
 
 template <int KS0, int KS1, int KS2>
 __global__ __launch_bounds__(LF_THREADS) void linear_multi_b16_kernel(const LmParams p) {
-    constexpr int KS = KS0 + KS1 + KS2, KT = 32 * KS, WS = KT + 8, OTW = 4;
+    // The W image is read once per MFMA (it does not fit the registers).  A lane reads 16 bytes of row 16 (li >> 2) + 4 ot + (li & 3):
+    // rows 16 apart start a multiple of 64 dwords apart whatever the (16-byte aligned) row stride, i.e. on the SAME banks — a 4-way
+    // conflict on every fragment read, which capped the wide products at ~200 TFLOP/s / 2.5 TB/s (tools/mbench.py).  So the 16-byte
+    // column chunks of row o are stored XOR ((o >> 4) & 3) << 2: the four row groups of a read then sit 16 banks apart.  (The XOR
+    // stays inside an aligned group of 16 chunks: rows are padded to a multiple of 128 channels.)
+    constexpr int KS = KS0 + KS1 + KS2, KT = 32 * KS, WS = (KT + 127) / 128 * 128 + 8, OTW = 4;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, lk = lane >> 4;
@@ -447,10 +469,37 @@ __global__ __launch_bounds__(LF_THREADS) void linear_multi_b16_kernel(const LmPa
     const int cg = wave % p.CG, rg = wave / p.CG, nrg = LF_WAVES / p.CG;
     uint16_t* Wl = reinterpret_cast<uint16_t*>(lf_lds);                    // [NW][WS] bf16: row o = output channel n0 + o, column = stacked k
     {
+        // W_s [K_s][Cout] f32 -> the bf16 image [o][stacked k]: 16-byte reads along o, FOUR of them in flight per thread (one value per
+        // iteration made the prologue a chain of ~100 L2 round trips: 90 of the 189 us of a 384 -> 128 product, tools/mbench.py)
         constexpr int K0 = 32 * KS0, K1 = 32 * KS1, K2 = 32 * KS2;
-        for (int f = tid; f < K0 * NW; f += LF_THREADS) { const int c = f / NW, o = f - c * NW; const __bf16 h = (__bf16)p.W[0][(int64_t)c * Cout + n0 + o]; Wl[o * WS + c] = __builtin_bit_cast(uint16_t, h); }
-        for (int f = tid; f < K1 * NW; f += LF_THREADS) { const int c = f / NW, o = f - c * NW; const __bf16 h = (__bf16)p.W[1][(int64_t)c * Cout + n0 + o]; Wl[o * WS + K0 + c] = __builtin_bit_cast(uint16_t, h); }
-        for (int f = tid; f < K2 * NW; f += LF_THREADS) { const int c = f / NW, o = f - c * NW; const __bf16 h = (__bf16)p.W[2][(int64_t)c * Cout + n0 + o]; Wl[o * WS + K0 + K1 + c] = __builtin_bit_cast(uint16_t, h); }
+        const int q4 = NW / 4;
+        auto stage = [&](const float* __restrict__ W, int K, int koff) {
+            const int total = K * q4;
+            for (int f0 = tid; f0 < total; f0 += 4 * LF_THREADS) {
+                f32x4 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int f = f0 + u * LF_THREADS;
+                    if (f < total) { const int c = f / q4, o = 4 * (f - c * q4); v[u] = *reinterpret_cast<const f32x4*>(W + (int64_t)c * Cout + n0 + o); }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int f = f0 + u * LF_THREADS;
+                    if (f < total) {
+                        const int c = f / q4, o = 4 * (f - c * q4);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const __bf16 h = (__bf16)v[u][j];
+                            const int k = koff + c, sw = (((o + j) >> 4) & 3) << 2;
+                            Wl[(o + j) * WS + (((k >> 3) ^ sw) << 3) + (k & 7)] = __builtin_bit_cast(uint16_t, h);
+                        }
+                    }
+                }
+            }
+        };
+        if constexpr (KS0 > 0) stage(p.W[0], K0, 0);
+        if constexpr (KS1 > 0) stage(p.W[1], K1, K0);
+        if constexpr (KS2 > 0) stage(p.W[2], K2, K0 + K1);
     }
     __syncthreads();
     const int o_base = cg * OTW * 16;                     // this wave's first channel inside the slice
@@ -493,15 +542,19 @@ __global__ __launch_bounds__(LF_THREADS) void linear_multi_b16_kernel(const LmPa
             ad[a][1] = (ap && ok) ? *reinterpret_cast<const uint4*>(ap + 8) : make_uint4(0, 0, 0, 0);
         }
         load_tile(tile + stride, nx);
-        const uint16_t* wl = Wl;
-        if constexpr (KS > 4) asm volatile("" : "+v"(wl));     // W fragments are re-read from LDS per tile: hoisted out of the loop they are 16 KS registers (spills from 10 k-steps on)
+        // W fragments are re-read from LDS per tile: hoisted out of the loop they are 16 KS registers (spills from 10 k-steps on).  The
+        // opaque value is an OFFSET, not the pointer: behind an asm the pointer is a generic one and every read a flat_load (750 cycles
+        // per MFMA: the first form of this kernel ran its wide shapes at 200 TFLOP/s)
+        int woff = 0;
+        if constexpr (KS > 4) asm volatile("" : "+v"(woff));
+        const uint16_t* wl = Wl + woff;
         f32x4 acc[OTW];
 #pragma unroll
         for (int ot = 0; ot < OTW; ++ot) {
             acc[ot] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int g = 0; g < KS; ++g) {
-                const lf_bf16x8 a = __builtin_bit_cast(lf_bf16x8, *reinterpret_cast<const uint4*>(wl + (o_base + orow(ot)) * WS + wcol(g)));
+                const lf_bf16x8 a = __builtin_bit_cast(lf_bf16x8, *reinterpret_cast<const uint4*>(wl + (o_base + orow(ot)) * WS + (((wcol(g) >> 3) ^ ((li >> 2) << 2)) << 3)));
                 acc[ot] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, __builtin_bit_cast(lf_bf16x8, bx[g]), acc[ot], 0, 0, 0);
             }
         }
@@ -550,14 +603,15 @@ extern "C" int fgnn_linear_multi_forward(const void* const* x, const int32_t* K,
     int kt = 0;
     for (int s = 0; s < 3; ++s) {
         p.x[s] = (const uint16_t*)x[s]; p.W[s] = W[s]; p.add[s] = (const uint16_t*)addend[s];
-        if (K[s] && (!x[s] || !W[s] || ((uintptr_t)x[s] & 15))) FGNN_FAIL(FGNN_EINVAL, "linear_multi_forward: source %d missing or misaligned", s);
+        if (K[s] && (!x[s] || !W[s] || ((uintptr_t)x[s] & 15) || ((uintptr_t)W[s] & 15))) FGNN_FAIL(FGNN_EINVAL, "linear_multi_forward: source %d missing or misaligned", s);
         if (addend[s] && ((uintptr_t)addend[s] & 15)) FGNN_FAIL(FGNN_EUNSUPPORTED, "linear_multi_forward: addend %d is not 16-byte aligned", s);
         kt += K[s];
     }
     if ((uintptr_t)y & 15) FGNN_FAIL(FGNN_EUNSUPPORTED, "linear_multi_forward: y is not 16-byte aligned");
     p.y = (uint16_t*)y; p.R = (int)R; p.Cout = Cout;
     int NW = Cout;
-    while ((int64_t)NW * (kt + 8) * 2 > 150 * 1024 && NW > 64) NW /= 2;
+    const int ws_row = (kt + 127) / 128 * 128 + 8;       // (the kernel's padded, swizzled row)
+    while ((int64_t)NW * ws_row * 2 > 150 * 1024 && NW > 64) NW /= 2;
     p.NW = NW; p.CG = NW / 64;
     const int nrg = LF_WAVES / p.CG;
     const int64_t ntile = (R + 15) / 16;
@@ -567,7 +621,7 @@ extern "C" int fgnn_linear_multi_forward(const void* const* x, const int32_t* K,
     if (g > maxg) g = maxg;
     if (g < 1) g = 1;
     void* fn = lm_pick(K[0] / 32, K[1] / 32, K[2] / 32);
-    const int lds = NW * (kt + 8) * 2;
+    const int lds = NW * ws_row * 2;
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "hipFuncSetAttribute(%d B LDS): %s", lds, hipGetErrorString(e));

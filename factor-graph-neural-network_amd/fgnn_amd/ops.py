@@ -781,7 +781,8 @@ class FanBox:
         if not self.ok or gz.dim() != 2 or gz.shape[0] != self.R or gz.dtype != torch.bfloat16 or not gz.is_contiguous():
             return False
         K = gz.shape[1]
-        if tuple(weight.shape) != (K, self.C) or weight.dtype != torch.float32 or not weight.is_contiguous() or gz.data_ptr() % 16:
+        if (tuple(weight.shape) != (K, self.C) or weight.dtype != torch.float32 or not weight.is_contiguous() or gz.data_ptr() % 16
+                or weight.data_ptr() % 16):
             return False
         order = (0, 2, 1) if K == 64 else ((1,) if K in (128, 256) else ())
         for i in order:

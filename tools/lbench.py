@@ -25,7 +25,7 @@ def graph_time(run, iters=48):
     return s.elapsed_time(e) / iters * 1e3
 
 
-for N in (96, 48):
+for N in ((96, 48) if __name__ == '__main__' else ()):
     for cin, cout in [(64, 64), (64, 128), (128, 64), (128, 128), (64, 256), (256, 64), (128, 256), (256, 128), (256, 256)]:
         R = 4096 * N
         K = max(2, int(2.4e9 // (R * (cin + cout) * 2)))
