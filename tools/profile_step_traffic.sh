@@ -13,5 +13,5 @@ for c in FETCH_SIZE WRITE_SIZE; do
         python bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/$c.log 2>&1
     find /tmp/st_$c -name "*counter_collection.csv" -exec cp {} $OUT/$c.csv \;
 done
-python tools/step_traffic.py $OUT/FETCH_SIZE.csv $OUT/WRITE_SIZE.csv profiles/r05/train_step_sequence.csv > $OUT/step_traffic.txt
+python tools/step_traffic.py $OUT/FETCH_SIZE.csv $OUT/WRITE_SIZE.csv ${FGNN_STEP_SEQ:-profiles/r05/train_step_sequence.csv} > $OUT/step_traffic.txt
 head -40 $OUT/step_traffic.txt

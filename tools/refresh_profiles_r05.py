@@ -6,7 +6,7 @@
   * pmc_traffic.json: what bench.py's roofline object reads — HBM bytes per launch (FETCH_SIZE x 2 for gfx950 + WRITE_SIZE,
     MI355X_MICROARCH.md) and the matrix-core busy fraction, keyed by kernel symbol,
   * bench_*.json: bench.py lines of the final code and of the A/B switches of the round's levers; kbench_* / lbench / wbench /
-    tbench / sbench: stand-alone device times; cpu_baseline_all_cores.json; train_step_{timeline,sequence}."""
+    tbench / sbench / mbench: stand-alone device times; cpu_baseline_all_cores.json; train_step_{timeline,sequence,traffic}."""
 import csv
 import glob
 import json
@@ -104,7 +104,7 @@ def main():
     json.dump(traffic, open(os.path.join(DST, 'pmc_traffic.json'), 'w'), indent=1)
     import glob as _g
     names = [os.path.basename(f) for f in _g.glob(os.path.join(SRC, 'bench_*.json'))] + ['cpu_baseline_all_cores.json', 'lbench.log',
-                                                                                       'wbench.log', 'tbench.log', 'sbench.log']
+                                                                                       'wbench.log', 'tbench.log', 'sbench.log', 'mbench.log']
     names += [os.path.basename(f) for f in _g.glob(os.path.join(SRC, 'kbench_*.log'))]
     for f in names:
         if os.path.exists(os.path.join(SRC, f)):
@@ -114,6 +114,8 @@ def main():
     for f in ('timeline.txt', 'timeline.json'):
         if os.path.exists(os.path.join(SRC, 'timeline', f)):
             shutil.copy(os.path.join(SRC, 'timeline', f), os.path.join(DST, 'train_step_' + f))
+    if os.path.exists(os.path.join(SRC, 'traffic', 'step_traffic.txt')):
+        shutil.copy(os.path.join(SRC, 'traffic', 'step_traffic.txt'), os.path.join(DST, 'train_step_traffic.txt'))
     print(json.dumps(traffic['kernels'], indent=1))
 
 
