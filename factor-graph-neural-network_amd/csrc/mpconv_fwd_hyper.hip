@@ -183,6 +183,132 @@ __global__ __launch_bounds__(512) void mpconv_fwd_fanin_kernel(const FhParams p)
 }
 
 // ----------------------------------------------------------------------------------------
+// fan-in, max aggregation, IDENTITY neighbour list (k == N, idx[j] == j: the LDPC hyper-factor listens to every variable in order,
+// /root/reference/train_ldpc.py:40-46) — round 5.  The kernel above is one dependency chain per wave (4 us fixed + 13 us projection
+// + 12 us neighbour walk at 4096 codewords, gpurun_out/r05s): it writes P to an LDS image and walks the 96 neighbours one by one
+// per output-channel lane — ~12 wave instructions per neighbour.  With the neighbours in node order the reduction stays in the MFMA
+// accumulators: D[i = channel][j = node] of a node tile gives lane (node li, channel group lk) four channels of ONE node, so the
+// lane keeps a running (max, first argmax) over its node position across the tiles — 4 instructions per value — and the 16 node
+// lanes meet once per sample through a 5 KB LDS transpose (lane <-> channel reads its 16 candidates: larger value, then smaller
+// node).  No P image (the projected values stay f32), no per-neighbour LDS reads or readlanes; 4 waves of 128 registers per
+// workgroup, so every sample of a 4096-codeword batch is resident at once.
+// ----------------------------------------------------------------------------------------
+#define FI_ROWPAD 4      // floats: candidate rows 16 bytes apart in their bank phase
+#ifndef FI_TB
+#define FI_TB 3          // node tiles whose loads are in flight together at 64 input channels: 6 (the whole sample) costs 166 registers = 2-3 waves per SIMD, 3 costs 118 = 4
+#endif
+
+template <int KS2, int OT, bool ARG>
+__global__ __launch_bounds__(256) void mpconv_fwd_fanin_id_kernel(const FhParams p) {
+    constexpr int NIN = 32 * KS2, NOU = 16 * OT, NO = NOU / 64, TB = KS2 == 2 ? FI_TB : 3, CROW = NOU + FI_ROWPAD;
+    const fgnn_mpconv_desc& d = p.d;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lk = lane >> 4;
+    const int N = d.N;
+    float* cand = reinterpret_cast<float*>(fgnn_lds_fh) + (size_t)wave * 16 * CROW;                   // [16 node lanes][NOU (+pad)] f32
+    uint8_t* carg = reinterpret_cast<uint8_t*>(reinterpret_cast<float*>(fgnn_lds_fh) + 4 * 16 * CROW) + (size_t)wave * 16 * NOU;   // [16][NOU] u8
+    const int ntile = p.Npad16 / 16;
+    const int nwaves = gridDim.x * 4;
+    int b = blockIdx.x * 4 + wave;
+    // the first sample's rows go out before the W fragments are fetched (64 strided 4-byte loads per lane: the kernel's fixed cost)
+    fh_bf16x8 aP[OT][KS2];
+#pragma unroll
+    for (int ot = 0; ot < OT; ++ot)
+#pragma unroll
+        for (int ks = 0; ks < KS2; ++ks) {
+            float w8[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) w8[u] = p.W[(int64_t)(32 * ks + 8 * lk + u) * NOU + ot * 16 + li];
+            aP[ot][ks] = __builtin_bit_cast(fh_bf16x8, make_uint4(fh_pack2(w8[0], w8[1]), fh_pack2(w8[2], w8[3]),
+                                                                  fh_pack2(w8[4], w8[5]), fh_pack2(w8[6], w8[7])));
+        }
+    float c_bias[NO], c_scale[NO], c_shift[NO];
+#pragma unroll
+    for (int q = 0; q < NO; ++q) {
+        const int o = lane + 64 * q;
+        c_bias[q] = p.bias ? p.bias[o] : 0.f;
+        c_scale[q] = p.pscale ? p.pscale[o] : 1.f;
+        c_shift[q] = p.pscale ? p.pshift[o] : 0.f;
+    }
+    for (; b < d.B; b += nwaves) {
+        const uint16_t* xb = p.x + (int64_t)b * d.x_sb;
+        const uint16_t* eb = p.et + (int64_t)b * d.et_sb;
+        float best[OT][4];
+        int arg[OT][4];
+#pragma unroll
+        for (int ot = 0; ot < OT; ++ot)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { best[ot][r] = -__builtin_huge_valf(); arg[ot][r] = 255; }
+        for (int nt0 = 0; nt0 < ntile; nt0 += TB) {
+            uint4 bx[TB][KS2];
+            float ew[TB];
+#pragma unroll
+            for (int t = 0; t < TB; ++t) {
+                const int n = (nt0 + t) * 16 + li;
+                const bool ok = n < N;
+#pragma unroll
+                for (int ks = 0; ks < KS2; ++ks)
+                    bx[t][ks] = ok ? *reinterpret_cast<const uint4*>(xb + (int64_t)n * NIN + 32 * ks + 8 * lk) : make_uint4(0, 0, 0, 0);
+                ew[t] = ok ? __uint_as_float((unsigned)eb[(int64_t)n * d.et_sk] << 16) : 0.f;
+            }
+#pragma unroll
+            for (int t = 0; t < TB; ++t) {
+                const int n = (nt0 + t) * 16 + li;
+                if (nt0 + t < ntile) {                               // (wave-uniform)
+                    const bool ok = n < N;
+#pragma unroll
+                    for (int ot = 0; ot < OT; ++ot) {
+                        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int ks = 0; ks < KS2; ++ks)
+                            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aP[ot][ks], __builtin_bit_cast(fh_bf16x8, bx[t][ks]), acc, 0, 0, 0);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {                // acc[r] = P[node n][channel 16 ot + 4 lk + r]
+                            const float v = ew[t] * acc[r];
+                            const bool take = ok && v > best[ot][r];   // strict >: the lane's first occurrence (its nodes ascend)
+                            best[ot][r] = take ? v : best[ot][r];
+                            if constexpr (ARG) arg[ot][r] = take ? n : arg[ot][r];
+                        }
+                    }
+                }
+            }
+        }
+        // the 16 node lanes meet: candidates [node lane][channel] through the wave's LDS rows, then lane <-> channel
+#pragma unroll
+        for (int ot = 0; ot < OT; ++ot) {
+            *reinterpret_cast<f32x4*>(cand + li * CROW + 16 * ot + 4 * lk) = (f32x4){best[ot][0], best[ot][1], best[ot][2], best[ot][3]};
+            if constexpr (ARG)
+                *reinterpret_cast<unsigned*>(carg + li * NOU + 16 * ot + 4 * lk) =
+                    (unsigned)arg[ot][0] | ((unsigned)arg[ot][1] << 8) | ((unsigned)arg[ot][2] << 16) | ((unsigned)arg[ot][3] << 24);
+        }
+#pragma unroll
+        for (int q = 0; q < NO; ++q) {
+            const int o = lane + 64 * q;
+            float bv = cand[o];
+            int ba = ARG ? (int)carg[o] : 0;
+#pragma unroll
+            for (int j = 1; j < 16; ++j) {
+                const float v = cand[j * CROW + o];
+                if constexpr (ARG) {
+                    const int a = (int)carg[j * NOU + o];
+                    const bool take = v > bv || (v == bv && a < ba);
+                    bv = take ? v : bv;
+                    ba = take ? a : ba;
+                } else {
+                    bv = fmaxf(bv, v);
+                }
+            }
+            float res = (bv + c_bias[q]) * c_scale[q] + c_shift[q];
+            if (d.relu) res = fmaxf(res, 0.f);
+            const int64_t off = (int64_t)b * d.y_sb + (int64_t)o * d.y_sc;
+            p.y[off] = fh_bf16(res);
+            if constexpr (ARG) p.argmax[off] = (uint8_t)ba;
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------------------
 // fan-out: N == 1, k == 1; y channel-fastest [M][nou].  CH = nou / 16 channels per lane.
 // ----------------------------------------------------------------------------------------
 template <int NI, int CH>
@@ -287,6 +413,24 @@ int fgnn_mpconv_forward_hyper(const fgnn_mpconv_desc* d, const void* x, const in
     if (fanin) {
         if (!(d->x_sc == 1 && d->x_sn == d->nin && d->x_sb % 8 == 0) || ((uintptr_t)x & 15)) FH_REJECT(4);
         const int KS2 = d->nin / 32, OT = d->nou / 16;
+        static const bool no_id = getenv("FGNN_NO_FANIN_ID") != nullptr;
+        // the caller vouches for an identity neighbour list (FGNN_DESC_IDENTITY_LIST): the reduction stays in the MFMA accumulators
+        if (!no_id && (d->reserved & FGNN_DESC_IDENTITY_LIST) && d->agg == FGNN_AGG_MAX && d->k == d->N && d->N <= 128 && d->N >= 2) {
+            void* idfn = nullptr;
+#define FI_CASE(ks, ot) if (KS2 == ks && OT == ot) idfn = argmax ? (void*)mpconv_fwd_fanin_id_kernel<ks, ot, true> : (void*)mpconv_fwd_fanin_id_kernel<ks, ot, false>;
+            FI_CASE(2, 4) FI_CASE(2, 8) FI_CASE(4, 4)
+#undef FI_CASE
+            if (idfn) {
+                int g = (d->B + 3) / 4;
+                if (g > 1024) g = 1024;
+                const int idlds = 4 * 16 * (d->nou + FI_ROWPAD) * 4 + 4 * 16 * d->nou;
+                fgnn_note_kernel("mpconv_fwd_fanin_id_kernel<%d, %d>", KS2, OT);
+                void* args[] = {(void*)&p};
+                hipError_t e = hipLaunchKernel(idfn, dim3(g), dim3(256), args, idlds, (hipStream_t)stream);
+                if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "mpconv hyper-edge forward launch: %s", hipGetErrorString(e));
+                return 1;
+            }
+        }
         fn = d->agg == FGNN_AGG_MAX ? fh_pick_fanin<FGNN_AGG_MAX>(KS2, OT)
            : d->agg == FGNN_AGG_LSE ? fh_pick_fanin<FGNN_AGG_LSE>(KS2, OT) : fh_pick_fanin<FGNN_AGG_MEAN>(KS2, OT);
         const int per_wave = p.Npad16 * d->nou * 2;

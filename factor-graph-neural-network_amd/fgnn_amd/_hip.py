@@ -15,6 +15,7 @@ LIB_PATH = os.environ.get('FGNN_HIP_LIB') or os.path.join(_HERE, 'libfgnn_hip.so
 
 EXT_NONE, EXT_NEIGHBOR, EXT_DIFF = 0, 1, 2
 DESC_GETYPE_REDUCED = 0x10000
+DESC_IDENTITY_LIST = 0x20000       # forward: the one-destination call's neighbour table is idx[j] == j
 AGG_MAX, AGG_LSE, AGG_MEAN = 0, 1, 2
 F32, BF16 = 0, 1
 ABI_VERSION = 9              # include/fgnn_hip.h: FGNN_ABI_VERSION (checked before any symbol is bound)

@@ -126,19 +126,7 @@ class flatten(torch.nn.Module):
 
 
 def _is_identity_list(nn_idx):
-    """nn_idx [B, 1, k] lists nodes 0..k-1 in order for every sample (the hyper-factor's neighbour table).  Checked on
-    the device once per table — the fused fan-in block does not read the table at all.  The verdict is remembered ON the
-    tensor that owns the memory (the view's base, e.g. LDPCModel's frozen `hnn_idx_v2f` behind its per-call `expand`),
-    keyed by version and view geometry, so it can never outlive or be confused with another table."""
-    owner = nn_idx._base if nn_idx._base is not None else nn_idx
-    key = (nn_idx._version, nn_idx.storage_offset(), tuple(nn_idx.shape), tuple(nn_idx.stride()))
-    memo = getattr(owner, '_fgnn_identity_list', None)
-    if memo is None or memo[0] != key:
-        k = nn_idx.shape[-1]
-        hit = bool((nn_idx == torch.arange(k, device=nn_idx.device, dtype=nn_idx.dtype)).all().item())
-        memo = (key, hit)
-        owner._fgnn_identity_list = memo
-    return memo[1]
+    return ops.is_identity_list(nn_idx)
 
 
 FUSE_TRAIN_TAIL = True       # training: BatchNorm2 + ReLU -> conv2 -> BatchNorm3 + LeakyReLU (+ addends) without storing conv2's output

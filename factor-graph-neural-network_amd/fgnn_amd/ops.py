@@ -319,6 +319,24 @@ def shared_graph_view(nn_idx):
     return nn_idx[:1].expand(B, -1, -1) if memo[1] else nn_idx
 
 
+def is_identity_list(nn_idx):
+    """nn_idx [B, 1, k] lists nodes 0..k-1 in order for every sample (the hyper-factor's neighbour table).  Checked on the device
+    once per table; the verdict is remembered ON the tensor that owns the memory (the view's base, e.g. LDPCModel's frozen
+    `hnn_idx_v2f` behind its per-call `expand`), keyed by version and view geometry, so it can never outlive or be confused with
+    another table.  While a hipGraph is being captured no host read is possible: an unseen table is then taken as general."""
+    owner = nn_idx._base if nn_idx._base is not None else nn_idx
+    key = (nn_idx._version, nn_idx.storage_offset(), tuple(nn_idx.shape), tuple(nn_idx.stride()))
+    memo = getattr(owner, '_fgnn_identity_list', None)
+    if memo is None or memo[0] != key:
+        if nn_idx.is_cuda and torch.cuda.is_current_stream_capturing():
+            return False
+        k = nn_idx.shape[-1]
+        hit = bool((nn_idx == torch.arange(k, device=nn_idx.device, dtype=nn_idx.dtype)).all().item())
+        memo = (key, hit)
+        owner._fgnn_identity_list = memo
+    return memo[1]
+
+
 def max_in_degree(nn_idx, N):
     """Largest number of times one source node appears in a batch-SHARED neighbour table (the degree of the transposed
     incidence), 0 when unknown.  The second-generation backward (csrc/mpconv_bwd_sg.hip) keeps every source node's
@@ -397,6 +415,8 @@ def mpconv_forward_raw(x, nn_idx, etype, filters, bias, nou, net, ext, agg, *,
     f32 = lambda t: None if t is None else t.detach().float().contiguous()
     bias, post_scale, post_shift = f32(bias), f32(post_scale), f32(post_shift)
     d = _hip.make_desc(x, nn_idx, etype, nou, net, ext, agg, relu, y)
+    if M == 1 and net == 1 and agg == _hip.AGG_MAX and nn_idx.shape[2] == x.shape[2] and x.shape[2] > 1 and is_identity_list(nn_idx):
+        d.reserved |= _hip.DESC_IDENTITY_LIST          # (the hyper-factor's table: the fan-in kernel reduces in its accumulators)
     nbytes = int(L.fgnn_mpconv_algorithmic_bytes(ctypes.byref(d))) if TIMER is not None else 0
     npart = 0
     if bn is not None and STATS_EPILOGUE and post_scale is None and not relu:

@@ -45,7 +45,7 @@ typedef struct fgnn_mpconv_desc {
     int32_t agg;    /* FGNN_AGG_*  */
     int32_t dtype;  /* FGNN_F32 / FGNN_BF16: storage type of x, etype, y (accumulation is f32) */
     int32_t relu;   /* apply max(.,0) last (forward only) */
-    int32_t reserved; /* backward only: bits 0-15 = largest in-degree of the shared neighbour table (0 = unknown),
+    int32_t reserved; /* forward: FGNN_DESC_IDENTITY_LIST (below); backward: bits 0-15 = largest in-degree of the shared neighbour table (0 = unknown),
                          FGNN_DESC_GETYPE_REDUCED = getype is the batch-summed [net, M, k] gradient (see below) */
     int64_t x_sb, x_sc, x_sn;
     int64_t idx_sb, idx_sm, idx_sk;
@@ -156,6 +156,11 @@ int fgnn_mpconv_backward_with_tables(const fgnn_mpconv_desc* d, const void* x, c
  * order) instead of [B, net, M, k]; with the flag set on any other descriptor the call fails with FGNN_EUNSUPPORTED.
  */
 #define FGNN_DESC_GETYPE_REDUCED 0x10000
+/* forward only, in fgnn_mpconv_desc.reserved: the caller vouches that the (batch-shared) neighbour table of a one-destination call
+ * (M == 1, k == N) is the identity list idx[j] == j — the LDPC hyper-factor's (train_ldpc.py:40-46).  The fan-in kernel then never reads
+ * the table and reduces over the nodes in the matrix-core accumulators (the projected values stay f32: the general kernel rounds them
+ * to bf16 before the edge weight — results agree to bf16 rounding).  Unset = the general kernel. */
+#define FGNN_DESC_IDENTITY_LIST 0x20000
 int fgnn_mpconv_backward_reduces_getype(const fgnn_mpconv_desc* d);
 
 /* Bytes of dynamic LDS the forward will request for this descriptor (diagnostics / tests). */

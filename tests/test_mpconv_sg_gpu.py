@@ -416,3 +416,44 @@ def test_ws_backward_with_prebuilt_tables_is_bit_identical(shape, dev, monkeypat
     b, c = run(False), run(True)
     for u, v, w in zip(a[:4], b[:4], c[:4]):
         assert torch.equal(u, v) and torch.equal(u, w)
+
+
+@pytest.mark.parametrize('width', [(64, 64), (64, 128), (128, 64)], ids=lambda w: '%dto%d' % w)
+@pytest.mark.parametrize('N', [96, 50, 16, 128, 1 + 16])
+@pytest.mark.parametrize('want_argmax', [True, False], ids=['train', 'eval'])
+def test_identity_list_fanin_forward_vs_general_kernel_and_oracle(width, N, want_argmax, dev, monkeypatch):
+    """The hyper-factor's V -> F call (ONE destination listening to all N variables in order, train_ldpc.py:40-46): when the
+    neighbour table is the identity list the forward reduces over the nodes in the matrix-core accumulators
+    (mpconv_fwd_fanin_id_kernel, FGNN_DESC_IDENTITY_LIST) instead of walking an LDS image of P neighbour by neighbour.  Against the
+    general kernel (which rounds the projected values to bf16 before the edge weight: agreement to bf16 rounding, the same winner
+    wherever the general kernel's margin is clear), against the f32 oracle, exact ties -> the first node, bit-reproducible."""
+    from fgnn_amd import _hip, ops
+    nin, nou = width
+    B = 37
+    g = torch.Generator().manual_seed(N + nin)
+    x = torch.randn(B, N, 1, nin, generator=g).bfloat16()
+    x[3, min(5, N - 1)] = x[3, 0]                                      # an exact tie between two nodes of one sample: first occurrence wins
+    idx = torch.arange(N).reshape(1, 1, N)
+    et = (torch.rand(B, 1, 1, N, generator=g) + 0.5).bfloat16()
+    et[3, 0, 0, min(5, N - 1)] = et[3, 0, 0, 0]
+    W = torch.randn(nin, nou, generator=g) * 0.1
+    bias = torch.randn(nou, generator=g)
+    xd = x.to(dev).permute(0, 3, 1, 2)
+    idxd = idx.to(dev).expand(B, -1, -1)
+    etd = et.to(dev)
+    Wd, bd = W.to(dev), bias.to(dev)
+    y1, a1 = ops.mpconv_forward_raw(xd, idxd, etd, Wd, bd, nou, 1, 0, _hip.AGG_MAX, want_argmax=want_argmax)
+    assert _hip.lib().fgnn_last_kernel().decode().startswith('mpconv_fwd_fanin_id_kernel')
+    y1b, a1b = ops.mpconv_forward_raw(xd, idxd, etd, Wd, bd, nou, 1, 0, _hip.AGG_MAX, want_argmax=want_argmax)
+    assert torch.equal(y1, y1b) and (a1 is None or torch.equal(a1, a1b))
+    monkeypatch.setattr(ops, 'is_identity_list', lambda t: False)
+    y0, a0 = ops.mpconv_forward_raw(xd, idxd, etd, Wd, bd, nou, 1, 0, _hip.AGG_MAX, want_argmax=True)
+    assert _hip.lib().fgnn_last_kernel().decode().startswith('mpconv_fwd_fanin_kernel')
+    assert H.rel_err(y1.float(), y0.float()) <= 2.0 ** -6
+    if want_argmax:
+        assert float((a1 != a0).float().mean()) <= 0.05                # (near-ties may resolve differently: f32 vs bf16-rounded projections)
+        if N > 5:
+            assert int((a1[3] == 5).sum()) == 0                        # the exact tie went to node 0, never to its copy
+    ref = O.mp_conv({'filters': W.bfloat16().float(), 'bias': bias}, '', x.permute(0, 3, 1, 2).float().contiguous(), idx.expand(B, -1, -1).contiguous(),
+                    et.float(), nou=nou, net=1, extension=0, aggregator='max', relu=False)
+    assert H.rel_err(y1.float().cpu(), ref) <= 2.0 ** -7

@@ -42,6 +42,7 @@ def main():
     ap.add_argument('--bwd', action='store_true')
     ap.add_argument('--regular', action='store_true', help='regular random graphs (constant in-degree) for the parity shapes')
     ap.add_argument('--only', default='')
+    ap.add_argument('--random-hyper', action='store_true', help='hyper V->F shapes with a random neighbour table instead of the identity list')
     ap.add_argument('--syn', action='store_true', help='the synthetic-PGM shapes instead of the LDPC ones')
     ap.add_argument('--shared-et', action='store_true', help='edge types shared by the batch ([1, net, M, k] expanded), as in the synthetic-PGM scripts')
     ap.add_argument('--argmax', action='store_true', help='forward that also stores the argmax (what training needs)')
@@ -65,7 +66,9 @@ def main():
         x = torch.randn(B, nin, N, 1, generator=g).to(dev, dt)
         if a.layout == 'cl':
             x = x.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
-        if a.regular and (M * k) % N == 0:
+        if M == 1 and k == N and not a.random_hyper:
+            idx = torch.arange(N).reshape(1, 1, N).to(dev).expand(B, -1, -1)       # the LDPC hyper-factor's table (train_ldpc.py:40-46): every variable, in order
+        elif a.regular and (M * k) % N == 0:
             # a random REGULAR bipartite graph (every source node appears M k / N times), like the 96.3.963 code
             slots = torch.arange(N).repeat_interleave(M * k // N)[torch.randperm(M * k, generator=g)]
             idx = slots.reshape(1, M, k).to(dev).expand(B, -1, -1)
