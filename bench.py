@@ -759,7 +759,9 @@ def main():
                 step_ms = (r2['ms'] / r2['launches']) if r2 else iso_ms
                 nb, nf = r['bytes'] / n, r['flops'] / n
                 gbs = nb / (step_ms * 1e-3) / 1e9
-                bf16 = any(t in sym for t in ('b16', '_sg_', '_ws_'))      # the bf16-storage, bf16-MFMA kernel families: HBM-bound (AI ~80 << ridge ~312)
+                # bf16 storage + bf16 MFMA (every operator kernel of a --dtype bf16 run, the hyper-factor fan-in / fan-out ones included:
+                # their symbols carry no 'b16'): HBM-bound (AI ~80 << ridge ~312); the f32 kernels price against the f32 matrix rate
+                bf16 = args.dtype == 'bf16' or any(t in sym for t in ('b16', '_sg_', '_ws_'))
                 d = {'kernel': sym, 'launches_per_step': n, 'bound': 'hbm' if bf16 else 'mfma',
                      'algorithmic_bytes_per_launch': int(nb), 'algorithmic_flops_per_launch': int(nf),
                      'avg_launch_us_isolated': round(iso_ms * 1e3, 2), 'avg_launch_us_in_step': round(step_ms * 1e3, 2),

@@ -22,6 +22,8 @@ struct FgnnFoldJob {
     float* gb;
     int64_t slab_len, nw;
     int nslab, kind;        // kind 0: gW[(i / a) * b + i % a] (a = ncols, b = ld); kind 1: the node-wise maps' register-order slabs
+                            // (kind 1: nw = the elements to fold, slab_len = the distance between slabs — a merged launch's slabs
+                            // hold several maps' slices, linear_wgrad_b16.hip::wb_launch; kind 0: slab_len is both)
     int a, b, c, d;         // kind 1: a = S, b = nso, c = Cin, d = Cout
 };
 
@@ -79,7 +81,7 @@ __global__ __launch_bounds__(1024) void fold_batch_kernel(const FbBatch t) {
     const FgnnFoldJob& q = t.job[j];
     const int l = threadIdx.x & (FB_LANES - 1), g = threadIdx.x / FB_LANES;
     const int64_t i0 = (int64_t)((int)blockIdx.x - t.first[j]) * FB_PER_WG + 4 * l;      // slab_len % 4 == 0 for every producer
-    const bool in = i0 < q.slab_len;
+    const bool in = i0 < (q.kind == 1 ? q.nw : q.slab_len);
     f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
     if (in) {
         const float* base = q.ws + i0;
@@ -158,7 +160,7 @@ extern "C" int fgnn_fold_flush(fgnn_stream_t stream) {
             if (clash) { skipped.push_back(n); continue; }
             t.first[t.njobs] = blocks;
             t.job[t.njobs++] = jobs[n];
-            blocks += (int)((jobs[n].slab_len + FB_PER_WG - 1) / FB_PER_WG);
+            blocks += (int)(((jobs[n].kind == 1 ? jobs[n].nw : jobs[n].slab_len) + FB_PER_WG - 1) / FB_PER_WG);
             done[n] = 1;
             --left;
         }

@@ -30,12 +30,19 @@ bool fgnn_fold_push(const float* ws, int nslab, int64_t slab_len, int64_t nw, fl
 typedef __bf16 wb_bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 wb_bf16x2 __attribute__((ext_vector_type(2)));
 
+#define WB_MAXSRC 3
 struct WgbParams {
     const uint16_t* x;   // [R][Cin]  bf16
-    const uint16_t* gy;  // [R][Cout] bf16
+    const uint16_t* gy;  // [R][Cout] bf16 (source 0)
     float* ws;           // [gridDim.x][S][WB_NACC][64]
     int R, Cin, Cout;
     int nso, S, RW;      // output-channel slices, slices per workgroup, row-waves per slice (S * RW == 16)
+    // Several gradient tensors contracted with the SAME x in one pass (fgnn_linear_wgrad_multi: the maps that consume one layer
+    // state — x is read once instead of once per map).  Source s owns slices [sb[s], sb[s + 1]), ordered sc * nso_s + so inside;
+    // slices >= sb[WB_MAXSRC] (S padded to a power of two) belong to nobody: their waves only take part in the fold's barriers.
+    const uint16_t* gys[WB_MAXSRC];
+    int couts[WB_MAXSRC];
+    int sb[WB_MAXSRC + 1];
 };
 
 extern __shared__ __attribute__((aligned(16))) float wb_lds[];
@@ -66,10 +73,14 @@ __global__ __launch_bounds__(WB_THREADS) void linear_wgrad_b16_kernel(const WgbP
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, lk = lane >> 4;
-    const int slice = wave % p.S, rw = wave / p.S;     // slice = sc * nso + so
-    const int so = slice % p.nso, sc = slice / p.nso;
-    const int R = p.R, Cin = p.Cin, Cout = p.Cout;
-    const uint16_t* gyp = p.gy + so * 64 + 4 * li;
+    const int slice = wave % p.S, rw = wave / p.S;     // slice = sb[source] + sc * nso + so
+    const int src = slice >= p.sb[2] ? 2 : (slice >= p.sb[1] ? 1 : 0);
+    const bool live = slice < p.sb[WB_MAXSRC];
+    const int Cout = src == 2 ? p.couts[2] : (src == 1 ? p.couts[1] : p.couts[0]);
+    const int nso = Cout >> 6, sl = slice - (src == 2 ? p.sb[2] : (src == 1 ? p.sb[1] : p.sb[0]));
+    const int so = sl % nso, sc = sl / nso;
+    const int R = p.R, Cin = p.Cin;
+    const uint16_t* gyp = (src == 2 ? p.gys[2] : (src == 1 ? p.gys[1] : p.gys[0])) + so * 64 + 4 * li;
     const uint16_t* xp = p.x + sc * 64 + 4 * li;
 
     f32x4 acc[4][4];
@@ -79,7 +90,7 @@ __global__ __launch_bounds__(WB_THREADS) void linear_wgrad_b16_kernel(const WgbP
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const int nblk = (R + 31) / 32;
+    const int nblk = live ? (R + 31) / 32 : 0;
     const int stride = gridDim.x * p.RW;
     uint2 rg[8], rx[8];
     auto load = [&](int blk) {
@@ -140,7 +151,7 @@ __global__ __launch_bounds__(WB_THREADS) void linear_wgrad_b16_kernel(const WgbP
         }
         __syncthreads();
     }
-    if (rw == 0) {                                     // register-order slab: [slice][q][lane], coalesced
+    if (rw == 0 && live) {                             // register-order slab: [slice][q][lane], coalesced
 #pragma unroll
         for (int a = 0; a < 4; ++a) {                  // dbias: fold the 4 row-group lanes of a channel
             bs[a] += __shfl_xor(bs[a], 16);
@@ -162,13 +173,12 @@ __global__ __launch_bounds__(WB_THREADS) void linear_wgrad_b16_kernel(const WgbP
 // accumulator register of one slice, lanes 0..63: a 256-byte line per slab): wave w folds slabs w, w+16, ... — at most 16
 // independent line loads, all in flight at once — and wave 0 folds the 16 partial sums in order.  Fixed order: deterministic.
 // (The first form gave each 256-thread block 16 elements: 64-byte pieces, 24 us per call for 4 MB of slabs.)
-__global__ __launch_bounds__(1024) void wgb_reduce_kernel(const float* __restrict__ ws, int nslab, int S, int nso,
+__global__ __launch_bounds__(1024) void wgb_reduce_kernel(const float* __restrict__ ws, int nslab, int64_t slab_len, int nso,
                                                           int Cin, int Cout, float* __restrict__ gW,
                                                           float* __restrict__ gb) {
     __shared__ float part[16][64];
-    const int l = threadIdx.x & 63, g = threadIdx.x >> 6;
-    const int64_t slab_len = (int64_t)S * WB_NACC * 64;
-    const int64_t i = (int64_t)blockIdx.x * 64 + l;    // i < slab_len (slab_len % 64 == 0)
+    const int l = threadIdx.x & 63, g = threadIdx.x >> 6;      // slab_len = distance between slabs (a merged launch's slabs hold several maps' slices)
+    const int64_t i = (int64_t)blockIdx.x * 64 + l;    // i < this map's S * WB_NACC * 64
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     {
         const float* base = ws + i;
@@ -369,6 +379,94 @@ int64_t fgnn_linear_wgrad_b16_workspace_bytes(int64_t R, int Cin, int Cout) {
     return (int64_t)gx * S * WB_NACC * 64 * 4;
 }
 
+// nsrc gradient tensors against one x: live slices, S padded to a power of two <= 16, row-waves, grid
+static bool wb_plan_multi(int64_t R, int Cin, int nsrc, const int32_t* couts, int* sb, int* S, int* RW, int* gx) {
+    if (nsrc < 1 || nsrc > WB_MAXSRC || Cin % 64 || Cin < 64 || Cin > 256) return false;
+    int live = 0;
+    for (int s = 0; s < WB_MAXSRC; ++s) {
+        sb[s] = live;
+        if (s < nsrc) {
+            if (couts[s] % 64 || couts[s] < 64 || couts[s] > 256) return false;
+            live += (couts[s] / 64) * (Cin / 64);
+        }
+    }
+    sb[WB_MAXSRC] = live;
+    if (live > 16) return false;
+    int sp = 1;
+    while (sp < live) sp *= 2;
+    *S = sp;
+    *RW = 16 / sp;
+    static const int wgs = getenv("FGNN_WB_GRID") ? atoi(getenv("FGNN_WB_GRID")) : 256;
+    const int64_t nblk = (R + 31) / 32;
+    int64_t g = (nblk + 2 * *RW - 1) / (2 * *RW);                      // >= 2 blocks per row-wave
+    if (g > wgs) g = wgs;
+    if (g < 1) g = 1;
+    *gx = (int)g;
+    return true;
+}
+
+static int wb_launch(const void* x, int64_t R, int Cin, int nsrc, const void* const* gys, const int32_t* couts, float* const* gWs,
+                     float* const* gbs, const int* sb, int S, int RW, int gx, void* workspace, hipStream_t st) {
+    WgbParams p = {};
+    p.x = (const uint16_t*)x; p.gy = (const uint16_t*)gys[0]; p.ws = (float*)workspace;
+    p.R = (int)R; p.Cin = Cin; p.Cout = couts[0]; p.nso = couts[0] / 64; p.S = S; p.RW = RW;
+    for (int s = 0; s < WB_MAXSRC; ++s) {
+        p.gys[s] = (const uint16_t*)gys[s < nsrc ? s : 0];
+        p.couts[s] = couts[s < nsrc ? s : 0];
+        p.sb[s] = sb[s];
+    }
+    p.sb[WB_MAXSRC] = sb[WB_MAXSRC];
+    const int lds = S * (RW / 2) * WB_NACC * 64 * 4;                   // 0 when every slice has one row-wave
+    void* fn = (void*)linear_wgrad_b16_kernel;
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+    }
+    void* args[] = {(void*)&p};
+    hipError_t e = hipLaunchKernel(fn, dim3(gx), dim3(WB_THREADS), args, lds, st);
+    if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "linear_wgrad_b16 launch: %s", hipGetErrorString(e));
+    const int64_t stride = (int64_t)S * WB_NACC * 64;                  // distance between the workgroups' slabs
+    for (int s = 0; s < nsrc; ++s) {
+        const int Ss = sb[s + 1] - sb[s], nso = couts[s] / 64;
+        const int64_t len = (int64_t)Ss * WB_NACC * 64;
+        const float* ws_s = p.ws + (int64_t)sb[s] * WB_NACC * 64;
+        if (fgnn_fold_push(ws_s, gx, stride, len, gWs[s], gbs ? gbs[s] : nullptr, 1, Ss, nso, Cin, couts[s])) continue;      // recorded (fold_batch.hip)
+        hipLaunchKernelGGL(wgb_reduce_kernel, dim3((unsigned)(len / 64)), dim3(1024), 0, st, ws_s, gx, stride, nso, Cin, couts[s], gWs[s],
+                           gbs ? gbs[s] : nullptr);
+    }
+    e = hipGetLastError();
+    if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "linear_wgrad_b16 reduce launch: %s", hipGetErrorString(e));
+    return 1;
+}
+
+// The weight / bias gradients of nsrc <= 3 node-wise maps that read the SAME rows x [R][Cin] (the maps consuming one layer state:
+// conv1 of the blocks' heads, the state's own v2v / f2f map — /root/reference/lib/model/mpnn/factor_mpnn_sp.py:136-168) in ONE
+// pass: gW_s [couts[s]][Cin] += gy_s^T x, gb_s [couts[s]] += column sums of gy_s (gb_s may be NULL).  bf16, channel counts in
+// multiples of 64 up to 256, sum_s (couts[s] / 64) (Cin / 64) <= 16.  x is read once instead of nsrc times.
+extern "C" int64_t fgnn_linear_wgrad_multi_workspace_bytes(int64_t R, int32_t Cin, int32_t nsrc, const int32_t* couts) {
+    int sb[WB_MAXSRC + 1], S, RW, gx;
+    if (R <= 0 || R > 0x7fffffff || !couts || !wb_plan_multi(R, Cin, nsrc, couts, sb, &S, &RW, &gx)) return -1;
+    return (int64_t)gx * S * WB_NACC * 64 * 4;
+}
+
+extern "C" int fgnn_linear_wgrad_multi(const void* x, int64_t R, int32_t Cin, int32_t nsrc, const void* const* gy, const int32_t* couts,
+                                       float* const* gW, float* const* gb, void* workspace, int64_t workspace_bytes,
+                                       fgnn_stream_t stream) {
+    int sb[WB_MAXSRC + 1], S, RW, gx;
+    if (!x || !gy || !couts || !gW || !workspace) FGNN_FAIL(FGNN_EINVAL, "linear_wgrad_multi: null pointer");
+    if (R <= 0 || R > 0x7fffffff) FGNN_FAIL(FGNN_EINVAL, "linear_wgrad_multi: bad sizes");
+    if (!wb_plan_multi(R, Cin, nsrc, couts, sb, &S, &RW, &gx))
+        FGNN_FAIL(FGNN_EUNSUPPORTED, "linear_wgrad_multi: Cin=%d with %d sources is outside the kernel's family", Cin, nsrc);
+    for (int s = 0; s < nsrc; ++s) {
+        if (!gy[s] || !gW[s]) FGNN_FAIL(FGNN_EINVAL, "linear_wgrad_multi: null pointer (source %d)", s);
+        if ((uintptr_t)gy[s] & 7) FGNN_FAIL(FGNN_EINVAL, "linear_wgrad_multi: gy[%d] not 8-byte aligned", s);
+    }
+    if ((uintptr_t)x & 7) FGNN_FAIL(FGNN_EINVAL, "linear_wgrad_multi: x not 8-byte aligned");
+    if (workspace_bytes < (int64_t)gx * S * WB_NACC * 64 * 4) FGNN_FAIL(FGNN_EINVAL, "linear_wgrad_multi: workspace too small");
+    const int rc = wb_launch(x, R, Cin, nsrc, gy, couts, gW, gb, sb, S, RW, gx, workspace, (hipStream_t)stream);
+    return rc < 0 ? rc : FGNN_OK;
+}
+
 // Returns 1 if launched, 0 if the shape is outside this kernel's family, <0 on error.
 int fgnn_linear_wgrad_b16(const void* x, const void* gy, int64_t R, int Cin, int Cout, float* gW, float* gb,
                           void* workspace, int64_t workspace_bytes, fgnn_stream_t stream) {
@@ -402,24 +500,10 @@ int fgnn_linear_wgrad_b16(const void* x, const void* gy, int64_t R, int Cin, int
     if (!wb_plan(R, Cin, Cout, &nso, &S, &RW, &gx)) return 0;
     if (((uintptr_t)x & 7) || ((uintptr_t)gy & 7)) return 0;
     if (workspace_bytes < (int64_t)gx * S * WB_NACC * 64 * 4) return 0;
-    WgbParams p;
-    p.x = (const uint16_t*)x; p.gy = (const uint16_t*)gy; p.ws = (float*)workspace;
-    p.R = (int)R; p.Cin = Cin; p.Cout = Cout; p.nso = nso; p.S = S; p.RW = RW;
-    const int lds = S * (RW / 2) * WB_NACC * 64 * 4;                   // 0 when every slice has one row-wave
-    void* fn = (void*)linear_wgrad_b16_kernel;
-    if (lds > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
-    }
-    void* args[] = {(void*)&p};
-    hipStream_t st = (hipStream_t)stream;
-    hipError_t e = hipLaunchKernel(fn, dim3(gx), dim3(WB_THREADS), args, lds, st);
-    if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "linear_wgrad_b16 launch: %s", hipGetErrorString(e));
-    const int64_t slab_len = (int64_t)S * WB_NACC * 64;
-    if (fgnn_fold_push(p.ws, gx, slab_len, slab_len, gW, gb, 1, S, nso, Cin, Cout)) return 1;      // recorded (fold_batch.hip)
-    hipLaunchKernelGGL(wgb_reduce_kernel, dim3((unsigned)(slab_len / 64)), dim3(1024), 0, st, p.ws, gx, S, nso, Cin,
-                       Cout, gW, gb);
-    e = hipGetLastError();
-    if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "linear_wgrad_b16 reduce launch: %s", hipGetErrorString(e));
-    return 1;
+    const int sb[WB_MAXSRC + 1] = {0, S, S, S};
+    const void* gys[1] = {gy};
+    const int32_t couts[1] = {Cout};
+    float* gWs[1] = {gW};
+    float* gbs[1] = {gb};
+    return wb_launch(x, R, Cin, 1, gys, couts, gWs, gbs, sb, S, RW, gx, workspace, (hipStream_t)stream);
 }

@@ -18,13 +18,14 @@ DESC_GETYPE_REDUCED = 0x10000
 DESC_IDENTITY_LIST = 0x20000       # forward: the one-destination call's neighbour table is idx[j] == j
 AGG_MAX, AGG_LSE, AGG_MEAN = 0, 1, 2
 F32, BF16 = 0, 1
-ABI_VERSION = 9              # include/fgnn_hip.h: FGNN_ABI_VERSION (checked before any symbol is bound)
+ABI_VERSION = 10             # include/fgnn_hip.h: FGNN_ABI_VERSION (checked before any symbol is bound)
 EUNSUPPORTED = -3            # FGNN_EUNSUPPORTED: shape outside a kernel's family (callers fall back)
 
 AGG_CODES = {'max': AGG_MAX, 'softmax': AGG_LSE, 'mean': AGG_MEAN}
 
 EXPORTS = ('fgnn_mpconv_forward', 'fgnn_mpconv_backward', 'fgnn_mpconv_forward_lds_bytes',
            'fgnn_mpconv_backward_workspace_bytes', 'fgnn_mpconv_backward_reduces_getype', 'fgnn_linear_wgrad', 'fgnn_linear_wgrad_workspace_bytes',
+           'fgnn_linear_wgrad_multi', 'fgnn_linear_wgrad_multi_workspace_bytes',
            'fgnn_instnorm_forward', 'fgnn_instnorm_backward', 'fgnn_instnorm_dot_forward', 'fgnn_instnorm_dot_backward',
            'fgnn_instnorm_dot_workspace_bytes', 'fgnn_bn_supported', 'fgnn_bn_workspace_bytes',
            'fgnn_bn_stats', 'fgnn_bn_finalize', 'fgnn_bn_apply', 'fgnn_bn_backward',
@@ -121,6 +122,10 @@ def lib():
     L.fgnn_linear_wgrad.argtypes = [vp, vp, i64, i32, i32, i32, vp, vp, vp, i64, vp]
     L.fgnn_linear_wgrad_workspace_bytes.restype = i64
     L.fgnn_linear_wgrad_workspace_bytes.argtypes = [i64, i32, i32]
+    L.fgnn_linear_wgrad_multi.restype = ctypes.c_int
+    L.fgnn_linear_wgrad_multi.argtypes = [vp, i64, i32, i32, vp, vp, vp, vp, vp, i64, vp]
+    L.fgnn_linear_wgrad_multi_workspace_bytes.restype = i64
+    L.fgnn_linear_wgrad_multi_workspace_bytes.argtypes = [i64, i32, i32, vp]
     L.fgnn_instnorm_forward.restype = ctypes.c_int
     L.fgnn_instnorm_forward.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp]
     L.fgnn_instnorm_backward.restype = ctypes.c_int

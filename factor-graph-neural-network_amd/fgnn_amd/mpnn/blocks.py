@@ -200,20 +200,26 @@ class _BlockHead(torch.autograd.Function):
             P(z1), P(ga1), P(stats[0]), P(stats[1]), P(bn_w.detach()), P(bn_b.detach()), ctx.slope, P(weight.detach()), P(gz1), P(gx),
             P(gw1), P(gb1), R, cin, P(ws), ws.numel() * 4, P(ops._fold_scratch(dev)), _hip.stream_ptr())), nflops=2 * R * 64 * cin)
 
-        record = s_W and s_bias and ops.folds_deferrable()
-
-        def launch(rows=rows, gz1=gz1, gW=gW, gbias=gbias):
-            with ops.fold_scope(record) as scope:
-                wsw = scope.slabs(dev, int(L.fgnn_linear_wgrad_workspace_bytes(R, cin, 64)))
-                ops.timed('linear_wgrad_b16_kernel', 2 * R * (cin + 64), lambda: _hip.check(L.fgnn_linear_wgrad(
-                    P(rows), P(gz1), R, cin, 64, _hip.BF16, P(gW.view(64, cin)), P(gbias), P(wsw), wsw.numel() * 4, _hip.stream_ptr())),
-                    nflops=2 * R * cin * 64)
-        if s_W and s_bias:
-            ops.defer_wgrad(launch, (rows, gz1))
-        else:
-            launch()
+        taken = 0
         if lazy:
-            if ctx.box.deposit(gz1, weight.detach()):
+            # (gz1 @ W1 joins the state's other gradients in the fan-out's backward; with conv1's parameter gradients going to sinks its
+            # weight gradient joins the state's other consumers' there too — ops.FanBox: one pass over the state's rows for all)
+            taken = ctx.box.deposit(gz1, weight.detach(), wgrad=(rows, gW, gbias) if (s_W and s_bias) else None)
+        if taken != 2:
+            record = s_W and s_bias and ops.folds_deferrable()
+
+            def launch(rows=rows, gz1=gz1, gW=gW, gbias=gbias):
+                with ops.fold_scope(record) as scope:
+                    wsw = scope.slabs(dev, int(L.fgnn_linear_wgrad_workspace_bytes(R, cin, 64)))
+                    ops.timed('linear_wgrad_b16_kernel', 2 * R * (cin + 64), lambda: _hip.check(L.fgnn_linear_wgrad(
+                        P(rows), P(gz1), R, cin, 64, _hip.BF16, P(gW.view(64, cin)), P(gbias), P(wsw), wsw.numel() * 4, _hip.stream_ptr())),
+                        nflops=2 * R * cin * 64)
+            if s_W and s_bias:
+                ops.defer_wgrad(launch, (rows, gz1))
+            else:
+                launch()
+        if lazy:
+            if taken:
                 gx = ctx.box.placeholder(rows.shape)
             else:                                        # no slot: the product after all (gz1 is in the infinity cache)
                 from . import pointwise

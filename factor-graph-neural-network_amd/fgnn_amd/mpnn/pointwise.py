@@ -257,15 +257,27 @@ class _RowLinear(torch.autograd.Function):
         gy = gy.contiguous()
         if gy.dtype != rows.dtype:
             gy = gy.to(rows.dtype)
+        R, cin = rows.shape
+        cout = weight.shape[0]
+        wparam, bparam = ctx.params
+        # weight may be a [cout,cin,1,1] Conv2d parameter viewed as [cout,cin]: its .grad lives on the base
+        base = wparam._base if wparam._base is not None and wparam._base.numel() == wparam.numel() else wparam
+        gw_sink, gb_sink = ops.grad_sink(base), ops.grad_sink(bparam)
+        sinks = gw_sink is not None and (not ctx.has_bias or gb_sink is not None)
         grows = None
-        if ctx.needs_input_grad[0] and ctx.box is not None and ctx.box.deposit(gy, weight):
-            grows = ctx.box.placeholder(rows.shape)                    # (gy @ weight joins the state's other gradients in the fan-out's backward)
+        taken = 0
+        if ctx.needs_input_grad[0] and ctx.box is not None:
+            # (gy @ weight joins the state's other gradients in the fan-out's backward — and, with the parameter gradients going to
+            # sinks, this map's weight gradient joins the other consumers' there too: one pass over the state's rows for all of them)
+            taken = ctx.box.deposit(gy, weight, wgrad=(rows, gw_sink, gb_sink if ctx.has_bias else None) if sinks else None)
+        if taken:
+            grows = ctx.box.placeholder(rows.shape)
         elif ctx.needs_input_grad[0]:
             grows = hip_linear(gy, weight, None, transposed=True)      # gy [R,cout] @ weight [cout,cin]
             if grows is None:
                 grows = gy @ cast_cached(weight._base if weight._base is not None else weight, gy.dtype).view(weight.shape)
-        R, cin = rows.shape
-        cout = weight.shape[0]
+        if taken == 2:
+            return grows, None, None, None, None, None
         # wide maps: bf16 multiples of 64 up to 256 and f32 multiples of 4 (csrc/linear_wgrad_f32.hip) have their own kernels;
         # what is left (odd widths) goes to the library
         if cin * cout >= 256 * 256 and not (rows.dtype == torch.bfloat16 and cin % 64 == 0 and cout % 64 == 0
@@ -275,15 +287,10 @@ class _RowLinear(torch.autograd.Function):
             gb = gy.float().sum(0) if ctx.has_bias else None
             return grows, gw.to(weight.dtype), (gb.to(weight.dtype) if gb is not None else None), None, None, None
         L = _hip.lib()
-        wparam, bparam = ctx.params
-        # weight may be a [cout,cin,1,1] Conv2d parameter viewed as [cout,cin]: its .grad lives on the base
-        base = wparam._base if wparam._base is not None and wparam._base.numel() == wparam.numel() else wparam
-        gw_sink, gb_sink = ops.grad_sink(base), ops.grad_sink(bparam)
         gw = gw_sink if gw_sink is not None else torch.zeros((cout, cin), device=rows.device, dtype=torch.float32)
         gb = None
         if ctx.has_bias:
             gb = gb_sink if gb_sink is not None else torch.zeros((cout,), device=rows.device, dtype=torch.float32)
-        sinks = gw_sink is not None and (gb is None or gb_sink is not None)
         record = sinks and ops.folds_deferrable()        # (decided here, inside the pass: a parked launch may go out from its end-of-pass callback)
 
         def launch(rows=rows, gy=gy, gw=gw, gb=gb):      # (the closure keeps rows / gy alive until the kernel is issued)

@@ -89,6 +89,8 @@ def timed(symbol, nbytes, fn, nflops=0):
 # a sink (ops.grad_sink: the flat bucket) are deferred: a gradient tensor handed back to autograd must be complete in stream order.
 DEFER_WGRAD = os.environ.get('FGNN_NO_DEFER_WGRAD') is None       # (the variable: an A/B switch for tools / bench runs)
 WGRAD_TO_SIDE = os.environ.get('FGNN_WGRAD_SIDE', '0') not in ('', '0')     # tuning knob (round 5): see defer_wgrad
+WGRAD_STREAM = os.environ.get('FGNN_WGRAD_STREAM', '0') not in ('', '0')   # tuning knob (round 5): a THIRD stream that takes every parked
+                            # weight-gradient kernel at once, behind an event on its operands (nothing waits for them before the pass ends)
 SIDE_ACTIVE = False         # set by the assemblies the first time a forward actually forks onto the side stream: with ONE stream in
                             # play parking buys no overlap and only keeps every layer's operands alive until the end of the backward
 _DEFERRED = {}              # stream -> [(launch closure, operands)]
@@ -109,6 +111,18 @@ def defer_wgrad(launch, operands=()):
     task = torch._C._current_graph_task_id()           # (-1 outside a backward pass: then nothing would ever issue the launch)
     if task < 0:
         launch()
+        return
+    if WGRAD_STREAM and operands and operands[0].is_cuda:
+        wst = wgrad_stream(operands[0].device)
+        _register_backward_callback(task)
+        ready = torch.cuda.Event()
+        ready.record(st)
+        with torch.cuda.stream(wst):
+            wst.wait_event(ready)
+            launch()
+            for t in operands:
+                t.record_stream(wst)
+        _DEFER_ISSUED.add(wst)
         return
     if WGRAD_TO_SIDE and operands and operands[0].is_cuda:
         # round 5 (tuning knob): the main stream is the critical one (15.0 vs 11.1 ms busy, gpurun_out/r05b/timeline) — ITS
@@ -532,6 +546,17 @@ _SIDE = {}
 SIDE_STREAM = os.environ.get('FGNN_NO_SIDE_STREAM') is None      # FactorNN: factor types beyond the first run on a second stream (captured as parallel graph branches)
 
 
+_WGRAD_ST = {}
+
+
+def wgrad_stream(device):
+    """The stream of the parked weight-gradient kernels under FGNN_WGRAD_STREAM=1 (one per device, created on first use)."""
+    st = _WGRAD_ST.get(device)
+    if st is None:
+        st = _WGRAD_ST[device] = torch.cuda.Stream(device)
+    return st
+
+
 def side_stream(device):
     """The second stream FactorNN issues its hyper-factor branch on (one per device, created on first use)."""
     st = _SIDE.get(device)
@@ -763,6 +788,7 @@ def sum_tensors(ts):
 
 
 MERGE_FAN_GRADS = os.environ.get('FGNN_NO_MERGED_FAN_GRADS') is None      # (the variable: an A/B switch for tools / bench runs)
+MERGE_FAN_WGRADS = os.environ.get('FGNN_NO_MERGED_FAN_WGRADS') is None    # (likewise)
 _PLACEHOLDERS = {}
 
 
@@ -773,7 +799,12 @@ class FanBox:
     backward then runs csrc/linear_fwd_b16.hip::linear_multi_b16_kernel over the deposited pairs with the gradients that did arrive
     as tensors (the residual, a skip link) as addends — instead of one [R, C] tensor per consumer and an n-input sum over them.
     Slots: 0 and 2 take 64-channel sources, 1 takes 64 / 128 / 256; a deposit that finds no slot is refused and its consumer forms
-    the gradient itself (a real tensor: an addend)."""
+    the gradient itself (a real tensor: an addend).
+
+    The same consumers' WEIGHT gradients all contract their gz with the same rows — the state.  A depositor whose parameter
+    gradients go to sinks hands that job over too (``wgrad = (rows, gW, gb)``): the fan-out's backward then parks ONE
+    csrc/linear_wgrad_b16.hip launch over all of them (``fgnn_linear_wgrad_multi``: the state is read once instead of once per
+    consumer)."""
 
     def __init__(self, x):
         self.shape, self.dtype, self.device = tuple(x.shape), x.dtype, x.device
@@ -782,6 +813,7 @@ class FanBox:
         self.ok = (MERGE_FAN_GRADS and x.is_cuda and x.dtype == torch.bfloat16 and C in (64, 128, 256) and self.R >= 1024
                    and (x.permute(0, 2, 3, 1).is_contiguous() or x.is_contiguous() and H * W == 1))
         self.slots = [None, None, None]
+        self.wg = [None, None, None]
         self._ph = None
 
     def placeholder(self, shape):
@@ -796,27 +828,86 @@ class FanBox:
     def is_placeholder(self, g):
         return self._ph is not None and g.data_ptr() == self._ph.data_ptr()
 
-    def deposit(self, gz, weight):
-        """gz [R, K] bf16 dense rows, weight [K, C] f32 (a map's [cout, cin] weight as it lies in memory).  True = taken."""
+    def deposit(self, gz, weight, wgrad=None):
+        """gz [R, K] bf16 dense rows, weight [K, C] f32 (a map's [cout, cin] weight as it lies in memory).  Returns 0 = refused,
+        1 = taken, 2 = taken together with the weight-gradient job ``wgrad`` = (rows [R, C] bf16 — the state as the depositor read
+        it —, gW [K, C] f32 accumulator, gb [K] f32 accumulator or None): the depositor then launches no weight-gradient kernel."""
         if not self.ok or gz.dim() != 2 or gz.shape[0] != self.R or gz.dtype != torch.bfloat16 or not gz.is_contiguous():
-            return False
+            return 0
         K = gz.shape[1]
         if (tuple(weight.shape) != (K, self.C) or weight.dtype != torch.float32 or not weight.is_contiguous() or gz.data_ptr() % 16
                 or weight.data_ptr() % 16):
-            return False
+            return 0
         order = (0, 2, 1) if K == 64 else ((1,) if K in (128, 256) else ())
         for i in order:
             if self.slots[i] is None:
                 self.slots[i] = (gz, weight)
-                return True
-        return False
+                if MERGE_FAN_WGRADS and wgrad is not None and self._wgrad_ok(K, *wgrad):
+                    self.wg[i] = wgrad
+                    return 2
+                return 1
+        return 0
+
+    def _wgrad_ok(self, K, rows, gW, gb):
+        if not (rows.dtype == torch.bfloat16 and tuple(rows.shape) == (self.R, self.C) and rows.is_contiguous() and rows.data_ptr() % 16 == 0):
+            return False
+        if not (gW.dtype == torch.float32 and gW.numel() == K * self.C and gW.is_contiguous()):
+            return False
+        if gb is not None and not (gb.dtype == torch.float32 and gb.numel() == K and gb.is_contiguous()):
+            return False
+        first = next((w for w in self.wg if w is not None), None)
+        return first is None or first[0].data_ptr() == rows.data_ptr()        # (every job of a box contracts with the SAME rows)
+
+    def _park_wgrads(self, slots, wg):
+        """One parked weight-gradient launch for the jobs handed over with the deposits (several: fgnn_linear_wgrad_multi)."""
+        jobs = [(slots[i][0], wg[i]) for i in range(3) if wg[i] is not None]
+        if not jobs:
+            return
+        if len(jobs) == 3 and self.C == 256 and jobs[1][0].shape[1] == 256:
+            # 256 -> (64 | 256 | 64): 24 slices, beyond a workgroup's 16 waves — the two 64-channel maps together, the wide one alone
+            self._park_wgrad_group([jobs[0], jobs[2]])
+            self._park_wgrad_group([jobs[1]])
+            return
+        self._park_wgrad_group(jobs)
+
+    def _park_wgrad_group(self, jobs):
+        L = _hip.lib()
+        P = _hip._ptr
+        rows = jobs[0][1][0]
+        R, C = self.R, self.C
+        gzs = [j[0] for j in jobs]
+        record = folds_deferrable()          # (decided inside the pass: the parked launch may go out from its end-of-pass callback)
+        couts = (ctypes.c_int32 * len(jobs))(*[g.shape[1] for g in gzs])
+        multi = len(jobs) > 1 and int(L.fgnn_linear_wgrad_multi_workspace_bytes(R, C, len(jobs), couts)) > 0
+
+        def launch(rows=rows, jobs=jobs):
+            with fold_scope(record) as scope:
+                if multi:
+                    nb = int(L.fgnn_linear_wgrad_multi_workspace_bytes(R, C, len(jobs), couts))
+                    ws = scope.slabs(rows.device, nb)
+                    gy = (ctypes.c_void_p * len(jobs))(*[P(j[0]) for j in jobs])
+                    gW = (ctypes.c_void_p * len(jobs))(*[P(j[1][1]) for j in jobs])
+                    gb = (ctypes.c_void_p * len(jobs))(*[P(j[1][2]) for j in jobs])
+                    timed('linear_wgrad_b16_kernel', 2 * R * (C + sum(couts)),
+                          lambda: _hip.check(L.fgnn_linear_wgrad_multi(P(rows), R, C, len(jobs), gy, couts, gW, gb, P(ws), ws.numel() * 4,
+                                                                       _hip.stream_ptr())), nflops=2 * R * C * sum(couts))
+                    return
+                for gz, (_, gW1, gb1) in jobs:       # (outside the merged kernel's family: one launch per map, as their owners would have)
+                    K = gz.shape[1]
+                    ws = scope.slabs(rows.device, int(L.fgnn_linear_wgrad_workspace_bytes(R, C, K)))
+                    timed('linear_wgrad_b16_kernel', 2 * R * (C + K),
+                          lambda: _hip.check(L.fgnn_linear_wgrad(P(rows), P(gz), R, C, K, _hip.BF16, P(gW1), P(gb1), P(ws), ws.numel() * 4,
+                                                                 _hip.stream_ptr())), nflops=2 * R * C * K)
+        defer_wgrad(launch, (rows,) + tuple(gzs))
 
     def merge(self, grads):
         """The state's gradient from the deposits + the gradients that arrived as tensors."""
         real = [g for g in grads if g is not None and not self.is_placeholder(g)]
         slots, self.slots = self.slots, [None, None, None]
+        wg, self.wg = self.wg, [None, None, None]
         if not any(slots):
             return sum_tensors(real) if real else None
+        self._park_wgrads(slots, wg)
         if slots[0] is None and slots[2] is not None:      # (a lone 64-channel source sits in slot 0 by construction; keep the kernel's rule anyway)
             slots[0], slots[2] = slots[2], None
         B, C, H, W = self.shape

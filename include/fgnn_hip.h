@@ -248,6 +248,18 @@ int fgnn_linear_wgrad(const void* x, const void* gy, int64_t R, int32_t Cin, int
 int64_t fgnn_linear_wgrad_workspace_bytes(int64_t R, int32_t Cin, int32_t Cout);
 
 /*
+ * The same gradients for nsrc <= 3 maps that read the SAME rows x [R][Cin] — the consumers of one layer state in FactorNN's layer body
+ * (factor_mpnn_sp.py:136-168: the state's own v2v / f2f map and conv1 of each block that starts from it, mp_nn_residual.py:25-29) —
+ * in ONE pass: gW[s] [couts[s]][Cin] += gy[s]^T x, gb[s] [couts[s]] += column sums of gy[s] (gb, or any gb[s], may be NULL).  x is read
+ * once instead of nsrc times.  bf16 only; Cin and every couts[s] multiples of 64 up to 256 with sum_s (couts[s] / 64) (Cin / 64) <= 16
+ * (fgnn_linear_wgrad_multi_workspace_bytes returns -1 outside that family; the call itself FGNN_EUNSUPPORTED).  Sums and rounding per
+ * map are those of fgnn_linear_wgrad on the same grid.  ABI >= 10.
+ */
+int fgnn_linear_wgrad_multi(const void* x, int64_t R, int32_t Cin, int32_t nsrc, const void* const* gy, const int32_t* couts,
+                            float* const* gW, float* const* gb, void* workspace, int64_t workspace_bytes, fgnn_stream_t stream);
+int64_t fgnn_linear_wgrad_multi_workspace_bytes(int64_t R, int32_t Cin, int32_t nsrc, const int32_t* couts);
+
+/*
  * InstanceNorm2d(affine=False, eps 1e-5, biased variance) over the node axis, optionally fused with ReLU,
  * on dense channel-fastest activations x[B][N][C] (the norm of iid_mapping_in, base_model.py:82-90).
  * backward: gx = d/dx of act(norm(x)) given gy; only x is needed (statistics are recomputed).
@@ -525,7 +537,7 @@ const char* fgnn_last_kernel(void);
  * mismatch and not as a missing symbol or a misread field.  4: round-2 additions (flat_adam, factor_layer_*,
  * ldpc_channel_features_rng, backward_reduces_getype, desc.reserved = in-degree | GETYPE_REDUCED); 5: fgnn_block_tail_*;
  * 6: fgnn_block_head_backward. */
-#define FGNN_ABI_VERSION 9
+#define FGNN_ABI_VERSION 10
 int fgnn_abi_version(void);
 
 #ifdef __cplusplus

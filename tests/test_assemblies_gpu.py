@@ -1090,6 +1090,44 @@ def test_merged_fan_out_gradients_match_the_per_consumer_sums(dev):
     assert torch.equal(b, grads(True)[0])
 
 
+def test_merged_fan_out_weight_gradients_match_the_per_consumer_launches(dev):
+    """ops.FanBox: the weight gradients of the maps that consume one layer state (the state's v2v / f2f map, conv1 of every block
+    that starts from it) leave through ONE csrc/linear_wgrad_b16.hip launch per state (fgnn_linear_wgrad_multi) instead of one per
+    map — same gradients for every parameter of the LDPC model up to the f32 rounding of another summation grid, fewer weight-gradient
+    launches, bit-reproducible."""
+    import fgnn_amd
+    from fgnn_amd import ops
+    from fgnn_amd.dp import FlatGradBucket
+    from fgnn_amd.ldpc import synthetic_batch
+    torch.manual_seed(4)
+    m = fgnn_amd.LDPCModel(2, 6, 4).to(dev).train()
+    bucket = FlatGradBucket(m.parameters())
+    data = synthetic_batch(64, dev, seed=12, dtype=torch.bfloat16)
+    state = {k: v.clone() for k, v in m.state_dict().items()}
+
+    def grads(merge):
+        m.load_state_dict(state)
+        bucket.zero()
+        ops.MERGE_FAN_WGRADS = merge
+        rec = []
+        ops.TIMER = type('T', (), {'run': staticmethod(lambda sym, nb, nf, launch, use_note=True, **kw: (rec.append(sym), launch()))})()
+        try:
+            with torch.autocast('cuda', dtype=torch.bfloat16):
+                logits, snr = m(*data[:6])
+            (torch.nn.functional.binary_cross_entropy_with_logits(logits.float(), data[6]) + 0.1 * snr.float().pow(2).mean()).backward()
+        finally:
+            ops.MERGE_FAN_WGRADS = True
+            ops.TIMER = None
+        torch.cuda.synchronize()
+        return bucket.flat.clone(), rec
+
+    (a, ra), (b, rb) = grads(False), grads(True)
+    na, nb = ra.count('linear_wgrad_b16_kernel'), rb.count('linear_wgrad_b16_kernel')
+    assert nb <= na - 12, (na, nb)
+    assert float(a.abs().max()) > 0 and float((a - b).abs().max()) <= 2e-5 * float(a.abs().max()), float((a - b).abs().max())
+    assert torch.equal(b, grads(True)[0])
+
+
 def test_regressor_head_through_the_map_kernels_matches_the_torch_modules(dev):
     """LDPCModel._regress: the burst-noise regressor (train_ldpc.py:48-54,93) through this package's node-wise map / BatchNorm
     kernels when training on bf16 activations, against the seven torch modules in f32 on the same input: prediction, input

@@ -648,6 +648,84 @@ def test_f32_blocked_weight_gradient_vs_torch(R, cin, cout, dev):
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
 
 
+@pytest.mark.parametrize('R,cin,couts', [(6144, 64, (64, 64, 64)), (6149, 64, (64, 128, 64)), (12288, 128, (64, 256, 64)), (6144, 256, (64, 64)),
+                                          (6144, 256, (64, 128, 64)), (3000, 128, (64, 64, 64)), (393216, 64, (64, 64)), (40, 64, (64, 64, 64)),
+                                          (6144, 64, (256,))])
+@pytest.mark.parametrize('deferred', [False, True])
+def test_bf16_weight_gradients_of_several_maps_over_one_state(R, cin, couts, deferred, dev):
+    """fgnn_linear_wgrad_multi (csrc/linear_wgrad_b16.hip: the weight / bias gradients of the node-wise maps that consume ONE layer
+    state — factor_mpnn_sp.py:136-168 — in one pass over its rows): every map's gW / gb against a float64 product on the same bf16
+    operands, ACCUMULATED into, equal to what fgnn_linear_wgrad gives map by map (same grid: same sums), with immediate and with
+    recorded folds (csrc/fold_batch.hip), bit-identical on a second run; R not a multiple of the 32-row blocks; shapes outside
+    the family are refused by the workspace query."""
+    import ctypes
+    from fgnn_amd import _hip, ops
+    L = _hip.lib()
+    P = _hip._ptr
+    g = torch.Generator().manual_seed(R + cin + sum(couts))
+    x = torch.randn(R, cin, generator=g).to(dev).to(torch.bfloat16)
+    gys = [torch.randn(R, c, generator=g).to(dev).to(torch.bfloat16) for c in couts]
+    n = len(couts)
+    cc = (ctypes.c_int32 * n)(*couts)
+    nb = int(L.fgnn_linear_wgrad_multi_workspace_bytes(R, cin, n, cc))
+    assert nb > 0
+
+    def run(multi):
+        gws = [torch.ones(c, cin, device=dev) for c in couts]
+        gbs = [torch.full((c,), 2.0, device=dev) for c in couts]
+        keep = []
+        L.fgnn_fold_discard()
+        L.fgnn_fold_defer(1 if deferred else 0)
+        try:
+            if multi:
+                ws = torch.empty(nb // 4, device=dev)
+                keep.append(ws)
+                _hip.check(L.fgnn_linear_wgrad_multi(P(x), R, cin, n, (ctypes.c_void_p * n)(*[P(t) for t in gys]), cc,
+                                                     (ctypes.c_void_p * n)(*[P(t) for t in gws]), (ctypes.c_void_p * n)(*[P(t) for t in gbs]),
+                                                     P(ws), nb, _hip.stream_ptr()))
+            else:
+                for gy, gw, gb, c in zip(gys, gws, gbs, couts):
+                    ws = torch.empty(int(L.fgnn_linear_wgrad_workspace_bytes(R, cin, c)) // 4, device=dev)
+                    keep.append(ws)
+                    _hip.check(L.fgnn_linear_wgrad(P(x), P(gy), R, cin, c, _hip.BF16, P(gw), P(gb), P(ws), ws.numel() * 4, _hip.stream_ptr()))
+        finally:
+            L.fgnn_fold_defer(0)
+        if deferred:
+            assert L.fgnn_fold_pending() == n
+            _hip.check(L.fgnn_fold_flush(_hip.stream_ptr()))
+        assert L.fgnn_fold_pending() == 0
+        torch.cuda.synchronize()
+        return gws, gbs
+
+    gws, gbs = run(True)
+    for gy, gw, gb in zip(gys, gws, gbs):
+        ref_w = gy.double().t() @ x.double()
+        ref_b = gy.double().sum(0)
+        assert float(((gw.double() - 1.0) - ref_w).abs().max()) <= 2e-5 * float(ref_w.abs().max()) + 1e-5
+        assert float(((gb.double() - 2.0) - ref_b).abs().max()) <= 2e-5 * float(ref_b.abs().max()) + 1e-5
+    gws2, gbs2 = run(True)
+    assert all(torch.equal(a, b) for a, b in zip(gws + gbs, gws2 + gbs2))
+    gws1, gbs1 = run(False)                      # map by map: other grids (row-waves per slice), so equal to f32 rounding, not to the bit
+    for a, b in zip(gws + gbs, gws1 + gbs1):
+        assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max())
+
+
+def test_weight_gradients_of_several_maps_refuses_what_it_cannot_tile(dev):
+    import ctypes
+    from fgnn_amd import _hip
+    L = _hip.lib()
+    q = lambda cin, couts: int(L.fgnn_linear_wgrad_multi_workspace_bytes(4096, cin, len(couts), (ctypes.c_int32 * len(couts))(*couts)))
+    assert q(256, (64, 256, 64)) == -1 and q(64, (32, 64)) == -1 and q(96, (64, 64)) == -1 and q(64, (64, 64, 64, 64)[:3]) > 0
+    x = torch.zeros(4096, 256, device=dev, dtype=torch.bfloat16)
+    gy = torch.zeros(4096, 256, device=dev, dtype=torch.bfloat16)
+    gw = torch.zeros(256, 256, device=dev)
+    ws = torch.zeros(1 << 20, device=dev)
+    P = _hip._ptr
+    rc = L.fgnn_linear_wgrad_multi(P(x), 4096, 256, 3, (ctypes.c_void_p * 3)(P(gy), P(gy), P(gy)), (ctypes.c_int32 * 3)(64, 256, 64),
+                                   (ctypes.c_void_p * 3)(P(gw), P(gw), P(gw)), None, P(ws), ws.numel() * 4, _hip.stream_ptr())
+    assert rc == _hip.EUNSUPPORTED
+
+
 @pytest.mark.parametrize('cin,cout', [(64, 64), (64, 128), (128, 256), (256, 256), (256, 128), (128, 64)])
 @pytest.mark.parametrize('N', [96, 48])
 def test_iid_mapping_in_as_one_kernel(cin, cout, N, dev, monkeypatch):
