@@ -353,6 +353,61 @@ def test_hyper_edge_backward_vs_routed_reference(shape, layout, dtype, dev):
         assert H.rel_err(Wd.grad, sd['filters'].grad) <= 1e-4
 
 
+@pytest.mark.parametrize('shape', [(64, 64, 96, 96), (64, 128, 96, 96), (128, 64, 96, 96), (64, 64, 40, 130), (64, 64, 96, 7)],
+                         ids=lambda s: 'x'.join(map(str, s)))
+@pytest.mark.parametrize('tables', ['ldpc', 'shared', 'per_sample'])
+def test_bf16_fan_in_backward_many_samples_per_wave_vs_routed_reference(shape, tables, dev):
+    """csrc/mpconv_bwd_hyper.hip::mpconv_bwd_fanin_kernel (bf16 channel-fastest states, one destination of degree k): at a batch
+    where the grid is capped and every wave owns several samples, with the LDPC hyper-factor's own tables (identity list, unit
+    weights, both stride-0 over the batch: train_ldpc.py:40-46), a random table shared by the batch and per-sample tables; dx
+    (zeros of the rows nobody routed to included), dW and dbias against torch autograd through the forward's own routing; the
+    kernel ran; bit-reproducible."""
+    from fgnn_amd import _hip, ops
+    nin, nou, N, k = shape
+    B = 2500
+    g = torch.Generator().manual_seed(11 + N + k + nou)
+    x = torch.randn(B, nin, N, 1, generator=g).to(torch.bfloat16)
+    if tables == 'ldpc' and k == N:
+        idx = torch.arange(N).reshape(1, 1, N).expand(B, -1, -1)
+        et = torch.ones(1, 1, 1, k, dtype=torch.bfloat16).expand(B, -1, -1, -1)
+    elif tables == 'per_sample':
+        idx = torch.randint(0, N, (B, 1, k), generator=g)
+        et = (torch.rand(B, 1, 1, k, generator=g) + 0.5).to(torch.bfloat16)
+    else:
+        idx = torch.randint(0, N, (1, 1, k), generator=g).expand(B, -1, -1)
+        et = (torch.rand(1, 1, 1, k, generator=g) + 0.5).to(torch.bfloat16).expand(B, -1, -1, -1)
+    W = torch.randn(nin, nou, generator=g) * 0.1
+    bias = torch.randn(nou, generator=g)
+    gz = torch.randn(B, nou, 1, 1, generator=g).to(torch.bfloat16)
+    idx_d, et_d = idx.to(dev), et.to(dev)
+    if tables != 'per_sample':           # (.to() materialises an expanded tensor: restore the stride-0 batch axis)
+        idx_d, et_d = idx[:1].to(dev).expand(B, -1, -1), et[:1].to(dev).expand(B, -1, -1, -1)
+    _, am = ops.mpconv_forward_raw(x.to(dev).contiguous(memory_format=torch.channels_last), idx_d, et_d, W.to(dev), bias.to(dev), nou, 1, 0,
+                                   _hip.AGG_MAX, want_argmax=True)
+    outs = []
+    for _ in range(2):
+        xd = x.to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        Wd, bd = W.to(dev).requires_grad_(True), bias.to(dev).requires_grad_(True)
+        z = ops.mpconv(xd, idx_d, et_d, Wd, bd, nou, 1, 0, _hip.AGG_MAX)
+        z.backward(gz.to(dev))
+        assert _hip.lib().fgnn_last_kernel().decode().startswith('mpconv_bwd_fanin_kernel'), _hip.lib().fgnn_last_kernel().decode()
+        outs.append((xd.grad.clone(), Wd.grad.clone(), bd.grad.clone()))
+    assert all(torch.equal(a, b) for a, b in zip(*outs))
+    xr = x.float().detach().clone().requires_grad_(True)
+    Wr, br = W.clone().requires_grad_(True), bias.clone().requires_grad_(True)
+    P = torch.einsum('bcn,co->bno', xr[..., 0], Wr)                                 # [B,N,nou]
+    E = P[torch.arange(B)[:, None, None], idx] * et.float()[:, 0, :, :, None]       # [B,1,k,nou]
+    sel = am.cpu().long()[..., 0].permute(0, 2, 1)[:, :, None, :]                   # [B,1,1,nou]
+    zr = E.gather(2, sel)[:, :, 0, :].permute(0, 2, 1)[..., None] + br[None, :, None, None]
+    zr.backward(gz.float())
+    gxd, gWd, gbd = outs[0]
+    assert H.rel_err(gxd.float(), xr.grad) <= 2.0 ** -7
+    assert H.rel_err(gWd, Wr.grad) <= 2.0 ** -7
+    assert H.rel_err(gbd, br.grad) <= 2.0 ** -7
+    # rows nobody routed to are exact zeros
+    assert bool(((xr.grad == 0) <= (gxd.float().cpu() == 0)).all())
+
+
 @pytest.mark.parametrize('cin,cout', [(64, 64), (2, 64), (7, 64), (96, 64), (64, 256), (256, 64), (256, 256),
                                       (128, 1), (64, 4), (100, 12), (7, 128), (256, 3)])
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
