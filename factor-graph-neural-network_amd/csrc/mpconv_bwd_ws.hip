@@ -879,7 +879,8 @@ int fgnn_mpconv_backward_ws(const fgnn_mpconv_desc* d, const void* x, const int6
                       : (KC == 6 ? (void*)mpconv_bwd_ws_kernel<6, 3> : (void*)mpconv_bwd_ws_kernel<3, 6>);
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, off_b);
     if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "hipFuncSetAttribute(%d B LDS): %s", off_b, hipGetErrorString(e));
-    int grid = 256;
+    static const int max_grid = getenv("FGNN_WS_GRID") ? atoi(getenv("FGNN_WS_GRID")) : 256;      // (tuning knob: CUs left to the other stream's kernels)
+    int grid = max_grid >= 1 && max_grid <= 256 ? max_grid : 256;
     if (grid > d->B) grid = d->B;
     const int chunk = (d->B + grid - 1) / grid;
     grid = (d->B + chunk - 1) / chunk;

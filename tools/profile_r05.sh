@@ -26,6 +26,7 @@ python tools/wbench.py --bf16 > $O/wbench.log 2>&1
 python tools/tbench.py > $O/tbench.log 2>&1
 python tools/sbench.py > $O/sbench.log 2>&1
 python tools/mbench.py > $O/mbench.log 2>&1
+python tools/wmbench.py > $O/wmbench.log 2>&1
 # 5. bench lines: the default one (with the CPU baselines), inference, f32, and the A/B switches of this round's levers
 python bench.py > $O/bench_default.json 2> $O/bench_default.err
 python bench.py --mode fwd --no-cpu-baseline > $O/bench_fwd.json 2> /dev/null
@@ -37,6 +38,8 @@ FGNN_F2F_SIDE=0 python bench.py --no-cpu-baseline > $O/bench_f2f_main.json 2> /d
 FGNN_NO_SIDE_STREAM=1 python bench.py --no-cpu-baseline > $O/bench_one_stream.json 2> /dev/null
 FGNN_BWD_TABLES=1 python bench.py --no-cpu-baseline > $O/bench_bwd_tables.json 2> /dev/null
 FGNN_NO_MERGED_FAN_GRADS=1 python bench.py --no-cpu-baseline > $O/bench_no_merged_fan_grads.json 2> /dev/null
+FGNN_NO_MERGED_FAN_WGRADS=1 python bench.py --no-cpu-baseline > $O/bench_no_merged_fan_wgrads.json 2> /dev/null
+FGNN_WGRAD_STREAM=1 python bench.py --no-cpu-baseline > $O/bench_wgrad_third_stream.json 2> /dev/null
 FGNN_NO_DEFER_FOLDS=1 python bench.py --no-cpu-baseline > $O/bench_immediate_folds.json 2> /dev/null
 FGNN_NO_INSTNORM_DOT=1 python bench.py --no-cpu-baseline > $O/bench_no_instnorm_dot.json 2> /dev/null
 FGNN_NO_FAST_REGRESSOR=1 python bench.py --no-cpu-baseline > $O/bench_torch_regressor.json 2> /dev/null
@@ -44,6 +47,7 @@ FGNN_NO_FAST_REGRESSOR=1 python bench.py --no-cpu-baseline > $O/bench_torch_regr
 timeout 900 python bench.py --cpu-baseline-only --cpu-batch 256 --cpu-threads $(nproc) > $O/cpu_baseline_all_cores.json 2> $O/cpu_baseline_all_cores.err
 # 7. wall-time attribution of one replayed training step (kernel trace -> tools/timeline.py)
 sh tools/profile_timeline.sh r05/timeline > /dev/null 2>&1
+python tools/critical_path.py $O/timeline/step_sequence.csv > $O/timeline/critical_path.txt 2>&1
 # 8. HBM bytes of every kernel of the step (two --pmc passes over bench.py; per-step launch counts from the sequence of 7.)
 cp $O/timeline/step_sequence.csv /tmp/seq_r05.csv
 FGNN_STEP_SEQ=/tmp/seq_r05.csv sh tools/profile_step_traffic.sh r05/traffic > /dev/null 2>&1

@@ -104,14 +104,14 @@ def main():
     json.dump(traffic, open(os.path.join(DST, 'pmc_traffic.json'), 'w'), indent=1)
     import glob as _g
     names = [os.path.basename(f) for f in _g.glob(os.path.join(SRC, 'bench_*.json'))] + ['cpu_baseline_all_cores.json', 'lbench.log',
-                                                                                       'wbench.log', 'tbench.log', 'sbench.log', 'mbench.log']
+                                                                                       'wbench.log', 'tbench.log', 'sbench.log', 'mbench.log', 'wmbench.log']
     names += [os.path.basename(f) for f in _g.glob(os.path.join(SRC, 'kbench_*.log'))]
     for f in names:
         if os.path.exists(os.path.join(SRC, f)):
             shutil.copy(os.path.join(SRC, f), os.path.join(DST, f))
     if os.path.exists(os.path.join(SRC, 'timeline', 'step_sequence.csv')):
         shutil.copy(os.path.join(SRC, 'timeline', 'step_sequence.csv'), os.path.join(DST, 'train_step_sequence.csv'))
-    for f in ('timeline.txt', 'timeline.json'):
+    for f in ('timeline.txt', 'timeline.json', 'critical_path.txt'):
         if os.path.exists(os.path.join(SRC, 'timeline', f)):
             shutil.copy(os.path.join(SRC, 'timeline', f), os.path.join(DST, 'train_step_' + f))
     if os.path.exists(os.path.join(SRC, 'traffic', 'step_traffic.txt')):

@@ -44,5 +44,5 @@ for R in (4096 * 96, 4096 * 48):
         mbm = 2 * R * (cin + sum(couts)) / 1e6
         mbs = 2 * R * (n * cin + sum(couts)) / 1e6
         print('R=%6d %3d -> %-15s merged %7.1f us (%5.2f TB/s of %4.0f MB) | one by one %7.1f us (%5.2f TB/s of %4.0f MB)'
-              % (R, cin, couts, res[0], mbm / res[0] * 1e-3 * 1e3 / 1e3, mbm, res[1], mbs / res[1] * 1e-3 * 1e3 / 1e3, mbs), flush=True)
+              % (R, cin, couts, res[0], mbm / res[0], mbm, res[1], mbs / res[1], mbs), flush=True)
         del xs, gys
