@@ -167,6 +167,7 @@ _V2V_MAIN = _parse_layers(os.environ.get('FGNN_V2V_MAIN', ''))      # tuning kno
 
 
 _F2F_SIDE = os.environ.get('FGNN_F2F_SIDE', '1') not in ('', '0')      # tuning knob: the parity factors' f2f map on the side stream
+_FAC_MERGE_SIDE = int(os.environ.get('FGNN_FAC_MERGE_SIDE', '1') or 0)      # tuning knob: 1 = the factor states' gradient merge on the side stream (2: the variables' instead)
 
 
 class FactorNN(torch.nn.Module):
@@ -350,8 +351,20 @@ class FactorNN(torch.nn.Module):
                     continue
             # every state feeds several consumers (v2v / f2f map, the message blocks, the residual, a skip link):
             # hand each its own alias so that the backward sums their gradients in one kernel (ops.fan_out)
-            var_c = fan_out(var, 1 + nft + res + keep)
-            fac_c = [fan_out(f, 2 + res + keep) for f in fac]
+            if _FAC_MERGE_SIDE == 2 and _ops.SIDE_STREAM and nft > 1 and var.is_cuda and torch.is_grad_enabled():
+                with torch.cuda.stream(_ops.side_stream(var.device)):
+                    var_c = fan_out(var, 1 + nft + res + keep)
+            else:
+                var_c = fan_out(var, 1 + nft + res + keep)
+            if _FAC_MERGE_SIDE == 1 and _ops.SIDE_STREAM and nft > 1 and var.is_cuda and torch.is_grad_enabled():
+                # round 5: a fan-out's backward (ops.FanBox.merge: the state's gradient as one product, 50-270 us) runs on the stream its
+                # forward was issued on.  Both states' merges used to sit back to back on the main stream at the end of a layer's
+                # backward while the side stream idled: the factor states' handles are made under the side stream (no kernel in the
+                # forward: views), so their merge runs there, beside the variables'.
+                with torch.cuda.stream(_ops.side_stream(var.device)):
+                    fac_c = [fan_out(f, 2 + res + keep) for f in fac]
+            else:
+                fac_c = [fan_out(f, 2 + res + keep) for f in fac]
             if keep:
                 history[L - 1] = [var_c.pop(), [fc.pop() for fc in fac_c]]
             skip = history[self.skip_link[L]] if L in self.skip_link else None

@@ -244,10 +244,13 @@ class _AddendRoute(torch.autograd.Function):
     profiles/r03/README.md).  No kernel runs here."""
 
     @staticmethod
-    def forward(ctx, out, periods, *adds):
+    def forward(ctx, out, periods, streams, *adds):
         """``periods[i]`` > 1: addend i is a per-sample row [R / period, C] the apply kernel broadcast over the sample's nodes; its
-        gradient is the node sum of the output's (one pass, csrc/sum_n.hip)."""
+        gradient is the node sum of the output's (one pass, csrc/sum_n.hip).  ``streams[i]``: the stream addend i was produced on
+        (or None): with FGNN_NODE_SUM_HOME=1 that pass is issued THERE — its only reader is the addend's own backward node, which
+        runs on that stream — instead of in front of this stream's tail backward."""
         ctx.periods = tuple(periods)[:len(adds)]
+        ctx.streams = tuple(streams)[:len(adds)]
         return out.view_as(out)
 
     @staticmethod
@@ -255,14 +258,27 @@ class _AddendRoute(torch.autograd.Function):
         from .pointwise import node_sum
         outs = []
         for i, q in enumerate(ctx.periods):
-            if not ctx.needs_input_grad[2 + i]:
+            if not ctx.needs_input_grad[3 + i]:
                 outs.append(None)
             elif q == 1:
                 outs.append(g)
             else:
                 ops.backward_node_begins()
-                outs.append(node_sum(g.contiguous(), q))
-        return (g, None) + tuple(outs)
+                home = ctx.streams[i] if NODE_SUM_HOME and g.is_cuda else None
+                cur = torch.cuda.current_stream(g.device) if g.is_cuda else None
+                if home is not None and home != cur:
+                    ready = torch.cuda.Event()
+                    ready.record(cur)
+                    with torch.cuda.stream(home):
+                        home.wait_event(ready)
+                        outs.append(node_sum(g.contiguous(), q))
+                    g.record_stream(home)
+                else:
+                    outs.append(node_sum(g.contiguous(), q))
+        return (g, None, None) + tuple(outs)
+
+
+NODE_SUM_HOME = os.environ.get('FGNN_NODE_SUM_HOME', '1') not in ('', '0')      # tuning knob (round 5): see _AddendRoute
 
 
 class _BlockTail(torch.autograd.Function):
@@ -616,6 +632,7 @@ class mp_conv_residual(base_mp_nn):
                     arows[i] = ar.view(-1, Cout)
             got['arows'] = arows
             got['periods'] = tuple((periods + [1, 1, 1])[:3])
+            got['streams'] = tuple(([getattr(t, '_fgnn_home_stream', None) for t in addends] + [None, None, None])[:3])
             return arows, got['periods']
 
         late = ROUTE_ADDEND_GRADS and LATE_JOIN and callable(addend) and torch.is_grad_enabled()
@@ -633,6 +650,6 @@ class mp_conv_residual(base_mp_nn):
                              bn2.num_batches_tracked, bn3.running_mean, bn3.running_var, bn3.num_batches_tracked,
                              0 if mult == 1 else B * M * mult, *tail_adds, periods)
         if route:
-            pairs = [(a, q) for a, q in zip(got['arows'], got['periods']) if a is not None]
-            y = _AddendRoute.apply(y, tuple(q for _, q in pairs), *[a for a, _ in pairs])
+            pairs = [(a, q, st) for a, q, st in zip(got['arows'], got['periods'], got['streams']) if a is not None]
+            y = _AddendRoute.apply(y, tuple(q for _, q, _ in pairs), tuple(st for _, _, st in pairs), *[a for a, _, _ in pairs])
         return y.view(B, M, 1, Cout).permute(0, 3, 1, 2)

@@ -753,6 +753,8 @@ def broadcast_nodes(y1, M):
     else:
         out = y1.expand(-1, -1, M, -1)
     out._fgnn_bcast_src = y1
+    if y1.is_cuda:
+        y1._fgnn_home_stream = torch.cuda.current_stream(y1.device)      # (where y1's producer ran, i.e. where its backward node will run)
     return out
 
 
