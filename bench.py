@@ -751,6 +751,28 @@ def main():
                         break
             except (OSError, ValueError, KeyError):
                 pass
+            # ... and the same trace of the step on ONE stream: every kernel alone on the chip inside the replayed graph (the two-stream
+            # averages carry the contention of whatever runs beside a launch on the other queue: an operator launch holds every CU)
+            in_graph1, in_graph1_file = {}, None
+            try:
+                pth = os.path.join(ROOT, 'profiles', 'r05', 'final_bf16_train1_kernel_stats_top40.csv')
+                if train and os.path.exists(pth):
+                    in_graph1_file = os.path.relpath(pth, ROOT)
+                    for row in csv.DictReader(open(pth)):
+                        in_graph1[row['Name']] = float(row['AverageNs'])
+            except (OSError, ValueError, KeyError):
+                pass
+
+            def trace_row(sym, table):
+                """Average duration (ns) of `sym` in a kernel-stats table: the symbol as the dispatcher names it, or with the row-stride
+                template argument the backward kernel grew in round 5 (<KC, DEG> = <KC, DEG, 64>)."""
+                s0 = sym.replace(' ', '')
+                for cand in (s0, s0[:-1] + ',64>' if s0.endswith('>') else None):
+                    if cand:
+                        for name, ns in table.items():
+                            if cand in name.replace(' ', ''):
+                                return ns
+                return None
 
             def describe(sym):
                 r, r2 = kernels[sym], kernels2.get(sym)
@@ -762,20 +784,26 @@ def main():
                 # bf16 storage + bf16 MFMA (every operator kernel of a --dtype bf16 run, the hyper-factor fan-in / fan-out ones included:
                 # their symbols carry no 'b16'): HBM-bound (AI ~80 << ridge ~312); the f32 kernels price against the f32 matrix rate
                 bf16 = args.dtype == 'bf16' or any(t in sym for t in ('b16', '_sg_', '_ws_'))
+                pm = pmc.get(sym[:-1] + ', 64>') or pmc.get(sym) or {}      # (this round's passes name the backward kernel with its row-stride argument)
                 d = {'kernel': sym, 'launches_per_step': n, 'bound': 'hbm' if bf16 else 'mfma',
                      'algorithmic_bytes_per_launch': int(nb), 'algorithmic_flops_per_launch': int(nf),
                      'avg_launch_us_isolated': round(iso_ms * 1e3, 2), 'avg_launch_us_in_step': round(step_ms * 1e3, 2),
                      'achieved': round(gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(gbs / HBM_PEAK_GBS, 4),
                      'frac_isolated': round(nb / (iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                     'traffic': pmc.get(sym, {}).get('traffic_bytes_per_launch'), 'mfma_busy': pmc.get(sym, {}).get('mfma_busy')}
+                     'traffic': pm.get('traffic_bytes_per_launch'), 'mfma_busy': pm.get('mfma_busy')}
                 # (two-launch calls — ' x2' — and launches with addends have no one-to-one row in a per-symbol average: no figure)
-                if in_graph_file and not sym.endswith(' x2'):
-                    for name, ns in in_graph.items():
-                        if sym.replace(' ', '') in name.replace(' ', ''):
-                            us = round(ns / 1e3, 2)
-                            d['from_committed_profile'] = {'file': in_graph_file, 'avg_launch_us_in_graph_rocprof': us,
-                                                           'frac_in_graph_rocprof': round(nb / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
-                                                           'note': 'average over ALL launches of the symbol in an earlier, committed trace of the replayed graph'}
+                if in_graph_file and not sym.endswith((' x2', ' k2')):
+                    ns = trace_row(sym, in_graph)
+                    if ns is not None:
+                        us = round(ns / 1e3, 2)
+                        d['from_committed_profile'] = {'file': in_graph_file, 'avg_launch_us_in_graph_rocprof': us,
+                                                       'frac_in_graph_rocprof': round(nb / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                                                       'note': 'average over ALL launches of the symbol in an earlier, committed trace of the replayed graph'}
+                        ns1 = trace_row(sym, in_graph1)
+                        if ns1 is not None:
+                            us1 = round(ns1 / 1e3, 2)
+                            d['from_committed_profile'].update({'one_stream_file': in_graph1_file, 'avg_launch_us_in_graph_one_stream': us1,
+                                                                'frac_in_graph_one_stream': round(nb / (us1 * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)})
                 if not bf16:                              # the f32-MFMA kernels (exact v_mfma_f32_16x16x4_f32) sit above the f32 ridge: matrix-core-bound
                     tfs = nf / (step_ms * 1e-3) / 1e12
                     d.update({'achieved': round(tfs, 2), 'peak': F32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',

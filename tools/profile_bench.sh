@@ -11,3 +11,9 @@ for mode in train fwd; do
   grep "^{\"metric" /tmp/prof_$mode.log | tail -1 > $R/gpurun_out/${FGNN_PROF_OUT:-prof4}/bench_$mode.json
   find /tmp/prof_$mode -name "*kernel_stats*.csv" -exec cp {} $R/gpurun_out/${FGNN_PROF_OUT:-prof4}/ \;
 done
+# the training step on ONE stream: every kernel alone on the chip inside the replayed graph (the two-stream averages above carry
+# the contention of whatever runs beside a launch on the other queue)
+rm -rf /tmp/prof_train1
+FGNN_NO_SIDE_STREAM=1 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_train1 -o train1 -- python bench.py --steps 10 --warmup 3 --mode train --no-cpu-baseline > /tmp/prof_train1.log 2>&1
+grep "^{\"metric" /tmp/prof_train1.log | tail -1 > $R/gpurun_out/${FGNN_PROF_OUT:-prof4}/bench_train1.json
+find /tmp/prof_train1 -name "*kernel_stats*.csv" -exec cp {} $R/gpurun_out/${FGNN_PROF_OUT:-prof4}/ \;

@@ -61,7 +61,7 @@ def kernel_names(d):
 
 def main():
     # kernel statistics
-    for mode in ('train', 'fwd'):
+    for mode in ('train', 'fwd', 'train1'):       # train1: the training step on ONE stream (tools/profile_bench.sh)
         src = os.path.join(SRC, 'prof', '%s_kernel_stats.csv' % mode)
         if not os.path.exists(src):
             continue
