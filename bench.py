@@ -764,10 +764,10 @@ def main():
                 pass
 
             def trace_row(sym, table):
-                """Average duration (ns) of `sym` in a kernel-stats table: the symbol as the dispatcher names it, or with the row-stride
-                template argument the backward kernel grew in round 5 (<KC, DEG> = <KC, DEG, 64>)."""
+                """Average duration (ns) of `sym` in a kernel-stats table: the symbol as the dispatcher names it, or with the row-stride /
+                node-loop template arguments the backward kernel grew in round 5 (<KC, DEG> = <KC, DEG, 64[, NL]>)."""
                 s0 = sym.replace(' ', '')
-                for cand in (s0, s0[:-1] + ',64>' if s0.endswith('>') else None):
+                for cand in (s0, s0[:-1] + ',64>' if s0.endswith('>') else None, s0[:-1] + ',64,' if s0.endswith('>') else None):
                     if cand:
                         for name, ns in table.items():
                             if cand in name.replace(' ', ''):
@@ -784,7 +784,8 @@ def main():
                 # bf16 storage + bf16 MFMA (every operator kernel of a --dtype bf16 run, the hyper-factor fan-in / fan-out ones included:
                 # their symbols carry no 'b16'): HBM-bound (AI ~80 << ridge ~312); the f32 kernels price against the f32 matrix rate
                 bf16 = args.dtype == 'bf16' or any(t in sym for t in ('b16', '_sg_', '_ws_'))
-                pm = pmc.get(sym[:-1] + ', 64>') or pmc.get(sym) or {}      # (this round's passes name the backward kernel with its row-stride argument)
+                # (this round's passes name the backward kernel with its row-stride and node-loop arguments: <KC, DEG> = <KC, DEG, 64[, NL]>)
+                pm = next((v for k, v in pmc.items() if k.startswith(sym[:-1] + ', 64')), None) or pmc.get(sym) or {}
                 d = {'kernel': sym, 'launches_per_step': n, 'bound': 'hbm' if bf16 else 'mfma',
                      'algorithmic_bytes_per_launch': int(nb), 'algorithmic_flops_per_launch': int(nf),
                      'avg_launch_us_isolated': round(iso_ms * 1e3, 2), 'avg_launch_us_in_step': round(step_ms * 1e3, 2),

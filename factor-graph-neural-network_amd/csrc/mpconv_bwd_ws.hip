@@ -215,7 +215,11 @@ __global__ __launch_bounds__(BW_THREADS) void mpconv_bwd_ws_tables_kernel(const 
 // KC = destination degree (3 / 6), DEG = in-edge slots per source node the tables are sized for (6 / 3)
 // XLD = row stride (elements) of x / gx in memory: 64, or 128 for one half of a 128-channel call (compile-time: as a runtime value
 // it cost 14 - 20 spilled registers at the 256-VGPR limit)
-template <int KC, int DEG, int XLD = 64>
+// NL = source nodes the detype / dP / dW loops run over (a multiple of 16, N <= NL <= NMAX).  The images stay sized for NMAX rows (the
+// projection and dx work in 32-node tiles), but the LDPC F -> V call has 48 factor nodes in a layout sized for 64: a quarter of the
+// detype tiles, of the per-node dP MFMAs and of dW's k-steps worked on rows that are zero for the kernel's lifetime.  Rows NL ..
+// NMAX - 1 of the dP image then keep what the projection left there (finite P values): only dx's discarded rows n >= N see them.
+template <int KC, int DEG, int XLD = 64, int NL = BwLayout<KC>::NMAX>
 __global__ __launch_bounds__(BW_THREADS) void mpconv_bwd_ws_kernel(const BwParams p) {
     typedef BwLayout<KC> LY;
     constexpr int QS = LY::QS;                        // G rows per source node (slots >= DEG stay zero)
@@ -223,10 +227,11 @@ __global__ __launch_bounds__(BW_THREADS) void mpconv_bwd_ws_kernel(const BwParam
     constexpr int OFF_X = LY::OFF_X, OFF_G = LY::OFF_G, OFF_PD = LY::OFF_PD, OFF_ET = LY::OFF_ET, OFF_GST = LY::OFF_GST,
                   OFF_TAB = LY::OFF_TAB, OFF_SLOT = LY::OFF_SLOT, OFF_GT = LY::OFF_GT;
     constexpr int NPG = 16 / QS;                      // source nodes per detype tile
-    constexpr int NG = KC == 6 ? 3 : 4;               // detype tiles per wave: Npad / NPG / 8
+    static_assert(NL % 16 == 0 && NL <= LY::NMAX && (NL / 8) % NPG == 0, "NL");
+    constexpr int NG = NL / NPG / 8;                  // detype tiles per wave
     constexpr int NSLOT = KC == 3 ? 2 : 1;            // staging items per staging thread (8 M <= 768 / 384 items, 384 staging threads)
     constexpr int ESLOT = 1;                          // in-edge slots per staging thread (N QS <= 384)
-    constexpr int MAXNPW = KC == 6 ? 12 : 8;          // source nodes per wave in the dP phase: Npad / 8
+    constexpr int MAXNPW = NL / 8;                    // source nodes per wave in the dP phase (a multiple of 16 / QS: the dP read patterns below)
     const int tid = threadIdx.x;
     BW_STAMP_G(0);
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
@@ -629,7 +634,7 @@ __global__ __launch_bounds__(BW_THREADS) void mpconv_bwd_ws_kernel(const BwParam
         };
         auto phase3_dw = [&](const uint4 (&pg)[NSLOT], const uint2 (&pa)[NSLOT], const uint2 (&pe)[ESLOT]) {
                 const unsigned xbase = lds0 + (unsigned)(OFF_X + cur * (BW_MAXN * BW_XROW));
-                constexpr int nks = NMAX / 16;            // even
+                constexpr int nks = NL / 16;
                 uint2 f0[8], f1[8];
                 auto load = [&](uint2 (&f)[8], int ks) {   // A: channel tiles 0 / 1 (two reads each); B: this wave's two column tiles
     #pragma unroll
@@ -656,12 +661,13 @@ __global__ __launch_bounds__(BW_THREADS) void mpconv_bwd_ws_kernel(const BwParam
                 load(f0, 0);
                 if (has_next) build(pg, pa, pe);           // G / etT of sample b + 1, under the first transpose reads
     #pragma unroll 1
-                for (int ks = 0; ks < nks; ks += 2) {      // the next k-step's eight transpose reads are in flight under this one's MFMAs
+                for (int ks = 0; ks + 1 < nks; ks += 2) {  // the next k-step's eight transpose reads are in flight under this one's MFMAs
                     load(f1, ks + 1);
                     mma(f0);
                     if (ks + 2 < nks) load(f0, ks + 2);
                     mma(f1);
                 }
+                if (nks & 1) mma(f0);                      // (an odd count: the last k-step was loaded by the loop's final iteration)
         };
         if (build_wave) {
             // the next sample's gz / argmax / edge types: requested two phases ahead of their use (past the last sample: a harmless re-read)
@@ -875,8 +881,10 @@ int fgnn_mpconv_backward_ws(const fgnn_mpconv_desc* d, const void* x, const int6
     p.tables = (bw_pending_tables && bw_tables_count(d) > 0) ? (const int*)bw_pending_tables : nullptr;
     const int off_b = KC == 6 ? BwLayout<6>::BYTES : BwLayout<3>::BYTES;
     static_assert(BwLayout<6>::BYTES <= 160 * 1024 && BwLayout<3>::BYTES <= 160 * 1024, "LDS");
-    void* fn = ksplit ? (KC == 6 ? (void*)mpconv_bwd_ws_kernel<6, 3, 128> : (void*)mpconv_bwd_ws_kernel<3, 6, 128>)
-                      : (KC == 6 ? (void*)mpconv_bwd_ws_kernel<6, 3> : (void*)mpconv_bwd_ws_kernel<3, 6>);
+    static const bool no_nl = getenv("FGNN_BWD_WS_NL64") != nullptr;     // (A/B switch: the degree-3 instance over all 64 node rows, as before)
+    const bool nl48 = KC == 3 && d->N <= 48 && !no_nl;                   // the LDPC F -> V call: 48 factor nodes
+    void* fn = ksplit ? (KC == 6 ? (void*)mpconv_bwd_ws_kernel<6, 3, 128> : nl48 ? (void*)mpconv_bwd_ws_kernel<3, 6, 128, 48> : (void*)mpconv_bwd_ws_kernel<3, 6, 128>)
+                      : (KC == 6 ? (void*)mpconv_bwd_ws_kernel<6, 3> : nl48 ? (void*)mpconv_bwd_ws_kernel<3, 6, 64, 48> : (void*)mpconv_bwd_ws_kernel<3, 6>);
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, off_b);
     if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "hipFuncSetAttribute(%d B LDS): %s", off_b, hipGetErrorString(e));
     static const int max_grid = getenv("FGNN_WS_GRID") ? atoi(getenv("FGNN_WS_GRID")) : 256;      // (tuning knob: CUs left to the other stream's kernels)
