@@ -484,12 +484,17 @@ __global__ __launch_bounds__(256) void block_tail_bwd_final_kernel(const float* 
 // ----------------------------------------------------------------------------------------
 // host side
 // ----------------------------------------------------------------------------------------
-static int bt_plan(int64_t R, int Cout, int* grid, bool bound = true) {
+// Workgroup cap = ONE resident wave of workgroups on the 256 CUs: the statistics / reduce / grad modes hold 2 workgroups per CU
+// (__launch_bounds__(256, 2)) -> 512, the apply mode 3 -> 768.  (768 for every mode, the first setting, left the reducing modes a
+// half-empty second wave: 13.70 -> 13.56 ms per LDPC step with 512, four interleaved A/B runs, gpurun_out/r05ar.)
+static int bt_plan(int64_t R, int Cout, int* grid, bool bound = true, bool apply = false) {
     if (R <= 0 || R > 0x7fffffff || (Cout != 64 && Cout != 128 && Cout != 256)) return -1;
     const int64_t ntile = (R + 15) / 16;
     const int nrg = bound ? BT_WAVES / (Cout / 64) : BT_WAVES;       // row groups per workgroup (modes 0-2: a wave is bound to a slab)
     int64_t g = (ntile + 2 * nrg - 1) / (2 * nrg);                    // >= 2 tiles per wave
-    static const int maxg = getenv("FGNN_BT_GRID") ? atoi(getenv("FGNN_BT_GRID")) : 768;
+    static const int maxg_r = getenv("FGNN_BT_GRID") ? atoi(getenv("FGNN_BT_GRID")) : 512;
+    static const int maxg_a = getenv("FGNN_BT_GRID_APPLY") ? atoi(getenv("FGNN_BT_GRID_APPLY")) : (getenv("FGNN_BT_GRID") ? atoi(getenv("FGNN_BT_GRID")) : 768);
+    const int maxg = apply ? maxg_a : maxg_r;
     if (g > maxg) g = maxg;
     if (g > BT_MAXGRID) g = BT_MAXGRID;
     if (g < 1) g = 1;
@@ -526,9 +531,9 @@ static int bt_launch(const BtParams& p, int grid, hipStream_t st) {
     return FGNN_OK;
 }
 
-static int bt_check(const char* who, const void* e, const float* s2, const float* t2, const float* W2, int64_t R, int Cout, int* grid) {
+static int bt_check(const char* who, const void* e, const float* s2, const float* t2, const float* W2, int64_t R, int Cout, int* grid, bool apply = false) {
     if (!e || !s2 || !t2 || !W2) FGNN_FAIL(FGNN_EINVAL, "%s: null pointer", who);
-    if (bt_plan(R, Cout, grid) || ((uintptr_t)e & 15) || ((uintptr_t)W2 & 7))
+    if (bt_plan(R, Cout, grid, true, apply) || ((uintptr_t)e & 15) || ((uintptr_t)W2 & 7))
         FGNN_FAIL(FGNN_EUNSUPPORTED, "%s: Cout=%d / alignment outside the fused block tail's family", who, Cout);
     return FGNN_OK;
 }
@@ -563,7 +568,7 @@ extern "C" int fgnn_block_tail_apply(const void* e, const float* scale2, const f
                                      const void* addend0, const void* addend1, const void* addend2, const int32_t* addend_period,
                                      void* out, void* a2_out, int64_t R, int Cout, fgnn_stream_t stream) {
     int grid, rc;
-    if ((rc = bt_check("block_tail_apply", e, scale2, shift2, W2, R, Cout, &grid))) return rc;
+    if ((rc = bt_check("block_tail_apply", e, scale2, shift2, W2, R, Cout, &grid, true))) return rc;
     if (!scale3 || !shift3 || !out) FGNN_FAIL(FGNN_EINVAL, "block_tail_apply: null pointer");
     if (((uintptr_t)out | (uintptr_t)a2_out | (uintptr_t)addend0 | (uintptr_t)addend1 | (uintptr_t)addend2) & 15)
         FGNN_FAIL(FGNN_EUNSUPPORTED, "block_tail_apply: misaligned operand");
@@ -786,7 +791,7 @@ extern "C" int fgnn_block_head_backward(const void* z1, const void* ga1, const f
     if (!z1 || !ga1 || !mean || !invstd || !gamma || !beta || !W1 || !gz1 || !workspace)
         FGNN_FAIL(FGNN_EINVAL, "block_head_backward: null pointer");
     int grid;
-    if (bt_plan(R, Cin, &grid) || (((uintptr_t)z1 | (uintptr_t)ga1 | (uintptr_t)gz1 | (uintptr_t)gx) & 15))
+    if (bt_plan(R, Cin, &grid, true, true) || (((uintptr_t)z1 | (uintptr_t)ga1 | (uintptr_t)gz1 | (uintptr_t)gx) & 15))      // (3 workgroups per CU: the 768 cap)
         FGNN_FAIL(FGNN_EUNSUPPORTED, "block_head_backward: Cin=%d / alignment outside the fused block head's family", Cin);
     if (workspace_bytes < (int64_t)BT_MAXGRID * 2 * 64 * 4 + 2 * 64 * 4) FGNN_FAIL(FGNN_EINVAL, "block_head_backward: workspace too small");
     hipStream_t st = (hipStream_t)stream;
