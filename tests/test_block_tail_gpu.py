@@ -411,3 +411,26 @@ def test_single_source_fanout_runs_on_one_row_per_sample(width, dev, monkeypatch
         assert db <= 1.5 * df + 2.0 ** -4, (n, db, df)
         checked += 1
     assert checked >= 3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float32], ids=['bf16', 'f32'])
+@pytest.mark.parametrize('B,M,C', [(4096, 96, 64), (515, 96, 128), (300, 48, 256), (77, 5, 64), (64, 96, 32), (33, 96, 192), (1, 1, 64)])
+def test_node_sum_vs_torch(B, M, C, dtype, dev):
+    """fgnn_node_sum (csrc/sum_n.hip: the gradient of a per-sample row broadcast over the sample's nodes, several threads per 16-byte
+    channel chunk with a fixed lane-permute tree): against a float64 sum, bit-identical on a second run; channel counts on both
+    sides of the power-of-two rule, node counts below and above the split threshold, a batch that is not a multiple of the block."""
+    from fgnn_amd import _hip
+    L = _hip.lib()
+    g = torch.Generator().manual_seed(B + M + C)
+    x = torch.randn(B, M, C, generator=g).to(dev).to(dtype)
+    outs = []
+    for _ in range(2):
+        out = torch.full((B, C), 7.0, device=dev, dtype=dtype)
+        _hip.check(L.fgnn_node_sum(_hip._ptr(x), _hip._ptr(out), B, M, C, _hip.dtype_code(x), _hip.stream_ptr()))
+        torch.cuda.synchronize()
+        outs.append(out.clone())
+    ref = x.double().sum(1)
+    tol = 2.0 ** -8 if dtype == torch.bfloat16 else 1e-6
+    assert float((outs[0].double() - ref).abs().max()) <= tol * max(1.0, float(ref.abs().max()))
+    assert torch.equal(outs[0], outs[1])
