@@ -155,7 +155,8 @@ class FlatGradBucket:
                 if st != cur:
                     cur.wait_stream(st)
             ops._DEFER_ISSUED.clear()
-        ops.flush_folds()        # (folds a dead pass recorded and never flushed: in front of the zeroing, like its parked launches)
+        if self.flat.is_cuda:    # (a CPU / gloo bucket never recorded a fold and must not need libfgnn_hip.so at all)
+            ops.flush_folds()    # folds a dead pass recorded and never flushed: in front of the zeroing, like its parked launches
         self.flat.zero_()
 
     @property

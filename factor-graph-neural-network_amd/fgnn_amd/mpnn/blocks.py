@@ -521,12 +521,11 @@ class mp_conv_residual(base_mp_nn):
         staged = self.training and torch.is_grad_enabled()
         if callable(addend) and not staged:
             addend = addend()                                            # the one-kernel block needs it up front
-        if isinstance(addend, (list, tuple)):
-            addend = as_addends(addend)
-            if not staged:                                               # ... and takes up to three (a fourth joins the third first)
-                if len(addend) > 3:
-                    addend = addend[:2] + [ops.add_n(addend[2:])]
-                addend = addend if addend else None
+        if not callable(addend):
+            addend = as_addends(addend)                                  # a tensor, a list or None -> a list (never truth-tested as a tensor)
+            if not staged and len(addend) > 3:                           # ... the one-kernel block takes up to three (a fourth joins the third first)
+                addend = addend[:2] + [ops.add_n(addend[2:])]
+            addend = addend if addend else None
         if not staged:
             y = self._fused_eval(node_feature, nn_idx, etype, addend)
             if y is not None:
@@ -536,7 +535,7 @@ class mp_conv_residual(base_mp_nn):
         # LeakyReLU all act on M identical rows — so it is computed on ONE row per sample and handed on as a broadcast
         # (ops.broadcast_nodes).  The batch statistics of M identical rows per sample are those of one row per sample (same mean and
         # biased variance); only the running variance's unbiased correction counts the rows: population_mult = M.
-        M = ops.single_source_fanout(node_feature, nn_idx, etype) if (staged and not self.with_residual and not addend
+        M = ops.single_source_fanout(node_feature, nn_idx, etype) if (staged and not self.with_residual and addend is None
                                                                      and node_feature.shape[0] > 1) else 0
         if M:
             B, C = node_feature.shape[:2]

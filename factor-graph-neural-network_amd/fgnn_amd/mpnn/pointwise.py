@@ -113,7 +113,32 @@ def cast_cached(t, dtype):
     return out
 
 
-_PENDING_STATS = None     # (rows tensor, stats [4, C]) finalised batch statistics of the last statistics-producing launch
+_PENDING_STATS = None     # (rows tensor, stats [4, C], running_mean) finalised batch statistics of the last statistics-producing launch
+# A producer that takes ``bn=`` finalises the BatchNorm ITSELF: momentum applied to the running statistics, num_batches_tracked + 1.
+# When the consumer then never sees the pending statistics (they describe another buffer: a non-contiguous copy; another map ran
+# in between; the BatchNorm fell back to torch), whoever re-derives the batch statistics must NOT finalise a second time — the
+# momentum would be applied twice and the counter advance by 2 for one forward.  The running_mean buffers of such dropped
+# finalisations are remembered here until that BatchNorm's own statistics pass (or its torch fallback) has run without them.
+_ALREADY_FINAL = set()    # data_ptr() of running_mean buffers whose BatchNorm a producer finalised for the forward in flight
+
+
+def _drop_pending():
+    global _PENDING_STATS
+    pend, _PENDING_STATS = _PENDING_STATS, None
+    if pend is not None and pend[2] is not None:
+        _ALREADY_FINAL.add(pend[2].data_ptr())
+
+
+def finalised_by_producer(running_mean):
+    """True ONCE when a producer launch already finalised the BatchNorm that owns ``running_mean`` for this forward and its
+    pending statistics were dropped: the caller forms the batch statistics again but leaves the running buffers alone."""
+    if running_mean is None or not _ALREADY_FINAL:
+        return False
+    key = running_mean.data_ptr()
+    if key in _ALREADY_FINAL:
+        _ALREADY_FINAL.discard(key)
+        return True
+    return False
 
 
 def bn_spec(bn):
@@ -142,7 +167,7 @@ def hip_linear(rows, weight, bias, bn=None, transposed=False):
     workgroup: csrc/fgnn_gridfold.h) — running statistics, num_batches_tracked, scale / shift; the result waits for the
     BatchNorm that follows (``take_pending_stats``).  None = shape not handled."""
     global _PENDING_STATS
-    _PENDING_STATS = None
+    _drop_pending()
     if not (rows.is_cuda and rows.dtype == torch.bfloat16 and weight.dtype == torch.float32 and rows.is_contiguous()):
         return None
     R, cin = rows.shape
@@ -174,22 +199,29 @@ def hip_linear(rows, weight, bias, bn=None, transposed=False):
               nflops=2 * R * cin * cout)
     if bn is not None:
         note_state_change()                 # running statistics / num_batches_tracked were just updated in place
-        _PENDING_STATS = (y, stats)
+        _ALREADY_FINAL.discard(bn[2].data_ptr())
+        _PENDING_STATS = (y, stats, bn[2])
     return y
 
 
-def set_pending_stats(rows, stats):
-    """A kernel just finalised the batch statistics ``stats`` [4, C] of ``rows`` ([R, C]) for the BatchNorm that follows."""
+def set_pending_stats(rows, stats, running_mean=None):
+    """A kernel just finalised the batch statistics ``stats`` [4, C] of ``rows`` ([R, C]) for the BatchNorm that follows (the one
+    that owns ``running_mean``)."""
     global _PENDING_STATS
-    _PENDING_STATS = (rows, stats)
+    _drop_pending()
+    if running_mean is not None:
+        _ALREADY_FINAL.discard(running_mean.data_ptr())
+    _PENDING_STATS = (rows, stats, running_mean)
 
 
 def take_pending_stats(rows):
     """The finalised statistics [4, C] waiting for exactly this tensor, else None."""
     global _PENDING_STATS
-    pend, _PENDING_STATS = _PENDING_STATS, None
+    pend = _PENDING_STATS
     if pend is not None and pend[0].data_ptr() == rows.data_ptr() and pend[0].shape == rows.shape:
+        _PENDING_STATS = None
         return pend[1]
+    _drop_pending()             # (missed: the producer's finalisation is remembered, see _ALREADY_FINAL)
     return None
 
 
@@ -202,6 +234,10 @@ def batch_stats(rows, spec, population=0):
         return stats
     L = _hip.lib()
     R, C = rows.shape
+    if finalised_by_producer(spec[2]):
+        # the producing launch already applied this forward's momentum update and counted the batch, but its statistics did not
+        # reach us (they described another buffer): scale / shift only, the running buffers and the counter stay as they are
+        spec = (spec[0], spec[1], None, None, None) + tuple(spec[5:])
     stats, fin = make_final(spec, C, rows.device, R, population)
     ws = ops._workspace(rows.device, int(L.fgnn_bn_workspace_bytes(R, C)))
     fold = ops._fold_scratch(rows.device)
@@ -218,8 +254,14 @@ def node_sum(g, M):
     R, C = g.shape
     g = g.contiguous()
     out = torch.empty((R // M, C), device=g.device, dtype=g.dtype)
-    ops.timed('node_sum_kernel', g.numel() * g.element_size(), lambda: _hip.check(_hip.lib().fgnn_node_sum(
+    rc = []
+    ops.timed('node_sum_kernel', g.numel() * g.element_size(), lambda: rc.append(_hip.lib().fgnn_node_sum(
         _hip._ptr(g), _hip._ptr(out), R // M, M, C, _hip.dtype_code(g), _hip.stream_ptr())))
+    if rc[0] == _hip.EUNSUPPORTED:
+        # channel counts outside the kernel's 16-byte chunks (C % 8 for bf16, % 4 for f32): the broadcast path is taken for any
+        # width (ops.single_source_fanout), so its backward must exist for any width too — a device-side f32 sum
+        return g.view(R // M, M, C).sum(1, dtype=torch.float32).to(g.dtype)
+    _hip.check(rc[0])
     return out
 
 
@@ -620,6 +662,11 @@ class BatchNormAct2d(torch.nn.BatchNorm2d):
         if not ok or (not self.training and wants_grad):
             if population_mult != 1 and self.training:
                 raise _hip.FgnnHipError('BatchNormAct2d: population_mult needs the HIP path (a ROCm tensor, running statistics)')
+            _drop_pending()
+            if self.training and finalised_by_producer(self.running_mean):
+                # the map in front already finalised this BatchNorm (momentum applied, batch counted): batch statistics only here
+                y = torch.nn.functional.batch_norm(x, None, None, self.weight, self.bias, True, 0.0, self.eps)
+                return add_all(self._activate(y, slope), addends)
             return add_all(self._activate(super().forward(x), slope), addends)
         rows = x.permute(0, 2, 3, 1)
         if not rows.is_contiguous():

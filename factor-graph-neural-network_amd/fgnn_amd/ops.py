@@ -445,7 +445,7 @@ def mpconv_forward_raw(x, nn_idx, etype, filters, bias, nou, net, ext, agg, *,
             ctypes.byref(d), _hip._ptr(x), _hip._ptr(nn_idx), _hip._ptr(etype), _hip._ptr(filters),
             _hip._ptr(bias), _hip._ptr(y), _hip._ptr(amax), _hip._ptr(ws), fin, _hip._ptr(fold), _hip.stream_ptr())))
         pointwise.note_state_change()
-        pointwise.set_pending_stats(y.permute(0, 2, 3, 1).reshape(R, nou), stats)
+        pointwise.set_pending_stats(y.permute(0, 2, 3, 1).reshape(R, nou), stats, bn[2])
         return y, amax
     if addends:
         # inference: the caller's running sums ride in the kernel's epilogue where it has one for them (``addends``: up to three
@@ -816,6 +816,7 @@ class FanBox:
                    and (x.permute(0, 2, 3, 1).is_contiguous() or x.is_contiguous() and H * W == 1))
         self.slots = [None, None, None]
         self.wg = [None, None, None]
+        self.task = None               # the backward pass (autograd graph task id) the deposits belong to
         self._ph = None
 
     def placeholder(self, shape):
@@ -836,6 +837,7 @@ class FanBox:
         it —, gW [K, C] f32 accumulator, gb [K] f32 accumulator or None): the depositor then launches no weight-gradient kernel."""
         if not self.ok or gz.dim() != 2 or gz.shape[0] != self.R or gz.dtype != torch.bfloat16 or not gz.is_contiguous():
             return 0
+        self._enter_pass()
         K = gz.shape[1]
         if (tuple(weight.shape) != (K, self.C) or weight.dtype != torch.float32 or not weight.is_contiguous() or gz.data_ptr() % 16
                 or weight.data_ptr() % 16):
@@ -849,6 +851,16 @@ class FanBox:
                     return 2
                 return 1
         return 0
+
+    def _enter_pass(self):
+        """Deposits belong to ONE backward pass.  A pass that cut the fan-out node off (``torch.autograd.grad(..., inputs=...)`` on
+        a retained graph, a pass that raised half-way) leaves its pairs behind; a later pass over the same graph must neither be
+        refused its slots by them nor have ``merge`` multiply them on top of its own gradients: they are dropped here."""
+        task = torch._C._current_graph_task_id()
+        if self.task != task:
+            if any(self.slots):
+                self.slots, self.wg = [None, None, None], [None, None, None]
+            self.task = task
 
     def _wgrad_ok(self, K, rows, gW, gb):
         if not (rows.dtype == torch.bfloat16 and tuple(rows.shape) == (self.R, self.C) and rows.is_contiguous() and rows.data_ptr() % 16 == 0):
@@ -905,6 +917,7 @@ class FanBox:
     def merge(self, grads):
         """The state's gradient from the deposits + the gradients that arrived as tensors."""
         real = [g for g in grads if g is not None and not self.is_placeholder(g)]
+        self._enter_pass()
         slots, self.slots = self.slots, [None, None, None]
         wg, self.wg = self.wg, [None, None, None]
         if not any(slots):

@@ -434,3 +434,74 @@ def test_node_sum_vs_torch(B, M, C, dtype, dev):
     tol = 2.0 ** -8 if dtype == torch.bfloat16 else 1e-6
     assert float((outs[0].double() - ref).abs().max()) <= tol * max(1.0, float(ref.abs().max()))
     assert torch.equal(outs[0], outs[1])
+
+
+def _parity_block(dev, seed=3):
+    from fgnn_amd.mpnn import mp_conv_residual, mp_conv_type
+    torch.manual_seed(seed)
+    m = mp_conv_residual(64, 64, 4, extension=mp_conv_type.NO_EXTENSION, with_residual=False, aggregator='max').to(dev).train()
+    with torch.no_grad():
+        m.mp_conv.filters.mul_(10.0)
+    return m
+
+
+def test_dropped_producer_statistics_do_not_finalise_a_batchnorm_twice(dev):
+    """Round-5 advisory: a statistics-producing launch given ``bn=`` finalises that BatchNorm itself (momentum, counter).  When the
+    consumer cannot use the pending statistics — here the operator's output is NOT channel-fastest (a plain-contiguous input), so
+    the fused tail copies the rows and drops them — the second statistics pass must leave the running buffers and
+    num_batches_tracked alone: ONE momentum update and ONE count per forward, the same as for the channel-fastest input."""
+    B, N, M, k = 40, 96, 48, 6
+    g = torch.Generator().manual_seed(11)
+    xr = torch.randn(B, N, 1, 64, generator=g).bfloat16().to(dev)
+    idx = torch.randint(0, N, (1, M, k), generator=g).to(dev).expand(B, -1, -1)
+    et = torch.randn(B, M, k, 4, generator=g).bfloat16().to(dev).permute(0, 3, 1, 2)
+    outs = []
+    for plain in (False, True):
+        m = _parity_block(dev)
+        x = xr.permute(0, 3, 1, 2)
+        if plain:
+            x = x.contiguous()                   # [B, C, N, 1] channel-slowest: every row view downstream needs a copy
+            assert not x.permute(0, 2, 3, 1).is_contiguous()
+        with torch.autocast('cuda', dtype=torch.bfloat16):
+            y = m(x, idx, et)
+        sd = m.state_dict()
+        for n, v in sd.items():
+            if n.endswith('num_batches_tracked'):
+                assert int(v) == 1, (plain, n, int(v))
+        outs.append((y.float(), {n: v.float().clone() for n, v in sd.items() if 'running' in n}))
+    (ya, sa), (yb, sb) = outs
+    assert H.rel_err(ya, yb) <= 2.0 ** -6
+    for n in sa:
+        assert H.rel_err(sa[n], sb[n]) <= 2e-3, n
+
+
+def test_training_block_takes_a_bare_tensor_addend(dev):
+    """Round-5 advisory: ``mp_conv_residual.forward`` documents ``addend`` as a tensor, a list or a callable; a bare multi-element
+    tensor in TRAINING mode used to be truth-tested (``not addend`` -> 'Boolean value of Tensor ... is ambiguous')."""
+    B, N, M, k = 24, 96, 48, 6
+    g = torch.Generator().manual_seed(12)
+    x = torch.randn(B, N, 1, 64, generator=g).bfloat16().to(dev).permute(0, 3, 1, 2)
+    idx = torch.randint(0, N, (1, M, k), generator=g).to(dev).expand(B, -1, -1)
+    et = torch.randn(B, M, k, 4, generator=g).bfloat16().to(dev).permute(0, 3, 1, 2)
+    a = torch.randn(B, M, 1, 64, generator=g).bfloat16().to(dev).permute(0, 3, 1, 2)
+    m = _parity_block(dev)
+    sd0 = {n: v.clone() for n, v in m.state_dict().items()}
+    with torch.autocast('cuda', dtype=torch.bfloat16):
+        y_t = m(x, idx, et, addend=a)
+        m.load_state_dict(sd0)
+        y_l = m(x, idx, et, addend=[a])
+        m.load_state_dict(sd0)
+        y_0 = m(x, idx, et)
+    assert torch.equal(y_t, y_l)
+    assert H.rel_err(y_t.float(), y_0.float() + a.float()) <= 2.0 ** -6
+
+
+@pytest.mark.parametrize('C', [5, 12])
+def test_node_sum_of_a_width_outside_the_kernel(C, dev):
+    """Round-5 advisory: the broadcast fan-out is taken for any channel count; its backward (pointwise.node_sum) must then exist for
+    any channel count (fgnn_node_sum itself wants 16-byte chunks)."""
+    from fgnn_amd.mpnn import pointwise
+    g = torch.randn(6 * 7, C, device=dev).bfloat16()
+    out = pointwise.node_sum(g, 7)
+    assert out.shape == (6, C)
+    assert H.rel_err(out.float(), g.float().view(6, 7, C).sum(1)) <= 2.0 ** -7

@@ -474,3 +474,31 @@ def test_decoding_loss_on_the_cpu_is_the_reference_expression():
     assert torch.equal(loss, ref)
     loss.backward()
     assert logits.grad is not None and pred.grad is not None
+
+
+def test_cpu_gradient_bucket_never_needs_the_hip_library(monkeypatch):
+    """Round-5 advisory: FlatGradBucket.zero() runs every step; on a CPU / gloo bucket it must not load libfgnn_hip.so (hosts of
+    the data-parallel CPU path may not have it)."""
+    from fgnn_amd import _hip, dp
+
+    def boom():
+        raise _hip.FgnnHipError('libfgnn_hip.so must not be loaded by a CPU bucket')
+    monkeypatch.setattr(_hip, 'lib', boom)
+    lin = torch.nn.Linear(4, 3)
+    bucket = dp.FlatGradBucket(lin.parameters())
+    lin(torch.randn(2, 4)).sum().backward()
+    assert float(bucket.flat.abs().sum()) > 0
+    bucket.zero()
+    assert float(bucket.flat.abs().sum()) == 0.0
+
+
+def test_fan_box_drops_the_deposits_of_another_backward_pass():
+    """Round-5 advisory: deposits left behind by a pass that cut the fan-out node off must not be multiplied into a later pass."""
+    from fgnn_amd import ops
+    box = ops.FanBox.__new__(ops.FanBox)
+    box.slots, box.wg, box.task, box._ph = ['stale', None, None], ['stale-job', None, None], 12345, None
+    box._enter_pass()                       # (outside any backward pass the current task id is -1: another pass)
+    assert box.slots == [None, None, None] and box.wg == [None, None, None] and box.task == -1
+    box.slots[0] = 'mine'
+    box._enter_pass()                       # same pass: kept
+    assert box.slots[0] == 'mine'
