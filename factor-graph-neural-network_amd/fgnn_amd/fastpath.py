@@ -14,8 +14,15 @@ over ~330 tensors (59.3 ms per step at 4096 codewords against 17 ms for ``bench.
   (schedulers and ``state_dict`` work) whose parameters and gradients live in the flat buffers of ``dp.FlatGradBucket`` and whose
   ``step`` is the one-kernel ``dp.FlatAdam`` update (``zero_grad`` = one memset).  Anything else gets the stock class.
 
-What the switch cannot give an unchanged script is the hipGraph replay (``graph.StepGraph`` needs the step as a closure); the
-eager step is launch-bound at ~25-30 ms.  ``disable_fast_path()`` undoes both patches (modules already optimised stay so).
+* round 6 — the hipGraph replay too (``GraphedForward``): once the optimised module has been called ``FGNN_FAST_GRAPH_AFTER``
+  (default 3) times in training mode with inputs of one geometry and every trainable parameter's gradient lives in a ``FastAdam``
+  bucket, its forward and its backward are captured as two hipGraphs (the script's own lines between them — the loss, ``backward()``,
+  ``optimizer.step()`` — stay eager: ~30 short launches) and replayed from then on: new inputs are copied into the captured
+  buffers, the outputs come back through an autograd node whose backward replays the second graph.  Any change the graphs
+  cannot follow — another batch size, neighbour tables with other contents, eval mode, no-grad, a replaced parameter — runs that
+  call eagerly as before.  ``FGNN_FAST_GRAPH_AFTER=0`` keeps every call eager.
+
+``disable_fast_path()`` undoes the patches (modules already optimised stay so).
 """
 import os
 import threading
@@ -63,6 +70,237 @@ def _fast_post(module, args, kwargs, out):
     return back(out)
 
 
+GRAPH_AFTER = int(os.environ.get('FGNN_FAST_GRAPH_AFTER', '3') or 0)
+
+
+def _flat_tensors(out):
+    if torch.is_tensor(out):
+        return [out]
+    if isinstance(out, (tuple, list)):
+        return [t for o in out for t in _flat_tensors(o)]
+    return []
+
+
+class _Replay(torch.autograd.Function):
+    """The captured forward as ONE autograd node: forward = replay of the first graph, backward = replay of the second (which
+    accumulates every parameter gradient into the optimizer's flat bucket, as the eager backward does)."""
+
+    @staticmethod
+    def forward(ctx, cap, anchor):
+        ctx.cap = cap
+        cap.fwd.replay()
+        outs = tuple(o.detach().clone() for o in cap.static_out)
+        ctx.mark_non_differentiable(*[o for o, g in zip(outs, cap.static_grad) if g is None])
+        return outs
+
+    @staticmethod
+    def backward(ctx, *grads):
+        cap = ctx.cap
+        with torch.no_grad():
+            for g, sg in zip(grads, cap.static_grad):
+                if sg is not None:
+                    if g is None:
+                        sg.zero_()
+                    else:
+                        sg.copy_(g)
+        cap.bwd.replay()
+        cap.after_replay()
+        return None, None
+
+
+class _Captured:
+    def __init__(self):
+        self.fwd = self.bwd = None
+        self.static_in = self.static_out = self.static_grad = None
+        self.out_tree = None
+        self.pointers = None
+        self.frozen = None
+
+    @staticmethod
+    def after_replay():
+        from .mpnn import pointwise
+        pointwise.note_state_change()       # the replayed kernels moved BatchNorm buffers / gradient slices behind torch's version counters
+        pointwise.invalidate_casts()
+
+
+class GraphedForward:
+    """Installed as ``module.forward`` of an optimised module (``fast_path``): eager calls until one input geometry has been seen
+    ``GRAPH_AFTER`` times in training mode, then two hipGraphs (see the module docstring).  The reference loop it serves:
+    /root/reference/train_ldpc.py:207-231."""
+
+    def __init__(self, module):
+        self.module = module      # (a reference cycle with the module's own attribute: collected with it)
+        self.seen = {}
+        self.cap = None
+        self.key = None
+        self.failed = False
+        self.anchor = None
+        self.replays = 0
+        self.checked = {}         # integer input position -> (data_ptr, version) last compared equal to the captured table
+
+    def eager(self, *args, **kwargs):
+        """The module's own forward (the class's: this object shadows it as an instance attribute)."""
+        return type(self.module).forward(self.module, *args, **kwargs)
+
+    def __getstate__(self):        # graphs and captured buffers do not travel (pickle / deepcopy give an eager module that re-captures)
+        return {'module': self.module, 'seen': {}, 'cap': None, 'key': None, 'failed': False, 'anchor': None, 'replays': 0,
+                'checked': {}}
+
+    # ---- what a call must look like to be captured / replayed ----
+    @staticmethod
+    def _signature(args):
+        sig = []
+        for a in args:
+            if torch.is_tensor(a):
+                if not a.is_cuda:
+                    return None
+                sig.append((tuple(a.shape), a.dtype, a.device))
+            else:
+                return None                # (a non-tensor argument would be baked into the graph)
+        return tuple(sig) if sig else None
+
+    def _trainable_in_bucket(self):
+        """Every trainable parameter's ``.grad`` is a persistent slice the gradient kernels add into (``FastAdam``'s flat bucket):
+        only then does a replayed backward land where the optimizer reads — an autograd-owned ``.grad`` is re-created (or set to None
+        by ``zero_grad``) every step, at addresses a graph cannot know."""
+        any_p = False
+        for q in self.module.parameters():
+            if q.requires_grad:
+                any_p = True
+                if q.grad is None or not getattr(q, '_fgnn_grad_sink', False):
+                    return False
+        return any_p
+
+    def _pointers(self):
+        return tuple(t.data_ptr() for t in list(self.module.parameters()) + list(self.module.buffers()))
+
+    def _frozen_versions(self):
+        return tuple(q._version for q in self.module.parameters() if not q.requires_grad)
+
+    def __call__(self, *args, **kwargs):
+        m = self.module
+        if (GRAPH_AFTER <= 0 or self.failed or kwargs or not m.training or not torch.is_grad_enabled()
+                or torch.cuda.is_current_stream_capturing()):
+            return self.eager(*args, **kwargs)
+        key = self._signature(args)
+        if key is None:
+            return self.eager(*args, **kwargs)
+        if self.cap is not None:
+            if key == self.key and self._valid(args):
+                return self._replay(args)
+            return self.eager(*args, **kwargs)
+        n = self.seen.get(key, 0) + 1
+        self.seen[key] = n
+        if n <= GRAPH_AFTER or not self._trainable_in_bucket():
+            return self.eager(*args, **kwargs)
+        try:
+            self._capture(key, args)
+        except Exception as e:      # noqa: BLE001 — a model the capture cannot follow keeps the eager fast path; say so once
+            import warnings
+            self.failed, self.cap = True, None
+            warnings.warn('fgnn_amd fast path: hipGraph capture of %s failed (%s: %s); its steps stay eager'
+                          % (type(m).__name__, type(e).__name__, e))
+            return self.eager(*args, **kwargs)
+        return self._replay(args, fresh=True)
+
+    def _valid(self, args):
+        cap = self.cap
+        if cap.pointers != self._pointers() or cap.frozen != self._frozen_versions():
+            self.cap, self.seen = None, {}             # a parameter / buffer was replaced, a frozen table rewritten: capture again later
+            return False
+        for i, (a, st) in enumerate(zip(args, cap.static_in)):
+            if a.dtype.is_floating_point or a.data_ptr() == st.data_ptr():
+                continue
+            mark = (a.data_ptr(), a._version)
+            if self.checked.get(i) == mark:
+                continue
+            if not torch.equal(a, st):                 # (one device comparison + host read per table and step: the loop it serves reads
+                return False                           # the loss back every step anyway) other neighbour tables: the graphs' fast paths
+            self.checked[i] = mark                     # were chosen for the captured ones
+        return True
+
+    def _replay(self, args, fresh=False):
+        cap = self.cap
+        if not fresh:
+            with torch.no_grad():
+                for a, st in zip(args, cap.static_in):
+                    if a.dtype.is_floating_point and a.data_ptr() != st.data_ptr():
+                        st.copy_(a)
+        outs = _Replay.apply(cap, self.anchor)
+        self.replays += 1
+        it = iter(outs)
+        return cap.out_tree(it)
+
+    def _capture(self, key, args):
+        from . import ops
+        from .mpnn import pointwise
+        m = self.module
+        dev = args[0].device
+        cap = _Captured()
+        with torch.no_grad():
+            cap.static_in = [a.clone() for a in args]
+        saved = [(b, b.detach().clone()) for b in m.buffers()]      # the warm-up runs below move BatchNorm's running statistics: put back
+        stream = torch.cuda.Stream(dev)
+        stream.wait_stream(torch.cuda.current_stream(dev))
+        verdicts = None
+        with torch.cuda.stream(stream):
+            for i in range(2):          # allocator / workspace / per-stream scratch warm-up ON the capture stream; the second run's
+                rec = ops.Verdicts.recording()     # host-side verdicts are what the capture takes for tensors built inside the forward
+                with rec as v, _uncached_autocast():
+                    out = self.eager(*cap.static_in)
+                    live = [t for t in _flat_tensors(out) if t.requires_grad]
+                    # zero upstream gradients: the pass exercises every backward kernel and adds exactly +0 to the gradient slices
+                    torch.autograd.backward(live, [torch.zeros_like(t) for t in live])
+                verdicts = v
+                del out, live
+        torch.cuda.current_stream(dev).wait_stream(stream)
+        torch.cuda.synchronize(dev)
+        with torch.no_grad():
+            for b, old in saved:
+                b.copy_(old)
+        pointwise.note_state_change()
+        pointwise.invalidate_casts()           # the weight casts are recorded: every replay derives them from the parameters of that moment
+        cap.fwd = torch.cuda.CUDAGraph()
+        with verdicts.replaying(), _uncached_autocast():
+            with torch.cuda.graph(cap.fwd, stream=stream):
+                out = self.eager(*cap.static_in)
+        cap.recorded = verdicts.taken
+        cap.unused = sum(len(q) for q in verdicts.fifo.values())
+        flat = _flat_tensors(out)
+        if not flat or not any(t.requires_grad for t in flat):
+            raise RuntimeError('the forward returned nothing differentiable')
+        cap.static_out = flat
+        cap.static_grad = [torch.zeros_like(t) if t.requires_grad else None for t in flat]
+        cap.bwd = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(cap.bwd, pool=cap.fwd.pool(), stream=stream):
+            torch.autograd.backward([t for t in flat if t.requires_grad], [g for g in cap.static_grad if g is not None])
+        # the captured passes did not EXECUTE: the first real execution is the replay the caller gets now
+        cap.out_tree = _tree_builder(out)
+        cap.pointers, cap.frozen = self._pointers(), self._frozen_versions()
+        self.anchor = torch.zeros((), device=dev, requires_grad=True)
+        self.cap, self.key = cap, key
+
+
+def _uncached_autocast():
+    """The autocast region the pre-hook opened caches its weight casts until it closes.  A warm-up run would leave casts there
+    that the captured forward then REUSES instead of recording their kernels (and that are freed when the region closes): every
+    run of the capture procedure starts from an empty cache and keeps none."""
+    torch.clear_autocast_cache()
+    on = torch.is_autocast_enabled('cuda')
+    return torch.autocast('cuda', dtype=torch.get_autocast_dtype('cuda') if on else None, enabled=on, cache_enabled=False)
+
+
+def _tree_builder(out):
+    """A function that rebuilds ``out``'s nesting (tensor | tuple / list of ...) from an iterator over replacement tensors."""
+    if torch.is_tensor(out):
+        return lambda it: next(it)
+    if isinstance(out, (tuple, list)):
+        subs = [_tree_builder(o) for o in out]
+        kind = type(out)
+        return lambda it: kind(b(it) for b in subs)
+    return lambda it, out=out: out
+
+
 def fast_path(module):
     """Optimise ONE module that owns a ``FactorNN`` (what the global hook does at its first call).  Idempotent."""
     from .edge_mlp import EdgeMLP
@@ -78,6 +316,8 @@ def fast_path(module):
             setattr(module, name, new)
     module.register_forward_pre_hook(_fast_pre, with_kwargs=True)
     module.register_forward_hook(_fast_post, with_kwargs=True, always_call=True)
+    if GRAPH_AFTER > 0 and 'forward' not in module.__dict__:
+        module.forward = GraphedForward(module)      # (inside the hooks: it sees bf16 inputs under autocast)
     return module
 
 

@@ -311,6 +311,70 @@ def _check_index_range(nn_idx, N):
 DEDUPE_GRAPHS = True     # recognise batch-identical neighbour tables passed as B copies (the reference's calling convention)
 
 
+class Verdicts:
+    """The host-side verdicts of one forward (is this table shared by the batch?  an identity list?  its in-degree?  are these
+    edge weights equal over the nodes?) in call order, so that a hipGraph capture of the SAME forward can take the fast paths for
+    tensors it meets for the first time — tensors the model builds inside its forward (the reference's
+    ``self.hnn_idx_f2v.repeat(bsize, 1, 1)``, /root/reference/train_ldpc.py:77-84) — where no host read is possible.
+
+    ``with Verdicts.recording() as v:`` around an EAGER run notes every device check + host read; ``with v.replaying():`` around the
+    capture hands them back in the same order, each only to a tensor of the same site, shape, strides and dtype (anything else:
+    the conservative answer, as before).  Sound when the capture runs the same module on the same inputs in the same state — the
+    tensors checked are functions of the integer inputs and of frozen parameters only; fastpath.GraphedForward re-validates both
+    before every replay."""
+    current = None
+
+    def __init__(self):
+        self.fifo = {}
+        self.mode = None
+        self.taken = 0          # verdicts handed to a capture
+
+    @staticmethod
+    def _sig(t):
+        return (tuple(t.shape), tuple(t.stride()), t.dtype)
+
+    @classmethod
+    def note(cls, site, t, value):
+        v = cls.current
+        if v is not None and v.mode == 'record':
+            v.fifo.setdefault(site, []).append((cls._sig(t), value))
+        return value
+
+    @classmethod
+    def recall(cls, site, t):
+        """The recorded verdict for the next check at ``site`` (None: nothing recorded / another tensor geometry)."""
+        v = cls.current
+        if v is None or v.mode != 'replay':
+            return None
+        q = v.fifo.get(site)
+        if not q or q[0][0] != cls._sig(t):
+            return None
+        v.taken += 1
+        return q.pop(0)[1]
+
+    class _Mode:
+        def __init__(self, v, mode):
+            self.v, self.mode = v, mode
+
+        def __enter__(self):
+            self.prev = Verdicts.current
+            self.v.mode = self.mode
+            Verdicts.current = self.v
+            return self.v
+
+        def __exit__(self, *exc):
+            Verdicts.current = self.prev
+            self.v.mode = None
+            return False
+
+    @classmethod
+    def recording(cls):
+        return cls._Mode(cls(), 'record')
+
+    def replaying(self):
+        return Verdicts._Mode(self, 'replay')
+
+
 def shared_graph_view(nn_idx):
     """The reference's scripts hand the operator one neighbour table PER SAMPLE even though every sample of a batch
     shares one graph (`.repeat(B,1,1)` in train_syn_*.py:264-293; DataLoader-collated copies of the same alist tables in
@@ -327,8 +391,12 @@ def shared_graph_view(nn_idx):
     memo = getattr(owner, '_fgnn_shared_graph', None)
     if memo is None or memo[0] != key:
         if torch.cuda.is_current_stream_capturing():
-            return nn_idx
-        memo = (key, bool((nn_idx == nn_idx[:1]).all().item()))
+            v = Verdicts.recall('shared_graph', nn_idx)
+            if v is None:
+                return nn_idx
+            memo = (key, v)
+        else:
+            memo = (key, Verdicts.note('shared_graph', nn_idx, bool((nn_idx == nn_idx[:1]).all().item())))
         owner._fgnn_shared_graph = memo
     return nn_idx[:1].expand(B, -1, -1) if memo[1] else nn_idx
 
@@ -343,9 +411,13 @@ def is_identity_list(nn_idx):
     memo = getattr(owner, '_fgnn_identity_list', None)
     if memo is None or memo[0] != key:
         if nn_idx.is_cuda and torch.cuda.is_current_stream_capturing():
-            return False
-        k = nn_idx.shape[-1]
-        hit = bool((nn_idx == torch.arange(k, device=nn_idx.device, dtype=nn_idx.dtype)).all().item())
+            hit = Verdicts.recall('identity_list', nn_idx)
+            if hit is None:
+                return False
+        else:
+            k = nn_idx.shape[-1]
+            hit = Verdicts.note('identity_list', nn_idx, bool(
+                (nn_idx == torch.arange(k, device=nn_idx.device, dtype=nn_idx.dtype)).all().item()))
         memo = (key, hit)
         owner._fgnn_identity_list = memo
     return memo[1]
@@ -365,9 +437,13 @@ def max_in_degree(nn_idx, N):
     memo = getattr(owner, '_fgnn_in_degree', None)
     if memo is None or memo[0] != key:
         if torch.cuda.is_current_stream_capturing():
-            return 0
-        flat = nn_idx[0].reshape(-1).clamp(0, N - 1)
-        memo = (key, int(torch.bincount(flat, minlength=N).max().item()) if flat.numel() else 0)
+            deg = Verdicts.recall('in_degree', nn_idx)
+            if deg is None:
+                return 0
+            memo = (key, deg)
+        else:
+            flat = nn_idx[0].reshape(-1).clamp(0, N - 1)
+            memo = (key, Verdicts.note('in_degree', nn_idx, int(torch.bincount(flat, minlength=N).max().item()) if flat.numel() else 0))
         owner._fgnn_in_degree = memo
     return memo[1]
 
@@ -671,10 +747,13 @@ def _unexpanded(etype):
                     or tuple(src) != (1,) + tuple(etype.shape[1:])):
                 return None
             return etype[:1]
-        if (not DEDUPE_GRAPHS or not etype.is_cuda or torch.cuda.is_current_stream_capturing()
-                or not bool((etype == etype[:1]).all().item())):
+        if not DEDUPE_GRAPHS or not etype.is_cuda:
             return None
-        return etype[:1]
+        if torch.cuda.is_current_stream_capturing():
+            same = Verdicts.recall('equal_rows', etype)
+        else:
+            same = Verdicts.note('equal_rows', etype, bool((etype == etype[:1]).all().item()))
+        return etype[:1] if same else None
     base = etype._base
     if (base is not None and base.dim() == 4 and base.shape[0] == 1 and base.shape[1:] == etype.shape[1:]
             and base.data_ptr() == etype.data_ptr() and base.stride()[1:] == etype.stride()[1:]
@@ -715,8 +794,12 @@ def single_source_fanout(x, nn_idx, etype):
     memo = getattr(owner, '_fgnn_node_invariant', None)
     if memo is None or memo[0] != key:
         if torch.cuda.is_current_stream_capturing():
-            return 0
-        memo = (key, bool((etype == etype[:, :, :1, :]).all().item()))
+            v = Verdicts.recall('node_invariant', etype)
+            if v is None:
+                return 0
+            memo = (key, v)
+        else:
+            memo = (key, Verdicts.note('node_invariant', etype, bool((etype == etype[:, :, :1, :]).all().item())))
         owner._fgnn_node_invariant = memo
     return M if memo[1] else 0
 

@@ -1303,3 +1303,107 @@ def test_fast_path_switch_for_an_unchanged_script(dev):
     finally:
         fgnn_amd.disable_fast_path()
     assert not hasattr(torch.optim.Adam, 'stock')
+
+
+def test_fast_path_replays_hipgraphs_for_an_unchanged_training_loop(dev):
+    """Round 6: `fgnn_amd.enable_fast_path()` also gives an UNCHANGED loop (/root/reference/train_ldpc.py:207-231: zero_grad, model(...),
+    the script's own loss lines, backward, optimizer.step, a fresh collated batch every iteration) the hipGraph replay — forward and
+    backward captured as two graphs after three eager calls (fastpath.GraphedForward).  The model is composed as the script composes
+    it, INCLUDING the tables its forward builds with `.repeat` on every call (train_ldpc.py:77-84): under capture no host read can
+    classify those, the verdicts recorded from the eager warm-up do (ops.Verdicts).  Checked: the replayed loop ends bit-identical to
+    the same loop with the graphs off; calls the graphs cannot follow (another batch size, eval mode, other tables) run eagerly."""
+    import os, sys
+    import fgnn_amd
+    from fgnn_amd import fastpath
+    from fgnn_amd.ldpc import synthetic_batch
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'factor-graph-neural-network_amd'))
+    from lib.model.mpnn import FactorNN
+
+    class ScriptModel(torch.nn.Module):                       # train_ldpc.py:19-99, restated
+        def __init__(self):
+            super().__init__()
+            self.main = FactorNN(2, [6, 96], [64, 64, 64, 128, 256, 256, 128, 64, 64], [4, 1], 2,
+                                 skip_link={4: 3, 5: 2, 7: 0}, ret_high=True, aggregator='max')
+            mk = lambda: torch.nn.Sequential(torch.nn.Conv2d(7, 64, 1), torch.nn.ReLU(inplace=True), torch.nn.Conv2d(64, 4, 1))
+            self.emodel_f2v, self.emodel_v2f = mk(), mk()
+            frozen = lambda t: torch.nn.Parameter(t, requires_grad=False)
+            self.hnn_idx_v2f = frozen(torch.arange(96).reshape(1, 1, 96))
+            self.hnn_idx_f2v = frozen(torch.zeros(1, 96, 1, dtype=torch.int64))
+            self.hetype_v2f, self.hetype_f2v = frozen(torch.ones(1, 1, 1, 96)), frozen(torch.ones(1, 1, 96, 1))
+            self.nhop_regressor = torch.nn.Sequential(torch.nn.Linear(64, 128), torch.nn.BatchNorm1d(128), torch.nn.ReLU(),
+                                                      torch.nn.Linear(128, 128), torch.nn.ReLU(), torch.nn.Linear(128, 1), torch.nn.ReLU())
+
+        def forward(self, node_feature, hop_feature, nn_idx_f2v, nn_idx_v2f, efeature_f2v, efeature_v2f):
+            etype_f2v, etype_v2f = self.emodel_f2v(efeature_f2v), self.emodel_v2f(efeature_v2f)
+            with torch.no_grad():
+                bsize = node_feature.shape[0]
+                nhop = node_feature[:, 0, :, :].reshape(bsize, 96, 1, 1)
+            res, nhops = self.main(node_feature, [hop_feature, nhop],
+                                   [nn_idx_f2v, self.hnn_idx_f2v.repeat(bsize, 1, 1)], [nn_idx_v2f, self.hnn_idx_v2f.repeat(bsize, 1, 1)],
+                                   [etype_f2v, self.hetype_f2v.repeat(bsize, 1, 1, 1)], [etype_v2f, self.hetype_v2f.repeat(bsize, 1, 1, 1)])
+            res = (res + node_feature[:, :1, :, :]).squeeze()
+            return res[:, :48].contiguous(), self.nhop_regressor(nhops[1].squeeze())
+
+    B, steps = 256, 9
+    batches = []
+    for i in range(steps):                                      # what the DataLoader collates: fresh tensors, per-sample table copies
+        d = synthetic_batch(B, dev, seed=40 + i, dtype=torch.float32, shared_graph=False)
+        batches.append(d)
+
+    def loop(graph_after):
+        fastpath.GRAPH_AFTER = graph_after
+        fgnn_amd.enable_fast_path()
+        try:
+            torch.manual_seed(3)
+            m = ScriptModel().to(dev).train()
+            opt = torch.optim.Adam(m.parameters(), lr=1e-3, weight_decay=1e-8)
+            losses = []
+            for d in batches:
+                opt.zero_grad()
+                pred, sb = m(*d[:6])
+                loss = torch.nn.functional.binary_cross_entropy_with_logits(pred.view(-1), d[6].view(-1).float())
+                sloss = torch.nn.functional.mse_loss(sb.view(-1), torch.pow(10.0, d[7].float() / 20).view(-1))
+                (loss + 0.1 * sloss).backward()
+                opt.step()
+                losses.append(float(loss))
+                assert pred.dtype == torch.float32 and ((pred > 0).long() == d[6]).sum() >= 0
+            params = torch.cat([q.detach().reshape(-1).float() for q in m.parameters()])
+            bufs = torch.cat([b.detach().reshape(-1).float() for b in m.buffers()])
+            return m, opt, losses, params, bufs
+        finally:
+            fgnn_amd.disable_fast_path()
+            fastpath.GRAPH_AFTER = 3
+
+    m0, _, l0, p0, b0 = loop(0)
+    assert not isinstance(m0.__dict__.get('forward'), fastpath.GraphedForward)
+    m1, opt1, l1, p1, b1 = loop(3)
+    gf = m1.__dict__.get('forward')
+    assert isinstance(gf, fastpath.GraphedForward) and not gf.failed and gf.cap is not None
+    assert gf.replays == steps - 3, gf.replays
+    assert gf.cap.recorded >= 4 and gf.cap.unused == 0, (gf.cap.recorded, gf.cap.unused)     # the in-forward tables were classified under capture
+    print('losses eager', l0, 'graphed', l1)
+    assert l0 == l1                                               # bit-identical: the same kernels in the same order
+    assert torch.equal(p0, p1) and torch.equal(b0, b1)
+    # calls the graphs cannot follow run eagerly: another batch size, eval mode, other neighbour tables
+    fgnn_amd.enable_fast_path()
+    try:
+        before = gf.replays
+        small = synthetic_batch(64, dev, seed=77, dtype=torch.float32, shared_graph=False)
+        pred, _ = m1(*small[:6])
+        assert pred.shape == (64, 48) and gf.replays == before
+        m1.eval()
+        with torch.no_grad():
+            pred, _ = m1(*batches[0][:6])
+        assert pred.shape == (B, 48) and gf.replays == before
+        m1.train()
+        other = list(batches[0][:6])
+        other[2] = other[2].flip(2).contiguous()                  # the same graph, neighbours listed in another order: other table contents
+        pe, _ = m1(*other)
+        assert gf.replays == before and bool(torch.isfinite(pe).all())
+        pr, _ = m1(*batches[0][:6])
+        assert gf.replays == before + 1
+        import copy
+        m2 = copy.deepcopy(m1)                                    # graphs do not travel; the copy is an eager module that may capture again
+        assert m2.__dict__['forward'].cap is None and m2.__dict__['forward'].module is m2
+    finally:
+        fgnn_amd.disable_fast_path()
