@@ -179,11 +179,10 @@ class GraphedForward:
 
     def __call__(self, *args, **kwargs):
         m = self.module
-        if (GRAPH_AFTER <= 0 or self.failed or kwargs or not m.training or not torch.is_grad_enabled()
-                or torch.cuda.is_current_stream_capturing()):
+        if GRAPH_AFTER <= 0 or self.failed or kwargs or not m.training or not torch.is_grad_enabled():
             return self.eager(*args, **kwargs)
-        key = self._signature(args)
-        if key is None:
+        key = self._signature(args)            # (None: a CPU or non-tensor argument — nothing below touches the device then)
+        if key is None or torch.cuda.is_current_stream_capturing():
             return self.eager(*args, **kwargs)
         if self.cap is not None:
             if key == self.key and self._valid(args):
@@ -231,11 +230,55 @@ class GraphedForward:
         it = iter(outs)
         return cap.out_tree(it)
 
+    class _FreshLeaves:
+        """For the duration of the capture procedure every trainable parameter of the module tree is replaced by a NEW leaf on the
+        same storage with the same ``.grad`` slice.  Why: a parameter of a plain torch module (the script's regressor head,
+        train_ldpc.py:60-66) gets its gradient through an AccumulateGrad node that is cached on the parameter while ANY autograd
+        graph that used it is alive — the previous iteration's, still referenced by the script's ``loss`` variable — and that node
+        runs on the stream it was created for, the script's default stream: outside the capture (torch warns 'AccumulateGrad
+        node's stream does not match', hipStreamEndCapture then segfaults; ``torch.autograd.grad`` routes through the same nodes).
+        A fresh leaf gets a fresh node, created on the capture stream.  The graphs only hold addresses, and those are the
+        originals'."""
+
+        def __init__(self, module):
+            self.module, self.swapped = module, []
+
+        def __enter__(self):
+            alias = {}
+            for mod in self.module.modules():
+                for name, q in list(mod._parameters.items()):
+                    if q is None or not q.requires_grad:
+                        continue
+                    a = alias.get(id(q))
+                    if a is None:
+                        a = alias[id(q)] = torch.nn.Parameter(q.detach(), requires_grad=True)
+                        a.grad = q.grad
+                        a._fgnn_grad_sink = getattr(q, '_fgnn_grad_sink', False)
+                    mod._parameters[name] = a
+                    self.swapped.append((mod, name, q))
+            return self
+
+        def __exit__(self, *exc):
+            for mod, name, q in self.swapped:
+                mod._parameters[name] = q
+            self.swapped = []
+            return False
+
     def _capture(self, key, args):
         from . import ops
         from .mpnn import pointwise
         m = self.module
         dev = args[0].device
+        with self._FreshLeaves(m):
+            cap = self._capture_with_fresh_leaves(key, args, dev)
+        cap.pointers, cap.frozen = self._pointers(), self._frozen_versions()
+        self.anchor = torch.zeros((), device=dev, requires_grad=True)
+        self.cap, self.key = cap, key
+
+    def _capture_with_fresh_leaves(self, key, args, dev):
+        from . import ops
+        from .mpnn import pointwise
+        m = self.module
         cap = _Captured()
         with torch.no_grad():
             cap.static_in = [a.clone() for a in args]
@@ -264,21 +307,20 @@ class GraphedForward:
         with verdicts.replaying(), _uncached_autocast():
             with torch.cuda.graph(cap.fwd, stream=stream):
                 out = self.eager(*cap.static_in)
-        cap.recorded = verdicts.taken
-        cap.unused = sum(len(q) for q in verdicts.fifo.values())
         flat = _flat_tensors(out)
         if not flat or not any(t.requires_grad for t in flat):
             raise RuntimeError('the forward returned nothing differentiable')
         cap.static_out = flat
         cap.static_grad = [torch.zeros_like(t) if t.requires_grad else None for t in flat]
         cap.bwd = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(cap.bwd, pool=cap.fwd.pool(), stream=stream):
-            torch.autograd.backward([t for t in flat if t.requires_grad], [g for g in cap.static_grad if g is not None])
+        with verdicts.replaying():             # (the backward asks too: the in-degree of a table its forward built)
+            with torch.cuda.graph(cap.bwd, pool=cap.fwd.pool(), stream=stream):
+                torch.autograd.backward([t for t in flat if t.requires_grad], [g for g in cap.static_grad if g is not None])
+        cap.recorded = verdicts.taken
+        cap.unused = sum(len(q) for q in verdicts.fifo.values())
         # the captured passes did not EXECUTE: the first real execution is the replay the caller gets now
         cap.out_tree = _tree_builder(out)
-        cap.pointers, cap.frozen = self._pointers(), self._frozen_versions()
-        self.anchor = torch.zeros((), device=dev, requires_grad=True)
-        self.cap, self.key = cap, key
+        return cap
 
 
 def _uncached_autocast():
@@ -410,10 +452,15 @@ class FastAdam(torch.optim.Optimizer):
 
 
 def _wants_fast_adam(params, amsgrad, kw):
-    """Every parameter a trainable CUDA f32 tensor, one group, nothing exotic asked for."""
+    """One group, nothing exotic asked for, every TRAINABLE parameter a CUDA f32 tensor (and at least one of them).  Frozen
+    parameters may ride along — the reference hands ``model.parameters()`` over with its four frozen hyper-edge tables in it,
+    two of them int64 (/root/reference/train_ldpc.py:45-58,160-161); stock Adam never touches a parameter without a gradient and
+    neither does ``FastAdam`` (they stay in ``param_groups``, so ``state_dict()`` numbers the parameters as the stock class does)."""
     plain = bool(params) and all(torch.is_tensor(p) for p in params)
-    return (plain and not amsgrad and not kw and
-            all(p.is_cuda and p.dtype == torch.float32 and p.requires_grad for p in params))
+    if not plain or amsgrad or kw:
+        return False
+    live = [p for p in params if p.requires_grad]
+    return bool(live) and all(p.is_cuda and p.dtype == torch.float32 for p in live)
 
 
 def _adam_factory(stock):

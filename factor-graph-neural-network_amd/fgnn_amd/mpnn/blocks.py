@@ -518,6 +518,9 @@ class mp_conv_residual(base_mp_nn):
         or a callable returning either, evaluated right before it is consumed) is added by conv2's fused
         BatchNorm+activation kernel instead of a separate elementwise pass."""
         nn_idx = ops.shared_graph_view(nn_idx)
+        if etype.dtype != node_feature.dtype and torch.is_autocast_enabled('cuda') and etype.is_floating_point():
+            # (conv1 brings the state to the autocast dtype; edge weights a script built from f32 constants follow — ops.autocast_operands)
+            etype = etype.to(torch.get_autocast_dtype('cuda'))
         staged = self.training and torch.is_grad_enabled()
         if callable(addend) and not staged:
             addend = addend()                                            # the one-kernel block needs it up front

@@ -94,6 +94,7 @@ class mp_conv_v2(base_mp_nn):
         """``addend``: optional tensor of the output's shape (or a list of them) added after the activation (fused
         into the BatchNorm kernel when training with the plain ReLU).  ``population_mult``: see BatchNormAct2d.forward (set by
         callers that run the operator on ONE row per sample in place of m identical ones)."""
+        x, etype = ops.autocast_operands(x, etype)
         if not isinstance(self.aggregtor, str):
             return self._forward_custom_aggregator(x, nn_idx, etype, addend)
         ext, agg = _EXT_CODE[self.extension], _hip.AGG_CODES[self.aggregtor]

@@ -762,6 +762,19 @@ def _unexpanded(etype):
     return etype[:1]
 
 
+def autocast_operands(x, etype):
+    """Inside an autocast region the operator behaves like torch's matmul-class ops: floating-point operands of DIFFERENT precisions
+    (bf16 activations from the layers in front, f32 edge weights a script built from its own frozen f32 tensors —
+    /root/reference/train_ldpc.py:83-84 `self.hetype_f2v.repeat(bsize, 1, 1, 1)`) are brought to the autocast dtype.  Outside a
+    region nothing is cast (mismatched operands raise, as torch's own ops do)."""
+    if (x.dtype != etype.dtype and x.is_cuda and x.is_floating_point() and etype.is_floating_point()
+            and torch.is_autocast_enabled('cuda')):
+        dt = torch.get_autocast_dtype('cuda')
+        x = x if x.dtype == dt else x.to(dt)
+        etype = etype if etype.dtype == dt else etype.to(dt)
+    return x, etype
+
+
 def mpconv(x, nn_idx, etype, filters, bias, nou, net, ext, agg, bn=None):
     """Differentiable pre-BatchNorm operator output z [B, nou, M, 1].  ``bn``: see mpconv_forward_raw."""
     if ext != _hip.EXT_NONE:                             # a [1, net, M, k] etype (shared edge weights, not expanded) is taken as is

@@ -1365,7 +1365,7 @@ def test_fast_path_replays_hipgraphs_for_an_unchanged_training_loop(dev):
                 sloss = torch.nn.functional.mse_loss(sb.view(-1), torch.pow(10.0, d[7].float() / 20).view(-1))
                 (loss + 0.1 * sloss).backward()
                 opt.step()
-                losses.append(float(loss))
+                losses.append(float(loss.detach()))
                 assert pred.dtype == torch.float32 and ((pred > 0).long() == d[6]).sum() >= 0
             params = torch.cat([q.detach().reshape(-1).float() for q in m.parameters()])
             bufs = torch.cat([b.detach().reshape(-1).float() for b in m.buffers()])
@@ -1379,7 +1379,7 @@ def test_fast_path_replays_hipgraphs_for_an_unchanged_training_loop(dev):
     m1, opt1, l1, p1, b1 = loop(3)
     gf = m1.__dict__.get('forward')
     assert isinstance(gf, fastpath.GraphedForward) and not gf.failed and gf.cap is not None
-    assert gf.replays == steps - 3, gf.replays
+    assert gf.replays == steps - 4, gf.replays          # call 1: the global hook optimises the module; 2-4: eager sightings; 5..: replays (the capturing call included)
     assert gf.cap.recorded >= 4 and gf.cap.unused == 0, (gf.cap.recorded, gf.cap.unused)     # the in-forward tables were classified under capture
     print('losses eager', l0, 'graphed', l1)
     assert l0 == l1                                               # bit-identical: the same kernels in the same order
