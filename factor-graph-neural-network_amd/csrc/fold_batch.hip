@@ -21,7 +21,7 @@ struct FgnnFoldJob {
     float* gW;
     float* gb;
     int64_t slab_len, nw;
-    int nslab, kind;        // kind 0: gW[(i / a) * b + i % a] (a = ncols, b = ld); kind 1: the node-wise maps' register-order slabs
+    int nslab, kind;        // kind 0: gW[(i / a) * b + i % a] (a = ncols, b = ld); kind 1 / 2: the node-wise maps' register-order slabs (2: the LDS-staged kernel's natural tile order)
                             // (kind 1: nw = the elements to fold, slab_len = the distance between slabs — a merged launch's slabs
                             // hold several maps' slices, linear_wgrad_b16.hip::wb_launch; kind 0: slab_len is both)
     int a, b, c, d;         // kind 1: a = S, b = nso, c = Cin, d = Cout
@@ -81,7 +81,7 @@ __global__ __launch_bounds__(1024) void fold_batch_kernel(const FbBatch t) {
     const FgnnFoldJob& q = t.job[j];
     const int l = threadIdx.x & (FB_LANES - 1), g = threadIdx.x / FB_LANES;
     const int64_t i0 = (int64_t)((int)blockIdx.x - t.first[j]) * FB_PER_WG + 4 * l;      // slab_len % 4 == 0 for every producer
-    const bool in = i0 < (q.kind == 1 ? q.nw : q.slab_len);
+    const bool in = i0 < (q.kind != 0 ? q.nw : q.slab_len);
     f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
     if (in) {
         const float* base = q.ws + i0;
@@ -115,10 +115,12 @@ __global__ __launch_bounds__(1024) void fold_batch_kernel(const FbBatch t) {
             const int li = e & 15, lk = e >> 4;
             if (r4 < 64) {
                 const int r = r4 & 3, b = (r4 >> 2) & 3, a = r4 >> 4;
-                const int o = so * 64 + 4 * (4 * lk + r) + a, c = sc * 64 + 4 * li + b;
+                const bool nat = q.kind == 2;
+                const int o = nat ? so * 64 + 16 * a + 4 * lk + r : so * 64 + 4 * (4 * lk + r) + a;
+                const int c = nat ? sc * 64 + 16 * b + li : sc * 64 + 4 * li + b;
                 q.gW[(int64_t)o * Cin + c] += s[e4];
             } else if (q.gb && sc == 0 && lk == 0) {
-                q.gb[so * 64 + 4 * li + (r4 - 64)] += s[e4];
+                q.gb[q.kind == 2 ? so * 64 + 16 * (r4 - 64) + li : so * 64 + 4 * li + (r4 - 64)] += s[e4];
             }
         }
     }
@@ -160,7 +162,7 @@ extern "C" int fgnn_fold_flush(fgnn_stream_t stream) {
             if (clash) { skipped.push_back(n); continue; }
             t.first[t.njobs] = blocks;
             t.job[t.njobs++] = jobs[n];
-            blocks += (int)(((jobs[n].kind == 1 ? jobs[n].nw : jobs[n].slab_len) + FB_PER_WG - 1) / FB_PER_WG);
+            blocks += (int)(((jobs[n].kind != 0 ? jobs[n].nw : jobs[n].slab_len) + FB_PER_WG - 1) / FB_PER_WG);
             done[n] = 1;
             --left;
         }

@@ -169,10 +169,227 @@ __global__ __launch_bounds__(WB_THREADS) void linear_wgrad_b16_kernel(const WgbP
     }
 }
 
+// ----------------------------------------------------------------------------------------
+// WIDE maps (8 or 16 slices per workgroup: 128 x 256, 256 x 256, the merged launches over a 256-channel state) — round 6.
+// With S slices the register-direct kernel above has 16 / S row-waves, i.e. ONE or TWO 32-row blocks in flight per CU, and every
+// wave fetches its own copy of the operands (128 KB of requests for 32 KB of rows): the 256 x 256 map ran at 2.2 TB/s, latency-bound
+// (profiles/r05/wbench.log; 64 x 256, four row-waves, ran at 5.0).  Here the workgroup's 16 waves copy each block of rows ONCE,
+// global -> LDS by LDS-DMA (global_load_lds_dwordx4: no registers, the 1 KB a wave instruction moves lands lane-linear at M0), three
+// or four stages deep, and every wave cuts its MFMA fragments out of the row-major image with ds_read_b64_tr_b16 (the 16 lanes of a
+// group name a [4 rows][16 channels] block and receive one channel's four rows: two reads = the eight k-values of a lane).
+// Bank conflicts: a 32-lane pass of a transpose read touches rows {r..r+3, r+8..r+11} of one 32-byte channel segment; the image
+// keeps segment g of row r at position g ^ f(r), f(r) = (r & 3) + 4 (r >> 3 & 1) (128-byte rows: (r >> 1 & 1) + 2 (r >> 3 & 1), the
+// row index itself supplying bank bit 2) — eight different 32-byte bank groups.  The swizzle is applied to the DMA's per-lane SOURCE
+// addresses; the LDS side stays a linear copy.  One barrier per stage.  A last partial stage goes through guarded loads + ds_write
+// (zero rows).  Slabs in NATURAL tile order (fold kind 2): o = 64 so + 16 a + 4 lk + r, c = 64 sc + 16 b + li.
+// ----------------------------------------------------------------------------------------
+struct WglParams {
+    WgbParams b;
+    int rows_stage, nst, stage_bytes;         // rows per stage (32 RW), stages, bytes per stage
+    int nsrc;
+    int off[WB_MAXSRC + 1];                   // byte offset of the x image (0) and of every gy image inside a stage
+};
+
+// uniform 64-bit base (SGPR pair) + per-lane 32-bit byte offset: no 64-bit VGPR address arithmetic in the loop
+__device__ __forceinline__ void wl_dma16(const void* sbase, unsigned voff, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ uint2 wl_tr(unsigned lds_addr) {
+    typedef short wl_s16x4 __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) wl_s16x4 lds_v4;
+    const wl_s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(reinterpret_cast<lds_v4*>(static_cast<uintptr_t>(lds_addr)));
+    return __builtin_bit_cast(uint2, v);
+}
+template <int N> __device__ __forceinline__ void wl_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void wl_wait_vm_n(int n) {          // n = (stages still in flight: 0..2) x (this wave's DMA instructions per stage: 1..3)
+    if (n >= 6) wl_wait_vm<6>();
+    else if (n >= 4) wl_wait_vm<4>();
+    else if (n == 3) wl_wait_vm<3>();
+    else if (n == 2) wl_wait_vm<2>();
+    else if (n == 1) wl_wait_vm<1>();
+    else wl_wait_vm<0>();
+}
+// swizzle of the 32-byte segments of a row whose pitch is `segs` segments (4, 8 or 16)
+__device__ __forceinline__ int wl_f(int row, int segs) {
+    return segs == 4 ? (((row >> 1) & 1) | (((row >> 3) & 1) << 1)) : ((row & 3) | (((row >> 3) & 1) << 2));
+}
+
+__global__ __launch_bounds__(WB_THREADS) void linear_wgrad_lds_kernel(const WglParams q) {
+    const WgbParams& p = q.b;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lk = lane >> 4;
+    const int slice = wave % p.S, rw = wave / p.S;
+    const int src = slice >= p.sb[2] ? 2 : (slice >= p.sb[1] ? 1 : 0);
+    const bool live = slice < p.sb[WB_MAXSRC];
+    const int Cout = src == 2 ? p.couts[2] : (src == 1 ? p.couts[1] : p.couts[0]);
+    const int nso = Cout >> 6, sl = slice - (src == 2 ? p.sb[2] : (src == 1 ? p.sb[1] : p.sb[0]));
+    const int so = sl % nso, sc = sl / nso;
+    const int R = p.R, Cin = p.Cin;
+    const unsigned lds0 = (unsigned)(uintptr_t)wb_lds;
+    const int ni = q.stage_bytes >> 10;                        // 1 KB DMA instructions per stage: wave w issues w, w + 16, w + 32 (< ni)
+    const int ndma = (ni - wave + 15) >> 4;                    // this wave's count (1..3; a stage need not be a multiple of 16 KB)
+
+    // ---- this wave's share of a stage's copy: instructions wave, wave + 16, ... (1 KB each, inside ONE image) ----
+    // (everything but the lane's byte offset is wave-uniform and lives in scalar registers; the offset is recomputed per
+    //  instruction — a dozen VALU operations against 16 MFMAs per stage — instead of held: the kernel sits at the 128-VGPR limit, and
+    //  ONE spilled register is fatal here: its scratch reload is a vector-memory load, in order behind the DMA just issued, so the
+    //  wait for it is a wait for the whole prefetch — 125 us instead of 9x us for the 256 x 256 map with 10 spilled registers)
+    const char* gbase[3];
+    unsigned gpitch[3], ldst[3], gpc0[3], gshift[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        gbase[j] = nullptr; gpitch[j] = 0; ldst[j] = 0; gpc0[j] = 0; gshift[j] = 0;
+        if (j < ndma) {
+            const int byte0 = (wave + 16 * j) * 1024;
+            // (selects, not indexed reads: a dynamically indexed by-value argument struct is copied to scratch)
+            const int img = (q.nsrc >= 3 && byte0 >= q.off[3]) ? 3 : ((q.nsrc >= 2 && byte0 >= q.off[2]) ? 2 : (byte0 >= q.off[1] ? 1 : 0));
+            const int ch = img == 0 ? Cin : (img == 1 ? p.couts[0] : (img == 2 ? p.couts[1] : p.couts[2]));
+            const int ioff = img == 0 ? 0 : (img == 1 ? q.off[1] : (img == 2 ? q.off[2] : q.off[3]));
+            const int pitch = __builtin_amdgcn_readfirstlane(2 * ch);          // bytes per row: 128 / 256 / 512
+            gbase[j] = (const char*)(img == 0 ? (const void*)p.x : (img == 1 ? (const void*)p.gys[0] : (img == 2 ? (const void*)p.gys[1] : (const void*)p.gys[2])));
+            gpitch[j] = (unsigned)pitch;
+            gshift[j] = pitch == 512 ? 5u : (pitch == 256 ? 4u : 3u);          // log2 of the 16-byte chunks per row
+            gpc0[j] = (unsigned)((byte0 - ioff) >> 4);                          // first chunk of the instruction inside its image
+            ldst[j] = (unsigned)byte0;
+        }
+    }
+    auto lane_off = [&](int j) -> unsigned {           // byte offset of this lane's 16 bytes from the stage's first row of the image
+        const unsigned pc = gpc0[j] + (unsigned)lane;
+        const unsigned row = pc >> gshift[j], c = pc & ((1u << gshift[j]) - 1u);
+        const unsigned col = (((c >> 1) ^ (unsigned)wl_f((int)row, (int)(gpitch[j] >> 5))) << 5) | ((c & 1u) << 4);
+        return row * gpitch[j] + col;
+    };
+    // ---- fragment addresses inside a stage: tile t of the slice's 64 gy / x channels, rows 32 rw + 8 lk + (li >> 2) (+ 4) ----
+    const int kr = 32 * rw + 8 * lk + (li >> 2);
+    const int pg = 2 * Cout, px = 2 * Cin;
+    unsigned aA[4], aB[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        aA[t] = (unsigned)((src == 2 ? q.off[3] : (src == 1 ? q.off[2] : q.off[1])) + kr * pg + (((so * 4 + t) ^ wl_f(kr, pg >> 5)) << 5) + 8 * (li & 3));
+        aB[t] = (unsigned)(kr * px + (((sc * 4 + t) ^ wl_f(kr, px >> 5)) << 5) + 8 * (li & 3));
+    }
+
+    f32x4 acc[4][4];
+    float bs[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    auto issue = [&](int blk, int stage) {
+        const unsigned base = lds0 + (unsigned)(stage * q.stage_bytes);
+        const int64_t row0 = (int64_t)blk * q.rows_stage;
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            if (j < ndma) {
+                const uint64_t sb = (uint64_t)(uintptr_t)gbase[j] + (uint64_t)row0 * gpitch[j];
+                wl_dma16((const void*)(uintptr_t)sb, lane_off(j), __builtin_amdgcn_readfirstlane(base + ldst[j]));
+            }
+    };
+    auto compute = [&](int stage) {
+        const unsigned base = lds0 + (unsigned)(stage * q.stage_bytes);
+        uint4 A[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const uint2 a0 = wl_tr(base + aA[t]), a1 = wl_tr(base + aA[t] + 4u * (unsigned)pg);
+            A[t] = make_uint4(a0.x, a0.y, a1.x, a1.y);
+        }
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {              // (one x fragment at a time: 16 + 4 operand registers beside the 64 accumulators)
+            const uint2 b0 = wl_tr(base + aB[b]), b1 = wl_tr(base + aB[b] + 4u * (unsigned)px);
+            const uint4 Bf = make_uint4(b0.x, b0.y, b1.x, b1.y);
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+                acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(wb_bf16x8, A[a]),
+                                                                    __builtin_bit_cast(wb_bf16x8, Bf), acc[a][b], 0, 0, 0);
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a) bs[a] = wb_sum8(A[a], bs[a]);
+    };
+
+    const int nfull = R / q.rows_stage, tail = R - nfull * q.rows_stage;
+    const int G = gridDim.x, me = blockIdx.x;
+    const int nb = me < nfull ? (nfull - me + G - 1) / G : 0;              // full stages of this workgroup: me, me + G, ...
+    const int depth = q.nst - 1;
+    for (int t = 0; t < depth && t < nb; ++t) issue(me + t * G, t);
+#pragma nounroll
+    for (int k = 0; k < nb; ++k) {
+        const int ahead = min(depth - 1, nb - 1 - k);                        // later stages already on their way
+        wl_wait_vm_n(ahead * ndma);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // everybody's share of stage k landed; stage k - 1 is free
+        if (k + depth < nb) issue(me + (k + depth) * G, (k + depth) % q.nst);
+        if (live) compute(k % q.nst);
+    }
+    if (tail > 0 && me == nfull % G) {                                      // the last, partial stage: guarded loads, zero rows
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        const int64_t row0 = (int64_t)nfull * q.rows_stage;
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            if (j < ndma) {
+                const unsigned lo = lane_off(j);
+                const int row = (int)(lo / gpitch[j]);
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (row < tail) v = *reinterpret_cast<const uint4*>(gbase[j] + row0 * gpitch[j] + lo);
+                *reinterpret_cast<uint4*>(reinterpret_cast<char*>(wb_lds) + ldst[j] + 16 * lane) = v;
+            }
+        __syncthreads();
+        if (live) compute(0);
+    }
+    __syncthreads();                                                         // the stages are dead: the fold may use their memory
+
+    // ---- binary-tree fold of the RW row-waves of each slice (fixed order), as in linear_wgrad_b16_kernel ----
+    for (int half = p.RW >> 1; half >= 1; half >>= 1) {
+        float* slot = wb_lds + ((int64_t)(slice * (p.RW >> 1) + (rw - half)) * WB_NACC) * 64 + lane;
+        if (rw >= half && rw < 2 * half) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) slot[((a * 4 + b) * 4 + r) * 64] = acc[a][b][r];
+                slot[(64 + a) * 64] = bs[a];
+            }
+        }
+        __syncthreads();
+        if (rw < half) {
+            const float* srcp = wb_lds + ((int64_t)(slice * (p.RW >> 1) + rw) * WB_NACC) * 64 + lane;
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[a][b][r] += srcp[((a * 4 + b) * 4 + r) * 64];
+                bs[a] += srcp[(64 + a) * 64];
+            }
+        }
+        __syncthreads();
+    }
+    if (rw == 0 && live) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            bs[a] += __shfl_xor(bs[a], 16);
+            bs[a] += __shfl_xor(bs[a], 32);
+        }
+        float* slab = p.ws + (((int64_t)blockIdx.x * p.S + slice) * WB_NACC) * 64 + lane;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) slab[((a * 4 + b) * 4 + r) * 64] = acc[a][b][r];
+            slab[(64 + a) * 64] = bs[a];
+        }
+    }
+}
+
 // gW[o][c] += sum over slabs;  gb[o] += sum over slabs.  One 1024-thread workgroup per 64 consecutive slab elements (one
 // accumulator register of one slice, lanes 0..63: a 256-byte line per slab): wave w folds slabs w, w+16, ... — at most 16
 // independent line loads, all in flight at once — and wave 0 folds the 16 partial sums in order.  Fixed order: deterministic.
 // (The first form gave each 256-thread block 16 elements: 64-byte pieces, 24 us per call for 4 MB of slabs.)
+template <bool NATURAL>      // NATURAL: the LDS-staged kernel's tile order (consecutive channels per tile), else the register-direct kernel's (stride 4)
 __global__ __launch_bounds__(1024) void wgb_reduce_kernel(const float* __restrict__ ws, int nslab, int64_t slab_len, int nso,
                                                           int Cin, int Cout, float* __restrict__ gW,
                                                           float* __restrict__ gb) {
@@ -202,10 +419,11 @@ __global__ __launch_bounds__(1024) void wgb_reduce_kernel(const float* __restric
     const int li = l & 15, lk = l >> 4;
     if (q < 64) {
         const int r = q & 3, b = (q >> 2) & 3, a = q >> 4;            // D row = 4*lk + r (tile a), D col = li (tile b)
-        const int o = so * 64 + 4 * (4 * lk + r) + a, c = sc * 64 + 4 * li + b;
+        const int o = NATURAL ? so * 64 + 16 * a + 4 * lk + r : so * 64 + 4 * (4 * lk + r) + a;
+        const int c = NATURAL ? sc * 64 + 16 * b + li : sc * 64 + 4 * li + b;
         gW[(int64_t)o * Cin + c] += s;
     } else if (gb && sc == 0 && lk == 0) {
-        gb[so * 64 + 4 * li + (q - 64)] += s;          // the main kernel already folded the 4 row-group lanes
+        gb[NATURAL ? so * 64 + 16 * (q - 64) + li : so * 64 + 4 * li + (q - 64)] += s;          // the main kernel already folded the 4 row-group lanes
     }
 }
 
@@ -417,22 +635,55 @@ static int wb_launch(const void* x, int64_t R, int Cin, int nsrc, const void* co
     }
     p.sb[WB_MAXSRC] = sb[WB_MAXSRC];
     const int lds = S * (RW / 2) * WB_NACC * 64 * 4;                   // 0 when every slice has one row-wave
-    void* fn = (void*)linear_wgrad_b16_kernel;
-    if (lds > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+    // wide maps (8 / 16 slices): rows staged ONCE per workgroup through LDS (linear_wgrad_lds_kernel)
+    WglParams q = {};
+    bool staged = false;
+    static const bool no_lds = getenv("FGNN_WG_NOLDS") != nullptr;      // A/B switch: the register-direct kernel for every shape
+    if (S >= 8 && !no_lds && R >= 2048) {
+        int ctot = Cin;
+        for (int s = 0; s < nsrc; ++s) ctot += couts[s];
+        q.b = p; q.nsrc = nsrc;
+        q.rows_stage = 32 * RW;
+        q.stage_bytes = q.rows_stage * ctot * 2;
+        q.nst = q.stage_bytes <= 32 * 1024 ? 4 : 3;
+        q.off[0] = 0;
+        q.off[1] = q.rows_stage * Cin * 2;
+        for (int s = 1; s <= WB_MAXSRC; ++s) if (s < WB_MAXSRC) q.off[s + 1] = q.off[s] + (s - 1 < nsrc ? q.rows_stage * couts[s - 1] * 2 : 0);
+        const bool aligned = ((uintptr_t)x & 15) == 0 && ((uintptr_t)gys[0] & 15) == 0 && (nsrc < 2 || ((uintptr_t)gys[1] & 15) == 0) &&
+                             (nsrc < 3 || ((uintptr_t)gys[2] & 15) == 0);
+        staged = aligned && q.stage_bytes % 1024 == 0 && q.stage_bytes >= 1024 * WB_WAVES && q.stage_bytes <= 3 * 1024 * WB_WAVES &&
+                 q.nst * q.stage_bytes <= 150 * 1024 && q.nst * q.stage_bytes >= lds;
     }
-    void* args[] = {(void*)&p};
-    hipError_t e = hipLaunchKernel(fn, dim3(gx), dim3(WB_THREADS), args, lds, st);
+    hipError_t e;
+    if (staged) {
+        void* fn = (void*)linear_wgrad_lds_kernel;
+        const int bytes = q.nst * q.stage_bytes;
+        e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+        void* args[] = {(void*)&q};
+        e = hipLaunchKernel(fn, dim3(gx), dim3(WB_THREADS), args, bytes, st);
+    } else {
+        void* fn = (void*)linear_wgrad_b16_kernel;
+        if (lds > 48 * 1024) {
+            e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+        }
+        void* args[] = {(void*)&p};
+        e = hipLaunchKernel(fn, dim3(gx), dim3(WB_THREADS), args, lds, st);
+    }
     if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "linear_wgrad_b16 launch: %s", hipGetErrorString(e));
     const int64_t stride = (int64_t)S * WB_NACC * 64;                  // distance between the workgroups' slabs
     for (int s = 0; s < nsrc; ++s) {
         const int Ss = sb[s + 1] - sb[s], nso = couts[s] / 64;
         const int64_t len = (int64_t)Ss * WB_NACC * 64;
         const float* ws_s = p.ws + (int64_t)sb[s] * WB_NACC * 64;
-        if (fgnn_fold_push(ws_s, gx, stride, len, gWs[s], gbs ? gbs[s] : nullptr, 1, Ss, nso, Cin, couts[s])) continue;      // recorded (fold_batch.hip)
-        hipLaunchKernelGGL(wgb_reduce_kernel, dim3((unsigned)(len / 64)), dim3(1024), 0, st, ws_s, gx, stride, nso, Cin, couts[s], gWs[s],
-                           gbs ? gbs[s] : nullptr);
+        if (fgnn_fold_push(ws_s, gx, stride, len, gWs[s], gbs ? gbs[s] : nullptr, staged ? 2 : 1, Ss, nso, Cin, couts[s])) continue;      // recorded (fold_batch.hip)
+        if (staged)
+            hipLaunchKernelGGL(wgb_reduce_kernel<true>, dim3((unsigned)(len / 64)), dim3(1024), 0, st, ws_s, gx, stride, nso, Cin, couts[s], gWs[s],
+                               gbs ? gbs[s] : nullptr);
+        else
+            hipLaunchKernelGGL(wgb_reduce_kernel<false>, dim3((unsigned)(len / 64)), dim3(1024), 0, st, ws_s, gx, stride, nso, Cin, couts[s], gWs[s],
+                               gbs ? gbs[s] : nullptr);
     }
     e = hipGetLastError();
     if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "linear_wgrad_b16 reduce launch: %s", hipGetErrorString(e));

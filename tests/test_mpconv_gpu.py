@@ -705,7 +705,13 @@ def test_f32_blocked_weight_gradient_vs_torch(R, cin, cout, dev):
 
 @pytest.mark.parametrize('R,cin,couts', [(6144, 64, (64, 64, 64)), (6149, 64, (64, 128, 64)), (12288, 128, (64, 256, 64)), (6144, 256, (64, 64)),
                                           (6144, 256, (64, 128, 64)), (3000, 128, (64, 64, 64)), (393216, 64, (64, 64)), (40, 64, (64, 64, 64)),
-                                          (6144, 64, (256,))])
+                                          (6144, 64, (256,)),
+                                          # the LDS-staged kernel (8 / 16 slices): partial last stages, fewer stages than workgroups / than the
+                                          # pipeline is deep, one wide map alone, 128- and 256-byte rows beside 512-byte ones
+                                          (6149, 256, (64, 128, 64)), (4101, 256, (64, 64)), (2048 + 37, 256, (256,)), (9000, 128, (256,)),
+                                          (8192 + 31, 256, (128,)), (12288 + 5, 128, (64, 256, 64)), (2049, 256, (128, 128)), (70000, 256, (256,)),
+                                          # stages that are not a multiple of 16 KB (waves issue different numbers of DMA instructions)
+                                          (6144 + 3, 128, (64, 256)), (5000, 256, (64, 128)), (4100, 128, (64, 64, 64))])
 @pytest.mark.parametrize('deferred', [False, True])
 def test_bf16_weight_gradients_of_several_maps_over_one_state(R, cin, couts, deferred, dev):
     """fgnn_linear_wgrad_multi (csrc/linear_wgrad_b16.hip: the weight / bias gradients of the node-wise maps that consume ONE layer
