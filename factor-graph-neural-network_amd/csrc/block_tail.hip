@@ -492,9 +492,7 @@ static int bt_plan(int64_t R, int Cout, int* grid, bool bound = true, bool apply
     const int64_t ntile = (R + 15) / 16;
     const int nrg = bound ? BT_WAVES / (Cout / 64) : BT_WAVES;       // row groups per workgroup (modes 0-2: a wave is bound to a slab)
     int64_t g = (ntile + 2 * nrg - 1) / (2 * nrg);                    // >= 2 tiles per wave
-    static const int maxg_r = getenv("FGNN_BT_GRID") ? atoi(getenv("FGNN_BT_GRID")) : 512;
-    static const int maxg_a = getenv("FGNN_BT_GRID_APPLY") ? atoi(getenv("FGNN_BT_GRID_APPLY")) : (getenv("FGNN_BT_GRID") ? atoi(getenv("FGNN_BT_GRID")) : 768);
-    const int maxg = apply ? maxg_a : maxg_r;
+    const int maxg = apply ? 768 : 512;      // one resident wave of workgroups: 3 per CU for the apply mode, 2 for the others (round 5: -0.13 ms)
     if (g > maxg) g = maxg;
     if (g > BT_MAXGRID) g = BT_MAXGRID;
     if (g < 1) g = 1;

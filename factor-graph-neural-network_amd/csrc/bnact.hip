@@ -287,13 +287,11 @@ __global__ __launch_bounds__(BN_THREADS) void bn_apply_kernel(const BnParams p) 
 }
 
 static int bn_apply_grid() {
-    static const int g = getenv("FGNN_BN_APPLY_GRID") ? atoi(getenv("FGNN_BN_APPLY_GRID")) : BN_APPLY_GRID;
-    return g;
+    return BN_APPLY_GRID;      // (swept 1024 / 2048 / 8192 in round 5: no effect, profiles/r05/README.md)
 }
 
 static int bn_reduce_grid() {
-    static const int g = getenv("FGNN_BN_GRID") ? atoi(getenv("FGNN_BN_GRID")) : BN_GRID;
-    return g > BN_MAXPART ? BN_MAXPART : g;
+    return BN_GRID > BN_MAXPART ? BN_MAXPART : BN_GRID;      // (swept 256 / 1024 in round 5: no effect)
 }
 
 static int bn_plan(int64_t R, int C, int dtype, BnParams* p, int* grid, int target = 0) {
@@ -327,10 +325,10 @@ extern "C" int64_t fgnn_bn_workspace_bytes(int64_t R, int C) { return (int64_t)B
 // MI355X (gpurun_out/r05b, LDPC step, 4096 codewords): the in-kernel fold is six serialised memory-side round trips (store
 // acknowledgement, ticket, loads — twice) = 8-10 us at the tail of EVERY producer (block_tail_stats 35.6 vs 27.9 us with its finaliser
 // launch included, mpconv_fwd_ws 54 vs 47 us, the step 15.66 vs 15.50 ms) against ~7 us for a finaliser kernel inside the replayed
-// graph: the separate launch is the default, FGNN_INKERNEL_FINALISERS=1 / fgnn_set_inkernel_finalisers(1) selects the fold.
+// graph: the separate launch is the default, fgnn_set_inkernel_finalisers(1) selects the fold (both run in the GPU suite).
 static int g_inkernel_finalisers = -1;
 int fgnn_separate_finalisers(void) {
-    if (g_inkernel_finalisers < 0) g_inkernel_finalisers = getenv("FGNN_INKERNEL_FINALISERS") ? atoi(getenv("FGNN_INKERNEL_FINALISERS")) : 0;
+    if (g_inkernel_finalisers < 0) g_inkernel_finalisers = 0;
     return !g_inkernel_finalisers;
 }
 extern "C" int fgnn_set_inkernel_finalisers(int on) {

@@ -484,8 +484,7 @@ __global__ __launch_bounds__(256) void edge_mlp_bwd_mfma_kernel(const EmParams p
 
 // the layouts the MFMA kernels stage: plane-major sample blocks, 16-byte aligned, whole 16-row tiles per sample
 static bool em_mfma_ok(const EmParams& p, bool bwd) {
-    static const bool valu = getenv("FGNN_EDGE_MLP_VALU") != nullptr;       // (A/B switch: the round 1-4 VALU kernels)
-    if (valu || p.E % 16 || p.E > EM_MAXE_ROWS || p.R >= (int64_t)0x7fffffff) return false;
+    if (p.E % 16 || p.E > EM_MAXE_ROWS || p.R >= (int64_t)0x7fffffff) return false;
     if (p.x_sr != 1 || p.x_sc != p.E || p.x_sb % 8 || ((uintptr_t)p.x & 15) || p.x_sb < (int64_t)p.Cin * p.E) return false;
     if (EM_PAIR * p.Cin * p.E / 8 > 256 * EM_MAXCHUNK) return false;
     if (bwd && (p.gy_sr != 1 || p.gy_se != p.E || p.gy_sb % 8 || ((uintptr_t)p.gy & 15) || p.gy_sb < (int64_t)p.net * p.E)) return false;

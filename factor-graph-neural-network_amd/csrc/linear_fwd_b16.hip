@@ -334,7 +334,7 @@ static int lf_plan(int64_t R, int Cin, int Cout, int* CG, int* grid) {
     const int nrg = LF_WAVES / *CG;
     const int64_t ntile = (R + 15) / 16;
     int64_t g = (ntile + 2 * nrg - 1) / (2 * nrg);         // >= 2 tiles per wave
-    static const int maxg = getenv("FGNN_LF_GRID") ? atoi(getenv("FGNN_LF_GRID")) : LF_MAXGRID;
+    const int maxg = LF_MAXGRID;
     if (g > maxg) g = maxg;
     if (g < 1) g = 1;
     *grid = (int)g;

@@ -304,7 +304,7 @@ static int wgrad_plan(int R, int Cin, int Cout, WgradParams* p, int* gx, int* gy
     p->XS = (p->Cip % 32 == 0) ? p->Cip + 16 : p->Cip;
     p->GS = (p->Cop % 32 == 0) ? p->Cop + 16 : p->Cop;
     *gy_ = (Cout + oc - 1) / oc;
-    int g = (getenv("FGNN_WG_GRID") ? atoi(getenv("FGNN_WG_GRID")) : 512) / *gy_;
+    int g = 512 / *gy_;
     if (g < 1) g = 1;
     int rows = (R + g - 1) / g;
     rows = fgnn_round_up(rows < 64 ? 64 : rows, 64);      // multiple of both kernels' row tiles

@@ -580,7 +580,7 @@ static bool wb_plan(int64_t R, int Cin, int Cout, int* nso, int* S, int* RW, int
     *S = *nso * (Cin / 64);
     if (*S > 16 || (*S & (*S - 1))) return false;
     *RW = 16 / *S;
-    static const int wgs = getenv("FGNN_WB_GRID") ? atoi(getenv("FGNN_WB_GRID")) : 256;
+    const int wgs = 256;      // one workgroup per CU (128: no effect, profiles/r05/README.md)
     const int64_t nblk = (R + 31) / 32;
     int64_t g = (nblk + 2 * *RW - 1) / (2 * *RW);                      // >= 2 blocks per row-wave
     if (g > wgs) g = wgs;
@@ -614,7 +614,7 @@ static bool wb_plan_multi(int64_t R, int Cin, int nsrc, const int32_t* couts, in
     while (sp < live) sp *= 2;
     *S = sp;
     *RW = 16 / sp;
-    static const int wgs = getenv("FGNN_WB_GRID") ? atoi(getenv("FGNN_WB_GRID")) : 256;
+    const int wgs = 256;      // one workgroup per CU (128: no effect, profiles/r05/README.md)
     const int64_t nblk = (R + 31) / 32;
     int64_t g = (nblk + 2 * *RW - 1) / (2 * *RW);                      // >= 2 blocks per row-wave
     if (g > wgs) g = wgs;
@@ -722,7 +722,6 @@ extern "C" int fgnn_linear_wgrad_multi(const void* x, int64_t R, int32_t Cin, in
 int fgnn_linear_wgrad_b16(const void* x, const void* gy, int64_t R, int Cin, int Cout, float* gW, float* gb,
                           void* workspace, int64_t workspace_bytes, fgnn_stream_t stream) {
     int nso, S, RW, gx;
-    if (getenv("FGNN_WG_OLD")) return 0;
     bool nx;
     if (wn_plan(R, Cin, Cout, &nx, &gx)) {
         if (((uintptr_t)(nx ? gy : x) & 7) || ((uintptr_t)(nx ? x : gy) & 1)) return 0;

@@ -803,7 +803,7 @@ int fgnn_check_desc(const fgnn_mpconv_desc* d);
 // Does this descriptor go to the kernel above, and with how many table entries?  (The shape rules of fgnn_mpconv_backward_ws that do
 // not depend on pointers.)
 static int bw_tables_count(const fgnn_mpconv_desc* d) {
-    static const bool off = getenv("FGNN_NO_WS") != nullptr || getenv("FGNN_NO_WS_BWD") != nullptr || getenv("FGNN_NO_BWD_TABLES") != nullptr;
+    static const bool off = getenv("FGNN_NO_WS") != nullptr;
     if (off || d->dtype != FGNN_BF16 || d->ext != FGNN_EXT_NONE || d->net != 4 || d->agg != FGNN_AGG_MAX) return 0;
     if (d->nin != 64 || (d->nou != 64 && d->nou != 128) || (d->k != 3 && d->k != 6)) return 0;
     if (d->idx_sb != 0 && d->B > 1) return 0;
@@ -843,7 +843,7 @@ int fgnn_mpconv_backward_ws(const fgnn_mpconv_desc* d, const void* x, const int6
                             const float* filters, const void* gz, const uint8_t* argmax, void* gx, void* getype,
                             float* gfilters, float* gbias, void* workspace, int64_t workspace_bytes,
                             fgnn_stream_t stream) {
-    static const bool off = getenv("FGNN_NO_WS") != nullptr || getenv("FGNN_NO_WS_BWD") != nullptr;
+    static const bool off = getenv("FGNN_NO_WS") != nullptr;       // (tests: the second-generation kernels on the same shapes)
     if (off) BW_REJECT(0);
     const bool split = d->nin == 64 && d->nou == 128;                    // 64 -> 128: two launches over the halves of the output channels
     // 128 -> 64 (round 5): two launches over the halves of the INPUT channels.  Everything the kernel computes is linear in the
@@ -851,8 +851,7 @@ int fgnn_mpconv_backward_ws(const fgnn_mpconv_desc* d, const void* x, const int6
     // getype); dP depends on G and etype only; dx and dW are per input channel — so the 64-channel kernel runs twice on x / W / gx /
     // gfilters offset by 64 channels / rows (x and gx rows stay 128 apart in memory: x_ld), dbias counted once.  Replaces the
     // first-generation mpconv_bwd_b16_kernel<4,2> for these calls (245 us at 4096 codewords, profiles/r04).
-    static const bool no_ksplit = getenv("FGNN_NO_WS_KSPLIT") != nullptr;
-    const bool ksplit = d->nin == 128 && d->nou == 64 && !no_ksplit;
+    const bool ksplit = d->nin == 128 && d->nou == 64;
     if (ksplit) {      // (the layout rules fgnn_mpconv_backward_sg checks for its callers)
         if (d->dtype != FGNN_BF16 || d->ext != FGNN_EXT_NONE || d->agg != FGNN_AGG_MAX || d->net != 4 || (d->k != 3 && d->k != 6)) BW_REJECT(10);
         if ((d->idx_sb != 0 && d->B > 1) || !(d->idx_sk == 1 && d->idx_sm == d->k) || !getype || !argmax || !gbias) BW_REJECT(11);
@@ -881,14 +880,12 @@ int fgnn_mpconv_backward_ws(const fgnn_mpconv_desc* d, const void* x, const int6
     p.tables = (bw_pending_tables && bw_tables_count(d) > 0) ? (const int*)bw_pending_tables : nullptr;
     const int off_b = KC == 6 ? BwLayout<6>::BYTES : BwLayout<3>::BYTES;
     static_assert(BwLayout<6>::BYTES <= 160 * 1024 && BwLayout<3>::BYTES <= 160 * 1024, "LDS");
-    static const bool no_nl = getenv("FGNN_BWD_WS_NL64") != nullptr;     // (A/B switch: the degree-3 instance over all 64 node rows, as before)
-    const bool nl48 = KC == 3 && d->N <= 48 && !no_nl;                   // the LDPC F -> V call: 48 factor nodes
+    const bool nl48 = KC == 3 && d->N <= 48;                   // the LDPC F -> V call: 48 factor nodes
     void* fn = ksplit ? (KC == 6 ? (void*)mpconv_bwd_ws_kernel<6, 3, 128> : nl48 ? (void*)mpconv_bwd_ws_kernel<3, 6, 128, 48> : (void*)mpconv_bwd_ws_kernel<3, 6, 128>)
                       : (KC == 6 ? (void*)mpconv_bwd_ws_kernel<6, 3> : nl48 ? (void*)mpconv_bwd_ws_kernel<3, 6, 64, 48> : (void*)mpconv_bwd_ws_kernel<3, 6>);
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, off_b);
     if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "hipFuncSetAttribute(%d B LDS): %s", off_b, hipGetErrorString(e));
-    static const int max_grid = getenv("FGNN_WS_GRID") ? atoi(getenv("FGNN_WS_GRID")) : 256;      // (tuning knob: CUs left to the other stream's kernels)
-    int grid = max_grid >= 1 && max_grid <= 256 ? max_grid : 256;
+    int grid = 256;      // one workgroup per CU (caps of 248 / 240 / 224 to leave CUs to the other stream: no effect, profiles/r05/README.md)
     if (grid > d->B) grid = d->B;
     const int chunk = (d->B + grid - 1) / grid;
     grid = (d->B + chunk - 1) / chunk;

@@ -562,8 +562,7 @@ int fgnn_mpconv_forward_ws(const fgnn_mpconv_desc* d, const void* x, const int64
     // (nin = 128: 64 resident A registers per producer; what spills under 128 VGPRs is the fragment-loading prologue only — none in the sample loops)
     else if (d->nin == 128) fn = KC == 6 ? ws_pick_mode<128, 6, 2>(mode) : ws_pick_mode<128, 3, 2>(mode);
     if (!fn) return 0;
-    static const int max_grid = getenv("FGNN_WS_GRID") ? atoi(getenv("FGNN_WS_GRID")) : 256;      // (tuning knob: CUs left to the other stream's kernels)
-    int grid = max_grid >= 1 && max_grid <= 256 ? max_grid : 256;
+    int grid = 256;      // one workgroup per CU
     if (grid > d->B) grid = d->B;
     if (plan_grid) { *plan_grid = grid; return 1; }
     WsParams p = {};

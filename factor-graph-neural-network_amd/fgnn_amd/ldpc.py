@@ -6,7 +6,6 @@ dims [64,64,64,128,256,256,128,64,64], 4 edge types on the 288 parity edges plus
 "hyper-factor" touching every variable, two edge-type MLPs and an SNR regressor head.
 32 message-operator calls per forward = 6144 VF+FV messages per codeword.
 """
-import os
 
 import numpy as np
 import torch
@@ -17,7 +16,7 @@ from .edge_mlp import EdgeMLP
 from .tables import LdpcGraph
 
 MESSAGES_PER_CODEWORD = 8 * (288 + 288 + 96 + 96)
-_FAST_REGRESSOR = os.environ.get('FGNN_NO_FAST_REGRESSOR', '') in ('', '0')      # tuning knob: the regressor head through torch's modules
+_FAST_REGRESSOR = True      # (module switch: the regressor head through torch's modules when False)
 
 
 def _edge_mlp(cin, hidden, cout):

@@ -8,7 +8,6 @@ so the reference's train_*.py scripts construct and call them unchanged; every V
 message inside runs through the fused HIP operator.
 """
 import contextlib
-import os
 
 import torch
 
@@ -153,21 +152,12 @@ class factor_mpnn(torch.nn.Module):
         return nfeat, ffeat
 
 
-def _parse_layers(text):
-    try:
-        return set(int(v) for v in text.split(',') if v.strip())
-    except ValueError:
-        import warnings
-        warnings.warn('FGNN_V2V_MAIN=%r is not a comma-separated list of layer numbers: ignored' % text)
-        return set()
+_V2V_MAIN = set()      # layers whose v2v map stays on the main stream.  Measured (round 4, 18.25 ms with none): layers 0,1,7: 18.27; 2-6:
+# 18.47; 3-5: 18.54; all: 18.48 — the map belongs on the side stream.
 
 
-_V2V_MAIN = _parse_layers(os.environ.get('FGNN_V2V_MAIN', ''))      # tuning knob: layers whose v2v map stays on the main
-# stream.  Measured on one box (18.25 ms with none): layers 0,1,7: 18.27; 2-6: 18.47; 3-5: 18.54; all: 18.48 — the map belongs on the side stream.
-
-
-_F2F_SIDE = os.environ.get('FGNN_F2F_SIDE', '1') not in ('', '0')      # tuning knob: the parity factors' f2f map on the side stream
-_FAC_MERGE_SIDE = int(os.environ.get('FGNN_FAC_MERGE_SIDE', '1') or 0)      # tuning knob: 1 = the factor states' gradient merge on the side stream (2: the variables' instead)
+_F2F_SIDE = True       # the parity factors' f2f map on the side stream (round 5: -0.1 ms)
+_FAC_MERGE_SIDE = 1    # 1 = the factor states' gradient merge on the side stream (2: the variables' instead; round 5: -0.13 ms with 1)
 
 
 class FactorNN(torch.nn.Module):

@@ -5,7 +5,6 @@ Mirrors (names, constructor signatures, state_dict keys) of
   iid_mapping / _bn / _in            /root/reference/lib/model/mpnn/base_model.py:43-90
   max_pool_layer, flatten            /root/reference/lib/model/mpnn/base_model.py:19-40
 """
-import os
 
 import torch
 
@@ -107,8 +106,8 @@ class iid_mapping_in(torch.nn.Module):
         return _InstNormAct.apply(zz.view(B, N, 1, cout).permute(0, 3, 1, 2), norm.relu, y)
 
 
-_IID_FUSE_MAX_CIN = int(os.environ.get('FGNN_IID_FUSE_MAX_CIN', '128'))
-FUSE_IID_IN = os.environ.get('FGNN_STAGED_IID_IN') is None      # iid_mapping_in: map + InstanceNorm + ReLU as one kernel where the shape allows
+_IID_FUSE_MAX_CIN = 128
+FUSE_IID_IN = True      # iid_mapping_in: map + InstanceNorm + ReLU as one kernel where the shape allows
 
 
 class max_pool_layer(torch.nn.Module):
@@ -132,14 +131,14 @@ def _is_identity_list(nn_idx):
 FUSE_TRAIN_TAIL = True       # training: BatchNorm2 + ReLU -> conv2 -> BatchNorm3 + LeakyReLU (+ addends) without storing conv2's output
 
 
-FUSE_TRAIN_HEAD = os.environ.get('FGNN_STAGED_HEAD') is None    # training: BatchNorm1's input gradient and conv1's input gradient in one pass
+FUSE_TRAIN_HEAD = True    # training: BatchNorm1's input gradient and conv1's input gradient in one pass
 
 
 # Input widths the fused head backward takes.  Measured alone (R = 393 216 rows): 73 vs 76 us staged at 64 channels in, 90 vs 88 at
 # 128, 127 vs 119 at 256 (R = 196 608: 40 / 46 / 65 vs 45 / 50 / 67) — the tensor it avoids re-reading (gz1, 25-50 MB) is read back
 # from the 256 MB infinity cache in the staged path, so the fusion only saves the launch and a cached pass; in the step 64 and 128
 # are worth ~0.05 ms together, 256 nothing.
-_HEAD_WIDTHS = tuple(int(v) for v in os.environ.get('FGNN_HEAD_WIDTHS', '64,128').split(',') if v)
+_HEAD_WIDTHS = (64, 128)
 
 
 class _BlockHead(torch.autograd.Function):
@@ -231,7 +230,7 @@ class _BlockHead(torch.autograd.Function):
                 None, None, None, None, None, None, None)
 
 
-LATE_JOIN = os.environ.get('FGNN_EARLY_JOIN') is None     # the tail asks for addends of another stream behind its statistics pass
+LATE_JOIN = True     # the tail asks for addends of another stream behind its statistics pass
 ROUTE_ADDEND_GRADS = True    # the addends' gradient leaves through its own autograd node, ahead of the tail's backward kernels
 
 
@@ -278,7 +277,7 @@ class _AddendRoute(torch.autograd.Function):
         return (g, None, None) + tuple(outs)
 
 
-NODE_SUM_HOME = os.environ.get('FGNN_NODE_SUM_HOME', '1') not in ('', '0')      # tuning knob (round 5): see _AddendRoute
+NODE_SUM_HOME = True      # see _AddendRoute (round 5: -0.13 ms together with the factor states' merge on the side stream)
 
 
 class _BlockTail(torch.autograd.Function):

@@ -9,7 +9,6 @@ dominate the step).  ``PointwiseConv2d`` keeps Conv2d's parameters / state_dict 
 kernel reads and writes without a transpose.  Outputs are logical [B,C,N,W] with
 channels-last strides; every consumer in this package is stride-agnostic.
 """
-import os
 import weakref
 
 import torch
@@ -479,7 +478,7 @@ class _InstNormDot(torch.autograd.Function):
                 None if (gb is None or gb_sink is not None) else gb.to(bparam.dtype))
 
 
-INSTNORM_DOT = os.environ.get('FGNN_NO_INSTNORM_DOT', '') in ('', '0')       # tuning knob: the classifier's closing pair staged
+INSTNORM_DOT = True       # (module switch: the classifier's closing pair staged when False)
 
 
 def instnorm_relu_dot(x, conv):

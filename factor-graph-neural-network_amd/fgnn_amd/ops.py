@@ -87,10 +87,9 @@ def timed(symbol, nbytes, fn, nflops=0):
 # stream's last critical kernel, into the slot where it would otherwise idle until the join — and at the latest when the
 # backward pass ends (an engine callback, which also joins every such stream into the caller's).  Only gradients that go to
 # a sink (ops.grad_sink: the flat bucket) are deferred: a gradient tensor handed back to autograd must be complete in stream order.
-DEFER_WGRAD = os.environ.get('FGNN_NO_DEFER_WGRAD') is None       # (the variable: an A/B switch for tools / bench runs)
-WGRAD_TO_SIDE = os.environ.get('FGNN_WGRAD_SIDE', '0') not in ('', '0')     # tuning knob (round 5): see defer_wgrad
-WGRAD_STREAM = os.environ.get('FGNN_WGRAD_STREAM', '0') not in ('', '0')   # tuning knob (round 5): a THIRD stream that takes every parked
-                            # weight-gradient kernel at once, behind an event on its operands (nothing waits for them before the pass ends)
+DEFER_WGRAD = True          # (module switch: tests compare parked against inline launches)
+# (round 5 also tried the parked launches on a THIRD stream and on the side stream, each behind an event on its operands: 15.5 / 15.1
+#  against 13.8 ms — every kernel that overlaps an operator launch waits for a CU; profiles/r05/README.md.  Removed.)
 SIDE_ACTIVE = False         # set by the assemblies the first time a forward actually forks onto the side stream: with ONE stream in
                             # play parking buys no overlap and only keeps every layer's operands alive until the end of the backward
 _DEFERRED = {}              # stream -> [(launch closure, operands)]
@@ -112,33 +111,6 @@ def defer_wgrad(launch, operands=()):
     if task < 0:
         launch()
         return
-    if WGRAD_STREAM and operands and operands[0].is_cuda:
-        wst = wgrad_stream(operands[0].device)
-        _register_backward_callback(task)
-        ready = torch.cuda.Event()
-        ready.record(st)
-        with torch.cuda.stream(wst):
-            wst.wait_event(ready)
-            launch()
-            for t in operands:
-                t.record_stream(wst)
-        _DEFER_ISSUED.add(wst)
-        return
-    if WGRAD_TO_SIDE and operands and operands[0].is_cuda:
-        # round 5 (tuning knob): the main stream is the critical one (15.0 vs 11.1 ms busy, gpurun_out/r05b/timeline) — ITS
-        # weight-gradient kernels go to the side stream at once, behind an event on what they read
-        side = side_stream(operands[0].device)
-        if st != side:
-            _register_backward_callback(task)
-            ready = torch.cuda.Event()
-            ready.record(st)
-            with torch.cuda.stream(side):
-                side.wait_event(ready)
-                launch()
-                for t in operands:
-                    t.record_stream(side)
-            _DEFER_ISSUED.add(side)
-            return
     _register_backward_callback(task)
     _DEFERRED.setdefault(st, []).append((launch, tuple(operands)))
 
@@ -163,7 +135,7 @@ def _register_backward_callback(task):
 # sink (ops.grad_sink: nothing in the pass reads it) the fold is RECORDED instead — the call gets a slab buffer of its own, kept
 # alive here — and ONE launch at the end of the pass folds them all (a fixed summation order of its own: reproducible, equal to the
 # immediate folds' sums to f32 rounding).
-DEFER_FOLDS = os.environ.get('FGNN_NO_DEFER_FOLDS') is None        # (the variable: an A/B switch for tools / bench runs)
+DEFER_FOLDS = True          # (module switch: tests compare recorded against immediate folds)
 _FOLD_KEEP = []
 
 
@@ -451,8 +423,8 @@ def max_in_degree(nn_idx, N):
 # Off by default: measured on MI355X (gpurun_out/r05c, 4096 codewords) the pre-built tables change nothing — stand-alone 90.3 / 79.9 us
 # with them against 87.8 / 81.5 us without (V->F / F->V 64 -> 64), the training step 15.49 against 15.46 ms: the ~17 k cycles a
 # workgroup spends building its tables (profiles/r04) overlap the first samples' LDS-DMA and the staging of W, they are not on the
-# launch's critical path.  FGNN_BWD_TABLES=1 turns them on (identical results).
-BACKWARD_TABLES = os.environ.get('FGNN_BWD_TABLES', '0') not in ('', '0')
+# launch's critical path.  ops.BACKWARD_TABLES = True turns them on (identical results).
+BACKWARD_TABLES = False     # (module switch: the GPU suite runs the table-driven entry point both ways)
 
 
 def backward_tables(nn_idx, d):
@@ -620,17 +592,6 @@ def _fold_scratch(device):
 
 _SIDE = {}
 SIDE_STREAM = os.environ.get('FGNN_NO_SIDE_STREAM') is None      # FactorNN: factor types beyond the first run on a second stream (captured as parallel graph branches)
-
-
-_WGRAD_ST = {}
-
-
-def wgrad_stream(device):
-    """The stream of the parked weight-gradient kernels under FGNN_WGRAD_STREAM=1 (one per device, created on first use)."""
-    st = _WGRAD_ST.get(device)
-    if st is None:
-        st = _WGRAD_ST[device] = torch.cuda.Stream(device)
-    return st
 
 
 def side_stream(device):
@@ -817,7 +778,7 @@ def single_source_fanout(x, nn_idx, etype):
     return M if memo[1] else 0
 
 
-FANOUT_BROADCAST = os.environ.get('FGNN_NO_FANOUT_BROADCAST') is None     # (the variable: an A/B switch for tools / bench runs)
+FANOUT_BROADCAST = True     # (module switch: tests compare against the materialised rows)
 
 
 class _BroadcastNodes(torch.autograd.Function):
@@ -885,8 +846,8 @@ def sum_tensors(ts):
     return out
 
 
-MERGE_FAN_GRADS = os.environ.get('FGNN_NO_MERGED_FAN_GRADS') is None      # (the variable: an A/B switch for tools / bench runs)
-MERGE_FAN_WGRADS = os.environ.get('FGNN_NO_MERGED_FAN_WGRADS') is None    # (likewise)
+MERGE_FAN_GRADS = True      # (module switches: tests compare against the per-consumer sums / launches)
+MERGE_FAN_WGRADS = True
 _PLACEHOLDERS = {}
 
 

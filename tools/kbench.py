@@ -121,7 +121,7 @@ def main():
                       + 8 * W.numel())
             flops *= 3.0
             wsb = ops._workspace(dev, int(L.fgnn_mpconv_backward_workspace_bytes(ctypes.byref(dsc))))
-            tables = ops.backward_tables(idx, dsc)          # per-graph tables (FGNN_NO_BWD_TABLES=1: every launch builds its own)
+            tables = ops.backward_tables(idx, dsc)          # per-graph tables (ops.BACKWARD_TABLES off — the default: every launch builds its own)
             cp = lambda t: None if t is None else t.clone(memory_format=torch.preserve_format)
             sets = [(x, et, gz, amax, gx, get)] + [(xs[i], ets[i], cp(gz), cp(amax), cp(gx), cp(get)) for i in range(1, K)]
 

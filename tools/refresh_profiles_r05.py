@@ -13,9 +13,12 @@ import json
 import os
 import shutil
 
+import sys
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(ROOT, 'gpurun_out', 'r05')
-DST = os.path.join(ROOT, 'profiles', 'r05')
+ROUND = sys.argv[1] if len(sys.argv) > 1 else 'r05'      # python tools/refresh_profiles_r05.py r06: the same layout for a later round
+SRC = os.path.join(ROOT, 'gpurun_out', ROUND)
+DST = os.path.join(ROOT, 'profiles', ROUND)
 os.makedirs(DST, exist_ok=True)
 
 
@@ -104,7 +107,30 @@ def main():
     json.dump(traffic, open(os.path.join(DST, 'pmc_traffic.json'), 'w'), indent=1)
     import glob as _g
     names = [os.path.basename(f) for f in _g.glob(os.path.join(SRC, 'bench_*.json'))] + ['cpu_baseline_all_cores.json', 'lbench.log',
-                                                                                       'wbench.log', 'tbench.log', 'sbench.log', 'mbench.log', 'wmbench.log']
+                                                                                       'wbench.log', 'tbench.log', 'sbench.log', 'mbench.log', 'wmbench.log',
+                                                                                       'wbench_register_direct.log', 'wmbench_register_direct.log', 'fastpath_step.log']
+    dd = os.path.join(SRC, 'pmc_wgrad')          # round 6: HBM bytes per launch of the weight-gradient kernels over tools/wbench.py's shapes
+    if os.path.isdir(dd):
+        rec = {}
+        for sub in ('linear_wgrad_lds_kernel', 'linear_wgrad_b16_kernel'):
+            sm = summarise(dd, sub)
+            if sm:
+                rec[sub] = {k: sm[k] for k in ('hbm_read_MB_corrected_x2', 'hbm_write_MB', 'traffic_bytes_per_launch') if k in sm}
+        json.dump({'_doc': 'averages over every launch of the symbol in tools/wbench.py --bf16 (R = 393 216 rows; the LDS-staged kernel takes the '
+                           '128x256, 256x128 and 256x256 maps: 302 / 302 / 403 MB of operands each); FETCH_SIZE x 2 (gfx950) + WRITE_SIZE', 'kernels': rec},
+                  open(os.path.join(DST, 'pmc_wgrad.json'), 'w'), indent=1)
+    if os.path.isdir(os.path.join(SRC, 'syn')):
+        for f in _g.glob(os.path.join(SRC, 'syn', '*')):
+            base = os.path.basename(f)
+            if base.endswith('kernel_stats.csv'):          # top 40 rows only
+                rows = list(csv.DictReader(open(f)))
+                with open(os.path.join(DST, 'syn_' + base.replace('_kernel_stats.csv', '_kernel_stats_top40.csv').replace('syn_', '')), 'w', newline='') as g:
+                    w = csv.DictWriter(g, fieldnames=rows[0].keys(), quoting=csv.QUOTE_NONNUMERIC)
+                    w.writeheader()
+                    for r in rows[:40]:
+                        w.writerow(r)
+            elif base.startswith('bench_'):
+                shutil.copy(f, os.path.join(DST, 'rocprof_' + base))
     names += [os.path.basename(f) for f in _g.glob(os.path.join(SRC, 'kbench_*.log'))]
     for f in names:
         if os.path.exists(os.path.join(SRC, f)):
