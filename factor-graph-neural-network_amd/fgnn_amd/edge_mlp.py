@@ -39,6 +39,7 @@ class _EdgeMLPFn(torch.autograd.Function):
     def backward(ctx, gy):
         from . import ops
         ops.backward_node_begins()
+        ops.backward_tail_begins()      # (behind this node the pass is one chain on this stream: what waits for its end goes to the side stream)
         x, w1, b1, w2 = ctx.saved_tensors
         B, cin, M, k = x.shape
         net = w2.shape[0]

@@ -219,6 +219,39 @@ def backward_node_begins():
         flush_deferred(except_stream=torch.cuda.current_stream())
 
 
+TAIL_TO_SIDE = True         # see backward_tail_begins (module switch for the A/B in tools/ and the tests)
+
+
+def backward_tail_begins():
+    """Called by a backward node behind which the pass is ONE dependent chain on the current stream — the edge-type MLPs' backward,
+    which needs the edge-weight gradients of all eight layers (/root/reference/train_ldpc.py:68-69: `emodel_*` feed every layer).
+    What is parked for the end of the pass — this stream's weight-gradient launches and every recorded parameter-gradient fold —
+    used to run BEHIND that chain, alone on the chip (0.3 ms of a 13 ms step: profiles/r06/README.md); it goes to the side stream
+    NOW, behind an event on this stream, and runs beside the chain.  The end-of-pass callback joins the side stream as before."""
+    if not (TAIL_TO_SIDE and SIDE_ACTIVE and _DEFER_CALLBACK[0] is not None
+            and _DEFER_CALLBACK[0] == torch._C._current_graph_task_id()):
+        return
+    cur = torch.cuda.current_stream()
+    side = side_stream(cur.device)
+    if side == cur:
+        return
+    flush_deferred(except_stream=cur)            # (the other streams' parked launches go out on their own streams, as at any node)
+    mine = _DEFERRED.get(cur) or []
+    if not mine and not _hip.lib().fgnn_fold_pending():
+        return
+    ready = torch.cuda.Event()
+    ready.record(cur)
+    with torch.cuda.stream(side):
+        side.wait_event(ready)
+        for fn, operands in mine:
+            fn()
+            for t in operands:
+                t.record_stream(side)
+        mine.clear()
+        flush_folds()       # every producer recorded so far is in front of `ready` on this stream or earlier on the side stream
+    _DEFER_ISSUED.add(side)
+
+
 def _require_device(*tensors):
     for t in tensors:
         if t is not None and not t.is_cuda:
