@@ -52,6 +52,8 @@ struct KbParams {
     float slope;         // LeakyReLU slope of conv1 / conv2
     int Npad, Mpad;
     int off_a1, off_ps, off_idx, off_et;   // byte offsets (x / a2 image at 0)
+    int ad_bcast;        // bit a: addend a is ONE row per sample [B][nout], added to every destination (the hyper-factor's message to
+                         // the variables: M identical rows the producer no longer writes — round 6)
 };
 
 extern __shared__ __attribute__((aligned(16))) unsigned char fgnn_lds_kb[];
@@ -195,18 +197,19 @@ __global__ __launch_bounds__(KB_THREADS) void mpconv_block_fwd_kernel(const KbPa
 
         // the addend of this wave's first conv2 node tile: asked for here, it lands under the gather
         // (up to three addends: their pieces are summed in f32 as they arrive — 4 registers per channel tile instead of 2)
-        const uint16_t* adb = p.addend ? p.addend + (int64_t)b * M * NOUT : nullptr;
-        const uint16_t* adb1 = p.addend1 ? p.addend1 + (int64_t)b * M * NOUT : nullptr;
-        const uint16_t* adb2 = p.addend2 ? p.addend2 + (int64_t)b * M * NOUT : nullptr;
+        const int rows0 = (p.ad_bcast & 1) ? 1 : M, rows1 = (p.ad_bcast & 2) ? 1 : M, rows2 = (p.ad_bcast & 4) ? 1 : M;
+        const uint16_t* adb = p.addend ? p.addend + (int64_t)b * rows0 * NOUT : nullptr;
+        const uint16_t* adb1 = p.addend1 ? p.addend1 + (int64_t)b * rows1 * NOUT : nullptr;
+        const uint16_t* adb2 = p.addend2 ? p.addend2 + (int64_t)b * rows2 * NOUT : nullptr;
         f32x4 adr[NO];
         auto ad_fetch = [&](int m0) {
 #pragma unroll
             for (int q = 0; q < NO; ++q) adr[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            const int64_t off = (int64_t)m0 * NOUT + cbase;
             const uint16_t* src[3] = {adb, adb1, adb2};
 #pragma unroll
             for (int a = 0; a < 3; ++a)
                 if (src[a]) {
+                    const int64_t off = ((p.ad_bcast >> a) & 1) ? (int64_t)cbase : (int64_t)m0 * NOUT + cbase;
                     const uint2* ap = reinterpret_cast<const uint2*>(src[a] + off);
 #pragma unroll
                     for (int q = 0; q < NO; ++q) {
@@ -313,6 +316,18 @@ extern "C" int fgnn_mpconv_block_forward(const fgnn_mpconv_desc* d, const void* 
                                          const float* filters, const float* s2, const float* t2, const float* W2,
                                          const float* s3, const float* t3, float slope, int nin, int nout,
                                          const void* addend, const void* addend1, const void* addend2, void* y, fgnn_stream_t stream) {
+    return fgnn_mpconv_block_forward_rows(d, x, nn_idx, etype, W1, s1, t1, filters, s2, t2, W2, s3, t3, slope, nin, nout, addend, addend1,
+                                          addend2, 0, y, stream);
+}
+
+// The same with per-sample ROW addends: bit a of `addend_row_mask` marks addend a as [B][nout] — one row per sample, added to every
+// destination (fgnn_mpconv_block_forward_fanout run with M = 1 produces it: the hyper-factor sends every variable the same message).
+extern "C" int fgnn_mpconv_block_forward_rows(const fgnn_mpconv_desc* d, const void* x, const int64_t* nn_idx,
+                                              const void* etype, const float* W1, const float* s1, const float* t1,
+                                              const float* filters, const float* s2, const float* t2, const float* W2,
+                                              const float* s3, const float* t3, float slope, int nin, int nout,
+                                              const void* addend, const void* addend1, const void* addend2, int32_t addend_row_mask,
+                                              void* y, fgnn_stream_t stream) {
     if (!d || !x || !nn_idx || !etype || !W1 || !s1 || !t1 || !filters || !s2 || !t2 || !W2 || !s3 || !t3 || !y)
         FGNN_FAIL(FGNN_EINVAL, "mpconv_block_forward: null pointer");
     const bool ok = d->dtype == FGNN_BF16 && d->ext == FGNN_EXT_NONE && d->agg == FGNN_AGG_MAX && d->net == 4 &&
@@ -332,6 +347,7 @@ extern "C" int fgnn_mpconv_block_forward(const fgnn_mpconv_desc* d, const void* 
     p.W1 = W1; p.s1 = s1; p.t1 = t1; p.F = filters; p.s2 = s2; p.t2 = t2; p.W2 = W2; p.s3 = s3; p.t3 = t3;
     p.addend = (const uint16_t*)addend; p.addend1 = (const uint16_t*)addend1; p.addend2 = (const uint16_t*)addend2;
     p.y = (uint16_t*)y; p.slope = slope;
+    p.ad_bcast = addend_row_mask & 7;
     p.Npad = fgnn_round_up(d->N, 16);
     p.Mpad = fgnn_round_up(d->M, 16);
     const int img0 = p.Npad * (nin + 8) > p.Mpad * KB_XSB ? p.Npad * (nin + 8) : p.Mpad * KB_XSB;   // x, later a2

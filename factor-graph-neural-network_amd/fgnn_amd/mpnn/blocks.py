@@ -479,6 +479,15 @@ class mp_conv_residual(base_mp_nn):
         adds = as_addends(addend)
         if len(adds) > 3:
             return None
+        # an addend that is a per-sample vector broadcast over the nodes (ops.broadcast_nodes: the hyper-factor's message to the
+        # variables, formed on ONE row per codeword — below) is handed over as that [B, nout] row: the parity block's kernel adds it to
+        # every destination (fgnn_mpconv_block_forward_rows); the 96 identical rows are neither written nor read
+        row_mask = 0
+        for i, a in enumerate(adds):
+            src = getattr(a, '_fgnn_bcast_src', None)
+            if src is not None and a.shape[2] > 1 and not (fanout or fanin) and src.dtype == x.dtype:
+                adds[i] = src
+                row_mask |= 1 << i
         for a in adds:
             if a.dtype != x.dtype or not a.permute(0, 2, 3, 1).is_contiguous():
                 return None
@@ -496,6 +505,18 @@ class mp_conv_residual(base_mp_nn):
                 return None
             _hip.check(rc)
             return y
+        if fanout and not adds and B > 1 and ops.single_source_fanout(x, nn_idx, etype):
+            # every destination receives the same message and the rest of the block maps identical rows to identical rows (eval-mode
+            # BatchNorms are per-channel affines): ONE row per codeword, handed on as a broadcast (round 5 did this for training)
+            y1 = torch.empty((B, 1, 1, nout), device=x.device, dtype=x.dtype).permute(0, 3, 1, 2)
+            et1 = etype[:, :, :1, :]
+            d1 = _hip.make_desc(x, nn_idx[:, :1, :], et1, 64, 1, _hip.EXT_NONE, _hip.AGG_MAX, True, y1)
+            d1.nin = 64
+            rc = _hip.lib().fgnn_mpconv_block_forward_fanout(ctypes.byref(d1), P(x), P(et1), P(W1), P(s1), P(t1), P(F), P(s2), P(t2), P(W2),
+                                                             P(s3), P(t3), float(bn1.slope), nin, nout, None, None, None, P(y1), _hip.stream_ptr())
+            if rc != _hip.EUNSUPPORTED:
+                _hip.check(rc)
+                return ops.broadcast_nodes(y1, M)
         if fanout:
             rc = _hip.lib().fgnn_mpconv_block_forward_fanout(ctypes.byref(d), P(x), P(etype), P(W1), P(s1), P(t1), P(F),
                                                              P(s2), P(t2), P(W2), P(s3), P(t3), float(bn1.slope), nin, nout,
@@ -504,9 +525,9 @@ class mp_conv_residual(base_mp_nn):
                 return None
             _hip.check(rc)
             return y
-        rc = _hip.lib().fgnn_mpconv_block_forward(ctypes.byref(d), P(x), P(nn_idx), P(etype), P(W1), P(s1), P(t1), P(F),
-                                                  P(s2), P(t2), P(W2), P(s3), P(t3), float(bn1.slope), nin, nout, P(a0), P(a1),
-                                                  P(a2), P(y), _hip.stream_ptr())
+        rc = _hip.lib().fgnn_mpconv_block_forward_rows(ctypes.byref(d), P(x), P(nn_idx), P(etype), P(W1), P(s1), P(t1), P(F),
+                                                       P(s2), P(t2), P(W2), P(s3), P(t3), float(bn1.slope), nin, nout, P(a0), P(a1),
+                                                       P(a2), row_mask, P(y), _hip.stream_ptr())
         if rc == _hip.EUNSUPPORTED:
             return None
         _hip.check(rc)

@@ -388,6 +388,16 @@ int fgnn_mpconv_block_forward(const fgnn_mpconv_desc* d, const void* x, const in
                               float slope, int32_t nin, int32_t nout, const void* addend, const void* addend1, const void* addend2, void* y,
                               fgnn_stream_t stream);
 
+/* fgnn_mpconv_block_forward with per-sample ROW addends (ABI 11): bit a of addend_row_mask marks addend a as [B][nout] — one row per
+ * sample, added to every destination.  That is the LDPC hyper-factor's message to the variables (/root/reference/train_ldpc.py:40-46,
+ * 82-88: one source node, identical single edges): fgnn_mpconv_block_forward_fanout run with M = 1 forms it once per codeword and
+ * the 96 identical rows the reference materialises are neither written nor read. */
+int fgnn_mpconv_block_forward_rows(const fgnn_mpconv_desc* d, const void* x, const int64_t* nn_idx, const void* etype,
+                                   const float* W1, const float* s1, const float* t1, const float* filters,
+                                   const float* s2, const float* t2, const float* W2, const float* s3, const float* t3,
+                                   float slope, int32_t nin, int32_t nout, const void* addend, const void* addend1, const void* addend2,
+                                   int32_t addend_row_mask, void* y, fgnn_stream_t stream);
+
 /* The same block around the hyper-factor FAN-OUT call: inner operator with N = 1 source, k = 1, one edge type
  * (filters [64][64]); x is the block's input [B, nin], y its output [B, M, nout]. */
 int fgnn_mpconv_block_forward_fanout(const fgnn_mpconv_desc* d, const void* x, const void* etype, const float* W1,
@@ -536,8 +546,8 @@ const char* fgnn_last_kernel(void);
  * (fgnn_amd/_hip.py: ABI_VERSION) checks it BEFORE binding symbols, so a stale library is reported as a version
  * mismatch and not as a missing symbol or a misread field.  4: round-2 additions (flat_adam, factor_layer_*,
  * ldpc_channel_features_rng, backward_reduces_getype, desc.reserved = in-degree | GETYPE_REDUCED); 5: fgnn_block_tail_*;
- * 6: fgnn_block_head_backward. */
-#define FGNN_ABI_VERSION 10
+ * 6: fgnn_block_head_backward.  11: fgnn_mpconv_block_forward_rows. */
+#define FGNN_ABI_VERSION 11
 int fgnn_abi_version(void);
 
 #ifdef __cplusplus

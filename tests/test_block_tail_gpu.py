@@ -505,3 +505,48 @@ def test_node_sum_of_a_width_outside_the_kernel(C, dev):
     out = pointwise.node_sum(g, 7)
     assert out.shape == (6, C)
     assert H.rel_err(out.float(), g.float().view(6, 7, C).sum(1)) <= 2.0 ** -7
+
+
+@pytest.mark.parametrize('nin,nout', [(256, 256), (128, 256), (256, 128), (64, 64)])
+def test_inference_fanout_block_runs_on_one_row_and_rides_as_a_row_addend(nin, nout, dev, monkeypatch):
+    """Round 6, inference: the hyper-factor -> variables `mp_conv_residual` (one source node, identical single edges,
+    /root/reference/train_ldpc.py:40-46,82-88) is formed on ONE row per codeword (`fgnn_mpconv_block_forward_fanout` with M = 1) and
+    handed on as a broadcast; the parity F->V block's kernel takes it as a per-sample ROW addend (`fgnn_mpconv_block_forward_rows`).
+    Both equal the materialised forms bit for bit: the 96 rows the reference writes are identical rows."""
+    from fgnn_amd import _hip, ops
+    from fgnn_amd.mpnn import mp_conv_residual, mp_conv_type
+    B, M = 48, 96
+    g = torch.Generator().manual_seed(nin + nout)
+    torch.manual_seed(7)
+    hyper = mp_conv_residual(nin, 64, 1, extension=mp_conv_type.NO_EXTENSION, with_residual=False, aggregator='max',
+                             nout=None if nout == nin else nout).to(dev).eval()
+    parity = mp_conv_residual(nin, 64, 4, extension=mp_conv_type.NO_EXTENSION, with_residual=False, aggregator='max',
+                              nout=None if nout == nin else nout).to(dev).eval()
+    with torch.no_grad():
+        for m in (hyper, parity):
+            m.mp_conv.filters.mul_(10.0)
+            for bn in (m.conv1[1], m.mp_conv.bn, m.conv2[1]):
+                bn.running_mean.normal_(0, 0.2, generator=None)
+                bn.running_var.uniform_(0.5, 1.5)
+    x1 = torch.randn(B, 1, 1, nin, generator=g).bfloat16().to(dev).permute(0, 3, 1, 2)
+    idx1 = torch.zeros(B, M, 1, dtype=torch.int64, device=dev)
+    et1 = torch.ones(B, 1, M, 1, device=dev, dtype=torch.bfloat16)
+    xf = torch.randn(B, 48, 1, nin, generator=g).bfloat16().to(dev).permute(0, 3, 1, 2)
+    idx = torch.randint(0, 48, (1, M, 3), generator=g).to(dev).expand(B, -1, -1)
+    et = torch.randn(B, M, 3, 4, generator=g).bfloat16().to(dev).permute(0, 3, 1, 2)
+    other = torch.randn(B, M, 1, nout, generator=g).bfloat16().to(dev).permute(0, 3, 1, 2)
+    with torch.no_grad():
+        h = hyper(x1, idx1, et1)
+        assert 'mpconv_block_fanout_kernel' in _hip.lib().fgnn_last_kernel().decode()
+        assert getattr(h, '_fgnn_bcast_src', None) is not None and h.shape == (B, nout, M, 1) and h.stride(2) == 0
+        monkeypatch.setattr(ops, 'FANOUT_BROADCAST', False)
+        h_full = hyper(x1, idx1, et1)
+        monkeypatch.setattr(ops, 'FANOUT_BROADCAST', True)
+        assert getattr(h_full, '_fgnn_bcast_src', None) is None and h_full.stride(2) != 0
+        assert torch.equal(h.contiguous(), h_full.contiguous())
+        y_row = parity(xf, idx, et, addend=[other, h])
+        assert 'mpconv_block_fwd_kernel' in _hip.lib().fgnn_last_kernel().decode()
+        y_full = parity(xf, idx, et, addend=[other, h_full])
+        assert torch.equal(y_row, y_full)
+        y_first = parity(xf, idx, et, addend=[h, other])         # the row addend in the first slot
+        assert H.rel_err(y_first.float(), y_full.float()) <= 2.0 ** -7      # (other summation order of the two addends)
