@@ -136,15 +136,13 @@ class GraphedForward:
         self.failed = False
         self.anchor = None
         self.replays = 0
-        self.checked = {}         # integer input position -> (data_ptr, version) last compared equal to the captured table
 
     def eager(self, *args, **kwargs):
         """The module's own forward (the class's: this object shadows it as an instance attribute)."""
         return type(self.module).forward(self.module, *args, **kwargs)
 
     def __getstate__(self):        # graphs and captured buffers do not travel (pickle / deepcopy give an eager module that re-captures)
-        return {'module': self.module, 'seen': {}, 'cap': None, 'key': None, 'failed': False, 'anchor': None, 'replays': 0,
-                'checked': {}}
+        return {'module': self.module, 'seen': {}, 'cap': None, 'key': None, 'failed': False, 'anchor': None, 'replays': 0}
 
     # ---- what a call must look like to be captured / replayed ----
     @staticmethod
@@ -172,7 +170,11 @@ class GraphedForward:
         return any_p
 
     def _pointers(self):
-        return tuple(t.data_ptr() for t in list(self.module.parameters()) + list(self.module.buffers()))
+        """Addresses the graphs hold: parameters, buffers, and the gradient slices the replayed backward adds into (a
+        ``model.zero_grad()`` — set_to_none — or a re-created optimizer moves those)."""
+        ps = list(self.module.parameters())
+        return (tuple(t.data_ptr() for t in ps + list(self.module.buffers()))
+                + tuple(0 if (q.grad is None or not q.requires_grad) else q.grad.data_ptr() for q in ps))
 
     def _frozen_versions(self):
         return tuple(q._version for q in self.module.parameters() if not q.requires_grad)
@@ -207,15 +209,14 @@ class GraphedForward:
         if cap.pointers != self._pointers() or cap.frozen != self._frozen_versions():
             self.cap, self.seen = None, {}             # a parameter / buffer was replaced, a frozen table rewritten: capture again later
             return False
-        for i, (a, st) in enumerate(zip(args, cap.static_in)):
+        for a, st in zip(args, cap.static_in):
             if a.dtype.is_floating_point or a.data_ptr() == st.data_ptr():
                 continue
-            mark = (a.data_ptr(), a._version)
-            if self.checked.get(i) == mark:
-                continue
-            if not torch.equal(a, st):                 # (one device comparison + host read per table and step: the loop it serves reads
-                return False                           # the loss back every step anyway) other neighbour tables: the graphs' fast paths
-            self.checked[i] = mark                     # were chosen for the captured ones
+            # one device comparison + host read per table and step (the loop this serves reads its loss back every step anyway).  No
+            # memo on (address, version): a collated batch is a NEW tensor every step, and the allocator hands the same address out
+            # again — a table with other contents at a remembered address would be replayed with the captured one's kernels
+            if not torch.equal(a, st):
+                return False                           # other neighbour tables: the graphs' fast paths were chosen for the captured ones
         return True
 
     def _replay(self, args, fresh=False):
