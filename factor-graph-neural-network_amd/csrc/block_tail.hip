@@ -17,7 +17,21 @@
 //                                                                                            a2 for the weight-gradient kernel)
 //   MODE 2 "reduce"  : e, gout -> z3 -> g' = gout act3'(.) -> partials (sum g', sum g' z3)  (BatchNorm3's backward sums)
 //   MODE 3 "grad"    : e, gout -> z3 -> gz3 = s3 g' + A z3 + B (BatchNorm3's input gradient, closed form per channel)
-//                      -> stores gz3 (bf16, read once by the weight-gradient kernel) and ga2 = gz3 W2 (64 channels)
+//                      -> ga2 = gz3 W2 (64 channels); gz3 itself is stored (bf16) only for callers that still run conv2's weight
+//                      gradient as its own kernel
+//
+// conv2's WEIGHT GRADIENT without a stored gz3 / a2 (round 6).  gW2[o][c] = sum_rows gz3[row][o] a2[row][c], and gz3 is affine in
+// quantities the "reduce" pass already holds: with acc = z3 - b2 = W2 a2 (bf16 operands, as every mode computes it),
+//     gz3 = s3 g' + A acc + K,   K = A b2 + Bc        =>       gW2 = diag(s3) M1 + diag(A) (W2b Gram) + K v^T
+//     M1[o][c] = sum_rows g'[row][o] a2[row][c]     Gram[c'][c] = sum_rows a2[row][c'] a2[row][c]     v[c] = sum_rows a2[row][c]
+// (sum acc a2^T = W2b Gram exactly, W2b = the bf16 W2 the matrix cores see).  MODE 2 with NA == 1 accumulates the three moments
+// beside BatchNorm3's sums: per 16-row tile a wave writes its g' and a2 fragments to a private 4 KB LDS tile (row-major, 32-byte
+// segments swizzled by (row >> 1) & 3) and reads them back TRANSPOSED (ds_read_b64_tr_b16: lane = channel, four rows) as the operands
+// of v_mfma_f32_16x16x16_bf16 with K = rows: 16 MFMAs for its slab of M1, 16 / CG for its share of Gram.  The constants A, Bc only
+// exist after the pass's grid-wide sums — which is why the staged form needed gz3 in memory — but the moments do not depend on them:
+// block_tail_wgrad_combine_kernel applies them to the FOLDED moments (a [Cout][64] problem).  Gone per block: gz3 written (R Cout
+// bf16) and read back, a2 written by the forward and read back, one weight-gradient launch with its slabs; conv2's bias gradient is
+// identically zero in front of a batch-statistics BatchNorm (sum gz3 = 0) and is no longer formed from rounding noise.
 //
 // Layout trick shared by all modes (as csrc/linear_fwd_b16.hip): the product is computed TRANSPOSED, D[i = out channel]
 // [j = row] = W2 a2^T, with the MFMA row <-> channel permutation that hands lane (row, lk) the 16 CONSECUTIVE channels
@@ -64,6 +78,8 @@ struct BtParams {
     float* A; float* Bc; float* gweight3; float* gbias3;
     const float* mean2; const float* invstd2;                           // mode 3: BatchNorm2's sums -> dsum2 [2][64], gweight2 / gbias2 +=
     float* dsum2; float* gweight2; float* gbias2;
+    float* mom;              // mode 2 with NA == 1 (round 6): per (workgroup, row group) slabs [Cout*64 + 64*64 + 64] of the MOMENTS conv2's weight
+                             // gradient is a closed form of (M1 = sum g' a2^T, Gram = sum a2 a2^T, v = sum a2): see block_tail_wgrad_* below
 };
 
 extern __shared__ __attribute__((aligned(16))) unsigned char bt_lds[];
@@ -135,7 +151,7 @@ __global__ __launch_bounds__(BT_THREADS, MODE == 1 ? 3 : 2) void block_tail_kern
     }
     // BatchNorm2 affine of this lane's 16 input channels (16 lk .. 16 lk + 15)
     // (mode 3 is short of registers: there the affine is re-read from LDS every tile — 8 broadcast reads)
-    constexpr bool S2REG = MODE != 3;
+    constexpr bool S2REG = MODE != 3 && !(MODE == 2 && NA == 1);        // (the moments variant of mode 2 needs its registers for 80 - 128 accumulators)
     float* s2l = red + ((MODE == 0 || MODE == 2) ? BT_WAVES * 2 * COUT : 0);             // [2][64] (mode 3)
     float s2[S2REG ? 16 : 1], t2[S2REG ? 16 : 1];
     if (S2REG) {
@@ -154,9 +170,10 @@ __global__ __launch_bounds__(BT_THREADS, MODE == 1 ? 3 : 2) void block_tail_kern
                                                             // fatter waves expose the MFMA -> statistics dependency)
     const int cg = BOUND ? wave % CG : 0, rg = BOUND ? wave / CG : wave;
     constexpr int NRG = BOUND ? BT_WAVES / CG : BT_WAVES;
-    uint4 aW[BOUND ? 4 : 1][2];
-    f32x4 c0[BOUND ? 4 : 1], c1[BOUND ? 4 : 1];
-    if (BOUND) {
+    constexpr bool WREG = BOUND && !(MODE == 2 && NA == 1);      // (the moments variant of mode 2: fragments and constants from LDS per tile, as mode 3)
+    uint4 aW[WREG ? 4 : 1][2];
+    f32x4 c0[WREG ? 4 : 1], c1[WREG ? 4 : 1];
+    if (WREG) {
 #pragma unroll
         for (int ot = 0; ot < 4; ++ot) {
             aW[ot][0] = Wf[((cg * 4 + ot) * 2 + 0) * 64 + lane];
@@ -168,6 +185,23 @@ __global__ __launch_bounds__(BT_THREADS, MODE == 1 ? 3 : 2) void block_tail_kern
     f32x4 s0[4], s1[4];
 #pragma unroll
     for (int ot = 0; ot < 4; ++ot) { s0[ot] = (f32x4){0.f, 0.f, 0.f, 0.f}; s1[ot] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    // moments of conv2's weight gradient (mode 2, NA == 1): this wave's slab of M1, its share of Gram (NTC column tiles), v
+    constexpr bool MOM = MODE == 2 && NA == 1;
+    constexpr int NTC = MOM ? 4 / CG : 1;
+    f32x4 m1[MOM ? 4 : 1][MOM ? 4 : 1], gr[MOM ? 4 : 1][NTC];
+    float vs[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int a = 0; a < (MOM ? 4 : 1); ++a) {
+#pragma unroll
+        for (int b = 0; b < (MOM ? 4 : 1); ++b) m1[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int b = 0; b < NTC; ++b) gr[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    // the wave's transposition tiles: g' [16 rows][64 o] and a2 [16 rows][64 c] bf16, behind the statistics fold's rows
+    const unsigned mom_tile = (unsigned)(CG * 8 * 64 * 16 + NCST * COUT * 4 + BT_WAVES * 2 * COUT * 4 + 512) + (unsigned)wave * 4096u;      // byte offset in bt_lds (behind s2l)
+    const unsigned mom_w = mom_tile + (unsigned)(li * 128 + ((lk ^ ((li >> 1) & 3)) << 5));                 // this lane's 32 bytes of row li (segment lk)
+    const int mom_kr = 4 * lk + (li >> 2);                                                                  // transpose reads: key row of lane (group lk, i = li)
+    const unsigned mom_r = (unsigned)(uintptr_t)bt_lds + mom_tile + (unsigned)(mom_kr * 128 + 8 * (li & 3)), mom_f = (unsigned)((mom_kr >> 1) & 3);
 
     const int ntile = (R + 15) / 16;
     const int stride = gridDim.x * NRG;
@@ -176,7 +210,7 @@ __global__ __launch_bounds__(BT_THREADS, MODE == 1 ? 3 : 2) void block_tail_kern
     // The loop body is STRAIGHT-LINE code — loads are unconditional (rows past the end are clamped to the last row and masked
     // where they are used, a wave's tile count is rounded up to a multiple of DEPTH): with loads under exec-masked branches
     // the compiler's s_waitcnt placement falls back to vmcnt(0) at every merge and the ring buys nothing.
-    constexpr int DEPTH = MODE == 0 ? 4 : (MODE == 2 ? 2 : 1);
+    constexpr int DEPTH = MODE == 0 ? 4 : ((MODE == 2 && NA != 1) ? 2 : 1);
     const int first = blockIdx.x * NRG + rg;
     const int mine = first < ntile ? (ntile - first + stride - 1) / stride : 0;           // tiles of this wave
     auto load_e = [&](int it, uint4 (&q)[2]) {
@@ -252,7 +286,7 @@ __global__ __launch_bounds__(BT_THREADS, MODE == 1 ? 3 : 2) void block_tail_kern
                 acc[ot] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks)
-                    acc[ot] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bt_bf16x8, aW[BOUND ? ot : 0][ks]), a2f[ks], acc[ot], 0, 0, 0);
+                    acc[ot] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bt_bf16x8, aW[WREG ? ot : 0][ks]), a2f[ks], acc[ot], 0, 0, 0);
             }
 #pragma unroll
             for (int ot = 0; ot < 4; ++ot)
@@ -292,7 +326,7 @@ __global__ __launch_bounds__(BT_THREADS, MODE == 1 ? 3 : 2) void block_tail_kern
                 acc[ot] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
-                    const uint4 a = BOUND ? aW[BOUND ? ot : 0][ks] : Wf[((sl * 4 + ot) * 2 + ks) * 64 + lane];
+                    const uint4 a = WREG ? aW[WREG ? ot : 0][ks] : Wf[((sl * 4 + ot) * 2 + ks) * 64 + lane];
                     acc[ot] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bt_bf16x8, a), a2f[ks], acc[ot], 0, 0, 0);
                 }
             }
@@ -304,7 +338,7 @@ __global__ __launch_bounds__(BT_THREADS, MODE == 1 ? 3 : 2) void block_tail_kern
 #pragma unroll
                 for (int ot = 0; ot < 4; ++ot)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) y[4 * ot + r] = bt_act2<false>(fmaf(acc[ot][r], c0[ot][r], c1[ot][r]), p.slope3);
+                    for (int r = 0; r < 4; ++r) y[4 * ot + r] = bt_act2<false>(fmaf(acc[ot][r], c0[WREG ? ot : 0][r], c1[WREG ? ot : 0][r]), p.slope3);
 #pragma unroll
                 for (int a = 0; a < NA; ++a) {
                     float v[8];
@@ -336,11 +370,15 @@ __global__ __launch_bounds__(BT_THREADS, MODE == 1 ? 3 : 2) void block_tail_kern
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 float gz[16];
+                float gp16[MOM ? 16 : 1];
 #pragma unroll
                 for (int ot = 0; ot < 4; ++ot) {
                     f32x4 s, t, ca = {0.f, 0.f, 0.f, 0.f}, cb = {0.f, 0.f, 0.f, 0.f};
-                    if (MODE == 2) { s = c0[ot]; t = c1[ot]; }
-                    else {
+                    if (MODE == 2 && WREG) { s = c0[WREG ? ot : 0]; t = c1[WREG ? ot : 0]; }
+                    else if (MODE == 2) {
+                        s = *reinterpret_cast<const f32x4*>(cp + 4 * ot);
+                        t = *reinterpret_cast<const f32x4*>(cp + COUT + 4 * ot);
+                    } else {
                         s = *reinterpret_cast<const f32x4*>(cp + 4 * ot);
                         t = *reinterpret_cast<const f32x4*>(cp + COUT + 4 * ot);
                         ca = *reinterpret_cast<const f32x4*>(cp + 2 * COUT + 4 * ot);
@@ -353,13 +391,56 @@ __global__ __launch_bounds__(BT_THREADS, MODE == 1 ? 3 : 2) void block_tail_kern
                         if (MODE == 2) {
                             s0[ot][r] += ge;                                       // rows >= R carry g = 0
                             s1[ot][r] = fmaf(ge, acc[ot][r], s1[ot][r]);
+                            if (MOM) gp16[MOM ? 4 * ot + r : 0] = ge;
                         } else gz[4 * ot + r] = fmaf(s[r], ge, fmaf(ca[r], acc[ot][r], cb[r]));
+                    }
+                }
+                if (MOM) {
+                    // g' (channels 64 cg + 16 lk .. + 15 of row li) and a2 (channels 16 lk .. + 15) -> the wave's LDS tiles; back transposed
+                    typedef short bt_s16x4 __attribute__((ext_vector_type(4)));
+                    typedef __attribute__((address_space(3))) bt_s16x4 lds_s4;
+                    uint4* wg = reinterpret_cast<uint4*>(bt_lds + mom_w);
+                    wg[0] = make_uint4(bt_pack2(gp16[0], gp16[1]), bt_pack2(gp16[2], gp16[3]), bt_pack2(gp16[4], gp16[5]), bt_pack2(gp16[6], gp16[7]));
+                    wg[1] = make_uint4(bt_pack2(gp16[8], gp16[9]), bt_pack2(gp16[10], gp16[11]), bt_pack2(gp16[12], gp16[13]), bt_pack2(gp16[14], gp16[15]));
+                    uint4* wa = reinterpret_cast<uint4*>(bt_lds + mom_w + 2048u);
+                    wa[0] = __builtin_bit_cast(uint4, a2f[0]);
+                    wa[1] = __builtin_bit_cast(uint4, a2f[1]);
+                    bt_s16x4 fa[4], fb[4];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const unsigned off = ((unsigned)t ^ mom_f) << 5;
+                        fa[t] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(reinterpret_cast<lds_s4*>(static_cast<uintptr_t>(mom_r + off)));
+                        fb[t] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(reinterpret_cast<lds_s4*>(static_cast<uintptr_t>(mom_r + 2048u + off)));
+                    }
+#pragma unroll
+                    for (int to = 0; to < 4; ++to)
+#pragma unroll
+                        for (int tc = 0; tc < 4; ++tc)
+                            m1[MOM ? to : 0][MOM ? tc : 0] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(fa[to], fb[tc], m1[MOM ? to : 0][MOM ? tc : 0], 0, 0, 0);
+#pragma unroll
+                    for (int tq = 0; tq < 4; ++tq)
+#pragma unroll
+                        for (int u = 0; u < NTC; ++u)
+                        {   // (selects, not an indexed register array: the column tile cg NTC + u is wave-uniform but not a constant)
+                            const int tcol = cg * NTC + u;
+                            const bt_s16x4 bsel = tcol == 0 ? fb[0] : (tcol == 1 ? fb[1] : (tcol == 2 ? fb[2] : fb[3]));
+                            gr[MOM ? tq : 0][u] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(fb[tq], bsel, gr[MOM ? tq : 0][u], 0, 0, 0);
+                        }
+                    if (cg == 0) {
+                        typedef __bf16 v2 __attribute__((ext_vector_type(2)));
+                        const v2 one = {(__bf16)1.0f, (__bf16)1.0f};
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            const uint2 w = __builtin_bit_cast(uint2, fb[t]);
+                            vs[t] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(v2, w.x), one, vs[t], false);
+                            vs[t] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(v2, w.y), one, vs[t], false);
+                        }
                     }
                 }
                 if (MODE == 3) {
                     const uint4 q0 = make_uint4(bt_pack2(gz[0], gz[1]), bt_pack2(gz[2], gz[3]), bt_pack2(gz[4], gz[5]), bt_pack2(gz[6], gz[7]));
                     const uint4 q1 = make_uint4(bt_pack2(gz[8], gz[9]), bt_pack2(gz[10], gz[11]), bt_pack2(gz[12], gz[13]), bt_pack2(gz[14], gz[15]));
-                    if (ok) {
+                    if (ok && p.out) {                          // (NULL: conv2's weight gradient comes from the moments, nobody reads gz3)
                         *reinterpret_cast<uint4*>(p.out + eoff) = q0;
                         *reinterpret_cast<uint4*>(p.out + eoff + 8) = q1;
                     }
@@ -398,6 +479,72 @@ __global__ __launch_bounds__(BT_THREADS, MODE == 1 ? 3 : 2) void block_tail_kern
         }
         if (MODE == 3) load_e(it + DEPTH, ring_e[d]);
       }
+    }
+    if (MOM && NRG > 1) {
+        // the row groups of the workgroup fold into row group 0 through LDS, one at a time in a fixed order (the fragments and tiles are
+        // dead): one slab per workgroup instead of NRG — at Cout 64 the slabs would otherwise outweigh the tensors the moments replace
+        constexpr int PER = 64 + 16 * NTC + 4;                               // floats per lane: m1, gr, vs
+        float* fb = reinterpret_cast<float*>(bt_lds) + (size_t)cg * PER * 64 + lane;
+        __syncthreads();
+        for (int w = 1; w < NRG; ++w) {
+            if (rg == w) {
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+#pragma unroll
+                    for (int b = 0; b < 4; ++b)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) fb[((a * 4 + b) * 4 + r) * 64] = m1[MOM ? a : 0][MOM ? b : 0][r];
+#pragma unroll
+                    for (int u = 0; u < NTC; ++u)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) fb[(64 + (a * NTC + u) * 4 + r) * 64] = gr[MOM ? a : 0][u][r];
+                    fb[(64 + 16 * NTC + a) * 64] = vs[a];
+                }
+            }
+            __syncthreads();
+            if (rg == 0) {
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+#pragma unroll
+                    for (int b = 0; b < 4; ++b)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) m1[MOM ? a : 0][MOM ? b : 0][r] += fb[((a * 4 + b) * 4 + r) * 64];
+#pragma unroll
+                    for (int u = 0; u < NTC; ++u)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) gr[MOM ? a : 0][u][r] += fb[(64 + (a * NTC + u) * 4 + r) * 64];
+                    vs[a] += fb[(64 + 16 * NTC + a) * 64];
+                }
+            }
+            __syncthreads();
+        }
+    }
+    if (MOM && rg == 0) {
+        // this wave's part of the workgroup's slab: M1 rows of its slab, its Gram column tiles, v (slab 0's wave)
+        float* slab = p.mom + (int64_t)blockIdx.x * (COUT * 64 + 64 * 64 + 64);
+#pragma unroll
+        for (int to = 0; to < 4; ++to)
+#pragma unroll
+            for (int tc = 0; tc < 4; ++tc)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    slab[(64 * cg + 16 * to + 4 * lk + r) * 64 + 16 * tc + li] = m1[MOM ? to : 0][MOM ? tc : 0][r];
+#pragma unroll
+        for (int tq = 0; tq < 4; ++tq)
+#pragma unroll
+            for (int u = 0; u < NTC; ++u)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    slab[COUT * 64 + (16 * tq + 4 * lk + r) * 64 + 16 * (cg * NTC + u) + li] = gr[MOM ? tq : 0][u][r];
+        if (cg == 0) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                float v = vs[t];
+                v += __shfl_xor(v, 16);
+                v += __shfl_xor(v, 32);
+                if (lk == 0) slab[COUT * 64 + 64 * 64 + 16 * t + li] = v;
+            }
+        }
     }
     if (MODE == 0 || MODE == 2 || (MODE == 3 && p.part2)) {
         // per-workgroup partial sums of every channel: fold the 16 rows of the tiles, then the row groups (mode 3: BatchNorm2's
@@ -518,7 +665,12 @@ static int bt_launch(const BtParams& p, int grid, hipStream_t st) {
     if (p.slope2 == 0.f) fn = CG == 1 ? (void*)block_tail_kernel<MODE, 1, NA, true> : (CG == 2 ? (void*)block_tail_kernel<MODE, 2, NA, true> : (void*)block_tail_kernel<MODE, 4, NA, true>);
     else fn = CG == 1 ? (void*)block_tail_kernel<MODE, 1, NA, false> : (CG == 2 ? (void*)block_tail_kernel<MODE, 2, NA, false> : (void*)block_tail_kernel<MODE, 4, NA, false>);
     const int ncst = MODE == 0 ? 1 : (MODE == 3 ? 4 : 2);
-    const int lds = CG * 8 * 64 * 16 * (MODE == 3 ? 2 : 1) + ncst * p.Cout * 4 + ((MODE == 0 || MODE == 2) ? BT_WAVES * 2 * p.Cout * 4 : 128 * 4);
+    int lds = CG * 8 * 64 * 16 * (MODE == 3 ? 2 : 1) + ncst * p.Cout * 4 + ((MODE == 0 || MODE == 2) ? BT_WAVES * 2 * p.Cout * 4 : 128 * 4)
+              + ((MODE == 2 && NA == 1) ? 512 + BT_WAVES * 4096 : 0);
+    if (MODE == 2 && NA == 1 && CG < 4) {                  // the in-workgroup fold of the moments: CG waves x (64 + 16 (4 / CG) + 4) floats per lane
+        const int fold = CG * (64 + 16 * (4 / CG) + 4) * 64 * 4;
+        if (fold > lds) lds = fold;
+    }
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "hipFuncSetAttribute(%d B LDS): %s", lds, hipGetErrorString(e));
@@ -594,25 +746,90 @@ extern "C" int fgnn_block_tail_apply(const void* e, const float* scale2, const f
     }
 }
 
-extern "C" int fgnn_block_tail_backward(const void* e, const float* scale2, const float* shift2, float slope2,
-                                        const float* W2, const float* b2, const float* mean3, const float* invstd3,
-                                        const float* gamma3, const float* scale3, const float* shift3, float slope3,
-                                        const void* gout, void* gz3, void* ga2, float* gweight3, float* gbias3,
-                                        const float* mean2, const float* invstd2, float* gweight2, float* gbias2, float* bn2_dsum,
-                                        int64_t R, int Cout, void* workspace, int64_t workspace_bytes, void* fold_scratch,
-                                        fgnn_stream_t stream) {
+// ----------------------------------------------------------------------------------------
+// conv2's weight gradient from the moments of the "reduce" pass (see the top of this file)
+// ----------------------------------------------------------------------------------------
+// moments buffer (floats): [nslab][slab_len] slabs | A [Cout] | Bc [Cout] | T [slab_len] (the folded moments), slab_len = Cout*64 + 64*64 + 64,
+// nslab = workgroups of the reduce pass
+static int64_t bt_mom_slab_len(int Cout) { return (int64_t)Cout * 64 + 64 * 64 + 64; }
+static int bt_mom_nslab(int64_t R, int Cout) {
+    int grid;
+    if (bt_plan(R, Cout, &grid)) return 0;
+    return grid;                                           // one slab per workgroup of the reduce pass (its row groups fold in LDS)
+}
+extern "C" int64_t fgnn_block_tail_moments_bytes(int64_t R, int Cout) {
+    const int n = bt_mom_nslab(R, Cout);
+    return n ? ((int64_t)(n + 1) * bt_mom_slab_len(Cout) + 2 * Cout) * 4 : 0;
+}
+
+// gW2[o][c] += s3[o] M1[o][c] + A[o] sum_c' bf16(W2[o][c']) Gram[c'][c] + (A[o] b2[o] + Bc[o]) v[c]   from the FOLDED moments T
+__global__ __launch_bounds__(256) void block_tail_wgrad_combine_kernel(const float* __restrict__ T, const float* __restrict__ W2,
+                                                                       const float* __restrict__ b2, const float* __restrict__ s3,
+                                                                       const float* __restrict__ A, const float* __restrict__ Bc,
+                                                                       float* __restrict__ gW2, int Cout) {
+    __shared__ float G[64 * 64];
+    __shared__ float w[4][64];
+    const int tid = threadIdx.x, ol = tid >> 6, c = tid & 63, o = blockIdx.x * 4 + ol;
+    const float* Gp = T + (int64_t)Cout * 64;
+    for (int f = tid; f < 64 * 64; f += 256) G[f] = Gp[f];
+    {
+        const __bf16 h = (__bf16)W2[(int64_t)o * 64 + c];                   // the operand the matrix cores multiplied a2 with
+        w[ol][c] = __uint_as_float((unsigned)__builtin_bit_cast(uint16_t, h) << 16);
+    }
+    __syncthreads();
+    float m2 = 0.f;
+#pragma unroll 16
+    for (int q = 0; q < 64; ++q) m2 = fmaf(w[ol][q], G[q * 64 + c], m2);
+    const float a = A[o], k = fmaf(a, b2 ? b2[o] : 0.f, Bc[o]);
+    gW2[(int64_t)o * 64 + c] += fmaf(s3[o], T[(int64_t)o * 64 + c], fmaf(a, m2, k * Gp[64 * 64 + c]));
+}
+
+void fgnn_launch_slab_store(const float* ws, int nslab, int64_t slab_len, float* out, hipStream_t st);     // mpconv_bwd_res.hip
+
+// Fold the moments fgnn_block_tail_backward_moments left and ADD conv2's weight gradient to gW2 [Cout][64] (two short launches; nothing
+// in a backward pass reads a weight gradient: callers park this call like any other weight-gradient launch).
+extern "C" int fgnn_block_tail_wgrad_finish(void* moments, int64_t moments_bytes, int64_t R, int Cout, const float* W2, const float* b2,
+                                            const float* scale3, float* gW2, fgnn_stream_t stream) {
+    const int nslab = bt_mom_nslab(R, Cout);
+    if (!moments || !W2 || !scale3 || !gW2) FGNN_FAIL(FGNN_EINVAL, "block_tail_wgrad_finish: null pointer");
+    if (!nslab || moments_bytes < fgnn_block_tail_moments_bytes(R, Cout)) FGNN_FAIL(FGNN_EINVAL, "block_tail_wgrad_finish: bad sizes");
+    const int64_t len = bt_mom_slab_len(Cout);
+    float* m = (float*)moments;
+    float* A = m + (int64_t)nslab * len;
+    float* Bc = A + Cout;
+    float* T = Bc + Cout;
+    hipStream_t st = (hipStream_t)stream;
+    fgnn_launch_slab_store(m, nslab, len, T, st);
+    hipLaunchKernelGGL(block_tail_wgrad_combine_kernel, dim3(Cout / 4), dim3(256), 0, st, T, W2, b2, scale3, A, Bc, gW2, Cout);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "block_tail_wgrad_finish launch: %s", hipGetErrorString(e));
+    return FGNN_OK;
+}
+
+static int bt_backward(const void* e, const float* scale2, const float* shift2, float slope2,
+                       const float* W2, const float* b2, const float* mean3, const float* invstd3,
+                       const float* gamma3, const float* scale3, const float* shift3, float slope3,
+                       const void* gout, void* gz3, void* ga2, float* gweight3, float* gbias3,
+                       const float* mean2, const float* invstd2, float* gweight2, float* gbias2, float* bn2_dsum,
+                       int64_t R, int Cout, void* workspace, int64_t workspace_bytes, void* fold_scratch,
+                       float* moments, int64_t moments_bytes, fgnn_stream_t stream) {
     int grid, rc;
     if ((rc = bt_check("block_tail_backward", e, scale2, shift2, W2, R, Cout, &grid))) return rc;
-    if (!mean3 || !invstd3 || !gamma3 || !scale3 || !shift3 || !gout || !gz3 || !ga2 || !workspace)
+    if (!mean3 || !invstd3 || !gamma3 || !scale3 || !shift3 || !gout || (!gz3 && !moments) || !ga2 || !workspace)
         FGNN_FAIL(FGNN_EINVAL, "block_tail_backward: null pointer");
+    if (moments && moments_bytes < fgnn_block_tail_moments_bytes(R, Cout)) FGNN_FAIL(FGNN_EINVAL, "block_tail_backward: moments buffer too small");
     if (bn2_dsum && (!mean2 || !invstd2)) FGNN_FAIL(FGNN_EINVAL, "block_tail_backward: bn2_dsum needs mean2 / invstd2");
-    if (((uintptr_t)gout | (uintptr_t)gz3 | (uintptr_t)ga2) & 15) FGNN_FAIL(FGNN_EUNSUPPORTED, "block_tail_backward: misaligned operand");
+    if (((uintptr_t)gout | (uintptr_t)gz3 | (uintptr_t)ga2 | (uintptr_t)moments) & 15) FGNN_FAIL(FGNN_EUNSUPPORTED, "block_tail_backward: misaligned operand");
     if (workspace_bytes < ((int64_t)BT_MAXGRID * 2 * Cout + 2 * Cout + (int64_t)BT_MAXGRID * 128) * 4)
         FGNN_FAIL(FGNN_EINVAL, "block_tail_backward: workspace too small");
     float* ws = (float*)workspace;
     float* A = ws + (int64_t)BT_MAXGRID * 2 * Cout;
     float* Bc = A + Cout;
     float* part2 = Bc + Cout;                              // [grid3][2][64] BatchNorm2's partial rows
+    if (moments) {     // the per-channel constants outlive this call's shared workspace: fgnn_block_tail_wgrad_finish reads them later
+        A = moments + (int64_t)bt_mom_nslab(R, Cout) * bt_mom_slab_len(Cout);
+        Bc = A + Cout;
+    }
     hipStream_t st = (hipStream_t)stream;
     const bool inkernel = fold_scratch && !fgnn_separate_finalisers();
     BtParams p = {};
@@ -620,7 +837,8 @@ extern "C" int fgnn_block_tail_backward(const void* e, const float* scale2, cons
     p.gout = (const uint16_t*)gout; p.part = ws; p.R = (int)R; p.Cout = Cout; p.slope2 = slope2; p.slope3 = slope3;
     p.mean3 = mean3; p.invstd3 = invstd3; p.gamma3 = gamma3; p.A = A; p.Bc = Bc; p.gweight3 = gweight3; p.gbias3 = gbias3;
     p.fold = fgnn_fold_make(ws, inkernel ? fold_scratch : nullptr, grid, Cout);
-    if ((rc = bt_launch<2>(p, grid, st))) return rc;
+    p.mom = moments;
+    if ((rc = moments ? bt_launch<2, 1>(p, grid, st) : bt_launch<2>(p, grid, st))) return rc;
     int grid3;
     (void)bt_plan(R, Cout, &grid3, false);
     if (!inkernel)
@@ -635,6 +853,33 @@ extern "C" int fgnn_block_tail_backward(const void* e, const float* scale2, cons
     hipError_t e2 = hipGetLastError();
     if (e2 != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "block_tail_backward launch: %s", hipGetErrorString(e2));
     return FGNN_OK;
+}
+
+extern "C" int fgnn_block_tail_backward(const void* e, const float* scale2, const float* shift2, float slope2,
+                                        const float* W2, const float* b2, const float* mean3, const float* invstd3,
+                                        const float* gamma3, const float* scale3, const float* shift3, float slope3,
+                                        const void* gout, void* gz3, void* ga2, float* gweight3, float* gbias3,
+                                        const float* mean2, const float* invstd2, float* gweight2, float* gbias2, float* bn2_dsum,
+                                        int64_t R, int Cout, void* workspace, int64_t workspace_bytes, void* fold_scratch,
+                                        fgnn_stream_t stream) {
+    if (!gz3) FGNN_FAIL(FGNN_EINVAL, "block_tail_backward: null pointer");
+    return bt_backward(e, scale2, shift2, slope2, W2, b2, mean3, invstd3, gamma3, scale3, shift3, slope3, gout, gz3, ga2, gweight3, gbias3,
+                       mean2, invstd2, gweight2, gbias2, bn2_dsum, R, Cout, workspace, workspace_bytes, fold_scratch, nullptr, 0, stream);
+}
+
+// The same, with the MOMENTS of conv2's weight gradient accumulated by the reduce pass into `moments`
+// (fgnn_block_tail_moments_bytes(R, Cout) bytes, owned by the caller until fgnn_block_tail_wgrad_finish has run); gz3 may then be NULL.
+extern "C" int fgnn_block_tail_backward_moments(const void* e, const float* scale2, const float* shift2, float slope2,
+                                                const float* W2, const float* b2, const float* mean3, const float* invstd3,
+                                                const float* gamma3, const float* scale3, const float* shift3, float slope3,
+                                                const void* gout, void* gz3, void* ga2, float* gweight3, float* gbias3,
+                                                const float* mean2, const float* invstd2, float* gweight2, float* gbias2, float* bn2_dsum,
+                                                int64_t R, int Cout, void* workspace, int64_t workspace_bytes, void* fold_scratch,
+                                                void* moments, int64_t moments_bytes, fgnn_stream_t stream) {
+    if (!moments) FGNN_FAIL(FGNN_EINVAL, "block_tail_backward_moments: null pointer");
+    return bt_backward(e, scale2, shift2, slope2, W2, b2, mean3, invstd3, gamma3, scale3, shift3, slope3, gout, gz3, ga2, gweight3, gbias3,
+                       mean2, invstd2, gweight2, gbias2, bn2_dsum, R, Cout, workspace, workspace_bytes, fold_scratch, (float*)moments,
+                       moments_bytes, stream);
 }
 
 // ----------------------------------------------------------------------------------------

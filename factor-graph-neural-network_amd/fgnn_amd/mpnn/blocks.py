@@ -128,6 +128,7 @@ def _is_identity_list(nn_idx):
     return ops.is_identity_list(nn_idx)
 
 
+TAIL_WGRAD_MOMENTS = True    # training: conv2's weight gradient from the moments of the tail's reduce pass (no gz3 / a2 in memory)
 FUSE_TRAIN_TAIL = True       # training: BatchNorm2 + ReLU -> conv2 -> BatchNorm3 + LeakyReLU (+ addends) without storing conv2's output
 
 
@@ -304,7 +305,8 @@ class _BlockTail(torch.autograd.Function):
         st2 = pointwise.batch_stats(e, (w2, b2, rm2, rv2, nbt2, momentum2, eps2), population)         # mean, invstd, scale, shift
         ws = ops._workspace(dev, int(L.fgnn_bn_workspace_bytes(R, Cout)))
         fold = ops._fold_scratch(dev)
-        a2 = torch.empty_like(e)
+        # a2 is stored only for a weight-gradient KERNEL; with the moments form (TAIL_WGRAD_MOMENTS) the backward recomputes it
+        a2 = None if TAIL_WGRAD_MOMENTS else torch.empty_like(e)
         W2c = W2.detach()
         bias2c = None if bias2 is None else bias2.detach()
         flops = 2 * R * 64 * Cout
@@ -354,7 +356,8 @@ class _BlockTail(torch.autograd.Function):
         Wbase = pW2._base if pW2._base is not None and pW2._base.numel() == pW2.numel() else pW2
         gW2, s_W2 = sink(Wbase, (Cout, 64))
         gbias2, s_bias2 = sink(pbias2, (Cout,)) if ctx.has_bias2 else (None, True)
-        gz3 = torch.empty((R, Cout), device=dev, dtype=e.dtype)
+        moments = a2 is None
+        gz3 = None if moments else torch.empty((R, Cout), device=dev, dtype=e.dtype)
         ga2 = torch.empty_like(e)
         nws = (2048 * Cout + 2 * Cout + 1024 * 128) * 4
         ws = ops._workspace(dev, max(nws, int(L.fgnn_linear_wgrad_workspace_bytes(R, 64, Cout))))
@@ -362,12 +365,23 @@ class _BlockTail(torch.autograd.Function):
         bias2c = None if pbias2 is None else pbias2.detach()
         # BatchNorm3 backward (sums, parameter gradients, input gradient gz3) + ga2 = gz3 W2 + BatchNorm2's backward sums and
         # parameter gradients: two launches
-        ops.timed('block_tail_backward (reduce + grad)', 2 * R * (2 * 64 + 2 * Cout + 64 + Cout),
-                  lambda: _hip.check(L.fgnn_block_tail_backward(
-                      P(e), P(st2[2]), P(st2[3]), slope2, P(W2.detach()), P(bias2c), P(st3[0]), P(st3[1]), P(w3.detach()), P(st3[2]),
-                      P(st3[3]), slope3, P(gout), P(gz3), P(ga2), P(gw3), P(gb3), P(st2[0]), P(st2[1]), P(gw2), P(gb2), P(dsum2),
-                      R, Cout, P(ws), ws.numel() * 4, P(ops._fold_scratch(dev)), _hip.stream_ptr())),
-                  nflops=6 * R * 64 * Cout)
+        if moments:
+            # conv2's weight gradient is a closed form of three moments the reduce pass accumulates (csrc/block_tail.hip): neither gz3
+            # nor a2 exists in memory; the buffer (slabs, A, Bc) is this call's own until the finish launch below has run
+            mom = torch.empty(int(L.fgnn_block_tail_moments_bytes(R, Cout)) // 4, device=dev, dtype=torch.float32)
+            ops.timed('block_tail_backward (reduce + moments + grad)', 2 * R * (2 * 64 + 2 * Cout + 64),
+                      lambda: _hip.check(L.fgnn_block_tail_backward_moments(
+                          P(e), P(st2[2]), P(st2[3]), slope2, P(W2.detach()), P(bias2c), P(st3[0]), P(st3[1]), P(w3.detach()), P(st3[2]),
+                          P(st3[3]), slope3, P(gout), None, P(ga2), P(gw3), P(gb3), P(st2[0]), P(st2[1]), P(gw2), P(gb2), P(dsum2),
+                          R, Cout, P(ws), ws.numel() * 4, P(ops._fold_scratch(dev)), P(mom), mom.numel() * 4, _hip.stream_ptr())),
+                      nflops=8 * R * 64 * Cout)
+        else:
+            ops.timed('block_tail_backward (reduce + grad)', 2 * R * (2 * 64 + 2 * Cout + 64 + Cout),
+                      lambda: _hip.check(L.fgnn_block_tail_backward(
+                          P(e), P(st2[2]), P(st2[3]), slope2, P(W2.detach()), P(bias2c), P(st3[0]), P(st3[1]), P(w3.detach()), P(st3[2]),
+                          P(st3[3]), slope3, P(gout), P(gz3), P(ga2), P(gw3), P(gb3), P(st2[0]), P(st2[1]), P(gw2), P(gb2), P(dsum2),
+                          R, Cout, P(ws), ws.numel() * 4, P(ops._fold_scratch(dev)), _hip.stream_ptr())),
+                      nflops=6 * R * 64 * Cout)
         # BatchNorm2 + activation backward on the 64-channel tensor: one element-wise pass (no reduction pass, no finaliser)
         ge = torch.empty_like(e)
         ops.timed('bn_backward (apply)', 3 * e.numel() * 2, lambda: _hip.check(L.fgnn_bn_backward_apply(
@@ -377,14 +391,24 @@ class _BlockTail(torch.autograd.Function):
         # bucket (ops.defer_wgrad: nothing in the backward reads it)
         record = s_W2 and s_bias2 and ops.folds_deferrable()
 
-        def launch(a2=a2, gz3=gz3, gW2=gW2, gbias2=gbias2):
-            with ops.fold_scope(record) as scope:
-                wsw = scope.slabs(dev, int(L.fgnn_linear_wgrad_workspace_bytes(R, 64, Cout)))
-                ops.timed('linear_wgrad_b16_kernel', 2 * R * (64 + Cout), lambda: _hip.check(L.fgnn_linear_wgrad(
-                    P(a2), P(gz3), R, 64, Cout, _hip.BF16, P(gW2.view(Cout, 64)), P(gbias2), P(wsw), wsw.numel() * 4, _hip.stream_ptr())),
-                    nflops=2 * R * 64 * Cout)
+        if moments:
+            scale3 = st3[2]
+
+            def launch(mom=mom, gW2=gW2, scale3=scale3, W2d=W2.detach(), bias2c=bias2c):
+                # (conv2's BIAS gradient in front of a batch-statistics BatchNorm is identically zero — sum gz3 = 0 — nothing is added to it)
+                ops.timed('block_tail_wgrad_finish (fold + combine)', 4 * mom.numel(), lambda: _hip.check(L.fgnn_block_tail_wgrad_finish(
+                    P(mom), mom.numel() * 4, R, Cout, P(W2d), P(bias2c), P(scale3), P(gW2.view(Cout, 64)), _hip.stream_ptr())))
+            operands = (mom, scale3)
+        else:
+            def launch(a2=a2, gz3=gz3, gW2=gW2, gbias2=gbias2):
+                with ops.fold_scope(record) as scope:
+                    wsw = scope.slabs(dev, int(L.fgnn_linear_wgrad_workspace_bytes(R, 64, Cout)))
+                    ops.timed('linear_wgrad_b16_kernel', 2 * R * (64 + Cout), lambda: _hip.check(L.fgnn_linear_wgrad(
+                        P(a2), P(gz3), R, 64, Cout, _hip.BF16, P(gW2.view(Cout, 64)), P(gbias2), P(wsw), wsw.numel() * 4, _hip.stream_ptr())),
+                        nflops=2 * R * 64 * Cout)
+            operands = (a2, gz3)
         if s_W2 and s_bias2:
-            ops.defer_wgrad(launch, (a2, gz3))
+            ops.defer_wgrad(launch, operands)
         else:
             launch()
         ha = ctx.has_add

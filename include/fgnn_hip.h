@@ -323,6 +323,23 @@ int fgnn_block_tail_backward(const void* e, const float* scale2, const float* sh
                              float* gbias2, float* bn2_dsum, int64_t R, int32_t Cout, void* workspace, int64_t workspace_bytes,
                              void* fold_scratch, fgnn_stream_t stream);
 int fgnn_block_tail_backward_partials(int64_t R, int32_t Cout);   /* workgroups (= BatchNorm2 partial rows) of the backward's grad launch */
+/* conv2's WEIGHT gradient without a stored gz3 / a2 (ABI 12).  gz3 = scale3 g' + A (z3 - b2) + (A b2 + Bc) is affine in what the reduce
+ * pass of the backward already holds, so  gW2 = diag(scale3) M1 + diag(A) (bf16(W2) Gram) + (A b2 + Bc) v^T  with the moments
+ * M1 = sum_rows g' a2^T [Cout][64], Gram = sum_rows a2 a2^T [64][64], v = sum_rows a2 [64].  fgnn_block_tail_backward_moments is
+ * fgnn_block_tail_backward whose reduce launch also accumulates the moments into `moments` (fgnn_block_tail_moments_bytes(R, Cout)
+ * bytes, 16-byte aligned, owned by the caller until the finish call has run; it also keeps A and Bc); gz3 may then be NULL (not stored).
+ * fgnn_block_tail_wgrad_finish folds the moments and ADDS conv2's weight gradient to gW2 [Cout][64] f32 (two short launches, to be
+ * issued any time before the optimizer).  conv2's bias gradient in front of a batch-statistics BatchNorm is identically zero.
+ * Replaces fgnn_linear_wgrad(a2, gz3) behind /root/reference/lib/model/mpnn/mp_nn_residual.py:31-35 (autograd of self.conv2). */
+int64_t fgnn_block_tail_moments_bytes(int64_t R, int32_t Cout);
+int fgnn_block_tail_backward_moments(const void* e, const float* scale2, const float* shift2, float slope2, const float* W2,
+                                     const float* b2, const float* mean3, const float* invstd3, const float* gamma3,
+                                     const float* scale3, const float* shift3, float slope3, const void* gout, void* gz3, void* ga2,
+                                     float* gweight3, float* gbias3, const float* mean2, const float* invstd2, float* gweight2,
+                                     float* gbias2, float* bn2_dsum, int64_t R, int32_t Cout, void* workspace, int64_t workspace_bytes,
+                                     void* fold_scratch, void* moments, int64_t moments_bytes, fgnn_stream_t stream);
+int fgnn_block_tail_wgrad_finish(void* moments, int64_t moments_bytes, int64_t R, int32_t Cout, const float* W2, const float* b2,
+                                 const float* scale3, float* gW2, fgnn_stream_t stream);
 
 /*
  * HEAD of a training-mode `mp_conv_residual`, backward: autograd through `self.conv1` = Conv2d(nin, nmed, 1) -> BatchNorm2d ->
@@ -546,8 +563,9 @@ const char* fgnn_last_kernel(void);
  * (fgnn_amd/_hip.py: ABI_VERSION) checks it BEFORE binding symbols, so a stale library is reported as a version
  * mismatch and not as a missing symbol or a misread field.  4: round-2 additions (flat_adam, factor_layer_*,
  * ldpc_channel_features_rng, backward_reduces_getype, desc.reserved = in-degree | GETYPE_REDUCED); 5: fgnn_block_tail_*;
- * 6: fgnn_block_head_backward.  11: fgnn_mpconv_block_forward_rows. */
-#define FGNN_ABI_VERSION 11
+ * 6: fgnn_block_head_backward.  11: fgnn_mpconv_block_forward_rows.  12: fgnn_block_tail_backward_moments,
+ * fgnn_block_tail_wgrad_finish, fgnn_block_tail_moments_bytes. */
+#define FGNN_ABI_VERSION 12
 int fgnn_abi_version(void);
 
 #ifdef __cplusplus

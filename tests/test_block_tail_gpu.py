@@ -550,3 +550,50 @@ def test_inference_fanout_block_runs_on_one_row_and_rides_as_a_row_addend(nin, n
         assert torch.equal(y_row, y_full)
         y_first = parity(xf, idx, et, addend=[h, other])         # the row addend in the first slot
         assert H.rel_err(y_first.float(), y_full.float()) <= 2.0 ** -7      # (other summation order of the two addends)
+
+
+@pytest.mark.parametrize('case', [(64, 64, 96, 48, 6, 4), (128, 256, 96, 48, 6, 4), (256, 128, 48, 96, 3, 4), (64, 64, 96, 1, 96, 1)],
+                         ids=lambda c: 'x'.join(map(str, c)))
+@pytest.mark.parametrize('B', [40, 171])
+def test_conv2_weight_gradient_from_the_reduce_pass_moments(case, B, dev, monkeypatch):
+    """Round 6: conv2's weight gradient as a closed form of three moments the tail's reduce pass accumulates (csrc/block_tail.hip:
+    gW2 = diag(s3) M1 + diag(A) (W2b Gram) + K v^T) against the kernel form (gz3 and a2 stored, fgnn_linear_wgrad over them) on the same
+    block: every other gradient is bit-identical (the moments do not touch them), conv2.weight agrees to the kernel form's own
+    rounding (it contracts a bf16-rounded gz3), conv2.bias receives nothing (its gradient is identically zero in front of a
+    batch-statistics BatchNorm; the kernel form adds rounding noise), and a second run is bit-identical."""
+    from fgnn_amd.mpnn import blocks, mp_conv_residual, mp_conv_type
+    nin, nout, N, M, k, net = case
+    g = torch.Generator().manual_seed(nin + nout + M + B)
+    torch.manual_seed(5)
+    m = mp_conv_residual(nin, 64, net, extension=mp_conv_type.NO_EXTENSION, with_residual=False, aggregator='max',
+                         nout=None if nout == nin else nout).to(dev).train()
+    with torch.no_grad():
+        m.mp_conv.filters.mul_(10.0)
+    x = torch.randn(B, N, 1, nin, generator=g).bfloat16().to(dev).permute(0, 3, 1, 2)
+    idx = (torch.arange(N).reshape(1, 1, N) if M == 1 else torch.randint(0, N, (1, M, k), generator=g)).to(dev).expand(B, -1, -1)
+    et = torch.randn(B, M, k, net, generator=g).bfloat16().to(dev).permute(0, 3, 1, 2)
+    gy = torch.randn(B, M, 1, nout, generator=g).bfloat16().to(dev).permute(0, 3, 1, 2)
+    sd0 = {k_: v.clone() for k_, v in m.state_dict().items()}
+
+    def run(moments):
+        monkeypatch.setattr(blocks, 'TAIL_WGRAD_MOMENTS', moments)
+        m.load_state_dict(sd0)
+        for q in m.parameters():
+            q.grad = None
+        xd, ed = x.detach().requires_grad_(True), et.detach().requires_grad_(True)
+        with torch.autocast('cuda', dtype=torch.bfloat16):
+            y = m(xd, idx, ed)
+        y.backward(gy)
+        out = {'y': y.detach().clone(), 'gx': xd.grad.clone(), 'get': ed.grad.clone()}
+        out.update({n: q.grad.detach().clone() for n, q in m.named_parameters()})
+        return out
+    a, b, a2 = run(True), run(False), run(True)
+    for n in a:
+        assert torch.equal(a[n], a2[n]), n                     # bit-reproducible
+        if n not in ('conv2.0.weight', 'conv2.0.bias'):
+            assert torch.equal(a[n], b[n]), n                  # untouched by the moments
+    gw_m, gw_k = a['conv2.0.weight'].float(), b['conv2.0.weight'].float()
+    scale = float(gw_k.abs().max())
+    assert scale > 0 and float((gw_m - gw_k).abs().max()) <= 2e-2 * scale, (float((gw_m - gw_k).abs().max()), scale)
+    assert float(a['conv2.0.bias'].abs().max()) == 0.0
+    assert float(b['conv2.0.bias'].abs().max()) <= 1e-2 * scale + 1e-3        # (the kernel form's bias gradient: rounding noise around zero)
