@@ -699,6 +699,11 @@ def main():
     fence()
     _trace('warmup done')
     trace_steps = os.environ.get('FGNN_BENCH_STEP_TIMES') is not None   # diagnosis: per-step wall times (adds a device sync per step)
+    host_times = os.environ.get('FGNN_BENCH_HOST_TIMES') is not None    # diagnosis: how far ahead of the device does the host run?
+    marks, host_done = [], []
+    if host_times:
+        e0 = torch.cuda.Event(enable_timing=True)
+        e0.record()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         t1 = time.perf_counter()
@@ -706,9 +711,22 @@ def main():
         if trace_steps:
             torch.cuda.synchronize()
             print('rank %d step %.3f ms' % (rank, (time.perf_counter() - t1) * 1e3), file=sys.stderr)
+        if host_times:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            marks.append(e)
+            host_done.append((time.perf_counter() - t0) * 1e3)
+    host_enqueue = time.perf_counter() - t0      # the host's share: when it is close to `elapsed` the replay is launch-bound
     fence()
     elapsed = time.perf_counter() - t0
     _trace('timed steps done')
+    if host_times:
+        print('rank %d: host enqueue %.3f ms per step, wall %.3f ms per step' % (rank, host_enqueue / args.steps * 1e3, elapsed / args.steps * 1e3),
+              file=sys.stderr)
+        print('   step: host returned at / device finished at (ms from the loop start): ' +
+              ' '.join('%.1f/%.1f' % (h, e0.elapsed_time(m)) for h, m in zip(host_done, marks)), file=sys.stderr)
+    if graphed is not None and getattr(graphed, 'stamps', None):
+        graphed.stamp_report(sys.stderr)
     dist_info = dist_report(world, dev, elapsed, args.steps)
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)

@@ -37,3 +37,13 @@ extern "C" int64_t fgnn_mpconv_algorithmic_bytes(const fgnn_mpconv_desc* d) {
     bytes += 4 * (R * d->nou * d->net + 5 * (int64_t)d->nou);
     return bytes;
 }
+
+// diagnostic: one device timestamp (the 100 MHz constant clock) written by a one-thread kernel on `stream` — placed inside a
+// captured step it tells when that point of the stream is reached in a replay WITHOUT a profiler attached (tools/stamps.py)
+__global__ void fgnn_stamp_kernel(unsigned long long* dst) { *dst = wall_clock64(); }
+
+extern "C" int fgnn_stamp(void* dst, void* stream) {
+    if (!dst) { fgnn_set_error("fgnn_stamp: null destination"); return FGNN_EINVAL; }
+    hipLaunchKernelGGL(fgnn_stamp_kernel, dim3(1), dim3(1), 0, static_cast<hipStream_t>(stream), static_cast<unsigned long long*>(dst));
+    return FGNN_OK;
+}

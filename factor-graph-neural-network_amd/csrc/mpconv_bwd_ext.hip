@@ -54,6 +54,10 @@ struct BxParams {
     long long slab_len, get_len;
     long long* prof;         // FGNN_PROF (builds with -DFGNN_ENABLE_PROF only): phase timeline of one stage
     int dbg;                 // prof builds: FGNN_EXT_DBG bits switch parts of phase B off (timing experiments)
+    // split form (mpconv_bwd_extq_kernel): the filters as bf16 pieces, written by bq_prep_kernel into the workspace
+    const uint16_t* wq1;     // [piece][S | T][column 0..1023][c 0..63]   (B operand of P = x W: 8 consecutive input channels per lane)
+    const uint16_t* wq2;     // [piece][S | T][c 0..63][column 0..1023]   (B operand of gx = dP Wc: 8 consecutive columns per lane)
+    int off_xq, off_dq;      // LDS: x pieces [piece][64][64] bf16, dP pieces [piece][64][128] bf16 (off_dq == off_ps: dP overwrites P)
 };
 
 extern __shared__ __attribute__((aligned(16))) unsigned char bx_lds[];
@@ -510,6 +514,516 @@ __global__ __launch_bounds__(BX_THREADS, 2) void mpconv_bwd_ext_kernel(const BxP
     }
 }
 
+
+// =====================================================================================================================
+// Split form (round 6): the three GEMMs of a stage on the bf16 matrix cores with every f32 operand cut into NP bf16
+// pieces (x = h + m + l: three 8-bit mantissa pieces, exact to 2^-24 — the arithmetic mpconv_fwd_extp_kernel uses for the
+// forward; NP = 2 keeps h + l: 2^-17).  The exact-f32 kernel above is bound by the f32 matrix pipe (192 v_mfma_f32_16x16x4_f32
+// = 6 144 cycles per wave and stage: 0.43 of the 157 TF f32 roof at B = 1024, and 42 % of the kernel time of BASELINE config 5's
+// training step); the same products as bf16 pieces are 24 fragment products x 6 (NP = 3) or x 3 (NP = 2) v_mfma_f32_16x16x32_bf16
+// of 16 cycles: 2 304 / 1 152 cycles.  What changes:
+//   * the filters arrive as bf16 pieces in both operand layouts (bq_prep_kernel, once per call): a pass's B operands are 18
+//     16-byte loads per lane instead of 96 scalar loads + their combination;
+//   * x and dP live in LDS as bf16 PIECE images (x: 128-byte rows, dP: 256-byte rows; 32-byte segments XOR-swizzled by the row so
+//     that the 16-byte operand reads AND the transpose reads are conflict-free); P stays f32 (the edge-type gradient reads it);
+//   * gW's node-contracted operands (x^T, dP with K = nodes) come out of the row-major piece images through ds_read_b64_tr_b16.
+// Max aggregation, 64 output channels; everything else (tables, phases B1 / dS / dT, slabs, fixed summation orders) is the
+// exact kernel's.  Same bits run to run.
+typedef __bf16 bq_bf16x8 __attribute__((ext_vector_type(8)));
+typedef short bq_s16x4 __attribute__((ext_vector_type(4)));
+#define BQ_XROW 128           // bytes per row of an x piece image (64 bf16)
+#define BQ_DROW 256           // bytes per row of a dP piece image (128 bf16)
+#define BQ_XPIECE (64 * BQ_XROW)
+#define BQ_DPIECE (64 * BQ_DROW)
+#define BQ_WPIECE (2 * 1024 * 64)   // elements per piece of wq1 / wq2
+
+// segment (32 bytes) swizzles: a transpose read's 32-lane pass takes rows {r..r+3, r+8..r+11} of ONE logical segment, a 16-byte
+// operand read's service group rows {0-3, 12-15} (first half of the segment) + {4-11} (second half)
+__device__ __forceinline__ int bq_swx(int r) { return ((r >> 1) & 1) | (((r >> 3) & 1) << 1); }      // 128-byte rows: bank bit 5 is the row's parity
+__device__ __forceinline__ int bq_swd(int r) { return (r & 3) | (((r >> 3) & 1) << 2); }             // 256-byte rows
+__device__ __forceinline__ unsigned bq_pack2(float a, float b) {
+    typedef __bf16 v2 __attribute__((ext_vector_type(2)));
+    const v2 h = {(__bf16)a, (__bf16)b};
+    return __builtin_bit_cast(unsigned, h);
+}
+template <int NP> __device__ __forceinline__ void bq_split2(float a, float b, unsigned (&o)[NP]) {
+#pragma unroll
+    for (int t = 0; t < NP; ++t) {
+        o[t] = bq_pack2(a, b);
+        if (t + 1 < NP) { a -= __uint_as_float(o[t] << 16); b -= __uint_as_float(o[t] & 0xffff0000u); }
+    }
+}
+__device__ __forceinline__ uint2 bq_tr(unsigned lds_addr) {
+    typedef __attribute__((address_space(3))) bq_s16x4 lds_v4;
+    const bq_s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(reinterpret_cast<lds_v4*>(static_cast<uintptr_t>(lds_addr)));
+    return __builtin_bit_cast(uint2, v);
+}
+// the piece products of a fragment pair, smallest first: (l h' + h l' + m m') + (m h' + h m') + h h'   |   NP = 2: l h' + h l' + h h'
+template <int NP> struct BqTerms;
+template <> struct BqTerms<3> { static constexpr int N = 6; static constexpr int A[6] = {2, 0, 1, 1, 0, 0}; static constexpr int B[6] = {0, 2, 1, 0, 1, 0}; };
+template <> struct BqTerms<2> { static constexpr int N = 3; static constexpr int A[3] = {1, 0, 0}; static constexpr int B[3] = {0, 1, 0}; };
+
+// filters [128][1024] f32 -> the S / T combinations as bf16 pieces in both operand layouts
+template <int NP>
+__global__ __launch_bounds__(256) void bq_prep_kernel(const float* W, uint16_t* wq1, uint16_t* wq2, int diff) {
+    const int col = blockIdx.x * 256 + threadIdx.x;       // 0..1023
+    const int c = blockIdx.y;                             // 0..63
+    const float wt = W[(int64_t)c * BX_NCOLS + col], wb = W[(int64_t)(BX_NIN + c) * BX_NCOLS + col];
+    const float sv = diff ? wt + wb : wt, tv = diff ? -wb : wb;
+    unsigned o[NP];
+    bq_split2<NP>(sv, tv, o);
+#pragma unroll
+    for (int t = 0; t < NP; ++t) {
+        const uint16_t hs = (uint16_t)(o[t] & 0xffffu), ht = (uint16_t)(o[t] >> 16);
+        wq1[(int64_t)t * BQ_WPIECE + ((int64_t)0 * 1024 + col) * 64 + c] = hs;
+        wq1[(int64_t)t * BQ_WPIECE + ((int64_t)1 * 1024 + col) * 64 + c] = ht;
+        wq2[(int64_t)t * BQ_WPIECE + ((int64_t)0 * 64 + c) * 1024 + col] = hs;
+        wq2[(int64_t)t * BQ_WPIECE + ((int64_t)1 * 64 + c) * 1024 + col] = ht;
+    }
+}
+
+template <int NP, bool SEP>
+__global__ __launch_bounds__(BX_THREADS, 1) void mpconv_bwd_extq_kernel(const BxParams p) {
+    typedef BqTerms<NP> TM;
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int li = lane & 15, lk = lane >> 4;
+    const int N = p.N, k = p.k, mk = N * k;
+    const int ntile = (N + 15) >> 4;
+    const bool want_get = p.get_ws != nullptr;
+    const bool diff = p.ext == FGNN_EXT_DIFF;
+    constexpr int nou = BX_NOU, ncols = BX_NCOLS, npass = BX_NPASS;
+
+    const unsigned lds0 = (unsigned)(uintptr_t)bx_lds;
+    unsigned char* xq = bx_lds + p.off_xq;                            // [NP][64][128 B]
+    unsigned char* dq = bx_lds + p.off_dq;                            // [NP][64][256 B]
+    float* ps = reinterpret_cast<float*>(bx_lds + p.off_ps);          // [64][PS]: P (f32)
+    unsigned short* e16 = reinterpret_cast<unsigned short*>(bx_lds + p.off_e16);
+    float* et_s = reinterpret_cast<float*>(bx_lds + p.off_et);
+    float* get_s = reinterpret_cast<float*>(bx_lds + p.off_get);
+    int* idx_s = reinterpret_cast<int*>(bx_lds + p.off_idx);
+    unsigned short* csr_ent = reinterpret_cast<unsigned short*>(bx_lds + p.off_csr);
+    int* csr_off = reinterpret_cast<int*>(bx_lds + p.off_csr + ((mk * 2 + 15) & ~15));
+    float* gz_s = reinterpret_cast<float*>(bx_lds + p.off_gz);
+    unsigned* am_s = reinterpret_cast<unsigned*>(bx_lds + p.off_am);
+    float* sel_s = reinterpret_cast<float*>(bx_lds + p.off_w);        // [mk + 1][4]: gz[m][oc] where edge (m, j) is the argmax of (m, oc), else 0; row mk = 0
+
+    const int chunk = (p.B + gridDim.x - 1) / gridDim.x;
+    const int b_begin = blockIdx.x * chunk;
+    const int ns = min(p.B, b_begin + chunk) - b_begin;
+    float* slab = p.ws + (int64_t)blockIdx.x * p.slab_len;
+    if (ns <= 0) {
+        for (int64_t f = tid; f < p.slab_len; f += BX_THREADS) slab[f] = 0.f;
+        if (want_get) for (int64_t f = tid; f < p.get_len; f += BX_THREADS) p.get_ws[(int64_t)blockIdx.x * p.get_len + f] = 0.f;
+        return;
+    }
+
+    // ---------------- one-time setup (as the exact kernel): graph tables, edge types, CSR by source node ----------------
+    for (int f = tid; f < NP * BQ_XPIECE / 4; f += BX_THREADS) reinterpret_cast<unsigned*>(xq)[f] = 0u;
+    for (int r = tid; r < mk; r += BX_THREADS) {
+        const int m = r / k, j = r - m * k;
+        long long v = p.idx[(int64_t)m * p.idx_sm + (int64_t)j * p.idx_sk];
+        idx_s[r] = (int)(v < 0 ? 0 : (v >= N ? N - 1 : v));
+    }
+    for (int f = tid; f < mk * BX_NET; f += BX_THREADS) {
+        const int e = f / mk, r = f - e * mk;
+        const int m = r / k, j = r - m * k;
+        et_s[r * BX_NET + e] = p.et[(int64_t)e * p.et_se + (int64_t)m * p.et_sm + (int64_t)j * p.et_sk];
+        get_s[r * BX_NET + e] = 0.f;
+    }
+    if (tid < BX_NET) et_s[mk * BX_NET + tid] = 0.f;                  // the row the empty in-edge slots name (weight 0 x a finite value)
+    if (tid < 4) sel_s[mk * 4 + tid] = 0.f;
+    __syncthreads();
+    if (tid < 64) {
+        int c = 0;
+        if (tid < N) for (int r = 0; r < mk; ++r) c += idx_s[r] == tid;
+        gz_s[tid] = __int_as_float(c);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int a = 0;
+        for (int n = 0; n < 64; ++n) { csr_off[n] = a; a += __float_as_int(gz_s[n]); }
+        csr_off[64] = a;
+    }
+    __syncthreads();
+    if (tid < N) {
+        int o = csr_off[tid];
+        for (int r = 0; r < mk; ++r) if (idx_s[r] == tid) csr_ent[o++] = (unsigned short)(((r / k) << 4) | (r % k));
+    }
+    __syncthreads();
+    for (int f = tid; f < 64 * 16; f += BX_THREADS) {
+        const int n = f >> 4, i = csr_off[n] + (f & 15);
+        unsigned short v = (unsigned short)mk;                         // first 16 in-edges of node n as EDGE INDICES m k + j; empty slot: row mk
+        if (n < N && i < csr_off[n + 1]) { const int ent = csr_ent[i]; v = (unsigned short)((ent >> 4) * k + (ent & 15)); }
+        e16[f] = v;
+    }
+
+    // ---------------- per-thread roles (the exact kernel's) ----------------
+    const int a_half = wave >> 2, a_sl = wave & 3;
+    const int b1_eq = lane & 3, b1_m = 16 * wave + 4 * ((lane >> 2) & 3) + (lane >> 4);
+    const int b2_t = tid & 255, b2_row = b2_t >> 2, b2_oc = b2_t & 3;
+    const int c_ct = wave & 3, c_np = wave >> 2;
+    const int w_t = wave & 3, w_cp = wave >> 2;
+
+    uint4 xr[2];
+    uint4 gzr = make_uint4(0, 0, 0, 0);
+    unsigned amr = 0;
+    auto prefetch = [&](int b, int pass) {
+        const uint4* xb = reinterpret_cast<const uint4*>(p.x + (int64_t)b * p.x_sb);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int f = tid + q * BX_THREADS;
+            xr[q] = (f >> 4) < N ? xb[f] : make_uint4(0, 0, 0, 0);
+        }
+        if (tid < 64) {
+            gzr = make_uint4(0, 0, 0, 0);
+            amr = 0;
+            if (tid < N) {
+                const int64_t o = (int64_t)b * p.y_sb + (int64_t)tid * nou + BX_PCH * pass;
+                gzr = *reinterpret_cast<const uint4*>(p.gz + o);
+                amr = *reinterpret_cast<const unsigned*>(p.am + o);
+            }
+        }
+    };
+    auto commit = [&]() {                                             // x chunk (row f >> 4, channels 4 (f & 15)..) -> the NP piece images
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int f = tid + q * BX_THREADS;
+            const int row = f >> 4, ch = f & 15;
+            if (row < N) {
+                unsigned a[NP], b[NP];
+                bq_split2<NP>(__uint_as_float(xr[q].x), __uint_as_float(xr[q].y), a);
+                bq_split2<NP>(__uint_as_float(xr[q].z), __uint_as_float(xr[q].w), b);
+                unsigned char* dst = xq + row * BQ_XROW + (((ch >> 2) ^ bq_swx(row)) << 5) + ((ch & 3) << 3);
+#pragma unroll
+                for (int t = 0; t < NP; ++t) *reinterpret_cast<uint2*>(dst + t * BQ_XPIECE) = make_uint2(a[t], b[t]);
+            }
+        }
+        if (tid < 64) {
+            *reinterpret_cast<uint4*>(gz_s + tid * 4) = gzr;
+            am_s[tid] = amr;
+            if (tid < N) {                                            // the routed gradient of this node's out-edges, per channel of the pass
+                const int j0 = min((int)(amr & 255u), k - 1), j1 = min((int)((amr >> 8) & 255u), k - 1);
+                const int j2 = min((int)((amr >> 16) & 255u), k - 1), j3 = min((int)(amr >> 24), k - 1);
+                for (int j = 0; j < k; ++j)
+                    *reinterpret_cast<uint4*>(sel_s + (tid * k + j) * 4) = make_uint4(j == j0 ? gzr.x : 0u, j == j1 ? gzr.y : 0u, j == j2 ? gzr.z : 0u, j == j3 ? gzr.w : 0u);
+            }
+        }
+    };
+    // in-degree of this thread's dT row (b2_row), capped at the 16 slots; the wave's loop bound is the largest of its 16 rows
+    int dt_deg = 0, dt_max = 0;
+    {
+        const int n = (tid & 255) >> 2;
+        dt_deg = n < N ? min(csr_off[n + 1] - csr_off[n], 16) : 0;
+        int mx = dt_deg;
+#pragma unroll
+        for (int o = 32; o >= 4; o >>= 1) mx = max(mx, __shfl_xor(mx, o));
+        dt_max = __builtin_amdgcn_readfirstlane(mx);
+    }
+
+    __syncthreads();
+    prefetch(b_begin, blockIdx.x % npass);
+
+    // ---- filter pieces of a pass: 6 NP 16-byte loads per lane; the next pass's are asked for behind the last stage of a pass, under
+    //      the slab stores and the bias reduction ----
+    bq_bf16x8 wA[NP][2];                                              // P = x W: B operand [k = c 32 ks + 8 lk ..][n = this wave's column li]
+    bq_bf16x8 wG[NP][4];                                              // gx = dP Wc: B operand [k = dP column 32 ks + 8 lk ..][n = c 16 ct + li]
+    auto load_w = [&](int pass) {
+        const int col = 16 * (BX_PCH * pass + a_sl) + li;
+        const uint16_t* base = p.wq1 + ((int64_t)a_half * 1024 + col) * 64 + 8 * lk;
+#pragma unroll
+        for (int t = 0; t < NP; ++t)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+                wA[t][ks] = __builtin_bit_cast(bq_bf16x8, *reinterpret_cast<const uint4*>(base + (int64_t)t * BQ_WPIECE + 32 * ks));
+        const int c = 16 * c_ct + li;
+#pragma unroll
+        for (int t = 0; t < NP; ++t)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+                wG[t][ks] = __builtin_bit_cast(bq_bf16x8, *reinterpret_cast<const uint4*>(
+                    p.wq2 + (int64_t)t * BQ_WPIECE + ((int64_t)(ks >> 1) * 64 + c) * 1024 + 64 * pass + 32 * (ks & 1) + 8 * lk));
+    };
+
+    for (int pp = 0; pp < npass; ++pp) {
+        const int pass = (pp + blockIdx.x) % npass;
+        const int pass_next = (pp + 1 + blockIdx.x) % npass;
+        load_w(pass);             // (asked for behind the previous pass's last stage instead: measured, slower — two more registers spill)
+        f32x4 accW[2][2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) accW[a][h] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        float gb_acc = 0.f;
+
+        for (int s = 0; s < ns; ++s) {
+            const int b = b_begin + s;
+            __syncthreads();                                          // previous stage is done with the x pieces, P / dP, gz_s
+            commit();
+            if (s + 1 < ns) prefetch(b + 1, pass);
+            else if (pp + 1 < npass) prefetch(b_begin, pass_next);
+            // gx of this sample as the earlier passes left it (read-modify-write through L2): asked for now, used at the end of phase C
+            float* gxb = p.gx + (int64_t)b * p.x_sb + 16 * c_ct + li;
+            f32x4 old[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                old[h] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (pp > 0) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int node = (2 * c_np + h) * 16 + 4 * lk + r;
+                        if (node < N) old[h][r] = gxb[(int64_t)node * BX_NIN];
+                    }
+                }
+            }
+            __syncthreads();
+            BX_STAMP(0);
+            // the lane's tile coordinates as values the compiler cannot prove loop-invariant: every operand address of the phases
+            // below is then formed where it is used (hoisted out of the stage loop they hold ~60 registers for the whole pass
+            // and the MFMA fragments spill)
+            int oz;
+            asm volatile("v_mov_b32 %0, 0" : "=v"(oz));
+            const int li_ = li + oz, lk_ = lk + oz;
+
+            // ================= phase A: P = x [Ws | Wt] =================
+            {
+                const int li = li_, lk = lk_;
+                const int colbase = 64 * a_half + 16 * a_sl + li;
+                for (int nt = 0; nt < ntile; ++nt) {
+                    const int row = 16 * nt + li;
+                    const unsigned char* xrow = xq + row * BQ_XROW + ((lk & 1) << 4);
+                    const int sw = bq_swx(row);
+                    bq_bf16x8 xa[NP][2];
+#pragma unroll
+                    for (int t = 0; t < NP; ++t)
+#pragma unroll
+                        for (int ks = 0; ks < 2; ++ks)
+                            xa[t][ks] = __builtin_bit_cast(bq_bf16x8, *reinterpret_cast<const uint4*>(xrow + t * BQ_XPIECE + (((2 * ks + (lk >> 1)) ^ sw) << 5)));
+                    f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+                    for (int pr = 0; pr < TM::N; ++pr)
+#pragma unroll
+                        for (int ks = 0; ks < 2; ++ks)
+                            acc[ks] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa[TM::A[pr]][ks], wA[TM::B[pr]][ks], acc[ks], 0, 0, 0);
+                    const f32x4 out = acc[0] + acc[1];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) ps[(16 * nt + 4 * lk + r) * BX_PS + colbase] = out[r];
+                }
+            }
+            BX_STAMP(1);
+            __syncthreads();
+            BX_STAMP(2);
+
+            // ================= phase B: get += gz (S + T) at the argmax; dS on waves 0-3, dT on waves 4-7 -> dP pieces =================
+            auto phase_b1 = [&]() {                                   // (one thread owns all four channels of (m, eq): two channels whose
+                if (want_get && b1_m < N) {                           // argmax is the same edge add into the same get_s words)
+                    const unsigned am4 = am_s[b1_m];
+                    const f32x4 g4 = *reinterpret_cast<const f32x4*>(gz_s + b1_m * 4);
+#pragma unroll
+                    for (int oc = 0; oc < BX_PCH; ++oc) {
+                        const f32x4 sv = *reinterpret_cast<const f32x4*>(ps + b1_m * BX_PS + 16 * oc + 4 * b1_eq);
+                        const int j = min((int)((am4 >> (8 * oc)) & 255u), k - 1);
+                        const int r = b1_m * k + j;
+                        const f32x4 tv = *reinterpret_cast<const f32x4*>(ps + idx_s[r] * BX_PS + 64 + 16 * oc + 4 * b1_eq);
+                        f32x4* gp = reinterpret_cast<f32x4*>(get_s + r * BX_NET + 4 * b1_eq);
+                        *gp = *gp + g4[oc] * (sv + tv);
+                    }
+                }
+            };
+            auto store_row = [&](int h, const f32x4 (&row)[4]) {      // 16 columns of dP row b2_row (segment 4 h + oc) -> the piece images
+                unsigned w[NP][8];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    unsigned a[NP], b[NP];
+                    bq_split2<NP>(row[q][0], row[q][1], a);
+                    bq_split2<NP>(row[q][2], row[q][3], b);
+#pragma unroll
+                    for (int t = 0; t < NP; ++t) { w[t][2 * q] = a[t]; w[t][2 * q + 1] = b[t]; }
+                }
+                unsigned char* dst = dq + b2_row * BQ_DROW + (((4 * h + b2_oc) ^ bq_swd(b2_row)) << 5);
+#pragma unroll
+                for (int t = 0; t < NP; ++t) {
+                    *reinterpret_cast<uint4*>(dst + t * BQ_DPIECE) = make_uint4(w[t][0], w[t][1], w[t][2], w[t][3]);
+                    *reinterpret_cast<uint4*>(dst + t * BQ_DPIECE + 16) = make_uint4(w[t][4], w[t][5], w[t][6], w[t][7]);
+                }
+            };
+            auto phase_ds = [&]() {
+                f32x4 row[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) row[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (b2_row < N) {
+                    const float g = gz_s[b2_row * 4 + b2_oc];
+                    const int j = min((int)((am_s[b2_row] >> (8 * b2_oc)) & 255u), k - 1);
+                    const float* er = et_s + (b2_row * k + j) * BX_NET;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) row[q] = g * *reinterpret_cast<const f32x4*>(er + 4 * q);
+                    gb_acc += g;
+                }
+                store_row(0, row);
+            };
+            f32x4 acc[4];                                             // dT of thread (n, eq): [oc][4 eq ..]
+            auto dt_compute = [&]() {                                 // dT[n][oc][4 eq ..] = sum over in-edges r of sel[r][oc] et[r][4 eq ..]
+                const int eq = b2_oc;
+#pragma unroll
+                for (int oc = 0; oc < 4; ++oc) acc[oc] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+                for (int i0 = 0; i0 < dt_max; i0 += 4) {              // four slots at a time: eight 16-byte reads in flight, then their 64 FMAs
+                    const uint2 e4 = *reinterpret_cast<const uint2*>(e16 + b2_row * 16 + i0);       // (a row with fewer in-edges names the zero row)
+                    const int r0 = e4.x & 0xffff, r1 = e4.x >> 16, r2 = e4.y & 0xffff, r3 = e4.y >> 16;
+                    const f32x4 s0 = *reinterpret_cast<const f32x4*>(sel_s + r0 * 4), v0 = *reinterpret_cast<const f32x4*>(et_s + r0 * BX_NET + 4 * eq);
+                    const f32x4 s1 = *reinterpret_cast<const f32x4*>(sel_s + r1 * 4), v1 = *reinterpret_cast<const f32x4*>(et_s + r1 * BX_NET + 4 * eq);
+                    const f32x4 s2 = *reinterpret_cast<const f32x4*>(sel_s + r2 * 4), v2 = *reinterpret_cast<const f32x4*>(et_s + r2 * BX_NET + 4 * eq);
+                    const f32x4 s3 = *reinterpret_cast<const f32x4*>(sel_s + r3 * 4), v3 = *reinterpret_cast<const f32x4*>(et_s + r3 * BX_NET + 4 * eq);
+#pragma unroll
+                    for (int oc = 0; oc < 4; ++oc) acc[oc] = s0[oc] * v0 + acc[oc];
+#pragma unroll
+                    for (int oc = 0; oc < 4; ++oc) acc[oc] = s1[oc] * v1 + acc[oc];
+#pragma unroll
+                    for (int oc = 0; oc < 4; ++oc) acc[oc] = s2[oc] * v2 + acc[oc];
+#pragma unroll
+                    for (int oc = 0; oc < 4; ++oc) acc[oc] = s3[oc] * v3 + acc[oc];
+                }
+                if (b2_row < N) {
+                    const int e1 = csr_off[b2_row + 1];
+                    for (int i = csr_off[b2_row] + 16; i < e1; ++i) {  // in-degree above 16: the tail of the list
+                        const int ent = csr_ent[i];
+                        const int r = (ent >> 4) * k + (ent & 15);
+                        const f32x4 sv = *reinterpret_cast<const f32x4*>(sel_s + r * 4);
+                        const f32x4 ev = *reinterpret_cast<const f32x4*>(et_s + r * BX_NET + 4 * eq);
+#pragma unroll
+                        for (int oc = 0; oc < 4; ++oc) acc[oc] = sv[oc] * ev + acc[oc];
+                    }
+                }
+                BX_STAMP(7);
+            };
+            auto dt_store = [&]() {
+                const int eq = b2_oc;
+                unsigned char* drow = dq + b2_row * BQ_DROW + (eq << 3);
+                const int sd = bq_swd(b2_row);
+#pragma unroll
+                for (int oc = 0; oc < 4; ++oc) {
+                    unsigned a[NP], b[NP];
+                    bq_split2<NP>(acc[oc][0], acc[oc][1], a);
+                    bq_split2<NP>(acc[oc][2], acc[oc][3], b);
+#pragma unroll
+                    for (int t = 0; t < NP; ++t) *reinterpret_cast<uint2*>(drow + t * BQ_DPIECE + (((4 + oc) ^ sd) << 5)) = make_uint2(a[t], b[t]);
+                }
+            };
+            if (SEP) {
+                if (tid < 256) { phase_b1(); phase_ds(); }
+                else { dt_compute(); dt_store(); }
+            } else {                                                  // the dP pieces overwrite P: the edge-type gradient reads P first
+                if (tid < 256) phase_b1();                            // (dT formed in registers beside it: measured, no gain — 4 more registers spill)
+                BX_STAMP(3);
+                __syncthreads();
+                if (tid < 256) phase_ds();
+                else { dt_compute(); dt_store(); }
+            }
+            BX_STAMP(4);
+            __syncthreads();
+            BX_STAMP(5);
+
+            // ================= phase C: gW += x^T dP (transpose reads), gx += dP Wc (global RMW) =================
+            {
+                const int li = li_, lk = lk_;
+                // gW: tiles (c tile 2 cp + a) x (S / T column tile t); K = 64 nodes in two k-steps; both operands by transpose reads
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const int r0 = 32 * ks + 8 * lk + (li >> 2), r1 = r0 + 4;
+                    const unsigned xo0 = lds0 + p.off_xq + r0 * BQ_XROW + ((li & 3) << 3), xo1 = lds0 + p.off_xq + r1 * BQ_XROW + ((li & 3) << 3);
+                    const unsigned do0 = lds0 + p.off_dq + r0 * BQ_DROW + ((li & 3) << 3), do1 = lds0 + p.off_dq + r1 * BQ_DROW + ((li & 3) << 3);
+                    const int sx0 = bq_swx(r0), sx1 = bq_swx(r1), sd0 = bq_swd(r0), sd1 = bq_swd(r1);
+                    bq_bf16x8 xa[2][NP], db[2][NP];
+#pragma unroll
+                    for (int a = 0; a < 2; ++a)
+#pragma unroll
+                        for (int t = 0; t < NP; ++t) {
+                            const int ct = 2 * w_cp + a;
+                            const uint2 lo = bq_tr(xo0 + t * BQ_XPIECE + ((ct ^ sx0) << 5)), hi = bq_tr(xo1 + t * BQ_XPIECE + ((ct ^ sx1) << 5));
+                            xa[a][t] = __builtin_bit_cast(bq_bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));
+                        }
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+#pragma unroll
+                        for (int t = 0; t < NP; ++t) {
+                            const int g = 4 * h + w_t;
+                            const uint2 lo = bq_tr(do0 + t * BQ_DPIECE + ((g ^ sd0) << 5)), hi = bq_tr(do1 + t * BQ_DPIECE + ((g ^ sd1) << 5));
+                            db[h][t] = __builtin_bit_cast(bq_bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));
+                        }
+#pragma unroll
+                    for (int pr = 0; pr < TM::N; ++pr)
+#pragma unroll
+                        for (int a = 0; a < 2; ++a)
+#pragma unroll
+                            for (int h = 0; h < 2; ++h)
+                                accW[a][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa[a][TM::A[pr]], db[h][TM::B[pr]], accW[a][h], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);                // (one k-step's fragments at a time: hoisted together they spill)
+                }
+                // gx tiles: nodes (2 np, 2 np + 1) x c tile ct, K = 128 dP columns in four k-steps
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int row = (2 * c_np + h) * 16 + li;
+                    const unsigned char* drow = dq + row * BQ_DROW + ((lk & 1) << 4);
+                    const int sd = bq_swd(row);
+                    f32x4 accx[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};       // two chains (even / odd k-steps)
+#pragma unroll
+                    for (int kp = 0; kp < 2; ++kp) {
+                        bq_bf16x8 da[2][NP];
+#pragma unroll
+                        for (int q = 0; q < 2; ++q)
+#pragma unroll
+                            for (int t = 0; t < NP; ++t)
+                                da[q][t] = __builtin_bit_cast(bq_bf16x8, *reinterpret_cast<const uint4*>(drow + t * BQ_DPIECE + (((2 * (2 * kp + q) + (lk >> 1)) ^ sd) << 5)));
+#pragma unroll
+                        for (int pr = 0; pr < TM::N; ++pr)
+#pragma unroll
+                            for (int q = 0; q < 2; ++q)
+                                accx[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da[q][TM::A[pr]], wG[TM::B[pr]][2 * kp + q], accx[q], 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int node = (2 * c_np + h) * 16 + 4 * lk + r;
+                        if (node < N) gxb[(int64_t)node * BX_NIN] = old[h][r] + (accx[0][r] + accx[1][r]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                BX_STAMP(6);
+            }
+        }
+
+        // ---- end of pass: filter-gradient tiles and the bias gradient of the pass -> this workgroup's slab ----
+        {
+            const int col = 64 * pass + 16 * w_t + li;
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int c = 16 * (2 * w_cp + a) + 4 * lk + r;
+                    const float gs = accW[a][0][r], gt = accW[a][1][r];
+                    slab[(int64_t)c * ncols + col] = gs;
+                    slab[(int64_t)(BX_NIN + c) * ncols + col] = diff ? gs - gt : gt;
+                }
+            // bias gradient of the pass: the (m, oc) threads' sums folded over m in a fixed tree (16 rows by lane exchanges, 4 waves in LDS)
+            float gsum = gb_acc;
+#pragma unroll
+            for (int o = 4; o <= 32; o <<= 1) gsum += __shfl_xor(gsum, o);
+            __syncthreads();                                          // phase C is done with the images: P's storage is scratch
+            if (tid < 256 && lane < 4) ps[wave * 4 + lane] = gsum;
+            __syncthreads();
+            if (tid < BX_PCH) slab[(int64_t)2 * BX_NIN * ncols + BX_PCH * pass + tid] = (ps[tid] + ps[4 + tid]) + (ps[8 + tid] + ps[12 + tid]);
+        }
+    }
+    if (want_get) {
+        __syncthreads();
+        float* go = p.get_ws + (int64_t)blockIdx.x * p.get_len;
+        for (int f = tid; f < mk * BX_NET; f += BX_THREADS) {
+            const int e = f / mk, r = f - e * mk;
+            go[f] = get_s[r * BX_NET + e];
+        }
+    }
+}
+
 void fgnn_launch_slab_store(const float* ws, int nslab, int64_t slab_len, float* out, hipStream_t st);
 void fgnn_launch_slab_reduce(const float* ws, int nslab, int64_t slab_len, int64_t nw, float* gW, float* gbias,
                              hipStream_t st);
@@ -517,7 +1031,7 @@ void fgnn_launch_slab_reduce(const float* ws, int nslab, int64_t slab_len, int64
 // bytes of workspace this kernel wants on top of the gW / gbias slabs: the edge-type gradient slabs
 int64_t fgnn_mpconv_backward_ext_extra_bytes(const fgnn_mpconv_desc* d) {
     if (d->ext == FGNN_EXT_NONE || d->dtype != FGNN_F32 || d->net != BX_NET) return 0;
-    return (int64_t)256 * BX_NET * d->M * d->k * 4;
+    return (int64_t)256 * BX_NET * d->M * d->k * 4 + (int64_t)2 * 3 * BQ_WPIECE * 2;      // edge-type slabs + the filters' bf16 pieces (split form)
 }
 
 // 1 when this descriptor's backward sums the edge-type gradient over the batch itself (getype = [net, M, k]); the caller
@@ -558,7 +1072,8 @@ int fgnn_mpconv_backward_ext(const fgnn_mpconv_desc* d, const void* x, const int
     if (grid > d->B) grid = d->B;
     const int chunk = (d->B + grid - 1) / grid;
     grid = (d->B + chunk - 1) / chunk;
-    const int64_t need = (grid * slab_len + (getype ? grid * get_len : 0)) * 4;
+    const int64_t pieces_bytes = (int64_t)2 * 3 * BQ_WPIECE * 2;
+    const int64_t need = (grid * slab_len + (getype ? grid * get_len : 0)) * 4 + pieces_bytes;
     if (!workspace || workspace_bytes < need)
         FGNN_FAIL(FGNN_EINVAL, "mpconv ext backward needs %lld bytes of workspace (fgnn_mpconv_backward_workspace_bytes)", (long long)need);
     BxParams p;
@@ -590,6 +1105,76 @@ int fgnn_mpconv_backward_ext(const fgnn_mpconv_desc* d, const void* x, const int
     }
     const bool narrow = d->nou != BX_NOU, wvec = p.wvec != 0;
     void* fn;
+    // ---- split form (bf16 pieces on the bf16 matrix cores): max aggregation, 64 output channels, when its images fit ----
+    // FGNN_EXT_BWD_PIECES: 2 (default: h + l pieces, three bf16 MFMAs per fragment product; gradients within 5e-6 of the exact kernel's,
+    // tools/xbench.py), 3 (h + m + l, six MFMAs: within 4e-7, 1.35 x the time), 0 (the exact-f32 kernel above: 2 x the time)
+    static const int want_np = getenv("FGNN_EXT_BWD_PIECES") ? atoi(getenv("FGNN_EXT_BWD_PIECES")) : 2;
+    if (want_np >= 2 && d->agg == FGNN_AGG_MAX && !narrow && (d->y_sb % 4) == 0) {
+        int np = 0, sep = 0, lds_q = 0;
+        for (int cand = want_np >= 3 ? 3 : 2; cand >= 2 && !np; --cand)
+            for (int sp = 1; sp >= 0 && !np; --sp) {
+                int ob = 0;
+                auto tk = [&](int bytes) { const int o = ob; ob = fgnn_round_up(ob + bytes, 16); return o; };
+                const int oxq = tk(cand * BQ_XPIECE);
+                const int ops_ = tk(sp ? 64 * BX_PS * 4 : (cand * BQ_DPIECE > 64 * BX_PS * 4 ? cand * BQ_DPIECE : 64 * BX_PS * 4));
+                const int odq = sp ? tk(cand * BQ_DPIECE) : ops_;
+                const int oet = tk((mk + 1) * BX_NET * 4), oget = tk(mk * BX_NET * 4), oidx = tk(mk * 4), osel = tk((mk + 1) * 16);
+                const int ocsr = tk(((mk * 2 + 15) & ~15) + 65 * 4), oe16 = tk(64 * 16 * 2), ogz = tk(64 * 4 * 4), oam = tk(64 * 4);
+                if (ob <= 160 * 1024) {
+                    np = cand; sep = sp; lds_q = ob;
+                    p.off_xq = oxq; p.off_ps = ops_; p.off_dq = odq; p.off_dp = odq; p.off_et = oet; p.off_get = oget; p.off_idx = oidx;
+                    p.off_csr = ocsr; p.off_e16 = oe16; p.off_gz = ogz; p.off_am = oam; p.off_w = osel; p.off_xs = 0;
+                }
+            }
+        if (np) {
+            uint16_t* wq = reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(workspace) + (grid * slab_len + (getype ? grid * get_len : 0)) * 4);
+            p.wq1 = wq;
+            p.wq2 = wq + (int64_t)3 * BQ_WPIECE;
+            void* prep = np == 3 ? (void*)bq_prep_kernel<3> : (void*)bq_prep_kernel<2>;
+            const float* Wf = filters;
+            uint16_t* a1 = wq;
+            uint16_t* a2 = wq + (int64_t)3 * BQ_WPIECE;
+            int is_diff = d->ext == FGNN_EXT_DIFF;
+            void* pargs[] = {(void*)&Wf, (void*)&a1, (void*)&a2, (void*)&is_diff};
+            hipError_t e = hipLaunchKernel(prep, dim3(BX_NCOLS / 256, BX_NIN), dim3(256), pargs, 0, (hipStream_t)stream);
+            if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "mpconv ext backward (filter pieces) launch: %s", hipGetErrorString(e));
+            fn = np == 3 ? (sep ? (void*)mpconv_bwd_extq_kernel<3, true> : (void*)mpconv_bwd_extq_kernel<3, false>)
+                         : (sep ? (void*)mpconv_bwd_extq_kernel<2, true> : (void*)mpconv_bwd_extq_kernel<2, false>);
+            e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_q);
+            if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "hipFuncSetAttribute(%d B LDS): %s", lds_q, hipGetErrorString(e));
+            fgnn_note_kernel("mpconv_bwd_extq_kernel<%d, %s>", np, sep ? "true" : "false");
+            p.prof = nullptr;
+            p.dbg = 0;
+#ifdef FGNN_ENABLE_PROF
+            static long long* prof_q = nullptr;
+            if (getenv("FGNN_PROF")) {
+                if (!prof_q) (void)hipMalloc(&prof_q, 64 * 8);
+                (void)hipMemset(prof_q, 0, 64 * 8);
+                p.prof = prof_q;
+            }
+#endif
+            void* qargs[] = {(void*)&p};
+            e = hipLaunchKernel(fn, dim3(grid), dim3(BX_THREADS), qargs, lds_q, (hipStream_t)stream);
+            if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "mpconv ext backward (split form) launch: %s", hipGetErrorString(e));
+#ifdef FGNN_ENABLE_PROF
+            if (p.prof) {
+                long long h[64];
+                (void)hipDeviceSynchronize();
+                (void)hipMemcpy(h, p.prof, sizeof(h), hipMemcpyDeviceToHost);
+                for (int w = 0; w < 8; ++w) {
+                    fprintf(stderr, "[fgnn prof extq bwd] wave %d:", w);
+                    for (int i = 0; i < 8; ++i) fprintf(stderr, " %lld", h[w * 8 + i] - h[0]);
+                    fprintf(stderr, "\n");
+                }
+            }
+#endif
+            fgnn_launch_slab_reduce(p.ws, grid, slab_len, nw, gfilters, gbias, (hipStream_t)stream);
+            if (getype) fgnn_launch_slab_store(p.get_ws, grid, get_len, (float*)getype, (hipStream_t)stream);
+            e = hipGetLastError();
+            if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "mpconv ext backward helper launch: %s", hipGetErrorString(e));
+            return 1;
+        }
+    }
 #define BX_PICK(A) (narrow ? (wvec ? (void*)mpconv_bwd_ext_kernel<A, true, true> : (void*)mpconv_bwd_ext_kernel<A, true, false>) \
                            : (wvec ? (void*)mpconv_bwd_ext_kernel<A, false, true> : (void*)mpconv_bwd_ext_kernel<A, false, false>))
     fn = d->agg == FGNN_AGG_MAX ? BX_PICK(FGNN_AGG_MAX) : BX_PICK(FGNN_AGG_LSE);

@@ -39,8 +39,21 @@ class StepGraph:
         if not self.static_params:
             pointwise.invalidate_casts()
         self.graph = torch.cuda.CUDAGraph()
+        import os
+        dot = os.environ.get('FGNN_GRAPH_DOT')          # diagnosis: the captured graph (nodes, edges) as hipGraphDebugDotPrint writes it
+        if dot:
+            self.graph.enable_debug_mode()
+        from . import ops
+        self.stamps = None
+        if os.environ.get('FGNN_STAMPS'):               # diagnosis: device timestamps inside the replayed step (ops.stamp)
+            ops.STAMPS = {'buf': torch.zeros(8192, dtype=torch.int64, device='cuda'), 'tags': []}
         with torch.cuda.graph(self.graph, stream=self.stream):
+            ops.stamp('step begin')
             fn()
+            ops.stamp('step end')
+        self.stamps, ops.STAMPS = ops.STAMPS, None
+        if dot:
+            self.graph.debug_dump(dot)
 
     def replay(self):
         self.graph.replay()
@@ -49,5 +62,15 @@ class StepGraph:
         from .mpnn import pointwise
         pointwise.note_state_change()       # the replayed kernels may have changed parameters / BatchNorm buffers
         pointwise.invalidate_casts()        # ... and with them the low-precision weight copies eager code reads next
+
+    def stamp_report(self, file):
+        """The stamps of the LAST replay, sorted by device time (microseconds from 'step begin')."""
+        if not self.stamps:
+            return
+        torch.cuda.synchronize()
+        v = self.stamps['buf'][:len(self.stamps['tags'])].cpu().tolist()
+        t0 = v[0]
+        for t, tag in sorted(zip(v, self.stamps['tags'])):
+            print('stamp %10.2f us  %s' % ((t - t0) / 100.0, tag), file=file)
 
     __call__ = replay

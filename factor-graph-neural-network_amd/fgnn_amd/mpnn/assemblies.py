@@ -157,6 +157,8 @@ _V2V_MAIN = set()      # layers whose v2v map stays on the main stream.  Measure
 
 
 _F2F_SIDE = True       # the parity factors' f2f map on the side stream (round 5: -0.1 ms)
+import os as _os
+_MAIN_FIRST = _os.environ.get('FGNN_MAIN_FIRST') is not None      # EXPERIMENT (round 6): issue the main stream's V->F parity block before the side chain
 _FAC_MERGE_SIDE = 1    # 1 = the factor states' gradient merge on the side stream (2: the variables' instead; round 5: -0.13 ms with 1)
 
 
@@ -372,6 +374,10 @@ class FactorNN(torch.nn.Module):
             if two:
                 main, side = torch.cuda.current_stream(var.device), _ops.side_stream(var.device)
                 side.wait_stream(main)
+                if _ops.STAMPS is not None:
+                    _ops.stamp('L%d main0' % L)
+                    with torch.cuda.stream(side):
+                        _ops.stamp('L%d side0' % L)
             f2f_side = two and _F2F_SIDE
             if f2f_side:
                 # round 5 (tuning knob): with the hyper-factor's message carried as a per-sample vector the side branch is the lighter
@@ -382,6 +388,12 @@ class FactorNN(torch.nn.Module):
                     nf0 = self.f2f_modules[L][0](fac_c[0][0])
                     f2f_done = torch.cuda.Event()
                     f2f_done.record(side)
+            main_first = f2f_side and _MAIN_FIRST
+            if main_first:
+                def fac_addends(nf=nf0, f2f_done=f2f_done, same_width=same_width, skip=skip, fac_c=fac_c):
+                    main.wait_event(f2f_done)
+                    return [nf, fac_c[0][-1] if same_width else None, skip[1][0] if skip else None]
+                new_fac[0] = _call(self.v2f_modules[L][0], var_c[1], nn_idx_v2f[0], etype_v2f[0][L], addend=fac_addends)
             for j in range(1, nft):
                 with (torch.cuda.stream(side) if two else contextlib.nullcontext()):
                     nf = self.f2f_modules[L][j](fac_c[j][0])
@@ -390,7 +402,11 @@ class FactorNN(torch.nn.Module):
                     h.append(_call(self.f2v_modules[L][j], fac_c[j][1], nn_idx_f2v[j], etype_f2v[j][L]))
             with (torch.cuda.stream(side) if (two and L not in _V2V_MAIN) else contextlib.nullcontext()):
                 new_var = self.v2v_modules[L](var_c[0])        # the variables' node-wise map rides with the side branch
-            if f2f_side:
+                if two and _ops.STAMPS is not None:
+                    _ops.stamp('L%d side_end' % L)
+            if main_first:
+                pass
+            elif f2f_side:
                 def fac_addends(nf=nf0, f2f_done=f2f_done, same_width=same_width, skip=skip, fac_c=fac_c):
                     main.wait_event(f2f_done)
                     return [nf, fac_c[0][-1] if same_width else None, skip[1][0] if skip else None]
@@ -405,7 +421,11 @@ class FactorNN(torch.nn.Module):
                 if two:
                     main.wait_stream(side)
                 return [new_var] + h + [var_c[-1] if same_width else None, skip[0] if skip else None]
+            if two and _ops.STAMPS is not None:
+                _ops.stamp('L%d main_v2f_end' % L)
             new_var = _call(self.f2v_modules[L][0], fac_c[0][1], nn_idx_f2v[0], etype_f2v[0][L], addend=joined)
+            if two and _ops.STAMPS is not None:
+                _ops.stamp('L%d joined' % L)
             var, fac = new_var, new_fac
         out = self._classify(var)
         if self.final_filter is not None:

@@ -215,6 +215,12 @@ def _flush_at_end_of_backward():
 def backward_node_begins():
     """Called at the top of every hand-written backward: the engine has moved to a node on the current stream, so the other
     streams' parked weight-gradient launches go out now (behind their last critical kernel)."""
+    if STAMPS is not None:
+        import sys
+        f = sys._getframe(1)
+        cur = torch.cuda.current_stream()
+        stamp('bwd %s %s:%d' % ('side' if (SIDE_STREAM and cur == side_stream(cur.device)) else 'main',
+                                f.f_code.co_filename.rsplit('/', 1)[-1], f.f_lineno))
     if _DEFER_CALLBACK[0] is not None and _DEFER_CALLBACK[0] == torch._C._current_graph_task_id():
         flush_deferred(except_stream=torch.cuda.current_stream())
 
@@ -578,6 +584,22 @@ def enable_grad_sink(params, on=True):
     """Opt parameters in to (or out of) in-place gradient accumulation by the kernels (see ``grad_sink``)."""
     for q in params:
         q._fgnn_grad_sink = bool(on)
+
+
+STAMPS = None            # diagnosis (tools/stamps.py): {'buf': uint64 device tensor, 'tags': [...]} — see stamp()
+
+
+def stamp(tag):
+    """Diagnosis only: when ``STAMPS`` is armed, a one-thread kernel on the current stream writes the device clock into the next
+    slot (fgnn_stamp).  Captured with the step, the slots tell when each point was reached in a replay with no profiler attached."""
+    st = STAMPS
+    if st is None:
+        return
+    i = len(st['tags'])
+    if i >= st['buf'].numel():
+        return
+    st['tags'].append(tag)
+    _hip.check(_hip.lib().fgnn_stamp(st['buf'].data_ptr() + 8 * i, _hip.stream_ptr()))
 
 
 ACCUMULATE_INTO_GRAD = True      # master switch for the opted-in parameters (False: always return gradients)

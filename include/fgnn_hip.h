@@ -566,6 +566,10 @@ const char* fgnn_last_kernel(void);
  * 6: fgnn_block_head_backward.  11: fgnn_mpconv_block_forward_rows.  12: fgnn_block_tail_backward_moments,
  * fgnn_block_tail_wgrad_finish, fgnn_block_tail_moments_bytes. */
 #define FGNN_ABI_VERSION 12
+/* Diagnostic: a one-thread kernel on `stream` writes the device's constant 100 MHz clock to *dst (uint64).  Inside a captured step
+ * it tells when that point of the stream is reached in a replay without a profiler attached.  No reference counterpart. */
+int fgnn_stamp(void* dst, void* stream);
+
 int fgnn_abi_version(void);
 
 #ifdef __cplusplus

@@ -1,0 +1,8 @@
+#!/bin/sh
+cd /tmp && export TMPDIR=/tmp
+R=${GRAFT_REPO_ROOT:-/root/repo}
+O=$R/gpurun_out/r06p
+mkdir -p $O
+cd $R
+timeout 300 python tools/ubench/graph_chain_latency.py > $O/chain_latency.txt 2>&1
+cat $O/chain_latency.txt
