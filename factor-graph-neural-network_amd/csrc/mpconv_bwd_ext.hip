@@ -1028,6 +1028,18 @@ void fgnn_launch_slab_store(const float* ws, int nslab, int64_t slab_len, float*
 void fgnn_launch_slab_reduce(const float* ws, int nslab, int64_t slab_len, int64_t nw, float* gW, float* gbias,
                              hipStream_t st);
 
+// which arithmetic the backward of this family runs in (process-wide; FGNN_EXT_BWD_PIECES gives the initial value)
+static int g_bq_pieces = -1;
+static int bq_pieces() {
+    if (g_bq_pieces < 0) g_bq_pieces = getenv("FGNN_EXT_BWD_PIECES") ? atoi(getenv("FGNN_EXT_BWD_PIECES")) : 2;
+    return g_bq_pieces;
+}
+extern "C" int fgnn_set_ext_backward_pieces(int pieces) {
+    const int before = bq_pieces();
+    if (pieces == 0 || pieces == 2 || pieces == 3) g_bq_pieces = pieces;
+    return before;
+}
+
 // bytes of workspace this kernel wants on top of the gW / gbias slabs: the edge-type gradient slabs
 int64_t fgnn_mpconv_backward_ext_extra_bytes(const fgnn_mpconv_desc* d) {
     if (d->ext == FGNN_EXT_NONE || d->dtype != FGNN_F32 || d->net != BX_NET) return 0;
@@ -1108,7 +1120,7 @@ int fgnn_mpconv_backward_ext(const fgnn_mpconv_desc* d, const void* x, const int
     // ---- split form (bf16 pieces on the bf16 matrix cores): max aggregation, 64 output channels, when its images fit ----
     // FGNN_EXT_BWD_PIECES: 2 (default: h + l pieces, three bf16 MFMAs per fragment product; gradients within 5e-6 of the exact kernel's,
     // tools/xbench.py), 3 (h + m + l, six MFMAs: within 4e-7, 1.35 x the time), 0 (the exact-f32 kernel above: 2 x the time)
-    static const int want_np = getenv("FGNN_EXT_BWD_PIECES") ? atoi(getenv("FGNN_EXT_BWD_PIECES")) : 2;
+    const int want_np = bq_pieces();
     if (want_np >= 2 && d->agg == FGNN_AGG_MAX && !narrow && (d->y_sb % 4) == 0) {
         int np = 0, sep = 0, lds_q = 0;
         for (int cand = want_np >= 3 ? 3 : 2; cand >= 2 && !np; --cand)

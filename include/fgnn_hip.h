@@ -565,7 +565,14 @@ const char* fgnn_last_kernel(void);
  * ldpc_channel_features_rng, backward_reduces_getype, desc.reserved = in-degree | GETYPE_REDUCED); 5: fgnn_block_tail_*;
  * 6: fgnn_block_head_backward.  11: fgnn_mpconv_block_forward_rows.  12: fgnn_block_tail_backward_moments,
  * fgnn_block_tail_wgrad_finish, fgnn_block_tail_moments_bytes. */
-#define FGNN_ABI_VERSION 12
+#define FGNN_ABI_VERSION 13
+/* Arithmetic of the f32 synthetic-PGM operator's BACKWARD (16 edge types, ORIG_WITH_NEIGHBOR / ORIG_WITH_DIFF, 64 -> 64, max: the
+ * autograd of /root/reference/lib/model/mpnn/mp_nn.py:136-175 as train_syn_*.py reaches it): 2 (default) = every f32 operand of the three
+ * GEMMs as two bf16 pieces on the bf16 matrix cores (gradients within 5e-6 of the exact kernel's), 3 = three pieces (4e-7), 0 = f32 matrix
+ * cores (exact f32 products).  Process-wide; the environment variable FGNN_EXT_BWD_PIECES gives the initial value.  Returns the previous
+ * setting; other values leave it unchanged.  No reference counterpart. */
+int fgnn_set_ext_backward_pieces(int pieces);
+
 /* Diagnostic: a one-thread kernel on `stream` writes the device's constant 100 MHz clock to *dst (uint64).  Inside a captured step
  * it tells when that point of the stream is reached in a replay without a profiler attached.  No reference counterpart. */
 int fgnn_stamp(void* dst, void* stream);

@@ -144,6 +144,52 @@ def test_ext_backward_vs_oracle_autograd(shape, ext, B, dev):
         assert err <= 2e-4, (name, err)
 
 
+@pytest.fixture
+def backward_pieces():
+    """Sets the arithmetic of the family's backward (fgnn_set_ext_backward_pieces) for one test and restores it."""
+    from fgnn_amd import _hip
+    before = []
+
+    def use(pieces):
+        prev = int(_hip.lib().fgnn_set_ext_backward_pieces(pieces))
+        if not before:
+            before.append(prev)
+    yield use
+    if before:
+        _hip.lib().fgnn_set_ext_backward_pieces(before[0])
+
+
+@pytest.mark.parametrize('shape', [(60, 2), (60, 9), (64, 10), (33, 3), (17, 16)], ids=['60x2', '60x9', '64x10', '33x3', '17x16'])
+@pytest.mark.parametrize('ext', [1, 2])
+def test_ext_backward_piece_forms_against_the_exact_kernel(shape, ext, dev, backward_pieces):
+    """Round 6: the three GEMMs of the backward as bf16 pieces on the bf16 matrix cores (csrc/mpconv_bwd_ext.hip:
+    mpconv_bwd_extq_kernel).  Two pieces (the default) stay within 2e-5 of the exact-f32 kernel's gradients, three pieces within
+    2e-6 (f32 rounding); each form names its kernel, meets the oracle's autograd at the family's 2e-4, and gives the same bits twice."""
+    from fgnn_amd import _hip
+    N, k = shape
+    res = {}
+    for pieces, name in ((0, 'mpconv_bwd_ext_kernel'), (2, 'mpconv_bwd_extq_kernel<2'), (3, 'mpconv_bwd_extq_kernel<3')):
+        backward_pieces(pieces)
+        ref, got = _grads_vs_oracle(N, k, 160, ext, dev, seed=7)
+        assert name in _hip.lib().fgnn_last_kernel().decode(), (pieces, _hip.lib().fgnn_last_kernel())
+        for r, g in zip(ref, got):
+            assert float((r - g).abs().max() / r.abs().max().clamp_min(1e-20)) <= 2e-4
+        _, again = _grads_vs_oracle(N, k, 160, ext, dev, seed=7)
+        for a, b in zip(got, again):
+            assert torch.equal(a, b)
+        res[pieces] = got
+    for pieces, bound in ((2, 2e-5), (3, 2e-6)):
+        for name, e, g in zip(('gx', 'getype', 'gfilters', 'gbias'), res[0], res[pieces]):
+            err = float((e - g).abs().max() / e.abs().max().clamp_min(1e-20))
+            assert err <= bound, (pieces, name, err)
+
+
+def test_ext_backward_default_is_the_two_piece_form(dev):
+    from fgnn_amd import _hip
+    _grads_vs_oracle(60, 9, 64, 2, dev, seed=3)
+    assert 'mpconv_bwd_extq_kernel<2' in _hip.lib().fgnn_last_kernel().decode(), _hip.lib().fgnn_last_kernel()
+
+
 def test_ext_backward_bitwise_reproducible(dev):
     """No float atomics anywhere: two runs of the same training call give the same bits (the shape-generic kernel scatters
     gx / gW with atomicAdd and does not)."""
