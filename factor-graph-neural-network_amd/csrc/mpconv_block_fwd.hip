@@ -504,6 +504,143 @@ __global__ __launch_bounds__(512) void mpconv_block_fanout_kernel(const KfParams
     }
 }
 
+
+// ----------------------------------------------------------------------------------------
+// The fan-out block on ONE row per sample (round 6; M = 1: the caller hands the result on as a per-sample broadcast,
+// blocks.py `_fused_eval`).  With one destination the block is three small GEMMs over the batch — [B x nin] W1^T, [B x 64] F,
+// [B x 64] W2^T — and the wave-per-sample kernel above spends its time in two readlane mat-vec chains per sample behind a 36 us
+// weight-staging prologue per workgroup (140 us per launch at B = 4096, on the inference forward's critical path:
+// profiles/r06/README.md).  Here a wave takes 16 SAMPLES as the N dimension of v_mfma_f32_16x16x32_bf16 and computes the
+// TRANSPOSED products a1^T = W1 x^T, P^T = F^T a1^T, y^T = W2 a2^T: the accumulator tiles of one product (lane: sample li, rows
+// 16 t + 4 lk + r) ARE the B fragments of the next (k-slot (ks, i) <-> row 16 (2 ks + (i >> 2)) + 4 lk + (i & 3); the weight
+// fragments are gathered in that order), so nothing goes through LDS and there is no prologue.  The f32 weights of conv1 and of
+// the operator enter as two bf16 pieces (two MFMAs: the f32 products of the kernel above up to the summation order), conv2's as
+// bf16, like there; the same bf16 rounding points (a1, P, a2, y).
+// ----------------------------------------------------------------------------------------
+__device__ __forceinline__ void kr_split8(const float* w, kb_bf16x8& hi, kb_bf16x8& lo) {      // 8 f32 -> bf16 hi + lo fragments
+    unsigned h[4], l[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float a = w[2 * q], b = w[2 * q + 1];
+        h[q] = kb_pack2(a, b);
+        l[q] = kb_pack2(a - __uint_as_float(h[q] << 16), b - __uint_as_float(h[q] & 0xffff0000u));
+    }
+    hi = __builtin_bit_cast(kb_bf16x8, make_uint4(h[0], h[1], h[2], h[3]));
+    lo = __builtin_bit_cast(kb_bf16x8, make_uint4(l[0], l[1], l[2], l[3]));
+}
+
+template <int NI>
+__global__ __launch_bounds__(64) void mpconv_block_rows1_kernel(const KfParams p) {
+    constexpr int NIN = 64 * NI, KS1 = NIN / 32;
+    const fgnn_mpconv_desc& d = p.d;
+    const int lane = threadIdx.x;
+    const int li = lane & 15, lk = lane >> 4;
+    const int nout = p.nout;
+    const int b = blockIdx.x * 16 + li;
+    const bool live = b < d.B;
+    const int64_t bs = live ? b : d.B - 1;                 // (rows beyond the batch compute on the last sample and store nothing)
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+
+    // ---- a1^T [64 o][16 samples] = W1 [o][c] x^T [c][sample] ----
+    f32x4 acc1[4] = {zero, zero, zero, zero};
+    const uint16_t* xrow = p.x + bs * d.x_sb + 8 * lk;
+#pragma unroll 2
+    for (int ks = 0; ks < KS1; ++ks) {
+        const kb_bf16x8 xb = __builtin_bit_cast(kb_bf16x8, *reinterpret_cast<const uint4*>(xrow + 32 * ks));
+#pragma unroll
+        for (int ot = 0; ot < 4; ++ot) {
+            const float* wr = p.W1 + (int64_t)(16 * ot + li) * NIN + 32 * ks + 8 * lk;
+            const f32x4 w0 = *reinterpret_cast<const f32x4*>(wr), w1 = *reinterpret_cast<const f32x4*>(wr + 4);
+            const float w[8] = {w0[0], w0[1], w0[2], w0[3], w1[0], w1[1], w1[2], w1[3]};
+            kb_bf16x8 hi, lo;
+            kr_split8(w, hi, lo);
+            acc1[ot] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lo, xb, acc1[ot], 0, 0, 0);
+            acc1[ot] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hi, xb, acc1[ot], 0, 0, 0);
+        }
+    }
+    // BatchNorm1 + LeakyReLU, rounded to bf16: the B fragments of the next product
+    kb_bf16x8 b2[2];
+    {
+        unsigned wq[8];
+#pragma unroll
+        for (int ot = 0; ot < 4; ++ot) {
+            const int o = 16 * ot + 4 * lk;
+            const f32x4 s1 = *reinterpret_cast<const f32x4*>(p.s1 + o), t1 = *reinterpret_cast<const f32x4*>(p.t1 + o);
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const float u = fmaf(acc1[ot][r], s1[r], t1[r]); v[r] = u > 0.f ? u : u * p.slope; }
+            wq[2 * ot] = kb_pack2(v[0], v[1]);
+            wq[2 * ot + 1] = kb_pack2(v[2], v[3]);
+        }
+        b2[0] = __builtin_bit_cast(kb_bf16x8, make_uint4(wq[0], wq[1], wq[2], wq[3]));
+        b2[1] = __builtin_bit_cast(kb_bf16x8, make_uint4(wq[4], wq[5], wq[6], wq[7]));
+    }
+    // ---- P^T [64 o2][16 samples] = F^T a1^T: A[o2 = 16 t + li][k-slot (ks, i)] = F[o = 16 (2 ks + (i >> 2)) + 4 lk + (i & 3)][o2] ----
+    f32x4 acc2[4] = {zero, zero, zero, zero};
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            float w[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) w[i] = p.F[(16 * (2 * ks + (i >> 2)) + 4 * lk + (i & 3)) * 64 + 16 * t + li];
+            kb_bf16x8 hi, lo;
+            kr_split8(w, hi, lo);
+            acc2[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lo, b2[ks], acc2[t], 0, 0, 0);
+            acc2[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hi, b2[ks], acc2[t], 0, 0, 0);
+        }
+    // P rounded to bf16, a2 = ReLU(e (s2 P) + t2) rounded to bf16: the B fragments of conv2
+    const float e = __uint_as_float((unsigned)p.et[bs * d.et_sb] << 16);
+    kb_bf16x8 b3[2];
+    {
+        unsigned wq[8];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int o2 = 16 * t + 4 * lk;
+            const f32x4 s2 = *reinterpret_cast<const f32x4*>(p.s2 + o2), t2 = *reinterpret_cast<const f32x4*>(p.t2 + o2);
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const __bf16 h = (__bf16)acc2[t][r];
+                const float P = __uint_as_float((unsigned)__builtin_bit_cast(uint16_t, h) << 16);
+                v[r] = fmaxf(fmaf(e, s2[r] * P, t2[r]), 0.f);
+            }
+            wq[2 * t] = kb_pack2(v[0], v[1]);
+            wq[2 * t + 1] = kb_pack2(v[2], v[3]);
+        }
+        b3[0] = __builtin_bit_cast(kb_bf16x8, make_uint4(wq[0], wq[1], wq[2], wq[3]));
+        b3[1] = __builtin_bit_cast(kb_bf16x8, make_uint4(wq[4], wq[5], wq[6], wq[7]));
+    }
+    // ---- y^T [nout q][16 samples] = W2 a2^T; BatchNorm3 + LeakyReLU + addends; 8 bytes (channels 16 qt + 4 lk ..) per lane and tile ----
+    uint16_t* yb = p.y + bs * nout;
+    const uint16_t* adbs[3] = {p.addend ? p.addend + bs * nout : nullptr, p.addend1 ? p.addend1 + bs * nout : nullptr,
+                               p.addend2 ? p.addend2 + bs * nout : nullptr};
+#pragma unroll 2
+    for (int qt = 0; qt < nout / 16; ++qt) {
+        f32x4 acc = zero;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const float* wr = p.W2 + (int64_t)(16 * qt + li) * 64 + 4 * lk;
+            const f32x4 w0 = *reinterpret_cast<const f32x4*>(wr + 16 * (2 * ks)), w1 = *reinterpret_cast<const f32x4*>(wr + 16 * (2 * ks + 1));
+            const kb_bf16x8 a = __builtin_bit_cast(kb_bf16x8, make_uint4(kb_pack2(w0[0], w0[1]), kb_pack2(w0[2], w0[3]), kb_pack2(w1[0], w1[1]), kb_pack2(w1[2], w1[3])));
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b3[ks], acc, 0, 0, 0);
+        }
+        const int q = 16 * qt + 4 * lk;
+        const f32x4 s3 = *reinterpret_cast<const f32x4*>(p.s3 + q), t3 = *reinterpret_cast<const f32x4*>(p.t3 + q);
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const float u = fmaf(acc[r], s3[r], t3[r]); v[r] = u > 0.f ? u : u * p.slope; }
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+            if (adbs[a]) {
+                const uint2 aw = *reinterpret_cast<const uint2*>(adbs[a] + q);
+                v[0] += __uint_as_float(aw.x << 16); v[1] += __uint_as_float(aw.x & 0xffff0000u);
+                v[2] += __uint_as_float(aw.y << 16); v[3] += __uint_as_float(aw.y & 0xffff0000u);
+            }
+        if (live) *reinterpret_cast<uint2*>(yb + q) = make_uint2(kb_pack2(v[0], v[1]), kb_pack2(v[2], v[3]));
+    }
+}
+
 // ----------------------------------------------------------------------------------------
 // Fan-in block (variables -> the hyper-factor): M = 1 destination listening to all N nodes in order (idx[j] = j,
 // k = N), one edge type with per-neighbour weights et[j].  One wave per sample, nothing but the two weight images
@@ -652,6 +789,7 @@ __global__ __launch_bounds__(512) void mpconv_block_fanin_kernel(const KfParams 
 
 // Fan-out form of fgnn_mpconv_block_forward: d describes the inner operator with N = 1, k = 1, net = 1, nin = nou = 64
 // (x strides: the block's input [B, nin]; y: [B, M, nout]); F is [64][64].
+static const bool ROWS1 = getenv("FGNN_NO_BLOCK_ROWS1") == nullptr;      // (A/B switch of the one-row form, tools/gpu_ab.sh)
 extern "C" int fgnn_mpconv_block_forward_fanout(const fgnn_mpconv_desc* d, const void* x, const void* etype,
                                                 const float* W1, const float* s1, const float* t1, const float* filters,
                                                 const float* s2, const float* t2, const float* W2, const float* s3,
@@ -671,6 +809,16 @@ extern "C" int fgnn_mpconv_block_forward_fanout(const fgnn_mpconv_desc* d, const
     p.x = (const uint16_t*)x; p.et = (const uint16_t*)etype; p.W1 = W1; p.s1 = s1; p.t1 = t1; p.F = filters;
     p.s2 = s2; p.t2 = t2; p.W2 = W2; p.s3 = s3; p.t3 = t3; p.addend = (const uint16_t*)addend; p.addend1 = (const uint16_t*)addend1; p.addend2 = (const uint16_t*)addend2; p.y = (uint16_t*)y;
     p.slope = slope; p.nin = nin; p.nout = nout; p.Mpad = fgnn_round_up(d->M, 16);
+    if (d->M == 1 && ROWS1 && d->x_sb % 8 == 0 && !((uintptr_t)x & 15) && !(((uintptr_t)W1 | (uintptr_t)W2 | (uintptr_t)s1 | (uintptr_t)t1 |
+        (uintptr_t)s2 | (uintptr_t)t2 | (uintptr_t)s3 | (uintptr_t)t3) & 15)) {
+        // one row per sample: 16 samples per wave on the matrix cores, no weight staging
+        void* fr = nin == 64 ? (void*)mpconv_block_rows1_kernel<1> : nin == 128 ? (void*)mpconv_block_rows1_kernel<2> : (void*)mpconv_block_rows1_kernel<4>;
+        fgnn_note_kernel("mpconv_block_rows1_kernel<%d>", nin / 64);
+        void* rargs[] = {(void*)&p};
+        hipError_t er = hipLaunchKernel(fr, dim3((d->B + 15) / 16), dim3(64), rargs, 0, (hipStream_t)stream);
+        if (er != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "mpconv_block_forward_fanout (one row) launch: %s", hipGetErrorString(er));
+        return FGNN_OK;
+    }
     const int lds = nin * 64 * 4 + 64 * 64 * 4 + nout * KB_XSB * 2 + 8 * 128 * 4;
     void* fn = nin == 64 ? (void*)mpconv_block_fanout_kernel<1> : nin == 128 ? (void*)mpconv_block_fanout_kernel<2>
                                                                              : (void*)mpconv_block_fanout_kernel<4>;
