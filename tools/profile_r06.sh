@@ -52,4 +52,24 @@ FGNN_STEP_SEQ=/tmp/seq_r06.csv sh tools/profile_step_traffic.sh r06/traffic > /d
 # 8. kernel statistics of the synthetic-PGM training steps (configs 2 / 5)
 sh tools/profile_syn.sh > /dev/null 2>&1
 mkdir -p $O/syn && cp $R/gpurun_out/prof_syn/* $O/syn/ 2>/dev/null
+# 9. the synthetic-PGM operator's backward (configs 2 / 5): exact-f32 kernel / three / two bf16 pieces — call times, gradients against the
+#    exact kernel's —, its PMC passes, and the training steps with the exact kernel (the round's A/B)
+mkdir -p $O/ext
+FGNN_EXT_BWD_PIECES=0 python tools/xbench.py --save=/tmp/ext_exact.pt 2>&1 | grep -v amdgpu.ids > $O/ext/xbench_exact_f32.txt
+FGNN_EXT_BWD_PIECES=3 python tools/xbench.py --compare=/tmp/ext_exact.pt 2>&1 | grep -v amdgpu.ids > $O/ext/xbench_three_pieces.txt
+FGNN_EXT_BWD_PIECES=2 python tools/xbench.py --compare=/tmp/ext_exact.pt 2>&1 | grep -v amdgpu.ids > $O/ext/xbench_two_pieces.txt
+sh tools/profile_pmc_ext.sh r06/ext/pmc > /dev/null 2>&1
+FGNN_EXT_BWD_PIECES=0 python bench.py --workload syn_hop --no-cpu-baseline > $O/bench_syn_hop_exact_f32_backward.json 2> /dev/null
+FGNN_EXT_BWD_PIECES=0 python bench.py --workload syn_pw --no-cpu-baseline > $O/bench_syn_pw_exact_f32_backward.json 2> /dev/null
+FGNN_EXT_BWD_PIECES=3 python bench.py --workload syn_hop --no-cpu-baseline > $O/bench_syn_hop_three_pieces.json 2> /dev/null
+# 10. what a replayed two-branch hipGraph really does, with NO profiler attached: dependent-kernel latency in one- / two-branch graphs, the
+#     fork probe, and device stamps inside the benched step (when each layer's two chains start and end) with the host's lead
+mkdir -p $O/graph
+python tools/ubench/graph_chain_latency.py 2>&1 | grep -v amdgpu.ids > $O/graph/chain_latency.txt
+python tools/ubench/graph_fork_probe.py --time 2>&1 | grep -v amdgpu.ids > $O/graph/fork_probe_time.txt
+FGNN_STAMPS=1 FGNN_BENCH_HOST_TIMES=1 python bench.py --no-cpu-baseline --steps 20 > $O/graph/bench_stamps.json 2> $O/graph/bench_stamps.err
+grep -E "^stamp|host enqueue|step: host" $O/graph/bench_stamps.err > $O/graph/step_stamps.txt
+FGNN_BENCH_HOST_TIMES=1 FGNN_NO_SIDE_STREAM=1 python bench.py --no-cpu-baseline --steps 20 2>&1 > /dev/null | grep -E "host enqueue" > $O/graph/host_times_one_stream.txt
+# 11. inference: the one-row hyper-factor block on the wave-per-sample kernel (A/B of mpconv_block_rows1_kernel)
+FGNN_NO_BLOCK_ROWS1=1 python bench.py --mode fwd --no-cpu-baseline > $O/bench_fwd_wave_per_sample_fanout.json 2> /dev/null
 ls -la $O

@@ -132,6 +132,13 @@ def main():
             elif base.startswith('bench_'):
                 shutil.copy(f, os.path.join(DST, 'rocprof_' + base))
     names += [os.path.basename(f) for f in _g.glob(os.path.join(SRC, 'kbench_*.log'))]
+    # round 6 (second half): the synthetic-PGM backward's piece forms, and the no-profiler measurements of the replayed graph
+    for sub, prefix in (('ext', 'ext_'), ('graph', 'graph_')):
+        for f in _g.glob(os.path.join(SRC, sub, '*.txt')) + _g.glob(os.path.join(SRC, sub, '*.json')):
+            if os.path.getsize(f) < 2 * 1024 * 1024:
+                shutil.copy(f, os.path.join(DST, prefix + os.path.basename(f)))
+    if os.path.exists(os.path.join(SRC, 'ext', 'pmc', 'pmc_ext_bwd.json')):
+        shutil.copy(os.path.join(SRC, 'ext', 'pmc', 'pmc_ext_bwd.json'), os.path.join(DST, 'pmc_ext_bwd.json'))
     for f in names:
         if os.path.exists(os.path.join(SRC, f)):
             shutil.copy(os.path.join(SRC, f), os.path.join(DST, f))
