@@ -157,8 +157,9 @@ _V2V_MAIN = set()      # layers whose v2v map stays on the main stream.  Measure
 
 
 _F2F_SIDE = True       # the parity factors' f2f map on the side stream (round 5: -0.1 ms)
-import os as _os
-_MAIN_FIRST = _os.environ.get('FGNN_MAIN_FIRST') is not None      # EXPERIMENT (round 6): issue the main stream's V->F parity block before the side chain
+# (Issue order of a layer's two chains — round 6, measured: the capture stream's V->F parity block issued BEFORE the side chain makes the
+# step 0.85 ms slower (13.57 against 12.74 ms): the runtime continues a graph branch with the FIRST child of its fork node, and the chain
+# that continues the fork's branch must be the side chain.  profiles/r06/README.md "What the replayed graph really does".)
 _FAC_MERGE_SIDE = 1    # 1 = the factor states' gradient merge on the side stream (2: the variables' instead; round 5: -0.13 ms with 1)
 
 
@@ -388,12 +389,6 @@ class FactorNN(torch.nn.Module):
                     nf0 = self.f2f_modules[L][0](fac_c[0][0])
                     f2f_done = torch.cuda.Event()
                     f2f_done.record(side)
-            main_first = f2f_side and _MAIN_FIRST
-            if main_first:
-                def fac_addends(nf=nf0, f2f_done=f2f_done, same_width=same_width, skip=skip, fac_c=fac_c):
-                    main.wait_event(f2f_done)
-                    return [nf, fac_c[0][-1] if same_width else None, skip[1][0] if skip else None]
-                new_fac[0] = _call(self.v2f_modules[L][0], var_c[1], nn_idx_v2f[0], etype_v2f[0][L], addend=fac_addends)
             for j in range(1, nft):
                 with (torch.cuda.stream(side) if two else contextlib.nullcontext()):
                     nf = self.f2f_modules[L][j](fac_c[j][0])
@@ -404,9 +399,7 @@ class FactorNN(torch.nn.Module):
                 new_var = self.v2v_modules[L](var_c[0])        # the variables' node-wise map rides with the side branch
                 if two and _ops.STAMPS is not None:
                     _ops.stamp('L%d side_end' % L)
-            if main_first:
-                pass
-            elif f2f_side:
+            if f2f_side:
                 def fac_addends(nf=nf0, f2f_done=f2f_done, same_width=same_width, skip=skip, fac_c=fac_c):
                     main.wait_event(f2f_done)
                     return [nf, fac_c[0][-1] if same_width else None, skip[1][0] if skip else None]
