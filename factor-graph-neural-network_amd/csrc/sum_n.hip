@@ -139,3 +139,60 @@ extern "C" int fgnn_node_sum(const void* g, void* out, int64_t B, int M, int C, 
     if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "node_sum launch: %s", hipGetErrorString(e));
     return FGNN_OK;
 }
+
+
+// ----------------------------------------------------------------------------------------
+// out[s][n] = [ a[s][n] | b[s][n] ]: two arrays of samples x `inner` chunks (ua / ub 16-byte units each, any sample / chunk strides:
+// slices of a larger activation qualify) interleaved chunk by chunk —
+// torch.cat of two channel-fastest activations along the node axis (inner = 1, chunk = nodes x channels:
+// /root/reference/lib/model/mpnn/factor_mpnn.py:104-107, variables and factors of one type stacked for a block) or along the channel
+// axis (inner = nodes, chunk = channels: factor_mpnn.py:116, the blocks' messages in front of the merge map).  torch runs one strided
+// copy kernel per input (~9 us each at the synthetic-PGM shapes: 100 launches = 0.9 ms of BASELINE config 5's step); this is one
+// 16-byte-per-lane pass.
+// ----------------------------------------------------------------------------------------
+struct CcParams {
+    const uint4* a;
+    const uint4* b;
+    uint4* out;
+    unsigned ua, ub;     // chunk sizes in 16-byte units
+    unsigned inner;      // chunks per sample
+    int64_t sab, san, sbb, sbn;      // strides (16-byte units) of a / b: per sample, per chunk within the sample
+    int64_t total;       // samples * inner * (ua + ub)
+};
+
+__global__ __launch_bounds__(256) void concat_pair_kernel(const CcParams p) {
+    const unsigned u = p.ua + p.ub;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < p.total; i += stride) {
+        const int64_t o = i / u;
+        const unsigned r = (unsigned)(i - o * u);
+        const int64_t s = o / p.inner;
+        const unsigned n = (unsigned)(o - s * p.inner);
+        p.out[i] = r < p.ua ? p.a[s * p.sab + n * p.san + r] : p.b[s * p.sbb + n * p.sbn + (r - p.ua)];
+    }
+}
+
+extern "C" int fgnn_concat_pair(const void* a, const void* b, void* out, int64_t samples, int64_t inner, int64_t chunk_a_bytes,
+                                int64_t chunk_b_bytes, int64_t a_sample_stride_bytes, int64_t a_chunk_stride_bytes,
+                                int64_t b_sample_stride_bytes, int64_t b_chunk_stride_bytes, fgnn_stream_t stream) {
+    if (!a || !b || !out) FGNN_FAIL(FGNN_EINVAL, "concat_pair: null pointer");
+    if (samples < 0 || inner < 1 || inner > 0x7fffffff || chunk_a_bytes <= 0 || chunk_b_bytes <= 0 ||
+        chunk_a_bytes > (int64_t)1 << 34 || chunk_b_bytes > (int64_t)1 << 34 ||
+        (chunk_a_bytes | chunk_b_bytes | a_sample_stride_bytes | a_chunk_stride_bytes | b_sample_stride_bytes | b_chunk_stride_bytes) % 16 ||
+        a_sample_stride_bytes < 0 || a_chunk_stride_bytes < 0 || b_sample_stride_bytes < 0 || b_chunk_stride_bytes < 0)
+        FGNN_FAIL(FGNN_EUNSUPPORTED, "concat_pair: chunks and strides must be non-negative multiples of 16 bytes");
+    if (((uintptr_t)a | (uintptr_t)b | (uintptr_t)out) & 15) FGNN_FAIL(FGNN_EUNSUPPORTED, "concat_pair: pointers must be 16-byte aligned");
+    if (samples == 0) return FGNN_OK;
+    CcParams p;
+    p.a = (const uint4*)a; p.b = (const uint4*)b; p.out = (uint4*)out;
+    p.ua = (unsigned)(chunk_a_bytes / 16); p.ub = (unsigned)(chunk_b_bytes / 16);
+    p.inner = (unsigned)inner;
+    p.sab = a_sample_stride_bytes / 16; p.san = a_chunk_stride_bytes / 16; p.sbb = b_sample_stride_bytes / 16; p.sbn = b_chunk_stride_bytes / 16;
+    p.total = samples * inner * (int64_t)(p.ua + p.ub);
+    int64_t grid = (p.total + 255) / 256;
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(concat_pair_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "concat_pair launch: %s", hipGetErrorString(e));
+    return FGNN_OK;
+}

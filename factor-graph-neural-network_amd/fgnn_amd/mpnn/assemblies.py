@@ -68,7 +68,8 @@ class _SplitNodes(torch.autograd.Function):
             g_nodes = ref.new_zeros((B, C, ctx.n, W))
         if g_factors is None:
             g_factors = ref.new_zeros((B, C, N - ctx.n, W))
-        g = torch.cat([g_nodes, g_factors], dim=2)
+        from .. import ops as _ops
+        g = _ops.concat2(g_nodes, g_factors, 2) if ctx.cl else torch.cat([g_nodes, g_factors], dim=2)
         return (g.contiguous(memory_format=torch.channels_last) if ctx.cl else g), None
 
 
@@ -123,6 +124,7 @@ class factor_mpnn(torch.nn.Module):
         ffeat = [m(f) for f, m in zip(factor_features, self.mapping_modules[1:])]
         history = []
         from ..ops import fan_out
+        from .. import ops as _ops
         track = torch.is_grad_enabled() and nfeat.requires_grad
         for L, row in enumerate(self.mp_nn_modules):
             to_nodes, to_factors = [], []
@@ -131,7 +133,7 @@ class factor_mpnn(torch.nn.Module):
             nf_c = fan_out(nfeat, len(row)) if (track and len(row) > 1 and L not in self.skip_link.values()) else [nfeat] * len(row)
             for j, m in enumerate(row):
                 # channel-fastest, like every activation on this path (the operator kernels read node rows of channels)
-                both = torch.cat([nf_c[j], ffeat[j]], dim=2).contiguous(memory_format=torch.channels_last)
+                both = _ops.concat2(nf_c[j], ffeat[j], 2)            # (one launch: torch.cat is a strided copy kernel per input)
                 nn_idx, etype = graph_structures[j]
                 both = _call(m, both, nn_idx, etype)
                 if track:
@@ -140,7 +142,7 @@ class factor_mpnn(torch.nn.Module):
                     nd, fc = both[:, :, :nnode, :], both[:, :, nnode:, :]
                 to_nodes.append(nd)
                 to_factors.append(fc)
-            nfeat = self.mp_merge_modules[L](torch.cat(to_nodes, dim=1))
+            nfeat = self.mp_merge_modules[L](_ops.concat2(to_nodes[0], to_nodes[1], 1) if len(to_nodes) == 2 else torch.cat(to_nodes, dim=1))
             ffeat = to_factors
             if L in self.skip_link:
                 pn, pf = history[self.skip_link[L]]

@@ -1124,6 +1124,72 @@ def add_n(ts):
     return _SumN.apply(*ts)
 
 
+def _concat2_plan(a, b, dim):
+    """(samples, inner, chunk bytes a / b, sample / chunk strides in bytes of a / b) when ``torch.cat([a, b], dim)`` of two [B, C, N, 1]
+    device tensors is in fgnn_concat_pair's family — channel-fastest (stride(1) == 1; slices of a larger channel-fastest activation
+    qualify), dim 1 (channels) or 2 (nodes), 16-byte granularity — else None."""
+    if not (a.is_cuda and b.is_cuda and a.dim() == 4 and b.dim() == 4 and a.dtype == b.dtype and a.shape[3] == 1 and b.shape[3] == 1
+            and a.shape[0] == b.shape[0] and dim in (1, 2) and a.shape[3 - dim] == b.shape[3 - dim] and a.numel() and b.numel()):
+        return None
+    es = a.element_size()
+    for t in (a, b):
+        C, N = t.shape[1], t.shape[2]
+        if (C > 1 and t.stride(1) != 1) or (N > 1 and t.stride(2) < C) or (t.shape[0] > 1 and t.stride(0) < C * N):
+            return None
+        if dim == 2 and N > 1 and t.stride(2) != C:          # a sample's nodes form one chunk
+            return None
+    B = a.shape[0]
+    if dim == 2:
+        inner, ca, cb = 1, a.shape[1] * a.shape[2] * es, b.shape[1] * b.shape[2] * es
+        sa, sb = (a.stride(0) * es, 0), (b.stride(0) * es, 0)
+    else:
+        inner, ca, cb = a.shape[2], a.shape[1] * es, b.shape[1] * es
+        sa, sb = (a.stride(0) * es, a.stride(2) * es), (b.stride(0) * es, b.stride(2) * es)
+    vals = (ca, cb) + sa + sb
+    if any(v % 16 for v in vals) or (a.data_ptr() | b.data_ptr()) % 16:
+        return None
+    return B, inner, ca, cb, sa[0], sa[1], sb[0], sb[1]
+
+
+def _concat2_raw(a, b, dim, plan=None):
+    """``torch.cat([a, b], dim)`` as one kernel (fgnn_concat_pair), channel-fastest result; None outside the family (see _concat2_plan)."""
+    plan = plan or _concat2_plan(a, b, dim)
+    if plan is None:
+        return None
+    B = a.shape[0]
+    if dim == 2:
+        out = torch.empty((B, a.shape[2] + b.shape[2], 1, a.shape[1]), device=a.device, dtype=a.dtype).permute(0, 3, 1, 2)
+    else:
+        out = torch.empty((B, a.shape[2], 1, a.shape[1] + b.shape[1]), device=a.device, dtype=a.dtype).permute(0, 3, 1, 2)
+    _hip.check(_hip.lib().fgnn_concat_pair(_hip._ptr(a), _hip._ptr(b), _hip._ptr(out), *plan, _hip.stream_ptr()))
+    return out
+
+
+class _Concat2(torch.autograd.Function):
+    """torch.cat of two tensors as one kernel; the backward is torch.cat's own (two narrow views of the gradient)."""
+
+    @staticmethod
+    def forward(ctx, a, b, dim):
+        ctx.dim, ctx.na = dim, a.shape[dim]
+        return _concat2_raw(a, b, dim)
+
+    @staticmethod
+    def backward(ctx, g):
+        nb = g.shape[ctx.dim] - ctx.na
+        return g.narrow(ctx.dim, 0, ctx.na), g.narrow(ctx.dim, ctx.na, nb), None
+
+
+def concat2(a, b, dim):
+    """``torch.cat([a, b], dim)`` — one launch for two channel-fastest device activations (factor_mpnn's node-axis and channel-axis
+    concatenations, /root/reference/lib/model/mpnn/factor_mpnn.py:104-107,116), torch.cat otherwise."""
+    if _concat2_plan(a.detach(), b.detach(), dim) is None:
+        out = torch.cat([a, b], dim=dim)
+        return out.contiguous(memory_format=torch.channels_last) if (out.dim() == 4 and dim == 2) else out
+    if torch.is_grad_enabled() and (a.requires_grad or b.requires_grad):
+        return _Concat2.apply(a, b, dim)
+    return _concat2_raw(a, b, dim)
+
+
 def algorithmic_bytes(x, nn_idx, etype, nou, net, ext, agg):
     """SURVEY §8d algorithmic HBM bytes of one forward call (for bench.py's roofline)."""
     y = _alloc_out(x, nou, nn_idx.shape[1]) if x.is_cuda else None

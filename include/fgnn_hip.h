@@ -458,6 +458,16 @@ int fgnn_factor_layer_forward(int32_t B, const void* var, const void* fac0, cons
  * a state that fans out into several consumers (factor_mpnn_sp.py:139-170) instead of autograd's pairwise adds.
  */
 int fgnn_sum_n(const void* const* inputs, int32_t n, int64_t numel, int32_t dtype, void* out, fgnn_stream_t stream);
+
+/* out[s][n] = [ a[s][n] | b[s][n] ], s < samples, n < inner: two arrays of chunks interleaved chunk by chunk in one pass, dense result —
+ * torch.cat of two channel-fastest activations along the node axis (inner = 1, chunk = a sample's nodes x channels;
+ * /root/reference/lib/model/mpnn/factor_mpnn.py:104-107: the variables and one factor type stacked for a block) or along the channel axis
+ * (inner = nodes, chunk = channels; factor_mpnn.py:116: the blocks' messages in front of the merge map).  The inputs may be slices of
+ * larger activations: per-sample and per-chunk strides in bytes.  Sizes and strides are multiples of 16 bytes, pointers 16-byte aligned;
+ * any element type.  ABI >= 13. */
+int fgnn_concat_pair(const void* a, const void* b, void* out, int64_t samples, int64_t inner, int64_t chunk_a_bytes, int64_t chunk_b_bytes,
+                     int64_t a_sample_stride_bytes, int64_t a_chunk_stride_bytes, int64_t b_sample_stride_bytes,
+                     int64_t b_chunk_stride_bytes, fgnn_stream_t stream);
 /*
  * out [B][C] = sum over the M rows of each sample of g [B][M][C] (dense channel-fastest rows): the backward of a per-sample row
  * broadcast over the sample's nodes — the LDPC hyper-factor's message to the variables (train_ldpc.py:40-46,82-88: one source node,
