@@ -154,8 +154,11 @@ class factor_mpnn(torch.nn.Module):
         return nfeat, ffeat
 
 
-_V2V_MAIN = set()      # layers whose v2v map stays on the main stream.  Measured (round 4, 18.25 ms with none): layers 0,1,7: 18.27; 2-6:
-# 18.47; 3-5: 18.54; all: 18.48 — the map belongs on the side stream.
+_V2V_MAIN = {4, 6}     # layers whose v2v map stays on the main stream.  Round 4 (18.25 ms with none): layers 0,1,7: 18.27; 2-6: 18.47; 3-5: 18.54;
+# all: 18.48 — the map belonged on the side stream.  Round 6: device stamps inside the replayed step (profiles/r06/graph_step_stamps.txt) show
+# the SIDE chain as the longer one of every layer since the hyper-factor's message became one row per codeword; re-measured (three
+# interleaved runs each, 12.78 - 12.83 ms with none): {4}: 12.62 - 12.66; {4, 6}: 12.58 - 12.59; {4, 5, 6}: 12.57 - 12.59; {2, 4, 6}: 12.61;
+# {4, 6, 7} / {1, 4, 6} / {0, 4, 6}: +0.03 - 0.09 over {4, 6}; {3}: 12.74; {5}: 12.71.
 
 
 _F2F_SIDE = True       # the parity factors' f2f map on the side stream (round 5: -0.1 ms)
