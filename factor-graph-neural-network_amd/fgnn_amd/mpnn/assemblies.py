@@ -400,7 +400,8 @@ class FactorNN(torch.nn.Module):
                     new_fac[j] = _call(self.v2f_modules[L][j], var_c[1 + j], nn_idx_v2f[j], etype_v2f[j][L],
                                        addend=[nf, fac_c[j][-1] if same_width else None, skip[1][j] if skip else None])
                     h.append(_call(self.f2v_modules[L][j], fac_c[j][1], nn_idx_f2v[j], etype_f2v[j][L]))
-            with (torch.cuda.stream(side) if (two and L not in _V2V_MAIN) else contextlib.nullcontext()):
+            v2v_main = L in _V2V_MAIN and self.training and torch.is_grad_enabled()      # (inference: the capture stream's two one-kernel blocks are the longer chain)
+            with (torch.cuda.stream(side) if (two and not v2v_main) else contextlib.nullcontext()):
                 new_var = self.v2v_modules[L](var_c[0])        # the variables' node-wise map rides with the side branch
                 if two and _ops.STAMPS is not None:
                     _ops.stamp('L%d side_end' % L)
