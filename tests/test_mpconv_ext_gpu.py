@@ -99,7 +99,7 @@ def test_ext_forward_matches_generic_kernel(dev, monkeypatch):
 BWD_SHAPES = [(60, 2), (60, 9), (59, 3), (64, 10), (17, 16), (1, 1)]
 
 
-def _grads_vs_oracle(N, k, B, ext, dev, seed=0, nou=64, agg='max'):
+def _grads_vs_oracle(N, k, B, ext, dev, seed=0, nou=64, agg='max', info=None):
     from fgnn_amd import _hip, ops
     x, idx, et, W, bias, g = _problem(N, k, B, seed=seed)
     W, bias = W[:, :nou * 16].contiguous(), bias[:nou].contiguous()
@@ -113,6 +113,8 @@ def _grads_vs_oracle(N, k, B, ext, dev, seed=0, nou=64, agg='max'):
     assert ('mpconv_fwd_ext' in _hip.lib().fgnn_last_kernel().decode()) == (nou == 64)
     (z * gy.to(dev).permute(0, 3, 1, 2)).sum().backward()
     assert 'mpconv_bwd_ext' in _hip.lib().fgnn_last_kernel().decode(), _hip.lib().fgnn_last_kernel()
+    if info is not None:
+        info['backward_kernel'] = _hip.lib().fgnn_last_kernel().decode()
     xo = x.permute(0, 3, 1, 2).clone().requires_grad_(True)
     eo = et.clone().requires_grad_(True)
     Wo, bo = W.clone().requires_grad_(True), bias.clone().requires_grad_(True)
@@ -167,18 +169,21 @@ def test_ext_backward_piece_forms_against_the_exact_kernel(shape, ext, dev, back
     2e-6 (f32 rounding); each form names its kernel, meets the oracle's autograd at the family's 2e-4, and gives the same bits twice."""
     from fgnn_amd import _hip
     N, k = shape
-    res = {}
+    res, ran = {}, {}
     for pieces, name in ((0, 'mpconv_bwd_ext_kernel'), (2, 'mpconv_bwd_extq_kernel<2'), (3, 'mpconv_bwd_extq_kernel<3')):
         backward_pieces(pieces)
-        ref, got = _grads_vs_oracle(N, k, 160, ext, dev, seed=7)
-        assert name in _hip.lib().fgnn_last_kernel().decode(), (pieces, _hip.lib().fgnn_last_kernel())
+        info = {}
+        ref, got = _grads_vs_oracle(N, k, 160, ext, dev, seed=7, info=info)
+        # (three pieces of the widest graphs do not fit the LDS beside the edge tables: the two-piece form takes them)
+        assert name in info['backward_kernel'] or (pieces == 3 and N * k > 600 and 'mpconv_bwd_extq_kernel<2' in info['backward_kernel']), (pieces, info)
+        ran[pieces] = info['backward_kernel']
         for r, g in zip(ref, got):
             assert float((r - g).abs().max() / r.abs().max().clamp_min(1e-20)) <= 2e-4
         _, again = _grads_vs_oracle(N, k, 160, ext, dev, seed=7)
         for a, b in zip(got, again):
             assert torch.equal(a, b)
         res[pieces] = got
-    for pieces, bound in ((2, 2e-5), (3, 2e-6)):
+    for pieces, bound in ((2, 2e-5), (3, 2e-6 if 'kernel<3' in ran[3] else 2e-5)):
         for name, e, g in zip(('gx', 'getype', 'gfilters', 'gbias'), res[0], res[pieces]):
             err = float((e - g).abs().max() / e.abs().max().clamp_min(1e-20))
             assert err <= bound, (pieces, name, err)
@@ -186,8 +191,9 @@ def test_ext_backward_piece_forms_against_the_exact_kernel(shape, ext, dev, back
 
 def test_ext_backward_default_is_the_two_piece_form(dev):
     from fgnn_amd import _hip
-    _grads_vs_oracle(60, 9, 64, 2, dev, seed=3)
-    assert 'mpconv_bwd_extq_kernel<2' in _hip.lib().fgnn_last_kernel().decode(), _hip.lib().fgnn_last_kernel()
+    info = {}
+    _grads_vs_oracle(60, 9, 64, 2, dev, seed=3, info=info)
+    assert 'mpconv_bwd_extq_kernel<2' in info['backward_kernel'], info
 
 
 def test_ext_backward_bitwise_reproducible(dev):
