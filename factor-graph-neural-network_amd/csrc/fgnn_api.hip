@@ -47,3 +47,18 @@ extern "C" int fgnn_stamp(void* dst, void* stream) {
     hipLaunchKernelGGL(fgnn_stamp_kernel, dim3(1), dim3(1), 0, static_cast<hipStream_t>(stream), static_cast<unsigned long long*>(dst));
     return FGNN_OK;
 }
+
+// diagnostic: one thread spins until the device clock has advanced by `ticks` (100 MHz).  At the head of a captured step it gives
+// the HOST a head start: under rocprofv3 the host enqueues a multi-branch graph more slowly than the device runs its short kernels,
+// and a kernel trace then shows the host's enqueue order instead of the graph's schedule; with every node already
+// in its queue when the spin ends, the trace shows what an unprofiled replay does.
+__global__ void fgnn_spin_kernel(unsigned long long ticks) {
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+
+extern "C" int fgnn_spin(int64_t ticks, void* stream) {
+    if (ticks < 0 || ticks > 100000000) { fgnn_set_error("fgnn_spin: 0 .. 1e8 ticks (1 s)"); return FGNN_EINVAL; }
+    hipLaunchKernelGGL(fgnn_spin_kernel, dim3(1), dim3(1), 0, static_cast<hipStream_t>(stream), (unsigned long long)ticks);
+    return FGNN_OK;
+}

@@ -47,7 +47,11 @@ class StepGraph:
         self.stamps = None
         if os.environ.get('FGNN_STAMPS'):               # diagnosis: device timestamps inside the replayed step (ops.stamp)
             ops.STAMPS = {'buf': torch.zeros(8192, dtype=torch.int64, device='cuda'), 'tags': []}
+        delay_ms = float(os.environ.get('FGNN_STEP_HEAD_START_MS', '0'))     # diagnosis (profiled runs): see fgnn_spin
         with torch.cuda.graph(self.graph, stream=self.stream):
+            if delay_ms > 0:
+                from . import _hip
+                _hip.check(_hip.lib().fgnn_spin(int(delay_ms * 1e5), _hip.stream_ptr()))
             ops.stamp('step begin')
             fn()
             ops.stamp('step end')

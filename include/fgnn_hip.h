@@ -587,6 +587,11 @@ int fgnn_set_ext_backward_pieces(int pieces);
  * it tells when that point of the stream is reached in a replay without a profiler attached.  No reference counterpart. */
 int fgnn_stamp(void* dst, void* stream);
 
+/* Diagnostic: one thread on `stream` spins for `ticks` of the 100 MHz device clock (<= 1e8).  At the head of a captured step it lets
+ * the host enqueue the rest of the graph before the device starts on it (a kernel trace taken under a profiler then shows the graph's
+ * own schedule, not the profiler-slowed host's enqueue order).  No reference counterpart. */
+int fgnn_spin(int64_t ticks, void* stream);
+
 int fgnn_abi_version(void);
 
 #ifdef __cplusplus

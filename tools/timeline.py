@@ -29,6 +29,7 @@ def main():
     ap.add_argument('--dump', default=None, help='kernel-name substring: list, per queue, what runs between consecutive launches of it')
     ap.add_argument('--dump-from', type=int, default=0)
     ap.add_argument('--dump-count', type=int, default=2)
+    ap.add_argument('--after', default=None, help='kernel-name substring: the window starts at the END of its last launch inside the step (a head-start spin kernel)')
     ap.add_argument('--seq', default=None, help='write the step window launch by launch (start offset us, duration us, queue, kernel) as CSV')
     a = ap.parse_args()
     rows = []
@@ -43,6 +44,11 @@ def main():
     assert len(marks) > a.marker_stride
     t0, t1 = marks[-1 - a.marker_stride][1], marks[-1][1]
     win = [r for r in rows if r[0] >= t0 and r[1] <= t1]
+    if a.after:
+        heads = [r for r in win if a.after in r[2]]
+        if heads:
+            t0 = max(r[1] for r in heads)
+            win = [r for r in win if r[0] >= t0]
     ev = []
     for i, (s, e, _, _, _) in enumerate(win):
         ev.append((s, 1, i)), ev.append((e, 0, i))
