@@ -111,6 +111,154 @@ __global__ __launch_bounds__(WF_THREADS, 2) void linear_wgrad_f32_kernel(const W
     if (bias_role && o0 + tid < Cout) slab[(int64_t)Cout * Cin + o0 + tid] = bsum;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Piece form (round 6): the same blocked product on the bf16 matrix cores.  The kernel above is bound by the f32 matrix pipe
+// (64 v_mfma_f32_16x16x4_f32 = 2 048 cycles per wave and 32-row tile; a 64 x 64 map pads its 128 x 128 block to a quarter full):
+// 29 us per map at the synthetic-PGM models' 61 440 rows, 38 maps per training step = 8 % of BASELINE config 5's step.  Here a
+// tile's operands are cut into three bf16 pieces when they are committed to LDS (h + m + l: 2^-24, the arithmetic of
+// mpconv_fwd_extp_kernel) and both operands — gy^T and x, contracted over the tile's 32 ROWS — come out of the row-major piece
+// images through ds_read_b64_tr_b16 (256-byte rows, 32-byte segments swizzled by (r & 3) | (r >> 3 & 1) << 2: conflict-free
+// transpose passes): one k-step of v_mfma_f32_16x16x32_bf16 per tile, 8 fragment products x 6 piece products = 768 cycles.
+// Same blocking, slabs and fold; the bias gradient is summed from the f32 registers at commit time.
+// ---------------------------------------------------------------------------------------------------------------------------
+typedef __bf16 wq_bf16x8 __attribute__((ext_vector_type(8)));
+typedef short wq_s16x4 __attribute__((ext_vector_type(4)));
+#define WQ_NP 3
+#define WQ_ROW 256                      // bytes per image row: 128 bf16
+#define WQ_PIECE (WF_TR * WQ_ROW)       // one piece image of a 32-row tile
+
+__device__ __forceinline__ int wq_sw(int r) { return (r & 3) | (((r >> 3) & 1) << 2); }
+__device__ __forceinline__ unsigned wq_pack2(float a, float b) {
+    typedef __bf16 v2 __attribute__((ext_vector_type(2)));
+    const v2 h = {(__bf16)a, (__bf16)b};
+    return __builtin_bit_cast(unsigned, h);
+}
+__device__ __forceinline__ uint2 wq_tr(unsigned lds_addr) {
+    typedef __attribute__((address_space(3))) wq_s16x4 lds_v4;
+    const wq_s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(reinterpret_cast<lds_v4*>(static_cast<uintptr_t>(lds_addr)));
+    return __builtin_bit_cast(uint2, v);
+}
+
+__global__ __launch_bounds__(WF_THREADS, 2) void linear_wgrad_f32q_kernel(const WfParams p) {
+    __shared__ __attribute__((aligned(16))) unsigned char gq[WQ_NP * WQ_PIECE];      // gy pieces [piece][32 rows][128 o]
+    __shared__ __attribute__((aligned(16))) unsigned char xq[WQ_NP * WQ_PIECE];      // x pieces  [piece][32 rows][128 c]
+    __shared__ float bpart[16 * WF_BLK];
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int li = lane & 15, lk = lane >> 4;
+    const int bo = blockIdx.y / p.nblk_c, bc = blockIdx.y - bo * p.nblk_c;
+    const int o0 = bo * WF_BLK, c0 = bc * WF_BLK;
+    const int Cin = p.Cin, Cout = p.Cout;
+    const int wo = wave & 3, wc = wave >> 2;              // o tiles 2 wo, 2 wo + 1; c tiles 4 wc .. 4 wc + 3
+    const unsigned gq0 = (unsigned)(uintptr_t)gq, xq0 = (unsigned)(uintptr_t)xq;
+
+    const int r_begin = blockIdx.x * p.rows_per_chunk;
+    const int r_end = min(p.R, r_begin + p.rows_per_chunk);
+
+    // staging: 2048 chunks of 4 floats per tile (1024 of gy, 1024 of x), four per thread: rows (tid >> 5) and (tid >> 5) + 16, columns 4 (tid & 31) ..
+    uint4 pr[4];
+    auto prefetch = [&](int r0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int q = (tid + (i & 1) * WF_THREADS), row = q >> 5, col = (q & 31) * 4;
+            const int r = r0 + row;
+            pr[i] = make_uint4(0, 0, 0, 0);
+            if (i < 2) { if (r < r_end && o0 + col < Cout) pr[i] = *reinterpret_cast<const uint4*>(p.gy + (int64_t)r * Cout + o0 + col); }
+            else { if (r < r_end && c0 + col < Cin) pr[i] = *reinterpret_cast<const uint4*>(p.x + (int64_t)r * Cin + c0 + col); }
+        }
+    };
+    float bs[4] = {0.f, 0.f, 0.f, 0.f};                   // bias gradient: this thread's columns 4 (tid & 31) .. of gy, over its rows
+    auto commit = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int q = (tid + (i & 1) * WF_THREADS), row = q >> 5, col = (q & 31) * 4;
+            float a = __uint_as_float(pr[i].x), b = __uint_as_float(pr[i].y), c = __uint_as_float(pr[i].z), d = __uint_as_float(pr[i].w);
+            if (i < 2) { bs[0] += a; bs[1] += b; bs[2] += c; bs[3] += d; }
+            unsigned char* dst = (i < 2 ? gq : xq) + row * WQ_ROW + ((((col >> 4)) ^ wq_sw(row)) << 5) + ((col & 15) << 1);
+#pragma unroll
+            for (int t = 0; t < WQ_NP; ++t) {
+                const unsigned w0 = wq_pack2(a, b), w1 = wq_pack2(c, d);
+                *reinterpret_cast<uint2*>(dst + t * WQ_PIECE) = make_uint2(w0, w1);
+                if (t + 1 < WQ_NP) {
+                    a -= __uint_as_float(w0 << 16); b -= __uint_as_float(w0 & 0xffff0000u);
+                    c -= __uint_as_float(w1 << 16); d -= __uint_as_float(w1 & 0xffff0000u);
+                }
+            }
+        }
+    };
+
+    f32x4 acc[2][4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // transpose-read addresses: lane (li, lk) names rows 8 lk + (li >> 2) (+ 4), four columns from 4 (li & 3) of a 16-column segment
+    const int r0t = 8 * lk + (li >> 2), r1t = r0t + 4;
+    const unsigned ro0 = r0t * WQ_ROW + ((li & 3) << 3), ro1 = r1t * WQ_ROW + ((li & 3) << 3);
+    const int s0 = wq_sw(r0t), s1 = wq_sw(r1t);
+    constexpr int TA[6] = {2, 0, 1, 1, 0, 0}, TB[6] = {0, 2, 1, 0, 1, 0};     // smallest piece products first
+
+    if (r_begin < r_end) prefetch(r_begin);
+    for (int r0 = r_begin; r0 < r_end; r0 += WF_TR) {
+        __syncthreads();                                  // the previous tile's operands have been read
+        commit();
+        if (r0 + WF_TR < r_end) prefetch(r0 + WF_TR);
+        __syncthreads();
+        wq_bf16x8 ga[2][WQ_NP], xb[4][WQ_NP];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int t = 0; t < WQ_NP; ++t) {
+                const int g = 2 * wo + a;
+                const uint2 lo = wq_tr(gq0 + t * WQ_PIECE + ro0 + ((g ^ s0) << 5)), hi = wq_tr(gq0 + t * WQ_PIECE + ro1 + ((g ^ s1) << 5));
+                ga[a][t] = __builtin_bit_cast(wq_bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));
+            }
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int t = 0; t < WQ_NP; ++t) {
+                const int g = 4 * wc + b;
+                const uint2 lo = wq_tr(xq0 + t * WQ_PIECE + ro0 + ((g ^ s0) << 5)), hi = wq_tr(xq0 + t * WQ_PIECE + ro1 + ((g ^ s1) << 5));
+                xb[b][t] = __builtin_bit_cast(wq_bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));
+            }
+#pragma unroll
+        for (int pr6 = 0; pr6 < 6; ++pr6)
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ga[a][TA[pr6]], xb[b][TB[pr6]], acc[a][b], 0, 0, 0);
+    }
+
+    // D[i = o (4 lk + r)][j = c (li)] of tile (ot, ct) -> this chunk's slab, in gW's own layout
+    float* slab = p.ws + (int64_t)blockIdx.x * ((int64_t)Cout * Cin + Cout);
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int c = c0 + (4 * wc + b) * 16 + li;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int o = o0 + (2 * wo + a) * 16 + 4 * lk + r;
+                if (o < Cout && c < Cin) slab[(int64_t)o * Cin + c] = acc[a][b][r];
+            }
+        }
+    if (p.want_bias && bc == 0) {                         // the 16 row groups' column sums, folded in a fixed order
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bpart[(tid >> 5) * WF_BLK + 4 * (tid & 31) + e] = bs[e];
+        __syncthreads();
+        if (tid < WF_BLK && o0 + tid < Cout) {
+            float sum = 0.f;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) sum += bpart[g * WF_BLK + tid];
+            slab[(int64_t)Cout * Cin + o0 + tid] = sum;
+        }
+    }
+}
+
 // fold of the per-chunk slabs: the fixed-order, LDS-staged slab reduction shared with the operator backward kernels
 // (mpconv_bwd_res.hip: 16 elements x 16 slab groups per workgroup, every group walks its slabs in order)
 void fgnn_launch_slab_reduce(const float* ws, int nslab, int64_t slab_len, int64_t nw, float* gW, float* gbias, hipStream_t st);
@@ -154,7 +302,9 @@ int fgnn_linear_wgrad_f32(const void* x, const void* gy, int64_t R, int Cin, int
     WfParams p;
     p.x = (const float*)x; p.gy = (const float*)gy; p.ws = (float*)workspace; p.R = (int)R; p.Cin = Cin; p.Cout = Cout;
     p.rows_per_chunk = rows; p.nblk_c = nbc; p.want_bias = gb != nullptr;
-    hipLaunchKernelGGL(linear_wgrad_f32_kernel, dim3(nrc, nbo * nbc), dim3(WF_THREADS), 0, (hipStream_t)stream, p);
+    static const bool exact = getenv("FGNN_WGRAD_F32_EXACT") != nullptr;      // (A/B switch: the f32 matrix-core kernel)
+    if (exact) hipLaunchKernelGGL(linear_wgrad_f32_kernel, dim3(nrc, nbo * nbc), dim3(WF_THREADS), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(linear_wgrad_f32q_kernel, dim3(nrc, nbo * nbc), dim3(WF_THREADS), 0, (hipStream_t)stream, p);
     fgnn_launch_slab_reduce(p.ws, nrc, slab_len, nw, gW, gb, (hipStream_t)stream);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "linear_wgrad f32 launch: %s", hipGetErrorString(e));
