@@ -140,64 +140,87 @@ __device__ __forceinline__ uint2 wq_tr(unsigned lds_addr) {
     return __builtin_bit_cast(uint2, v);
 }
 
+// BO x BC = the output block (64 or 128 each: a 64-channel side takes a 64-wide block instead of padding a 128-wide one);
+// waves = 4 (o) x 2 (c): BO / 64 o tiles and BC / 32 c tiles per wave
+template <int BO, int BC>
 __global__ __launch_bounds__(WF_THREADS, 2) void linear_wgrad_f32q_kernel(const WfParams p) {
-    __shared__ __attribute__((aligned(16))) unsigned char gq[WQ_NP * WQ_PIECE];      // gy pieces [piece][32 rows][128 o]
-    __shared__ __attribute__((aligned(16))) unsigned char xq[WQ_NP * WQ_PIECE];      // x pieces  [piece][32 rows][128 c]
-    __shared__ float bpart[16 * WF_BLK];
+    constexpr int GROW = 2 * BO, XROW = 2 * BC;                      // image row bytes
+    constexpr int GPIECE = WF_TR * GROW, XPIECE = WF_TR * XROW;
+    constexpr int NO = BO / 64, NC = BC / 32;                         // tiles per wave
+    constexpr int GCH = BO / 4, XCH = BC / 4;                         // 16-byte chunks (4 floats) per tile row
+    constexpr int GPT = WF_TR * GCH / WF_THREADS, XPT = WF_TR * XCH / WF_THREADS;     // chunks per thread and tile (1 or 2)
+    constexpr int RG = WF_THREADS / GCH;                              // row groups of the gy staging (bias partials)
+    __shared__ __attribute__((aligned(16))) unsigned char gq[WQ_NP * GPIECE];      // gy pieces [piece][32 rows][BO]
+    __shared__ __attribute__((aligned(16))) unsigned char xq[WQ_NP * XPIECE];      // x pieces  [piece][32 rows][BC]
+    __shared__ float bpart[RG * BO];
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int li = lane & 15, lk = lane >> 4;
     const int bo = blockIdx.y / p.nblk_c, bc = blockIdx.y - bo * p.nblk_c;
-    const int o0 = bo * WF_BLK, c0 = bc * WF_BLK;
+    const int o0 = bo * BO, c0 = bc * BC;
     const int Cin = p.Cin, Cout = p.Cout;
-    const int wo = wave & 3, wc = wave >> 2;              // o tiles 2 wo, 2 wo + 1; c tiles 4 wc .. 4 wc + 3
+    const int wo = wave & 3, wc = wave >> 2;              // o tiles NO wo ..; c tiles NC wc ..
     const unsigned gq0 = (unsigned)(uintptr_t)gq, xq0 = (unsigned)(uintptr_t)xq;
+    // 32-byte segment swizzles (conflict-free transpose passes over rows {r..r+3, r+8..r+11}): 256-byte rows / 128-byte rows
+    auto swz = [](int r, int rowbytes) { return rowbytes == 256 ? ((r & 3) | (((r >> 3) & 1) << 2)) : (((r >> 1) & 1) | (((r >> 3) & 1) << 1)); };
 
     const int r_begin = blockIdx.x * p.rows_per_chunk;
     const int r_end = min(p.R, r_begin + p.rows_per_chunk);
 
-    // staging: 2048 chunks of 4 floats per tile (1024 of gy, 1024 of x), four per thread: rows (tid >> 5) and (tid >> 5) + 16, columns 4 (tid & 31) ..
-    uint4 pr[4];
+    uint4 pg[GPT], px[XPT];
     auto prefetch = [&](int r0) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int q = (tid + (i & 1) * WF_THREADS), row = q >> 5, col = (q & 31) * 4;
+        for (int i = 0; i < GPT; ++i) {
+            const int q = tid + i * WF_THREADS, row = q / GCH, col = (q % GCH) * 4;
             const int r = r0 + row;
-            pr[i] = make_uint4(0, 0, 0, 0);
-            if (i < 2) { if (r < r_end && o0 + col < Cout) pr[i] = *reinterpret_cast<const uint4*>(p.gy + (int64_t)r * Cout + o0 + col); }
-            else { if (r < r_end && c0 + col < Cin) pr[i] = *reinterpret_cast<const uint4*>(p.x + (int64_t)r * Cin + c0 + col); }
+            pg[i] = (r < r_end && o0 + col < Cout) ? *reinterpret_cast<const uint4*>(p.gy + (int64_t)r * Cout + o0 + col) : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < XPT; ++i) {
+            const int q = tid + i * WF_THREADS, row = q / XCH, col = (q % XCH) * 4;
+            const int r = r0 + row;
+            px[i] = (r < r_end && c0 + col < Cin) ? *reinterpret_cast<const uint4*>(p.x + (int64_t)r * Cin + c0 + col) : make_uint4(0, 0, 0, 0);
         }
     };
-    float bs[4] = {0.f, 0.f, 0.f, 0.f};                   // bias gradient: this thread's columns 4 (tid & 31) .. of gy, over its rows
-    auto commit = [&]() {
+    float bs[4] = {0.f, 0.f, 0.f, 0.f};                   // bias gradient: this thread's four gy columns, over its rows
+    auto put = [&](unsigned char* img, int piece, int rowbytes, int row, int col, const uint4& v) {
+        float a = __uint_as_float(v.x), b = __uint_as_float(v.y), c = __uint_as_float(v.z), d = __uint_as_float(v.w);
+        unsigned char* dst = img + row * rowbytes + (((col >> 4) ^ swz(row, rowbytes)) << 5) + ((col & 15) << 1);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int q = (tid + (i & 1) * WF_THREADS), row = q >> 5, col = (q & 31) * 4;
-            float a = __uint_as_float(pr[i].x), b = __uint_as_float(pr[i].y), c = __uint_as_float(pr[i].z), d = __uint_as_float(pr[i].w);
-            if (i < 2) { bs[0] += a; bs[1] += b; bs[2] += c; bs[3] += d; }
-            unsigned char* dst = (i < 2 ? gq : xq) + row * WQ_ROW + ((((col >> 4)) ^ wq_sw(row)) << 5) + ((col & 15) << 1);
-#pragma unroll
-            for (int t = 0; t < WQ_NP; ++t) {
-                const unsigned w0 = wq_pack2(a, b), w1 = wq_pack2(c, d);
-                *reinterpret_cast<uint2*>(dst + t * WQ_PIECE) = make_uint2(w0, w1);
-                if (t + 1 < WQ_NP) {
-                    a -= __uint_as_float(w0 << 16); b -= __uint_as_float(w0 & 0xffff0000u);
-                    c -= __uint_as_float(w1 << 16); d -= __uint_as_float(w1 & 0xffff0000u);
-                }
+        for (int t = 0; t < WQ_NP; ++t) {
+            const unsigned w0 = wq_pack2(a, b), w1 = wq_pack2(c, d);
+            *reinterpret_cast<uint2*>(dst + t * piece) = make_uint2(w0, w1);
+            if (t + 1 < WQ_NP) {
+                a -= __uint_as_float(w0 << 16); b -= __uint_as_float(w0 & 0xffff0000u);
+                c -= __uint_as_float(w1 << 16); d -= __uint_as_float(w1 & 0xffff0000u);
             }
         }
     };
+    auto commit = [&]() {
+#pragma unroll
+        for (int i = 0; i < GPT; ++i) {
+            const int q = tid + i * WF_THREADS, row = q / GCH, col = (q % GCH) * 4;
+            bs[0] += __uint_as_float(pg[i].x); bs[1] += __uint_as_float(pg[i].y); bs[2] += __uint_as_float(pg[i].z); bs[3] += __uint_as_float(pg[i].w);
+            put(gq, GPIECE, GROW, row, col, pg[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < XPT; ++i) {
+            const int q = tid + i * WF_THREADS, row = q / XCH, col = (q % XCH) * 4;
+            put(xq, XPIECE, XROW, row, col, px[i]);
+        }
+    };
 
-    f32x4 acc[2][4];
+    f32x4 acc[NO][NC];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < NO; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int b = 0; b < NC; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     // transpose-read addresses: lane (li, lk) names rows 8 lk + (li >> 2) (+ 4), four columns from 4 (li & 3) of a 16-column segment
     const int r0t = 8 * lk + (li >> 2), r1t = r0t + 4;
-    const unsigned ro0 = r0t * WQ_ROW + ((li & 3) << 3), ro1 = r1t * WQ_ROW + ((li & 3) << 3);
-    const int s0 = wq_sw(r0t), s1 = wq_sw(r1t);
+    const unsigned g0 = r0t * GROW + ((li & 3) << 3), g1 = r1t * GROW + ((li & 3) << 3);
+    const unsigned x0 = r0t * XROW + ((li & 3) << 3), x1 = r1t * XROW + ((li & 3) << 3);
+    const int sg0 = swz(r0t, GROW), sg1 = swz(r1t, GROW), sx0 = swz(r0t, XROW), sx1 = swz(r1t, XROW);
     constexpr int TA[6] = {2, 0, 1, 1, 0, 0}, TB[6] = {0, 2, 1, 0, 1, 0};     // smallest piece products first
 
     if (r_begin < r_end) prefetch(r_begin);
@@ -206,54 +229,54 @@ __global__ __launch_bounds__(WF_THREADS, 2) void linear_wgrad_f32q_kernel(const 
         commit();
         if (r0 + WF_TR < r_end) prefetch(r0 + WF_TR);
         __syncthreads();
-        wq_bf16x8 ga[2][WQ_NP], xb[4][WQ_NP];
+        wq_bf16x8 ga[NO][WQ_NP], xb[NC][WQ_NP];
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+        for (int a = 0; a < NO; ++a)
 #pragma unroll
             for (int t = 0; t < WQ_NP; ++t) {
-                const int g = 2 * wo + a;
-                const uint2 lo = wq_tr(gq0 + t * WQ_PIECE + ro0 + ((g ^ s0) << 5)), hi = wq_tr(gq0 + t * WQ_PIECE + ro1 + ((g ^ s1) << 5));
+                const int g = NO * wo + a;
+                const uint2 lo = wq_tr(gq0 + t * GPIECE + g0 + ((g ^ sg0) << 5)), hi = wq_tr(gq0 + t * GPIECE + g1 + ((g ^ sg1) << 5));
                 ga[a][t] = __builtin_bit_cast(wq_bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));
             }
 #pragma unroll
-        for (int b = 0; b < 4; ++b)
+        for (int b = 0; b < NC; ++b)
 #pragma unroll
             for (int t = 0; t < WQ_NP; ++t) {
-                const int g = 4 * wc + b;
-                const uint2 lo = wq_tr(xq0 + t * WQ_PIECE + ro0 + ((g ^ s0) << 5)), hi = wq_tr(xq0 + t * WQ_PIECE + ro1 + ((g ^ s1) << 5));
+                const int g = NC * wc + b;
+                const uint2 lo = wq_tr(xq0 + t * XPIECE + x0 + ((g ^ sx0) << 5)), hi = wq_tr(xq0 + t * XPIECE + x1 + ((g ^ sx1) << 5));
                 xb[b][t] = __builtin_bit_cast(wq_bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));
             }
 #pragma unroll
         for (int pr6 = 0; pr6 < 6; ++pr6)
 #pragma unroll
-            for (int a = 0; a < 2; ++a)
+            for (int a = 0; a < NO; ++a)
 #pragma unroll
-                for (int b = 0; b < 4; ++b)
+                for (int b = 0; b < NC; ++b)
                     acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ga[a][TA[pr6]], xb[b][TB[pr6]], acc[a][b], 0, 0, 0);
     }
 
     // D[i = o (4 lk + r)][j = c (li)] of tile (ot, ct) -> this chunk's slab, in gW's own layout
     float* slab = p.ws + (int64_t)blockIdx.x * ((int64_t)Cout * Cin + Cout);
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < NO; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            const int c = c0 + (4 * wc + b) * 16 + li;
+        for (int b = 0; b < NC; ++b) {
+            const int c = c0 + (NC * wc + b) * 16 + li;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int o = o0 + (2 * wo + a) * 16 + 4 * lk + r;
+                const int o = o0 + (NO * wo + a) * 16 + 4 * lk + r;
                 if (o < Cout && c < Cin) slab[(int64_t)o * Cin + c] = acc[a][b][r];
             }
         }
-    if (p.want_bias && bc == 0) {                         // the 16 row groups' column sums, folded in a fixed order
+    if (p.want_bias && bc == 0) {                         // the row groups' column sums, folded in a fixed order
         __syncthreads();
 #pragma unroll
-        for (int e = 0; e < 4; ++e) bpart[(tid >> 5) * WF_BLK + 4 * (tid & 31) + e] = bs[e];
+        for (int e = 0; e < 4; ++e) bpart[(tid / GCH) * BO + 4 * (tid % GCH) + e] = bs[e];
         __syncthreads();
-        if (tid < WF_BLK && o0 + tid < Cout) {
+        if (tid < BO && o0 + tid < Cout) {
             float sum = 0.f;
 #pragma unroll
-            for (int g = 0; g < 16; ++g) sum += bpart[g * WF_BLK + tid];
+            for (int g = 0; g < RG; ++g) sum += bpart[g * BO + tid];
             slab[(int64_t)Cout * Cin + o0 + tid] = sum;
         }
     }
@@ -264,8 +287,8 @@ __global__ __launch_bounds__(WF_THREADS, 2) void linear_wgrad_f32q_kernel(const 
 void fgnn_launch_slab_reduce(const float* ws, int nslab, int64_t slab_len, int64_t nw, float* gW, float* gbias, hipStream_t st);
 
 static void wf_plan(int64_t R, int Cin, int Cout, int* nrc, int* rows_per, int* nblk_o, int* nblk_c) {
-    *nblk_o = (Cout + WF_BLK - 1) / WF_BLK;
-    *nblk_c = (Cin + WF_BLK - 1) / WF_BLK;
+    *nblk_o = (Cout + WF_BLK - 1) / WF_BLK;               // (a side of <= 64 channels is ONE block in both block sizes: the plan does not
+    *nblk_c = (Cin + WF_BLK - 1) / WF_BLK;                //  depend on the form that runs)
     const int nblk = *nblk_o * *nblk_c;
     int target = 256 / nblk;                              // one workgroup per CU: enough for the chip, and the slab traffic stays down
     if (target < 1) target = 1;
@@ -304,7 +327,10 @@ int fgnn_linear_wgrad_f32(const void* x, const void* gy, int64_t R, int Cin, int
     p.rows_per_chunk = rows; p.nblk_c = nbc; p.want_bias = gb != nullptr;
     static const bool exact = getenv("FGNN_WGRAD_F32_EXACT") != nullptr;      // (A/B switch: the f32 matrix-core kernel)
     if (exact) hipLaunchKernelGGL(linear_wgrad_f32_kernel, dim3(nrc, nbo * nbc), dim3(WF_THREADS), 0, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL(linear_wgrad_f32q_kernel, dim3(nrc, nbo * nbc), dim3(WF_THREADS), 0, (hipStream_t)stream, p);
+    else if (Cout <= 64 && Cin <= 64) hipLaunchKernelGGL((linear_wgrad_f32q_kernel<64, 64>), dim3(nrc, nbo * nbc), dim3(WF_THREADS), 0, (hipStream_t)stream, p);
+    else if (Cout <= 64) hipLaunchKernelGGL((linear_wgrad_f32q_kernel<64, 128>), dim3(nrc, nbo * nbc), dim3(WF_THREADS), 0, (hipStream_t)stream, p);
+    else if (Cin <= 64) hipLaunchKernelGGL((linear_wgrad_f32q_kernel<128, 64>), dim3(nrc, nbo * nbc), dim3(WF_THREADS), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((linear_wgrad_f32q_kernel<128, 128>), dim3(nrc, nbo * nbc), dim3(WF_THREADS), 0, (hipStream_t)stream, p);
     fgnn_launch_slab_reduce(p.ws, nrc, slab_len, nw, gW, gb, (hipStream_t)stream);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "linear_wgrad f32 launch: %s", hipGetErrorString(e));
