@@ -153,12 +153,6 @@ __global__ __launch_bounds__(BN_THREADS) void bn_reduce_kernel(const BnParams p)
     }
 }
 
-// K = row 0 of x (f32 path)
-__global__ void bn_ref_kernel(const float* x, float* ref, int C) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c < C) ref[c] = x[c];
-}
-
 // Sum of the workgroup partials of one channel: 16 channels x 16 partial groups per block, folded in LDS.
 // 4 channels x 64 partial groups per block (grid = C/4 blocks: enough workgroups in flight to cover the
 // cross-die latency of partials written on all 8 XCDs); folded in f64 through LDS in a fixed order.
@@ -361,12 +355,11 @@ extern "C" int fgnn_bn_stats(const void* x, int64_t R, int C, int dtype, const f
     if (bn_plan(R, C, dtype, &p, &grid)) FGNN_FAIL(FGNN_EUNSUPPORTED, "bn: C=%d not a supported channel count", C);
     if (workspace_bytes < fgnn_bn_workspace_bytes(R, C)) FGNN_FAIL(FGNN_EINVAL, "bn: workspace too small");
     float* ws = (float*)workspace;
-    float* ref = ws + (int64_t)BN_MAXPART * 2 * C;          // per-channel shift K = x[0][:]
     hipStream_t st = (hipStream_t)stream;
-    // K: copy row 0 as f32 (tiny) — reuse the apply kernel's chunk loader through a 1-row reduce is overkill
-    // (a kernel, not hipMemcpyAsync: copy / memset NODES of a captured hipGraph have been seen to run out of order on replay)
-    if (dtype == FGNN_F32) hipLaunchKernelGGL(bn_ref_kernel, dim3((C + 255) / 256), dim3(256), 0, st, (const float*)x, ref, C);
-    else ref = nullptr;      // bf16: accumulate against K = 0 (values are O(1) after the preceding map; f32 sums, f64 finaliser)
+    // per-channel shift K = x[0][:] (f32): row 0 of x where it lies — the reducing kernel and the finaliser read it there (until round 6 a
+    // 4 us launch copied it into the workspace first: 39 launches of a synthetic-PGM training step); nothing writes x between the two
+    const float* ref = dtype == FGNN_F32 ? (const float*)x : nullptr;      // bf16: accumulate against K = 0 (values are O(1) after the
+                                                                           // preceding map; f32 sums, f64 finaliser)
     p.x = x; p.ws = ws; p.ref = ref;
     p.fin = *fin;
     if (ref) {
