@@ -172,6 +172,52 @@ __global__ __launch_bounds__(256) void concat_pair_kernel(const CcParams p) {
     }
 }
 
+// the node-axis form for inputs whose ROWS are strided (a channel slice of a wider channel-fastest activation — what torch.cat's own
+// backward hands on): out[s][r][:] = r < ra ? a[s][r][:] : b[s][r - ra][:], rows of uc 16-byte units
+struct CrParams {
+    const uint4* a;
+    const uint4* b;
+    uint4* out;
+    unsigned uc, ra, rb;
+    int64_t sas, sar, sbs, sbr;      // strides in 16-byte units: per sample, per row
+    int64_t total;                   // samples * (ra + rb) * uc
+};
+
+__global__ __launch_bounds__(256) void concat_rows_kernel(const CrParams p) {
+    const unsigned rows = p.ra + p.rb;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < p.total; i += stride) {
+        const int64_t row = i / p.uc;
+        const unsigned u = (unsigned)(i - row * p.uc);
+        const int64_t s = row / rows;
+        const unsigned r = (unsigned)(row - s * rows);
+        p.out[i] = r < p.ra ? p.a[s * p.sas + r * p.sar + u] : p.b[s * p.sbs + (r - p.ra) * p.sbr + u];
+    }
+}
+
+extern "C" int fgnn_concat_rows(const void* a, const void* b, void* out, int64_t samples, int64_t rows_a, int64_t rows_b, int64_t row_bytes,
+                                int64_t a_sample_stride_bytes, int64_t a_row_stride_bytes, int64_t b_sample_stride_bytes,
+                                int64_t b_row_stride_bytes, fgnn_stream_t stream) {
+    if (!a || !b || !out) FGNN_FAIL(FGNN_EINVAL, "concat_rows: null pointer");
+    if (samples < 0 || rows_a < 1 || rows_b < 1 || rows_a + rows_b > 0x7fffffff || row_bytes <= 0 || row_bytes > (int64_t)1 << 34 ||
+        (row_bytes | a_sample_stride_bytes | a_row_stride_bytes | b_sample_stride_bytes | b_row_stride_bytes) % 16 ||
+        a_sample_stride_bytes < 0 || a_row_stride_bytes < 0 || b_sample_stride_bytes < 0 || b_row_stride_bytes < 0)
+        FGNN_FAIL(FGNN_EUNSUPPORTED, "concat_rows: rows and strides must be non-negative multiples of 16 bytes");
+    if (((uintptr_t)a | (uintptr_t)b | (uintptr_t)out) & 15) FGNN_FAIL(FGNN_EUNSUPPORTED, "concat_rows: pointers must be 16-byte aligned");
+    if (samples == 0) return FGNN_OK;
+    CrParams p;
+    p.a = (const uint4*)a; p.b = (const uint4*)b; p.out = (uint4*)out;
+    p.uc = (unsigned)(row_bytes / 16); p.ra = (unsigned)rows_a; p.rb = (unsigned)rows_b;
+    p.sas = a_sample_stride_bytes / 16; p.sar = a_row_stride_bytes / 16; p.sbs = b_sample_stride_bytes / 16; p.sbr = b_row_stride_bytes / 16;
+    p.total = samples * (rows_a + rows_b) * (int64_t)p.uc;
+    int64_t grid = (p.total + 255) / 256;
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(concat_rows_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) FGNN_FAIL(FGNN_ELAUNCH, "concat_rows launch: %s", hipGetErrorString(e));
+    return FGNN_OK;
+}
+
 extern "C" int fgnn_concat_pair(const void* a, const void* b, void* out, int64_t samples, int64_t inner, int64_t chunk_a_bytes,
                                 int64_t chunk_b_bytes, int64_t a_sample_stride_bytes, int64_t a_chunk_stride_bytes,
                                 int64_t b_sample_stride_bytes, int64_t b_chunk_stride_bytes, fgnn_stream_t stream) {

@@ -29,7 +29,7 @@ EXPORTS = ('fgnn_mpconv_forward', 'fgnn_mpconv_backward', 'fgnn_mpconv_forward_l
            'fgnn_instnorm_forward', 'fgnn_instnorm_backward', 'fgnn_instnorm_dot_forward', 'fgnn_instnorm_dot_backward',
            'fgnn_instnorm_dot_workspace_bytes', 'fgnn_bn_supported', 'fgnn_bn_workspace_bytes',
            'fgnn_bn_stats', 'fgnn_bn_finalize', 'fgnn_bn_apply', 'fgnn_bn_backward',
-           'fgnn_linear_forward', 'fgnn_linear_forward_partials', 'fgnn_linear_instnorm_forward', 'fgnn_sum_n', 'fgnn_concat_pair', 'fgnn_flat_adam', 'fgnn_flat_adam_dev', 'fgnn_edge_mlp_forward', 'fgnn_edge_mlp_workspace_bytes', 'fgnn_edge_mlp_backward', 'fgnn_ldpc_encode', 'fgnn_ldpc_channel_features', 'fgnn_ldpc_channel_features_rng', 'fgnn_ldpc_decode', 'fgnn_ldpc_loss_forward', 'fgnn_ldpc_loss_backward', 'fgnn_ldpc_loss_workspace_bytes', 'fgnn_linear_multi_supported', 'fgnn_linear_multi_forward', 'fgnn_fold_defer', 'fgnn_fold_pending', 'fgnn_fold_discard', 'fgnn_fold_flush', 'fgnn_mpconv_block_forward', 'fgnn_mpconv_block_forward_rows', 'fgnn_mpconv_block_forward_fanout', 'fgnn_mpconv_block_forward_fanin', 'fgnn_factor_layer_forward', 'fgnn_factor_layer_param_count', 'fgnn_mpconv_forward_stats', 'fgnn_mpconv_forward_stats_partials', 'fgnn_block_tail_partials', 'fgnn_block_tail_stats', 'fgnn_block_tail_apply', 'fgnn_block_tail_backward', 'fgnn_block_tail_backward_partials', 'fgnn_block_tail_moments_bytes', 'fgnn_block_tail_backward_moments', 'fgnn_block_tail_wgrad_finish', 'fgnn_bn_backward_apply', 'fgnn_block_head_backward', 'fgnn_node_sum', 'fgnn_set_inkernel_finalisers', 'fgnn_mpconv_backward_tables_bytes', 'fgnn_mpconv_backward_tables', 'fgnn_mpconv_backward_with_tables',
+           'fgnn_linear_forward', 'fgnn_linear_forward_partials', 'fgnn_linear_instnorm_forward', 'fgnn_sum_n', 'fgnn_concat_pair', 'fgnn_concat_rows', 'fgnn_flat_adam', 'fgnn_flat_adam_dev', 'fgnn_edge_mlp_forward', 'fgnn_edge_mlp_workspace_bytes', 'fgnn_edge_mlp_backward', 'fgnn_ldpc_encode', 'fgnn_ldpc_channel_features', 'fgnn_ldpc_channel_features_rng', 'fgnn_ldpc_decode', 'fgnn_ldpc_loss_forward', 'fgnn_ldpc_loss_backward', 'fgnn_ldpc_loss_workspace_bytes', 'fgnn_linear_multi_supported', 'fgnn_linear_multi_forward', 'fgnn_fold_defer', 'fgnn_fold_pending', 'fgnn_fold_discard', 'fgnn_fold_flush', 'fgnn_mpconv_block_forward', 'fgnn_mpconv_block_forward_rows', 'fgnn_mpconv_block_forward_fanout', 'fgnn_mpconv_block_forward_fanin', 'fgnn_factor_layer_forward', 'fgnn_factor_layer_param_count', 'fgnn_mpconv_forward_stats', 'fgnn_mpconv_forward_stats_partials', 'fgnn_block_tail_partials', 'fgnn_block_tail_stats', 'fgnn_block_tail_apply', 'fgnn_block_tail_backward', 'fgnn_block_tail_backward_partials', 'fgnn_block_tail_moments_bytes', 'fgnn_block_tail_backward_moments', 'fgnn_block_tail_wgrad_finish', 'fgnn_bn_backward_apply', 'fgnn_block_head_backward', 'fgnn_node_sum', 'fgnn_set_inkernel_finalisers', 'fgnn_mpconv_backward_tables_bytes', 'fgnn_mpconv_backward_tables', 'fgnn_mpconv_backward_with_tables',
            'fgnn_mpconv_algorithmic_bytes', 'fgnn_mpconv_forward_addends', 'fgnn_last_error', 'fgnn_last_kernel', 'fgnn_stamp', 'fgnn_spin', 'fgnn_set_ext_backward_pieces', 'fgnn_abi_version')
 
 
@@ -194,6 +194,8 @@ def lib():
     L.fgnn_sum_n.argtypes = [vp, i32, i64, i32, vp, vp]
     L.fgnn_concat_pair.restype = ctypes.c_int
     L.fgnn_concat_pair.argtypes = [vp, vp, vp] + [i64] * 8 + [vp]
+    L.fgnn_concat_rows.restype = ctypes.c_int
+    L.fgnn_concat_rows.argtypes = [vp, vp, vp] + [i64] * 8 + [vp]
     L.fgnn_ldpc_decode.restype = ctypes.c_int
     L.fgnn_ldpc_decode.argtypes = [vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, vp, vp, vp, vp, vp]
     L.fgnn_ldpc_encode.restype = ctypes.c_int

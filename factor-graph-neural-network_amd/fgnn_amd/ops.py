@@ -1136,9 +1136,14 @@ def _concat2_plan(a, b, dim):
         C, N = t.shape[1], t.shape[2]
         if (C > 1 and t.stride(1) != 1) or (N > 1 and t.stride(2) < C) or (t.shape[0] > 1 and t.stride(0) < C * N):
             return None
-        if dim == 2 and N > 1 and t.stride(2) != C:          # a sample's nodes form one chunk
-            return None
     B = a.shape[0]
+    if dim == 2 and any(t.shape[2] > 1 and t.stride(2) != t.shape[1] for t in (a, b)):
+        # rows strided inside a sample (a channel slice of a wider activation): the row form (fgnn_concat_rows)
+        rb_ = a.shape[1] * es
+        vals = (rb_, a.stride(0) * es, a.stride(2) * es, b.stride(0) * es, b.stride(2) * es)
+        if any(v % 16 for v in vals) or (a.data_ptr() | b.data_ptr()) % 16:
+            return None
+        return ('rows', B, a.shape[2], b.shape[2]) + vals
     if dim == 2:
         inner, ca, cb = 1, a.shape[1] * a.shape[2] * es, b.shape[1] * b.shape[2] * es
         sa, sb = (a.stride(0) * es, 0), (b.stride(0) * es, 0)
@@ -1161,7 +1166,10 @@ def _concat2_raw(a, b, dim, plan=None):
         out = torch.empty((B, a.shape[2] + b.shape[2], 1, a.shape[1]), device=a.device, dtype=a.dtype).permute(0, 3, 1, 2)
     else:
         out = torch.empty((B, a.shape[2], 1, a.shape[1] + b.shape[1]), device=a.device, dtype=a.dtype).permute(0, 3, 1, 2)
-    _hip.check(_hip.lib().fgnn_concat_pair(_hip._ptr(a), _hip._ptr(b), _hip._ptr(out), *plan, _hip.stream_ptr()))
+    if plan[0] == 'rows':
+        _hip.check(_hip.lib().fgnn_concat_rows(_hip._ptr(a), _hip._ptr(b), _hip._ptr(out), *plan[1:], _hip.stream_ptr()))
+    else:
+        _hip.check(_hip.lib().fgnn_concat_pair(_hip._ptr(a), _hip._ptr(b), _hip._ptr(out), *plan, _hip.stream_ptr()))
     return out
 
 

@@ -459,6 +459,14 @@ int fgnn_factor_layer_forward(int32_t B, const void* var, const void* fac0, cons
  */
 int fgnn_sum_n(const void* const* inputs, int32_t n, int64_t numel, int32_t dtype, void* out, fgnn_stream_t stream);
 
+/* The node-axis concatenation of two channel-fastest activations whose ROWS may be strided (a channel slice of a wider activation — what
+ * torch.cat's backward hands on): out[s][r] = r < rows_a ? a[s][r] : b[s][r - rows_a], rows of row_bytes, dense result.
+ * /root/reference/lib/model/mpnn/factor_mpnn.py:104-112 (the stacking of variables and factors, and autograd's gradient of the two
+ * slices).  Multiples of 16 bytes, 16-byte aligned pointers.  ABI >= 13. */
+int fgnn_concat_rows(const void* a, const void* b, void* out, int64_t samples, int64_t rows_a, int64_t rows_b, int64_t row_bytes,
+                     int64_t a_sample_stride_bytes, int64_t a_row_stride_bytes, int64_t b_sample_stride_bytes,
+                     int64_t b_row_stride_bytes, fgnn_stream_t stream);
+
 /* out[s][n] = [ a[s][n] | b[s][n] ], s < samples, n < inner: two arrays of chunks interleaved chunk by chunk in one pass, dense result —
  * torch.cat of two channel-fastest activations along the node axis (inner = 1, chunk = a sample's nodes x channels;
  * /root/reference/lib/model/mpnn/factor_mpnn.py:104-107: the variables and one factor type stacked for a block) or along the channel axis

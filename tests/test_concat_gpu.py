@@ -45,6 +45,19 @@ def test_concat_pair_takes_node_slices_of_a_larger_activation(dim, dev):
         assert out is not None and torch.equal(out, torch.cat([x, y], dim=dim)) and out.stride(1) == 1
 
 
+def test_concat_rows_takes_channel_slices(dev):
+    """torch.cat's backward hands on channel slices of a wider channel-fastest gradient (rows strided inside a sample): the node-axis
+    concatenation of such slices is the row form (fgnn_concat_rows)."""
+    from fgnn_amd import ops
+    g = torch.Generator().manual_seed(5)
+    wide = torch.randn(6, 30, 1, 128, generator=g).to(dev).permute(0, 3, 1, 2)
+    other = torch.randn(6, 30, 1, 64, generator=g).to(dev).permute(0, 3, 1, 2)
+    lo, hi = wide[:, :64], wide[:, 64:]
+    for x, y in ((lo, hi), (lo, other), (other, hi)):
+        out = ops._concat2_raw(x, y, 2)
+        assert out is not None and torch.equal(out, torch.cat([x, y], dim=2)) and out.stride(1) == 1 and out.stride(2) == 64
+
+
 def test_concat_pair_falls_back_outside_its_family(dev):
     from fgnn_amd import ops
     a = torch.randn(4, 6, 5, 1, device=dev)                  # NCHW-contiguous, odd sizes: torch.cat
