@@ -539,7 +539,9 @@ def test_inference_fanout_block_runs_on_one_row_and_rides_as_a_row_addend(nin, n
         h = hyper(x1, idx1, et1)
         # (the one-row form has a kernel of its own since round 6: 16 samples per wave on the matrix cores, csrc/mpconv_block_fwd.hip
         # mpconv_block_rows1_kernel — the same products and rounding points in another summation order)
-        assert 'mpconv_block_rows1_kernel' in _hip.lib().fgnn_last_kernel().decode(), _hip.lib().fgnn_last_kernel()
+        import os
+        one_row = 'mpconv_block_fanout_kernel' if os.environ.get('FGNN_NO_BLOCK_ROWS1') else 'mpconv_block_rows1_kernel'      # (the A/B switch)
+        assert one_row in _hip.lib().fgnn_last_kernel().decode(), _hip.lib().fgnn_last_kernel()
         assert getattr(h, '_fgnn_bcast_src', None) is not None and h.shape == (B, nout, M, 1) and h.stride(2) == 0
         monkeypatch.setattr(ops, 'FANOUT_BROADCAST', False)
         h_full = hyper(x1, idx1, et1)
