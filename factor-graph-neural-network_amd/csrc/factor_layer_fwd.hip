@@ -122,6 +122,22 @@ __device__ __forceinline__ fl_bf16x8 fl_frag8(const float* p8) {            // 8
     const f32x4 a = *reinterpret_cast<const f32x4*>(p8), b = *reinterpret_cast<const f32x4*>(p8 + 4);
     return __builtin_bit_cast(fl_bf16x8, make_uint4(fl_pack2(a[0], a[1]), fl_pack2(a[2], a[3]), fl_pack2(b[0], b[1]), fl_pack2(b[2], b[3])));
 }
+// uniform 64-bit base + UNSIGNED 32-bit per-lane byte offset: the form that compiles to `global_load v, v_off, s[base]`.  Per-lane 64-bit
+// pointers are hoisted out of the sample loop and SPILLED at this kernel's 256 VGPRs — and a spill reload is a memory operation that waits
+// (vmcnt(0)) for every load issued before it: the next sample's prefetch then paid two or three HBM round trips back to back, ~3 000
+// cycles per sample (round 6: profiles/r06/infer_layer_phase_timeline.txt, phase 7 -> 8).
+template <typename T> __device__ __forceinline__ const T* fl_at(const void* base, unsigned byte_off) {
+    return reinterpret_cast<const T*>(static_cast<const char*>(base) + byte_off);
+}
+template <typename T> __device__ __forceinline__ T* fl_at(void* base, unsigned byte_off) {
+    return reinterpret_cast<T*>(static_cast<char*>(base) + byte_off);
+}
+// LDS-DMA piece: 64 lanes x 16 B of global memory -> lds_dst + 16 lane, no registers in between (the idiom of mpconv_bwd_ws.hip)
+__device__ __forceinline__ void fl_dma16(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
 // sum / max over the 16 lanes of a DPP row (the 16 nodes of a tile)
 __device__ __forceinline__ float fl_row_sum(float v) {
     v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, false));
@@ -311,24 +327,40 @@ __global__ __launch_bounds__(FL_THREADS) void factor_layer_fwd_kernel(const FlPa
     const int ch4 = ot * 16 + 4 * lk;
     const float slope = p.slope;
 
-    // ---- prefetch registers: 768 + 384 16-byte chunks of state, 288 + 288 8-byte edge-type quads, 64 hyper-factor channels ----
-    uint4 xr0, xr1, fr;
+    // ---- the next sample's inputs.  Its state (768 + 384 16-byte chunks) goes by LDS-DMA into the projection image, which is dead from
+    // the end of the F -> V gather to the next sample's first projection — round 6: held in registers across the last three phases
+    // (12 VGPRs of a kernel at its 256) the data or the pointers were spilled, and a spill is a memory operation that waits for every
+    // load before it: two or three HBM round trips back to back, ~3 000 cycles per sample.  The 288 + 288 edge-type quads and the 64
+    // hyper-factor channels stay in registers (5) ----
     uint2 e0r, e1r;
-    uint16_t hr = 0;
+    uint16_t hr = 0, skh = 0;
+    const unsigned lds_stage = (unsigned)(uintptr_t)ps;
     auto prefetch = [&](int b) {
-        const uint4* vb = reinterpret_cast<const uint4*>(p.var + (int64_t)b * FL_NV * 64);
-        const uint4* fb = reinterpret_cast<const uint4*>(p.fac0 + (int64_t)b * FL_NF * 64);
-        xr0 = vb[tid];
-        xr1 = tid < 256 ? vb[512 + tid] : make_uint4(0, 0, 0, 0);
-        fr = tid < 384 ? fb[tid] : make_uint4(0, 0, 0, 0);
-        e0r = tid < FL_NF * FL_KF ? *reinterpret_cast<const uint2*>(p.et_v2f + (int64_t)b * p.et_v2f_sb + (int64_t)tid * 4) : make_uint2(0, 0);
-        e1r = tid < FL_NV * FL_KV ? *reinterpret_cast<const uint2*>(p.et_f2v + (int64_t)b * p.et_f2v_sb + (int64_t)tid * 4) : make_uint2(0, 0);
-        if (tid < 64) hr = p.fac1[(int64_t)b * 64 + tid];
+        const unsigned char* vb = reinterpret_cast<const unsigned char*>(p.var + (int64_t)b * FL_NV * 64);      // (uniform bases: scalar registers)
+        const unsigned char* fb = reinterpret_cast<const unsigned char*>(p.fac0 + (int64_t)b * FL_NF * 64);
+        const uint16_t* e0b = p.et_v2f + (int64_t)b * p.et_v2f_sb;
+        const uint16_t* e1b = p.et_f2v + (int64_t)b * p.et_f2v_sb;
+        const uint16_t* hb = p.fac1 + (int64_t)b * 64;
+        unsigned t = (unsigned)tid, l16 = (unsigned)lane * 16u;
+        asm volatile("" : "+v"(t), "+v"(l16));                          // the lane offsets are formed here, not carried across the loop
+        if (wave < 6) {                                                 // 12 pieces of the variables' state, 6 of the checks'
+#pragma unroll
+            for (int u = 0; u < 2; ++u) fl_dma16(vb + (wave * 2 + u) * 1024 + l16, lds_stage + (unsigned)((wave * 2 + u) * 1024));
+        } else {
+#pragma unroll
+            for (int u = 0; u < 3; ++u) fl_dma16(fb + ((wave - 6) * 3 + u) * 1024 + l16, lds_stage + (unsigned)(12288 + ((wave - 6) * 3 + u) * 1024));
+        }
+        // UNCONDITIONAL loads (threads beyond an array re-read its first element; commit() stores under the conditions): a load in one
+        // arm of a branch meets the other arm's value at the merge, and the wave waits for it there
+        e0r = *fl_at<uint2>(e0b, tid < FL_NF * FL_KF ? t * 8u : 0u);
+        e1r = *fl_at<uint2>(e1b, tid < FL_NV * FL_KV ? t * 8u : 0u);
+        hr = *fl_at<uint16_t>(hb, (t & 63u) * 2u);
     };
-    auto commit = [&]() {
-        *reinterpret_cast<uint4*>(vs + (tid >> 3) * FL_XS + (tid & 7) * 8) = xr0;
-        if (tid < 256) *reinterpret_cast<uint4*>(vs + (64 + (tid >> 3)) * FL_XS + (tid & 7) * 8) = xr1;
-        if (tid < 384) *reinterpret_cast<uint4*>(fs + (tid >> 3) * FL_XS + (tid & 7) * 8) = fr;
+    auto commit = [&]() {                              // (behind a barrier that follows `s_waitcnt vmcnt(0)` on every wave: the DMA has landed)
+        const uint4* st = reinterpret_cast<const uint4*>(ps);
+        *reinterpret_cast<uint4*>(vs + (tid >> 3) * FL_XS + (tid & 7) * 8) = st[tid];
+        if (tid < 256) *reinterpret_cast<uint4*>(vs + (64 + (tid >> 3)) * FL_XS + (tid & 7) * 8) = st[512 + tid];
+        if (tid < 384) *reinterpret_cast<uint4*>(fs + (tid >> 3) * FL_XS + (tid & 7) * 8) = st[768 + tid];
         if (tid < FL_NF * FL_KF) et_vf[tid] = e0r;
         if (tid < FL_NV * FL_KV) et_fv[tid] = e1r;
         if (tid < 64) hv[tid] = fl_lo(hr);
@@ -343,12 +375,15 @@ __global__ __launch_bounds__(FL_THREADS) void factor_layer_fwd_kernel(const FlPa
         float u = fmaf(acc, aff[(2 * 6 + 4) * 64 + lane], aff[(2 * 6 + 5) * 64 + lane]);
         u = u > 0.f ? u : u * slope;
         if (p.residual) u += hv[lane];
-        if (p.skip_fac1) u += fl_lo(p.skip_fac1[(int64_t)bp * 64 + lane]);
+        unsigned l2 = (unsigned)lane * 2u;
+        asm volatile("" : "+v"(l2));
+        if (p.skip_fac1) u += fl_lo(skh);                 // (requested with the sample's other skip terms, a phase before the sample ended)
         const __bf16 h = (__bf16)u;
-        p.out_fac1[(int64_t)bp * 64 + lane] = __builtin_bit_cast(uint16_t, h);
+        *fl_at<uint16_t>(p.out_fac1 + (int64_t)bp * 64, l2) = __builtin_bit_cast(uint16_t, h);
     };
     int b_prev = -1;
     for (; b < p.B; b += gridDim.x) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's LDS-DMA pieces of the sample have landed
         __syncthreads();                               // the previous sample's last readers of the images are done (and the tables are in)
         FL_STAMP(0);
         if (wave == 0 && b_prev >= 0) close_hyper(b_prev);     // before this wave's commit() overwrites hv[0..63]
@@ -588,14 +623,20 @@ __global__ __launch_bounds__(FL_THREADS) void factor_layer_fwd_kernel(const FlPa
 
         // the skip link's terms of this lane's elements: asked for here, consumed in the last phase
         uint2 skv[3] = {make_uint2(0, 0), make_uint2(0, 0), make_uint2(0, 0)}, skf[2] = {make_uint2(0, 0), make_uint2(0, 0)};
-        if (p.skip_var) {
+        unsigned eo = (unsigned)(((hf * 16 + li) * 64 + ch4) * 2);     // this lane's element of tile (ot, hf) in a [nodes][64] bf16 state: + 4096 per tile step
+        asm volatile("" : "+v"(eo));
+        {   // UNCONDITIONAL loads (without a skip link: the layer's own input, never used): a load inside `if (skip)` meets the zero of the
+            // other arm at the branch merge, i.e. the wave waits for it right there instead of behind the last block's products
+            const uint16_t* sv_ = (p.skip_var ? p.skip_var : p.var) + (int64_t)b * FL_NV * 64;
+            const uint16_t* sf_ = (p.skip_fac0 ? p.skip_fac0 : p.fac0) + (int64_t)b * FL_NF * 64;
 #pragma unroll
-            for (int i = 0; i < 3; ++i) skv[i] = *reinterpret_cast<const uint2*>(p.skip_var + ((int64_t)b * FL_NV + (hf + 2 * i) * 16 + li) * 64 + ch4);
-        }
-        if (p.skip_fac0) {
+            for (int i = 0; i < 3; ++i) skv[i] = *fl_at<uint2>(sv_, eo + 4096u * i);
 #pragma unroll
             for (int i = 0; i < 2; ++i)
-                if (hf + 2 * i < 3) skf[i] = *reinterpret_cast<const uint2*>(p.skip_fac0 + ((int64_t)b * FL_NF + (hf + 2 * i) * 16 + li) * 64 + ch4);
+                if (hf + 2 * i < 3) skf[i] = *fl_at<uint2>(sf_, eo + 4096u * i);
+            unsigned l2 = (unsigned)lane * 2u;
+            asm volatile("" : "+v"(l2));
+            skh = *fl_at<uint16_t>((p.skip_fac1 ? p.skip_fac1 : p.fac1) + (int64_t)b * 64, l2);
         }
         // ---- phase 10: the fan-out block's conv2 onto the variables; residual, skip link, store; wave 0 first closes the
         //      fan-in block (the hyper-factor's new state: a matrix-vector product) ----
@@ -609,10 +650,14 @@ __global__ __launch_bounds__(FL_THREADS) void factor_layer_fwd_kernel(const FlPa
                 part = fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(z), 8 * wave + i)), fl_lo(W2c[(8 * wave + i) * 64 + lane]), part);
             mvp[wave * 64 + lane] = part;
         }
+        int rsb;
         {
             f32x4 acc[3], s4, t4;
             fl_tiles<true>(aW2d, bs, hf, li, lk, acc);
             affine(3 * 6 + 4, s4, t4);
+            asm volatile("" : "+v"(eo));                // (the stores' lane offset stays a 32-bit offset beside a scalar base)
+            rsb = (hf * 16 + li) * FL_XS + ch4;         // the residual's element of tile (ot, hf) in the LDS images, formed here (not carried)
+            asm volatile("" : "+v"(rsb));
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
                 const int n = (hf + 2 * i) * 16 + li;
@@ -621,11 +666,11 @@ __global__ __launch_bounds__(FL_THREADS) void factor_layer_fwd_kernel(const FlPa
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] += oV[i][r];
                 if (p.residual) {
-                    const uint2 a = *reinterpret_cast<const uint2*>(vs + n * FL_XS + ch4);
+                    const uint2 a = *reinterpret_cast<const uint2*>(vs + rsb + 2 * i * 16 * FL_XS);
                     v[0] += fl_lo(a.x); v[1] += fl_hi(a.x); v[2] += fl_lo(a.y); v[3] += fl_hi(a.y);
                 }
-                v[0] += fl_lo(skv[i].x); v[1] += fl_hi(skv[i].x); v[2] += fl_lo(skv[i].y); v[3] += fl_hi(skv[i].y);
-                *reinterpret_cast<uint2*>(p.out_var + ((int64_t)b * FL_NV + n) * 64 + ch4) = make_uint2(fl_pack2(v[0], v[1]), fl_pack2(v[2], v[3]));
+                if (p.skip_var) { v[0] += fl_lo(skv[i].x); v[1] += fl_hi(skv[i].x); v[2] += fl_lo(skv[i].y); v[3] += fl_hi(skv[i].y); }
+                *fl_at<uint2>(p.out_var + (int64_t)b * FL_NV * 64, eo + 4096u * i) = make_uint2(fl_pack2(v[0], v[1]), fl_pack2(v[2], v[3]));
             }
         }
 #pragma unroll
@@ -634,11 +679,11 @@ __global__ __launch_bounds__(FL_THREADS) void factor_layer_fwd_kernel(const FlPa
                 const int n = (hf + 2 * i) * 16 + li;
                 float v[4] = {oF[i][0], oF[i][1], oF[i][2], oF[i][3]};
                 if (p.residual) {
-                    const uint2 a = *reinterpret_cast<const uint2*>(fs + n * FL_XS + ch4);
+                    const uint2 a = *reinterpret_cast<const uint2*>(fs + rsb + 2 * i * 16 * FL_XS);
                     v[0] += fl_lo(a.x); v[1] += fl_hi(a.x); v[2] += fl_lo(a.y); v[3] += fl_hi(a.y);
                 }
-                v[0] += fl_lo(skf[i].x); v[1] += fl_hi(skf[i].x); v[2] += fl_lo(skf[i].y); v[3] += fl_hi(skf[i].y);
-                *reinterpret_cast<uint2*>(p.out_fac0 + ((int64_t)b * FL_NF + n) * 64 + ch4) = make_uint2(fl_pack2(v[0], v[1]), fl_pack2(v[2], v[3]));
+                if (p.skip_fac0) { v[0] += fl_lo(skf[i].x); v[1] += fl_hi(skf[i].x); v[2] += fl_lo(skf[i].y); v[3] += fl_hi(skf[i].y); }
+                *fl_at<uint2>(p.out_fac0 + (int64_t)b * FL_NF * 64, eo + 4096u * i) = make_uint2(fl_pack2(v[0], v[1]), fl_pack2(v[2], v[3]));
             }
         }
         FL_STAMP(10);
