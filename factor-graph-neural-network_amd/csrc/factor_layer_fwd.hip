@@ -182,35 +182,40 @@ __device__ __forceinline__ void fl_tiles(const fl_bf16x8 (&aW)[2], const uint16_
 }
 
 // gather + edge-type contraction + max over KC neighbours, then a2 = ReLU(s2 z + t2) as bf16 into `dst` rows (lane <-> channel);
-// ND destinations in flight per wave (M = 8 waves x ND x iterations)
+// ND destinations in flight per wave (M = 8 waves x ND x iterations).  `off_s` holds the BYTE offset of every edge's source row in the
+// projection image (the tables are shared by the batch: formed once per launch).  A wave's edge list is uniform, so its offsets and edge
+// weights are BROADCAST LDS reads (every lane the same address, immediate offsets from one base register) — round 6: fetched by the
+// first lanes and spread with v_readlane they cost 3 readlanes + their hazard no-ops + a scalar multiply per edge, ~11 issue slots
+// for 2 dot products and a max; the gathers were 9 300 of a sample's 28 600 cycles and the kernel is VALU-issue-bound.
 template <int KC, int ND>
-__device__ __forceinline__ void fl_gather(const uint16_t* ps, const int* idx_s, const uint2* et_s, uint16_t* dst, int M, int wave, int lane,
+__device__ __forceinline__ void fl_gather(const uint16_t* ps, const int* off_s, const uint2* et_s, uint16_t* dst, int M, int wave, int lane,
                                           float c2s, float c2t) {
-    const unsigned* et_w = reinterpret_cast<const unsigned*>(et_s);
-    const uint16_t* pc = ps + lane * 4;
+    const unsigned char* pc = reinterpret_cast<const unsigned char*>(ps) + lane * 8;
     for (int m0 = wave; m0 < M; m0 += 8 * ND) {
-        int id[ND];
-        unsigned ew[ND];
+        const int* ob = off_s + m0 * KC;
+        const uint2* eb = et_s + m0 * KC;
+        int off[ND][KC];
+        uint2 ew[ND][KC];
 #pragma unroll
-        for (int d = 0; d < ND; ++d) {
-            const int m = m0 + 8 * d;
-            id[d] = lane < KC ? idx_s[m * KC + lane] : 0;
-            ew[d] = lane < 2 * KC ? et_w[m * KC * 2 + lane] : 0u;
-        }
+        for (int d = 0; d < ND; ++d)
+#pragma unroll
+            for (int j = 0; j < KC; ++j) off[d][j] = ob[8 * d * KC + j];
+#pragma unroll
+        for (int d = 0; d < ND; ++d)
+#pragma unroll
+            for (int j = 0; j < KC; ++j) ew[d][j] = eb[8 * d * KC + j];
         uint2 pk[ND][KC];
 #pragma unroll
         for (int j = 0; j < KC; ++j)
 #pragma unroll
-            for (int d = 0; d < ND; ++d) pk[d][j] = *reinterpret_cast<const uint2*>(pc + __builtin_amdgcn_readlane(id[d], j) * FL_PS);
+            for (int d = 0; d < ND; ++d) pk[d][j] = *reinterpret_cast<const uint2*>(pc + off[d][j]);
 #pragma unroll
         for (int d = 0; d < ND; ++d) {
             float best = 0.f;
 #pragma unroll
             for (int j = 0; j < KC; ++j) {
-                float v = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(fl_bf16x2, pk[d][j].x),
-                    __builtin_bit_cast(fl_bf16x2, (unsigned)__builtin_amdgcn_readlane(ew[d], 2 * j)), 0.f, false);
-                v = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(fl_bf16x2, pk[d][j].y),
-                    __builtin_bit_cast(fl_bf16x2, (unsigned)__builtin_amdgcn_readlane(ew[d], 2 * j + 1)), v, false);
+                float v = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(fl_bf16x2, pk[d][j].x), __builtin_bit_cast(fl_bf16x2, ew[d][j].x), 0.f, false);
+                v = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(fl_bf16x2, pk[d][j].y), __builtin_bit_cast(fl_bf16x2, ew[d][j].y), v, false);
                 best = j == 0 ? v : fmaxf(best, v);
             }
             const __bf16 h = (__bf16)fmaxf(fmaf(best, c2s, c2t), 0.f);
@@ -303,12 +308,12 @@ __global__ __launch_bounds__(FL_THREADS) void factor_layer_fwd_kernel(const FlPa
     for (int t = tid; t < FL_NF * FL_KF; t += FL_THREADS) {
         const int m = t / FL_KF, j = t - m * FL_KF;
         const long long v = p.idx_v2f[(int64_t)m * p.idx_v2f_sm + (int64_t)j * p.idx_v2f_sk];
-        idx_vf[t] = (int)(v < 0 ? 0 : (v >= FL_NV ? FL_NV - 1 : v));
+        idx_vf[t] = (int)(v < 0 ? 0 : (v >= FL_NV ? FL_NV - 1 : v)) * (FL_PS * 2);      // byte offset of the source's projection row
     }
     for (int t = tid; t < FL_NV * FL_KV; t += FL_THREADS) {
         const int m = t / FL_KV, j = t - m * FL_KV;
         const long long v = p.idx_f2v[(int64_t)m * p.idx_f2v_sm + (int64_t)j * p.idx_f2v_sk];
-        idx_fv[t] = (int)(v < 0 ? 0 : (v >= FL_NF ? FL_NF - 1 : v));
+        idx_fv[t] = (int)(v < 0 ? 0 : (v >= FL_NF ? FL_NF - 1 : v)) * (FL_PS * 2);
     }
     for (int f = tid; f < 24 * 64; f += FL_THREADS) {
         const int row = f >> 6, c = f & 63, blk = row / 6, which = row - blk * 6;
@@ -358,9 +363,12 @@ __global__ __launch_bounds__(FL_THREADS) void factor_layer_fwd_kernel(const FlPa
     };
     auto commit = [&]() {                              // (behind a barrier that follows `s_waitcnt vmcnt(0)` on every wave: the DMA has landed)
         const uint4* st = reinterpret_cast<const uint4*>(ps);
-        *reinterpret_cast<uint4*>(vs + (tid >> 3) * FL_XS + (tid & 7) * 8) = st[tid];
-        if (tid < 256) *reinterpret_cast<uint4*>(vs + (64 + (tid >> 3)) * FL_XS + (tid & 7) * 8) = st[512 + tid];
-        if (tid < 384) *reinterpret_cast<uint4*>(fs + (tid >> 3) * FL_XS + (tid & 7) * 8) = st[768 + tid];
+        int t = tid;
+        asm volatile("" : "+v"(t));                    // (addresses formed here: carried across the loop they were spilled)
+        const int row = (t >> 3) * FL_XS + (t & 7) * 8;
+        *reinterpret_cast<uint4*>(vs + row) = st[t];
+        if (tid < 256) *reinterpret_cast<uint4*>(vs + 64 * FL_XS + row) = st[512 + t];
+        if (tid < 384) *reinterpret_cast<uint4*>(fs + row) = st[768 + t];
         if (tid < FL_NF * FL_KF) et_vf[tid] = e0r;
         if (tid < FL_NV * FL_KV) et_fv[tid] = e1r;
         if (tid < 64) hv[tid] = fl_lo(hr);
