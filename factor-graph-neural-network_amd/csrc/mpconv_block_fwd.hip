@@ -146,7 +146,7 @@ __global__ __launch_bounds__(KB_THREADS) void mpconv_block_fwd_kernel(const KbPa
         if (t < mk) {
             et_s[t] = er;
             const long long v = ir;
-            idx_s[t] = (int)(v < 0 ? 0 : (v >= N ? N - 1 : v));
+            idx_s[t] = (int)(v < 0 ? 0 : (v >= N ? N - 1 : v)) * (KB_PSB * 2);      // BYTE offset of the source's projection row
         }
     };
     // rows N..Npad of the a1 image are read by the projection and never written by conv1's stores (n < N only)
@@ -223,33 +223,37 @@ __global__ __launch_bounds__(KB_THREADS) void mpconv_block_fwd_kernel(const KbPa
         for (int q = 0; q < NO; ++q) adr[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (adb && (wave >> 2) * 16 + li < M) ad_fetch((wave >> 2) * 16 + li);
         // ---- gather + edge-type contraction + max, two destinations in flight per wave; a2 = ReLU(BN2(z)) -> LDS ----
+        // A wave's edge list is uniform: the source rows' byte offsets and the edge weights are BROADCAST LDS reads (every lane the same
+        // address).  Round 6: fetched by the first lanes and spread with v_readlane they cost 3 readlanes + hazard no-ops + a scalar
+        // multiply per edge — ~11 issue slots for two dot products and a max (factor_layer_fwd.hip: fl_gather).
         {
-            const unsigned* et_w = reinterpret_cast<const unsigned*>(et_s);
-            const uint16_t* pc = ps + lane * 4;
+            const unsigned char* pc = reinterpret_cast<const unsigned char*>(ps) + lane * 8;
             for (int m0 = wave; m0 < M; m0 += 2 * KB_WAVES) {
                 const bool two = m0 + KB_WAVES < M;
                 const int m1 = two ? m0 + KB_WAVES : m0;
-                const int id0 = lane < KC ? idx_s[m0 * KC + lane] : 0;
-                const int id1 = lane < KC ? idx_s[m1 * KC + lane] : 0;
-                const unsigned e0 = lane < 2 * KC ? et_w[m0 * KC * 2 + lane] : 0u;
-                const unsigned e1 = lane < 2 * KC ? et_w[m1 * KC * 2 + lane] : 0u;
+                const int* o0 = idx_s + m0 * KC;
+                const int* o1 = idx_s + m1 * KC;
+                const uint2* w0 = et_s + m0 * KC;
+                const uint2* w1 = et_s + m1 * KC;
+                int of0[KC], of1[KC];
+                uint2 ew0[KC], ew1[KC];
+#pragma unroll
+                for (int j = 0; j < KC; ++j) { of0[j] = o0[j]; of1[j] = o1[j]; }
+#pragma unroll
+                for (int j = 0; j < KC; ++j) { ew0[j] = w0[j]; ew1[j] = w1[j]; }
                 uint2 pk0[KC], pk1[KC];
 #pragma unroll
                 for (int j = 0; j < KC; ++j) {
-                    pk0[j] = *reinterpret_cast<const uint2*>(pc + __builtin_amdgcn_readlane(id0, j) * KB_PSB);
-                    pk1[j] = *reinterpret_cast<const uint2*>(pc + __builtin_amdgcn_readlane(id1, j) * KB_PSB);
+                    pk0[j] = *reinterpret_cast<const uint2*>(pc + of0[j]);
+                    pk1[j] = *reinterpret_cast<const uint2*>(pc + of1[j]);
                 }
                 float b0 = 0.f, b1 = 0.f;
 #pragma unroll
                 for (int j = 0; j < KC; ++j) {
-                    float v0 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(kb_bf16x2, pk0[j].x),
-                        __builtin_bit_cast(kb_bf16x2, (unsigned)__builtin_amdgcn_readlane(e0, 2 * j)), 0.f, false);
-                    v0 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(kb_bf16x2, pk0[j].y),
-                        __builtin_bit_cast(kb_bf16x2, (unsigned)__builtin_amdgcn_readlane(e0, 2 * j + 1)), v0, false);
-                    float v1 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(kb_bf16x2, pk1[j].x),
-                        __builtin_bit_cast(kb_bf16x2, (unsigned)__builtin_amdgcn_readlane(e1, 2 * j)), 0.f, false);
-                    v1 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(kb_bf16x2, pk1[j].y),
-                        __builtin_bit_cast(kb_bf16x2, (unsigned)__builtin_amdgcn_readlane(e1, 2 * j + 1)), v1, false);
+                    float v0 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(kb_bf16x2, pk0[j].x), __builtin_bit_cast(kb_bf16x2, ew0[j].x), 0.f, false);
+                    v0 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(kb_bf16x2, pk0[j].y), __builtin_bit_cast(kb_bf16x2, ew0[j].y), v0, false);
+                    float v1 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(kb_bf16x2, pk1[j].x), __builtin_bit_cast(kb_bf16x2, ew1[j].x), 0.f, false);
+                    v1 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(kb_bf16x2, pk1[j].y), __builtin_bit_cast(kb_bf16x2, ew1[j].y), v1, false);
                     b0 = j == 0 ? v0 : fmaxf(b0, v0);
                     b1 = j == 0 ? v1 : fmaxf(b1, v1);
                 }
