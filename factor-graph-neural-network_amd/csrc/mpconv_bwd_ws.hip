@@ -102,6 +102,15 @@ __device__ __forceinline__ void bw_dma16(const void* gsrc, unsigned lds_dst) {
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
+// the same with a UNIFORM 64-bit base (scalar registers) + an unsigned 32-bit per-lane byte offset.  Round 6: dma_x's three per-lane
+// sources were carried across the sample loop as 64-bit register pairs, one pair was spilled in the V -> F instance, and its reload —
+// a memory operation — waited (vmcnt(0)) behind the two pieces just requested: an HBM round trip on the dW waves at the tail of every
+// sample's phase 3, the phase's long pole.
+__device__ __forceinline__ void bw_dma16s(const void* sbase, unsigned voff, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
 __device__ __forceinline__ void bw_wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 // phase barrier: this wave's LDS operations done, then s_barrier — NOT __syncthreads(), which would also drain the gx /
 // getype stores and the next sample's prefetch loads four times per sample
@@ -272,7 +281,7 @@ __global__ __launch_bounds__(BW_THREADS) void mpconv_bwd_ws_kernel(const BwParam
 #pragma unroll
         for (int u = 0; u < 3; ++u) {
             const int piece = dwq + 4 * u;
-            if (piece < npieces) bw_dma16(xb + dsrc[u], lds0 + (unsigned)(OFF_X + buf * (BW_MAXN * BW_XROW) + piece * 1024));
+            if (piece < npieces) bw_dma16s(xb, dsrc[u], lds0 + (unsigned)(OFF_X + buf * (BW_MAXN * BW_XROW) + piece * 1024));
         }
     };
     // the first two samples' x: requested before anything else (the tables below take ~5 us)
