@@ -44,6 +44,14 @@ __device__ __forceinline__ unsigned lf_pack2(float a, float b) {
     return __builtin_bit_cast(unsigned, h);
 }
 
+// uniform 64-bit base + UNSIGNED 32-bit per-lane byte offset: the form that compiles to `global_load v, v_off, s[base]`
+template <typename T> __device__ __forceinline__ const T* lf_at(const void* base, unsigned byte_off) {
+    return reinterpret_cast<const T*>(static_cast<const char*>(base) + byte_off);
+}
+template <typename T> __device__ __forceinline__ T* lf_at(void* base, unsigned byte_off) {
+    return reinterpret_cast<T*>(static_cast<char*>(base) + byte_off);
+}
+
 // KS = Cin / 32 k-steps, OTW = 16-channel output tiles per wave (Cout / 16 / CG), WREG: W fragments in registers
 template <int KS, int OTW, bool WREG>
 __global__ __launch_bounds__(LF_THREADS) void linear_fwd_b16_kernel(const LfParams p) {
@@ -114,11 +122,17 @@ __global__ __launch_bounds__(LF_THREADS) void linear_fwd_b16_kernel(const LfPara
 
     const int ntile = (R + 15) / 16;
     const int stride = gridDim.x * nrg;
+    // A tile's rows: uniform 64-bit base (the tile) + a 32-bit lane offset, every load UNCONDITIONAL (a tile past the end re-reads the last
+    // one, a row past R the last row: neither is stored or counted).  Round 6: per-lane 64-bit pointers + a guard per load made the
+    // 256-input instance spill, and the reload in front of the stores — a memory operation — waited (vmcnt(0)) for the NEXT tile's
+    // eight loads just requested: no tile was ever in flight under the products (1.1 TB/s in the training step).
     auto load_tile = [&](int tile, uint4 (&bx)[KS]) {
-        const int row = tile * 16 + li;
+        const int tl = tile < ntile ? tile : ntile - 1;
+        const uint16_t* xt = p.x + (int64_t)tl * 16 * CIN;
+        const int rl = tl * 16 + li < R ? li : R - 1 - tl * 16;
+        const unsigned off = (unsigned)((rl * CIN + kcol(0)) * 2);
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks)
-            bx[ks] = (tile < ntile && row < R) ? *reinterpret_cast<const uint4*>(p.x + (int64_t)row * CIN + kcol(ks)) : make_uint4(0, 0, 0, 0);
+        for (int ks = 0; ks < KS; ++ks) bx[ks] = *lf_at<uint4>(xt, off + 16u * ks);
     };
     uint4 nx[KS];
     load_tile(blockIdx.x * nrg + rg, nx);
@@ -143,11 +157,12 @@ __global__ __launch_bounds__(LF_THREADS) void linear_fwd_b16_kernel(const LfPara
         }
         // D[i = 4 lk + r][j = row] of tile ot = channel o_base + 16 lk + 4 ot + r of this lane's row
         if (ok) {
-            uint16_t* yp = p.y + (int64_t)row * Cout + o_base + 16 * lk;
-            *reinterpret_cast<uint4*>(yp) = make_uint4(lf_pack2(acc[0][0], acc[0][1]), lf_pack2(acc[0][2], acc[0][3]),
-                                                       lf_pack2(acc[1][0], acc[1][1]), lf_pack2(acc[1][2], acc[1][3]));
-            *reinterpret_cast<uint4*>(yp + 8) = make_uint4(lf_pack2(acc[2][0], acc[2][1]), lf_pack2(acc[2][2], acc[2][3]),
-                                                           lf_pack2(acc[3][0], acc[3][1]), lf_pack2(acc[3][2], acc[3][3]));
+            uint16_t* yt = p.y + (int64_t)tile * 16 * Cout;
+            const unsigned yo = (unsigned)((li * Cout + o_base + 16 * lk) * 2);
+            *lf_at<uint4>(yt, yo) = make_uint4(lf_pack2(acc[0][0], acc[0][1]), lf_pack2(acc[0][2], acc[0][3]),
+                                               lf_pack2(acc[1][0], acc[1][1]), lf_pack2(acc[1][2], acc[1][3]));
+            *lf_at<uint4>(yt, yo + 16u) = make_uint4(lf_pack2(acc[2][0], acc[2][1]), lf_pack2(acc[2][2], acc[2][3]),
+                                                     lf_pack2(acc[3][0], acc[3][1]), lf_pack2(acc[3][2], acc[3][3]));
             if (p.part) {
 #pragma unroll
                 for (int ot = 0; ot < OTW; ++ot)
