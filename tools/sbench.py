@@ -102,7 +102,7 @@ for C, N in [(64, 96), (128, 96)]:
 
 # node-wise maps (1x1 convolutions) and their weight gradients, cold: the other two streaming families of the step
 print('node-wise maps, cold (24 rotating tensor pairs):')
-for Cin, Cout, N in [(64, 64, 96), (64, 64, 48), (128, 64, 96), (64, 128, 96)]:
+for Cin, Cout, N in [(64, 64, 96), (64, 64, 48), (128, 64, 96), (64, 128, 96), (256, 256, 48), (256, 128, 48)]:
     R = 4096 * N
     K = 24
     xs = [torch.randn(R, Cin, device=dev).bfloat16() for _ in range(K)]
