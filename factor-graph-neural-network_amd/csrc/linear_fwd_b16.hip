@@ -102,8 +102,12 @@ __global__ __launch_bounds__(LF_THREADS) void linear_fwd_b16_kernel(const LfPara
     //  * output tile ot, MFMA row i  <->  channel 16 (i >> 2) + 4 ot + (i & 3): the D fragments of the four tiles then give lane
     //    (row li, lk) the 16 CONSECUTIVE channels 16 lk .. 16 lk + 15 of its row: two 16-byte stores instead of four 8-byte ones;
     //  * k-step ks, k-group lk  <->  input channels 8 KS lk + 8 ks .. + 7: a lane's KS loads are one contiguous 16 KS-byte run.
-    static_assert(OTW == 4, "the channel permutation assumes 64 output channels per wave");
-    auto orow = [&](int ot) { return 16 * (li >> 2) + 4 * ot + (li & 3); };
+    // OTW == 8 (round 6: the 256-input maps with >= 128 outputs): TWO 64-channel slabs per wave, each with the permutation above — the
+    // column-group waves of a workgroup each fetch the tile's rows through L1 as 16-byte pieces of 64 different lines per load, and at
+    // four column groups that line rate, not the LDS or HBM, was the bound (2.5 TB/s at 256 -> 256); two groups halve the re-reads.
+    static_assert(OTW == 4 || OTW == 8, "64 or 128 output channels per wave");
+    auto orow = [&](int ot) { return 64 * (ot >> 2) + 16 * (li >> 2) + 4 * (ot & 3) + (li & 3); };
+    auto ocol = [&](int ot) { return 64 * (ot >> 2) + 16 * lk + 4 * (ot & 3); };          // the lane's four channels of tile ot, from o_base
     auto kcol = [&](int ks) { return 8 * KS * lk + 8 * ks; };
     lf_bf16x8 aW[WREG ? OTW : 1][WREG ? KS : 1];
     if constexpr (WREG) {
@@ -115,7 +119,7 @@ __global__ __launch_bounds__(LF_THREADS) void linear_fwd_b16_kernel(const LfPara
     }
     f32x4 bv[OTW];
 #pragma unroll
-    for (int ot = 0; ot < OTW; ++ot) bv[ot] = *reinterpret_cast<const f32x4*>(bl + o_base + 16 * lk + 4 * ot);
+    for (int ot = 0; ot < OTW; ++ot) bv[ot] = *reinterpret_cast<const f32x4*>(bl + o_base + ocol(ot));
     f32x4 s0[OTW], s1[OTW];
 #pragma unroll
     for (int ot = 0; ot < OTW; ++ot) { s0[ot] = (f32x4){0.f, 0.f, 0.f, 0.f}; s1[ot] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
@@ -143,6 +147,7 @@ __global__ __launch_bounds__(LF_THREADS) void linear_fwd_b16_kernel(const LfPara
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) bx[ks] = nx[ks];
         load_tile(tile + stride, nx);                     // the next tile's rows are in flight while this one is multiplied and stored
+        if (!WREG && OTW == 8) asm volatile("" ::: "memory");      // the LDS operands are re-read per tile, not hoisted into (spilled) registers
         f32x4 acc[OTW];
 #pragma unroll
         for (int ot = 0; ot < OTW; ++ot) {
@@ -159,10 +164,14 @@ __global__ __launch_bounds__(LF_THREADS) void linear_fwd_b16_kernel(const LfPara
         if (ok) {
             uint16_t* yt = p.y + (int64_t)tile * 16 * Cout;
             const unsigned yo = (unsigned)((li * Cout + o_base + 16 * lk) * 2);
-            *lf_at<uint4>(yt, yo) = make_uint4(lf_pack2(acc[0][0], acc[0][1]), lf_pack2(acc[0][2], acc[0][3]),
-                                               lf_pack2(acc[1][0], acc[1][1]), lf_pack2(acc[1][2], acc[1][3]));
-            *lf_at<uint4>(yt, yo + 16u) = make_uint4(lf_pack2(acc[2][0], acc[2][1]), lf_pack2(acc[2][2], acc[2][3]),
-                                                     lf_pack2(acc[3][0], acc[3][1]), lf_pack2(acc[3][2], acc[3][3]));
+#pragma unroll
+            for (int sl = 0; sl < OTW / 4; ++sl) {
+                const f32x4 (&a4)[OTW] = acc;
+                *lf_at<uint4>(yt, yo + 128u * sl) = make_uint4(lf_pack2(a4[4 * sl][0], a4[4 * sl][1]), lf_pack2(a4[4 * sl][2], a4[4 * sl][3]),
+                                                              lf_pack2(a4[4 * sl + 1][0], a4[4 * sl + 1][1]), lf_pack2(a4[4 * sl + 1][2], a4[4 * sl + 1][3]));
+                *lf_at<uint4>(yt, yo + 128u * sl + 16u) = make_uint4(lf_pack2(a4[4 * sl + 2][0], a4[4 * sl + 2][1]), lf_pack2(a4[4 * sl + 2][2], a4[4 * sl + 2][3]),
+                                                                    lf_pack2(a4[4 * sl + 3][0], a4[4 * sl + 3][1]), lf_pack2(a4[4 * sl + 3][2], a4[4 * sl + 3][3]));
+            }
             if (p.part) {
 #pragma unroll
                 for (int ot = 0; ot < OTW; ++ot)
@@ -180,7 +189,7 @@ __global__ __launch_bounds__(LF_THREADS) void linear_fwd_b16_kernel(const LfPara
 #pragma unroll
                 for (int m = 1; m < 16; m <<= 1) { a += __shfl_xor(a, m); b += __shfl_xor(b, m); }   // the 16 rows of a tile
                 if (li == 0) {
-                    const int o = o_base + 16 * lk + 4 * ot + r;
+                    const int o = o_base + ocol(ot) + r;
                     red[(rg * 2) * Cout + o] = a;
                     red[(rg * 2 + 1) * Cout + o] = b;
                 }
@@ -342,9 +351,12 @@ __global__ __launch_bounds__(LF_THREADS) void linear_instnorm_fwd_kernel(const L
     }
 }
 
-static int lf_plan(int64_t R, int Cin, int Cout, int* CG, int* grid) {
+// 16-channel output tiles per wave of fgnn_linear_forward: 8 (two slabs) for the 256-input maps with >= 128 outputs, else 4
+static int lf_otw(int Cin, int Cout) { return (Cin > 192 && Cout >= 128 && Cout % 128 == 0) ? 8 : 4; }
+
+static int lf_plan(int64_t R, int Cin, int Cout, int* CG, int* grid, int otw = 4) {
     if (Cin % 64 || Cout % 64 || Cin > 256 || Cout > 256 || R <= 0 || R > 0x7fffffff) return -1;
-    *CG = Cout / 64;                                      // <= 64 output channels (4 tiles) per wave
+    *CG = Cout / (16 * otw);                              // 64 (or 128) output channels per wave
     if (*CG == 3) return -1;
     const int nrg = LF_WAVES / *CG;
     const int64_t ntile = (R + 15) / 16;
@@ -359,7 +371,7 @@ static int lf_plan(int64_t R, int Cin, int Cout, int* CG, int* grid) {
 // Number of per-workgroup statistics partials a call with these sizes writes (0 = shape not supported).
 extern "C" int fgnn_linear_forward_partials(int64_t R, int Cin, int Cout) {
     int CG, grid;
-    return lf_plan(R, Cin, Cout, &CG, &grid) ? 0 : grid;
+    return lf_plan(R, Cin, Cout, &CG, &grid, lf_otw(Cin, Cout)) ? 0 : grid;
 }
 
 // y = x W^T + b for bf16 x / y, f32 W / b.  stats_partials: NULL, or device scratch of
@@ -373,7 +385,8 @@ extern "C" int fgnn_linear_forward(const void* x, const float* W, const float* b
                                    int w_transposed, fgnn_stream_t stream) {
     if (!x || !W || !y) FGNN_FAIL(FGNN_EINVAL, "linear_forward: null pointer");
     int CG, grid;
-    if (lf_plan(R, Cin, Cout, &CG, &grid) || ((uintptr_t)x & 15) || ((uintptr_t)y & 15) || ((uintptr_t)W & 7))
+    const int otw = lf_otw(Cin, Cout);
+    if (lf_plan(R, Cin, Cout, &CG, &grid, otw) || ((uintptr_t)x & 15) || ((uintptr_t)y & 15) || ((uintptr_t)W & 7))
         FGNN_FAIL(FGNN_EUNSUPPORTED, "linear_forward: Cin=%d Cout=%d outside the bf16 streaming kernel's family", Cin, Cout);
     if (fin && (!stats_partials || !fin->mean || !fin->invstd || !fin->scale || !fin->shift || fin->count != R || fin->shift_k))
         FGNN_FAIL(FGNN_EINVAL, "linear_forward: fgnn_bn_final needs stats_partials, its outputs, count == R and no shift_k");
@@ -389,7 +402,7 @@ extern "C" int fgnn_linear_forward(const void* x, const float* W, const float* b
         case 2: fn = (void*)linear_fwd_b16_kernel<2, 4, true>; break;
         case 4: fn = (void*)linear_fwd_b16_kernel<4, 4, true>; break;
         case 6: fn = (void*)linear_fwd_b16_kernel<6, 4, false>; break;
-        default: fn = (void*)linear_fwd_b16_kernel<8, 4, false>; break;
+        default: fn = otw == 8 ? (void*)linear_fwd_b16_kernel<8, 8, false> : (void*)linear_fwd_b16_kernel<8, 4, false>; break;
     }
     const int lds = Cout * (Cin + 8) * 2 + Cout * 4 + (LF_WAVES / CG) * 2 * Cout * 4;
     if (lds > 48 * 1024) {
