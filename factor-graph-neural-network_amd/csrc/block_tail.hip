@@ -89,6 +89,9 @@ __device__ __forceinline__ unsigned bt_pack2(float a, float b) {
     const v2 h = {(__bf16)a, (__bf16)b};
     return __builtin_bit_cast(unsigned, h);
 }
+template <typename T> __device__ __forceinline__ const T* bt_at(const void* base, unsigned byte_off) {
+    return reinterpret_cast<const T*>(static_cast<const char*>(base) + byte_off);
+}
 __device__ __forceinline__ float bt_lo(unsigned u) { return __uint_as_float(u << 16); }
 __device__ __forceinline__ float bt_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
 __device__ __forceinline__ void bt_unpack8(const uint4 q, float (&v)[8]) {
@@ -213,17 +216,23 @@ __global__ __launch_bounds__(BT_THREADS, MODE == 1 ? 3 : 2) void block_tail_kern
     constexpr int DEPTH = MODE == 0 ? 4 : ((MODE == 2 && NA != 1) ? 2 : 1);
     const int first = blockIdx.x * NRG + rg;
     const int mine = first < ntile ? (ntile - first + stride - 1) / stride : 0;           // tiles of this wave
+    // (uniform 64-bit base of the tile + a 32-bit lane offset: per-lane 64-bit pointers were what the moments variant spilled, DESIGN 4.14;
+    // rows past the end are clamped to the last row, tiles past the end to the last tile — masked where they are used)
     auto load_e = [&](int it, uint4 (&q)[2]) {
-        const int row = min((first + it * stride) * 16 + li, R - 1);
-        const uint16_t* ep = p.e + (int64_t)row * 64 + 16 * lk;
-        q[0] = *reinterpret_cast<const uint4*>(ep);
-        q[1] = *reinterpret_cast<const uint4*>(ep + 8);
+        const int tl = min(first + it * stride, ntile - 1);
+        const int rl = min(li, R - 1 - tl * 16);
+        const uint16_t* eb = p.e + (int64_t)tl * 16 * 64;
+        const unsigned off = (unsigned)((rl * 64 + 16 * lk) * 2);
+        q[0] = *bt_at<uint4>(eb, off);
+        q[1] = *bt_at<uint4>(eb, off + 16u);
     };
     auto load_g = [&](int it, uint4 (&gp)[2]) {           // a slab-bound wave knows its slab: the upstream gradient rides along (mode 2)
-        const int row = min((first + it * stride) * 16 + li, R - 1);
-        const uint16_t* gpp = p.gout + (int64_t)row * COUT + 64 * cg + 16 * lk;
-        gp[0] = *reinterpret_cast<const uint4*>(gpp);
-        gp[1] = *reinterpret_cast<const uint4*>(gpp + 8);
+        const int tl = min(first + it * stride, ntile - 1);
+        const int rl = min(li, R - 1 - tl * 16);
+        const uint16_t* gb = p.gout + (int64_t)tl * 16 * COUT;
+        const unsigned off = (unsigned)((rl * COUT + 64 * cg + 16 * lk) * 2);
+        gp[0] = *bt_at<uint4>(gb, off);
+        gp[1] = *bt_at<uint4>(gb, off + 16u);
     };
     // A slot is refilled right AFTER its last use, into the same registers: a refill issued while the old value is still
     // live gets registers of its own and a copy at the loop's back edge — a copy that has to wait for the load.

@@ -20,6 +20,7 @@ MUST = {
     'mpconv_block_fwd.hip': ['mpconv_block_fwd_kernel', 'mpconv_block_rows1_kernel', 'mpconv_block_fanin_kernel', 'mpconv_block_fanout_kernel'],
     'linear_fwd_b16.hip': ['linear_fwd_b16_kernel', 'linear_instnorm_fwd_kernel', 'linear_multi_b16_kernel'],
     'mpconv_bwd_ws.hip': ['mpconv_bwd_ws_kernel'],
+    'block_tail.hip': ['block_tail_kernel', 'block_head_bwd_kernel'],
     'mpconv_fwd_ws.hip': ['mpconv_fwd_ws_kernelILi64E'],          # (the 128-input instances spill at their 128-register budget: consumers only, profiles/r06/README.md)
 }
 
@@ -27,7 +28,7 @@ MUST = {
 def _scratch(src):
     cmd = [HIPCC, '--offload-arch=gfx950', '-O3', '-std=c++17',      # (the Makefile's flags)
            '-I' + os.path.join(ROOT, 'include'), '-I' + CSRC, '-Wno-unused-function',
-           '-Wno-pass-failed', '-fPIC', '-c', '--cuda-device-only', os.path.join(CSRC, src), '-o', os.devnull,
+           '-Wno-pass-failed', '-fPIC'] + (['-fno-slp-vectorize'] if src == 'block_tail.hip' else []) + ['-c', '--cuda-device-only', os.path.join(CSRC, src), '-o', os.devnull,
            '-Rpass-analysis=kernel-resource-usage']
     err = subprocess.run(cmd, capture_output=True, text=True, timeout=1500).stderr
     out, name = {}, None
